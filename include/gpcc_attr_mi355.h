@@ -1,0 +1,181 @@
+/* gpcc_attr_mi355.h -- C ABI of the MI355X attribute-transform library.
+ *
+ * Drop-in boundary for the attribute-transform hot path of TMC13
+ * (reference: MPEGGroup/mpeg-pcc-tmc13 @ release-23.0-rc2).  Every entry
+ * point names the reference interface it replaces (file:line relative to
+ * the reference tree).  Plain pointers and sizes only; no STL, no torch
+ * types.  All entry points return 0 on success and a negative
+ * gpcc_status on failure; on failure no output buffer holds a valid
+ * result and the caller is expected to run the reference CPU function.
+ *
+ * Two tiers:
+ *   - host tier   (gpcc_raht_forward / gpcc_raht_inverse / gpcc_attr_*):
+ *     synchronous, caller-owned HOST buffers, exactly the call shape of the
+ *     reference free functions, so a replacement translation unit can
+ *     forward to it.
+ *   - device tier (gpcc_dev_*): the same operations on buffers already
+ *     resident in HBM, batched over slices, asynchronous on a HIP stream.
+ *     The host tier is implemented on top of it.
+ */
+#ifndef GPCC_ATTR_MI355_H
+#define GPCC_ATTR_MI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPCC_ABI_VERSION 1
+
+#define GPCC_MAX_QP_LAYERS 32
+#define GPCC_MAX_AC_QP_LAYERS 32
+
+typedef enum gpcc_status {
+  GPCC_OK = 0,
+  GPCC_ERR_INVALID_ARG = -1,   /* null pointer, n < 0, c not in {1,2,3}, ... */
+  GPCC_ERR_UNSUPPORTED = -2,   /* parameter combination kept on the CPU path */
+  GPCC_ERR_NO_DEVICE = -3,     /* no gfx950 device / HIP runtime failure     */
+  GPCC_ERR_OUT_OF_MEMORY = -4,
+  GPCC_ERR_HIP = -5,           /* a HIP call failed; see gpcc_last_error()   */
+  GPCC_ERR_UNSORTED = -6       /* Morton codes not ascending                 */
+} gpcc_status;
+
+/* Flattened RahtPredictionParams (hls.h:439-466) + QpSet
+ * (quantization.h:124-139) + the raht_extension flag
+ * (AttributeParameterSet, hls.h:782-876), exactly the values
+ * AttributeEncoder.cpp:1273/1341 and AttributeDecoder.cpp:595/658 hand to
+ * regionAdaptiveHierarchical{,Inverse}Transform. */
+typedef struct gpcc_raht_params {
+  int32_t raht_prediction_enabled_flag;
+  int32_t integer_haar_enable_flag;
+  int32_t raht_prediction_threshold0;
+  int32_t raht_prediction_threshold1;
+  int32_t raht_subnode_prediction_enabled_flag;
+  int32_t raht_prediction_search_range;
+  int32_t pred_weight_parent[19]; /* RahtPredictionParams::predWeightParent */
+  int32_t pred_weight_child[12];  /* RahtPredictionParams::predWeightChild  */
+  int32_t raht_extension;         /* aps.raht_extension                     */
+
+  int32_t num_qp_layers;                      /* QpSet::layers.size() >= 1  */
+  int32_t layer_qp[GPCC_MAX_QP_LAYERS][2];    /* QpSet::layers[i] = {luma,
+                                                 chroma offset}             */
+  int32_t max_qp;                             /* QpSet::maxQp               */
+  int32_t fixed_point_qp_offset;              /* QpSet::fixedPointQpOffset  */
+  int32_t num_ac_qp_layers;                   /* QpSet::rahtAcCoeffQps.size */
+  int32_t ac_qp_offset[GPCC_MAX_AC_QP_LAYERS][7][2];
+} gpcc_raht_params;
+
+/* Fill pred_weight_parent / pred_weight_child from the five signalled
+ * raht_prediction_weights, as RahtPredictionParams::setPredictionWeights
+ * does (hls.h:456-465). */
+void gpcc_raht_set_prediction_weights(gpcc_raht_params* p, const int32_t w[5]);
+
+/* ------------------------------------------------------------------ */
+/* library / device management                                         */
+
+int gpcc_abi_version(void);
+/* Human readable description of the most recent failure on this thread. */
+const char* gpcc_last_error(void);
+/* Number of usable gfx950 devices (0 if none / no HIP runtime). */
+int gpcc_device_count(void);
+
+typedef struct gpcc_ctx gpcc_ctx; /* opaque: device, stream, workspace */
+
+/* Create a context bound to HIP device `device`.  `stream` is a
+ * hipStream_t passed as void* (NULL = the library creates its own
+ * non-blocking stream).  Workspace grows on demand and is reused. */
+int gpcc_ctx_create(int device, void* stream, gpcc_ctx** out);
+void gpcc_ctx_destroy(gpcc_ctx* ctx);
+/* Block until all work queued by this context has completed. */
+int gpcc_ctx_synchronize(gpcc_ctx* ctx);
+/* Bytes of HBM currently held by the context's workspace. */
+size_t gpcc_ctx_workspace_bytes(const gpcc_ctx* ctx);
+
+/* ------------------------------------------------------------------ */
+/* host tier: one slice, host buffers, synchronous                      */
+
+/* Replaces pcc::regionAdaptiveHierarchicalTransform (RAHT.h:47-57,
+ * RAHT.cpp:1997-2018) for intra slices.
+ *   morton  [n]     ascending Morton codes (mortonAddr, PCCMath.h:606)
+ *   qp_off  [n][2]  per-point region QP offsets (QpSet::regionQpOffset),
+ *                   NULL = all zero
+ *   attrs   [n*c]   in: source attributes, row-major; out: reconstruction
+ *                   (unclipped, RAHT.cpp:1969-1975)
+ *   coeffs  [c*n]   out: quantised coefficients, planar (coeff[k*n+i],
+ *                   RAHT.cpp:992-996), traversal order
+ */
+int gpcc_raht_forward(
+  gpcc_ctx* ctx, const gpcc_raht_params* params, const int64_t* morton,
+  const int32_t* qp_off, int32_t* attrs, int32_t* coeffs, int32_t n,
+  int32_t c);
+
+/* Replaces pcc::regionAdaptiveHierarchicalInverseTransform (RAHT.h:59-69,
+ * RAHT.cpp:2037-2058).  coeffs is read, attrs [n*c] is written. */
+int gpcc_raht_inverse(
+  gpcc_ctx* ctx, const gpcc_raht_params* params, const int64_t* morton,
+  const int32_t* qp_off, int32_t* attrs, const int32_t* coeffs, int32_t n,
+  int32_t c);
+
+/* Replaces the Morton-code + std::sort(MortonCodeWithIndex) prologue of
+ * encode/decode{Colors,Reflectances}TransformRaht
+ * (AttributeEncoder.cpp:1225-1229,1316-1321; AttributeDecoder.cpp:538-542,
+ * 624-628; ordering MortonCodeWithIndex::operator< PCCTMC3Common.h:184-190:
+ * by code, ties by original index).
+ *   xyz     [n][3]  point positions (Vec3<int32_t>, non-negative, < 2^21)
+ *   morton  [n]     out: sorted codes
+ *   order   [n]     out: original index of the i-th sorted point
+ */
+int gpcc_attr_morton_sort(
+  gpcc_ctx* ctx, const int32_t* xyz, int32_t n, int64_t* morton,
+  int32_t* order);
+
+/* ------------------------------------------------------------------ */
+/* device tier: batched over slices, buffers resident in HBM            */
+
+/* A batch of `num_slices` independent slices laid out back to back.
+ * slice s owns points [offsets[s], offsets[s+1]).  offsets is a HOST
+ * array of num_slices+1 entries (offsets[0] == 0).  All d_* pointers are
+ * device addresses (passed as void* so that no HIP header is needed).
+ * For slice s with n_s points and base b = offsets[s]:
+ *   d_morton  + b           int64  [n_s]
+ *   d_qp_off  + 2*b         int32  [n_s][2]  (d_qp_off may be NULL)
+ *   d_attrs   + c*b         int32  [n_s][c]
+ *   d_coeffs  + c*b         int32  [c][n_s]   planar per slice
+ * The call enqueues work on the context's stream and returns; results
+ * are valid after gpcc_ctx_synchronize (or stream ordering). */
+int gpcc_dev_raht_forward(
+  gpcc_ctx* ctx, const gpcc_raht_params* params, int32_t num_slices,
+  const int64_t* offsets, const void* d_morton, const void* d_qp_off,
+  void* d_attrs, void* d_coeffs, int32_t c);
+
+int gpcc_dev_raht_inverse(
+  gpcc_ctx* ctx, const gpcc_raht_params* params, int32_t num_slices,
+  const int64_t* offsets, const void* d_morton, const void* d_qp_off,
+  void* d_attrs, const void* d_coeffs, int32_t c);
+
+/* Morton encode + stable sort per slice.  d_xyz int32 [n][3];
+ * d_morton int64 [n]; d_order int32 [n] (index local to the slice). */
+int gpcc_dev_attr_morton_sort(
+  gpcc_ctx* ctx, int32_t num_slices, const int64_t* offsets,
+  const void* d_xyz, void* d_morton, void* d_order);
+
+/* Per-kernel timing of the most recent gpcc_dev_raht_* call on this
+ * context, measured with HIP events on the context's stream when
+ * profiling is enabled (gpcc_ctx_set_profiling(ctx, 1)).  Returns the
+ * number of entries written (<= max_entries).  names[i] points to a
+ * static string. */
+typedef struct gpcc_kernel_time {
+  const char* name;
+  double total_ms;
+  int32_t launches;
+} gpcc_kernel_time;
+int gpcc_ctx_set_profiling(gpcc_ctx* ctx, int enable);
+int gpcc_ctx_kernel_times(
+  gpcc_ctx* ctx, gpcc_kernel_time* out, int32_t max_entries);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPCC_ATTR_MI355_H */

@@ -1,0 +1,8 @@
+"""mpeg-pcc-tmc13_amd -- MI355X-native attribute-transform hot path of TMC13.
+
+The directory name carries the reference's name (with hyphens), so it is
+loaded under the importable alias ``mpeg_pcc_tmc13_amd`` by
+``__graft_entry__.load_package()`` / ``tests/conftest.py``.
+"""
+from . import params, synth  # noqa: F401
+from .params import RahtParams, raht_params  # noqa: F401

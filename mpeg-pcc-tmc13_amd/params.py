@@ -1,0 +1,86 @@
+"""Flattened RAHT parameter block (ctypes mirror of ``gpcc_raht_params`` in
+include/gpcc_attr_mi355.h) and the presets the reference encoder hands to
+``regionAdaptiveHierarchicalTransform`` after its own sanitising
+(reference: tmc3/TMC3.cpp:1270-1345,1883-1912, tmc3/encoder.cpp:710-842,
+cfg/octree-raht-ctc-*.yaml)."""
+import ctypes as C
+
+GPCC_MAX_QP_LAYERS = 32
+GPCC_MAX_AC_QP_LAYERS = 32
+
+
+class RahtParams(C.Structure):
+    _fields_ = [
+        ("raht_prediction_enabled_flag", C.c_int32),
+        ("integer_haar_enable_flag", C.c_int32),
+        ("raht_prediction_threshold0", C.c_int32),
+        ("raht_prediction_threshold1", C.c_int32),
+        ("raht_subnode_prediction_enabled_flag", C.c_int32),
+        ("raht_prediction_search_range", C.c_int32),
+        ("pred_weight_parent", C.c_int32 * 19),
+        ("pred_weight_child", C.c_int32 * 12),
+        ("raht_extension", C.c_int32),
+        ("num_qp_layers", C.c_int32),
+        ("layer_qp", (C.c_int32 * 2) * GPCC_MAX_QP_LAYERS),
+        ("max_qp", C.c_int32),
+        ("fixed_point_qp_offset", C.c_int32),
+        ("num_ac_qp_layers", C.c_int32),
+        ("ac_qp_offset", ((C.c_int32 * 2) * 7) * GPCC_MAX_AC_QP_LAYERS),
+    ]
+
+    def set_prediction_weights(self, w):
+        """RahtPredictionParams::setPredictionWeights (hls.h:456-465)."""
+        w = list(w)
+        child = [w[4], w[4], w[3], w[4], w[3], w[3], w[4], w[4], w[4], w[4], w[4], w[4]]
+        parent = [w[0], w[1], w[1], w[1], w[2], w[2], w[2], w[2], w[2], w[1],
+                  w[2], w[1], w[1], w[2], w[2], w[2], w[2], w[2], w[2]]
+        for i, v in enumerate(parent):
+            self.pred_weight_parent[i] = v
+        for i, v in enumerate(child):
+            self.pred_weight_child[i] = v
+
+    def set_layers(self, layers):
+        """QpSet::layers: list of (luma qp, chroma qp offset)."""
+        assert 1 <= len(layers) <= GPCC_MAX_QP_LAYERS
+        self.num_qp_layers = len(layers)
+        for i, (a, b) in enumerate(layers):
+            self.layer_qp[i][0] = a
+            self.layer_qp[i][1] = b
+
+    def set_ac_offsets(self, layers):
+        """QpSet::rahtAcCoeffQps: list of 7 (luma, chroma) pairs per layer."""
+        assert len(layers) <= GPCC_MAX_AC_QP_LAYERS
+        self.num_ac_qp_layers = len(layers)
+        for i, lay in enumerate(layers):
+            for j, (a, b) in enumerate(lay):
+                self.ac_qp_offset[i][j][0] = a
+                self.ac_qp_offset[i][j][1] = b
+
+    def copy(self):
+        o = RahtParams()
+        C.memmove(C.byref(o), C.byref(self), C.sizeof(RahtParams))
+        return o
+
+
+def raht_params(qp=34, chroma_offset=-1, bitdepth=8, prediction=True,
+                subnode=True, haar=False, extension=True, search_range=50000,
+                threshold0=2, threshold1=6, weights=(9, 3, 1, 5, 2),
+                layers=None, ac_offsets=None):
+    """The effective values of the CTC RAHT configs:
+    cfg/octree-raht-ctc-lossless-geom-lossy-attrs.yaml (qp 22..46,
+    qpChromaOffset -1, search range 50000 / 2500 for cat3-frame) and, with
+    ``haar=True, qp=4``, ...-lossless-attrs.yaml."""
+    p = RahtParams()
+    p.raht_prediction_enabled_flag = int(prediction)
+    p.integer_haar_enable_flag = int(haar)
+    p.raht_prediction_threshold0 = threshold0
+    p.raht_prediction_threshold1 = threshold1
+    p.raht_subnode_prediction_enabled_flag = int(subnode)
+    p.raht_prediction_search_range = search_range
+    p.set_prediction_weights(weights)
+    p.raht_extension = int(extension)
+    p.set_layers(layers if layers is not None else [(qp, chroma_offset)])
+    p.max_qp = 51 + 6 * (bitdepth - 8)   # quantization.cpp:151
+    p.fixed_point_qp_offset = 0          # RAHT: quantization.cpp:155-158
+    p.set_ac_offsets(ac_offsets or [])
+    return p
