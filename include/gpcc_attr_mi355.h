@@ -92,6 +92,10 @@ void gpcc_ctx_destroy(gpcc_ctx* ctx);
 int gpcc_ctx_synchronize(gpcc_ctx* ctx);
 /* Bytes of HBM currently held by the context's workspace. */
 size_t gpcc_ctx_workspace_bytes(const gpcc_ctx* ctx);
+/* Device-tier hint: number of significant Morton-code bits (3 x coordinate
+ * bits) of the batches that follow; 0 = unknown (63).  Bounds the number of
+ * octree levels that are launched; the host tier derives it itself. */
+int gpcc_ctx_set_morton_bits(gpcc_ctx* ctx, int32_t bits);
 
 /* ------------------------------------------------------------------ */
 /* host tier: one slice, host buffers, synchronous                      */

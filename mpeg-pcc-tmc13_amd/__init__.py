@@ -6,3 +6,9 @@ loaded under the importable alias ``mpeg_pcc_tmc13_amd`` by
 """
 from . import params, synth  # noqa: F401
 from .params import RahtParams, raht_params  # noqa: F401
+
+
+def context(device=0, stream=None):
+    """Open a device context (raises if the HIP library / a gfx950 GPU is missing)."""
+    from .raht import Context
+    return Context(device, stream)

@@ -1,0 +1,72 @@
+"""ctypes binding of include/gpcc_attr_mi355.h.  There is NO CPU fallback:
+if the HIP library is missing or a call fails this module raises."""
+import ctypes as C
+import os
+
+from .params import RahtParams
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "libgpcc_attr_mi355.so")
+
+# every symbol the header declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "gpcc_raht_set_prediction_weights", "gpcc_abi_version", "gpcc_last_error",
+    "gpcc_device_count", "gpcc_ctx_create", "gpcc_ctx_destroy",
+    "gpcc_ctx_synchronize", "gpcc_ctx_workspace_bytes", "gpcc_ctx_set_morton_bits",
+    "gpcc_raht_forward", "gpcc_raht_inverse", "gpcc_attr_morton_sort",
+    "gpcc_dev_raht_forward", "gpcc_dev_raht_inverse", "gpcc_dev_attr_morton_sort",
+    "gpcc_ctx_set_profiling", "gpcc_ctx_kernel_times",
+]
+
+
+class GpccError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"gpcc error {code}: {msg}")
+        self.code = code
+
+
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("total_ms", C.c_double), ("launches", C.c_int32)]
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m __graft_entry__` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64p = C.c_void_p, C.c_int32, C.POINTER(C.c_int64)
+    pp = C.POINTER(RahtParams)
+    lib.gpcc_abi_version.restype = C.c_int
+    lib.gpcc_last_error.restype = C.c_char_p
+    lib.gpcc_device_count.restype = C.c_int
+    lib.gpcc_ctx_create.argtypes = [C.c_int, vp, C.POINTER(vp)]
+    lib.gpcc_ctx_destroy.argtypes = [vp]
+    lib.gpcc_ctx_destroy.restype = None
+    lib.gpcc_ctx_synchronize.argtypes = [vp]
+    lib.gpcc_ctx_workspace_bytes.argtypes = [vp]
+    lib.gpcc_ctx_workspace_bytes.restype = C.c_size_t
+    lib.gpcc_ctx_set_morton_bits.argtypes = [vp, i32]
+    lib.gpcc_ctx_set_profiling.argtypes = [vp, C.c_int]
+    lib.gpcc_ctx_kernel_times.argtypes = [vp, C.POINTER(KernelTime), i32]
+    lib.gpcc_raht_set_prediction_weights.argtypes = [pp, C.POINTER(i32)]
+    lib.gpcc_raht_set_prediction_weights.restype = None
+    for name in ("gpcc_raht_forward", "gpcc_raht_inverse"):
+        getattr(lib, name).argtypes = [vp, pp, vp, vp, vp, vp, i32, i32]
+    lib.gpcc_attr_morton_sort.argtypes = [vp, vp, i32, vp, vp]
+    for name in ("gpcc_dev_raht_forward", "gpcc_dev_raht_inverse"):
+        getattr(lib, name).argtypes = [vp, pp, i32, i64p, vp, vp, vp, vp, i32]
+    lib.gpcc_dev_attr_morton_sort.argtypes = [vp, i32, i64p, vp, vp, vp]
+    _lib = lib
+    return lib
+
+
+def check(code):
+    if code != 0:
+        raise GpccError(code, load().gpcc_last_error().decode())

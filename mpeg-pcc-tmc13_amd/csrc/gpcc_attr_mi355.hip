@@ -1,0 +1,807 @@
+// gpcc_attr_mi355.hip -- C ABI (include/gpcc_attr_mi355.h) over the gfx950
+// RAHT kernels: context / workspace management and the launch sequences.
+//
+// Launch sequence of one batched transform (S slices, N points):
+//
+//   tree_count -> tree_scan -> tree_emit      all octree levels at once
+//   [ascend_leaf, ascend_level x nlev]        only integer Haar / region QP
+//   schedule                                  per-slice level plan
+//   for li = top .. 0:
+//     lossy encoder : level<kAnalyze> -> rdoq classify/carry/apply
+//                     -> level<kSynth>
+//     Haar encoder  : level<kFused>
+//     decoder       : level<kSynth>
+//   finish                                    duplicates, write-back
+//
+// Every kernel is launched with a grid that depends only on host-known
+// sizes; node counts stay on the device, so a whole transform is enqueued
+// without a single host synchronisation.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "gpcc_attr_mi355.h"
+#include "raht_common.hpp"
+#include "raht_edges.hpp"
+#include "raht_levels.hpp"
+#include "raht_rdoq.hpp"
+#include "raht_tree.hpp"
+#include "morton_sort.hpp"
+
+using namespace gpcc;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int
+fail(int code, const std::string& msg)
+{
+  g_last_error = msg;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                        \
+  do {                                                                       \
+    hipError_t e_ = (expr);                                                  \
+    if (e_ != hipSuccess)                                                    \
+      return fail(                                                           \
+        e_ == hipErrorOutOfMemory ? GPCC_ERR_OUT_OF_MEMORY : GPCC_ERR_HIP,   \
+        std::string(#expr) + ": " + hipGetErrorString(e_));                  \
+  } while (0)
+
+constexpr int kGridMax = 2048;  // 256 CUs x 8 workgroups of 256 threads
+
+int
+grid_for(int64_t items, int per_block)
+{
+  int64_t g = (items + per_block - 1) / per_block;
+  g = std::min<int64_t>(std::max<int64_t>(g, 1), kGridMax);
+  return (int)((g + 7) / 8 * 8);  // xcd_chunk() wants a multiple of 8
+}
+
+struct Arena {
+  char* base = nullptr;
+  size_t cap = 0;
+  size_t used = 0;
+
+  void reset() { used = 0; }
+  template<typename T>
+  T* take(size_t count)
+  {
+    size_t bytes = (count * sizeof(T) + 255) & ~size_t(255);
+    T* p = base ? reinterpret_cast<T*>(base + used) : nullptr;
+    used += bytes;
+    return p;
+  }
+};
+
+}  // namespace
+
+struct gpcc_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  Arena arena;
+  int morton_bits = 0;  // hint for the device tier, 0 = unknown
+  // host staging for the host tier
+  void* h_pinned = nullptr;
+  size_t h_pinned_cap = 0;
+  // profiling
+  bool profiling = false;
+  struct Span {
+    const char* name;
+    hipEvent_t a, b;
+  };
+  std::vector<Span> spans;
+  std::vector<hipEvent_t> event_pool;
+  std::vector<std::pair<const char*, std::pair<double, int>>> times;
+};
+
+namespace {
+
+struct Timer {
+  gpcc_ctx* ctx;
+  hipEvent_t a = nullptr, b = nullptr;
+  const char* name;
+  Timer(gpcc_ctx* c, const char* n) : ctx(c), name(n)
+  {
+    if (!ctx->profiling)
+      return;
+    auto get = [&]() {
+      hipEvent_t e;
+      if (!ctx->event_pool.empty()) {
+        e = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+      } else {
+        hipEventCreate(&e);
+      }
+      return e;
+    };
+    a = get();
+    b = get();
+    hipEventRecord(a, ctx->stream);
+  }
+  ~Timer()
+  {
+    if (!ctx->profiling)
+      return;
+    hipEventRecord(b, ctx->stream);
+    ctx->spans.push_back({name, a, b});
+  }
+};
+
+// ---- workspace plan ---------------------------------------------------
+
+struct Plan {
+  int n = 0, s = 0, c = 0, nlev = 0;
+  bool encoder = false, haar = false, has_qp = false, lossy = false;
+  std::vector<int64_t> cap;  // node capacity per level
+
+  TreeView tv{};
+  int32_t* pt_off = nullptr;
+  uint32_t* tile_cnt = nullptr;
+  int32_t* tile_attr = nullptr;
+  int32_t* attr_prefix = nullptr;
+  int32_t** haar_lf_tab = nullptr;
+  int32_t** asc_qp_tab = nullptr;
+  int32_t* dup_hf = nullptr;
+  int64_t* rec[2] = {nullptr, nullptr};
+  int64_t* rec_us[2] = {nullptr, nullptr};
+  int32_t* nneigh[2] = {nullptr, nullptr};
+  int32_t* dqp[2] = {nullptr, nullptr};
+  SliceSched* sched = nullptr;
+  gpcc_raht_params* params = nullptr;
+  uint32_t* desc = nullptr;
+  int32_t* rtile_base = nullptr;
+  int2* rtile_sum = nullptr;
+  int32_t* rtile_lin = nullptr;
+  int32_t* slice_l = nullptr;
+  int num_rtiles = 0;
+  std::vector<int32_t*> haar_lf, asc_qp;
+};
+
+// Carve the workspace.  With arena.base == nullptr this only measures.
+void
+carve(Arena& ar, Plan& pl)
+{
+  ar.reset();
+  const int n = pl.n, s = pl.s, c = pl.c, nlev = pl.nlev;
+  pl.pt_off = ar.take<int32_t>(s + 1);
+  pl.cap.assign(nlev, 0);
+  for (int li = 0; li < nlev; li++) {
+    // a level cannot hold more nodes than points, nor more than a full
+    // octree below the one-node-per-slice top level
+    int64_t cap = n;
+    const int up = nlev - 1 - li;
+    if (up < 11) {
+      int64_t full = (int64_t)s << (3 * up);
+      cap = std::min<int64_t>(cap, full);
+    }
+    pl.cap[li] = cap;
+    pl.tv.key[li] = ar.take<int64_t>(cap + 1);
+    pl.tv.fp[li] = ar.take<int32_t>(cap + 2);
+    pl.tv.fc[li] = ar.take<int32_t>(cap + 2);
+    pl.tv.soff[li] = ar.take<int32_t>(s + 1);
+  }
+  pl.tv.nlev = nlev;
+  pl.tv.num_slices = s;
+  pl.tv.n_total = n;
+  pl.tv.num_tiles = (n + kTilePoints - 1) / kTilePoints;
+  pl.tv.pt_off = pl.pt_off;
+  pl.tile_cnt = ar.take<uint32_t>((size_t)pl.tv.num_tiles * nlev);
+  pl.tile_attr = ar.take<int32_t>((size_t)pl.tv.num_tiles * c);
+  pl.sched = ar.take<SliceSched>(s);
+  pl.params = ar.take<gpcc_raht_params>(1);
+  for (int i = 0; i < 2; i++) {
+    pl.rec[i] = ar.take<int64_t>((size_t)n * c);
+    pl.rec_us[i] = ar.take<int64_t>((size_t)n * c);
+    pl.nneigh[i] = ar.take<int32_t>(n);
+    pl.dqp[i] = pl.has_qp ? ar.take<int32_t>((size_t)n * 2) : nullptr;
+  }
+  pl.attr_prefix = nullptr;
+  pl.dup_hf = nullptr;
+  pl.haar_lf.assign(nlev, nullptr);
+  pl.asc_qp.assign(nlev, nullptr);
+  pl.haar_lf_tab = nullptr;
+  pl.asc_qp_tab = nullptr;
+  if (pl.encoder && !pl.haar)
+    pl.attr_prefix = ar.take<int32_t>(((size_t)n + 1) * c);
+  if (pl.encoder && pl.haar) {
+    pl.dup_hf = ar.take<int32_t>((size_t)n * c);
+    pl.haar_lf_tab = ar.take<int32_t*>(nlev);
+    for (int li = 0; li < nlev; li++)
+      pl.haar_lf[li] = ar.take<int32_t>((size_t)(pl.cap[li] + 1) * c);
+  }
+  if (pl.has_qp) {
+    pl.asc_qp_tab = ar.take<int32_t*>(nlev);
+    for (int li = 0; li < nlev; li++)
+      pl.asc_qp[li] = ar.take<int32_t>((size_t)(pl.cap[li] + 1) * 2);
+  }
+  pl.desc = nullptr;
+  if (pl.lossy) {
+    pl.desc = ar.take<uint32_t>(n);
+    pl.rtile_base = ar.take<int32_t>(s + 1);
+    pl.rtile_sum = ar.take<int2>(pl.num_rtiles + 1);
+    pl.rtile_lin = ar.take<int32_t>(pl.num_rtiles + 1);
+    pl.slice_l = ar.take<int32_t>(s);
+  }
+}
+
+int
+ensure_arena(gpcc_ctx* ctx, size_t bytes)
+{
+  if (ctx->arena.cap >= bytes)
+    return GPCC_OK;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (ctx->arena.base)
+    HIP_TRY(hipFree(ctx->arena.base));
+  ctx->arena.base = nullptr;
+  ctx->arena.cap = 0;
+  size_t want = bytes + bytes / 8;
+  HIP_TRY(hipMalloc((void**)&ctx->arena.base, want));
+  ctx->arena.cap = want;
+  return GPCC_OK;
+}
+
+int
+check_params(const gpcc_raht_params* p, int c)
+{
+  if (!p)
+    return fail(GPCC_ERR_INVALID_ARG, "params is null");
+  if (c < 1 || c > 3)
+    return fail(GPCC_ERR_INVALID_ARG, "attribute count must be 1..3");
+  if (p->num_qp_layers < 1 || p->num_qp_layers > GPCC_MAX_QP_LAYERS)
+    return fail(GPCC_ERR_INVALID_ARG, "num_qp_layers out of range");
+  if (p->num_ac_qp_layers < 0 || p->num_ac_qp_layers > GPCC_MAX_AC_QP_LAYERS)
+    return fail(GPCC_ERR_INVALID_ARG, "num_ac_qp_layers out of range");
+  if (
+    p->raht_prediction_enabled_flag
+    && p->raht_subnode_prediction_enabled_flag)
+    return fail(
+      GPCC_ERR_UNSUPPORTED,
+      "raht_subnode_prediction_enabled_flag=1 is not on the device path "
+      "yet: run the reference CPU function for this slice");
+  return GPCC_OK;
+}
+
+template<int C>
+int
+launch_transform(
+  gpcc_ctx* ctx, Plan& pl, const gpcc_raht_params* hp, bool encoder,
+  const int64_t* offsets, const int64_t* d_morton, const int32_t* d_qp_off,
+  int32_t* d_attrs, int32_t* d_coeffs)
+{
+  hipStream_t st = ctx->stream;
+  const int n = pl.n, s = pl.s, nlev = pl.nlev;
+
+  // ---- small host -> device tables (pinned staging, async) ------------
+  std::vector<int32_t> h_off(s + 1), h_rbase(s + 1);
+  for (int i = 0; i <= s; i++)
+    h_off[i] = (int32_t)offsets[i];
+  h_rbase[0] = 0;
+  for (int i = 0; i < s; i++)
+    h_rbase[i + 1] =
+      h_rbase[i] + (h_off[i + 1] - h_off[i] + kRdoqTile - 1) / kRdoqTile;
+
+  size_t stage_bytes = sizeof(gpcc_raht_params) + 2 * (s + 1) * sizeof(int32_t)
+    + 2 * nlev * sizeof(void*) + 64;
+  if (ctx->h_pinned_cap < stage_bytes) {
+    HIP_TRY(hipStreamSynchronize(st));
+    if (ctx->h_pinned)
+      HIP_TRY(hipHostFree(ctx->h_pinned));
+    HIP_TRY(hipHostMalloc(&ctx->h_pinned, stage_bytes * 2));
+    ctx->h_pinned_cap = stage_bytes * 2;
+  } else {
+    // the previous call's async copies read this buffer
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  char* hp_base = (char*)ctx->h_pinned;
+  size_t o = 0;
+  auto stage = [&](const void* src, size_t bytes, void* dst) -> hipError_t {
+    memcpy(hp_base + o, src, bytes);
+    hipError_t e =
+      hipMemcpyAsync(dst, hp_base + o, bytes, hipMemcpyHostToDevice, st);
+    o += (bytes + 15) & ~size_t(15);
+    return e;
+  };
+  HIP_TRY(stage(hp, sizeof(*hp), pl.params));
+  HIP_TRY(stage(h_off.data(), (s + 1) * sizeof(int32_t), pl.pt_off));
+  if (pl.lossy)
+    HIP_TRY(stage(h_rbase.data(), (s + 1) * sizeof(int32_t), pl.rtile_base));
+  if (pl.haar_lf_tab)
+    HIP_TRY(stage(pl.haar_lf.data(), nlev * sizeof(void*), pl.haar_lf_tab));
+  if (pl.asc_qp_tab)
+    HIP_TRY(stage(pl.asc_qp.data(), nlev * sizeof(void*), pl.asc_qp_tab));
+
+  pl.tv.pos = d_morton;
+  const TreeView tv = pl.tv;
+
+  // ---- tree ------------------------------------------------------------
+  const int32_t* sum_attrs = (encoder && !pl.haar) ? d_attrs : nullptr;
+  {
+    Timer t(ctx, "tree_count");
+    tree_count_kernel<C><<<grid_for(tv.num_tiles, 4), 256, 0, st>>>(
+      tv, sum_attrs, pl.tile_cnt, pl.tile_attr);
+  }
+  {
+    Timer t(ctx, "tree_scan");
+    tree_scan_kernel<C><<<1, 1024, 0, st>>>(
+      tv, pl.tile_cnt, pl.tile_attr, pl.attr_prefix, sum_attrs != nullptr);
+  }
+  {
+    Timer t(ctx, "tree_emit");
+    tree_emit_kernel<C><<<grid_for(tv.num_tiles, 4), 256, 0, st>>>(
+      tv, sum_attrs, pl.tile_cnt, pl.tile_attr, pl.attr_prefix);
+  }
+  {
+    Timer t(ctx, "schedule");
+    schedule_kernel<<<(s + 63) / 64, 64, 0, st>>>(
+      tv, pl.sched, hp->num_qp_layers);
+  }
+
+  // ---- non-associative ascent (integer Haar / region QP) ----------------
+  if ((encoder && pl.haar) || pl.has_qp) {
+    AscendCtx ac{};
+    ac.tv = tv;
+    ac.attrs = (encoder && pl.haar) ? d_attrs : nullptr;
+    ac.qp_off = d_qp_off;
+    ac.haar_lf = (encoder && pl.haar) ? pl.haar_lf_tab : nullptr;
+    ac.asc_qp = pl.has_qp ? pl.asc_qp_tab : nullptr;
+    ac.dup_hf = pl.dup_hf;
+    ac.dqp_root = pl.dqp[1];
+    {
+      Timer t(ctx, "ascend");
+      ac.li = 0;
+      ascend_leaf_kernel<C><<<grid_for(pl.cap[0], 256), 256, 0, st>>>(ac);
+      for (int li = 1; li < nlev; li++) {
+        ac.li = li;
+        ascend_level_kernel<C><<<grid_for(pl.cap[li], 256), 256, 0, st>>>(ac);
+      }
+      if (pl.has_qp)
+        qp_root_kernel<<<(s + 63) / 64, 64, 0, st>>>(ac, pl.sched);
+    }
+  }
+
+  // ---- descent -----------------------------------------------------------
+  LevelCtx lc{};
+  lc.tv = tv;
+  lc.params = pl.params;
+  lc.sched = pl.sched;
+  lc.attr_prefix = pl.attr_prefix;
+  lc.haar_lf = (encoder && pl.haar) ? pl.haar_lf_tab : nullptr;
+  lc.asc_qp = pl.has_qp ? pl.asc_qp_tab : nullptr;
+  for (int i = 0; i < 2; i++) {
+    lc.rec[i] = pl.rec[i];
+    lc.rec_us[i] = pl.rec_us[i];
+    lc.nneigh[i] = pl.nneigh[i];
+    lc.dqp[i] = pl.dqp[i];
+  }
+  lc.coeffs = d_coeffs;
+  lc.desc = pl.desc;
+
+  RdoqCtx rc{};
+  if (pl.lossy) {
+    rc.tv = tv;
+    rc.sched = pl.sched;
+    rc.tile_base = pl.rtile_base;
+    rc.num_tiles = pl.num_rtiles;
+    rc.desc = pl.desc;
+    rc.coeffs = d_coeffs;
+    rc.tile_sum = pl.rtile_sum;
+    rc.tile_lin = pl.rtile_lin;
+    rc.slice_l = pl.slice_l;
+    rc.c = C;
+    HIP_TRY(hipMemsetAsync(pl.slice_l, 0xff, s * sizeof(int32_t), st));
+  }
+
+  for (int li = nlev - 2; li >= 0; li--) {
+    lc.li = li;
+    const int grid = grid_for(pl.cap[li + 1], 32);
+    if (!encoder) {
+      Timer t(ctx, "level_synth");
+      raht_level_kernel<C, kSynth><<<grid, 256, 0, st>>>(lc);
+    } else if (pl.haar) {
+      Timer t(ctx, "level_fused");
+      raht_level_kernel<C, kFused><<<grid, 256, 0, st>>>(lc);
+    } else {
+      {
+        Timer t(ctx, "level_analyze");
+        raht_level_kernel<C, kAnalyze><<<grid, 256, 0, st>>>(lc);
+      }
+      rc.li = li;
+      // tiles that can intersect this level's coefficients
+      const int64_t lvl_coeffs = pl.cap[li];
+      const int rgrid =
+        grid_for(std::min<int64_t>(pl.num_rtiles, lvl_coeffs / kRdoqTile + 2 * s), 4);
+      {
+        Timer t(ctx, "rdoq_classify");
+        rdoq_classify_kernel<<<rgrid, 256, 0, st>>>(rc);
+      }
+      {
+        Timer t(ctx, "rdoq_carry");
+        rdoq_carry_kernel<<<std::min(s, 1024), 64, 0, st>>>(rc);
+      }
+      {
+        Timer t(ctx, "rdoq_apply");
+        rdoq_apply_kernel<<<rgrid, 256, 0, st>>>(rc);
+      }
+      {
+        Timer t(ctx, "level_synth");
+        raht_level_kernel<C, kSynth><<<grid, 256, 0, st>>>(lc);
+      }
+    }
+  }
+
+  // ---- duplicates + write-back ------------------------------------------
+  FinishCtx fc{};
+  fc.tv = tv;
+  fc.params = pl.params;
+  fc.sched = pl.sched;
+  fc.attr_prefix = pl.attr_prefix;
+  fc.haar_lf = (encoder && pl.haar) ? pl.haar_lf_tab : nullptr;
+  fc.dup_hf = pl.dup_hf;
+  fc.asc_qp = pl.has_qp ? pl.asc_qp_tab : nullptr;
+  fc.qp_off = d_qp_off;
+  for (int i = 0; i < 2; i++) {
+    fc.rec[i] = pl.rec[i];
+    fc.dqp[i] = pl.dqp[i];
+  }
+  fc.attrs = d_attrs;
+  fc.coeffs = d_coeffs;
+  fc.encoder = encoder;
+  {
+    Timer t(ctx, "finish");
+    finish_kernel<C><<<grid_for(pl.cap[0], 256), 256, 0, st>>>(fc);
+  }
+  HIP_TRY(hipGetLastError());
+  return GPCC_OK;
+}
+
+int
+dev_transform(
+  gpcc_ctx* ctx, const gpcc_raht_params* params, bool encoder, int32_t s,
+  const int64_t* offsets, const void* d_morton, const void* d_qp_off,
+  void* d_attrs, void* d_coeffs, int32_t c, int morton_bits)
+{
+  if (!ctx)
+    return fail(GPCC_ERR_INVALID_ARG, "ctx is null");
+  int rcode = check_params(params, c);
+  if (rcode)
+    return rcode;
+  if (s < 1 || !offsets || offsets[0] != 0)
+    return fail(GPCC_ERR_INVALID_ARG, "bad slice offsets");
+  for (int i = 0; i < s; i++)
+    if (offsets[i + 1] <= offsets[i])
+      return fail(GPCC_ERR_INVALID_ARG, "empty or unordered slice");
+  if (offsets[s] >= (int64_t)1 << 30)
+    return fail(GPCC_ERR_INVALID_ARG, "more than 2^30 points per batch");
+  if (!d_morton || !d_attrs || !d_coeffs)
+    return fail(GPCC_ERR_INVALID_ARG, "null device buffer");
+  HIP_TRY(hipSetDevice(ctx->device));
+
+  Plan pl;
+  pl.n = (int)offsets[s];
+  pl.s = s;
+  pl.c = c;
+  const int bits = morton_bits > 0 ? std::min(morton_bits, 63) : 63;
+  pl.nlev = std::min((bits + 2) / 3 + 1, (int)kMaxLevels);
+  pl.encoder = encoder;
+  pl.haar = params->integer_haar_enable_flag != 0;
+  pl.has_qp = d_qp_off != nullptr;
+  pl.lossy = encoder && !pl.haar;
+  pl.num_rtiles = 0;
+  for (int i = 0; i < s; i++)
+    pl.num_rtiles +=
+      (int)((offsets[i + 1] - offsets[i] + kRdoqTile - 1) / kRdoqTile);
+
+  Arena measure;
+  carve(measure, pl);
+  rcode = ensure_arena(ctx, measure.used);
+  if (rcode)
+    return rcode;
+  carve(ctx->arena, pl);
+
+  switch (c) {
+  case 1:
+    return launch_transform<1>(
+      ctx, pl, params, encoder, offsets, (const int64_t*)d_morton,
+      (const int32_t*)d_qp_off, (int32_t*)d_attrs, (int32_t*)d_coeffs);
+  case 2:
+    return launch_transform<2>(
+      ctx, pl, params, encoder, offsets, (const int64_t*)d_morton,
+      (const int32_t*)d_qp_off, (int32_t*)d_attrs, (int32_t*)d_coeffs);
+  default:
+    return launch_transform<3>(
+      ctx, pl, params, encoder, offsets, (const int64_t*)d_morton,
+      (const int32_t*)d_qp_off, (int32_t*)d_attrs, (int32_t*)d_coeffs);
+  }
+}
+
+// host tier: stage one slice through HBM
+int
+host_transform(
+  gpcc_ctx* ctx, const gpcc_raht_params* params, bool encoder,
+  const int64_t* morton, const int32_t* qp_off, int32_t* attrs,
+  int32_t* coeffs, int32_t n, int32_t c)
+{
+  if (!ctx)
+    return fail(GPCC_ERR_INVALID_ARG, "ctx is null");
+  if (!morton || !attrs || !coeffs || n <= 0)
+    return fail(GPCC_ERR_INVALID_ARG, "null buffer or n <= 0");
+  int rcode = check_params(params, c);
+  if (rcode)
+    return rcode;
+  for (int i = 1; i < n; i++)
+    if (morton[i] < morton[i - 1])
+      return fail(GPCC_ERR_UNSORTED, "Morton codes are not ascending");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const int bits = bitlen64((uint64_t)(morton[0] ^ morton[n - 1]));
+
+  int64_t* d_m = nullptr;
+  int32_t *d_q = nullptr, *d_a = nullptr, *d_c = nullptr;
+  auto cleanup = [&]() {
+    hipFree(d_m);
+    hipFree(d_q);
+    hipFree(d_a);
+    hipFree(d_c);
+  };
+  auto run = [&]() -> int {
+    HIP_TRY(hipMalloc((void**)&d_m, sizeof(int64_t) * n));
+    HIP_TRY(hipMalloc((void**)&d_a, sizeof(int32_t) * n * c));
+    HIP_TRY(hipMalloc((void**)&d_c, sizeof(int32_t) * n * c));
+    HIP_TRY(hipMemcpyAsync(d_m, morton, sizeof(int64_t) * n, hipMemcpyHostToDevice, st));
+    if (qp_off) {
+      HIP_TRY(hipMalloc((void**)&d_q, sizeof(int32_t) * n * 2));
+      HIP_TRY(hipMemcpyAsync(d_q, qp_off, sizeof(int32_t) * n * 2, hipMemcpyHostToDevice, st));
+    }
+    if (encoder)
+      HIP_TRY(hipMemcpyAsync(d_a, attrs, sizeof(int32_t) * n * c, hipMemcpyHostToDevice, st));
+    else
+      HIP_TRY(hipMemcpyAsync(d_c, coeffs, sizeof(int32_t) * n * c, hipMemcpyHostToDevice, st));
+    const int64_t offs[2] = {0, n};
+    int r = dev_transform(
+      ctx, params, encoder, 1, offs, d_m, d_q, d_a, d_c, c, std::max(bits, 1));
+    if (r)
+      return r;
+    HIP_TRY(hipMemcpyAsync(attrs, d_a, sizeof(int32_t) * n * c, hipMemcpyDeviceToHost, st));
+    if (encoder)
+      HIP_TRY(hipMemcpyAsync(coeffs, d_c, sizeof(int32_t) * n * c, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return GPCC_OK;
+  };
+  int r = run();
+  cleanup();
+  return r;
+}
+
+}  // namespace
+
+// =========================================================================
+extern "C" {
+
+void
+gpcc_raht_set_prediction_weights(gpcc_raht_params* p, const int32_t w[5])
+{
+  const int32_t child[12] = {w[4], w[4], w[3], w[4], w[3], w[3],
+                             w[4], w[4], w[4], w[4], w[4], w[4]};
+  const int32_t parent[19] = {w[0], w[1], w[1], w[1], w[2], w[2], w[2],
+                              w[2], w[2], w[1], w[2], w[1], w[1], w[2],
+                              w[2], w[2], w[2], w[2], w[2]};
+  memcpy(p->pred_weight_child, child, sizeof(child));
+  memcpy(p->pred_weight_parent, parent, sizeof(parent));
+}
+
+int
+gpcc_abi_version(void)
+{
+  return GPCC_ABI_VERSION;
+}
+
+const char*
+gpcc_last_error(void)
+{
+  return g_last_error.c_str();
+}
+
+int
+gpcc_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess)
+    return 0;
+  return n;
+}
+
+int
+gpcc_ctx_create(int device, void* stream, gpcc_ctx** out)
+{
+  if (!out)
+    return fail(GPCC_ERR_INVALID_ARG, "out is null");
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n == 0)
+    return fail(GPCC_ERR_NO_DEVICE, "no HIP device visible");
+  if (device < 0 || device >= n)
+    return fail(GPCC_ERR_INVALID_ARG, "device index out of range");
+  HIP_TRY(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(
+      GPCC_ERR_NO_DEVICE,
+      std::string("device is ") + prop.gcnArchName
+        + ", this library is built for gfx950 only");
+  gpcc_ctx* ctx = new gpcc_ctx();
+  ctx->device = device;
+  if (stream) {
+    ctx->stream = (hipStream_t)stream;
+  } else {
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      delete ctx;
+      return fail(GPCC_ERR_HIP, hipGetErrorString(e));
+    }
+    ctx->own_stream = true;
+  }
+  *out = ctx;
+  return GPCC_OK;
+}
+
+void
+gpcc_ctx_destroy(gpcc_ctx* ctx)
+{
+  if (!ctx)
+    return;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  for (auto& sp : ctx->spans) {
+    hipEventDestroy(sp.a);
+    hipEventDestroy(sp.b);
+  }
+  for (auto e : ctx->event_pool)
+    hipEventDestroy(e);
+  if (ctx->arena.base)
+    hipFree(ctx->arena.base);
+  if (ctx->h_pinned)
+    hipHostFree(ctx->h_pinned);
+  if (ctx->own_stream)
+    hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int
+gpcc_ctx_synchronize(gpcc_ctx* ctx)
+{
+  if (!ctx)
+    return fail(GPCC_ERR_INVALID_ARG, "ctx is null");
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return GPCC_OK;
+}
+
+size_t
+gpcc_ctx_workspace_bytes(const gpcc_ctx* ctx)
+{
+  return ctx ? ctx->arena.cap : 0;
+}
+
+int
+gpcc_ctx_set_morton_bits(gpcc_ctx* ctx, int32_t bits)
+{
+  if (!ctx || bits < 0 || bits > 63)
+    return fail(GPCC_ERR_INVALID_ARG, "bad ctx / bits");
+  ctx->morton_bits = bits;
+  return GPCC_OK;
+}
+
+int
+gpcc_ctx_set_profiling(gpcc_ctx* ctx, int enable)
+{
+  if (!ctx)
+    return fail(GPCC_ERR_INVALID_ARG, "ctx is null");
+  ctx->profiling = enable != 0;
+  return GPCC_OK;
+}
+
+int
+gpcc_ctx_kernel_times(gpcc_ctx* ctx, gpcc_kernel_time* out, int32_t max_entries)
+{
+  if (!ctx)
+    return fail(GPCC_ERR_INVALID_ARG, "ctx is null");
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess)
+    return fail(GPCC_ERR_HIP, "synchronize failed");
+  std::vector<std::pair<const char*, std::pair<double, int>>> acc;
+  for (auto& sp : ctx->spans) {
+    float ms = 0;
+    hipEventElapsedTime(&ms, sp.a, sp.b);
+    bool found = false;
+    for (auto& a : acc)
+      if (!strcmp(a.first, sp.name)) {
+        a.second.first += ms;
+        a.second.second++;
+        found = true;
+      }
+    if (!found)
+      acc.push_back({sp.name, {ms, 1}});
+    ctx->event_pool.push_back(sp.a);
+    ctx->event_pool.push_back(sp.b);
+  }
+  ctx->spans.clear();
+  int nout = 0;
+  for (auto& a : acc) {
+    if (nout >= max_entries)
+      break;
+    out[nout].name = a.first;
+    out[nout].total_ms = a.second.first;
+    out[nout].launches = a.second.second;
+    nout++;
+  }
+  return nout;
+}
+
+int
+gpcc_raht_forward(
+  gpcc_ctx* ctx, const gpcc_raht_params* params, const int64_t* morton,
+  const int32_t* qp_off, int32_t* attrs, int32_t* coeffs, int32_t n, int32_t c)
+{
+  return host_transform(ctx, params, true, morton, qp_off, attrs, coeffs, n, c);
+}
+
+int
+gpcc_raht_inverse(
+  gpcc_ctx* ctx, const gpcc_raht_params* params, const int64_t* morton,
+  const int32_t* qp_off, int32_t* attrs, const int32_t* coeffs, int32_t n,
+  int32_t c)
+{
+  return host_transform(
+    ctx, params, false, morton, qp_off, attrs, const_cast<int32_t*>(coeffs), n, c);
+}
+
+int
+gpcc_dev_raht_forward(
+  gpcc_ctx* ctx, const gpcc_raht_params* params, int32_t num_slices,
+  const int64_t* offsets, const void* d_morton, const void* d_qp_off,
+  void* d_attrs, void* d_coeffs, int32_t c)
+{
+  return dev_transform(
+    ctx, params, true, num_slices, offsets, d_morton, d_qp_off, d_attrs,
+    d_coeffs, c, ctx ? ctx->morton_bits : 0);
+}
+
+int
+gpcc_dev_raht_inverse(
+  gpcc_ctx* ctx, const gpcc_raht_params* params, int32_t num_slices,
+  const int64_t* offsets, const void* d_morton, const void* d_qp_off,
+  void* d_attrs, const void* d_coeffs, int32_t c)
+{
+  return dev_transform(
+    ctx, params, false, num_slices, offsets, d_morton, d_qp_off, d_attrs,
+    const_cast<void*>(d_coeffs), c, ctx ? ctx->morton_bits : 0);
+}
+
+int
+gpcc_dev_attr_morton_sort(
+  gpcc_ctx* ctx, int32_t num_slices, const int64_t* offsets, const void* d_xyz,
+  void* d_morton, void* d_order)
+{
+  if (!ctx)
+    return fail(GPCC_ERR_INVALID_ARG, "ctx is null");
+  return fail(GPCC_ERR_UNSUPPORTED, "device Morton sort not built yet");
+}
+
+int
+gpcc_attr_morton_sort(
+  gpcc_ctx* ctx, const int32_t* xyz, int32_t n, int64_t* morton, int32_t* order)
+{
+  if (!ctx)
+    return fail(GPCC_ERR_INVALID_ARG, "ctx is null");
+  return fail(GPCC_ERR_UNSUPPORTED, "device Morton sort not built yet");
+}
+
+}  // extern "C"

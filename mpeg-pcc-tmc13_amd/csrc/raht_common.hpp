@@ -1,0 +1,151 @@
+// raht_common.hpp -- device-side data layout shared by the RAHT kernels.
+//
+// Layout in HBM (one batch = S slices laid back to back, N points):
+//
+//   points      pos[N] int64 (ascending per slice), attrs[N][C] int32
+//   level li    nodes of the octree level `li` (key = pos >> 3*li) of ALL
+//               slices, slice after slice, Morton order inside a slice:
+//                 key[li][M]    int64   pos >> 3*li
+//                 fp [li][M+1]  int32   first point of the node
+//                               (weight = fp[j+1] - fp[j])
+//                 fc [li][M+1]  int32   first child in level li-1
+//                 soff[li][S+1] int32   first node of each slice
+//   P[N+1][C]   exclusive prefix sums of the attributes (int32, modular):
+//               a node's attribute sum is P[fp[j+1]] - P[fp[j]]
+//   rec*/nn*    reconstruction ping-pong buffers indexed by
+//               (slice point offset + slice-local node index)
+//
+// The reference keeps one std::vector<UrahtNode> (40 B per node) that is
+// repeatedly compacted and re-expanded (tmc3/RAHT.cpp:95-264); here each
+// level exists once, as 16 B of index data per node.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gpcc_attr_mi355.h"
+#include "gpcc_primitives.hpp"
+
+namespace gpcc {
+
+constexpr int kMaxLevels = 22;   // ceil(63 / 3) + root
+constexpr int kTilePoints = 1024;  // points per wave in the tree build
+constexpr int kWave = 64;
+
+struct TreeView {
+  int32_t nlev;         // level arrays in use (top one has 1 node / slice)
+  int32_t num_slices;
+  int32_t n_total;
+  int32_t num_tiles;
+  const int64_t* pos;
+  const int32_t* pt_off;  // [S+1] device copy of the slice point offsets
+  int64_t* key[kMaxLevels];
+  int32_t* fp[kMaxLevels];
+  int32_t* fc[kMaxLevels];
+  int32_t* soff[kMaxLevels];
+};
+
+// Per (slice, level) processing schedule, derived on the device from the
+// node counts (tmc3/RAHT.cpp:1165-1265: which levels run the block loop,
+// which quantisation layer they use, where their coefficients start).
+struct LevelSched {
+  int32_t coeff_base;  // first coefficient of the level, slice relative
+  uint8_t processed;
+  uint8_t is_root;     // first processed level: DC is coded, no prediction
+  uint8_t qp_layer;
+  int8_t ac_layer;
+  uint8_t parity;      // reconstruction buffer written by this level
+  uint8_t pad[3];
+};
+
+struct SliceSched {
+  int32_t num_unique;
+  int32_t top_level;       // smallest li with one node
+  int32_t final_qp_layer;  // qpLayer when the level loop ends
+  int32_t final_parity;    // buffer holding the leaf reconstruction
+  LevelSched lvl[kMaxLevels];
+};
+
+// slice of a node / point index: off[] is ascending with off[0] == 0
+__device__ __forceinline__ int
+find_slice(const int32_t* __restrict__ off, int num_slices, int idx)
+{
+  int lo = 0, hi = num_slices;  // answer in [lo, hi)
+  while (hi - lo > 1) {
+    int mid = (lo + hi) >> 1;
+    if (off[mid] <= idx)
+      lo = mid;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+
+// ---- wave / 8-lane group helpers --------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
+
+__device__ __forceinline__ int64_t
+shfl_xor_i64(int64_t v, int mask)
+{
+  int lo = __shfl_xor((int)(uint32_t)v, mask);
+  int hi = __shfl_xor((int)(v >> 32), mask);
+  return ((int64_t)hi << 32) | (uint32_t)lo;
+}
+
+__device__ __forceinline__ int64_t
+shfl_i64(int64_t v, int src)
+{
+  int lo = __shfl((int)(uint32_t)v, src);
+  int hi = __shfl((int)(v >> 32), src);
+  return ((int64_t)hi << 32) | (uint32_t)lo;
+}
+
+// OR / sum over the 8 lanes of a group (lanes g*8 .. g*8+7)
+__device__ __forceinline__ uint32_t
+group8_or(uint32_t v)
+{
+  v |= __shfl_xor(v, 1);
+  v |= __shfl_xor(v, 2);
+  v |= __shfl_xor(v, 4);
+  return v;
+}
+__device__ __forceinline__ int
+group8_sum(int v)
+{
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 4);
+  return v;
+}
+
+__device__ __forceinline__ uint32_t
+wave_incl_scan_u32(uint32_t v)
+{
+  const int lane = lane_id();
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) {
+    uint32_t o = __shfl_up(v, d);
+    if (lane >= d)
+      v += o;
+  }
+  return v;
+}
+
+// XCD-aware work split: workgroup b runs on XCD b % 8 (observed dispatch,
+// used for L2 locality only).  Give every XCD one contiguous eighth of the
+// work so neighbouring nodes are looked up in the same L2.
+__device__ __forceinline__ void
+xcd_chunk(int64_t total, int64_t* begin, int64_t* end)
+{
+  const int nb = gridDim.x;
+  const int b = blockIdx.x;
+  const int per_xcd = (nb + 7) >> 3;
+  const int slot = (b & 7) * per_xcd + (b >> 3);  // position in XCD-major order
+  const int64_t chunk = (total + (int64_t)per_xcd * 8 - 1) / ((int64_t)per_xcd * 8);
+  int64_t s = (int64_t)slot * chunk;
+  int64_t e = s + chunk;
+  *begin = s < total ? s : total;
+  *end = e < total ? e : total;
+}
+
+}  // namespace gpcc

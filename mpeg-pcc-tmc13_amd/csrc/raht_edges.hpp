@@ -1,0 +1,307 @@
+// raht_edges.hpp -- the non-block parts of the RAHT pipeline:
+//   ascend_*  : integer-Haar low-pass values and region-QP averages, which
+//               are NOT associative and therefore computed level by level
+//               exactly as reduceUnique/reduceLevel do
+//               (tmc3/RAHT.cpp:108-205);
+//   finish    : duplicate-point tail (tmc3/RAHT.cpp:1840-1964), the
+//               single-point shortcut (:998-1017) and the rounded
+//               write-back of the reconstruction (:1967-1975).
+#pragma once
+
+#include "raht_common.hpp"
+#include "raht_levels.hpp"
+
+namespace gpcc {
+
+struct AscendCtx {
+  TreeView tv;
+  const int32_t* attrs;    // [N][C] source attributes (Haar encoder) or null
+  const int32_t* qp_off;   // [N][2] or null
+  int32_t* const* haar_lf; // [nlev] -> [M][C]
+  int32_t* const* asc_qp;  // [nlev] -> [M][2]
+  int32_t* dup_hf;         // [N][C] Haar difference of each duplicate point
+  int32_t* dqp_root;       // dqp[1]: the root block's parent qp lives here
+  int32_t li;              // level being produced
+};
+
+// level 0 from the points (reduceUnique)
+template<int C>
+__global__ __launch_bounds__(256) void
+ascend_leaf_kernel(AscendCtx cx)
+{
+  const TreeView& tv = cx.tv;
+  const int m = tv.soff[0][tv.num_slices];
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < m;
+       j += gridDim.x * blockDim.x) {
+    const int f0 = tv.fp[0][j], f1 = tv.fp[0][j + 1];
+    if (cx.asc_qp) {
+      cx.asc_qp[0][(size_t)j * 2] = cx.qp_off[(size_t)f0 * 2] * 16;
+      cx.asc_qp[0][(size_t)j * 2 + 1] = cx.qp_off[(size_t)f0 * 2 + 1] * 16;
+    }
+    if (cx.haar_lf) {
+#pragma unroll
+      for (int k = 0; k < C; k++) {
+        int32_t acc = cx.attrs[(size_t)f0 * C + k];
+        for (int i = f0 + 1; i < f1; i++) {
+          const int32_t d = (int32_t)((uint32_t)cx.attrs[(size_t)i * C + k] - (uint32_t)acc);
+          cx.dup_hf[(size_t)i * C + k] = d;
+          acc = (int32_t)((uint32_t)acc + (uint32_t)(d >> 1));
+        }
+        cx.haar_lf[0][(size_t)j * C + k] = acc;
+      }
+    }
+  }
+}
+
+// level li from level li-1: three binary merges z, y, x (reduceLevel)
+template<int C>
+__global__ __launch_bounds__(256) void
+ascend_level_kernel(AscendCtx cx)
+{
+  const TreeView& tv = cx.tv;
+  const int li = cx.li;
+  const int m = tv.soff[li][tv.num_slices];
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < m;
+       j += gridDim.x * blockDim.x) {
+    const int c0 = tv.fc[li][j], c1 = tv.fc[li][j + 1];
+    int32_t w[8], a[8][C], q[8][2];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      w[i] = 0;
+      q[i][0] = q[i][1] = 0;
+#pragma unroll
+      for (int k = 0; k < C; k++)
+        a[i][k] = 0;
+    }
+    for (int ch = c0; ch < c1; ch++) {
+      const int idx = (int)(tv.key[li - 1][ch] & 7);
+      // select by idx with a compare chain to keep the arrays in registers
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        if (i == idx) {
+          w[i] = tv.fp[li - 1][ch + 1] - tv.fp[li - 1][ch];
+          if (cx.asc_qp) {
+            q[i][0] = cx.asc_qp[li - 1][(size_t)ch * 2];
+            q[i][1] = cx.asc_qp[li - 1][(size_t)ch * 2 + 1];
+          }
+          if (cx.haar_lf) {
+#pragma unroll
+            for (int k = 0; k < C; k++)
+              a[i][k] = cx.haar_lf[li - 1][(size_t)ch * C + k];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int step = 1; step < 8; step <<= 1) {
+#pragma unroll
+      for (int l = 0; l < 8; l += 2 * step) {
+        const int r = l + step;
+        if (!w[r])
+          continue;
+        if (!w[l]) {
+          w[l] = w[r];
+          q[l][0] = q[r][0];
+          q[l][1] = q[r][1];
+#pragma unroll
+          for (int k = 0; k < C; k++)
+            a[l][k] = a[r][k];
+        } else {
+          w[l] += w[r];
+          q[l][0] = (q[l][0] + q[r][0]) >> 1;
+          q[l][1] = (q[l][1] + q[r][1]) >> 1;
+#pragma unroll
+          for (int k = 0; k < C; k++) {
+            const int32_t d = (int32_t)((uint32_t)a[r][k] - (uint32_t)a[l][k]);
+            a[l][k] = (int32_t)((uint32_t)a[l][k] + (uint32_t)(d >> 1));
+          }
+        }
+        w[r] = 0;
+      }
+    }
+    if (cx.asc_qp) {
+      cx.asc_qp[li][(size_t)j * 2] = q[0][0];
+      cx.asc_qp[li][(size_t)j * 2 + 1] = q[0][1];
+    }
+    if (cx.haar_lf) {
+#pragma unroll
+      for (int k = 0; k < C; k++)
+        cx.haar_lf[li][(size_t)j * C + k] = a[0][k];
+    }
+  }
+}
+
+// the root keeps its ascent average as descent qp
+__global__ void
+qp_root_kernel(AscendCtx cx, const SliceSched* sched)
+{
+  const TreeView& tv = cx.tv;
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= tv.num_slices)
+    return;
+  const int top = sched[s].top_level;
+  const int node = tv.soff[top][s];
+  const int64_t row = tv.pt_off[s];
+  cx.dqp_root[row * 2] = cx.asc_qp[top][(size_t)node * 2];
+  cx.dqp_root[row * 2 + 1] = cx.asc_qp[top][(size_t)node * 2 + 1];
+}
+
+struct FinishCtx {
+  TreeView tv;
+  const gpcc_raht_params* params;
+  const SliceSched* sched;
+  const int32_t* attr_prefix;
+  const int32_t* const* haar_lf;
+  const int32_t* dup_hf;
+  const int32_t* const* asc_qp;
+  const int32_t* qp_off;
+  const int64_t* rec[2];
+  const int32_t* dqp[2];
+  int32_t* attrs;   // in: source (encoder), out: reconstruction
+  int32_t* coeffs;
+  int32_t encoder;
+};
+
+template<int C>
+__global__ __launch_bounds__(256) void
+finish_kernel(FinishCtx cx)
+{
+  __shared__ SharedLut lut_s;
+  load_lut(&lut_s);
+  const RsqrtLut& lut = lut_s.rsqrt;
+  const TreeView& tv = cx.tv;
+  const gpcc_raht_params* __restrict__ prm = cx.params;
+  const bool haar = prm->integer_haar_enable_flag != 0;
+  const bool ext = prm->raht_extension != 0;
+  const int m = tv.soff[0][tv.num_slices];
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < m;
+       j += gridDim.x * blockDim.x) {
+    const int s = find_slice(tv.soff[0], tv.num_slices, j);
+    const SliceSched* sc = &cx.sched[s];
+    const int pt0 = tv.pt_off[s];
+    const int n_s = tv.pt_off[s + 1] - pt0;
+    const int f0 = tv.fp[0][j], f1 = tv.fp[0][j + 1];
+    const int weight = f1 - f0;
+    const int jl = j - tv.soff[0][s];
+    int32_t* __restrict__ co = cx.coeffs + (size_t)pt0 * C;
+
+    if (n_s == 1) {
+      // single point (tmc3/RAHT.cpp:998-1017): quantise directly, layer 0
+      Quantizer q[2];
+      qpset_quantizers(
+        prm, 0, cx.qp_off ? cx.qp_off[(size_t)f0 * 2] : 0,
+        cx.qp_off ? cx.qp_off[(size_t)f0 * 2 + 1] : 0, q);
+#pragma unroll
+      for (int k = 0; k < C; k++) {
+        int64_t coeff;
+        if (cx.encoder) {
+          coeff = quantize(q[k ? 1 : 0], (int64_t)cx.attrs[(size_t)f0 * C + k] << 8);
+          co[k] = (int32_t)coeff;
+        } else {
+          coeff = co[k];
+        }
+        cx.attrs[(size_t)f0 * C + k] = (int32_t)dequantize(q[k ? 1 : 0], coeff);
+      }
+      continue;
+    }
+
+    const bool any_level = sc->num_unique > 1;
+    const int par = sc->final_parity;
+    const int64_t row = (int64_t)pt0 + jl;
+    int64_t rec[C];
+#pragma unroll
+    for (int k = 0; k < C; k++)
+      rec[k] = any_level ? cx.rec[par][row * C + k] : 0;
+
+    if (weight == 1) {
+#pragma unroll
+      for (int k = 0; k < C; k++)
+        cx.attrs[(size_t)f0 * C + k] =
+          ext ? (int32_t)((rec[k] + kFpHalf) >> kFpFrac) : (int32_t)rec[k];
+      continue;
+    }
+
+    // ---- duplicates: a chain of (w, 1) two-point transforms ------------
+    int nq0 = 0, nq1 = 0;
+    if (cx.asc_qp) {
+      if (any_level) {
+        nq0 = cx.dqp[par][row * 2] >> 4;
+        nq1 = cx.dqp[par][row * 2 + 1] >> 4;
+      } else {
+        nq0 = cx.asc_qp[0][(size_t)j * 2] >> 4;
+        nq1 = cx.asc_qp[0][(size_t)j * 2 + 1] >> 4;
+      }
+    }
+    Quantizer q[2];
+    qpset_quantizers(prm, sc->final_qp_layer, nq0, nq1, q);
+    const int64_t sq = (int64_t)isqrt((uint64_t)weight << (2 * kFpFrac), lut);
+    int64_t attr_sum[C], rec_dc[C];
+#pragma unroll
+    for (int k = 0; k < C; k++) {
+      attr_sum[k] = 0;
+      if (cx.encoder) {
+        const int32_t v = haar
+          ? cx.haar_lf[0][(size_t)j * C + k]
+          : (int32_t)((uint32_t)cx.attr_prefix[(size_t)f1 * C + k]
+                      - (uint32_t)cx.attr_prefix[(size_t)f0 * C + k]);
+        attr_sum[k] = fp_from_int(v);
+      }
+      rec_dc[k] = ext ? rec[k] : fp_from_int(rec[k]);
+      if (!haar)
+        rec_dc[k] = fp_mul(rec_dc[k], sq);
+    }
+    // coefficients of this node follow all level coefficients and the
+    // tails of the earlier duplicated leaves
+    int cidx = sc->num_unique + (f0 - pt0) - jl;
+    for (int wv = weight - 1; wv > 0; wv--, cidx++) {
+      int64_t a = 0, b = 0;
+      if (!haar)
+        raht_coeffs(wv, 1, lut, &a, &b);
+#pragma unroll
+      for (int k = 0; k < C; k++) {
+        const Quantizer qk = q[k ? 1 : 0];
+        int64_t t0, t1, coeff;
+        if (cx.encoder) {
+          if (haar) {
+            t1 = fp_from_int(cx.dup_hf[(size_t)(f0 + wv) * C + k]);
+            attr_sum[k] -= t1 >> 1;
+            t1 += attr_sum[k];
+            t0 = attr_sum[k];
+            t1 = t1 - t0;  // HaarKernel::fwdTransform high-pass
+          } else {
+            t1 = fp_from_int(cx.attrs[(size_t)(f0 + wv) * C + k]);
+            attr_sum[k] -= t1;
+            t0 = scale_rsqrt(attr_sum[k], wv, lut);
+            t1 = fp_mul(t1, a) - fp_mul(b, t0);
+          }
+          coeff = quantize(qk, fp_round(t1) * 256);
+          co[(size_t)k * n_s + cidx] = (int32_t)coeff;
+        } else {
+          coeff = co[(size_t)k * n_s + cidx];
+        }
+        t1 = fp_from_int(dequantize(qk, coeff));
+        t0 = rec_dc[k];
+        if (haar) {
+          const int64_t left = t0 - ((t1 >> (1 + kFpFrac)) << kFpFrac);
+          t1 = t1 + left;
+          t0 = left;
+        } else {
+          const int64_t lf = t0, hf = t1;
+          t0 = fp_mul(lf, a) - fp_mul(b, hf);
+          t1 = fp_mul(lf, b) + fp_mul(a, hf);
+        }
+        rec_dc[k] = t0;
+        const int64_t o1 = ext ? t1 : fp_round(t1);
+        cx.attrs[(size_t)(f0 + wv) * C + k] =
+          ext ? (int32_t)((o1 + kFpHalf) >> kFpFrac) : (int32_t)o1;
+        if (wv == 1) {
+          const int64_t o0 = ext ? t0 : fp_round(t0);
+          cx.attrs[(size_t)f0 * C + k] =
+            ext ? (int32_t)((o0 + kFpHalf) >> kFpFrac) : (int32_t)o0;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace gpcc

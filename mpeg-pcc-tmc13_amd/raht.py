@@ -1,0 +1,103 @@
+"""Host-side mirror of the reference's RAHT interface over the C ABI.
+
+``raht_forward`` / ``raht_inverse`` have the argument meaning of
+``pcc::regionAdaptiveHierarchicalTransform`` / ``...InverseTransform``
+(reference tmc3/RAHT.h:47-69): ascending Morton codes, row-major attributes
+(overwritten with the reconstruction), planar coefficients.  Errors raise
+(the reference asserts); GPCC_ERR_UNSUPPORTED tells the caller to keep the
+slice on the reference CPU path."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .params import RahtParams
+
+
+class Context:
+    """gpcc_ctx: one HIP device + stream + workspace."""
+
+    def __init__(self, device=0, stream=None):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self._lib.gpcc_ctx_create(device, C.c_void_p(stream or 0), C.byref(h)))
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.gpcc_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        _lib.check(self._lib.gpcc_ctx_synchronize(self._h))
+
+    def workspace_bytes(self):
+        return int(self._lib.gpcc_ctx_workspace_bytes(self._h))
+
+    def set_morton_bits(self, bits):
+        _lib.check(self._lib.gpcc_ctx_set_morton_bits(self._h, int(bits)))
+
+    def set_profiling(self, on):
+        _lib.check(self._lib.gpcc_ctx_set_profiling(self._h, int(bool(on))))
+
+    def kernel_times(self):
+        """{kernel name: (total ms, launches)} since the last call."""
+        buf = (_lib.KernelTime * 64)()
+        n = self._lib.gpcc_ctx_kernel_times(self._h, buf, 64)
+        if n < 0:
+            _lib.check(n)
+        return {buf[i].name.decode(): (buf[i].total_ms, buf[i].launches) for i in range(n)}
+
+    # ---- host tier ------------------------------------------------------
+    def raht_forward(self, params: RahtParams, morton, attrs, qp_off=None):
+        """-> (coeffs int32 [c*n] planar, recon int32 [n, c])"""
+        morton = np.ascontiguousarray(morton, dtype=np.int64)
+        rec = np.ascontiguousarray(attrs, dtype=np.int32).copy()
+        n, c = rec.shape
+        coeffs = np.zeros(c * n, dtype=np.int32)
+        q = None if qp_off is None else np.ascontiguousarray(qp_off, dtype=np.int32)
+        _lib.check(self._lib.gpcc_raht_forward(
+            self._h, C.byref(params), morton.ctypes.data, q.ctypes.data if q is not None else None,
+            rec.ctypes.data, coeffs.ctypes.data, n, c))
+        return coeffs, rec
+
+    def raht_inverse(self, params: RahtParams, morton, coeffs, c, qp_off=None):
+        """-> recon int32 [n, c] (unclipped)"""
+        morton = np.ascontiguousarray(morton, dtype=np.int64)
+        n = morton.shape[0]
+        co = np.ascontiguousarray(coeffs, dtype=np.int32)
+        rec = np.zeros((n, c), dtype=np.int32)
+        q = None if qp_off is None else np.ascontiguousarray(qp_off, dtype=np.int32)
+        _lib.check(self._lib.gpcc_raht_inverse(
+            self._h, C.byref(params), morton.ctypes.data, q.ctypes.data if q is not None else None,
+            rec.ctypes.data, co.ctypes.data, n, c))
+        return rec
+
+    def morton_sort(self, xyz):
+        xyz = np.ascontiguousarray(xyz, dtype=np.int32)
+        n = xyz.shape[0]
+        morton = np.zeros(n, dtype=np.int64)
+        order = np.zeros(n, dtype=np.int32)
+        _lib.check(self._lib.gpcc_attr_morton_sort(
+            self._h, xyz.ctypes.data, n, morton.ctypes.data, order.ctypes.data))
+        return morton, order
+
+    # ---- device tier (raw device addresses, e.g. torch tensor.data_ptr()) -
+    def dev_raht_forward(self, params, offsets, d_morton, d_attrs, d_coeffs, c, d_qp_off=None):
+        off = (C.c_int64 * len(offsets))(*[int(o) for o in offsets])
+        _lib.check(self._lib.gpcc_dev_raht_forward(
+            self._h, C.byref(params), len(offsets) - 1, off, C.c_void_p(d_morton),
+            C.c_void_p(d_qp_off or 0), C.c_void_p(d_attrs), C.c_void_p(d_coeffs), c))
+
+    def dev_raht_inverse(self, params, offsets, d_morton, d_attrs, d_coeffs, c, d_qp_off=None):
+        off = (C.c_int64 * len(offsets))(*[int(o) for o in offsets])
+        _lib.check(self._lib.gpcc_dev_raht_inverse(
+            self._h, C.byref(params), len(offsets) - 1, off, C.c_void_p(d_morton),
+            C.c_void_p(d_qp_off or 0), C.c_void_p(d_attrs), C.c_void_p(d_coeffs), c))
