@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py -- RAHT attribute-transform throughput on MI355X.
+
+One STEP = one pass of the hot path over one batch of synthetic,
+Morton-sorted frames resident in HBM: RAHT forward (encoder side:
+coefficients + reconstruction) followed by RAHT inverse (decoder side) of
+every frame of the batch.  At N=1 the workload is BASELINE.json configs[1]:
+a 1M-point lidar-shaped cloud (S-lidar, 18-bit grid, reflectance, C=1),
+flags of cfg/octree-raht-ctc-lossless-geom-lossy-attrs.yaml (qp 34, search
+range 2500) with raht_subnode_prediction_enabled_flag as stated in
+`config`.  With N>1 every rank transforms its own frame(s) (weak scaling,
+frames shard one-per-GPU) and the quantised coefficients are gathered on
+rank 0 with one RCCL gather inside the timed region.
+
+Prints ONE JSON line (see the driver contract).  value = points entering
+the forward+inverse pass per second, whole job.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--points", type=int, default=1_000_000, help="points per frame")
+    ap.add_argument("--frames", type=int, default=1, help="frames (slices) per GPU per step")
+    ap.add_argument("--cloud", choices=["lidar", "dense"], default="lidar")
+    ap.add_argument("--qp", type=int, default=34)
+    ap.add_argument("--subnode", type=int, default=0)
+    ap.add_argument("--haar", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    return ap.parse_args()
+
+
+def make_frame(args, seed):
+    from mpeg_pcc_tmc13_amd import synth
+    if args.cloud == "lidar":
+        xyz, attrs = synth.lidar_cloud(args.points, seed=seed)
+        bits = 18
+    else:
+        bits = 10 if args.points <= 1_500_000 else 12
+        xyz, attrs = synth.dense_cloud(args.points, seed=seed, bits=bits)
+    morton, attrs, _ = synth.sort_by_morton(xyz, attrs)
+    return morton, attrs, 3 * bits
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    ge.load_package()
+    from mpeg_pcc_tmc13_amd import context, raht_params
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    if args.haar:
+        p = raht_params(qp=4, haar=True, chroma_offset=0, subnode=bool(args.subnode), search_range=2500)
+    else:
+        p = raht_params(qp=args.qp, subnode=bool(args.subnode),
+                        search_range=2500 if args.cloud == "lidar" else 50000)
+
+    # ---- synthetic frames of this rank, resident in HBM -------------------
+    frames = [make_frame(args, seed=1 + rank * args.frames + f) for f in range(args.frames)]
+    c = frames[0][1].shape[1]
+    sizes = [len(f[0]) for f in frames]
+    offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    n = int(offsets[-1])
+    d_morton = torch.from_numpy(np.concatenate([f[0] for f in frames])).to(dev)
+    src = torch.from_numpy(np.concatenate([f[1] for f in frames]).reshape(-1)).to(dev)
+    d_attrs = torch.empty_like(src)
+    d_coeffs = torch.zeros(c * n, dtype=torch.int32, device=dev)
+    d_dec = torch.empty_like(src)
+    gathered = [torch.empty_like(d_coeffs) for _ in range(world)] if (world > 1 and rank == 0) else None
+
+    stream = torch.cuda.current_stream(dev)
+    ctx = context(local_rank, stream=stream.cuda_stream)
+    ctx.set_morton_bits(frames[0][2])
+
+    def step():
+        d_attrs.copy_(src)  # the transform overwrites its input with the reconstruction
+        ctx.dev_raht_forward(p, offsets, d_morton.data_ptr(), d_attrs.data_ptr(), d_coeffs.data_ptr(), c)
+        ctx.dev_raht_inverse(p, offsets, d_morton.data_ptr(), d_dec.data_ptr(), d_coeffs.data_ptr(), c)
+        if world > 1:
+            dist.gather(d_coeffs, gathered, dst=0)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # in-run sanity: decoder output == encoder reconstruction (the
+    # reference's own conformance criterion)
+    roundtrip_ok = bool(torch.equal(d_attrs, d_dec))
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = n * world * args.steps / elapsed / 1e6
+
+    out = {
+        "metric": "RAHT forward+inverse attribute-transform Mpoints/s (bit-exact vs CPU reference)",
+        "value": round(value, 3), "unit": "Mpoints/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "int64 (Q15 fixed point), int32 I/O",
+        "data": "synthetic",
+        "config": {
+            "workload": f"RAHT forward+inverse, {args.frames}x{args.points}-point Morton-sorted "
+                        f"S-{args.cloud} frame(s) per GPU, C={c}, "
+                        + ("integer Haar qp 4" if args.haar else f"qp {args.qp}")
+                        + f", raht_prediction=1, raht_subnode_prediction={int(args.subnode)}, raht_extension=1",
+            "points_per_gpu_per_step": n, "frames_per_gpu": args.frames,
+            "roundtrip_decoder_equals_encoder_recon": roundtrip_ok,
+        },
+    }
+
+    if rank == 0 and world == 1:
+        # ---- per-kernel durations: HIP events on the context's stream -----
+        if not args.no_profile:
+            ctx.set_profiling(True)
+            ctx.kernel_times()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize(dev)
+            kt = ctx.kernel_times()
+            ctx.set_profiling(False)
+            total_ms = sum(v[0] for v in kt.values())
+            name, (dom_ms, dom_launches) = max(kt.items(), key=lambda kv: kv[1][0])
+            # algorithmic bytes of one step: forward
+            # (8 + 12 C) B/pt + inverse (8 + 8 C) B/pt; the level kernels
+            # are where attributes and coefficients are consumed/produced,
+            # so one step's launches of the dominant kernel are priced as
+            # one pass over those bytes
+            alg_bytes = n * ((8 + 12 * c) + (8 + 8 * c))
+            dom_s = dom_ms / 1e3 / args.steps
+            achieved = alg_bytes / dom_s / 1e9
+            out["roofline"] = {
+                "bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                "launches_per_step": dom_launches / args.steps,
+                "avg_launch_us": round(dom_ms * 1e3 / dom_launches, 2),
+                "pipeline_achieved": round(alg_bytes / (ms_per_step / 1e3) / 1e9, 2),
+                "pipeline_frac": round(alg_bytes / (ms_per_step / 1e3) / 1e9 / HBM_PEAK_GBPS, 5),
+                "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(kt.items(), key=lambda kv: -kv[1][0])},
+                "kernel_sum_ms_per_step": round(total_ms / args.steps, 4),
+            }
+        # ---- CPU baseline: the compiled reference on one host core --------
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(frames[0], p, c)
+
+    if rank == 0:
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(frame, p, c):
+    """oracle/_ref (the reference's own RAHT.cpp, -O3) forward+inverse on the
+    same frame, one core; falls back to the C oracle port if the compiled
+    reference did not travel."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_loader as ol
+    morton, attrs, _ = frame
+    kind = "reference" if ol.ref_available() else "port"
+    chk = ol.ref() if kind == "reference" else ol.oracle()
+    n = len(morton)
+    # bounded sample: at most ~400k points of the frame (a prefix in Morton
+    # order is a spatially compact sub-cloud), about 1-3 s of CPU work
+    m = min(n, 400_000)
+    t0 = time.perf_counter()
+    co, rec = chk.raht_forward(p, morton[:m], attrs[:m])
+    chk.raht_inverse(p, morton[:m], co, c)
+    dt = time.perf_counter() - t0
+    return {"value": round(m / dt / 1e6, 4), "unit": "Mpoints/s", "cores": 1, "kind": kind,
+            "sample": f"forward+inverse of the first {m} points (Morton order) of frame 0, same flags, "
+                      f"{dt:.2f} s wall, host {os.cpu_count()} logical cores, 1 used"}
+
+
+if __name__ == "__main__":
+    main()

@@ -40,6 +40,14 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -m __graft_entry__` "
             "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64
+    # (SONAME libamdhip64.so.7, same as /opt/rocm's).  Importing torch first
+    # makes our NEEDED entry bind to the copy torch already mapped; the
+    # other order maps two runtimes and torch then sees "No HIP GPUs".
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     vp, i32, i64p = C.c_void_p, C.c_int32, C.POINTER(C.c_int64)
     pp = C.POINTER(RahtParams)

@@ -561,9 +561,12 @@ host_transform(
       HIP_TRY(hipMalloc((void**)&d_q, sizeof(int32_t) * n * 2));
       HIP_TRY(hipMemcpyAsync(d_q, qp_off, sizeof(int32_t) * n * 2, hipMemcpyHostToDevice, st));
     }
-    if (encoder)
+    if (encoder) {
       HIP_TRY(hipMemcpyAsync(d_a, attrs, sizeof(int32_t) * n * c, hipMemcpyHostToDevice, st));
-    else
+      // the reference's callers hand in a zero-initialised coefficient
+      // vector; the one slot an all-duplicates slice leaves unwritten stays 0
+      HIP_TRY(hipMemsetAsync(d_c, 0, sizeof(int32_t) * n * c, st));
+    } else
       HIP_TRY(hipMemcpyAsync(d_c, coeffs, sizeof(int32_t) * n * c, hipMemcpyHostToDevice, st));
     const int64_t offs[2] = {0, n};
     int r = dev_transform(

@@ -252,7 +252,8 @@ finish_kernel(FinishCtx cx)
     }
     // coefficients of this node follow all level coefficients and the
     // tails of the earlier duplicated leaves
-    int cidx = sc->num_unique + (f0 - pt0) - jl;
+    // (a slice with one unique position codes no level coefficient at all)
+    int cidx = (any_level ? sc->num_unique : 0) + (f0 - pt0) - jl;
     for (int wv = weight - 1; wv > 0; wv--, cidx++) {
       int64_t a = 0, b = 0;
       if (!haar)
