@@ -27,6 +27,7 @@ def build(force=False, verbose=False):
         return LIB
     cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-Wno-unused-value", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+           *os.environ.get("GPCC_EXTRA_FLAGS", "").split(),
            os.path.join(CSRC, "gpcc_attr_mi355.hip"), "-o", LIB]
     if verbose:
         print(" ".join(cmd))

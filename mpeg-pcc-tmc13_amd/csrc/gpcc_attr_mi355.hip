@@ -56,6 +56,8 @@ fail(int code, const std::string& msg)
   } while (0)
 
 constexpr int kGridMax = 2048;  // 256 CUs x 8 workgroups of 256 threads
+constexpr int kLevelGridMax = 1 << 16;
+constexpr int kRoundsPerGroup = 4;  // level kernels: rounds of 32 blocks per workgroup
 
 int
 grid_for(int64_t items, int per_block)
@@ -89,6 +91,7 @@ struct gpcc_ctx {
   bool own_stream = false;
   Arena arena;
   int morton_bits = 0;  // hint for the device tier, 0 = unknown
+  SharedLut* d_lut = nullptr;  // small-weight tables, built once
   // host staging for the host tier
   void* h_pinned = nullptr;
   size_t h_pinned_cap = 0;
@@ -162,6 +165,8 @@ struct Plan {
   int2* rtile_sum = nullptr;
   int32_t* rtile_lin = nullptr;
   int32_t* slice_l = nullptr;
+  int32_t* worklist = nullptr;
+  int32_t* work_count = nullptr;
   int num_rtiles = 0;
   std::vector<int32_t*> haar_lf, asc_qp;
 };
@@ -197,6 +202,8 @@ carve(Arena& ar, Plan& pl)
   pl.tile_cnt = ar.take<uint32_t>((size_t)pl.tv.num_tiles * nlev);
   pl.tile_attr = ar.take<int32_t>((size_t)pl.tv.num_tiles * c);
   pl.sched = ar.take<SliceSched>(s);
+  pl.worklist = ar.take<int32_t>((size_t)n + 1);
+  pl.work_count = ar.take<int32_t>(kMaxLevels);
   pl.params = ar.take<gpcc_raht_params>(1);
   for (int i = 0; i < 2; i++) {
     pl.rec[i] = ar.take<int64_t>((size_t)n * c);
@@ -384,6 +391,10 @@ launch_transform(
   }
   lc.coeffs = d_coeffs;
   lc.desc = pl.desc;
+  lc.lut = ctx->d_lut;
+  lc.worklist = pl.worklist;
+  lc.work_count = pl.work_count;
+  HIP_TRY(hipMemsetAsync(pl.work_count, 0, kMaxLevels * sizeof(int32_t), st));
 
   RdoqCtx rc{};
   if (pl.lossy) {
@@ -402,7 +413,16 @@ launch_transform(
 
   for (int li = nlev - 2; li >= 0; li--) {
     lc.li = li;
-    const int grid = grid_for(pl.cap[li + 1], 32);
+    // many small workgroups: the cost of a round varies by an order of
+    // magnitude (single-child copies vs predicted blocks), the hardware
+    // dispatcher evens it out
+    const int grid = (int)std::min<int64_t>(
+      kLevelGridMax,
+      ((pl.cap[li + 1] + 32 * kRoundsPerGroup - 1) / (32 * kRoundsPerGroup) + 7) / 8 * 8);
+    {
+      Timer t(ctx, "level_prepass");
+      raht_level_prepass_kernel<C><<<std::min(grid_for(pl.cap[li + 1], 1024), 1024), 256, 0, st>>>(lc);
+    }
     if (!encoder) {
       Timer t(ctx, "level_synth");
       raht_level_kernel<C, kSynth><<<grid, 256, 0, st>>>(lc);
@@ -455,6 +475,7 @@ launch_transform(
   fc.attrs = d_attrs;
   fc.coeffs = d_coeffs;
   fc.encoder = encoder;
+  fc.lut = ctx->d_lut;
   {
     Timer t(ctx, "finish");
     finish_kernel<C><<<grid_for(pl.cap[0], 256), 256, 0, st>>>(fc);
@@ -653,6 +674,11 @@ gpcc_ctx_create(int device, void* stream, gpcc_ctx** out)
     }
     ctx->own_stream = true;
   }
+  if (hipMalloc((void**)&ctx->d_lut, sizeof(SharedLut)) != hipSuccess) {
+    gpcc_ctx_destroy(ctx);
+    return fail(GPCC_ERR_OUT_OF_MEMORY, "hipMalloc(lut)");
+  }
+  lut_init_kernel<<<1, 256, 0, ctx->stream>>>(ctx->d_lut);
   *out = ctx;
   return GPCC_OK;
 }
@@ -672,6 +698,8 @@ gpcc_ctx_destroy(gpcc_ctx* ctx)
     hipEventDestroy(e);
   if (ctx->arena.base)
     hipFree(ctx->arena.base);
+  if (ctx->d_lut)
+    hipFree(ctx->d_lut);
   if (ctx->h_pinned)
     hipHostFree(ctx->h_pinned);
   if (ctx->own_stream)

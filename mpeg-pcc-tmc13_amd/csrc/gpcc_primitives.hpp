@@ -26,19 +26,30 @@ GPCC_HD int64_t fp_from_int(int64_t v)
   return v < 0 ? -(int64_t)m : (int64_t)m;
 }
 
-// FixedPoint::round(): sign-symmetric round to nearest, >> 15
-GPCC_HD int64_t fp_round(int64_t v)
+// Sign-symmetric "round half away from zero, then >> s" without the
+// abs/negate pair: for p < 0,  -((h - p) >> s) == (p + h - 1) >> s  with an
+// arithmetic shift (h = 2^(s-1)), so one conditional -1 replaces four
+// 64-bit operations.
+GPCC_HD int64_t round_shift_sym(int64_t p, int s)
 {
-  int64_t m = (kFpHalf + (v < 0 ? -v : v)) >> kFpFrac;
-  return v < 0 ? -m : m;
+  return (p + ((int64_t)1 << (s - 1)) + (p >> 63)) >> s;
 }
+
+// FixedPoint::round(): sign-symmetric round to nearest, >> 15
+GPCC_HD int64_t fp_round(int64_t v) { return round_shift_sym(v, kFpFrac); }
 
 // FixedPoint::operator*=: 64-bit product, sign-symmetric rounding >> 15
 GPCC_HD int64_t fp_mul(int64_t a, int64_t b)
 {
-  int64_t p = (int64_t)((uint64_t)a * (uint64_t)b);
-  int64_t m = (kFpHalf + (p < 0 ? -p : p)) >> kFpFrac;
-  return p < 0 ? -m : m;
+  return round_shift_sym((int64_t)((uint64_t)a * (uint64_t)b), kFpFrac);
+}
+
+// The same with a coefficient known to fit 32 bits (butterfly a/b, 1/sqrt(w),
+// sqrt(w) < 2^26, prediction divisor): a 64x32 multiply is two
+// v_mad_u64_u32 instead of the 64x64 sequence.
+GPCC_HD int64_t fp_mul32(int64_t a, int32_t b)
+{
+  return round_shift_sym(a * (int64_t)b, kFpFrac);
 }
 
 // ---- bit helpers --------------------------------------------------------
@@ -198,9 +209,11 @@ GPCC_HD Quantizer make_quantizer(int qp)
 
 GPCC_HD int64_t quantize(Quantizer q, int64_t x)
 {
+  // x >= 0: (x r + off) >> 26;  x < 0: -((off - x r) >> 26)
+  //                                  == (x r + 2^26 - 1 - off) >> 26
   constexpr int64_t off = ((int64_t)1 << 26) / 3;
-  int64_t m = ((x < 0 ? -x : x) * q.recip + off) >> 26;
-  return x < 0 ? -m : m;
+  constexpr int64_t noff = ((int64_t)1 << 26) - 1 - off;
+  return (x * (int64_t)q.recip + (x < 0 ? noff : off)) >> 26;
 }
 
 GPCC_HD int64_t dequantize(Quantizer q, int64_t c)

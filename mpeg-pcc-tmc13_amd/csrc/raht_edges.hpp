@@ -160,6 +160,7 @@ struct FinishCtx {
   int32_t* attrs;   // in: source (encoder), out: reconstruction
   int32_t* coeffs;
   int32_t encoder;
+  const SharedLut* lut;
 };
 
 template<int C>
@@ -167,8 +168,8 @@ __global__ __launch_bounds__(256) void
 finish_kernel(FinishCtx cx)
 {
   __shared__ SharedLut lut_s;
-  load_lut(&lut_s);
-  const RsqrtLut& lut = lut_s.rsqrt;
+  load_lut(&lut_s, cx.lut);
+  const SharedLut& lut = lut_s;
   const TreeView& tv = cx.tv;
   const gpcc_raht_params* __restrict__ prm = cx.params;
   const bool haar = prm->integer_haar_enable_flag != 0;
@@ -234,7 +235,7 @@ finish_kernel(FinishCtx cx)
     }
     Quantizer q[2];
     qpset_quantizers(prm, sc->final_qp_layer, nq0, nq1, q);
-    const int64_t sq = (int64_t)isqrt((uint64_t)weight << (2 * kFpFrac), lut);
+    const int64_t sq = sqrt_weight(weight, lut);
     int64_t attr_sum[C], rec_dc[C];
 #pragma unroll
     for (int k = 0; k < C; k++) {

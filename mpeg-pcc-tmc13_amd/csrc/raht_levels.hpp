@@ -43,41 +43,107 @@ struct LevelCtx {
   int32_t* coeffs;                 // planar per slice
   uint32_t* desc;                  // RDOQ descriptors, one per coefficient
   int32_t li;                      // children level of this launch
+  const struct SharedLut* lut;     // tables built by lut_init_kernel
+  int32_t* worklist;               // [cap] parents with >= 2 children (or non-ext)
+  int32_t* work_count;             // [nlev] entries of the worklist per level
 };
+
+// Small-weight tables.  Near the leaves almost every node weight is a
+// small integer, so the butterfly coefficients (a, b) of a (wl, wr) pair
+// and the 1/sqrt(w), sqrt(w) normalisers are looked up in LDS instead of
+// running the fixed-point Newton iteration three times per butterfly; the
+// tables are filled by the same functions, so the values are identical.
+constexpr int kSmallW = 16;   // butterfly pairs with wl, wr < 16
+constexpr int kSmallN = 64;   // normalisers with w < 64
 
 struct SharedLut {
   RsqrtLut rsqrt;
+  int32_t bfly_a[kSmallW * kSmallW];
+  int32_t bfly_b[kSmallW * kSmallW];
+  int32_t norm_rs[kSmallN];   // irsqrt(w) >> 25
+  int32_t norm_sq[kSmallN];   // isqrt(w << 30)
 };
-
-__device__ __forceinline__ void
-load_lut(SharedLut* s)
-{
-  constexpr uint16_t r3[96] = {GPCC_RSQRT_R3};
-  constexpr uint32_t rc[96] = {GPCC_RSQRT_RC};
-  for (int i = threadIdx.x; i < 96; i += blockDim.x) {
-    s->rsqrt.r3[i] = r3[i];
-    s->rsqrt.rc[i] = rc[i];
-  }
-  __syncthreads();
-}
 
 // RahtKernel ctor (tmc3/RAHT.cpp:596-604)
 __device__ __forceinline__ void
-raht_coeffs(int32_t wl, int32_t wr, const RsqrtLut& lut, int64_t* a, int64_t* b)
+raht_coeffs_slow(int32_t wl, int32_t wr, const RsqrtLut& lut, int64_t* a, int64_t* b)
 {
   const uint64_t rs = irsqrt((uint64_t)wl + (uint64_t)wr, lut);
   *a = (int64_t)(((uint64_t)isqrt((uint64_t)wl << 30, lut) * rs) >> 40);
   *b = (int64_t)(((uint64_t)isqrt((uint64_t)wr << 30, lut) * rs) >> 40);
 }
 
+// Fill the tables once per context (lut_init_kernel) ...
+__global__ __launch_bounds__(256) void
+lut_init_kernel(SharedLut* g)
+{
+  __shared__ RsqrtLut rs;
+  constexpr uint16_t r3[96] = {GPCC_RSQRT_R3};
+  constexpr uint32_t rc[96] = {GPCC_RSQRT_RC};
+  for (int i = threadIdx.x; i < 96; i += blockDim.x) {
+    rs.r3[i] = r3[i];
+    rs.rc[i] = rc[i];
+    g->rsqrt.r3[i] = r3[i];
+    g->rsqrt.rc[i] = rc[i];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kSmallW * kSmallW; i += blockDim.x) {
+    const int wl = i / kSmallW, wr = i % kSmallW;
+    int64_t a = 0, b = 0;
+    if (wl && wr)
+      raht_coeffs_slow(wl, wr, rs, &a, &b);
+    g->bfly_a[i] = (int32_t)a;
+    g->bfly_b[i] = (int32_t)b;
+  }
+  for (int i = threadIdx.x; i < kSmallN; i += blockDim.x) {
+    g->norm_rs[i] = i ? (int32_t)(irsqrt((uint64_t)i, rs) >> (40 - kFpFrac)) : 0;
+    g->norm_sq[i] = i ? (int32_t)isqrt((uint64_t)i << (2 * kFpFrac), rs) : 0;
+  }
+}
+
+// ... and stage them into LDS at the start of every workgroup (3.4 KB,
+// L2 resident).
+__device__ __forceinline__ void
+load_lut(SharedLut* s, const SharedLut* __restrict__ g)
+{
+  static_assert(sizeof(SharedLut) % 4 == 0, "word copy");
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(g);
+  uint32_t* dst = reinterpret_cast<uint32_t*>(s);
+  for (int i = threadIdx.x; i < (int)(sizeof(SharedLut) / 4); i += blockDim.x)
+    dst[i] = src[i];
+  __syncthreads();
+}
+
+__device__ __forceinline__ void
+raht_coeffs(int32_t wl, int32_t wr, const SharedLut& L, int64_t* a, int64_t* b)
+{
+  if (wl < kSmallW && wr < kSmallW) {
+    *a = L.bfly_a[wl * kSmallW + wr];
+    *b = L.bfly_b[wl * kSmallW + wr];
+    return;
+  }
+  raht_coeffs_slow(wl, wr, L.rsqrt, a, b);
+}
+
 // value / sqrt(weight) (tmc3/RAHT.cpp:1474-1481, 1780-1787)
 __device__ __forceinline__ int64_t
-scale_rsqrt(int64_t v, int32_t weight, const RsqrtLut& lut)
+scale_rsqrt(int64_t v, int32_t weight, const SharedLut& L)
 {
+  if (weight < kSmallN)
+    return fp_mul(v, L.norm_rs[weight]);
   const uint64_t w = (uint64_t)weight;
   const int shift = w > 1024 ? ilog2_u64(w - 1) >> 1 : 0;
-  const int64_t rs = (int64_t)(irsqrt(w, lut) >> (40 - shift - kFpFrac));
+  const int64_t rs = (int64_t)(irsqrt(w, L.rsqrt) >> (40 - shift - kFpFrac));
   return fp_mul(v >> shift, rs);
+}
+
+// sqrt(weight) in Q15 (tmc3/RAHT.cpp:1487-1488)
+__device__ __forceinline__ int64_t
+sqrt_weight(int32_t weight, const SharedLut& L)
+{
+  if (weight < kSmallN)
+    return L.norm_sq[weight];
+  return (int64_t)isqrt((uint64_t)weight << (2 * kFpFrac), L.rsqrt);
 }
 
 // QpSet::quantizers (tmc3/quantization.cpp:165-174)
@@ -93,6 +159,9 @@ qpset_quantizers(
 
 // findNeighbour (tmc3/RAHT.cpp:272-293): lower_bound inside a window of
 // |d| entries before / after `from`, clamped to the slice's node range.
+// (A per-level hash table was measured instead of this search: the level
+// kernels are VALU-bound, not latency-bound, so the look-ups bought nothing
+// while the 3.3 M atomic inserts cost 1 ms -- see DESIGN.md.)
 __device__ __forceinline__ int
 find_in_window(
   const int64_t* __restrict__ key, int first, int last, int from,
@@ -161,13 +230,111 @@ rdoq_threshold(int64_t dist2, int64_t lambda, int rate_coeff, uint32_t limit)
   return kDescNever;
 }
 
-template<int C, int MODE>
+// Pre-pass of a level, ONE THREAD PER PARENT (64 blocks in flight per
+// wavefront instead of 8): single-child blocks are finished here -- no
+// prediction, no coefficient, the three butterfly stages only move the
+// inherited DC to the child's position and the child has its parent's
+// weight, so its reconstruction IS the parent's (tmc3/RAHT.cpp:1382-1401
+// with the extension).  Sparse (lidar) clouds are mostly such chains.
+// Every other processed block is appended to the level's worklist, which
+// the 8-lanes-per-block kernels then walk densely.
+template<int C>
 __global__ __launch_bounds__(256) void
+raht_level_prepass_kernel(LevelCtx ctx)
+{
+  __shared__ int wave_cnt[4];
+  __shared__ int base_s;
+  const TreeView& tv = ctx.tv;
+  const int li = ctx.li;
+  const bool ext = ctx.params->raht_extension != 0;
+  const int num_parents = tv.soff[li + 1][tv.num_slices];
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  int64_t gbeg, gend;
+  xcd_chunk(((int64_t)num_parents + 255) >> 8, &gbeg, &gend);
+
+  // pass 1: how many blocks does this workgroup append?  (one atomic per
+  // workgroup: same-address atomics retire at ~11 ns each)
+  int mine = 0;
+  for (int64_t chunk = gbeg; chunk < gend; chunk++) {
+    const int j = (int)(chunk * 256) + threadIdx.x;
+    if (j < num_parents) {
+      const int s = find_slice(tv.soff[li + 1], tv.num_slices, j);
+      if (ctx.sched[s].lvl[li].processed) {
+        const int nchild = tv.fc[li + 1][j + 1] - tv.fc[li + 1][j];
+        mine += !(ext && nchild == 1);
+      }
+    }
+  }
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1)
+    mine += __shfl_xor(mine, d);
+  if (lane == 0)
+    wave_cnt[wave] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int total = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    base_s = total ? atomicAdd(&ctx.work_count[li], total) : 0;
+  }
+  __syncthreads();
+  int running = base_s;
+
+  // pass 2: finish the single-child blocks, append the others in order
+  for (int64_t chunk = gbeg; chunk < gend; chunk++) {
+    const int j = (int)(chunk * 256) + threadIdx.x;
+    bool real = false;
+    if (j < num_parents) {
+      const int s = find_slice(tv.soff[li + 1], tv.num_slices, j);
+      const LevelSched e = ctx.sched[s].lvl[li];
+      if (e.processed) {
+        const int c0 = tv.fc[li + 1][j];
+        const int nchild = tv.fc[li + 1][j + 1] - c0;
+        if (ext && nchild == 1) {
+          const int pt0 = tv.pt_off[s];
+          const int64_t prow = (int64_t)pt0 + (j - tv.soff[li + 1][s]);
+          const int64_t crow = (int64_t)pt0 + (c0 - tv.soff[li][s]);
+          const int pp = e.parity ^ 1, cp = e.parity;
+#pragma unroll
+          for (int k = 0; k < C; k++) {
+            ctx.rec_us[cp][crow * C + k] = ctx.rec_us[pp][prow * C + k];
+            ctx.rec[cp][crow * C + k] = ctx.rec[pp][prow * C + k];
+          }
+          ctx.nneigh[cp][crow] = 19;
+          if (ctx.asc_qp) {
+            ctx.dqp[cp][crow * 2] = ctx.dqp[pp][prow * 2];
+            ctx.dqp[cp][crow * 2 + 1] = ctx.dqp[pp][prow * 2 + 1];
+          }
+        } else {
+          real = true;
+        }
+      }
+    }
+    const unsigned long long m = __ballot(real);
+    __syncthreads();  // previous iteration's readers are done
+    if (lane == 0)
+      wave_cnt[wave] = __popcll(m);
+    __syncthreads();
+    int off = running;
+    for (int w = 0; w < wave; w++)
+      off += wave_cnt[w];
+    if (real)
+      ctx.worklist[off + __popcll(m & ((1ull << lane) - 1))] = j;
+    running += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+  }
+}
+
+// The block kernels are bound by dependent-load latency (rocprofv3: VALU
+// active 12 % of wave cycles), so residency is bought with registers:
+// GPCC_LEVEL_WAVES waves per SIMD (see DESIGN.md for the measured sweep).
+#ifndef GPCC_LEVEL_WAVES
+#define GPCC_LEVEL_WAVES 4
+#endif
+template<int C, int MODE>
+__global__ __launch_bounds__(256, GPCC_LEVEL_WAVES) void
 raht_level_kernel(LevelCtx ctx)
 {
   __shared__ SharedLut lut_s;
-  load_lut(&lut_s);
-  const RsqrtLut& lut = lut_s.rsqrt;
+  load_lut(&lut_s, ctx.lut);
+  const SharedLut& lut = lut_s;
 
   constexpr bool kEnc = MODE != kSynth;
   constexpr bool kRecon = MODE != kAnalyze;
@@ -178,17 +345,18 @@ raht_level_kernel(LevelCtx ctx)
   const bool haar = prm->integer_haar_enable_flag != 0;
   const bool ext = prm->raht_extension != 0;
 
-  const int num_parents = tv.soff[li + 1][tv.num_slices];
+  const int num_work = ctx.work_count[li];
   int64_t gbeg, gend;
   {
     // blocks are dealt out in XCD-contiguous chunks of 32 (one workgroup
     // iteration), see xcd_chunk()
-    const int64_t rounds = ((int64_t)num_parents + 31) >> 5;
+    const int64_t rounds = ((int64_t)num_work + 31) >> 5;
     xcd_chunk(rounds, &gbeg, &gend);
   }
   for (int64_t round = gbeg; round < gend; round++) {
-    const int j = (int)(round * 32) + (threadIdx.x >> 3);
-    const bool live = j < num_parents;
+    const int wi = (int)(round * 32) + (threadIdx.x >> 3);
+    const bool live = wi < num_work;
+    const int j = live ? ctx.worklist[wi] : 0;
     // ---- locate the block -------------------------------------------
     int s = 0;
     LevelSched e;
@@ -338,22 +506,58 @@ raht_level_kernel(LevelCtx ctx)
     }
     // (group-uniform; other groups of the wave idle through the shuffles)
     int pn[3] = {-1, -1, -1};  // neighbour i = 1 + t + 8*slot
-    if (do_search) {
-      const int64_t cur_pos = tv.key[li + 1][j];
-      const uint64_t base = morton3d_add((uint64_t)cur_pos, ~0ull);
-      const int64_t range = prm->raht_prediction_search_range;
+    {
+      // the three lower_bound searches of a lane advance in lock step, so
+      // their probes are in flight together (12 dependent steps, not 36)
+      int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}, end[3] = {0, 0, 0};
+      int64_t want[3] = {0, 0, 0};
+      if (do_search) {
+        const int64_t cur_pos = tv.key[li + 1][j];
+        const uint64_t base = morton3d_add((uint64_t)cur_pos, ~0ull);
+        const int64_t range = prm->raht_prediction_search_range;
+#pragma unroll
+        for (int slot = 0; slot < 3; slot++) {
+          const int i = 1 + t + 8 * slot;
+          if (i < 19 && (occ & neigh_mask(i))) {
+            const int64_t np = (int64_t)morton3d_add(base, neigh_offset(i));
+            int64_t d = np - cur_pos;
+            if (d >= 0) {
+              d = d >= range ? range : d;
+              lo[slot] = j;
+              end[slot] = (d + 1 < (int64_t)(sp1 - j)) ? j + (int)(d + 1) : sp1;
+            } else {
+              d = (-d) >= range ? range : -d;
+              end[slot] = j;
+              lo[slot] = (d < (int64_t)(j - sp0)) ? j - (int)d : sp0;
+            }
+            hi[slot] = end[slot];
+            want[slot] = np;
+          }
+        }
+      }
+      const int64_t* __restrict__ pkey = tv.key[li + 1];
+      while (__any((lo[0] < hi[0]) | (lo[1] < hi[1]) | (lo[2] < hi[2]))) {
+        int mid[3];
+        int64_t kv[3];
+#pragma unroll
+        for (int slot = 0; slot < 3; slot++) {
+          mid[slot] = lo[slot] + ((hi[slot] - lo[slot]) >> 1);
+          kv[slot] = lo[slot] < hi[slot] ? pkey[mid[slot]] : 0;
+        }
+#pragma unroll
+        for (int slot = 0; slot < 3; slot++) {
+          if (lo[slot] < hi[slot]) {
+            if (kv[slot] < want[slot])
+              lo[slot] = mid[slot] + 1;
+            else
+              hi[slot] = mid[slot];
+          }
+        }
+      }
 #pragma unroll
       for (int slot = 0; slot < 3; slot++) {
-        const int i = 1 + t + 8 * slot;
-        if (i < 19 && (occ & neigh_mask(i))) {
-          const int64_t np = (int64_t)morton3d_add(base, neigh_offset(i));
-          int64_t d = np - cur_pos;
-          if (d >= 0)
-            d = d >= range ? range : d;
-          else
-            d = (-d) >= range ? -range : d;
-          pn[slot] = find_in_window(tv.key[li + 1], sp0, sp1, j, np, d);
-        }
+        if (lo[slot] < end[slot] && pkey[lo[slot]] == want[slot])
+          pn[slot] = lo[slot];
       }
     }
     {
@@ -369,6 +573,7 @@ raht_level_kernel(LevelCtx ctx)
     {
       const bool run = do_search && enable_pred;
       int wsum = 0;
+      if (__any(run)) {
       int64_t lim_lo = 0, lim_hi = 0;
       const int64_t* __restrict__ prec = ctx.rec[par_par];
       const int64_t rbase = (int64_t)pt0 - sp0;
@@ -401,6 +606,7 @@ raht_level_kernel(LevelCtx ctx)
             pred[k] += v[k] * mul;
         }
       }
+      }
       if (run && has) {
         const int64_t div = pred_divisor(wsum);
 #pragma unroll
@@ -420,7 +626,7 @@ raht_level_kernel(LevelCtx ctx)
           src[k] = scale_rsqrt(src[k], w, lut);
       }
       if (enable_pred) {
-        const int64_t sq = (int64_t)isqrt((uint64_t)w << (2 * kFpFrac), lut);
+        const int64_t sq = sqrt_weight(w, lut);
 #pragma unroll
         for (int k = 0; k < C; k++)
           pred[k] = fp_mul(pred[k], sq);
