@@ -823,7 +823,112 @@ gpcc_dev_attr_morton_sort(
 {
   if (!ctx)
     return fail(GPCC_ERR_INVALID_ARG, "ctx is null");
-  return fail(GPCC_ERR_UNSUPPORTED, "device Morton sort not built yet");
+  if (num_slices < 1 || !offsets || offsets[0] != 0 || !d_xyz || !d_morton || !d_order)
+    return fail(GPCC_ERR_INVALID_ARG, "bad arguments");
+  for (int i = 0; i < num_slices; i++)
+    if (offsets[i + 1] <= offsets[i])
+      return fail(GPCC_ERR_INVALID_ARG, "empty or unordered slice");
+  if (offsets[num_slices] >= (int64_t)1 << 30)
+    return fail(GPCC_ERR_INVALID_ARG, "more than 2^30 points per batch");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const int n = (int)offsets[num_slices];
+  const int bits = ctx->morton_bits > 0 ? ctx->morton_bits : 63;
+  const int passes = std::max(1, (bits + 7) / 8);
+
+  // tiles never straddle a slice
+  std::vector<int32_t> h_off(num_slices + 1), t_first, t_count, t_slice;
+  for (int s = 0; s <= num_slices; s++)
+    h_off[s] = (int32_t)offsets[s];
+  for (int s = 0; s < num_slices; s++)
+    for (int b = h_off[s]; b < h_off[s + 1]; b += kSortTile) {
+      t_first.push_back(b);
+      t_count.push_back(std::min(kSortTile, h_off[s + 1] - b));
+      t_slice.push_back(s);
+    }
+  const int nt = (int)t_first.size();
+
+  Arena measure;
+  auto carve_sort = [&](Arena& ar, SortCtx& cx, int64_t*& kbuf, int32_t*& vbuf,
+                        int32_t*& pt_off) {
+    ar.reset();
+    pt_off = ar.take<int32_t>(num_slices + 1);
+    cx.tile_first = ar.take<int32_t>(nt);
+    cx.tile_count = ar.take<int32_t>(nt);
+    cx.tile_slice = ar.take<int32_t>(nt);
+    cx.hist = ar.take<uint32_t>((size_t)256 * nt);
+    kbuf = ar.take<int64_t>(n);
+    vbuf = ar.take<int32_t>(n);
+  };
+  SortCtx cx{};
+  int64_t* kbuf = nullptr;
+  int32_t* vbuf = nullptr;
+  int32_t* d_pt = nullptr;
+  carve_sort(measure, cx, kbuf, vbuf, d_pt);
+  int rcode = ensure_arena(ctx, measure.used);
+  if (rcode)
+    return rcode;
+  carve_sort(ctx->arena, cx, kbuf, vbuf, d_pt);
+
+  const size_t stage_bytes = (num_slices + 1 + 3 * (size_t)nt) * sizeof(int32_t) + 64;
+  HIP_TRY(hipStreamSynchronize(st));
+  if (ctx->h_pinned_cap < stage_bytes) {
+    if (ctx->h_pinned)
+      HIP_TRY(hipHostFree(ctx->h_pinned));
+    HIP_TRY(hipHostMalloc(&ctx->h_pinned, stage_bytes * 2));
+    ctx->h_pinned_cap = stage_bytes * 2;
+  }
+  char* hb = (char*)ctx->h_pinned;
+  size_t o = 0;
+  auto stage = [&](const void* src, size_t bytes, const void* dst) -> hipError_t {
+    memcpy(hb + o, src, bytes);
+    hipError_t e = hipMemcpyAsync(
+      const_cast<void*>(dst), hb + o, bytes, hipMemcpyHostToDevice, st);
+    o += (bytes + 15) & ~size_t(15);
+    return e;
+  };
+  HIP_TRY(stage(h_off.data(), h_off.size() * 4, d_pt));
+  HIP_TRY(stage(t_first.data(), nt * 4, cx.tile_first));
+  HIP_TRY(stage(t_count.data(), nt * 4, cx.tile_count));
+  HIP_TRY(stage(t_slice.data(), nt * 4, cx.tile_slice));
+
+  cx.n = n;
+  cx.num_tiles = nt;
+  cx.num_slices = num_slices;
+  cx.pt_off = d_pt;
+  // ping-pong so that the last pass writes the caller's buffers
+  int64_t* ka = passes % 2 ? kbuf : (int64_t*)d_morton;
+  int32_t* va = passes % 2 ? vbuf : (int32_t*)d_order;
+  int64_t* kb = passes % 2 ? (int64_t*)d_morton : kbuf;
+  int32_t* vb = passes % 2 ? (int32_t*)d_order : vbuf;
+  {
+    Timer t(ctx, "morton_encode");
+    morton_encode_kernel<<<grid_for(n, 256), 256, 0, st>>>(
+      (const int32_t*)d_xyz, d_pt, num_slices, n, ka, va);
+  }
+  for (int p = 0; p < passes; p++) {
+    cx.key_in = ka;
+    cx.val_in = va;
+    cx.key_out = kb;
+    cx.val_out = vb;
+    cx.shift = 8 * p;
+    {
+      Timer t(ctx, "sort_hist");
+      sort_hist_kernel<<<std::min(nt, kGridMax), kSortThreads, 0, st>>>(cx);
+    }
+    {
+      Timer t(ctx, "sort_scan");
+      sort_scan_kernel<<<1, 1024, 0, st>>>(cx);
+    }
+    {
+      Timer t(ctx, "sort_scatter");
+      sort_scatter_kernel<<<std::min(nt, kGridMax), kSortThreads, 0, st>>>(cx);
+    }
+    std::swap(ka, kb);
+    std::swap(va, vb);
+  }
+  HIP_TRY(hipGetLastError());
+  return GPCC_OK;
 }
 
 int
@@ -832,7 +937,44 @@ gpcc_attr_morton_sort(
 {
   if (!ctx)
     return fail(GPCC_ERR_INVALID_ARG, "ctx is null");
-  return fail(GPCC_ERR_UNSUPPORTED, "device Morton sort not built yet");
+  if (!xyz || !morton || !order || n <= 0)
+    return fail(GPCC_ERR_INVALID_ARG, "null buffer or n <= 0");
+  int32_t mx = 0;
+  for (int64_t i = 0; i < (int64_t)n * 3; i++) {
+    if (xyz[i] < 0 || xyz[i] >= (1 << 21))
+      return fail(GPCC_ERR_INVALID_ARG, "coordinate outside [0, 2^21)");
+    mx = std::max(mx, xyz[i]);
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  int32_t* d_x = nullptr;
+  int64_t* d_m = nullptr;
+  int32_t* d_o = nullptr;
+  auto cleanup = [&]() {
+    hipFree(d_x);
+    hipFree(d_m);
+    hipFree(d_o);
+  };
+  auto run = [&]() -> int {
+    HIP_TRY(hipMalloc((void**)&d_x, sizeof(int32_t) * 3 * n));
+    HIP_TRY(hipMalloc((void**)&d_m, sizeof(int64_t) * n));
+    HIP_TRY(hipMalloc((void**)&d_o, sizeof(int32_t) * n));
+    HIP_TRY(hipMemcpyAsync(d_x, xyz, sizeof(int32_t) * 3 * n, hipMemcpyHostToDevice, st));
+    const int saved = ctx->morton_bits;
+    ctx->morton_bits = std::max(1, 3 * bitlen64((uint64_t)mx));
+    const int64_t offs[2] = {0, n};
+    int r = gpcc_dev_attr_morton_sort(ctx, 1, offs, d_x, d_m, d_o);
+    ctx->morton_bits = saved;
+    if (r)
+      return r;
+    HIP_TRY(hipMemcpyAsync(morton, d_m, sizeof(int64_t) * n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(order, d_o, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return GPCC_OK;
+  };
+  int r = run();
+  cleanup();
+  return r;
 }
 
 }  // extern "C"

@@ -1,0 +1,178 @@
+// RAHT_mi355.cpp -- drop-in replacement translation unit for the reference's
+// tmc3/RAHT.cpp link seam.
+//
+// It defines the two free functions every caller of the reference binds to
+//   pcc::regionAdaptiveHierarchicalTransform         (tmc3/RAHT.h:47-57)
+//   pcc::regionAdaptiveHierarchicalInverseTransform  (tmc3/RAHT.h:59-69)
+// (call sites: AttributeEncoder.cpp:1273,1341; AttributeDecoder.cpp:595,658)
+// with the reference's own signatures, flattens the reference's parameter
+// structs into the POD block of include/gpcc_attr_mi355.h and runs the slice
+// on the MI355X through the C ABI.  When the device path declines a slice
+// (GPCC_ERR_UNSUPPORTED: inter prediction, sub-node prediction this round)
+// or no GPU is present it calls the reference's CPU implementation, which
+// the integrator keeps in the link under a suffixed name (see
+// RAHT.cpp is compiled with
+//   -DregionAdaptiveHierarchicalTransform=regionAdaptiveHierarchicalTransformCpu
+//   -DregionAdaptiveHierarchicalInverseTransform=regionAdaptiveHierarchicalInverseTransformCpu).
+//
+// Built against the reference's headers; contains no reference code.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "FixedPoint.h"
+#include "PCCTMC3Common.h"
+#include "hls.h"
+#include "quantization.h"
+
+#include "gpcc_attr_mi355.h"
+
+namespace pcc {
+
+// the reference implementation, renamed at compile time (see above)
+void regionAdaptiveHierarchicalTransformCpu(
+  const RahtPredictionParams& rahtPredParams, const QpSet& qpset,
+  const Qps* pointQPOffset, int64_t* mortonCode, int* attributes,
+  const int attribCount, const int voxelCount, int* coefficients,
+  const bool removeRoundingOps, AttributeInterPredParams& attrInterPredParam);
+
+void regionAdaptiveHierarchicalInverseTransformCpu(
+  const RahtPredictionParams& rahtPredParams, const QpSet& qpset,
+  const Qps* pointQpOffset, int64_t* mortonCode, int* attributes,
+  const int attribCount, const int voxelCount, int* coefficients,
+  const bool removeRoundingOps, AttributeInterPredParams& attrInterPredParams);
+
+namespace {
+
+gpcc_ctx*
+device_context()
+{
+  // one context per process; the reference is single threaded
+  static gpcc_ctx* ctx = nullptr;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    const char* dev = std::getenv("GPCC_DEVICE");
+    if (gpcc_ctx_create(dev ? std::atoi(dev) : 0, nullptr, &ctx) != GPCC_OK) {
+      std::fprintf(
+        stderr, "gpcc: no MI355X context (%s); RAHT stays on the CPU\n",
+        gpcc_last_error());
+      ctx = nullptr;
+    }
+  }
+  return ctx;
+}
+
+// false: the block cannot express these parameters -> CPU path
+bool
+flatten(
+  const RahtPredictionParams& rp, const QpSet& qs, bool extension,
+  const AttributeInterPredParams& inter, gpcc_raht_params* p)
+{
+  if (inter.enableAttrInterPred)
+    return false;  // inter-frame RAHT is not on the device
+  if (rp.predWeightParent.size() != 19)
+    return false;
+  if (
+    rp.raht_subnode_prediction_enabled_flag && rp.predWeightChild.size() != 12)
+    return false;
+  if (qs.layers.empty() || qs.layers.size() > GPCC_MAX_QP_LAYERS)
+    return false;
+  if (qs.rahtAcCoeffQps.size() > GPCC_MAX_AC_QP_LAYERS)
+    return false;
+  *p = gpcc_raht_params{};
+  p->raht_prediction_enabled_flag = rp.raht_prediction_enabled_flag;
+  p->integer_haar_enable_flag = rp.integer_haar_enable_flag;
+  p->raht_prediction_threshold0 = rp.raht_prediction_threshold0;
+  p->raht_prediction_threshold1 = rp.raht_prediction_threshold1;
+  p->raht_subnode_prediction_enabled_flag =
+    rp.raht_subnode_prediction_enabled_flag;
+  p->raht_prediction_search_range = rp.raht_prediction_search_range;
+  for (int i = 0; i < 19; i++)
+    p->pred_weight_parent[i] = rp.predWeightParent[i];
+  for (size_t i = 0; i < 12 && i < rp.predWeightChild.size(); i++)
+    p->pred_weight_child[i] = rp.predWeightChild[i];
+  p->raht_extension = extension;
+  p->num_qp_layers = int(qs.layers.size());
+  for (size_t i = 0; i < qs.layers.size(); i++) {
+    p->layer_qp[i][0] = qs.layers[i][0];
+    p->layer_qp[i][1] = qs.layers[i][1];
+  }
+  p->max_qp = qs.maxQp;
+  p->fixed_point_qp_offset = qs.fixedPointQpOffset;
+  p->num_ac_qp_layers = int(qs.rahtAcCoeffQps.size());
+  for (size_t i = 0; i < qs.rahtAcCoeffQps.size(); i++) {
+    if (qs.rahtAcCoeffQps[i].size() != 7)
+      return false;
+    for (int j = 0; j < 7; j++) {
+      p->ac_qp_offset[i][j][0] = qs.rahtAcCoeffQps[i][j][0];
+      p->ac_qp_offset[i][j][1] = qs.rahtAcCoeffQps[i][j][1];
+    }
+  }
+  return true;
+}
+
+// region offsets are all zero in every CTC configuration: skip the upload
+const int32_t*
+qp_offsets_or_null(const Qps* q, int n)
+{
+  static_assert(sizeof(Qps) == 2 * sizeof(int32_t), "Qps is two ints");
+  for (int i = 0; i < n; i++)
+    if (q[i][0] | q[i][1])
+      return reinterpret_cast<const int32_t*>(q);
+  return nullptr;
+}
+
+}  // namespace
+
+void
+regionAdaptiveHierarchicalTransform(
+  const RahtPredictionParams& rahtPredParams, const QpSet& qpset,
+  const Qps* pointQpOffsets, int64_t* mortonCode, int* attributes,
+  const int attribCount, const int voxelCount, int* coefficients,
+  const bool rahtExtension, AttributeInterPredParams& attrInterPredParams)
+{
+  gpcc_raht_params p;
+  gpcc_ctx* ctx = device_context();
+  if (
+    ctx && voxelCount > 0
+    && flatten(rahtPredParams, qpset, rahtExtension, attrInterPredParams, &p)) {
+    int rc = gpcc_raht_forward(
+      ctx, &p, mortonCode, qp_offsets_or_null(pointQpOffsets, voxelCount),
+      attributes, coefficients, voxelCount, attribCount);
+    if (rc == GPCC_OK)
+      return;
+    if (rc != GPCC_ERR_UNSUPPORTED)
+      std::fprintf(stderr, "gpcc: %s; slice falls back to the CPU\n", gpcc_last_error());
+  }
+  regionAdaptiveHierarchicalTransformCpu(
+    rahtPredParams, qpset, pointQpOffsets, mortonCode, attributes,
+    attribCount, voxelCount, coefficients, rahtExtension, attrInterPredParams);
+}
+
+void
+regionAdaptiveHierarchicalInverseTransform(
+  const RahtPredictionParams& rahtPredParams, const QpSet& qpset,
+  const Qps* pointQpOffsets, int64_t* mortonCode, int* attributes,
+  const int attribCount, const int voxelCount, int* coefficients,
+  const bool rahtExtension, AttributeInterPredParams& attrInterPredParams)
+{
+  gpcc_raht_params p;
+  gpcc_ctx* ctx = device_context();
+  if (
+    ctx && voxelCount > 0
+    && flatten(rahtPredParams, qpset, rahtExtension, attrInterPredParams, &p)) {
+    int rc = gpcc_raht_inverse(
+      ctx, &p, mortonCode, qp_offsets_or_null(pointQpOffsets, voxelCount),
+      attributes, coefficients, voxelCount, attribCount);
+    if (rc == GPCC_OK)
+      return;
+    if (rc != GPCC_ERR_UNSUPPORTED)
+      std::fprintf(stderr, "gpcc: %s; slice falls back to the CPU\n", gpcc_last_error());
+  }
+  regionAdaptiveHierarchicalInverseTransformCpu(
+    rahtPredParams, qpset, pointQpOffsets, mortonCode, attributes,
+    attribCount, voxelCount, coefficients, rahtExtension, attrInterPredParams);
+}
+
+}  // namespace pcc
