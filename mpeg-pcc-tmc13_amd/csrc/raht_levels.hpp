@@ -333,6 +333,14 @@ __global__ __launch_bounds__(256, GPCC_LEVEL_WAVES) void
 raht_level_kernel(LevelCtx ctx)
 {
   __shared__ SharedLut lut_s;
+  {
+    // the grid is sized from a host-side bound; workgroups beyond the
+    // level's real work leave before touching anything
+    int64_t b0, b1;
+    xcd_chunk(((int64_t)ctx.work_count[ctx.li] + 31) >> 5, &b0, &b1);
+    if (b0 >= b1)
+      return;
+  }
   load_lut(&lut_s, ctx.lut);
   const SharedLut& lut = lut_s;
 
