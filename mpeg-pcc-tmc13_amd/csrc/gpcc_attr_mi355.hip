@@ -30,6 +30,7 @@
 #include "raht_edges.hpp"
 #include "raht_levels.hpp"
 #include "raht_rdoq.hpp"
+#include "raht_subnode.hpp"
 #include "raht_tree.hpp"
 #include "morton_sort.hpp"
 
@@ -57,6 +58,7 @@ fail(int code, const std::string& msg)
 
 constexpr int kGridMax = 2048;  // 256 CUs x 8 workgroups of 256 threads
 constexpr int kLevelGridMax = 1 << 16;
+constexpr int kSubGrid = 1024;      // sub-node kernel: 4 workgroups per CU, resident
 constexpr int kRoundsPerGroup = 4;  // level kernels: rounds of 32 blocks per workgroup
 
 int
@@ -92,6 +94,7 @@ struct gpcc_ctx {
   Arena arena;
   int morton_bits = 0;  // hint for the device tier, 0 = unknown
   SharedLut* d_lut = nullptr;  // small-weight tables, built once
+  int32_t* h_error = nullptr;  // pinned: device-side error word of the last call
   // host staging for the host tier
   void* h_pinned = nullptr;
   size_t h_pinned_cap = 0;
@@ -166,7 +169,10 @@ struct Plan {
   int32_t* rtile_lin = nullptr;
   int32_t* slice_l = nullptr;
   int32_t* worklist = nullptr;
-  int32_t* work_count = nullptr;
+  int32_t* work_count = nullptr;  // [kMaxLevels] then ticket[kMaxLevels*8], error[1] (one memset)
+  unsigned long long* scan_state = nullptr;
+  int32_t* done = nullptr;
+  bool sub = false;
   int num_rtiles = 0;
   std::vector<int32_t*> haar_lf, asc_qp;
 };
@@ -203,7 +209,9 @@ carve(Arena& ar, Plan& pl)
   pl.tile_attr = ar.take<int32_t>((size_t)pl.tv.num_tiles * c);
   pl.sched = ar.take<SliceSched>(s);
   pl.worklist = ar.take<int32_t>((size_t)n + 1);
-  pl.work_count = ar.take<int32_t>(kMaxLevels);
+  pl.work_count = ar.take<int32_t>(kMaxLevels * 9 + 1);
+  pl.scan_state = ar.take<unsigned long long>(1024);
+  pl.done = pl.sub ? ar.take<int32_t>((size_t)n + 1) : nullptr;
   pl.params = ar.take<gpcc_raht_params>(1);
   for (int i = 0; i < 2; i++) {
     pl.rec[i] = ar.take<int64_t>((size_t)n * c);
@@ -257,7 +265,7 @@ ensure_arena(gpcc_ctx* ctx, size_t bytes)
 }
 
 int
-check_params(const gpcc_raht_params* p, int c)
+check_params(const gpcc_raht_params* p, int c, bool encoder)
 {
   if (!p)
     return fail(GPCC_ERR_INVALID_ARG, "params is null");
@@ -268,12 +276,13 @@ check_params(const gpcc_raht_params* p, int c)
   if (p->num_ac_qp_layers < 0 || p->num_ac_qp_layers > GPCC_MAX_AC_QP_LAYERS)
     return fail(GPCC_ERR_INVALID_ARG, "num_ac_qp_layers out of range");
   if (
-    p->raht_prediction_enabled_flag
+    encoder && !p->integer_haar_enable_flag && p->raht_prediction_enabled_flag
     && p->raht_subnode_prediction_enabled_flag)
     return fail(
       GPCC_ERR_UNSUPPORTED,
-      "raht_subnode_prediction_enabled_flag=1 is not on the device path "
-      "yet: run the reference CPU function for this slice");
+      "lossy forward RAHT with raht_subnode_prediction_enabled_flag=1 (RDOQ "
+      "state coupled into the block dependency order) is not on the device "
+      "path yet: run the reference CPU function for this slice");
   return GPCC_OK;
 }
 
@@ -394,7 +403,14 @@ launch_transform(
   lc.lut = ctx->d_lut;
   lc.worklist = pl.worklist;
   lc.work_count = pl.work_count;
-  HIP_TRY(hipMemsetAsync(pl.work_count, 0, kMaxLevels * sizeof(int32_t), st));
+  lc.scan_state = pl.scan_state;
+  lc.done = pl.done;
+  lc.ticket = pl.work_count + kMaxLevels;
+  lc.error = pl.work_count + kMaxLevels * 9;
+  HIP_TRY(hipMemsetAsync(pl.work_count, 0, (kMaxLevels * 9 + 1) * sizeof(int32_t), st));
+  HIP_TRY(hipMemsetAsync(pl.scan_state, 0, 1024 * sizeof(unsigned long long), st));
+  if (pl.done)
+    HIP_TRY(hipMemsetAsync(pl.done, 0, ((size_t)n + 1) * sizeof(int32_t), st));
 
   RdoqCtx rc{};
   if (pl.lossy) {
@@ -421,9 +437,15 @@ launch_transform(
       ((pl.cap[li + 1] + 32 * kRoundsPerGroup - 1) / (32 * kRoundsPerGroup) + 7) / 8 * 8);
     {
       Timer t(ctx, "level_prepass");
-      raht_level_prepass_kernel<C><<<std::min(grid_for(pl.cap[li + 1], 1024), 1024), 256, 0, st>>>(lc);
+      raht_level_prepass_kernel<C><<<(int)std::min<int64_t>((pl.cap[li + 1] + 1023) / 1024, 1024), 256, 0, st>>>(lc);
     }
-    if (!encoder) {
+    if (pl.sub && !encoder) {
+      Timer t(ctx, "level_sub_synth");
+      raht_level_sub_kernel<C, kSynth><<<kSubGrid, 256, 0, st>>>(lc);
+    } else if (pl.sub && pl.haar) {
+      Timer t(ctx, "level_sub_fused");
+      raht_level_sub_kernel<C, kFused><<<kSubGrid, 256, 0, st>>>(lc);
+    } else if (!encoder) {
       Timer t(ctx, "level_synth");
       raht_level_kernel<C, kSynth><<<grid, 256, 0, st>>>(lc);
     } else if (pl.haar) {
@@ -480,7 +502,22 @@ launch_transform(
     Timer t(ctx, "finish");
     finish_kernel<C><<<grid_for(pl.cap[0], 256), 256, 0, st>>>(fc);
   }
+  if (ctx->h_error)
+    HIP_TRY(hipMemcpyAsync(ctx->h_error, lc.error, sizeof(int32_t), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipGetLastError());
+  return GPCC_OK;
+}
+
+int
+check_device_error(gpcc_ctx* ctx)
+{
+  if (ctx->h_error && *ctx->h_error) {
+    *ctx->h_error = 0;
+    return fail(
+      GPCC_ERR_HIP,
+      "a dependency wait in the sub-node prediction kernel expired; the "
+      "result is invalid");
+  }
   return GPCC_OK;
 }
 
@@ -492,7 +529,7 @@ dev_transform(
 {
   if (!ctx)
     return fail(GPCC_ERR_INVALID_ARG, "ctx is null");
-  int rcode = check_params(params, c);
+  int rcode = check_params(params, c, encoder);
   if (rcode)
     return rcode;
   if (s < 1 || !offsets || offsets[0] != 0)
@@ -516,6 +553,8 @@ dev_transform(
   pl.haar = params->integer_haar_enable_flag != 0;
   pl.has_qp = d_qp_off != nullptr;
   pl.lossy = encoder && !pl.haar;
+  pl.sub = params->raht_prediction_enabled_flag
+    && params->raht_subnode_prediction_enabled_flag;
   pl.num_rtiles = 0;
   for (int i = 0; i < s; i++)
     pl.num_rtiles +=
@@ -555,7 +594,7 @@ host_transform(
     return fail(GPCC_ERR_INVALID_ARG, "ctx is null");
   if (!morton || !attrs || !coeffs || n <= 0)
     return fail(GPCC_ERR_INVALID_ARG, "null buffer or n <= 0");
-  int rcode = check_params(params, c);
+  int rcode = check_params(params, c, encoder);
   if (rcode)
     return rcode;
   for (int i = 1; i < n; i++)
@@ -598,7 +637,7 @@ host_transform(
     if (encoder)
       HIP_TRY(hipMemcpyAsync(coeffs, d_c, sizeof(int32_t) * n * c, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    return GPCC_OK;
+    return check_device_error(ctx);
   };
   int r = run();
   cleanup();
@@ -679,6 +718,10 @@ gpcc_ctx_create(int device, void* stream, gpcc_ctx** out)
     return fail(GPCC_ERR_OUT_OF_MEMORY, "hipMalloc(lut)");
   }
   lut_init_kernel<<<1, 256, 0, ctx->stream>>>(ctx->d_lut);
+  if (hipHostMalloc((void**)&ctx->h_error, sizeof(int32_t)) == hipSuccess)
+    *ctx->h_error = 0;
+  else
+    ctx->h_error = nullptr;
   *out = ctx;
   return GPCC_OK;
 }
@@ -700,6 +743,8 @@ gpcc_ctx_destroy(gpcc_ctx* ctx)
     hipFree(ctx->arena.base);
   if (ctx->d_lut)
     hipFree(ctx->d_lut);
+  if (ctx->h_error)
+    hipHostFree(ctx->h_error);
   if (ctx->h_pinned)
     hipHostFree(ctx->h_pinned);
   if (ctx->own_stream)
@@ -713,7 +758,7 @@ gpcc_ctx_synchronize(gpcc_ctx* ctx)
   if (!ctx)
     return fail(GPCC_ERR_INVALID_ARG, "ctx is null");
   HIP_TRY(hipStreamSynchronize(ctx->stream));
-  return GPCC_OK;
+  return check_device_error(ctx);
 }
 
 size_t

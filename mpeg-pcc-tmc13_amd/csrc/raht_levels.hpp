@@ -46,6 +46,11 @@ struct LevelCtx {
   const struct SharedLut* lut;     // tables built by lut_init_kernel
   int32_t* worklist;               // [cap] parents with >= 2 children (or non-ext)
   int32_t* work_count;             // [nlev] entries of the worklist per level
+  unsigned long long* scan_state;  // [<=1024] prepass look-back words
+  // sub-node prediction (raht_subnode.hpp)
+  int32_t* done;                   // [cap] done[j] == li + 1: block j of this level is reconstructed
+  int32_t* ticket;                 // [nlev][8] wave-round tickets
+  int32_t* error;                  // set when a bounded spin expires
 };
 
 // Small-weight tables.  Near the leaves almost every node weight is a
@@ -249,11 +254,15 @@ raht_level_prepass_kernel(LevelCtx ctx)
   const bool ext = ctx.params->raht_extension != 0;
   const int num_parents = tv.soff[li + 1][tv.num_slices];
   const int lane = lane_id(), wave = threadIdx.x >> 6;
-  int64_t gbeg, gend;
-  xcd_chunk(((int64_t)num_parents + 255) >> 8, &gbeg, &gend);
+  // workgroup b owns the b-th contiguous range of 256-parent chunks, so the
+  // worklist comes out in ascending block order (the dependency order of
+  // sub-node prediction, and the coefficient order)
+  const int64_t chunks = ((int64_t)num_parents + 255) >> 8;
+  const int64_t per = (chunks + gridDim.x - 1) / gridDim.x;
+  const int64_t gbeg = min((int64_t)blockIdx.x * per, chunks);
+  const int64_t gend = min(gbeg + per, chunks);
 
-  // pass 1: how many blocks does this workgroup append?  (one atomic per
-  // workgroup: same-address atomics retire at ~11 ns each)
+  // pass 1: how many blocks does this workgroup append?
   int mine = 0;
   for (int64_t chunk = gbeg; chunk < gend; chunk++) {
     const int j = (int)(chunk * 256) + threadIdx.x;
@@ -272,8 +281,37 @@ raht_level_prepass_kernel(LevelCtx ctx)
     wave_cnt[wave] = mine;
   __syncthreads();
   if (threadIdx.x == 0) {
-    const int total = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-    base_s = total ? atomicAdd(&ctx.work_count[li], total) : 0;
+    // exclusive prefix over workgroups by decoupled look-back.  One 8-byte
+    // word per workgroup: {epoch:16 | kind:16 | count:32}; kind 1 = this
+    // workgroup's own count, 2 = inclusive prefix.  The grid (<= 1024
+    // workgroups of 256 threads) is resident, so every predecessor publishes.
+    const unsigned long long ep = (unsigned long long)(li + 1) << 48;
+    const unsigned total = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    unsigned excl = 0;
+    if (blockIdx.x > 0) {
+      __hip_atomic_store(
+        &ctx.scan_state[blockIdx.x], ep | (1ull << 32) | total, __ATOMIC_RELAXED,
+        __HIP_MEMORY_SCOPE_AGENT);
+      int k = (int)blockIdx.x - 1;
+      for (;;) {
+        const unsigned long long v = __hip_atomic_load(
+          &ctx.scan_state[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((v >> 48) != (unsigned long long)(li + 1)) {
+          __builtin_amdgcn_s_sleep(2);
+          continue;
+        }
+        excl += (unsigned)v;
+        if (((v >> 32) & 0xffff) == 2)
+          break;
+        k--;
+      }
+    }
+    __hip_atomic_store(
+      &ctx.scan_state[blockIdx.x], ep | (2ull << 32) | (excl + total),
+      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (blockIdx.x == gridDim.x - 1)
+      ctx.work_count[li] = (int)(excl + total);
+    base_s = (int)excl;
   }
   __syncthreads();
   int running = base_s;
@@ -303,6 +341,8 @@ raht_level_prepass_kernel(LevelCtx ctx)
             ctx.dqp[cp][crow * 2] = ctx.dqp[pp][prow * 2];
             ctx.dqp[cp][crow * 2 + 1] = ctx.dqp[pp][prow * 2 + 1];
           }
+          if (ctx.done)
+            ctx.done[j] = li + 1;  // visible to the block kernel (next launch)
         } else {
           real = true;
         }

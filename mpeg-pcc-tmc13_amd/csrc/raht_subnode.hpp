@@ -1,0 +1,603 @@
+// raht_subnode.hpp -- level kernel for raht_subnode_prediction_enabled_flag=1
+// (the CTC default): the prediction of a block additionally uses the
+// ALREADY RECONSTRUCTED children of up to 12 causal neighbour parents of the
+// same level (tmc3/RAHT.cpp:370-415, 503-565).  A neighbour parent counts
+// only once it has been processed (its `occupancy` is zeroed at level start
+// :1223 and set at :1393), and blocks are processed in Morton order, so
+// block j depends on neighbour blocks q < j: a wavefront of dependencies
+// sweeps each level (about 2 000 sequential steps per slice).
+//
+// Execution model.  Wavefronts claim 8 consecutive worklist blocks with a
+// ticket (8 counters, workgroup index mod 8, so claiming is monotone per
+// counter and the lowest unfinished block can always run: every dependency
+// points to a lower block).  Everything that does not depend on neighbours
+// of the same level runs first for all 8 blocks (children gather, butterfly
+// coefficients, neighbour search, parent-level part of the prediction,
+// encoder-side forward transform of the source).  Then a wave-uniform loop
+// polls one `done` word per dependency (relaxed agent-scope loads), and for
+// the groups whose dependencies are complete finishes the block:
+// child-level prediction terms, transform, coefficients, inverse,
+// reconstruction.  The children's reconstruction that later blocks of the
+// SAME launch read is written write-through (agent-scope relaxed stores,
+// `sc1`) and read with agent-scope loads; the producer drains its stores
+// (`s_waitcnt vmcnt(0)`) before one lane publishes done[j] = epoch
+// (cdna_hip_programming.md G16, form R1).  Spins are bounded: a stuck launch
+// raises ctx.error instead of hanging the GPU.
+//
+// Modes: kSynth (decoder) and kFused (integer-Haar encoder).  The lossy
+// encoder with sub-node prediction also couples the RDOQ zero-run state
+// into this dependency order and is not on the device yet.
+#pragma once
+
+#include "raht_levels.hpp"
+
+namespace gpcc {
+
+constexpr uint8_t kOccuShiftTab[12] = {6, 5, 4, 3, 2, 1, 3, 1, 2, 1, 2, 3};
+
+__device__ __forceinline__ int
+occu_shift(int i12)
+{
+  constexpr uint8_t s[12] = {6, 5, 4, 3, 2, 1, 3, 1, 2, 1, 2, 3};
+  return s[i12];
+}
+
+__device__ __forceinline__ int32_t
+load_agent_i32(const int32_t* p)
+{
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int64_t
+load_agent_i64(const int64_t* p)
+{
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void
+store_agent_i64(int64_t* p, int64_t v)
+{
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template<int C, int MODE>
+__global__ __launch_bounds__(256, 4) void
+raht_level_sub_kernel(LevelCtx ctx)
+{
+  static_assert(MODE == kSynth || MODE == kFused, "decoder or Haar encoder");
+  __shared__ SharedLut lut_s;
+  load_lut(&lut_s, ctx.lut);
+  const SharedLut& lut = lut_s;
+
+  constexpr bool kEnc = MODE != kSynth;
+  constexpr bool kRecon = true;
+  const TreeView& tv = ctx.tv;
+  const gpcc_raht_params* __restrict__ prm = ctx.params;
+  const int li = ctx.li;
+  const int t = threadIdx.x & 7;
+  const int lane = lane_id();
+  const int gbase = threadIdx.x & 56;  // first lane of this 8-lane group
+  const bool haar = prm->integer_haar_enable_flag != 0;
+  const bool ext = prm->raht_extension != 0;
+  const int32_t epoch = li + 1;
+  const int cls = blockIdx.x & 7;
+
+  const int num_work = ctx.work_count[li];
+  for (;;) {
+    int tk = 0;
+    if (lane == 0)
+      tk = atomicAdd(&ctx.ticket[li * 8 + cls], 1);
+    tk = __shfl(tk, 0);
+    const int64_t wround = (int64_t)tk * 8 + cls;
+    if (wround * 8 >= num_work)
+      break;
+    const int wi = (int)(wround * 8) + (lane >> 3);
+    const bool live = wi < num_work;
+    const int j = live ? ctx.worklist[wi] : 0;
+    // ---- locate the block -------------------------------------------
+    int s = 0;
+    LevelSched e;
+    e.processed = 0;
+    if (live) {
+      s = find_slice(tv.soff[li + 1], tv.num_slices, j);
+      e = ctx.sched[s].lvl[li];
+    }
+    // all shuffles below run in wave-uniform control flow; lanes of dead
+    // groups carry zeros and store nothing
+    const bool on = live && e.processed;
+    const int sp0 = on ? tv.soff[li + 1][s] : 0;      // slice's parents
+    const int sp1 = on ? tv.soff[li + 1][s + 1] : 0;
+    const int sc0 = on ? tv.soff[li][s] : 0;          // slice's children
+    const int pt0 = on ? tv.pt_off[s] : 0;
+    const int n_s = on ? tv.pt_off[s + 1] - pt0 : 0;
+    const int c0 = on ? tv.fc[li + 1][j] : 0;
+    const int nchild = on ? tv.fc[li + 1][j + 1] - c0 : 0;
+    const int pj = j - sp0;
+    const int par_par = e.parity ^ 1, cur_par = e.parity;
+    const int64_t prow = (int64_t)pt0 + pj;  // parent row in rec buffers
+
+    // ---- children -> positions ---------------------------------------
+    const int64_t ckey = t < nchild ? tv.key[li][c0 + t] : 0;
+    const uint32_t occ = group8_or(t < nchild ? 1u << (int)(ckey & 7) : 0u);
+    const bool has = (occ >> t) & 1;
+    const int child = c0 + popc32(occ & ((1u << t) - 1));
+    const int64_t crow = (int64_t)pt0 + (child - sc0);
+    int32_t w = 0;
+    int64_t src[C];
+#pragma unroll
+    for (int k = 0; k < C; k++)
+      src[k] = 0;
+    if (has) {
+      const int f0 = tv.fp[li][child], f1 = tv.fp[li][child + 1];
+      w = f1 - f0;
+      if (kEnc) {
+        if (haar) {
+          const int32_t* lf = ctx.haar_lf[li];
+#pragma unroll
+          for (int k = 0; k < C; k++)
+            src[k] = fp_from_int(lf[(size_t)child * C + k]);
+        } else {
+#pragma unroll
+          for (int k = 0; k < C; k++)
+            src[k] = fp_from_int((int32_t)(
+              (uint32_t)ctx.attr_prefix[(size_t)f1 * C + k]
+              - (uint32_t)ctx.attr_prefix[(size_t)f0 * C + k]));
+        }
+      }
+    }
+
+    // ---- node qp on the way down (see oracle/raht_oracle.c,
+    //      descend_block_qp; tmc3/RAHT.cpp:185-189 vs :246-253) ----------
+    int32_t nq0 = 0, nq1 = 0;
+    if (ctx.asc_qp) {
+      int32_t a0 = 0, a1 = 0;
+      if (has) {
+        a0 = ctx.asc_qp[li][(size_t)child * 2];
+        a1 = ctx.asc_qp[li][(size_t)child * 2 + 1];
+      }
+      // ascent averages of the pair / quad this position belongs to
+      int32_t wa = w, b0 = a0, b1 = a1;   // current sub-tree weight, avg
+      int32_t st_w[3], st_a0[3], st_a1[3], st_pw[3];
+#pragma unroll
+      for (int st = 0; st < 3; st++) {
+        const int bit = 1 << st;
+        const int32_t pw = __shfl_xor(wa, bit);
+        const int32_t p0 = __shfl_xor(b0, bit), p1 = __shfl_xor(b1, bit);
+        st_w[st] = wa;
+        st_a0[st] = b0;
+        st_a1[st] = b1;
+        st_pw[st] = pw;
+        if (wa && pw) {
+          b0 = (b0 + p0) >> 1;
+          b1 = (b1 + p1) >> 1;
+        } else if (pw) {
+          b0 = p0;
+          b1 = p1;
+        }
+        wa += pw;
+      }
+      // descend: the sub-tree containing this position is the RIGHT one
+      // of a real pair -> its own ascent average, otherwise inherit
+      int32_t d0 = on ? ctx.dqp[par_par][prow * 2] : 0;
+      int32_t d1 = on ? ctx.dqp[par_par][prow * 2 + 1] : 0;
+#pragma unroll
+      for (int st = 2; st >= 0; st--) {
+        const int bit = 1 << st;
+        if ((t & bit) && st_w[st] && st_pw[st]) {
+          d0 = st_a0[st];
+          d1 = st_a1[st];
+        }
+      }
+      if (has) {
+        nq0 = d0 >> 4;
+        nq1 = d1 >> 4;
+        if (kRecon) {
+          ctx.dqp[cur_par][crow * 2] = d0;
+          ctx.dqp[cur_par][crow * 2 + 1] = d1;
+        }
+      }
+    }
+
+    // ---- butterfly weights + coefficients (mkWeightTree :742) ----------
+    int32_t wl[3], wr[3];
+    int64_t ca[3], cb[3];
+    int32_t cw = w;
+#pragma unroll
+    for (int st = 0; st < 3; st++) {
+      const int bit = 1 << st;
+      const int32_t pw = __shfl_xor(cw, bit);
+      const bool left = !(t & bit);
+      wl[st] = left ? cw : pw;
+      wr[st] = left ? pw : cw;
+      ca[st] = cb[st] = 0;
+      if (wl[st] && wr[st]) {
+        if (!haar)
+          raht_coeffs(wl[st], wr[st], lut, &ca[st], &cb[st]);
+        cw = wl[st] + wr[st];
+      } else {
+        cw = left ? wl[st] + wr[st] : 0;
+      }
+    }
+
+    // ---- inter-level prediction (tmc3/RAHT.cpp:1391-1432) --------------
+    const bool inherit_dc = !e.is_root;
+    const bool pred_in_level =
+      on && inherit_dc && prm->raht_prediction_enabled_flag != 0;
+    bool enable_pred = pred_in_level;
+    int neigh_count = 0;
+    int64_t pred[C];
+#pragma unroll
+    for (int k = 0; k < C; k++)
+      pred[k] = 0;
+
+    bool do_search = false;
+    if (pred_in_level) {
+      if (ext && nchild == 1) {
+        enable_pred = false;
+        neigh_count = 19;
+      } else if (ctx.nneigh[par_par][prow] < prm->raht_prediction_threshold0) {
+        enable_pred = false;
+      } else {
+        do_search = true;
+      }
+    }
+    // (group-uniform; other groups of the wave idle through the shuffles)
+    int pn[3] = {-1, -1, -1};  // neighbour i = 1 + t + 8*slot
+    {
+      // the three lower_bound searches of a lane advance in lock step, so
+      // their probes are in flight together (12 dependent steps, not 36)
+      int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}, end[3] = {0, 0, 0};
+      int64_t want[3] = {0, 0, 0};
+      if (do_search) {
+        const int64_t cur_pos = tv.key[li + 1][j];
+        const uint64_t base = morton3d_add((uint64_t)cur_pos, ~0ull);
+        const int64_t range = prm->raht_prediction_search_range;
+#pragma unroll
+        for (int slot = 0; slot < 3; slot++) {
+          const int i = 1 + t + 8 * slot;
+          if (i < 19 && (occ & neigh_mask(i))) {
+            const int64_t np = (int64_t)morton3d_add(base, neigh_offset(i));
+            int64_t d = np - cur_pos;
+            if (d >= 0) {
+              d = d >= range ? range : d;
+              lo[slot] = j;
+              end[slot] = (d + 1 < (int64_t)(sp1 - j)) ? j + (int)(d + 1) : sp1;
+            } else {
+              d = (-d) >= range ? range : -d;
+              end[slot] = j;
+              lo[slot] = (d < (int64_t)(j - sp0)) ? j - (int)d : sp0;
+            }
+            hi[slot] = end[slot];
+            want[slot] = np;
+          }
+        }
+      }
+      const int64_t* __restrict__ pkey = tv.key[li + 1];
+      while (__any((lo[0] < hi[0]) | (lo[1] < hi[1]) | (lo[2] < hi[2]))) {
+        int mid[3];
+        int64_t kv[3];
+#pragma unroll
+        for (int slot = 0; slot < 3; slot++) {
+          mid[slot] = lo[slot] + ((hi[slot] - lo[slot]) >> 1);
+          kv[slot] = lo[slot] < hi[slot] ? pkey[mid[slot]] : 0;
+        }
+#pragma unroll
+        for (int slot = 0; slot < 3; slot++) {
+          if (lo[slot] < hi[slot]) {
+            if (kv[slot] < want[slot])
+              lo[slot] = mid[slot] + 1;
+            else
+              hi[slot] = mid[slot];
+          }
+        }
+      }
+#pragma unroll
+      for (int slot = 0; slot < 3; slot++) {
+        if (lo[slot] < end[slot] && pkey[lo[slot]] == want[slot])
+          pn[slot] = lo[slot];
+      }
+    }
+    {
+      int found = (pn[0] >= 0) + (pn[1] >= 0) + (pn[2] >= 0);
+      found = group8_sum(found);
+      if (do_search) {
+        neigh_count = found + 1;
+        if (neigh_count < prm->raht_prediction_threshold1)
+          enable_pred = false;
+      }
+    }
+
+    // ---- everything that does not wait: coefficient slots, quantisers,
+    //      the encoder's source transform, parent-level prediction terms ---
+    // ---- coefficient slot of this position (scanBlock :776-791) --------
+    const uint32_t present = group8_or((on && cw != 0) ? 1u << t : 0u) | (on ? 1u : 0u);
+    // scan order 0,4,2,1,6,5,3,7 -> scan position of t
+    const int spos = (0x74516230u >> (4 * t)) & 7;
+    const uint32_t pscan = ((present >> 0) & 1) | (((present >> 4) & 1) << 1)
+      | (((present >> 2) & 1) << 2) | (((present >> 1) & 1) << 3)
+      | (((present >> 6) & 1) << 4) | (((present >> 5) & 1) << 5)
+      | (((present >> 3) & 1) << 6) | (((present >> 7) & 1) << 7);
+    const int rank = popc32(pscan & ((1u << spos) - 1));
+    const bool coded = on && ((present >> t) & 1) && (t != 0 || !inherit_dc);
+    // slice-relative coefficient index
+    const int cidx = e.coeff_base
+      + (inherit_dc ? (c0 - sc0) - pj + rank - 1 : rank);
+    int32_t* __restrict__ cplane = ctx.coeffs + (size_t)pt0 * C + cidx;
+
+
+    Quantizer qa[2] = {{1, 1}, {1, 1}};
+    if (coded) {
+      int ac0 = 0, ac1 = 0;
+      if (e.ac_layer < prm->num_ac_qp_layers && t) {
+        ac0 = prm->ac_qp_offset[e.ac_layer][t - 1][0];
+        ac1 = prm->ac_qp_offset[e.ac_layer][t - 1][1];
+      }
+      qpset_quantizers(prm, e.qp_layer, nq0 + ac0, nq1 + ac1, qa);
+    }
+    if (kEnc) {
+      // integer Haar: no normalisation; forward butterflies of the source
+#pragma unroll
+      for (int st = 0; st < 3; st++) {
+        const int bit = 1 << st;
+        const bool left = !(t & bit);
+        const bool both = wl[st] && wr[st];
+        const bool swap = !wl[st] && wr[st];
+#pragma unroll
+        for (int k = 0; k < C; k++) {
+          const int64_t own = src[k], oth = shfl_xor_i64(own, bit);
+          if (both) {
+            const int64_t hf = left ? oth - own : own - oth;
+            src[k] = left ? own + ((hf >> (1 + kFpFrac)) << kFpFrac) : hf;
+          } else if (swap) {
+            src[k] = oth;
+          }
+        }
+      }
+    }
+    int64_t dc[C];
+#pragma unroll
+    for (int k = 0; k < C; k++)
+      dc[k] = 0;
+    if (on && inherit_dc && t == 0) {
+#pragma unroll
+      for (int k = 0; k < C; k++) {
+        const int64_t val = ctx.rec_us[par_par][prow * C + k];
+        dc[k] = ext ? val
+                    : (val > 0 ? val << (kFpFrac - 2) : -((-val) << (kFpFrac - 2)));
+      }
+    }
+
+    const bool run = do_search && enable_pred;
+    const int64_t* __restrict__ prec = ctx.rec[par_par];
+    const int64_t rbase = (int64_t)pt0 - sp0;
+    int wsum = 0;
+    int64_t lim_lo = 0, lim_hi = 0;
+    // intraDcPred, the seven neighbours that never use child values
+    // (tmc3/RAHT.cpp:463-502 with parentOnlyCheckMaxIdx = 7)
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+      int q;
+      if (i == 0)
+        q = j;
+      else
+        q = __shfl(pn[0], gbase | (i - 1));
+      if (!run || q < 0)
+        continue;
+      int64_t v[C];
+#pragma unroll
+      for (int k = 0; k < C; k++)
+        v[k] = prec[(rbase + q) * C + k];
+      if (i) {
+        if (10 * v[0] <= lim_lo || 10 * v[0] >= lim_hi)
+          continue;
+      } else {
+        lim_lo = 2 * v[0];
+        lim_hi = 25 * v[0];
+      }
+      if (has && ((neigh_mask(i) >> t) & 1)) {
+        const int64_t pw = prm->pred_weight_parent[i];
+        wsum += (int)pw;
+        const int64_t mul = ext ? pw : (pw << kFpFrac);
+#pragma unroll
+        for (int k = 0; k < C; k++)
+          pred[k] += v[k] * mul;
+      }
+    }
+
+    // ---- dependencies: neighbour parents 7..18 that precede this block --
+    // lane t owns neighbours i = 1 + t + 8*slot (the lanes that searched them)
+    int dep[3] = {-1, -1, -1};
+#pragma unroll
+    for (int slot = 0; slot < 3; slot++) {
+      const int i = 1 + t + 8 * slot;
+      if (run && i >= 7 && i < 19 && pn[slot] >= 0 && pn[slot] < j)
+        dep[slot] = pn[slot];
+    }
+
+    bool pending = on;
+    unsigned spins = 0;
+    while (__any(pending)) {
+      bool unmet = false;
+#pragma unroll
+      for (int slot = 0; slot < 3; slot++)
+        if (pending && dep[slot] >= 0
+            && load_agent_i32(&ctx.done[dep[slot]]) != epoch)
+          unmet = true;
+      const bool blocked = group8_or(unmet ? 1u : 0u) != 0;
+      const bool ready = pending && !blocked;
+      if (!__any(ready)) {
+        if (++spins > (1u << 22)) {
+          if (lane == 0)
+            atomicExch(ctx.error, 1);  // fail loudly instead of hanging
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+        continue;
+      }
+
+      // occupancy + first child of the owned, already processed neighbours
+      int nb_c0[3] = {0, 0, 0};
+      uint32_t nb_occ[3] = {0, 0, 0};
+#pragma unroll
+      for (int slot = 0; slot < 3; slot++) {
+        if (ready && dep[slot] >= 0) {
+          const int q = dep[slot];
+          const int qc0 = tv.fc[li + 1][q];
+          const int qn = tv.fc[li + 1][q + 1] - qc0;
+          uint32_t o = 0;
+          for (int u = 0; u < qn; u++)
+            o |= 1u << (int)(tv.key[li][qc0 + u] & 7);
+          nb_c0[slot] = qc0;
+          nb_occ[slot] = o;
+        }
+      }
+
+      int64_t pw_[C];  // working copy: groups that are not ready recompute
+      int ws = wsum;
+#pragma unroll
+      for (int k = 0; k < C; k++)
+        pw_[k] = pred[k];
+
+      // intraDcPred, neighbours 7..18 (tmc3/RAHT.cpp:503-565)
+#pragma unroll
+      for (int i12 = 0; i12 < 12; i12++) {
+        const int i = 7 + i12;
+        const int owner = gbase | ((i - 1) & 7);
+        const int q = __shfl(pn[(i - 1) >> 3], owner);
+        const int qc0 = __shfl(nb_c0[(i - 1) >> 3], owner);
+        const uint32_t qocc = __shfl(nb_occ[(i - 1) >> 3], owner);
+        if (!(run && ready) || q < 0)
+          continue;
+        int64_t v[C];
+#pragma unroll
+        for (int k = 0; k < C; k++)
+          v[k] = prec[(rbase + q) * C + k];
+        if (10 * v[0] <= lim_lo || 10 * v[0] >= lim_hi)
+          continue;
+        if (has && ((neigh_mask(i) >> t) & 1)) {
+          const int sh = occu_shift(i12);
+          const int cpos = i12 < 9 ? t + sh : t - sh;
+          const bool child_ok = cpos >= 0 && cpos < 8 && ((qocc >> cpos) & 1);
+          if (child_ok) {
+            const int cidx_n = qc0 + popc32(qocc & ((1u << cpos) - 1));
+            const int64_t nrow = (int64_t)pt0 + (cidx_n - sc0);
+            const int64_t pwc = prm->pred_weight_child[i12];
+            ws += (int)pwc;
+            const int64_t mul = ext ? pwc : (pwc << kFpFrac);
+#pragma unroll
+            for (int k = 0; k < C; k++)
+              pw_[k] += load_agent_i64(&ctx.rec[cur_par][nrow * C + k]) * mul;
+          } else {
+            const int64_t pwp = prm->pred_weight_parent[i];
+            ws += (int)pwp;
+            const int64_t mul = ext ? pwp : (pwp << kFpFrac);
+#pragma unroll
+            for (int k = 0; k < C; k++)
+              pw_[k] += v[k] * mul;
+          }
+        }
+      }
+      if (run && has) {
+        const int64_t div = pred_divisor(ws > 0 ? ws : 1);
+#pragma unroll
+        for (int k = 0; k < C; k++) {
+          pw_[k] = fp_mul(pw_[k], div);
+          if (haar)
+            pw_[k] = (pw_[k] >> kFpFrac) << kFpFrac;
+        }
+      }
+      // normalise + forward butterflies of the prediction
+      if (!haar && w > 1 && enable_pred) {
+        const int64_t sq = sqrt_weight(w, lut);
+#pragma unroll
+        for (int k = 0; k < C; k++)
+          pw_[k] = fp_mul(pw_[k], sq);
+      }
+#pragma unroll
+      for (int st = 0; st < 3; st++) {
+        const int bit = 1 << st;
+        const bool left = !(t & bit);
+        const bool both = wl[st] && wr[st];
+        const bool swap = !wl[st] && wr[st];
+#pragma unroll
+        for (int k = 0; k < C; k++) {
+          const int64_t own = pw_[k], oth = shfl_xor_i64(own, bit);
+          if (enable_pred) {
+            if (both) {
+              if (haar) {
+                const int64_t hf = left ? oth - own : own - oth;
+                pw_[k] = left ? own + ((hf >> (1 + kFpFrac)) << kFpFrac) : hf;
+              } else {
+                pw_[k] = left ? fp_mul(oth, cb[st]) + fp_mul(ca[st], own)
+                              : fp_mul(own, ca[st]) - fp_mul(cb[st], oth);
+              }
+            } else if (swap) {
+              pw_[k] = oth;
+            }
+          }
+        }
+      }
+      // coefficients
+      if (coded && ready) {
+#pragma unroll
+        for (int k = 0; k < C; k++) {
+          int64_t co;
+          if (kEnc) {
+            const int64_t res = enable_pred ? src[k] - pw_[k] : src[k];
+            co = quantize(qa[k ? 1 : 0], fp_round(res) * 256);
+            cplane[(size_t)k * n_s] = (int32_t)co;
+          } else {
+            co = cplane[(size_t)k * n_s];
+          }
+          pw_[k] += fp_from_int(dequantize(qa[k ? 1 : 0], co));
+        }
+      }
+      if (on && inherit_dc && t == 0) {
+#pragma unroll
+        for (int k = 0; k < C; k++)
+          pw_[k] = dc[k];
+      }
+      // inverse butterflies
+#pragma unroll
+      for (int st = 2; st >= 0; st--) {
+        const int bit = 1 << st;
+        const bool left = !(t & bit);
+        const bool both = wl[st] && wr[st];
+        const bool swap = !wl[st] && wr[st];
+#pragma unroll
+        for (int k = 0; k < C; k++) {
+          const int64_t own = pw_[k], oth = shfl_xor_i64(own, bit);
+          if (both) {
+            if (haar) {
+              const int64_t lf = left ? own : oth, hf = left ? oth : own;
+              const int64_t lv = lf - ((hf >> (1 + kFpFrac)) << kFpFrac);
+              pw_[k] = left ? lv : hf + lv;
+            } else {
+              pw_[k] = left ? fp_mul(own, ca[st]) - fp_mul(cb[st], oth)
+                            : fp_mul(oth, cb[st]) + fp_mul(ca[st], own);
+            }
+          } else if (swap) {
+            pw_[k] = oth;
+          }
+        }
+      }
+      // commit: children of the ready groups, write-through, then the flag
+      if (ready && has) {
+#pragma unroll
+        for (int k = 0; k < C; k++) {
+          int64_t v = pw_[k];
+          ctx.rec_us[cur_par][crow * C + k] = ext ? v : fp_round(v * 4);
+          if (!haar && w > 1)
+            v = scale_rsqrt(v, w, lut);
+          store_agent_i64(&ctx.rec[cur_par][crow * C + k], ext ? v : fp_round(v));
+        }
+        ctx.nneigh[cur_par][crow] = inherit_dc ? neigh_count : 19;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (ready && t == 0)
+        __hip_atomic_store(&ctx.done[j], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      pending = pending && !ready;
+    }
+  }
+}
+
+}  // namespace gpcc

@@ -25,8 +25,17 @@ def golden():
 
 
 def on_device_path(params):
-    """Sub-node prediction is kept on the reference CPU path this round."""
-    return not (params.raht_prediction_enabled_flag and params.raht_subnode_prediction_enabled_flag)
+    """Only the LOSSY FORWARD transform with sub-node prediction is kept on the
+    reference CPU path this round (RDOQ state coupled into the block order);
+    the inverse transform and the integer-Haar forward run on the device."""
+    return not (params.raht_prediction_enabled_flag and params.raht_subnode_prediction_enabled_flag
+                and not params.integer_haar_enable_flag)
+
+
+def golden_or_oracle_coeffs(name, golden, p, morton, attrs, qp):
+    if name + "/coeffs" in golden:
+        return golden[name + "/coeffs"]
+    return ol.oracle().raht_forward(p, morton, attrs, qp)[0]
 
 
 @pytest.mark.parametrize("name", rc.CASE_NAMES)
@@ -39,7 +48,12 @@ def test_case_vs_golden_and_oracle(name, ctx, golden):
         with pytest.raises(GpccError) as ei:
             ctx.raht_forward(p, morton, attrs, qp)
         assert ei.value.code == -2  # GPCC_ERR_UNSUPPORTED: caller keeps the CPU path
-        # same case with the flag off: compared with the oracle below
+        # ... but the DECODER side of the same case runs on the device: the
+        # reference's coefficients in, the reference's reconstruction out
+        inv = ctx.raht_inverse(p, morton, golden_or_oracle_coeffs(name, golden, p, morton, attrs, qp), c, qp)
+        o_coeffs, o_rec = ol.oracle().raht_forward(p, morton, attrs, qp)
+        np.testing.assert_array_equal(inv, o_rec)
+        # and the forward case with the flag off is compared with the oracle below
         p = p.copy()
         p.raht_subnode_prediction_enabled_flag = 0
         native = False
@@ -68,7 +82,7 @@ def test_random_flags_vs_oracle(seed, ctx):
         haar = bool(rng.integers(2))
         p = raht_params(
             qp=4 if haar else int(rng.integers(4, 52)), chroma_offset=0 if haar else int(rng.integers(-3, 3)),
-            haar=haar, prediction=bool(rng.integers(4) > 0), subnode=False,
+            haar=haar, prediction=bool(rng.integers(4) > 0), subnode=bool(haar and rng.integers(2)),
             extension=bool(rng.integers(4) > 0), search_range=int(rng.choice([4, 64, 50000])),
             threshold0=int(rng.integers(0, 6)), threshold1=int(rng.integers(0, 12)))
         morton, a, order = synth.sort_by_morton(xyz, attrs)
@@ -143,3 +157,32 @@ def test_error_paths(ctx):
     assert ei.value.code == -6  # unsorted
     with pytest.raises(GpccError):
         ctx.raht_forward(p, np.array([1, 2], dtype=np.int64), np.zeros((2, 4), np.int32))
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_subnode_inverse_random_vs_oracle(seed, ctx):
+    """CTC-default flags (sub-node prediction on): decoder on the device."""
+    from mpeg_pcc_tmc13_amd import raht_params, synth
+    rng = np.random.default_rng(7000 + seed)
+    o = ol.oracle()
+    for _ in range(8):
+        n = int(rng.integers(2, 6000))
+        c = int(rng.choice([1, 3]))
+        xyz, attrs = synth.random_cloud(n, seed=int(rng.integers(1 << 30)), bits=int(rng.integers(2, 7)),
+                                        c=c, dup_fraction=float(rng.choice([0.0, 0.2])))
+        p = raht_params(qp=int(rng.integers(10, 46)), subnode=True, extension=bool(rng.integers(4) > 0),
+                        search_range=int(rng.choice([8, 50000])))
+        morton, a, _ = synth.sort_by_morton(xyz, attrs)
+        o_co, o_rec = o.raht_forward(p, morton, a)
+        np.testing.assert_array_equal(ctx.raht_inverse(p, morton, o_co, c), o_rec)
+
+
+def test_subnode_full_size_decode(ctx):
+    """1M-point lidar frame, CTC flags: device decode of the reference's
+    (oracle's) coefficients equals the encoder reconstruction."""
+    from mpeg_pcc_tmc13_amd import raht_params, synth
+    xyz, refl = synth.lidar_cloud(300_000, seed=5)
+    morton, attrs, _ = synth.sort_by_morton(xyz, refl)
+    p = raht_params(qp=34, subnode=True, search_range=2500)
+    o_co, o_rec = ol.oracle().raht_forward(p, morton, attrs)
+    np.testing.assert_array_equal(ctx.raht_inverse(p, morton, o_co, 1), o_rec)
