@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--qp", type=int, default=34)
     ap.add_argument("--subnode", type=int, default=0)
     ap.add_argument("--haar", type=int, default=0)
+    ap.add_argument("--direction", choices=["both", "inverse"], default="both",
+                    help="inverse: decoder only (coefficients prepared on the CPU outside the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     return ap.parse_args()
@@ -99,9 +101,20 @@ def main():
     ctx = context(local_rank, stream=stream.cuda_stream)
     ctx.set_morton_bits(frames[0][2])
 
+    if args.direction == "inverse":
+        # decoder-only run (e.g. CTC flags with sub-node prediction, whose lossy
+        # forward is not on the device yet): coefficients from the CPU checker
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_loader as ol
+        chk = ol.ref() if ol.ref_available() else ol.oracle()
+        cos, recs = zip(*[chk.raht_forward(p, f[0], f[1]) for f in frames])
+        d_coeffs.copy_(torch.from_numpy(np.concatenate(cos)).to(dev))
+        d_attrs.copy_(torch.from_numpy(np.concatenate(recs).reshape(-1)).to(dev))
+
     def step():
-        d_attrs.copy_(src)  # the transform overwrites its input with the reconstruction
-        ctx.dev_raht_forward(p, offsets, d_morton.data_ptr(), d_attrs.data_ptr(), d_coeffs.data_ptr(), c)
+        if args.direction == "both":
+            d_attrs.copy_(src)  # the transform overwrites its input with the reconstruction
+            ctx.dev_raht_forward(p, offsets, d_morton.data_ptr(), d_attrs.data_ptr(), d_coeffs.data_ptr(), c)
         ctx.dev_raht_inverse(p, offsets, d_morton.data_ptr(), d_dec.data_ptr(), d_coeffs.data_ptr(), c)
         if world > 1:
             dist.gather(d_coeffs, gathered, dst=0)
@@ -139,7 +152,7 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "int64 (Q15 fixed point), int32 I/O",
         "data": "synthetic",
         "config": {
-            "workload": f"RAHT forward+inverse, {args.frames}x{args.points}-point Morton-sorted "
+            "workload": f"RAHT {'forward+inverse' if args.direction == 'both' else 'inverse only'}, {args.frames}x{args.points}-point Morton-sorted "
                         f"S-{args.cloud} frame(s) per GPU, C={c}, "
                         + ("integer Haar qp 4" if args.haar else f"qp {args.qp}")
                         + f", raht_prediction=1, raht_subnode_prediction={int(args.subnode)}, raht_extension=1",
@@ -165,7 +178,7 @@ def main():
             # are where attributes and coefficients are consumed/produced,
             # so one step's launches of the dominant kernel are priced as
             # one pass over those bytes
-            alg_bytes = n * ((8 + 12 * c) + (8 + 8 * c))
+            alg_bytes = n * (((8 + 12 * c) if args.direction == 'both' else 0) + (8 + 8 * c))
             dom_s = dom_ms / 1e3 / args.steps
             achieved = alg_bytes / dom_s / 1e9
             out["roofline"] = {

@@ -172,6 +172,7 @@ struct Plan {
   int32_t* work_count = nullptr;  // [kMaxLevels] then ticket[kMaxLevels*8], error[1] (one memset)
   unsigned long long* scan_state = nullptr;
   int32_t* done = nullptr;
+  unsigned long long* rdoq_state = nullptr;
   bool sub = false;
   int num_rtiles = 0;
   std::vector<int32_t*> haar_lf, asc_qp;
@@ -212,6 +213,7 @@ carve(Arena& ar, Plan& pl)
   pl.work_count = ar.take<int32_t>(kMaxLevels * 9 + 1);
   pl.scan_state = ar.take<unsigned long long>(1024);
   pl.done = pl.sub ? ar.take<int32_t>((size_t)n + 1) : nullptr;
+  pl.rdoq_state = (pl.sub && pl.lossy) ? ar.take<unsigned long long>((size_t)n + 1) : nullptr;
   pl.params = ar.take<gpcc_raht_params>(1);
   for (int i = 0; i < 2; i++) {
     pl.rec[i] = ar.take<int64_t>((size_t)n * c);
@@ -275,14 +277,6 @@ check_params(const gpcc_raht_params* p, int c, bool encoder)
     return fail(GPCC_ERR_INVALID_ARG, "num_qp_layers out of range");
   if (p->num_ac_qp_layers < 0 || p->num_ac_qp_layers > GPCC_MAX_AC_QP_LAYERS)
     return fail(GPCC_ERR_INVALID_ARG, "num_ac_qp_layers out of range");
-  if (
-    encoder && !p->integer_haar_enable_flag && p->raht_prediction_enabled_flag
-    && p->raht_subnode_prediction_enabled_flag)
-    return fail(
-      GPCC_ERR_UNSUPPORTED,
-      "lossy forward RAHT with raht_subnode_prediction_enabled_flag=1 (RDOQ "
-      "state coupled into the block dependency order) is not on the device "
-      "path yet: run the reference CPU function for this slice");
   return GPCC_OK;
 }
 
@@ -411,6 +405,10 @@ launch_transform(
   HIP_TRY(hipMemsetAsync(pl.scan_state, 0, 1024 * sizeof(unsigned long long), st));
   if (pl.done)
     HIP_TRY(hipMemsetAsync(pl.done, 0, ((size_t)n + 1) * sizeof(int32_t), st));
+  if (pl.rdoq_state)
+    HIP_TRY(hipMemsetAsync(pl.rdoq_state, 0, ((size_t)n + 1) * sizeof(unsigned long long), st));
+  lc.rdoq_state = pl.rdoq_state;
+  lc.slice_l = pl.slice_l;
 
   RdoqCtx rc{};
   if (pl.lossy) {
@@ -445,6 +443,9 @@ launch_transform(
     } else if (pl.sub && pl.haar) {
       Timer t(ctx, "level_sub_fused");
       raht_level_sub_kernel<C, kFused><<<kSubGrid, 256, 0, st>>>(lc);
+    } else if (pl.sub) {
+      Timer t(ctx, "level_sub_lossy");
+      raht_level_sub_kernel<C, kLossySub><<<kSubGrid, 256, 0, st>>>(lc);
     } else if (!encoder) {
       Timer t(ctx, "level_synth");
       raht_level_kernel<C, kSynth><<<grid, 256, 0, st>>>(lc);

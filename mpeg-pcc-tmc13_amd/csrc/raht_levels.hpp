@@ -24,7 +24,7 @@
 
 namespace gpcc {
 
-enum LevelMode { kAnalyze = 0, kSynth = 1, kFused = 2 };
+enum LevelMode { kAnalyze = 0, kSynth = 1, kFused = 2, kLossySub = 3 };
 
 constexpr uint32_t kDescNever = 0x7fffffffu;  // threshold that never passes
 constexpr uint32_t kDescZero = 0x80000000u;   // all components quantise to 0
@@ -51,6 +51,8 @@ struct LevelCtx {
   int32_t* done;                   // [cap] done[j] == li + 1: block j of this level is reconstructed
   int32_t* ticket;                 // [nlev][8] wave-round tickets
   int32_t* error;                  // set when a bounded spin expires
+  unsigned long long* rdoq_state;  // [cap] per worklist block: RDOQ hand-off word
+  int32_t* slice_l;                // [S] last RDOQ reset carried between levels
 };
 
 // Small-weight tables.  Near the leaves almost every node weight is a

@@ -24,9 +24,15 @@
 // (cdna_hip_programming.md G16, form R1).  Spins are bounded: a stuck launch
 // raises ctx.error instead of hanging the GPU.
 //
-// Modes: kSynth (decoder) and kFused (integer-Haar encoder).  The lossy
-// encoder with sub-node prediction also couples the RDOQ zero-run state
-// into this dependency order and is not on the device yet.
+// Modes: kSynth (decoder), kFused (integer-Haar encoder) and kLossySub, the
+// lossy encoder.  There the RDOQ zero-run state (tmc3/RAHT.cpp:1618-1669)
+// is a second dependency: a block's decisions need L, the index of the last
+// reset before its first coefficient (raht_rdoq.hpp).  Each block evaluates
+// its <= 8 coefficients under the two extreme hypotheses for L; when both
+// agree it commits at once and publishes either its absolute outgoing L
+// ("final") or "transparent" (no reset inside, L passes through).  Only a
+// block whose outcome really depends on L looks back over its
+// predecessors' words (skipping transparent ones) and waits if needed.
 #pragma once
 
 #include "raht_levels.hpp"
@@ -62,7 +68,8 @@ template<int C, int MODE>
 __global__ __launch_bounds__(256, 4) void
 raht_level_sub_kernel(LevelCtx ctx)
 {
-  static_assert(MODE == kSynth || MODE == kFused, "decoder or Haar encoder");
+  static_assert(MODE == kSynth || MODE == kFused || MODE == kLossySub, "mode");
+  constexpr bool kLossy = MODE == kLossySub;
   __shared__ SharedLut lut_s;
   load_lut(&lut_s, ctx.lut);
   const SharedLut& lut = lut_s;
@@ -333,7 +340,12 @@ raht_level_sub_kernel(LevelCtx ctx)
       qpset_quantizers(prm, e.qp_layer, nq0 + ac0, nq1 + ac1, qa);
     }
     if (kEnc) {
-      // integer Haar: no normalisation; forward butterflies of the source
+      // forward butterflies of the source (normalised first unless Haar)
+      if (!haar && w > 1) {
+#pragma unroll
+        for (int k = 0; k < C; k++)
+          src[k] = scale_rsqrt(src[k], w, lut);
+      }
 #pragma unroll
       for (int st = 0; st < 3; st++) {
         const int bit = 1 << st;
@@ -344,14 +356,34 @@ raht_level_sub_kernel(LevelCtx ctx)
         for (int k = 0; k < C; k++) {
           const int64_t own = src[k], oth = shfl_xor_i64(own, bit);
           if (both) {
-            const int64_t hf = left ? oth - own : own - oth;
-            src[k] = left ? own + ((hf >> (1 + kFpFrac)) << kFpFrac) : hf;
+            if (haar) {
+              const int64_t hf = left ? oth - own : own - oth;
+              src[k] = left ? own + ((hf >> (1 + kFpFrac)) << kFpFrac) : hf;
+            } else {
+              src[k] = left ? fp_mul(oth, cb[st]) + fp_mul(ca[st], own)
+                            : fp_mul(own, ca[st]) - fp_mul(cb[st], oth);
+            }
           } else if (swap) {
             src[k] = oth;
           }
         }
       }
     }
+    // RDOQ bookkeeping of the lossy encoder: rank of this lane's coefficient
+    // among the block's coded coefficients, first coefficient index
+    const uint32_t coded_mask = group8_or(coded ? 1u << t : 0u);
+    const int ncoef = popc32(coded_mask);
+    const int crank = inherit_dc ? rank - 1 : rank;         // valid when coded
+    const int cfirst = e.coeff_base + (inherit_dc ? (c0 - sc0) - pj : 0);
+    Quantizer qr[2] = {{1, 1}, {1, 1}};
+    bool last_of_slice = false;
+    if (kLossy && coded)
+      qpset_quantizers(prm, e.qp_layer, nq0, nq1, qr);
+    if (kLossy && on)
+      last_of_slice = wi + 1 >= num_work || ctx.worklist[wi + 1] >= sp1;
+    bool lin_known = false;
+    int lin = -1;
+    int look = wi - 1;  // look-back cursor
     int64_t dc[C];
 #pragma unroll
     for (int k = 0; k < C; k++)
@@ -536,7 +568,150 @@ raht_level_sub_kernel(LevelCtx ctx)
         }
       }
       // coefficients
-      if (coded && ready) {
+      bool commit = ready;
+      if (kLossy) {
+        // ---- RDOQ: descriptor of this lane's coefficient ----------------
+        int64_t res[C], qc[C];
+        uint32_t d = kDescZero;  // lanes without a coefficient: inert
+        if (coded) {
+          int64_t sum_coeff = 0, dist2 = 0;
+          int rate_coeff = 0;
+#pragma unroll
+          for (int k = 0; k < C; k++) {
+            res[k] = enable_pred ? src[k] - pw_[k] : src[k];
+            const int64_t co = fp_round(res[k]);
+            dist2 += co * co;
+            int64_t aq = quantize(qr[k ? 1 : 0], co * 256);
+            aq = aq < 0 ? -aq : aq;
+            sum_coeff += aq;
+            constexpr int lutlog[16] = {0,   256, 406, 512, 594, 662, 719, 768,
+                                        812, 850, 886, 918, 947, 975, 1000,
+                                        1024};
+            rate_coeff += lutlog[aq < 15 ? (int)aq : 15];
+            qc[k] = quantize(qa[k ? 1 : 0], co * 256);
+          }
+          d = kDescNever;
+          if (sum_coeff < 3) {
+            const int64_t l0 = qr[0].step;
+            d = rdoq_threshold(dist2, l0 * l0 * (C == 1 ? 25 : 35), rate_coeff, (uint32_t)n_s);
+            if (sum_coeff == 0)
+              d |= kDescZero;
+          }
+        }
+        // descriptors in coding order: lane r of the group gets rank r
+        uint32_t dr = kDescZero;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const uint32_t du = __shfl(d, gbase | u);
+          const int ru = __shfl(crank, gbase | u);
+          const bool cu = (coded_mask >> u) & 1;
+          if (cu && ru == t)
+            dr = du;
+        }
+        const bool rvalid = t < ncoef;
+        const bool rz = dr >> 31;
+        const uint32_t rthr = dr & kDescNever;
+        const bool isdef = rvalid && !rz && rthr == kDescNever;
+        const bool isthr = rvalid && !rz && rthr != kDescNever && rthr != 0;
+        const int ci = cfirst + t;  // slice-relative index of rank t
+        // least fixed point of "fails iff a reset lies in its window", for
+        // an incoming last-reset index l0 (see raht_rdoq.hpp)
+        auto resolve = [&](int l0, uint32_t* resets_out) -> int {
+          uint32_t resets = group8_or(isdef ? 1u << t : 0u);
+          int lhat = l0;
+#pragma unroll
+          for (int it = 0; it < 8; it++) {
+            const uint32_t below = resets & ((1u << t) - 1);
+            lhat = below ? cfirst + (31 - __clz(below)) : l0;
+            const bool fail = isthr && !((resets >> t) & 1)
+              && (uint32_t)(ci - lhat) <= rthr;
+            resets |= group8_or(fail ? 1u << t : 0u);
+          }
+          const uint32_t below = resets & ((1u << t) - 1);
+          lhat = below ? cfirst + (31 - __clz(below)) : l0;
+          *resets_out = resets;
+          return ci - 1 - lhat;  // zero-run length seen by rank t
+        };
+        uint32_t resets = 0;
+        bool zero_r = false;
+        if (!lin_known && !last_of_slice) {
+          uint32_t ra, rb;
+          const int tza = resolve(-1, &ra);
+          const int tzb = resolve(cfirst - 1, &rb);
+          const bool fa = rvalid && rthr != kDescNever && (uint32_t)tza >= rthr;
+          const bool fb = rvalid && rthr != kDescNever && (uint32_t)tzb >= rthr;
+          const bool same = group8_or((fa != fb) ? 1u : 0u) == 0 && ra == rb;
+          resets = rb;
+          zero_r = fb;
+          if (!same)
+            commit = false;
+        } else if (lin_known) {
+          const int tz = resolve(lin, &resets);
+          zero_r = rvalid && rthr != kDescNever && (uint32_t)tz >= rthr;
+        } else {
+          commit = false;  // the slice's last block always resolves L
+        }
+        if (ready && !commit && !lin_known) {
+          // one look-back attempt: 8 predecessor words per step
+          const int k = look - t;
+          unsigned long long sv = 0;
+          bool boundary = k < 0;
+          if (!boundary)
+            boundary = ctx.worklist[k] < sp0;
+          if (!boundary)
+            sv = __hip_atomic_load(&ctx.rdoq_state[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const bool cur_ep = (sv >> 48) == (unsigned long long)epoch;
+          const int kind = boundary ? 3 : (cur_ep ? (int)((sv >> 32) & 0xffff) : 0);
+          // kind: 0 pending, 1 transparent, 2 final, 3 slice boundary
+          const uint32_t stop = group8_or((kind != 1) ? 1u << t : 0u);
+          if (stop) {
+            const int first = __ffs(stop) - 1;  // nearest predecessor that is not transparent
+            const int fkind = __shfl(kind, gbase | first);
+            const int fval = __shfl((int)(uint32_t)sv, gbase | first);
+            if (fkind == 2) {
+              lin = fval;
+              lin_known = true;
+            } else if (fkind == 3) {
+              lin = ctx.slice_l[s];
+              lin_known = true;
+            }  // pending: try again next iteration
+            if (fkind != 2 && fkind != 3)
+              look -= first;  // everything nearer is transparent
+          } else {
+            look -= 8;
+          }
+        }
+        // flags back to positions, final coefficients, reconstruction
+        bool zero_me = false;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const bool zu = __shfl((int)zero_r, gbase | u);
+          if (coded && crank == u)
+            zero_me = zu;
+        }
+        if (coded && ready && commit) {
+#pragma unroll
+          for (int k = 0; k < C; k++) {
+            const int64_t co = zero_me ? 0 : qc[k];
+            cplane[(size_t)k * n_s] = (int32_t)co;
+            pw_[k] += fp_from_int(dequantize(qa[k ? 1 : 0], co));
+          }
+        }
+        if (ready && commit && t == 0) {
+          // publish the outgoing RDOQ state of this block
+          const unsigned long long ep = (unsigned long long)epoch << 48;
+          unsigned long long word;
+          if (resets)
+            word = ep | (2ull << 32) | (uint32_t)(cfirst + (31 - __clz(resets)));
+          else if (lin_known)
+            word = ep | (2ull << 32) | (uint32_t)lin;
+          else
+            word = ep | (1ull << 32);
+          __hip_atomic_store(&ctx.rdoq_state[wi], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (last_of_slice)
+            ctx.slice_l[s] = resets ? cfirst + (31 - __clz(resets)) : lin;
+        }
+      } else if (coded && ready) {
 #pragma unroll
         for (int k = 0; k < C; k++) {
           int64_t co;
@@ -580,7 +755,7 @@ raht_level_sub_kernel(LevelCtx ctx)
         }
       }
       // commit: children of the ready groups, write-through, then the flag
-      if (ready && has) {
+      if (ready && commit && has) {
 #pragma unroll
         for (int k = 0; k < C; k++) {
           int64_t v = pw_[k];
@@ -592,10 +767,18 @@ raht_level_sub_kernel(LevelCtx ctx)
         ctx.nneigh[cur_par][crow] = inherit_dc ? neigh_count : 19;
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (ready && t == 0)
+      if (ready && commit && t == 0)
         __hip_atomic_store(&ctx.done[j], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      pending = pending && !ready;
+      pending = pending && !(ready && commit);
+      if (!__any(ready && commit)) {
+        // RDOQ look-back did not resolve yet: bounded like the flag wait
+        if (++spins > (1u << 22)) {
+          if (lane == 0)
+            atomicExch(ctx.error, 1);
+          break;
+        }
+      }
     }
   }
 }

@@ -25,11 +25,8 @@ def golden():
 
 
 def on_device_path(params):
-    """Only the LOSSY FORWARD transform with sub-node prediction is kept on the
-    reference CPU path this round (RDOQ state coupled into the block order);
-    the inverse transform and the integer-Haar forward run on the device."""
-    return not (params.raht_prediction_enabled_flag and params.raht_subnode_prediction_enabled_flag
-                and not params.integer_haar_enable_flag)
+    """Every intra parameter combination runs on the device."""
+    return True
 
 
 def golden_or_oracle_coeffs(name, golden, p, morton, attrs, qp):
@@ -82,7 +79,7 @@ def test_random_flags_vs_oracle(seed, ctx):
         haar = bool(rng.integers(2))
         p = raht_params(
             qp=4 if haar else int(rng.integers(4, 52)), chroma_offset=0 if haar else int(rng.integers(-3, 3)),
-            haar=haar, prediction=bool(rng.integers(4) > 0), subnode=bool(haar and rng.integers(2)),
+            haar=haar, prediction=bool(rng.integers(4) > 0), subnode=bool(rng.integers(2)),
             extension=bool(rng.integers(4) > 0), search_range=int(rng.choice([4, 64, 50000])),
             threshold0=int(rng.integers(0, 6)), threshold1=int(rng.integers(0, 12)))
         morton, a, order = synth.sort_by_morton(xyz, attrs)
