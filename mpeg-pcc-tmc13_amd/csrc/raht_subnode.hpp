@@ -444,178 +444,216 @@ raht_level_sub_kernel(LevelCtx ctx)
         dep[slot] = pn[slot];
     }
 
-    bool pending = on;
+    // ---- the staged dependency loop -------------------------------------
+    // stage 0: waiting for neighbour blocks   -> (P) predict + transform,
+    //          results cached in registers
+    // stage 1: waiting for the RDOQ state L (lossy encoder only)
+    // stage 3: committed
+    // A waiting iteration costs only the polls; the expensive part (P) runs
+    // when a group becomes neighbour-ready, the commit part (W) when one can
+    // commit.
+    int stage = on ? 0 : 3;
     unsigned spins = 0;
-    while (__any(pending)) {
+    int64_t pt[C];          // transformed prediction of this position
+    int32_t qc[C];          // tentative quantised coefficients (encoder)
+    uint32_t dr = kDescZero;  // RDOQ descriptor of rank t (lossy encoder)
+    bool l_published = false;
+#pragma unroll
+    for (int k = 0; k < C; k++) {
+      pt[k] = 0;
+      qc[k] = 0;
+    }
+    while (__any(stage != 3)) {
+      bool progressed = false;
+      // ---- (X) neighbour flags ------------------------------------------
       bool unmet = false;
 #pragma unroll
       for (int slot = 0; slot < 3; slot++)
-        if (pending && dep[slot] >= 0
+        if (stage == 0 && dep[slot] >= 0
             && load_agent_i32(&ctx.done[dep[slot]]) != epoch)
           unmet = true;
       const bool blocked = group8_or(unmet ? 1u : 0u) != 0;
-      const bool ready = pending && !blocked;
-      if (!__any(ready)) {
-        if (++spins > (1u << 22)) {
-          if (lane == 0)
-            atomicExch(ctx.error, 1);  // fail loudly instead of hanging
-          break;
-        }
-        __builtin_amdgcn_s_sleep(8);
-        continue;
-      }
+      const bool nready = stage == 0 && !blocked;
 
-      // occupancy + first child of the owned, already processed neighbours
-      int nb_c0[3] = {0, 0, 0};
-      uint32_t nb_occ[3] = {0, 0, 0};
+      if (__any(nready)) {
+        progressed = true;
+        // ---- (P) prediction with child-level terms + transform -----------
+        int nb_c0[3] = {0, 0, 0};
+        uint32_t nb_occ[3] = {0, 0, 0};
 #pragma unroll
-      for (int slot = 0; slot < 3; slot++) {
-        if (ready && dep[slot] >= 0) {
-          const int q = dep[slot];
-          const int qc0 = tv.fc[li + 1][q];
-          const int qn = tv.fc[li + 1][q + 1] - qc0;
-          uint32_t o = 0;
-          for (int u = 0; u < qn; u++)
-            o |= 1u << (int)(tv.key[li][qc0 + u] & 7);
-          nb_c0[slot] = qc0;
-          nb_occ[slot] = o;
-        }
-      }
-
-      int64_t pw_[C];  // working copy: groups that are not ready recompute
-      int ws = wsum;
-#pragma unroll
-      for (int k = 0; k < C; k++)
-        pw_[k] = pred[k];
-
-      // intraDcPred, neighbours 7..18 (tmc3/RAHT.cpp:503-565)
-#pragma unroll
-      for (int i12 = 0; i12 < 12; i12++) {
-        const int i = 7 + i12;
-        const int owner = gbase | ((i - 1) & 7);
-        const int q = __shfl(pn[(i - 1) >> 3], owner);
-        const int qc0 = __shfl(nb_c0[(i - 1) >> 3], owner);
-        const uint32_t qocc = __shfl(nb_occ[(i - 1) >> 3], owner);
-        if (!(run && ready) || q < 0)
-          continue;
-        int64_t v[C];
-#pragma unroll
-        for (int k = 0; k < C; k++)
-          v[k] = prec[(rbase + q) * C + k];
-        if (10 * v[0] <= lim_lo || 10 * v[0] >= lim_hi)
-          continue;
-        if (has && ((neigh_mask(i) >> t) & 1)) {
-          const int sh = occu_shift(i12);
-          const int cpos = i12 < 9 ? t + sh : t - sh;
-          const bool child_ok = cpos >= 0 && cpos < 8 && ((qocc >> cpos) & 1);
-          if (child_ok) {
-            const int cidx_n = qc0 + popc32(qocc & ((1u << cpos) - 1));
-            const int64_t nrow = (int64_t)pt0 + (cidx_n - sc0);
-            const int64_t pwc = prm->pred_weight_child[i12];
-            ws += (int)pwc;
-            const int64_t mul = ext ? pwc : (pwc << kFpFrac);
-#pragma unroll
-            for (int k = 0; k < C; k++)
-              pw_[k] += load_agent_i64(&ctx.rec[cur_par][nrow * C + k]) * mul;
-          } else {
-            const int64_t pwp = prm->pred_weight_parent[i];
-            ws += (int)pwp;
-            const int64_t mul = ext ? pwp : (pwp << kFpFrac);
-#pragma unroll
-            for (int k = 0; k < C; k++)
-              pw_[k] += v[k] * mul;
+        for (int slot = 0; slot < 3; slot++) {
+          if (nready && dep[slot] >= 0) {
+            const int q = dep[slot];
+            const int qc0 = tv.fc[li + 1][q];
+            const int qn = tv.fc[li + 1][q + 1] - qc0;
+            uint32_t o = 0;
+            for (int u = 0; u < qn; u++)
+              o |= 1u << (int)(tv.key[li][qc0 + u] & 7);
+            nb_c0[slot] = qc0;
+            nb_occ[slot] = o;
           }
         }
-      }
-      if (run && has) {
-        const int64_t div = pred_divisor(ws > 0 ? ws : 1);
-#pragma unroll
-        for (int k = 0; k < C; k++) {
-          pw_[k] = fp_mul(pw_[k], div);
-          if (haar)
-            pw_[k] = (pw_[k] >> kFpFrac) << kFpFrac;
-        }
-      }
-      // normalise + forward butterflies of the prediction
-      if (!haar && w > 1 && enable_pred) {
-        const int64_t sq = sqrt_weight(w, lut);
+        int64_t pw_[C];
+        int ws = wsum;
 #pragma unroll
         for (int k = 0; k < C; k++)
-          pw_[k] = fp_mul(pw_[k], sq);
-      }
+          pw_[k] = pred[k];
+        // intraDcPred, neighbours 7..18 (tmc3/RAHT.cpp:503-565)
 #pragma unroll
-      for (int st = 0; st < 3; st++) {
-        const int bit = 1 << st;
-        const bool left = !(t & bit);
-        const bool both = wl[st] && wr[st];
-        const bool swap = !wl[st] && wr[st];
+        for (int i12 = 0; i12 < 12; i12++) {
+          const int i = 7 + i12;
+          const int owner = gbase | ((i - 1) & 7);
+          const int q = __shfl(pn[(i - 1) >> 3], owner);
+          const int qc0 = __shfl(nb_c0[(i - 1) >> 3], owner);
+          const uint32_t qocc = __shfl(nb_occ[(i - 1) >> 3], owner);
+          if (!(run && nready) || q < 0)
+            continue;
+          int64_t v[C];
 #pragma unroll
-        for (int k = 0; k < C; k++) {
-          const int64_t own = pw_[k], oth = shfl_xor_i64(own, bit);
-          if (enable_pred) {
-            if (both) {
-              if (haar) {
-                const int64_t hf = left ? oth - own : own - oth;
-                pw_[k] = left ? own + ((hf >> (1 + kFpFrac)) << kFpFrac) : hf;
-              } else {
-                pw_[k] = left ? fp_mul(oth, cb[st]) + fp_mul(ca[st], own)
-                              : fp_mul(own, ca[st]) - fp_mul(cb[st], oth);
-              }
-            } else if (swap) {
-              pw_[k] = oth;
+          for (int k = 0; k < C; k++)
+            v[k] = prec[(rbase + q) * C + k];
+          if (10 * v[0] <= lim_lo || 10 * v[0] >= lim_hi)
+            continue;
+          if (has && ((neigh_mask(i) >> t) & 1)) {
+            const int sh = occu_shift(i12);
+            const int cpos = i12 < 9 ? t + sh : t - sh;
+            const bool child_ok = cpos >= 0 && cpos < 8 && ((qocc >> cpos) & 1);
+            if (child_ok) {
+              const int cidx_n = qc0 + popc32(qocc & ((1u << cpos) - 1));
+              const int64_t nrow = (int64_t)pt0 + (cidx_n - sc0);
+              const int64_t pwc = prm->pred_weight_child[i12];
+              ws += (int)pwc;
+              const int64_t mul = ext ? pwc : (pwc << kFpFrac);
+#pragma unroll
+              for (int k = 0; k < C; k++)
+                pw_[k] += load_agent_i64(&ctx.rec[cur_par][nrow * C + k]) * mul;
+            } else {
+              const int64_t pwp = prm->pred_weight_parent[i];
+              ws += (int)pwp;
+              const int64_t mul = ext ? pwp : (pwp << kFpFrac);
+#pragma unroll
+              for (int k = 0; k < C; k++)
+                pw_[k] += v[k] * mul;
             }
           }
         }
-      }
-      // coefficients
-      bool commit = ready;
-      if (kLossy) {
-        // ---- RDOQ: descriptor of this lane's coefficient ----------------
-        int64_t res[C], qc[C];
-        uint32_t d = kDescZero;  // lanes without a coefficient: inert
-        if (coded) {
+        if (run && has) {
+          const int64_t div = pred_divisor(ws > 0 ? ws : 1);
+#pragma unroll
+          for (int k = 0; k < C; k++) {
+            pw_[k] = fp_mul(pw_[k], div);
+            if (haar)
+              pw_[k] = (pw_[k] >> kFpFrac) << kFpFrac;
+          }
+        }
+        if (!haar && w > 1 && enable_pred) {
+          const int64_t sq = sqrt_weight(w, lut);
+#pragma unroll
+          for (int k = 0; k < C; k++)
+            pw_[k] = fp_mul(pw_[k], sq);
+        }
+#pragma unroll
+        for (int st = 0; st < 3; st++) {
+          const int bit = 1 << st;
+          const bool left = !(t & bit);
+          const bool both = wl[st] && wr[st];
+          const bool swap = !wl[st] && wr[st];
+#pragma unroll
+          for (int k = 0; k < C; k++) {
+            const int64_t own = pw_[k], oth = shfl_xor_i64(own, bit);
+            if (enable_pred) {
+              if (both) {
+                if (haar) {
+                  const int64_t hf = left ? oth - own : own - oth;
+                  pw_[k] = left ? own + ((hf >> (1 + kFpFrac)) << kFpFrac) : hf;
+                } else {
+                  pw_[k] = left ? fp_mul(oth, cb[st]) + fp_mul(ca[st], own)
+                                : fp_mul(own, ca[st]) - fp_mul(cb[st], oth);
+                }
+              } else if (swap) {
+                pw_[k] = oth;
+              }
+            }
+          }
+        }
+        // encoder: residual, tentative coefficient, RDOQ descriptor
+        uint32_t d = kDescZero;
+        int32_t qn_[C];
+#pragma unroll
+        for (int k = 0; k < C; k++)
+          qn_[k] = 0;
+        if (kEnc && coded) {
           int64_t sum_coeff = 0, dist2 = 0;
           int rate_coeff = 0;
 #pragma unroll
           for (int k = 0; k < C; k++) {
-            res[k] = enable_pred ? src[k] - pw_[k] : src[k];
-            const int64_t co = fp_round(res[k]);
-            dist2 += co * co;
-            int64_t aq = quantize(qr[k ? 1 : 0], co * 256);
-            aq = aq < 0 ? -aq : aq;
-            sum_coeff += aq;
-            constexpr int lutlog[16] = {0,   256, 406, 512, 594, 662, 719, 768,
-                                        812, 850, 886, 918, 947, 975, 1000,
-                                        1024};
-            rate_coeff += lutlog[aq < 15 ? (int)aq : 15];
-            qc[k] = quantize(qa[k ? 1 : 0], co * 256);
+            const int64_t res = enable_pred ? src[k] - pw_[k] : src[k];
+            const int64_t co = fp_round(res);
+            qn_[k] = (int32_t)quantize(qa[k ? 1 : 0], co * 256);
+            if (kLossy) {
+              dist2 += co * co;
+              int64_t aq = quantize(qr[k ? 1 : 0], co * 256);
+              aq = aq < 0 ? -aq : aq;
+              sum_coeff += aq;
+              constexpr int lutlog[16] = {0,   256, 406, 512, 594, 662, 719, 768,
+                                          812, 850, 886, 918, 947, 975, 1000,
+                                          1024};
+              rate_coeff += lutlog[aq < 15 ? (int)aq : 15];
+            }
           }
-          d = kDescNever;
-          if (sum_coeff < 3) {
-            const int64_t l0 = qr[0].step;
-            d = rdoq_threshold(dist2, l0 * l0 * (C == 1 ? 25 : 35), rate_coeff, (uint32_t)n_s);
-            if (sum_coeff == 0)
-              d |= kDescZero;
-          }
-        }
-        // descriptors in coding order: lane r of the group gets rank r
-        uint32_t dr = kDescZero;
+          if (kLossy) {
+            d = kDescNever;
+            if (sum_coeff < 3) {
+              const int64_t l0 = qr[0].step;
+              d = rdoq_threshold(dist2, l0 * l0 * (C == 1 ? 25 : 35), rate_coeff, (uint32_t)n_s);
+              if (sum_coeff == 0) {
+                // an all-zero coefficient never resets; whether RDOQ "zeroes"
+                // it only matters if the AC-offset quantiser made the
+                // tentative value non-zero -- otherwise it must not make the
+                // block wait for L
+                bool any = false;
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-          const uint32_t du = __shfl(d, gbase | u);
-          const int ru = __shfl(crank, gbase | u);
-          const bool cu = (coded_mask >> u) & 1;
-          if (cu && ru == t)
-            dr = du;
+                for (int k = 0; k < C; k++)
+                  any |= qn_[k] != 0;
+                d = (any ? d : 0u) | kDescZero;
+              }
+            }
+          }
         }
+        uint32_t drn = kDescZero;
+        if (kLossy) {
+          // descriptors in coding order: lane r of the group gets rank r
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            const uint32_t du = __shfl(d, gbase | u);
+            const int ru = __shfl(crank, gbase | u);
+            if (((coded_mask >> u) & 1) && ru == t)
+              drn = du;
+          }
+        }
+        if (nready) {
+#pragma unroll
+          for (int k = 0; k < C; k++) {
+            pt[k] = pw_[k];
+            qc[k] = qn_[k];
+          }
+          dr = drn;
+          stage = 1;
+        }
+      }
+
+      // ---- (Z) RDOQ state: can the stage-1 groups commit? ----------------
+      bool can = stage == 1;
+      bool zero_r = false;
+      if (kLossy) {
         const bool rvalid = t < ncoef;
         const bool rz = dr >> 31;
         const uint32_t rthr = dr & kDescNever;
         const bool isdef = rvalid && !rz && rthr == kDescNever;
         const bool isthr = rvalid && !rz && rthr != kDescNever && rthr != 0;
         const int ci = cfirst + t;  // slice-relative index of rank t
-        // least fixed point of "fails iff a reset lies in its window", for
-        // an incoming last-reset index l0 (see raht_rdoq.hpp)
+        // least fixed point of "fails iff a reset lies in its window" for an
+        // incoming last-reset index l0 (see raht_rdoq.hpp)
         auto resolve = [&](int l0, uint32_t* resets_out) -> int {
           uint32_t resets = group8_or(isdef ? 1u << t : 0u);
           int lhat = l0;
@@ -633,8 +671,10 @@ raht_level_sub_kernel(LevelCtx ctx)
           return ci - 1 - lhat;  // zero-run length seen by rank t
         };
         uint32_t resets = 0;
-        bool zero_r = false;
-        if (!lin_known && !last_of_slice) {
+        if (lin_known) {
+          const int tz = resolve(lin, &resets);
+          zero_r = rvalid && rthr != kDescNever && (uint32_t)tz >= rthr;
+        } else {
           uint32_t ra, rb;
           const int tza = resolve(-1, &ra);
           const int tzb = resolve(cfirst - 1, &rb);
@@ -643,28 +683,39 @@ raht_level_sub_kernel(LevelCtx ctx)
           const bool same = group8_or((fa != fb) ? 1u : 0u) == 0 && ra == rb;
           resets = rb;
           zero_r = fb;
-          if (!same)
-            commit = false;
-        } else if (lin_known) {
-          const int tz = resolve(lin, &resets);
-          zero_r = rvalid && rthr != kDescNever && (uint32_t)tz >= rthr;
-        } else {
-          commit = false;  // the slice's last block always resolves L
+          // outgoing L known before the decisions are: both hypotheses end
+          // with the same last reset -> publish it now, successors go on
+          const int la = ra ? 31 - __clz(ra) : -1, lb = rb ? 31 - __clz(rb) : -1;
+          if (stage == 1 && !l_published && ra && la == lb) {
+            if (t == 0)
+              __hip_atomic_store(
+                &ctx.rdoq_state[wi],
+                ((unsigned long long)epoch << 48) | (2ull << 32) | (uint32_t)(cfirst + lb),
+                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            l_published = true;
+            progressed = true;
+          }
+          if (!same || last_of_slice)
+            can = false;
         }
-        if (ready && !commit && !lin_known) {
-          // one look-back attempt: 8 predecessor words per step
-          const int k = look - t;
-          unsigned long long sv = 0;
-          bool boundary = k < 0;
-          if (!boundary)
-            boundary = ctx.worklist[k] < sp0;
-          if (!boundary)
-            sv = __hip_atomic_load(&ctx.rdoq_state[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const bool cur_ep = (sv >> 48) == (unsigned long long)epoch;
-          const int kind = boundary ? 3 : (cur_ep ? (int)((sv >> 32) & 0xffff) : 0);
-          // kind: 0 pending, 1 transparent, 2 final, 3 slice boundary
-          const uint32_t stop = group8_or((kind != 1) ? 1u << t : 0u);
-          if (stop) {
+        // look-back for the groups that need L: up to 8 steps of 8 words
+        if (stage == 1 && !can && !lin_known) {
+          for (int step = 0; step < 8 && !lin_known; step++) {
+            const int k = look - t;
+            unsigned long long sv = 0;
+            bool boundary = k < 0;
+            if (!boundary)
+              boundary = ctx.worklist[k] < sp0;
+            if (!boundary)
+              sv = __hip_atomic_load(&ctx.rdoq_state[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool cur_ep = (sv >> 48) == (unsigned long long)epoch;
+            // kind: 0 pending, 1 transparent, 2 final, 3 slice boundary
+            const int kind = boundary ? 3 : (cur_ep ? (int)((sv >> 32) & 0xffff) : 0);
+            const uint32_t stop = group8_or((kind != 1) ? 1u << t : 0u);
+            if (!stop) {
+              look -= 8;
+              continue;
+            }
             const int first = __ffs(stop) - 1;  // nearest predecessor that is not transparent
             const int fkind = __shfl(kind, gbase | first);
             const int fval = __shfl((int)(uint32_t)sv, gbase | first);
@@ -674,30 +725,19 @@ raht_level_sub_kernel(LevelCtx ctx)
             } else if (fkind == 3) {
               lin = ctx.slice_l[s];
               lin_known = true;
-            }  // pending: try again next iteration
-            if (fkind != 2 && fkind != 3)
-              look -= first;  // everything nearer is transparent
-          } else {
-            look -= 8;
+            } else {
+              look -= first;  // pending: everything nearer is transparent
+              break;
+            }
+          }
+          if (lin_known) {
+            progressed = true;
+            const int tz = resolve(lin, &resets);
+            zero_r = rvalid && rthr != kDescNever && (uint32_t)tz >= rthr;
+            can = true;
           }
         }
-        // flags back to positions, final coefficients, reconstruction
-        bool zero_me = false;
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-          const bool zu = __shfl((int)zero_r, gbase | u);
-          if (coded && crank == u)
-            zero_me = zu;
-        }
-        if (coded && ready && commit) {
-#pragma unroll
-          for (int k = 0; k < C; k++) {
-            const int64_t co = zero_me ? 0 : qc[k];
-            cplane[(size_t)k * n_s] = (int32_t)co;
-            pw_[k] += fp_from_int(dequantize(qa[k ? 1 : 0], co));
-          }
-        }
-        if (ready && commit && t == 0) {
+        if (can && t == 0) {
           // publish the outgoing RDOQ state of this block
           const unsigned long long ep = (unsigned long long)epoch << 48;
           unsigned long long word;
@@ -711,73 +751,92 @@ raht_level_sub_kernel(LevelCtx ctx)
           if (last_of_slice)
             ctx.slice_l[s] = resets ? cfirst + (31 - __clz(resets)) : lin;
         }
-      } else if (coded && ready) {
-#pragma unroll
-        for (int k = 0; k < C; k++) {
-          int64_t co;
-          if (kEnc) {
-            const int64_t res = enable_pred ? src[k] - pw_[k] : src[k];
-            co = quantize(qa[k ? 1 : 0], fp_round(res) * 256);
-            cplane[(size_t)k * n_s] = (int32_t)co;
-          } else {
-            co = cplane[(size_t)k * n_s];
-          }
-          pw_[k] += fp_from_int(dequantize(qa[k ? 1 : 0], co));
-        }
       }
-      if (on && inherit_dc && t == 0) {
+
+      if (__any(can)) {
+        progressed = true;
+        // ---- (W) coefficients, DC, inverse transform, commit ---------------
+        int64_t pw_[C];
 #pragma unroll
         for (int k = 0; k < C; k++)
-          pw_[k] = dc[k];
-      }
-      // inverse butterflies
+          pw_[k] = pt[k];
+        bool zero_me = false;
+        if (kLossy) {
 #pragma unroll
-      for (int st = 2; st >= 0; st--) {
-        const int bit = 1 << st;
-        const bool left = !(t & bit);
-        const bool both = wl[st] && wr[st];
-        const bool swap = !wl[st] && wr[st];
-#pragma unroll
-        for (int k = 0; k < C; k++) {
-          const int64_t own = pw_[k], oth = shfl_xor_i64(own, bit);
-          if (both) {
-            if (haar) {
-              const int64_t lf = left ? own : oth, hf = left ? oth : own;
-              const int64_t lv = lf - ((hf >> (1 + kFpFrac)) << kFpFrac);
-              pw_[k] = left ? lv : hf + lv;
-            } else {
-              pw_[k] = left ? fp_mul(own, ca[st]) - fp_mul(cb[st], oth)
-                            : fp_mul(oth, cb[st]) + fp_mul(ca[st], own);
-            }
-          } else if (swap) {
-            pw_[k] = oth;
+          for (int u = 0; u < 8; u++) {
+            const bool zu = __shfl((int)zero_r, gbase | u);
+            if (coded && crank == u)
+              zero_me = zu;
           }
         }
-      }
-      // commit: children of the ready groups, write-through, then the flag
-      if (ready && commit && has) {
+        if (coded && can) {
 #pragma unroll
-        for (int k = 0; k < C; k++) {
-          int64_t v = pw_[k];
-          ctx.rec_us[cur_par][crow * C + k] = ext ? v : fp_round(v * 4);
-          if (!haar && w > 1)
-            v = scale_rsqrt(v, w, lut);
-          store_agent_i64(&ctx.rec[cur_par][crow * C + k], ext ? v : fp_round(v));
+          for (int k = 0; k < C; k++) {
+            int64_t co;
+            if (kEnc) {
+              co = zero_me ? 0 : qc[k];
+              cplane[(size_t)k * n_s] = (int32_t)co;
+            } else {
+              co = cplane[(size_t)k * n_s];
+            }
+            pw_[k] += fp_from_int(dequantize(qa[k ? 1 : 0], co));
+          }
         }
-        ctx.nneigh[cur_par][crow] = inherit_dc ? neigh_count : 19;
+        if (on && inherit_dc && t == 0) {
+#pragma unroll
+          for (int k = 0; k < C; k++)
+            pw_[k] = dc[k];
+        }
+#pragma unroll
+        for (int st = 2; st >= 0; st--) {
+          const int bit = 1 << st;
+          const bool left = !(t & bit);
+          const bool both = wl[st] && wr[st];
+          const bool swap = !wl[st] && wr[st];
+#pragma unroll
+          for (int k = 0; k < C; k++) {
+            const int64_t own = pw_[k], oth = shfl_xor_i64(own, bit);
+            if (both) {
+              if (haar) {
+                const int64_t lf = left ? own : oth, hf = left ? oth : own;
+                const int64_t lv = lf - ((hf >> (1 + kFpFrac)) << kFpFrac);
+                pw_[k] = left ? lv : hf + lv;
+              } else {
+                pw_[k] = left ? fp_mul(own, ca[st]) - fp_mul(cb[st], oth)
+                              : fp_mul(oth, cb[st]) + fp_mul(ca[st], own);
+              }
+            } else if (swap) {
+              pw_[k] = oth;
+            }
+          }
+        }
+        // children of the committing groups, write-through, then the flag
+        if (can && has) {
+#pragma unroll
+          for (int k = 0; k < C; k++) {
+            int64_t v = pw_[k];
+            ctx.rec_us[cur_par][crow * C + k] = ext ? v : fp_round(v * 4);
+            if (!haar && w > 1)
+              v = scale_rsqrt(v, w, lut);
+            store_agent_i64(&ctx.rec[cur_par][crow * C + k], ext ? v : fp_round(v));
+          }
+          ctx.nneigh[cur_par][crow] = inherit_dc ? neigh_count : 19;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (can && t == 0)
+          __hip_atomic_store(&ctx.done[j], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (can)
+          stage = 3;
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (ready && commit && t == 0)
-        __hip_atomic_store(&ctx.done[j], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      pending = pending && !(ready && commit);
-      if (!__any(ready && commit)) {
-        // RDOQ look-back did not resolve yet: bounded like the flag wait
-        if (++spins > (1u << 22)) {
+
+      if (!progressed) {
+        if (++spins > (1u << 24)) {
           if (lane == 0)
-            atomicExch(ctx.error, 1);
+            atomicExch(ctx.error, 1);  // fail loudly instead of hanging
           break;
         }
+        __builtin_amdgcn_s_sleep(4);
       }
     }
   }
