@@ -191,6 +191,29 @@ def main():
                 "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(kt.items(), key=lambda kv: -kv[1][0])},
                 "kernel_sum_ms_per_step": round(total_ms / args.steps, 4),
             }
+        # ---- the same frames with the reference's DEFAULT flags ------------
+        # (raht_subnode_prediction_enabled_flag = 1: blocks of a level depend
+        # on earlier blocks of the level -- latency-bound)
+        if not args.subnode and args.direction == "both":
+            p1 = p.copy()
+            p1.raht_subnode_prediction_enabled_flag = 1
+            p_saved = p
+            def step1():
+                d_attrs.copy_(src)
+                ctx.dev_raht_forward(p1, offsets, d_morton.data_ptr(), d_attrs.data_ptr(), d_coeffs.data_ptr(), c)
+                ctx.dev_raht_inverse(p1, offsets, d_morton.data_ptr(), d_dec.data_ptr(), d_coeffs.data_ptr(), c)
+            step1()
+            torch.cuda.synchronize(dev)
+            k1 = 3
+            t1 = time.perf_counter()
+            for _ in range(k1):
+                step1()
+            torch.cuda.synchronize(dev)
+            dt1 = (time.perf_counter() - t1) / k1
+            out["ctc_default_flags"] = {
+                "raht_subnode_prediction": 1, "value": round(n / dt1 / 1e6, 3), "unit": "Mpoints/s",
+                "ms_per_step": round(dt1 * 1e3, 3), "steps": k1,
+                "roundtrip_decoder_equals_encoder_recon": bool(torch.equal(d_attrs, d_dec))}
         # ---- CPU baseline: the compiled reference on one host core --------
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames[0], p, c)

@@ -165,6 +165,92 @@ int gpcc_dev_attr_morton_sort(
   gpcc_ctx* ctx, int32_t num_slices, const int64_t* offsets,
   const void* d_xyz, void* d_morton, void* d_order);
 
+/* ------------------------------------------------------------------ */
+/* lifting transform (predictors given)                                 */
+
+#define GPCC_MAX_LODS 32
+
+/* What encode/decode{Colors,Reflectances}Lift (AttributeEncoder.cpp:1379-1648,
+ * AttributeDecoder.cpp:678-857) read besides the LoD structure: the
+ * cumulative LoD sizes (AttributeLods::numPointsInLod, coarse to fine), the
+ * QpSet (fixed_point_qp_offset = 24 for lifting, quantization.cpp:155-158),
+ * the bit depth for the final clip and the last-component-prediction flag. */
+typedef struct gpcc_lift_params {
+  int32_t num_lods;
+  int32_t num_points_in_lod[GPCC_MAX_LODS];
+  int32_t last_component_prediction_enabled_flag;
+  int32_t bitdepth;
+  int32_t num_qp_layers;
+  int32_t layer_qp[GPCC_MAX_QP_LAYERS][2];
+  int32_t max_qp;
+  int32_t fixed_point_qp_offset;
+} gpcc_lift_params;
+
+/* The predictors of AttributeLods (AttributeCommon.h:89-94) as flat arrays in
+ * PREDICTOR order (coding order, coarsest LoD first), after
+ * PCCPredictor::computeWeights:
+ *   neigh_count [n]     PCCPredictor::neighborCount (0..3)
+ *   neigh_index [n][3]  PCCNeighborInfo::predictorIndex (< start of the LoD)
+ *   neigh_weight[n][3]  PCCNeighborInfo::weight (8-bit fixed point, sum 256)
+ *   indexes     [n]     AttributeLods::indexes: predictor order -> point index
+ *   qp_off      [n][2]  region QP offset of each POINT (QpSet::regionQpOffset),
+ *                       NULL = none
+ * Forward: replaces the body of encodeColorsLift / encodeReflectancesLift
+ * minus the entropy calls.  attrs [n][c] in point order: in source, out the
+ * reconstructed (rounded, clipped) attributes, as the reference writes them
+ * back with setColor/setReflectance.  coeffs [n][c] out: the quantised
+ * values of each predictor in coding order (`values[]`, the input of
+ * PCCResidualsEncoder::encode and of the zero-run counter).  lcp_coeffs
+ * [GPCC_MAX_LODS] out: AttributeBrickHeader::attrLcpCoeffs (c == 3 and the
+ * flag set, otherwise untouched). */
+int gpcc_lift_forward(
+  gpcc_ctx* ctx, const gpcc_lift_params* params, int32_t n, int32_t c,
+  const int32_t* neigh_count, const int32_t* neigh_index,
+  const int32_t* neigh_weight, const int32_t* indexes, const int32_t* qp_off,
+  int32_t* attrs, int32_t* coeffs, int8_t* lcp_coeffs);
+
+/* Replaces decodeColorsLift / decodeReflectancesLift after the entropy
+ * decode: coeffs and lcp_coeffs in, attrs [n][c] (point order) out. */
+int gpcc_lift_inverse(
+  gpcc_ctx* ctx, const gpcc_lift_params* params, int32_t n, int32_t c,
+  const int32_t* neigh_count, const int32_t* neigh_index,
+  const int32_t* neigh_weight, const int32_t* indexes, const int32_t* qp_off,
+  int32_t* attrs, const int32_t* coeffs, const int8_t* lcp_coeffs);
+
+/* Flattened LoD-generation parameters: the AttributeParameterSet fields
+ * buildPredictorsFast reads (hls.h:782-876) plus
+ * AttributeBrickHeader::attr_dist2_delta.  The LoD structure itself
+ * (sub-sampling + neighbour search, PCCTMC3Common.h:1147-2469) is still
+ * built by the reference's AttributeLods::generate on the host this round;
+ * the struct is the parameter block of that call for tests and tools. */
+typedef struct gpcc_lod_params {
+  int32_t attr_encoding;           /* 1 predicting, 2 lifting */
+  int32_t lod_decimation_type;     /* LodDecimationMethod */
+  int32_t num_detail_levels_minus1;
+  int32_t num_pred_nearest_neighbours_minus1;
+  int32_t intra_lod_search_range;
+  int32_t inter_lod_search_range;
+  int32_t prediction_with_distribution_enabled;
+  int32_t lod_neigh_bias[3];
+  int32_t intra_lod_prediction_skip_layers;
+  int32_t dist2;
+  int32_t attr_dist2_delta;
+  int32_t canonical_point_order_flag;
+  int32_t max_points_per_sort_log2_plus1;
+  int32_t scalable_lifting_enabled_flag;
+  int32_t max_neigh_range_minus1;
+  int32_t pred_weight_blending_enabled_flag;
+  int32_t lod_sampling_period[GPCC_MAX_LODS];
+} gpcc_lod_params;
+
+/* PCCPredictor::computeWeights (PCCTMC3Common.h:589-633) for n predictors:
+ * squared distances in neigh_weight (uint64 [n][3]) -> 8-bit weights
+ * (int32 [n][3]); neigh_count is updated in place (far neighbours are
+ * dropped). */
+int gpcc_lod_compute_weights(
+  gpcc_ctx* ctx, int32_t n, int32_t* neigh_count, const uint64_t* dist2,
+  int32_t* neigh_weight);
+
 /* Per-kernel timing of the most recent gpcc_dev_raht_* call on this
  * context, measured with HIP events on the context's stream when
  * profiling is enabled (gpcc_ctx_set_profiling(ctx, 1)).  Returns the

@@ -84,3 +84,91 @@ def raht_params(qp=34, chroma_offset=-1, bitdepth=8, prediction=True,
     p.fixed_point_qp_offset = 0          # RAHT: quantization.cpp:155-158
     p.set_ac_offsets(ac_offsets or [])
     return p
+
+
+GPCC_MAX_LODS = 32
+
+
+class LiftParams(C.Structure):
+    """ctypes mirror of gpcc_lift_params."""
+    _fields_ = [
+        ("num_lods", C.c_int32),
+        ("num_points_in_lod", C.c_int32 * GPCC_MAX_LODS),
+        ("last_component_prediction_enabled_flag", C.c_int32),
+        ("bitdepth", C.c_int32),
+        ("num_qp_layers", C.c_int32),
+        ("layer_qp", (C.c_int32 * 2) * GPCC_MAX_QP_LAYERS),
+        ("max_qp", C.c_int32),
+        ("fixed_point_qp_offset", C.c_int32),
+    ]
+
+
+def lift_params(num_points_in_lod, qp=34, chroma_offset=-1, bitdepth=8, lcp=True, layers=None):
+    """Effective values of cfg/octree-liftt-ctc-lossless-geom-lossy-attrs.yaml
+    (transformType 2): fixedPointQpOffset = (kFixedPointWeightShift / 2) * 6
+    = 24 (quantization.cpp:155-158), last component prediction on."""
+    p = LiftParams()
+    npl = [int(v) for v in num_points_in_lod]
+    assert 1 <= len(npl) <= GPCC_MAX_LODS
+    p.num_lods = len(npl)
+    for i, v in enumerate(npl):
+        p.num_points_in_lod[i] = v
+    p.last_component_prediction_enabled_flag = int(lcp)
+    p.bitdepth = bitdepth
+    lay = layers if layers is not None else [(qp, chroma_offset)]
+    p.num_qp_layers = len(lay)
+    for i, (a, b) in enumerate(lay):
+        p.layer_qp[i][0] = a
+        p.layer_qp[i][1] = b
+    p.max_qp = 51 + 6 * (bitdepth - 8)
+    p.fixed_point_qp_offset = 24
+    return p
+
+
+class LodParams(C.Structure):
+    """Flattened LoD-generation parameters (AttributeParameterSet LoD fields +
+    AttributeBrickHeader::attr_dist2_delta) handed to AttributeLods::generate
+    (reference tmc3/AttributeCommon.cpp:44-72)."""
+    _fields_ = [
+        ("attr_encoding", C.c_int32),            # 1 predicting, 2 lifting
+        ("lod_decimation_type", C.c_int32),      # 0 distance, 1 periodic, 2 centroid
+        ("num_detail_levels_minus1", C.c_int32),
+        ("num_pred_nearest_neighbours_minus1", C.c_int32),
+        ("intra_lod_search_range", C.c_int32),
+        ("inter_lod_search_range", C.c_int32),
+        ("prediction_with_distribution_enabled", C.c_int32),
+        ("lod_neigh_bias", C.c_int32 * 3),
+        ("intra_lod_prediction_skip_layers", C.c_int32),
+        ("dist2", C.c_int32),
+        ("attr_dist2_delta", C.c_int32),
+        ("canonical_point_order_flag", C.c_int32),
+        ("max_points_per_sort_log2_plus1", C.c_int32),
+        ("scalable_lifting_enabled_flag", C.c_int32),
+        ("max_neigh_range_minus1", C.c_int32),
+        ("pred_weight_blending_enabled_flag", C.c_int32),
+        ("lod_sampling_period", C.c_int32 * GPCC_MAX_LODS),
+    ]
+
+
+def lod_params(levels=12, decimation=0, dist2=0, dist2_delta=0, neighbours=3, lifting=True,
+               distribution=True, bias=(1, 1, 1), inter_range=1100000, intra_range=0,
+               sampling_period=4):
+    """cfg/octree-liftt-ctc-*.yaml after encoder.cpp:799-808 (search ranges
+    of -1 become 1100000): 12 detail levels, distance decimation, three
+    nearest neighbours, distribution-aware third neighbour."""
+    p = LodParams()
+    p.attr_encoding = 2 if lifting else 1
+    p.lod_decimation_type = decimation
+    p.num_detail_levels_minus1 = levels - 1
+    p.num_pred_nearest_neighbours_minus1 = neighbours - 1
+    p.intra_lod_search_range = intra_range
+    p.inter_lod_search_range = inter_range
+    p.prediction_with_distribution_enabled = int(distribution)
+    for i in range(3):
+        p.lod_neigh_bias[i] = bias[i]
+    p.intra_lod_prediction_skip_layers = 0x7FFFFFFF
+    p.dist2 = dist2
+    p.attr_dist2_delta = dist2_delta
+    for i in range(GPCC_MAX_LODS):
+        p.lod_sampling_period[i] = sampling_period
+    return p

@@ -257,3 +257,6 @@ ref_div_approx(int64_t a, uint64_t b, int32_t log2scale)
 }
 
 }  // extern "C"
+
+#include "io_hls.h"
+#include "ref_lod_harness.inc"

@@ -1,0 +1,77 @@
+"""ctypes access to the LoD / lifting entry points of the two CPU checkers
+(TEST INFRASTRUCTURE)."""
+import ctypes as C
+
+import numpy as np
+
+import oracle_loader as ol
+
+i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+u64p = np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")
+u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+
+
+def ref_lod_generate(xyz, lp, raw=False):
+    """reference AttributeLods::generate (raw: buildPredictorsFast only) ->
+    dict(nc [n], ni [n,3], w [n,3] uint64, indexes [n], npl [L])"""
+    lib = ol.ref().lib
+    lib.ref_lod_generate.argtypes = [C.c_void_p, i32p, C.c_int32, C.c_int32, i32p, i32p, u64p, i32p, i32p,
+                                     C.POINTER(C.c_int32)]
+    xyz = np.ascontiguousarray(xyz, dtype=np.int32)
+    n = len(xyz)
+    nc = np.zeros(n, np.int32)
+    ni = np.zeros((n, 3), np.int32)
+    w = np.zeros((n, 3), np.uint64)
+    idx = np.zeros(n, np.int32)
+    npl = np.zeros(32, np.int32)
+    nl = C.c_int32()
+    rc = lib.ref_lod_generate(C.addressof(lp), xyz.reshape(-1), n, int(raw), nc, ni.reshape(-1), w.reshape(-1),
+                              idx, npl, C.byref(nl))
+    assert rc == 0
+    return dict(nc=nc, ni=ni, w=w, indexes=idx, npl=npl[:nl.value].copy())
+
+
+def compute_weights(checker, nc, dist2):
+    f = checker.fn("compute_weights", None, [C.c_int32, i32p, u64p])
+    nc2 = np.ascontiguousarray(nc, dtype=np.int32).copy()
+    w = np.ascontiguousarray(dist2, dtype=np.uint64).copy()
+    f(len(nc2), nc2, w.reshape(-1))
+    return nc2, w
+
+
+def lift(checker, forward, lf, lod, attrs, coeffs=None, lcp=None, qp_off=None):
+    """-> (coeffs [n,c] coding order, recon [n,c] point order, lcp int8[32])"""
+    name = "lift_forward" if forward else "lift_inverse"
+    f = checker.fn(name, C.c_int, [C.c_void_p, C.c_int32, C.c_int32, i32p, i32p, i32p, i32p, C.c_void_p, i32p,
+                                   i32p, C.c_void_p])
+    n = len(lod["nc"])
+    a = np.ascontiguousarray(attrs, dtype=np.int32).copy() if forward else np.zeros_like(np.asarray(attrs, np.int32))
+    c = a.shape[1]
+    co = np.zeros((n, c), np.int32) if forward else np.ascontiguousarray(coeffs, dtype=np.int32).copy()
+    l = (C.c_int8 * 32)()
+    if lcp is not None:
+        for i in range(32):
+            l[i] = int(lcp[i])
+    q = None if qp_off is None else np.ascontiguousarray(qp_off, dtype=np.int32)
+    rc = f(C.addressof(lf), n, c, lod["nc"], np.ascontiguousarray(lod["ni"]).reshape(-1),
+           np.ascontiguousarray(lod["w"].astype(np.int32)).reshape(-1), lod["indexes"],
+           q.ctypes.data_as(C.c_void_p) if q is not None else None, a.reshape(-1), co.reshape(-1), l)
+    assert rc == 0
+    return co, a, np.array(list(l), dtype=np.int8)
+
+
+def ref_operator_roundtrip(lp, transform, rp, qp, chroma, bitdepth, lcp, xyz, attrs):
+    """reference AttributeEncoder::encode + AttributeDecoder::decode ->
+    (payload bytes, recon_enc, recon_dec)"""
+    lib = ol.ref().lib
+    lib.ref_operator_roundtrip.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                           C.c_int32, i32p, i32p, C.c_int32, C.c_int32, i32p, i32p, u8p, C.c_int32]
+    xyz = np.ascontiguousarray(xyz, dtype=np.int32)
+    attrs = np.ascontiguousarray(attrs, dtype=np.int32)
+    n, c = attrs.shape
+    re = np.zeros(n * c, np.int32)
+    rd = np.zeros(n * c, np.int32)
+    pay = np.zeros(n * c * 8 + 4096, np.uint8)
+    ln = lib.ref_operator_roundtrip(C.addressof(lp), transform, C.addressof(rp), qp, chroma, bitdepth, int(lcp),
+                                    xyz.reshape(-1), attrs.reshape(-1), n, c, re, rd, pay, pay.size)
+    return pay[:ln].tobytes(), re.reshape(n, c), rd.reshape(n, c)
