@@ -32,6 +32,7 @@
 #include "raht_rdoq.hpp"
 #include "raht_subnode.hpp"
 #include "raht_tree.hpp"
+#include "lift_kernels.hpp"
 #include "morton_sort.hpp"
 
 using namespace gpcc;
@@ -645,6 +646,256 @@ host_transform(
   return r;
 }
 
+
+// ---- lifting transform ---------------------------------------------------
+
+struct LiftDev {
+  const int32_t *nc, *ni, *nw, *indexes, *qp_off;
+  int32_t *attrs, *coeffs;
+};
+
+int
+check_lift_params(const gpcc_lift_params* p, int n, int c)
+{
+  if (!p)
+    return fail(GPCC_ERR_INVALID_ARG, "params is null");
+  if (n <= 0 || c < 1 || c > 3)
+    return fail(GPCC_ERR_INVALID_ARG, "n <= 0 or attribute count not 1..3");
+  if (p->num_lods < 1 || p->num_lods > GPCC_MAX_LODS)
+    return fail(GPCC_ERR_INVALID_ARG, "num_lods out of range");
+  if (p->num_points_in_lod[p->num_lods - 1] != n)
+    return fail(GPCC_ERR_INVALID_ARG, "num_points_in_lod does not end at n");
+  for (int l = 1; l < p->num_lods; l++)
+    if (p->num_points_in_lod[l] < p->num_points_in_lod[l - 1])
+      return fail(GPCC_ERR_INVALID_ARG, "num_points_in_lod not ascending");
+  if (p->num_qp_layers < 1 || p->num_qp_layers > GPCC_MAX_QP_LAYERS)
+    return fail(GPCC_ERR_INVALID_ARG, "num_qp_layers out of range");
+  return GPCC_OK;
+}
+
+template<int C>
+int
+launch_lift(
+  gpcc_ctx* ctx, bool encoder, const gpcc_lift_params* p, int n,
+  const LiftDev& d, int8_t* d_lcp_io, char* scratch)
+{
+  hipStream_t st = ctx->stream;
+  LiftCtx cx{};
+  cx.n = n;
+  cx.c = C;
+  cx.num_lods = p->num_lods;
+  for (int l = 0; l < p->num_lods; l++)
+    cx.npl[l] = p->num_points_in_lod[l];
+  // replay the reference's running counters over the distinct LoD
+  // boundaries (AttributeEncoder.cpp:1430-1440)
+  {
+    int ql = 0, lod = 0, nr = 0;
+    cx.range_start[nr] = 0;
+    cx.range_qlayer[nr] = 0;
+    cx.range_lcp[nr] = 0;
+    nr++;
+    int prev = -1;
+    for (int l = 0; l < p->num_lods; l++) {
+      const int b = p->num_points_in_lod[l];
+      if (b == prev || b >= n || b == 0) {
+        prev = b;
+        if (b == 0) {
+          // index 0 itself is a boundary: the counters step before the
+          // first coefficient
+          if (cx.range_start[0] == 0 && nr == 1) {
+            if (0 == p->num_points_in_lod[ql])
+              ql = std::min(p->num_qp_layers - 1, ql + 1);
+            if (lod < p->num_lods && 0 == p->num_points_in_lod[lod])
+              lod++;
+            cx.range_qlayer[0] = ql;
+            cx.range_lcp[0] = lod;
+          }
+        }
+        continue;
+      }
+      prev = b;
+      if (b == p->num_points_in_lod[ql])
+        ql = std::min(p->num_qp_layers - 1, ql + 1);
+      if (lod < p->num_lods && b == p->num_points_in_lod[lod])
+        lod++;
+      cx.range_start[nr] = b;
+      cx.range_qlayer[nr] = ql;
+      cx.range_lcp[nr] = std::min(lod, GPCC_MAX_LODS - 1);
+      nr++;
+    }
+    cx.num_ranges = nr;
+  }
+  cx.lcp_enabled = p->last_component_prediction_enabled_flag && C == 3;
+  cx.bitdepth = p->bitdepth;
+  cx.num_qp_layers = p->num_qp_layers;
+  memcpy(cx.layer_qp, p->layer_qp, sizeof(cx.layer_qp));
+  cx.max_qp = p->max_qp;
+  cx.fixed_point_qp_offset = p->fixed_point_qp_offset;
+  cx.nc = d.nc;
+  cx.ni = d.ni;
+  cx.nw = d.nw;
+  cx.indexes = d.indexes;
+  cx.qp_off = d.qp_off;
+  cx.attrs = d.attrs;
+  cx.coeffs = d.coeffs;
+  cx.lcp = d_lcp_io;
+  Arena ar;
+  ar.base = scratch;
+  ar.cap = ~size_t(0);
+  cx.a = ar.take<int64_t>((size_t)n * C);
+  cx.qw = ar.take<unsigned long long>(n);
+  cx.uw = ar.take<unsigned long long>(n);
+  cx.up = ar.take<unsigned long long>((size_t)n * C);
+  cx.lcp_sums = ar.take<long long>(2 * GPCC_MAX_LODS);
+  cx.rsqrt = &ctx->d_lut->rsqrt;
+
+  const int* npl = cx.npl;
+  auto grid = [&](int items) { return grid_for(std::max(items, 1), 256); };
+  {
+    Timer t(ctx, "lift_init");
+    lift_init_kernel<<<grid(n), 256, 0, st>>>(cx, encoder);
+  }
+  {
+    Timer t(ctx, "lift_quant_weights");
+    for (int l = p->num_lods - 1; l >= 1; l--)
+      if (npl[l] > npl[l - 1])
+        lift_quant_weights_kernel<<<grid(npl[l] - npl[l - 1]), 256, 0, st>>>(cx, npl[l - 1], npl[l]);
+  }
+  if (encoder) {
+    Timer t(ctx, "lift_forward");
+    for (int l = p->num_lods - 1; l >= 1; l--) {
+      if (npl[l] == npl[l - 1])
+        continue;
+      const int cnt = npl[l] - npl[l - 1];
+      lift_predict_kernel<C><<<grid(cnt), 256, 0, st>>>(cx, npl[l - 1], npl[l], 1);
+      lift_update_scatter_kernel<C><<<grid(cnt), 256, 0, st>>>(cx, npl[l - 1], npl[l]);
+      lift_update_apply_kernel<C><<<grid(npl[l - 1]), 256, 0, st>>>(cx, npl[l - 1], 1);
+    }
+    if (cx.lcp_enabled) {
+      lift_lcp_sums_kernel<<<grid(n), 256, 0, st>>>(cx);
+      lift_lcp_resolve_kernel<<<1, 64, 0, st>>>(cx);
+    }
+  }
+  {
+    Timer t(ctx, "lift_quantise");
+    lift_quantise_kernel<C><<<grid(n), 256, 0, st>>>(cx, encoder);
+  }
+  {
+    Timer t(ctx, "lift_inverse");
+    for (int l = 1; l < p->num_lods; l++) {
+      if (npl[l] == npl[l - 1])
+        continue;
+      const int cnt = npl[l] - npl[l - 1];
+      lift_update_scatter_kernel<C><<<grid(cnt), 256, 0, st>>>(cx, npl[l - 1], npl[l]);
+      lift_update_apply_kernel<C><<<grid(npl[l - 1]), 256, 0, st>>>(cx, npl[l - 1], 0);
+      lift_predict_kernel<C><<<grid(cnt), 256, 0, st>>>(cx, npl[l - 1], npl[l], 0);
+    }
+    lift_writeback_kernel<<<grid(n), 256, 0, st>>>(cx);
+  }
+  HIP_TRY(hipGetLastError());
+  return GPCC_OK;
+}
+
+size_t
+lift_scratch_bytes(int n, int c)
+{
+  Arena ar;
+  ar.take<int64_t>((size_t)n * c);
+  ar.take<unsigned long long>(n);
+  ar.take<unsigned long long>(n);
+  ar.take<unsigned long long>((size_t)n * c);
+  ar.take<long long>(2 * GPCC_MAX_LODS);
+  return ar.used;
+}
+
+int
+host_lift(
+  gpcc_ctx* ctx, bool encoder, const gpcc_lift_params* p, int n, int c,
+  const int32_t* nc, const int32_t* ni, const int32_t* nw,
+  const int32_t* indexes, const int32_t* qp_off, int32_t* attrs,
+  int32_t* coeffs, int8_t* lcp)
+{
+  if (!ctx)
+    return fail(GPCC_ERR_INVALID_ARG, "ctx is null");
+  int rcode = check_lift_params(p, n, c);
+  if (rcode)
+    return rcode;
+  if (!nc || !ni || !nw || !indexes || !attrs || !coeffs)
+    return fail(GPCC_ERR_INVALID_ARG, "null buffer");
+  const bool lcp_on = c == 3 && p->last_component_prediction_enabled_flag;
+  if (lcp_on && !lcp)
+    return fail(GPCC_ERR_INVALID_ARG, "lcp_coeffs is null");
+  for (int i = 0; i < n; i++) {
+    if (nc[i] < 0 || nc[i] > 3 || indexes[i] < 0 || indexes[i] >= n)
+      return fail(GPCC_ERR_INVALID_ARG, "bad neighbour count / index table");
+    for (int j = 0; j < nc[i]; j++)
+      if (ni[3 * (size_t)i + j] < 0 || ni[3 * (size_t)i + j] >= i)
+        return fail(GPCC_ERR_INVALID_ARG, "a neighbour does not precede its predictor");
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+
+  // one arena: inputs, outputs, scratch
+  Arena m;
+  auto carve = [&](Arena& ar, LiftDev& d, int32_t*& d_nc, int32_t*& d_ni,
+                   int32_t*& d_nw, int32_t*& d_ix, int32_t*& d_qp,
+                   int8_t*& d_lcp, char*& scratch) {
+    ar.reset();
+    d_nc = ar.take<int32_t>(n);
+    d_ni = ar.take<int32_t>((size_t)n * 3);
+    d_nw = ar.take<int32_t>((size_t)n * 3);
+    d_ix = ar.take<int32_t>(n);
+    d_qp = qp_off ? ar.take<int32_t>((size_t)n * 2) : nullptr;
+    d.attrs = ar.take<int32_t>((size_t)n * c);
+    d.coeffs = ar.take<int32_t>((size_t)n * c);
+    d_lcp = ar.take<int8_t>(GPCC_MAX_LODS);
+    scratch = ar.base ? ar.base + ar.used : nullptr;
+    ar.used += lift_scratch_bytes(n, c);
+  };
+  LiftDev d{};
+  int32_t *d_nc, *d_ni, *d_nw, *d_ix, *d_qp;
+  int8_t* d_lcp;
+  char* scratch;
+  carve(m, d, d_nc, d_ni, d_nw, d_ix, d_qp, d_lcp, scratch);
+  rcode = ensure_arena(ctx, m.used);
+  if (rcode)
+    return rcode;
+  carve(ctx->arena, d, d_nc, d_ni, d_nw, d_ix, d_qp, d_lcp, scratch);
+  d.nc = d_nc;
+  d.ni = d_ni;
+  d.nw = d_nw;
+  d.indexes = d_ix;
+  d.qp_off = d_qp;
+  HIP_TRY(hipMemcpyAsync(d_nc, nc, sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d_ni, ni, sizeof(int32_t) * n * 3, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d_nw, nw, sizeof(int32_t) * n * 3, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d_ix, indexes, sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
+  if (qp_off)
+    HIP_TRY(hipMemcpyAsync(d_qp, qp_off, sizeof(int32_t) * n * 2, hipMemcpyHostToDevice, st));
+  if (encoder) {
+    HIP_TRY(hipMemcpyAsync(d.attrs, attrs, sizeof(int32_t) * n * c, hipMemcpyHostToDevice, st));
+  } else {
+    HIP_TRY(hipMemcpyAsync(d.coeffs, coeffs, sizeof(int32_t) * n * c, hipMemcpyHostToDevice, st));
+    if (lcp_on)
+      HIP_TRY(hipMemcpyAsync(d_lcp, lcp, GPCC_MAX_LODS, hipMemcpyHostToDevice, st));
+  }
+  switch (c) {
+  case 1: rcode = launch_lift<1>(ctx, encoder, p, n, d, d_lcp, scratch); break;
+  case 2: rcode = launch_lift<2>(ctx, encoder, p, n, d, d_lcp, scratch); break;
+  default: rcode = launch_lift<3>(ctx, encoder, p, n, d, d_lcp, scratch); break;
+  }
+  if (rcode)
+    return rcode;
+  HIP_TRY(hipMemcpyAsync(attrs, d.attrs, sizeof(int32_t) * n * c, hipMemcpyDeviceToHost, st));
+  if (encoder) {
+    HIP_TRY(hipMemcpyAsync(coeffs, d.coeffs, sizeof(int32_t) * n * c, hipMemcpyDeviceToHost, st));
+    if (lcp_on)
+      HIP_TRY(hipMemcpyAsync(lcp, d_lcp, GPCC_MAX_LODS, hipMemcpyDeviceToHost, st));
+  }
+  HIP_TRY(hipStreamSynchronize(st));
+  return GPCC_OK;
+}
+
 }  // namespace
 
 // =========================================================================
@@ -1021,6 +1272,63 @@ gpcc_attr_morton_sort(
   int r = run();
   cleanup();
   return r;
+}
+
+int
+gpcc_lift_forward(
+  gpcc_ctx* ctx, const gpcc_lift_params* params, int32_t n, int32_t c,
+  const int32_t* neigh_count, const int32_t* neigh_index,
+  const int32_t* neigh_weight, const int32_t* indexes, const int32_t* qp_off,
+  int32_t* attrs, int32_t* coeffs, int8_t* lcp_coeffs)
+{
+  return host_lift(
+    ctx, true, params, n, c, neigh_count, neigh_index, neigh_weight, indexes,
+    qp_off, attrs, coeffs, lcp_coeffs);
+}
+
+int
+gpcc_lift_inverse(
+  gpcc_ctx* ctx, const gpcc_lift_params* params, int32_t n, int32_t c,
+  const int32_t* neigh_count, const int32_t* neigh_index,
+  const int32_t* neigh_weight, const int32_t* indexes, const int32_t* qp_off,
+  int32_t* attrs, const int32_t* coeffs, const int8_t* lcp_coeffs)
+{
+  return host_lift(
+    ctx, false, params, n, c, neigh_count, neigh_index, neigh_weight, indexes,
+    qp_off, attrs, const_cast<int32_t*>(coeffs), const_cast<int8_t*>(lcp_coeffs));
+}
+
+int
+gpcc_lod_compute_weights(
+  gpcc_ctx* ctx, int32_t n, int32_t* neigh_count, const uint64_t* dist2,
+  int32_t* neigh_weight)
+{
+  if (!ctx)
+    return fail(GPCC_ERR_INVALID_ARG, "ctx is null");
+  if (n <= 0 || !neigh_count || !dist2 || !neigh_weight)
+    return fail(GPCC_ERR_INVALID_ARG, "null buffer or n <= 0");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  Arena m;
+  m.take<int32_t>(n);
+  m.take<uint64_t>((size_t)n * 3);
+  m.take<int32_t>((size_t)n * 3);
+  int rcode = ensure_arena(ctx, m.used);
+  if (rcode)
+    return rcode;
+  Arena& ar = ctx->arena;
+  ar.reset();
+  int32_t* d_nc = ar.take<int32_t>(n);
+  uint64_t* d_d = ar.take<uint64_t>((size_t)n * 3);
+  int32_t* d_w = ar.take<int32_t>((size_t)n * 3);
+  HIP_TRY(hipMemcpyAsync(d_nc, neigh_count, sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d_d, dist2, sizeof(uint64_t) * n * 3, hipMemcpyHostToDevice, st));
+  lod_compute_weights_kernel<<<grid_for(n, 256), 256, 0, st>>>(n, d_nc, d_d, d_w);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(neigh_count, d_nc, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(neigh_weight, d_w, sizeof(int32_t) * n * 3, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return GPCC_OK;
 }
 
 }  // extern "C"

@@ -101,3 +101,45 @@ class Context:
         _lib.check(self._lib.gpcc_dev_raht_inverse(
             self._h, C.byref(params), len(offsets) - 1, off, C.c_void_p(d_morton),
             C.c_void_p(d_qp_off or 0), C.c_void_p(d_attrs), C.c_void_p(d_coeffs), c))
+
+    # ---- lifting transform (predictors given, host tier) -------------------
+    def _lift(self, forward, params, nc, ni, nw, indexes, attrs, coeffs, lcp, qp_off):
+        nc = np.ascontiguousarray(nc, dtype=np.int32)
+        ni = np.ascontiguousarray(ni, dtype=np.int32)
+        nw = np.ascontiguousarray(nw, dtype=np.int32)
+        ix = np.ascontiguousarray(indexes, dtype=np.int32)
+        n = nc.shape[0]
+        q = None if qp_off is None else np.ascontiguousarray(qp_off, dtype=np.int32)
+        l = np.zeros(32, dtype=np.int8) if lcp is None else np.ascontiguousarray(lcp, dtype=np.int8).copy()
+        if forward:
+            a = np.ascontiguousarray(attrs, dtype=np.int32).copy()
+            c = a.shape[1]
+            co = np.zeros((n, c), dtype=np.int32)
+            fn = self._lib.gpcc_lift_forward
+        else:
+            co = np.ascontiguousarray(coeffs, dtype=np.int32)
+            c = co.shape[1]
+            a = np.zeros((n, c), dtype=np.int32)
+            fn = self._lib.gpcc_lift_inverse
+        _lib.check(fn(self._h, C.byref(params), n, c, nc.ctypes.data, ni.ctypes.data, nw.ctypes.data,
+                      ix.ctypes.data, q.ctypes.data if q is not None else None, a.ctypes.data,
+                      co.ctypes.data, l.ctypes.data))
+        return co, a, l
+
+    def lift_forward(self, params, nc, ni, nw, indexes, attrs, qp_off=None):
+        """encodeColorsLift / encodeReflectancesLift minus the entropy calls ->
+        (coeffs [n,c] coding order, recon [n,c] point order (clipped), lcp int8[32])"""
+        return self._lift(True, params, nc, ni, nw, indexes, attrs, None, None, qp_off)
+
+    def lift_inverse(self, params, nc, ni, nw, indexes, coeffs, lcp=None, qp_off=None):
+        """decodeColorsLift / decodeReflectancesLift after the entropy decode -> recon [n,c]"""
+        return self._lift(False, params, nc, ni, nw, indexes, None, coeffs, lcp, qp_off)[1]
+
+    def lod_compute_weights(self, nc, dist2):
+        """PCCPredictor::computeWeights -> (neighbour counts, 8-bit weights [n,3])"""
+        nc = np.ascontiguousarray(nc, dtype=np.int32).copy()
+        d = np.ascontiguousarray(dist2, dtype=np.uint64)
+        w = np.zeros(d.shape, dtype=np.int32)
+        _lib.check(self._lib.gpcc_lod_compute_weights(self._h, nc.shape[0], nc.ctypes.data, d.ctypes.data,
+                                                      w.ctypes.data))
+        return nc, w

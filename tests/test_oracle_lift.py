@@ -11,8 +11,14 @@ import pytest
 import lod_helpers as lh
 import oracle_loader as ol
 
-pytestmark = [pytest.mark.ref,
-              pytest.mark.skipif(not ol.ref_available(), reason="compiled reference absent")]
+needs_ref = [pytest.mark.ref,
+             pytest.mark.skipif(not ol.ref_available(), reason="compiled reference absent")]
+
+
+def _mark(f):
+    for m in needs_ref:
+        f = m(f)
+    return f
 
 
 def clouds():
@@ -26,6 +32,7 @@ def clouds():
     yield "one", synth.random_cloud(1, seed=1, bits=3)
 
 
+@_mark
 @pytest.mark.parametrize("qp", [4, 28, 40])
 def test_lift_oracle_vs_reference_driver_and_operator(qp):
     from mpeg_pcc_tmc13_amd import lift_params, lod_params, raht_params
@@ -47,6 +54,7 @@ def test_lift_oracle_vs_reference_driver_and_operator(qp):
             np.testing.assert_array_equal(inv_o, rec_r)
 
 
+@_mark
 def test_reference_driver_equals_whole_operator():
     """The harness driver (reference templates, our glue) reconstructs what
     the real AttributeEncoder::encode does; decode(encode) agrees."""
@@ -67,6 +75,7 @@ def test_reference_driver_equals_whole_operator():
         np.testing.assert_array_equal(rec_drv, rec_enc, err_msg=name)
 
 
+@_mark
 def test_compute_weights_vs_reference():
     from mpeg_pcc_tmc13_amd import lod_params, synth
     o, r = ol.oracle(), ol.ref()
@@ -88,3 +97,23 @@ def test_compute_weights_vs_reference():
     nc_o, w_o = lh.compute_weights(o, nc, d)
     np.testing.assert_array_equal(nc_o, nc_r)
     np.testing.assert_array_equal(w_o, w_r)
+
+
+def test_lift_oracle_vs_committed_golden():
+    """Runs without the compiled reference: golden inputs AND outputs."""
+    import ast
+    import os
+    from mpeg_pcc_tmc13_amd import lift_params
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "lift_golden.npz"))
+    for name in ("dense3k_qp34", "dense3k_qp10", "rand2k_layers", "lidar3k_refl", "tiny5"):
+        pk = ast.literal_eval(str(g[name + "/params"]))
+        attrs = g[name + "/attrs"]
+        c = attrs.shape[1]
+        lf = lift_params(g[name + "/npl"], lcp=(c == 3), **pk)
+        lod = dict(nc=g[name + "/nc"], ni=g[name + "/ni"], w=g[name + "/w"], indexes=g[name + "/indexes"])
+        co, rec, lcp = lh.lift(ol.oracle(), True, lf, lod, attrs)
+        np.testing.assert_array_equal(co, g[name + "/coeffs"])
+        np.testing.assert_array_equal(rec, g[name + "/rec"])
+        nc2, w2 = lh.compute_weights(ol.oracle(), g[name + "/nc_raw"], g[name + "/dist2"])
+        np.testing.assert_array_equal(nc2, g[name + "/nc"])
+        np.testing.assert_array_equal(w2.astype(np.int32), g[name + "/w"])
