@@ -1,0 +1,793 @@
+/* lod_oracle.c -- TEST INFRASTRUCTURE (CPU oracle), not product code.
+ *
+ * Plain-C restatement of the level-of-detail generation of TMC13 for intra,
+ * non-scalable attribute coding:
+ *   buildPredictorsFast          tmc3/PCCTMC3Common.h:2300-2469
+ *   subsampleByDistance          :1984-2085   (MortonIndexMap3d :111-172)
+ *   subsampleByDecimation        :2198-2214
+ *   subsampleByOctree(+Centroid) :2089-2194
+ *   computeNearestNeighbors      :1147-1953   (BoxHierarchy :58-107,
+ *                                              updateNearestNeigh* :944-1143)
+ *   updatePredictors             :2273-2296
+ * written the way the kernels need it: the nearest-neighbour search of a
+ * refinement point is a PURE FUNCTION of the point, the sorted retained
+ * list and one per-LoD scalar (see `atlas_limit`), so all points of a LoD
+ * are independent; the reference's sliding atlas (a 128^3-cell window that
+ * is filled while walking the list) becomes binary searches in the
+ * retained list.  Pinned against the compiled reference by
+ * tests/test_oracle_lod.py.
+ */
+#include <limits.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "gpcc_attr_mi355.h"
+#include "primitives.h"
+
+typedef struct {
+  int64_t code;
+  int32_t pos[3];
+  int32_t index; /* original point index */
+} voxel_t;
+
+static int
+cmp_voxel(const void* a, const void* b)
+{
+  const voxel_t* x = (const voxel_t*)a;
+  const voxel_t* y = (const voxel_t*)b;
+  if (x->code != y->code)
+    return x->code < y->code ? -1 : 1;
+  return x->index < y->index ? -1 : (x->index > y->index);
+}
+
+enum { kAtlasLog2 = 7, kAtlasBits = 3 * kAtlasLog2 };
+
+static inline int
+min_i(int a, int b)
+{
+  return a < b ? a : b;
+}
+static inline int
+max_i(int a, int b)
+{
+  return a > b ? a : b;
+}
+
+static inline int64_t
+norm2(const int32_t* a, const int32_t* b)
+{
+  int64_t dx = (int64_t)a[0] - b[0], dy = (int64_t)a[1] - b[1], dz = (int64_t)a[2] - b[2];
+  return dx * dx + dy * dy + dz * dz;
+}
+static inline int32_t
+norm1(const int32_t* a, const int32_t* b)
+{
+  return abs(a[0] - b[0]) + abs(a[1] - b[1]) + abs(a[2] - b[2]);
+}
+/* Vec3::getDir of (a - b), PCCMath.h:105-109 */
+static inline int
+dir_of(const int32_t* a, const int32_t* b)
+{
+  return ((a[0] - b[0] >= 0) << 2) + ((a[1] - b[1] >= 0) << 1) + (a[2] - b[2] >= 0);
+}
+
+/* range [lo, hi) of entries of the sorted index list `list` (codes
+ * ascending) with (code >> shift) == cell */
+static void
+cell_range(
+  const voxel_t* pv, const int32_t* list, int n, int shift, int64_t cell,
+  int* lo_out, int* hi_out)
+{
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if ((pv[list[mid]].code >> shift) < cell)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  int start = lo;
+  hi = n;
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if ((pv[list[mid]].code >> shift) <= cell)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  *lo_out = start;
+  *hi_out = lo;
+}
+
+/* ---- sub-sampling ------------------------------------------------------ */
+
+static const uint8_t kSubNeigh[20] = {7, 3, 5, 6, 12, 10, 17, 20, 34, 33,
+                                      4, 2, 1, 24, 40, 48, 32, 16, 8, 0};
+
+/* subsampleByDistance :1984-2085.  Sequential greedy; the atlas of the
+ * reference only ever holds retained points of the current 128^3-cell
+ * block, i.e. the retained entries inserted since the block began. */
+static void
+subsample_by_distance(
+  const voxel_t* pv, const int32_t* input, int n_in, int shift_bits0,
+  int32_t* retained, int* n_ret, int32_t* refine, int* n_ref)
+{
+  *n_ret = 0;
+  if (n_in == 1) {
+    refine[(*n_ref)++] = input[0];
+    return;
+  }
+  const int64_t radius2 = (int64_t)3 << (shift_bits0 << 1);
+  const int shift3 = 3 * (shift_bits0 + 1);
+  const int boundary = min_i(63, shift3 + kAtlasBits);
+  int64_t cur_atlas = -1, last_cell = -1;
+  int block_first = 0; /* first retained entry of the current atlas block */
+  for (int t = 0; t < n_in; t++) {
+    const int idx = input[t];
+    const int64_t code = pv[idx].code;
+    const int64_t atlas_id = code >> boundary;
+    const int64_t cell = code >> shift3;
+    if (cur_atlas != atlas_id) {
+      cur_atlas = atlas_id;
+      block_first = *n_ret;
+    }
+    if (*n_ret == 0) {
+      retained[(*n_ret)++] = idx;
+      last_cell = cell;
+      continue;
+    }
+    if (last_cell == cell) {
+      refine[(*n_ref)++] = idx;
+      continue;
+    }
+    const uint64_t base = morton3d_add((uint64_t)cell, ~(uint64_t)0);
+    int found = 0;
+    for (int k = 0; k < 20 && !found; k++) {
+      const int64_t nb = (int64_t)morton3d_add(base, kSubNeigh[k]);
+      if ((nb >> kAtlasBits) != cur_atlas)
+        continue;
+      /* atlas.get(): the low 21 bits address the cell inside the block */
+      int lo, hi;
+      cell_range(pv, retained + block_first, *n_ret - block_first, shift3, nb, &lo, &hi);
+      /* NB: the reference compares only the low 21 bits; inside one block
+       * these identify the cell uniquely */
+      for (int r = block_first + lo; r < block_first + hi; r++)
+        if (norm2(pv[retained[r]].pos, pv[idx].pos) <= radius2) {
+          found = 1;
+          break;
+        }
+    }
+    if (found) {
+      refine[(*n_ref)++] = idx;
+    } else {
+      retained[(*n_ret)++] = idx;
+      last_cell = cell;
+    }
+  }
+}
+
+/* subsampleByDecimation :2198-2214 */
+static void
+subsample_by_decimation(
+  const int32_t* input, int n_in, int period, int32_t* retained, int* n_ret,
+  int32_t* refine, int* n_ref)
+{
+  *n_ret = 0;
+  for (int i = 0, j = 1; i < n_in; i++) {
+    if (--j)
+      refine[(*n_ref)++] = input[i];
+    else {
+      retained[(*n_ret)++] = input[i];
+      j = period;
+    }
+  }
+}
+
+/* subsampleByOctree :2146-2194 with subsampleByOctreeWithCentroid
+ * :2089-2142 (backward direction; clacIntermediatePosition masks the low
+ * octreeNodeSizeLog2 bits) */
+static void
+subsample_by_octree(
+  const voxel_t* pv, const int32_t* input, int n_in, int node_log2, int period,
+  int32_t* retained, int* n_ret, int32_t* refine, int* n_ref)
+{
+  *n_ret = 0;
+  if (n_in == 1) {
+    refine[(*n_ref)++] = input[0];
+    return;
+  }
+  const int quant = 3 * (node_log2 + 1);
+  const uint32_t mask = node_log2 ? (uint32_t)(-1) << node_log2 : (uint32_t)(-1);
+  int32_t* vox = (int32_t*)malloc(sizeof(int32_t) * (size_t)n_in);
+  int nv = 0;
+  for (int i = 0; i < n_in; i++) {
+    const uint64_t cur = (uint64_t)pv[input[i]].code >> quant;
+    uint64_t next = cur;
+    if (i < n_in - 1)
+      next = (uint64_t)pv[input[i + 1]].code >> quant;
+    vox[nv++] = input[i];
+    if (i == n_in - 1 || cur < next) {
+      if (nv < period && i != n_in - 1)
+        continue;
+      int32_t cen[3] = {0, 0, 0};
+      for (int v = 0; v < nv; v++)
+        for (int d = 0; d < 3; d++)
+          cen[d] += (int32_t)((uint32_t)pv[vox[v]].pos[d] & mask);
+      int best = nv - 1;
+      int64_t best_m = INT64_MAX;
+      for (int v = nv - 1; v >= 0; v--) {
+        int64_t m = 0;
+        for (int d = 0; d < 3; d++) {
+          int32_t p = (int32_t)((uint32_t)pv[vox[v]].pos[d] & mask) * nv;
+          m += abs(p - cen[d]);
+        }
+        m = (int32_t)m; /* getNorm1 on Vec3<int32_t> */
+        if (best_m > m) {
+          best_m = m;
+          best = v;
+        }
+      }
+      const int32_t picked = vox[best];
+      for (int v = 0; v < nv; v++) {
+        if (vox[v] == picked)
+          retained[(*n_ret)++] = vox[v];
+        else
+          refine[(*n_ref)++] = vox[v];
+      }
+      nv = 0;
+    }
+  }
+  free(vox);
+}
+
+/* ---- nearest-neighbour search ------------------------------------------ */
+
+typedef struct {
+  int32_t idx[6];
+  int64_t dist[6];
+  int idx2;
+} nn_state_t;
+
+/* updateNearestNeigh :1030-1076 */
+static void
+nn_update(nn_state_t* s, int32_t d, int32_t index)
+{
+  if (d >= s->dist[2])
+    return;
+  if (d < s->dist[0]) {
+    s->dist[2] = s->dist[1];
+    s->dist[1] = s->dist[0];
+    s->dist[0] = d;
+    s->idx[2] = s->idx[1];
+    s->idx[1] = s->idx[0];
+    s->idx[0] = index;
+  } else if (d < s->dist[1]) {
+    s->dist[2] = s->dist[1];
+    s->dist[1] = d;
+    s->idx[2] = s->idx[1];
+    s->idx[1] = index;
+  } else {
+    s->dist[2] = d;
+    s->idx[2] = index;
+  }
+}
+
+/* updateNearestNeighByDistanceAndDistribution :944-1027 */
+static void
+nn_update_dist(nn_state_t* s, int32_t d, int32_t index)
+{
+  if (d > s->dist[2]) {
+    /* nothing */
+  } else if (d < s->dist[0]) {
+    if (s->idx[2] != -1)
+      s->idx[s->idx2++] = s->idx[2];
+    s->dist[2] = s->dist[1];
+    s->dist[1] = s->dist[0];
+    s->dist[0] = d;
+    s->idx[2] = s->idx[1];
+    s->idx[1] = s->idx[0];
+    s->idx[0] = index;
+  } else if (d < s->dist[1]) {
+    if (s->idx[2] != -1)
+      s->idx[s->idx2++] = s->idx[2];
+    s->dist[2] = s->dist[1];
+    s->dist[1] = d;
+    s->idx[2] = s->idx[1];
+    s->idx[1] = index;
+  } else if (d < s->dist[2]) {
+    if (s->idx[2] != -1)
+      s->idx[s->idx2++] = s->idx[2];
+    s->dist[2] = d;
+    s->idx[2] = index;
+  } else if (s->idx[5] == -1) {
+    s->idx[s->idx2++] = index;
+  }
+  if (s->idx2 == 6)
+    s->idx2 = 3;
+}
+
+static void
+nn_visit(nn_state_t* s, int distribution, int check, int32_t d, int32_t index)
+{
+  if (check) {
+    const int lim = distribution ? 6 : 3;
+    for (int h = 0; h < lim; h++)
+      if (s->idx[h] == index)
+        return;
+  }
+  if (distribution)
+    nn_update_dist(s, d, index);
+  else
+    nn_update(s, d, index);
+}
+
+static const uint8_t kNnNeigh[27] = {7,  3,  5,  6,  35, 21, 14, 28, 42,
+                                     49, 12, 10, 17, 20, 34, 33, 4,  2,
+                                     1,  56, 24, 40, 48, 32, 16, 8,  0};
+
+/* three-level bounding boxes over buckets of 32 (BoxHierarchy<5,3>) */
+typedef struct {
+  int32_t* mn[3];
+  int32_t* mx[3];
+  int count[3];
+} bbox_t;
+
+static void
+bbox_build(bbox_t* h, const int32_t* bpos /*[n][3] in list order*/, int n)
+{
+  int cnt = n;
+  for (int l = 0; l < 3; l++) {
+    cnt = (cnt + 31) >> 5;
+    h->count[l] = cnt;
+    h->mn[l] = (int32_t*)malloc(sizeof(int32_t) * 3 * (size_t)(cnt + 1));
+    h->mx[l] = (int32_t*)malloc(sizeof(int32_t) * 3 * (size_t)(cnt + 1));
+    for (int i = 0; i < 3 * cnt; i++) {
+      h->mn[l][i] = INT32_MAX;
+      h->mx[l][i] = INT32_MIN;
+    }
+  }
+  for (int i = 0; i < n; i++)
+    for (int d = 0; d < 3; d++) {
+      int b = i >> 5;
+      if (bpos[3 * i + d] < h->mn[0][3 * b + d])
+        h->mn[0][3 * b + d] = bpos[3 * i + d];
+      if (bpos[3 * i + d] > h->mx[0][3 * b + d])
+        h->mx[0][3 * b + d] = bpos[3 * i + d];
+    }
+  for (int l = 0; l < 2; l++)
+    for (int j = 0; j < h->count[l]; j++)
+      for (int d = 0; d < 3; d++) {
+        int b = j >> 5;
+        if (h->mn[l][3 * j + d] < h->mn[l + 1][3 * b + d])
+          h->mn[l + 1][3 * b + d] = h->mn[l][3 * j + d];
+        if (h->mx[l][3 * j + d] > h->mx[l + 1][3 * b + d])
+          h->mx[l + 1][3 * b + d] = h->mx[l][3 * j + d];
+      }
+}
+
+static void
+bbox_free(bbox_t* h)
+{
+  for (int l = 0; l < 3; l++) {
+    free(h->mn[l]);
+    free(h->mx[l]);
+  }
+}
+
+/* Box3::getDist1 PCCMath.h:504-510 */
+static inline int32_t
+bbox_dist1(const bbox_t* h, int level, int b, const int32_t* p)
+{
+  int32_t s = 0;
+  for (int d = 0; d < 3; d++) {
+    int32_t a = h->mn[level][3 * b + d] - p[d];
+    int32_t c = p[d] - h->mx[level][3 * b + d];
+    int32_t m = a > 0 ? a : 0;
+    s += m > c ? m : c;
+  }
+  return s;
+}
+
+/* the bucketed window scans of :1436-1522 / :1551-1604; dir +1: k0..k1
+ * ascending, dir -1: descending */
+static void
+window_scan(
+  nn_state_t* s, const bbox_t* h, const int32_t* bpos_list, const int32_t* bp,
+  int k0, int k1, int dir, int distribution, int check, const int32_t* cand_id,
+  int cand_base)
+{
+  if (k0 > k1)
+    return;
+  if (dir > 0) {
+    for (int b2 = k0 >> 15; b2 <= (k1 >> 15); b2++) {
+      if (s->idx[2] != -1 && bbox_dist1(h, 2, b2, bp) >= s->dist[2])
+        continue;
+      const int s1 = max_i(k0 >> 10, b2 << 5), e1 = min_i(k1 >> 10, (b2 << 5) + 31);
+      for (int b1 = s1; b1 <= e1; b1++) {
+        if (s->idx[2] != -1 && bbox_dist1(h, 1, b1, bp) >= s->dist[2])
+          continue;
+        const int s0 = max_i(k0 >> 5, b1 << 5), e0 = min_i(k1 >> 5, (b1 << 5) + 31);
+        for (int b0 = s0; b0 <= e0; b0++) {
+          if (s->idx[2] != -1 && bbox_dist1(h, 0, b0, bp) >= s->dist[2])
+            continue;
+          const int h0 = max_i(k0, b0 << 5), h1 = min_i(k1, (b0 << 5) + 31);
+          for (int k = h0; k <= h1; k++)
+            nn_visit(
+              s, distribution, check, norm1(bp, &bpos_list[3 * k]),
+              cand_id ? cand_id[cand_base + k] : k);
+        }
+      }
+    }
+  } else {
+    for (int c2 = k1 >> 15; c2 >= (k0 >> 15); c2--) {
+      if (s->idx[2] != -1 && bbox_dist1(h, 2, c2, bp) >= s->dist[2])
+        continue;
+      const int s1 = max_i(k0 >> 10, c2 << 5), e1 = min_i(k1 >> 10, (c2 << 5) + 31);
+      for (int c1 = e1; c1 >= s1; c1--) {
+        if (s->idx[2] != -1 && bbox_dist1(h, 1, c1, bp) >= s->dist[2])
+          continue;
+        const int s0 = max_i(k0 >> 5, c1 << 5), e0 = min_i(k1 >> 5, (c1 << 5) + 31);
+        for (int c0 = e0; c0 >= s0; c0--) {
+          if (s->idx[2] != -1 && bbox_dist1(h, 0, c0, bp) >= s->dist[2])
+            continue;
+          const int h0 = max_i(k0, c0 << 5), h1 = min_i(k1, (c0 << 5) + 31);
+          for (int k = h1; k >= h0; k--)
+            nn_visit(
+              s, distribution, check, norm1(bp, &bpos_list[3 * k]),
+              cand_id ? cand_id[cand_base + k] : k);
+        }
+      }
+    }
+  }
+}
+
+typedef struct {
+  int32_t count;
+  int32_t pidx[3];   /* neighbour POINT index */
+  uint64_t w[3];     /* squared distance */
+} raw_pred_t;
+
+static void
+compute_nearest_neighbours(
+  const gpcc_lod_params* lp, const voxel_t* pv, const int32_t* bias_pos /*[n][3]*/,
+  const int32_t* retained, int n_ret, int32_t* indexes /* in: packed idx, out: point idx */,
+  int start, int end, int lod_index, raw_pred_t* preds, int32_t* pt2pred,
+  int* pred_index)
+{
+  const int shift_bits = 1 + lp->dist2 + lp->attr_dist2_delta + lod_index;
+  const int shift3 = 3 * shift_bits;
+  const int boundary = min_i(63, shift3 + kAtlasBits);
+  const int distribution = lp->prediction_with_distribution_enabled != 0;
+  const int range_inter = lp->inter_lod_search_range;
+  const int range_intra = lp->intra_lod_search_range;
+  const int intra = lod_index >= lp->intra_lod_prediction_skip_layers;
+  const int n_ref = end - start;
+
+  /* biased positions in list order + hierarchies */
+  int32_t* bret = (int32_t*)malloc(sizeof(int32_t) * 3 * (size_t)(n_ret + 1));
+  for (int i = 0; i < n_ret; i++)
+    memcpy(&bret[3 * i], &bias_pos[3 * retained[i]], 12);
+  bbox_t hb, hi;
+  bbox_build(&hb, bret, n_ret);
+  int32_t* bref = NULL;
+  if (intra) {
+    bref = (int32_t*)malloc(sizeof(int32_t) * 3 * (size_t)(n_ref + 1));
+    for (int i = 0; i < n_ref; i++)
+      memcpy(&bref[3 * i], &bias_pos[3 * indexes[start + i]], 12);
+    bbox_build(&hi, bref, n_ref);
+  }
+
+  /* The reference fills its atlas block by block from a cursor that only
+   * advances over retained entries of the block being entered (:1349-1363).
+   * A retained entry whose block holds no refinement point is never passed:
+   * from that block on the atlas stays empty.  atlas_limit = id of the first
+   * such block (INT64_MAX if none). */
+  int64_t atlas_limit = INT64_MAX;
+  {
+    int r = 0;
+    int64_t cur = -1;
+    for (int i = start; i < end && atlas_limit == INT64_MAX; i++) {
+      const int64_t id = pv[indexes[i]].code >> boundary;
+      if (id == cur)
+        continue;
+      cur = id;
+      if (r < n_ret && (pv[retained[r]].code >> boundary) < id) {
+        atlas_limit = pv[retained[r]].code >> boundary;
+        break;
+      }
+      while (r < n_ret && (pv[retained[r]].code >> boundary) == id)
+        r++;
+    }
+  }
+
+  /* packed indices of the refinement list survive in a copy: indexes[] is
+   * rewritten with point indices as the walk proceeds */
+  int32_t* packed = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n_ref + 1));
+  memcpy(packed, &indexes[start], sizeof(int32_t) * (size_t)n_ref);
+
+  for (int i = start; i < end; i++) {
+    nn_state_t s;
+    for (int h = 0; h < 6; h++) {
+      s.idx[h] = -1;
+      s.dist[h] = INT64_MAX;
+    }
+    s.idx2 = 3;
+    const int index = packed[i - start];
+    const int64_t code = pv[index].code;
+    const int64_t atlas_id = code >> boundary;
+    const int64_t cell = code >> shift3;
+    const int32_t* bp = &bias_pos[3 * index];
+    indexes[i] = pv[index].index;
+    raw_pred_t* pr = &preds[--(*pred_index)];
+    pt2pred[pv[index].index] = *pred_index;
+
+    if (n_ret) {
+      /* j: first retained entry with a larger code, clipped (:1343-1346) */
+      int lo = 0, hi2 = n_ret;
+      while (lo < hi2) {
+        int mid = (lo + hi2) >> 1;
+        if (pv[retained[mid]].code <= code)
+          lo = mid + 1;
+        else
+          hi2 = mid;
+      }
+      const int j = min_i(lo, n_ret - 1);
+
+      if (atlas_id < atlas_limit) {
+        const uint64_t base = morton3d_add((uint64_t)cell, ~(uint64_t)0);
+        for (int nn = 0; nn < 27; nn++) {
+          const int64_t nb = (int64_t)morton3d_add(base, kNnNeigh[nn]);
+          if ((nb >> kAtlasBits) != atlas_id)
+            continue;
+          int r0, r1;
+          cell_range(pv, retained, n_ret, shift3, nb, &r0, &r1);
+          for (int k = r0; k < r1; k++)
+            nn_visit(&s, distribution, 0, norm1(bp, &bret[3 * k]), k);
+        }
+      }
+
+      if (s.idx[2] == -1) {
+        const int center = s.idx[0] == -1 ? j : s.idx[0];
+        const int k0 = max_i(0, center - range_inter);
+        const int k1 = min_i(n_ret - 1, center + range_inter);
+        nn_visit(&s, distribution, 1, norm1(bp, &bret[3 * center]), center);
+        for (int nn = 1; nn <= 2; nn++) {
+          const int kp = center + nn;
+          if (kp <= k1)
+            nn_visit(&s, distribution, 1, norm1(bp, &bret[3 * kp]), kp);
+          const int kn = center - nn;
+          if (kn >= k0)
+            nn_visit(&s, distribution, 1, norm1(bp, &bret[3 * kn]), kn);
+        }
+        const int p1 = min_i(n_ret - 1, center + 3);
+        const int p0 = max_i(0, center - 3);
+        window_scan(&s, &hb, bret, bp, p1, k1, +1, distribution, 1, NULL, 0);
+        window_scan(&s, &hb, bret, bp, k0, p0, -1, distribution, 1, NULL, 0);
+      }
+      /* retained-list indices -> packed indices */
+      const int cnt = (s.idx[0] != -1) + (s.idx[1] != -1) + (s.idx[2] != -1);
+      for (int h = 0; h < cnt; h++)
+        s.idx[h] = retained[s.idx[h]];
+      if (distribution) {
+        const int cnt2 = (s.idx[3] != -1) + (s.idx[4] != -1) + (s.idx[5] != -1);
+        for (int h = 3; h < 3 + cnt2; h++)
+          s.idx[h] = retained[s.idx[h]];
+      }
+    }
+
+    if (intra) {
+      /* same-LoD candidates: the points that FOLLOW in the list (:1537-1604) */
+      const int k00 = i + 1;
+      const int k01 = min_i(end - 1, k00 + 2);
+      for (int k = k00; k <= k01; k++)
+        nn_visit(
+          &s, distribution, 0, norm1(bp, &bref[3 * (k - start)]), packed[k - start]);
+      const int w0 = k01 + 1 - start;
+      const int w1 = min_i(end - 1, k00 + range_intra) - start;
+      window_scan(&s, &hi, bref, bp, w0, w1, +1, distribution, 0, packed, 0);
+    }
+
+    int count = (s.idx[0] != -1) + (s.idx[1] != -1) + (s.idx[2] != -1);
+    count = min_i(lp->num_pred_nearest_neighbours_minus1 + 1, count);
+    if (distribution) {
+      const int c1 = 3 + (s.idx[3] != -1) + (s.idx[4] != -1) + (s.idx[5] != -1);
+      for (int m = 3; m < c1; m++)
+        if (s.dist[m] == INT64_MAX)
+          s.dist[m] = norm1(bp, &bias_pos[3 * s.idx[m]]);
+      for (int m = 3; m < c1; m++)
+        for (int l = m + 1; l < c1; l++)
+          if (s.dist[l] < s.dist[m]) {
+            int32_t ti = s.idx[l];
+            s.idx[l] = s.idx[m];
+            s.idx[m] = ti;
+            int64_t td = s.dist[l];
+            s.dist[l] = s.dist[m];
+            s.dist[m] = td;
+          }
+      if (count >= 3) {
+        /* third neighbour replaced by one on the far side (:1836-1902) */
+        static const int8_t loose[8][3] = {{3, 5, 6}, {2, 4, 7}, {1, 4, 7},
+                                           {0, 5, 6}, {1, 2, 7}, {0, 3, 6},
+                                           {0, 3, 5}, {1, 2, 4}};
+        int dir[6] = {-1, -1, -1, -1, -1, -1};
+        int numend = 3;
+        for (; numend < c1; numend++)
+          if ((s.dist[numend] << 5) >= s.dist[2] * 54)
+            break;
+        for (int h = 0; h < numend; h++)
+          dir[h] = dir_of(&bias_pos[3 * s.idx[h]], bp);
+        int replace = 1, ridx = -1;
+        if (dir[1] == 7 - dir[0] || dir[2] == 7 - dir[0] || dir[2] == 7 - dir[1])
+          replace = 0;
+        for (int h = 3; replace && h < numend; h++)
+          if (dir[h] == 7 - dir[0] || dir[h] == 7 - dir[1]) {
+            replace = 0;
+            ridx = h;
+          }
+        const int e01 = dir[0] == dir[1], e02 = dir[0] == dir[2], e12 = dir[1] == dir[2];
+        const int8_t* l0 = loose[dir[0]];
+        if (replace) {
+          if ((e02 || e12) && e01) {
+            for (int h = 3; replace && h < numend; h++)
+              if (dir[h] == l0[0] || dir[h] == l0[1] || dir[h] == l0[2]) {
+                replace = 0;
+                ridx = h;
+              }
+          } else if ((e02 || e12) && !e01) {
+            if (!(dir[1] == l0[0] || dir[1] == l0[1] || dir[1] == l0[2]))
+              for (int h = 3; replace && h < numend; h++)
+                if (dir[h] != dir[0] && dir[h] != dir[1]) {
+                  replace = 0;
+                  ridx = h;
+                }
+          } else if (e01) {
+            if (!(dir[2] == l0[0] || dir[2] == l0[1] || dir[2] == l0[2]))
+              for (int h = 3; replace && h < numend; h++)
+                if (dir[h] == l0[0] || dir[h] == l0[1] || dir[h] == l0[2]) {
+                  replace = 0;
+                  ridx = h;
+                }
+          }
+        }
+        if (ridx >= 0)
+          s.idx[2] = s.idx[ridx];
+      }
+    }
+    pr->count = count;
+    for (int h = 0; h < 3; h++) {
+      pr->pidx[h] = 0;
+      pr->w[h] = 0;
+    }
+    for (int h = 0; h < count; h++) {
+      pr->pidx[h] = pv[s.idx[h]].index;
+      pr->w[h] = (uint64_t)norm2(&bias_pos[3 * s.idx[h]], bp);
+    }
+    /* order by weight (:1941-1951) */
+    if (count > 1) {
+#define SWAP_PRED(a, b)                                                      \
+  do {                                                                       \
+    int32_t ti_ = pr->pidx[a];                                               \
+    pr->pidx[a] = pr->pidx[b];                                               \
+    pr->pidx[b] = ti_;                                                       \
+    uint64_t tw_ = pr->w[a];                                                 \
+    pr->w[a] = pr->w[b];                                                     \
+    pr->w[b] = tw_;                                                          \
+  } while (0)
+      if (pr->w[0] > pr->w[1])
+        SWAP_PRED(0, 1);
+      if (count == 3 && pr->w[1] > pr->w[2]) {
+        SWAP_PRED(1, 2);
+        if (pr->w[0] > pr->w[1])
+          SWAP_PRED(0, 1);
+      }
+#undef SWAP_PRED
+    }
+  }
+  free(packed);
+  free(bret);
+  bbox_free(&hb);
+  if (intra) {
+    free(bref);
+    bbox_free(&hi);
+  }
+}
+
+/* buildPredictorsFast.  raw != 0: stop before computeWeights (weights are
+ * squared distances).  Outputs as ref_lod_generate in ref_lod_harness.inc. */
+void oracle_compute_weights(int32_t n, int32_t* neigh_count, uint64_t* w);
+
+int
+oracle_lod_generate(
+  const gpcc_lod_params* lp, const int32_t* xyz, int32_t n, int32_t raw,
+  int32_t* neigh_count, int32_t* neigh_index, uint64_t* weight64,
+  int32_t* indexes_out, int32_t* num_points_in_lod, int32_t* num_lods)
+{
+  if (lp->scalable_lifting_enabled_flag || lp->canonical_point_order_flag
+      || lp->max_points_per_sort_log2_plus1)
+    return -2; /* not restated */
+  voxel_t* pv = (voxel_t*)malloc(sizeof(voxel_t) * (size_t)n);
+  for (int i = 0; i < n; i++) {
+    pv[i].code = morton_addr(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+    memcpy(pv[i].pos, &xyz[3 * i], 12);
+    pv[i].index = i;
+  }
+  qsort(pv, (size_t)n, sizeof(voxel_t), cmp_voxel);
+  int32_t* bias_pos = (int32_t*)malloc(sizeof(int32_t) * 3 * (size_t)n);
+  for (int i = 0; i < n; i++)
+    for (int d = 0; d < 3; d++)
+      bias_pos[3 * i + d] = pv[i].pos[d] * lp->lod_neigh_bias[d];
+
+  int32_t* input = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
+  int32_t* retained = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
+  int32_t* indexes = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
+  int32_t* pt2pred = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
+  raw_pred_t* preds = (raw_pred_t*)calloc((size_t)n, sizeof(raw_pred_t));
+  int n_in = n, n_idx = 0, pred_index = n;
+  for (int i = 0; i < n; i++)
+    input[i] = i;
+  int32_t npl[GPCC_MAX_LODS + 2];
+  int nl = 0;
+  npl[nl++] = n;
+  const int max_levels = lp->num_detail_levels_minus1 + 1;
+  for (int lod = 0; n_in > 0 && lod < max_levels; lod++) {
+    const int start = n_idx;
+    int n_ret = 0;
+    if (lod == max_levels - 1) {
+      for (int i = 0; i < n_in; i++)
+        indexes[n_idx++] = input[i];
+    } else if (lp->lod_decimation_type == 1) {
+      subsample_by_decimation(
+        input, n_in, lp->lod_sampling_period[lod], retained, &n_ret, indexes, &n_idx);
+    } else if (lp->lod_decimation_type == 2) {
+      subsample_by_octree(
+        pv, input, n_in, lp->dist2 + lp->attr_dist2_delta + lod,
+        lp->lod_sampling_period[lod], retained, &n_ret, indexes, &n_idx);
+    } else {
+      subsample_by_distance(
+        pv, input, n_in, lp->dist2 + lp->attr_dist2_delta + lod, retained, &n_ret,
+        indexes, &n_idx);
+    }
+    compute_nearest_neighbours(
+      lp, pv, bias_pos, retained, n_ret, indexes, start, n_idx, lod, preds, pt2pred,
+      &pred_index);
+    if (n_ret && nl < GPCC_MAX_LODS + 1)
+      npl[nl++] = n_ret;
+    int32_t* t = input;
+    input = retained;
+    retained = t;
+    n_in = n_ret;
+  }
+  /* reverse, updatePredictors :2273-2296 */
+  for (int i = 0; i < n; i++)
+    indexes_out[i] = indexes[n - 1 - i];
+  for (int i = 0; i < n; i++) {
+    raw_pred_t* p = &preds[i];
+    if (p->count < 2) {
+      p->w[0] = 1;
+    } else if (p->w[0] == 0) {
+      p->count = 1;
+      p->w[0] = 1;
+    }
+    neigh_count[i] = p->count;
+    for (int k = 0; k < 3; k++) {
+      /* entries beyond the count keep their point index un-mapped, as the
+       * reference leaves them */
+      neigh_index[3 * i + k] = k < p->count ? pt2pred[p->pidx[k]] : p->pidx[k];
+      weight64[3 * i + k] = p->w[k];
+    }
+  }
+  *num_lods = nl;
+  for (int i = 0; i < nl; i++)
+    num_points_in_lod[i] = npl[nl - 1 - i];
+  if (!raw)
+    oracle_compute_weights(n, neigh_count, weight64);
+  free(pv);
+  free(bias_pos);
+  free(input);
+  free(retained);
+  free(indexes);
+  free(pt2pred);
+  free(preds);
+  return 0;
+}

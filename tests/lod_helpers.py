@@ -11,11 +11,20 @@ u64p = np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")
 u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
 
 
+def oracle_lod_generate(xyz, lp, raw=False):
+    return _lod_generate(ol.oracle().lib, "oracle_lod_generate", xyz, lp, raw)
+
+
 def ref_lod_generate(xyz, lp, raw=False):
     """reference AttributeLods::generate (raw: buildPredictorsFast only) ->
     dict(nc [n], ni [n,3], w [n,3] uint64, indexes [n], npl [L])"""
-    lib = ol.ref().lib
-    lib.ref_lod_generate.argtypes = [C.c_void_p, i32p, C.c_int32, C.c_int32, i32p, i32p, u64p, i32p, i32p,
+    return _lod_generate(ol.ref().lib, "ref_lod_generate", xyz, lp, raw)
+
+
+def _lod_generate(lib, fname, xyz, lp, raw):
+    fn = getattr(lib, fname)
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, i32p, C.c_int32, C.c_int32, i32p, i32p, u64p, i32p, i32p,
                                      C.POINTER(C.c_int32)]
     xyz = np.ascontiguousarray(xyz, dtype=np.int32)
     n = len(xyz)
@@ -25,9 +34,9 @@ def ref_lod_generate(xyz, lp, raw=False):
     idx = np.zeros(n, np.int32)
     npl = np.zeros(32, np.int32)
     nl = C.c_int32()
-    rc = lib.ref_lod_generate(C.addressof(lp), xyz.reshape(-1), n, int(raw), nc, ni.reshape(-1), w.reshape(-1),
-                              idx, npl, C.byref(nl))
-    assert rc == 0
+    rc = fn(C.addressof(lp), xyz.reshape(-1), n, int(raw), nc, ni.reshape(-1), w.reshape(-1),
+            idx, npl, C.byref(nl))
+    assert rc == 0, rc
     return dict(nc=nc, ni=ni, w=w, indexes=idx, npl=npl[:nl.value].copy())
 
 
