@@ -243,6 +243,22 @@ typedef struct gpcc_lod_params {
   int32_t lod_sampling_period[GPCC_MAX_LODS];
 } gpcc_lod_params;
 
+/* Replaces pcc::AttributeLods::generate (AttributeCommon.h:80-87,
+ * AttributeCommon.cpp:44-72 -> buildPredictorsFast PCCTMC3Common.h:2300-2469
+ * + PCCPredictor::computeWeights) for one intra slice:
+ *   xyz [n][3] point positions (point order, as PCCPointSet3::positions)
+ * out, all in PREDICTOR (coding) order, coarsest level of detail first:
+ *   neigh_count [n], neigh_index [n][3] (predictor indices), neigh_weight
+ *   [n][3] (8-bit weights), indexes [n] (predictor -> point index),
+ *   num_points_in_lod [GPCC_MAX_LODS] cumulative, *num_lods.
+ * Sub-sampling by distance (lod_decimation_type 0) and periodic (1) run on
+ * the device; centroid decimation (2), scalable lifting, canonical point
+ * order and inter prediction return GPCC_ERR_UNSUPPORTED. */
+int gpcc_lod_build(
+  gpcc_ctx* ctx, const gpcc_lod_params* params, const int32_t* xyz, int32_t n,
+  int32_t* neigh_count, int32_t* neigh_index, int32_t* neigh_weight,
+  int32_t* indexes, int32_t* num_points_in_lod, int32_t* num_lods);
+
 /* PCCPredictor::computeWeights (PCCTMC3Common.h:589-633) for n predictors:
  * squared distances in neigh_weight (uint64 [n][3]) -> 8-bit weights
  * (int32 [n][3]); neigh_count is updated in place (far neighbours are

@@ -3,7 +3,7 @@ if the HIP library is missing or a call fails this module raises."""
 import ctypes as C
 import os
 
-from .params import LiftParams, RahtParams
+from .params import LiftParams, LodParams, RahtParams
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libgpcc_attr_mi355.so")
@@ -16,7 +16,7 @@ ABI_SYMBOLS = [
     "gpcc_raht_forward", "gpcc_raht_inverse", "gpcc_attr_morton_sort",
     "gpcc_dev_raht_forward", "gpcc_dev_raht_inverse", "gpcc_dev_attr_morton_sort",
     "gpcc_ctx_set_profiling", "gpcc_ctx_kernel_times",
-    "gpcc_lift_forward", "gpcc_lift_inverse", "gpcc_lod_compute_weights",
+    "gpcc_lift_forward", "gpcc_lift_inverse", "gpcc_lod_compute_weights", "gpcc_lod_build",
 ]
 
 
@@ -75,6 +75,7 @@ def load():
     for name in ("gpcc_lift_forward", "gpcc_lift_inverse"):
         getattr(lib, name).argtypes = [vp, C.POINTER(LiftParams), i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.gpcc_lod_compute_weights.argtypes = [vp, i32, vp, vp, vp]
+    lib.gpcc_lod_build.argtypes = [vp, C.POINTER(LodParams), vp, i32, vp, vp, vp, vp, vp, C.POINTER(i32)]
     _lib = lib
     return lib
 

@@ -33,6 +33,7 @@
 #include "raht_subnode.hpp"
 #include "raht_tree.hpp"
 #include "lift_kernels.hpp"
+#include "lod_kernels.hpp"
 #include "morton_sort.hpp"
 
 using namespace gpcc;
@@ -1329,6 +1330,265 @@ gpcc_lod_compute_weights(
   HIP_TRY(hipMemcpyAsync(neigh_weight, d_w, sizeof(int32_t) * n * 3, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   return GPCC_OK;
+}
+
+int
+gpcc_lod_build(
+  gpcc_ctx* ctx, const gpcc_lod_params* lp, const int32_t* xyz, int32_t n,
+  int32_t* neigh_count, int32_t* neigh_index, int32_t* neigh_weight,
+  int32_t* indexes, int32_t* num_points_in_lod, int32_t* num_lods)
+{
+  if (!ctx)
+    return fail(GPCC_ERR_INVALID_ARG, "ctx is null");
+  if (!lp || !xyz || n <= 0 || !neigh_count || !neigh_index || !neigh_weight
+      || !indexes || !num_points_in_lod || !num_lods)
+    return fail(GPCC_ERR_INVALID_ARG, "null buffer or n <= 0");
+  if (lp->scalable_lifting_enabled_flag || lp->canonical_point_order_flag
+      || lp->max_points_per_sort_log2_plus1 || lp->lod_decimation_type == 2
+      || lp->pred_weight_blending_enabled_flag)
+    return fail(
+      GPCC_ERR_UNSUPPORTED,
+      "scalable lifting / canonical point order / centroid decimation / "
+      "weight blending stay on the reference CPU path");
+  const int max_levels = lp->num_detail_levels_minus1 + 1;
+  if (max_levels < 1 || max_levels > GPCC_MAX_LODS - 1)
+    return fail(GPCC_ERR_INVALID_ARG, "num_detail_levels out of range");
+  int32_t mx = 0;
+  for (int64_t i = 0; i < (int64_t)n * 3; i++) {
+    if (xyz[i] < 0 || xyz[i] >= (1 << 21))
+      return fail(GPCC_ERR_INVALID_ARG, "coordinate outside [0, 2^21)");
+    mx = std::max(mx, xyz[i]);
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+
+  std::vector<void*> allocs;
+  auto dmalloc = [&](size_t bytes) -> void* {
+    void* p = nullptr;
+    if (hipMalloc(&p, std::max<size_t>(bytes, 256)) != hipSuccess)
+      return nullptr;
+    allocs.push_back(p);
+    return p;
+  };
+  auto cleanup = [&]() {
+    for (void* p : allocs)
+      hipFree(p);
+  };
+  auto run = [&]() -> int {
+    const size_t N = (size_t)n;
+    const int nb0 = (n + 31) >> 5, nb1 = (nb0 + 31) >> 5, nb2 = (nb1 + 31) >> 5;
+#define DM(type, name, count)                                   \
+  type* name = (type*)dmalloc(sizeof(type) * (count));          \
+  if (!name)                                                    \
+    return fail(GPCC_ERR_OUT_OF_MEMORY, "hipMalloc(" #name ")");
+    DM(int32_t, d_xyz, 3 * N)
+    DM(int64_t, d_code, N)
+    DM(int32_t, d_order, N)
+    DM(int32_t, d_pos, 3 * N)
+    DM(int32_t, d_bpos, 3 * N)
+    DM(int32_t, d_list_a, N + 1)
+    DM(int32_t, d_list_b, N + 1)
+    DM(int32_t, d_refine, N + 1)
+    DM(uint8_t, d_flags, N + 1)
+    DM(uint8_t, d_heads, N + 1)
+    DM(int32_t, d_positions, N + 1)
+    DM(int32_t, d_cell_first, N + 2)
+    DM(int32_t, d_cell_ret, N + 1)
+    DM(int32_t, d_done, N + 1)
+    DM(int32_t, d_small, 64)  // ticket[8], error, counts[2]
+    DM(unsigned long long, d_scan, 1024)
+    DM(long long, d_atlas_limit, 1)
+    DM(int32_t, d_box, (size_t)2 * 2 * 3 * (nb0 + nb1 + nb2 + 3))
+    DM(int32_t, d_pred_count, N)
+    DM(int32_t, d_pred_point, 3 * N)
+    DM(uint64_t, d_pred_dist2, 3 * N)
+    DM(int32_t, d_pt2pred, N)
+    DM(int32_t, d_indexes, N)
+    DM(int32_t, d_neigh_index, 3 * N)
+    DM(int32_t, d_weight, 3 * N)
+#undef DM
+    int32_t* d_ticket = d_small;
+    int32_t* d_error = d_small + 8;
+    int32_t* d_counts = d_small + 16;
+    HIP_TRY(hipMemcpyAsync(d_xyz, xyz, sizeof(int32_t) * 3 * N, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(d_done, 0, sizeof(int32_t) * (N + 1), st));
+    HIP_TRY(hipMemsetAsync(d_small, 0, sizeof(int32_t) * 64, st));
+    HIP_TRY(hipMemsetAsync(d_scan, 0, sizeof(unsigned long long) * 1024, st));
+    // Morton order (code, then index)
+    {
+      const int saved = ctx->morton_bits;
+      ctx->morton_bits = std::max(1, 3 * bitlen64((uint64_t)mx));
+      const int64_t offs[2] = {0, n};
+      int r = gpcc_dev_attr_morton_sort(ctx, 1, offs, d_xyz, d_code, d_order);
+      ctx->morton_bits = saved;
+      if (r)
+        return r;
+    }
+    lod_gather_pos_kernel<<<grid_for(n, 256), 256, 0, st>>>(
+      n, d_xyz, d_order, lp->lod_neigh_bias[0], lp->lod_neigh_bias[1],
+      lp->lod_neigh_bias[2], d_pos, d_bpos, d_list_a);
+
+    // box storage: [list 0 = retained, 1 = refine][level][min/max]
+    int32_t* box[2][3][2];
+    {
+      int32_t* p = d_box;
+      const int cnt[3] = {nb0 + 1, nb1 + 1, nb2 + 1};
+      for (int l = 0; l < 2; l++)
+        for (int lev = 0; lev < 3; lev++)
+          for (int m = 0; m < 2; m++) {
+            box[l][lev][m] = p;
+            p += 3 * cnt[lev];
+          }
+    }
+    auto build_boxes = [&](int which, const int32_t* list, int cnt) {
+      const int c0 = (cnt + 31) >> 5, c1 = (c0 + 31) >> 5;
+      lod_box0_kernel<<<grid_for(std::max(c0, 1), 256), 256, 0, st>>>(
+        cnt, list, d_bpos, box[which][0][0], box[which][0][1]);
+      lod_box_up_kernel<<<grid_for(std::max(c1, 1), 256), 256, 0, st>>>(
+        c0, box[which][0][0], box[which][0][1], box[which][1][0], box[which][1][1]);
+      lod_box_up_kernel<<<1, 256, 0, st>>>(
+        c1, box[which][1][0], box[which][1][1], box[which][2][0], box[which][2][1]);
+    };
+
+    int scan_epoch = 0;
+    auto partition = [&](int cnt, const uint8_t* flags, const int32_t* list,
+                         int32_t* out_true, int32_t* out_false, int* n_true) -> int {
+      scan_epoch++;
+      const int grid = (int)std::min<int64_t>(1024, ((int64_t)cnt + 1023) / 1024);
+      lod_partition_kernel<<<std::max(grid, 1), 256, 0, st>>>(
+        cnt, flags, list, out_true, out_false, d_counts, d_scan, scan_epoch);
+      int32_t h = 0;
+      HIP_TRY(hipMemcpyAsync(&h, d_counts, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      *n_true = h;
+      return GPCC_OK;
+    };
+
+    std::vector<int32_t> npl;
+    npl.push_back(n);
+    int32_t* d_input = d_list_a;
+    int32_t* d_ret = d_list_b;
+    int n_in = n, n_idx = 0;
+    for (int lod = 0; n_in > 0 && lod < max_levels; lod++) {
+      const int start = n_idx;
+      int n_ret = 0, n_ref = 0;
+      const int shift_bits0 = lp->dist2 + lp->attr_dist2_delta + lod;
+      if (lod == max_levels - 1 || (lp->lod_decimation_type == 0 && n_in == 1)) {
+        HIP_TRY(hipMemcpyAsync(
+          d_refine + start, d_input, sizeof(int32_t) * n_in, hipMemcpyDeviceToDevice, st));
+        n_ref = n_in;
+      } else {
+        if (lp->lod_decimation_type == 1) {
+          const int period = lp->lod_sampling_period[lod];
+          if (period < 1)
+            return fail(GPCC_ERR_INVALID_ARG, "lod_sampling_period < 1");
+          lod_flag_periodic_kernel<<<grid_for(n_in, 256), 256, 0, st>>>(n_in, period, d_flags);
+        } else {
+          LodCtx lc{};
+          lc.n = n;
+          lc.code = d_code;
+          lc.order = d_order;
+          lc.pos = d_pos;
+          lc.bpos = d_bpos;
+          lc.input = d_input;
+          lc.n_in = n_in;
+          lc.shift3 = 3 * (shift_bits0 + 1);
+          lc.boundary = std::min(63, lc.shift3 + 21);
+          lc.radius2 = (int64_t)3 << (shift_bits0 << 1);
+          lc.cell_first = d_cell_first;
+          lc.cell_ret = d_cell_ret;
+          lc.done = d_done;
+          lc.ticket = d_ticket;
+          lc.error = d_error;
+          lc.epoch = lod + 1;
+          lc.flags = d_flags;
+          lod_flag_cell_heads_kernel<<<grid_for(n_in, 256), 256, 0, st>>>(lc, d_heads, d_positions);
+          int ncell = 0;
+          int r = partition(n_in, d_heads, d_positions, d_cell_first, nullptr, &ncell);
+          if (r)
+            return r;
+          HIP_TRY(hipMemcpyAsync(
+            d_cell_first + ncell, &n_in, sizeof(int32_t), hipMemcpyHostToDevice, st));
+          HIP_TRY(hipMemsetAsync(d_ticket, 0, sizeof(int32_t) * 8, st));
+          lc.ncell = ncell;
+          const int grid = (int)std::min<int64_t>(512, ((int64_t)ncell + 255) / 256);
+          lod_subsample_distance_kernel<<<std::max(8, (grid + 7) / 8 * 8), 256, 0, st>>>(lc);
+        }
+        int r = partition(n_in, d_flags, d_input, d_ret, d_refine + start, &n_ret);
+        if (r)
+          return r;
+        n_ref = n_in - n_ret;
+      }
+      n_idx += n_ref;
+
+      // nearest neighbours of this LoD's refinement points
+      if (n_ref > 0) {
+        NnCtx nc{};
+        nc.n = n;
+        nc.code = d_code;
+        nc.order = d_order;
+        nc.bpos = d_bpos;
+        nc.retained = d_ret;
+        nc.n_ret = n_ret;
+        nc.refine = d_refine + start;
+        nc.n_ref = n_ref;
+        nc.start = start;
+        nc.shift3 = 3 * (1 + shift_bits0);
+        nc.boundary = std::min(63, nc.shift3 + 21);
+        nc.distribution = lp->prediction_with_distribution_enabled;
+        nc.range_inter = lp->inter_lod_search_range;
+        nc.range_intra = lp->intra_lod_search_range;
+        nc.intra = lod >= lp->intra_lod_prediction_skip_layers;
+        nc.max_neigh = lp->num_pred_nearest_neighbours_minus1 + 1;
+        for (int lev = 0; lev < 3; lev++)
+          for (int m = 0; m < 2; m++) {
+            nc.box_ret[lev][m] = box[0][lev][m];
+            nc.box_ref[lev][m] = box[1][lev][m];
+          }
+        nc.atlas_limit = d_atlas_limit;
+        nc.pred_count = d_pred_count;
+        nc.pred_point = d_pred_point;
+        nc.pred_dist2 = d_pred_dist2;
+        nc.pt2pred = d_pt2pred;
+        nc.indexes = d_indexes;
+        if (n_ret > 0)
+          build_boxes(0, d_ret, n_ret);
+        if (nc.intra)
+          build_boxes(1, d_refine + start, n_ref);
+        const long long inf = INT64_MAX;
+        HIP_TRY(hipMemcpyAsync(d_atlas_limit, &inf, sizeof(inf), hipMemcpyHostToDevice, st));
+        if (n_ret > 0)
+          lod_atlas_limit_kernel<<<grid_for(n_ret, 256), 256, 0, st>>>(nc, d_atlas_limit);
+        lod_nn_search_kernel<<<grid_for(n_ref, 256), 256, 0, st>>>(nc);
+      }
+      if (n_ret > 0)
+        npl.push_back(n_ret);
+      std::swap(d_input, d_ret);
+      n_in = n_ret;
+    }
+    lod_finalise_kernel<<<grid_for(n, 256), 256, 0, st>>>(
+      n, 0, d_pred_count, d_pred_point, d_pt2pred, d_pred_dist2, d_neigh_index);
+    lod_compute_weights_kernel<<<grid_for(n, 256), 256, 0, st>>>(
+      n, d_pred_count, d_pred_dist2, d_weight);
+    HIP_TRY(hipGetLastError());
+    int32_t h_err = 0;
+    HIP_TRY(hipMemcpyAsync(neigh_count, d_pred_count, sizeof(int32_t) * N, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(neigh_index, d_neigh_index, sizeof(int32_t) * 3 * N, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(neigh_weight, d_weight, sizeof(int32_t) * 3 * N, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(indexes, d_indexes, sizeof(int32_t) * N, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&h_err, d_error, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (h_err)
+      return fail(GPCC_ERR_HIP, "a dependency wait in the LoD sub-sampling kernel expired");
+    *num_lods = (int)npl.size();
+    for (size_t i = 0; i < npl.size(); i++)
+      num_points_in_lod[i] = npl[npl.size() - 1 - i];
+    return GPCC_OK;
+  };
+  int r = run();
+  hipStreamSynchronize(st);
+  cleanup();
+  return r;
 }
 
 }  // extern "C"

@@ -1,0 +1,799 @@
+// lod_kernels.hpp -- level-of-detail generation on gfx950
+// (buildPredictorsFast, tmc3/PCCTMC3Common.h:2300-2469) for intra,
+// non-scalable attribute coding.
+//
+// The reference walks the Morton-sorted point list once per LoD with two
+// pieces of sliding state (a 128^3-cell "atlas" and a window cursor).  Here:
+//
+//  * sub-sampling by distance (subsampleByDistance :1984-2085) is a greedy
+//    over points, but its state collapses per CELL of size 2^(shift+1): at
+//    most one point of a cell is retained (the first without a retained
+//    point within the radius in the 19 neighbour cells of its atlas block),
+//    and a cell only depends on neighbour cells that PRECEDE it in Morton
+//    order.  Cells are processed by a dependency-ordered kernel (tickets +
+//    done flags, the scheme of raht_subnode.hpp), one lane per cell.
+//  * the nearest-neighbour search of a refinement point
+//    (computeNearestNeighbors :1147-1953) is a pure function of the point,
+//    the sorted retained list, its three-level bounding boxes and one scalar
+//    per LoD (`atlas_limit`, see lod_atlas_limit_kernel): one thread per
+//    point replays the reference's exact visit order (27 atlas cells, then
+//    the +-range window with box pruning, then the same-LoD window, then the
+//    distribution-aware replacement of the third neighbour), with the atlas
+//    look-ups replaced by binary searches in the retained list.
+#pragma once
+
+#include "raht_common.hpp"
+#include "raht_subnode.hpp"
+#include "lift_kernels.hpp"
+
+namespace gpcc {
+
+constexpr int kAtlasBits = 21;  // 3 * log2(128)
+
+struct LodCtx {
+  int32_t n;                 // points of the slice
+  const int64_t* code;       // [n] sorted Morton codes
+  const int32_t* order;      // [n] point index of each sorted entry
+  const int32_t* pos;        // [n][3] positions, sorted order
+  const int32_t* bpos;       // [n][3] positions * lodNeighBias, sorted order
+  // the LoD being built
+  const int32_t* input;      // [n_in] packed (sorted-order) indices, ascending
+  int32_t n_in;
+  int32_t shift3;            // 3 * (shift bits) of this step
+  int32_t boundary;          // min(63, shift3 + 21)
+  int64_t radius2;
+  // cells of the input list (sub-sampling by distance)
+  int32_t* cell_first;       // [ncell + 1] position in `input`
+  int32_t ncell;
+  int32_t* cell_ret;         // [ncell] packed index retained in the cell, -1 none
+  int32_t* done;             // [ncell] == epoch when decided
+  int32_t* ticket;           // [8]
+  int32_t* error;
+  int32_t epoch;
+  uint8_t* flags;            // [n_in] 1 = retained
+};
+
+__device__ __forceinline__ int64_t
+norm2_i3(const int32_t* a, const int32_t* b)
+{
+  const int64_t dx = (int64_t)a[0] - b[0], dy = (int64_t)a[1] - b[1], dz = (int64_t)a[2] - b[2];
+  return dx * dx + dy * dy + dz * dz;
+}
+__device__ __forceinline__ int32_t
+norm1_i3(const int32_t* a, const int32_t* b)
+{
+  return abs(a[0] - b[0]) + abs(a[1] - b[1]) + abs(a[2] - b[2]);
+}
+
+// ---- gather sorted positions ---------------------------------------------
+__global__ __launch_bounds__(256) void
+lod_gather_pos_kernel(
+  int n, const int32_t* __restrict__ xyz, const int32_t* __restrict__ order,
+  int b0, int b1, int b2, int32_t* pos, int32_t* bpos, int32_t* list)
+{
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += gridDim.x * blockDim.x) {
+    const int p = order[i];
+    const int32_t x = xyz[3 * (size_t)p], y = xyz[3 * (size_t)p + 1], z = xyz[3 * (size_t)p + 2];
+    pos[3 * (size_t)i] = x;
+    pos[3 * (size_t)i + 1] = y;
+    pos[3 * (size_t)i + 2] = z;
+    bpos[3 * (size_t)i] = x * b0;
+    bpos[3 * (size_t)i + 1] = y * b1;
+    bpos[3 * (size_t)i + 2] = z * b2;
+    list[i] = i;
+  }
+}
+
+// ---- stable partition of positions 0..n-1 by a flag ----------------------
+// out_true / out_false receive list[t] of the flagged / unflagged positions
+// in order; counts[0] = number flagged.  Decoupled look-back over <= 1024
+// resident workgroups (cf. raht_level_prepass_kernel).
+__global__ __launch_bounds__(256) void
+lod_partition_kernel(
+  int n, const uint8_t* __restrict__ flags, const int32_t* __restrict__ list,
+  int32_t* out_true, int32_t* out_false, int32_t* counts,
+  unsigned long long* scan_state, int epoch)
+{
+  __shared__ int wave_cnt[4];
+  __shared__ int base_s;
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  const int64_t chunks = ((int64_t)n + 255) >> 8;
+  const int64_t per = (chunks + gridDim.x - 1) / gridDim.x;
+  const int64_t gbeg = min((int64_t)blockIdx.x * per, chunks);
+  const int64_t gend = min(gbeg + per, chunks);
+  int mine = 0;
+  for (int64_t ch = gbeg; ch < gend; ch++) {
+    const int t = (int)(ch * 256) + threadIdx.x;
+    if (t < n)
+      mine += flags[t] != 0;
+  }
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1)
+    mine += __shfl_xor(mine, d);
+  if (lane == 0)
+    wave_cnt[wave] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long ep = (unsigned long long)epoch << 48;
+    const unsigned total = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    unsigned excl = 0;
+    if (blockIdx.x > 0) {
+      __hip_atomic_store(&scan_state[blockIdx.x], ep | (1ull << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int k = (int)blockIdx.x - 1;
+      for (;;) {
+        const unsigned long long v = __hip_atomic_load(&scan_state[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((v >> 48) != (unsigned long long)epoch) {
+          __builtin_amdgcn_s_sleep(2);
+          continue;
+        }
+        excl += (unsigned)v;
+        if (((v >> 32) & 0xffff) == 2)
+          break;
+        k--;
+      }
+    }
+    __hip_atomic_store(&scan_state[blockIdx.x], ep | (2ull << 32) | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (blockIdx.x == gridDim.x - 1)
+      counts[0] = (int)(excl + total);
+    base_s = (int)excl;
+  }
+  __syncthreads();
+  int running = base_s;
+  for (int64_t ch = gbeg; ch < gend; ch++) {
+    const int t = (int)(ch * 256) + threadIdx.x;
+    const bool f = t < n && flags[t] != 0;
+    const unsigned long long m = __ballot(f);
+    __syncthreads();
+    if (lane == 0)
+      wave_cnt[wave] = __popcll(m);
+    __syncthreads();
+    int off = running;
+    for (int w = 0; w < wave; w++)
+      off += wave_cnt[w];
+    const int rank_true = off + __popcll(m & ((1ull << lane) - 1));
+    if (t < n) {
+      if (f)
+        out_true[rank_true] = list[t];
+      else if (out_false)
+        out_false[t - rank_true] = list[t];
+    }
+    running += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+  }
+}
+
+// ---- sub-sampling ----------------------------------------------------------
+// periodic decimation (subsampleByDecimation :2198-2214)
+__global__ __launch_bounds__(256) void
+lod_flag_periodic_kernel(int n_in, int period, uint8_t* flags)
+{
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n_in;
+       t += gridDim.x * blockDim.x)
+    flags[t] = (t % period) == 0;
+}
+
+// cell heads of the input list
+__global__ __launch_bounds__(256) void
+lod_flag_cell_heads_kernel(LodCtx cx, uint8_t* heads, int32_t* positions)
+{
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < cx.n_in;
+       t += gridDim.x * blockDim.x) {
+    const int64_t c = cx.code[cx.input[t]] >> cx.shift3;
+    heads[t] = t == 0 || (cx.code[cx.input[t - 1]] >> cx.shift3) != c;
+    positions[t] = t;
+    cx.flags[t] = 0;
+  }
+}
+
+__device__ __forceinline__ int
+find_cell(const LodCtx& cx, int64_t key)
+{
+  int lo = 0, hi = cx.ncell;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if ((cx.code[cx.input[cx.cell_first[mid]]] >> cx.shift3) < key)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  if (lo < cx.ncell && (cx.code[cx.input[cx.cell_first[lo]]] >> cx.shift3) == key)
+    return lo;
+  return -1;
+}
+
+// subsampleByDistance: one lane per cell, dependency ordered
+__global__ __launch_bounds__(256, 2) void
+lod_subsample_distance_kernel(LodCtx cx)
+{
+  constexpr uint8_t kOff[19] = {3, 5, 6, 12, 10, 17, 20, 34, 33, 4,
+                                2, 1, 24, 40, 48, 32, 16, 8, 0};
+  const int lane = lane_id();
+  const int cls = blockIdx.x & 7;
+  for (;;) {
+    int tk = 0;
+    if (lane == 0)
+      tk = atomicAdd(&cx.ticket[cls], 1);
+    tk = __shfl(tk, 0);
+    const int64_t wround = (int64_t)tk * 8 + cls;
+    if (wround * 64 >= cx.ncell)
+      break;
+    const int x = (int)(wround * 64) + lane;
+    const bool live = x < cx.ncell;
+    int deps[19];
+    int ndep = 0;
+    int t0 = 0, t1 = 0;
+    if (live) {
+      t0 = cx.cell_first[x];
+      t1 = cx.cell_first[x + 1];
+      const int64_t cell = cx.code[cx.input[t0]] >> cx.shift3;
+      const int64_t atlas = cx.code[cx.input[t0]] >> cx.boundary;
+      const uint64_t base = morton3d_add((uint64_t)cell, ~0ull);
+#pragma unroll
+      for (int k = 0; k < 19; k++) {
+        const int64_t nb = (int64_t)morton3d_add(base, kOff[k]);
+        deps[k] = -1;
+        if ((nb >> kAtlasBits) != atlas || nb < 0)
+          continue;
+        const int c = find_cell(cx, nb);
+        // only cells that precede this one hold retained points when it is
+        // examined; later cells never matter
+        if (c >= 0 && c < x) {
+          deps[k] = c;
+          ndep++;
+        }
+      }
+    }
+    bool pending = live;
+    unsigned spins = 0;
+    while (__any(pending)) {
+      bool unmet = false;
+      if (pending) {
+#pragma unroll
+        for (int k = 0; k < 19; k++)
+          if (deps[k] >= 0 && load_agent_i32(&cx.done[deps[k]]) != cx.epoch)
+            unmet = true;
+      }
+      const bool ready = pending && !unmet;
+      if (!__any(ready)) {
+        if (++spins > (1u << 24)) {
+          if (lane == 0)
+            atomicExch(cx.error, 1);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+        continue;
+      }
+      if (ready) {
+        int32_t rp[19][3];
+        int nr = 0;
+#pragma unroll
+        for (int k = 0; k < 19; k++) {
+          if (deps[k] < 0)
+            continue;
+          const int r = load_agent_i32(&cx.cell_ret[deps[k]]);
+          if (r >= 0) {
+            rp[nr][0] = cx.pos[3 * (size_t)r];
+            rp[nr][1] = cx.pos[3 * (size_t)r + 1];
+            rp[nr][2] = cx.pos[3 * (size_t)r + 2];
+            nr++;
+          }
+        }
+        int kept = -1;
+        for (int t = t0; t < t1 && kept < 0; t++) {
+          const int idx = cx.input[t];
+          const int32_t* p = &cx.pos[3 * (size_t)idx];
+          bool found = false;
+          for (int q = 0; q < nr && !found; q++)
+            found = norm2_i3(rp[q], p) <= cx.radius2;
+          if (!found) {
+            kept = idx;
+            cx.flags[t] = 1;
+          }
+        }
+        __hip_atomic_store(&cx.cell_ret[x], kept, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (ready)
+        __hip_atomic_store(&cx.done[x], cx.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      pending = pending && !ready;
+    }
+  }
+}
+
+// ---- nearest-neighbour search ----------------------------------------------
+struct NnCtx {
+  int32_t n;
+  const int64_t* code;
+  const int32_t* order;
+  const int32_t* bpos;       // [n][3] biased positions, sorted order
+  const int32_t* retained;   // [n_ret] packed indices (ascending codes)
+  int32_t n_ret;
+  const int32_t* refine;     // [n_ref] packed indices of this LoD's points
+  int32_t n_ref;
+  int32_t start;             // position of refine[0] in the coding-order list
+  int32_t shift3, boundary;
+  int32_t distribution, range_inter, range_intra, intra, max_neigh;
+  const int32_t* box_ret[3][2];  // [level][min/max] -> [buckets][3]
+  const int32_t* box_ref[3][2];
+  const long long* atlas_limit;
+  // outputs (predictor p = n - 1 - position in coding-order list)
+  int32_t* pred_count;       // [n]
+  int32_t* pred_point;       // [n][3] neighbour POINT index
+  uint64_t* pred_dist2;      // [n][3]
+  int32_t* pt2pred;          // [n]
+  int32_t* indexes;          // [n] predictor order -> point index
+};
+
+struct NnState {
+  int32_t idx[6];
+  int64_t dist[6];
+  int idx2;
+};
+
+__device__ __forceinline__ void
+nn_update(NnState& s, int32_t d, int32_t index)
+{
+  if (d >= s.dist[2])
+    return;
+  if (d < s.dist[0]) {
+    s.dist[2] = s.dist[1];
+    s.dist[1] = s.dist[0];
+    s.dist[0] = d;
+    s.idx[2] = s.idx[1];
+    s.idx[1] = s.idx[0];
+    s.idx[0] = index;
+  } else if (d < s.dist[1]) {
+    s.dist[2] = s.dist[1];
+    s.dist[1] = d;
+    s.idx[2] = s.idx[1];
+    s.idx[1] = index;
+  } else {
+    s.dist[2] = d;
+    s.idx[2] = index;
+  }
+}
+
+// slots 3..5 form a small ring written at s.idx2; the register-array form
+// avoids dynamic indexing
+__device__ __forceinline__ void
+nn_push_extra(NnState& s, int32_t v)
+{
+  if (s.idx2 == 3)
+    s.idx[3] = v;
+  else if (s.idx2 == 4)
+    s.idx[4] = v;
+  else
+    s.idx[5] = v;
+  s.idx2++;
+}
+
+__device__ __forceinline__ void
+nn_update_dist(NnState& s, int32_t d, int32_t index)
+{
+  if (d > s.dist[2]) {
+  } else if (d < s.dist[0]) {
+    if (s.idx[2] != -1)
+      nn_push_extra(s, s.idx[2]);
+    s.dist[2] = s.dist[1];
+    s.dist[1] = s.dist[0];
+    s.dist[0] = d;
+    s.idx[2] = s.idx[1];
+    s.idx[1] = s.idx[0];
+    s.idx[0] = index;
+  } else if (d < s.dist[1]) {
+    if (s.idx[2] != -1)
+      nn_push_extra(s, s.idx[2]);
+    s.dist[2] = s.dist[1];
+    s.dist[1] = d;
+    s.idx[2] = s.idx[1];
+    s.idx[1] = index;
+  } else if (d < s.dist[2]) {
+    if (s.idx[2] != -1)
+      nn_push_extra(s, s.idx[2]);
+    s.dist[2] = d;
+    s.idx[2] = index;
+  } else if (s.idx[5] == -1) {
+    nn_push_extra(s, index);
+  }
+  if (s.idx2 == 6)
+    s.idx2 = 3;
+}
+
+__device__ __forceinline__ void
+nn_visit(NnState& s, bool distribution, bool check, int32_t d, int32_t index)
+{
+  if (check) {
+    if (index == s.idx[0] || index == s.idx[1] || index == s.idx[2])
+      return;
+    if (distribution && (index == s.idx[3] || index == s.idx[4] || index == s.idx[5]))
+      return;
+  }
+  if (distribution)
+    nn_update_dist(s, d, index);
+  else
+    nn_update(s, d, index);
+}
+
+__device__ __forceinline__ int32_t
+box_dist1(const int32_t* const box[2], int b, const int32_t* p)
+{
+  int32_t s = 0;
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    const int32_t a = box[0][3 * (size_t)b + d] - p[d];
+    const int32_t c = p[d] - box[1][3 * (size_t)b + d];
+    const int32_t m = a > 0 ? a : 0;
+    s += m > c ? m : c;
+  }
+  return s;
+}
+
+// the bucketed window scans of :1436-1522 / :1551-1604 over a list whose
+// biased positions are bpos[list[k]]; candidates are reported as `k` (list
+// position) or list[k] (packed index)
+__device__ __forceinline__ void
+window_scan(
+  NnState& s, const int32_t* const box[3][2], const int32_t* __restrict__ bpos,
+  const int32_t* __restrict__ list, const int32_t* bp, int k0, int k1, int dir,
+  bool distribution, bool check, bool report_packed)
+{
+  if (k0 > k1)
+    return;
+  if (dir > 0) {
+    for (int b2 = k0 >> 15; b2 <= (k1 >> 15); b2++) {
+      if (s.idx[2] != -1 && box_dist1(box[2], b2, bp) >= s.dist[2])
+        continue;
+      const int s1 = max(k0 >> 10, b2 << 5), e1 = min(k1 >> 10, (b2 << 5) + 31);
+      for (int b1 = s1; b1 <= e1; b1++) {
+        if (s.idx[2] != -1 && box_dist1(box[1], b1, bp) >= s.dist[2])
+          continue;
+        const int s0 = max(k0 >> 5, b1 << 5), e0 = min(k1 >> 5, (b1 << 5) + 31);
+        for (int b0 = s0; b0 <= e0; b0++) {
+          if (s.idx[2] != -1 && box_dist1(box[0], b0, bp) >= s.dist[2])
+            continue;
+          const int h0 = max(k0, b0 << 5), h1 = min(k1, (b0 << 5) + 31);
+          for (int k = h0; k <= h1; k++) {
+            const int pk = list[k];
+            nn_visit(s, distribution, check, norm1_i3(bp, &bpos[3 * (size_t)pk]), report_packed ? pk : k);
+          }
+        }
+      }
+    }
+  } else {
+    for (int c2 = k1 >> 15; c2 >= (k0 >> 15); c2--) {
+      if (s.idx[2] != -1 && box_dist1(box[2], c2, bp) >= s.dist[2])
+        continue;
+      const int s1 = max(k0 >> 10, c2 << 5), e1 = min(k1 >> 10, (c2 << 5) + 31);
+      for (int c1 = e1; c1 >= s1; c1--) {
+        if (s.idx[2] != -1 && box_dist1(box[1], c1, bp) >= s.dist[2])
+          continue;
+        const int s0 = max(k0 >> 5, c1 << 5), e0 = min(k1 >> 5, (c1 << 5) + 31);
+        for (int c0 = e0; c0 >= s0; c0--) {
+          if (s.idx[2] != -1 && box_dist1(box[0], c0, bp) >= s.dist[2])
+            continue;
+          const int h0 = max(k0, c0 << 5), h1 = min(k1, (c0 << 5) + 31);
+          for (int k = h1; k >= h0; k--) {
+            const int pk = list[k];
+            nn_visit(s, distribution, check, norm1_i3(bp, &bpos[3 * (size_t)pk]), report_packed ? pk : k);
+          }
+        }
+      }
+    }
+  }
+}
+
+// level-0 boxes: one thread per bucket of 32 list entries
+__global__ __launch_bounds__(256) void
+lod_box0_kernel(
+  int n_list, const int32_t* __restrict__ list, const int32_t* __restrict__ bpos,
+  int32_t* bmin, int32_t* bmax)
+{
+  const int nb = (n_list + 31) >> 5;
+  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < nb;
+       b += gridDim.x * blockDim.x) {
+    int32_t mn[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, mx[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+    const int e = min(n_list, (b + 1) << 5);
+    for (int i = b << 5; i < e; i++)
+      for (int d = 0; d < 3; d++) {
+        const int32_t v = bpos[3 * (size_t)list[i] + d];
+        mn[d] = min(mn[d], v);
+        mx[d] = max(mx[d], v);
+      }
+    for (int d = 0; d < 3; d++) {
+      bmin[3 * (size_t)b + d] = mn[d];
+      bmax[3 * (size_t)b + d] = mx[d];
+    }
+  }
+}
+
+// upper levels: merge 32 boxes
+__global__ __launch_bounds__(256) void
+lod_box_up_kernel(
+  int n_lo, const int32_t* __restrict__ lo_min, const int32_t* __restrict__ lo_max,
+  int32_t* bmin, int32_t* bmax)
+{
+  const int nb = (n_lo + 31) >> 5;
+  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < nb;
+       b += gridDim.x * blockDim.x) {
+    int32_t mn[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, mx[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+    const int e = min(n_lo, (b + 1) << 5);
+    for (int i = b << 5; i < e; i++)
+      for (int d = 0; d < 3; d++) {
+        mn[d] = min(mn[d], lo_min[3 * (size_t)i + d]);
+        mx[d] = max(mx[d], lo_max[3 * (size_t)i + d]);
+      }
+    for (int d = 0; d < 3; d++) {
+      bmin[3 * (size_t)b + d] = mn[d];
+      bmax[3 * (size_t)b + d] = mx[d];
+    }
+  }
+}
+
+// The reference fills its atlas block by block from a cursor that only
+// advances over retained entries of the block being entered (:1349-1363): a
+// retained entry whose block holds no refinement point is never passed and
+// from that block on the atlas stays empty.  atlas_limit = smallest block id
+// of a retained entry without a refinement point in the same block.
+__global__ __launch_bounds__(256) void
+lod_atlas_limit_kernel(NnCtx cx, long long* atlas_limit)
+{
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < cx.n_ret;
+       r += gridDim.x * blockDim.x) {
+    const int64_t id = cx.code[cx.retained[r]] >> cx.boundary;
+    int lo = 0, hi = cx.n_ref;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if ((cx.code[cx.refine[mid]] >> cx.boundary) < id)
+        lo = mid + 1;
+      else
+        hi = mid;
+    }
+    const bool present = lo < cx.n_ref && (cx.code[cx.refine[lo]] >> cx.boundary) == id;
+    if (!present)
+      atomicMin(atlas_limit, (long long)id);
+  }
+}
+
+__device__ __forceinline__ void
+retained_cell_range(const NnCtx& cx, int64_t cell, int* r0, int* r1)
+{
+  int lo = 0, hi = cx.n_ret;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if ((cx.code[cx.retained[mid]] >> cx.shift3) < cell)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  *r0 = lo;
+  hi = cx.n_ret;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if ((cx.code[cx.retained[mid]] >> cx.shift3) <= cell)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  *r1 = lo;
+}
+
+__global__ __launch_bounds__(256) void
+lod_nn_search_kernel(NnCtx cx)
+{
+  constexpr uint8_t kNeigh[27] = {7,  3,  5,  6,  35, 21, 14, 28, 42,
+                                  49, 12, 10, 17, 20, 34, 33, 4,  2,
+                                  1,  56, 24, 40, 48, 32, 16, 8,  0};
+  const bool distribution = cx.distribution != 0;
+  const int64_t atlas_limit = *cx.atlas_limit;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < cx.n_ref;
+       q += gridDim.x * blockDim.x) {
+    NnState s;
+#pragma unroll
+    for (int h = 0; h < 6; h++) {
+      s.idx[h] = -1;
+      s.dist[h] = INT64_MAX;
+    }
+    s.idx2 = 3;
+    const int index = cx.refine[q];
+    const int64_t code = cx.code[index];
+    const int64_t atlas_id = code >> cx.boundary;
+    const int64_t cell = code >> cx.shift3;
+    const int32_t bp[3] = {cx.bpos[3 * (size_t)index], cx.bpos[3 * (size_t)index + 1], cx.bpos[3 * (size_t)index + 2]};
+
+    if (cx.n_ret) {
+      int lo = 0, hi = cx.n_ret;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (cx.code[cx.retained[mid]] <= code)
+          lo = mid + 1;
+        else
+          hi = mid;
+      }
+      const int j = min(lo, cx.n_ret - 1);
+      if (atlas_id < atlas_limit) {
+        const uint64_t base = morton3d_add((uint64_t)cell, ~0ull);
+        for (int nn = 0; nn < 27; nn++) {
+          const int64_t nb = (int64_t)morton3d_add(base, kNeigh[nn]);
+          if ((nb >> kAtlasBits) != atlas_id)
+            continue;
+          int r0, r1;
+          retained_cell_range(cx, nb, &r0, &r1);
+          for (int k = r0; k < r1; k++)
+            nn_visit(s, distribution, false, norm1_i3(bp, &cx.bpos[3 * (size_t)cx.retained[k]]), k);
+        }
+      }
+      if (s.idx[2] == -1) {
+        const int center = s.idx[0] == -1 ? j : s.idx[0];
+        const int k0 = max(0, center - cx.range_inter);
+        const int k1 = min(cx.n_ret - 1, center + cx.range_inter);
+        nn_visit(s, distribution, true, norm1_i3(bp, &cx.bpos[3 * (size_t)cx.retained[center]]), center);
+        for (int nn = 1; nn <= 2; nn++) {
+          const int kp = center + nn;
+          if (kp <= k1)
+            nn_visit(s, distribution, true, norm1_i3(bp, &cx.bpos[3 * (size_t)cx.retained[kp]]), kp);
+          const int kn = center - nn;
+          if (kn >= k0)
+            nn_visit(s, distribution, true, norm1_i3(bp, &cx.bpos[3 * (size_t)cx.retained[kn]]), kn);
+        }
+        const int p1 = min(cx.n_ret - 1, center + 3);
+        const int p0 = max(0, center - 3);
+        window_scan(s, cx.box_ret, cx.bpos, cx.retained, bp, p1, k1, +1, distribution, true, false);
+        window_scan(s, cx.box_ret, cx.bpos, cx.retained, bp, k0, p0, -1, distribution, true, false);
+      }
+      // retained-list positions -> packed indices
+#pragma unroll
+      for (int h = 0; h < 6; h++)
+        if ((h < 3 || distribution) && s.idx[h] != -1)
+          s.idx[h] = cx.retained[s.idx[h]];
+    }
+
+    if (cx.intra) {
+      const int k00 = q + 1;
+      const int k01 = min(cx.n_ref - 1, k00 + 2);
+      for (int k = k00; k <= k01; k++)
+        nn_visit(s, distribution, false, norm1_i3(bp, &cx.bpos[3 * (size_t)cx.refine[k]]), cx.refine[k]);
+      const int w0 = k01 + 1;
+      const int w1 = min(cx.n_ref - 1, k00 + cx.range_intra);
+      window_scan(s, cx.box_ref, cx.bpos, cx.refine, bp, w0, w1, +1, distribution, false, true);
+    }
+
+    int count = (s.idx[0] != -1) + (s.idx[1] != -1) + (s.idx[2] != -1);
+    count = min(cx.max_neigh, count);
+    if (distribution) {
+      const int c1 = 3 + (s.idx[3] != -1) + (s.idx[4] != -1) + (s.idx[5] != -1);
+#pragma unroll
+      for (int m = 3; m < 6; m++)
+        if (m < c1 && s.dist[m] == INT64_MAX)
+          s.dist[m] = norm1_i3(bp, &cx.bpos[3 * (size_t)s.idx[m]]);
+#pragma unroll
+      for (int m = 3; m < 6; m++)
+#pragma unroll
+        for (int l = m + 1; l < 6; l++)
+          if (l < c1 && s.dist[l] < s.dist[m]) {
+            const int32_t ti = s.idx[l];
+            s.idx[l] = s.idx[m];
+            s.idx[m] = ti;
+            const int64_t td = s.dist[l];
+            s.dist[l] = s.dist[m];
+            s.dist[m] = td;
+          }
+      if (count >= 3) {
+        // every index below is a compile-time constant after unrolling, so
+        // the candidate state stays in registers
+        constexpr int8_t loose[8][3] = {{3, 5, 6}, {2, 4, 7}, {1, 4, 7}, {0, 5, 6},
+                                        {1, 2, 7}, {0, 3, 6}, {0, 3, 5}, {1, 2, 4}};
+        int numend = 3;
+        bool open_end = true;
+#pragma unroll
+        for (int m = 3; m < 6; m++) {
+          open_end = open_end && m < c1 && (s.dist[m] << 5) < s.dist[2] * 54;
+          numend += open_end;
+        }
+        int dir[6];
+#pragma unroll
+        for (int h = 0; h < 6; h++) {
+          dir[h] = -1;
+          if (h < numend) {
+            const int32_t* o = &cx.bpos[3 * (size_t)s.idx[h]];
+            dir[h] = ((o[0] - bp[0] >= 0) << 2) + ((o[1] - bp[1] >= 0) << 1) + (o[2] - bp[2] >= 0);
+          }
+        }
+        bool replace = true;
+        int32_t rep = -1;
+        if (dir[1] == 7 - dir[0] || dir[2] == 7 - dir[0] || dir[2] == 7 - dir[1])
+          replace = false;
+#pragma unroll
+        for (int h = 3; h < 6; h++)
+          if (replace && h < numend && (dir[h] == 7 - dir[0] || dir[h] == 7 - dir[1])) {
+            replace = false;
+            rep = s.idx[h];
+          }
+        const bool e01 = dir[0] == dir[1], e02 = dir[0] == dir[2], e12 = dir[1] == dir[2];
+        int l0 = 0, l1 = 0, l2 = 0;
+#pragma unroll
+        for (int v = 0; v < 8; v++)
+          if (dir[0] == v) {
+            l0 = loose[v][0];
+            l1 = loose[v][1];
+            l2 = loose[v][2];
+          }
+        // which of the three candidate filters applies (:1861-1899)
+        int filter = 0;  // 1: in loose set, 2: differs from dir[0] and dir[1]
+        if ((e02 || e12) && e01)
+          filter = 1;
+        else if ((e02 || e12) && !e01)
+          filter = (dir[1] == l0 || dir[1] == l1 || dir[1] == l2) ? 0 : 2;
+        else if (e01)
+          filter = (dir[2] == l0 || dir[2] == l1 || dir[2] == l2) ? 0 : 1;
+#pragma unroll
+        for (int h = 3; h < 6; h++) {
+          const bool hit = filter == 1 ? (dir[h] == l0 || dir[h] == l1 || dir[h] == l2)
+                                       : (dir[h] != dir[0] && dir[h] != dir[1]);
+          if (replace && filter != 0 && h < numend && hit) {
+            replace = false;
+            rep = s.idx[h];
+          }
+        }
+        if (rep >= 0)
+          s.idx[2] = rep;
+      }
+    }
+    int32_t pp[3] = {0, 0, 0};
+    uint64_t pw[3] = {0, 0, 0};
+    for (int h = 0; h < count; h++) {
+      pp[h] = cx.order[s.idx[h]];
+      pw[h] = (uint64_t)norm2_i3(&cx.bpos[3 * (size_t)s.idx[h]], bp);
+    }
+    if (count > 1) {
+      if (pw[0] > pw[1]) {
+        const int32_t ti = pp[0]; pp[0] = pp[1]; pp[1] = ti;
+        const uint64_t tw = pw[0]; pw[0] = pw[1]; pw[1] = tw;
+      }
+      if (count == 3 && pw[1] > pw[2]) {
+        int32_t ti = pp[1]; pp[1] = pp[2]; pp[2] = ti;
+        uint64_t tw = pw[1]; pw[1] = pw[2]; pw[2] = tw;
+        if (pw[0] > pw[1]) {
+          ti = pp[0]; pp[0] = pp[1]; pp[1] = ti;
+          tw = pw[0]; pw[0] = pw[1]; pw[1] = tw;
+        }
+      }
+    }
+    const int pred = cx.n - 1 - (cx.start + q);
+    const int point = cx.order[index];
+    cx.pred_count[pred] = count;
+    for (int h = 0; h < 3; h++) {
+      cx.pred_point[3 * (size_t)pred + h] = pp[h];
+      cx.pred_dist2[3 * (size_t)pred + h] = pw[h];
+    }
+    cx.pt2pred[point] = pred;
+    cx.indexes[pred] = point;
+  }
+}
+
+// updatePredictors (:2273-2296) + optional computeWeights
+__global__ __launch_bounds__(256) void
+lod_finalise_kernel(
+  int n, int raw, int32_t* count, const int32_t* __restrict__ pred_point,
+  const int32_t* __restrict__ pt2pred, uint64_t* dist2, int32_t* neigh_index)
+{
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += gridDim.x * blockDim.x) {
+    int c = count[i];
+    uint64_t w0 = dist2[3 * (size_t)i];
+    if (c < 2) {
+      w0 = 1;
+    } else if (w0 == 0) {
+      c = 1;
+      w0 = 1;
+    }
+    dist2[3 * (size_t)i] = w0;
+    count[i] = c;
+    for (int k = 0; k < 3; k++) {
+      const int p = pred_point[3 * (size_t)i + k];
+      neigh_index[3 * (size_t)i + k] = k < c ? pt2pred[p] : p;
+    }
+  }
+}
+
+}  // namespace gpcc

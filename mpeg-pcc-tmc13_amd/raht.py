@@ -143,3 +143,18 @@ class Context:
         _lib.check(self._lib.gpcc_lod_compute_weights(self._h, nc.shape[0], nc.ctypes.data, d.ctypes.data,
                                                       w.ctypes.data))
         return nc, w
+
+    def lod_build(self, params, xyz):
+        """AttributeLods::generate -> dict(nc, ni, w, indexes, npl) in coding order"""
+        xyz = np.ascontiguousarray(xyz, dtype=np.int32)
+        n = xyz.shape[0]
+        nc = np.zeros(n, np.int32)
+        ni = np.zeros((n, 3), np.int32)
+        w = np.zeros((n, 3), np.int32)
+        idx = np.zeros(n, np.int32)
+        npl = np.zeros(32, np.int32)
+        nl = C.c_int32()
+        _lib.check(self._lib.gpcc_lod_build(self._h, C.byref(params), xyz.ctypes.data, n, nc.ctypes.data,
+                                            ni.ctypes.data, w.ctypes.data, idx.ctypes.data, npl.ctypes.data,
+                                            C.byref(nl)))
+        return dict(nc=nc, ni=ni, w=w, indexes=idx, npl=npl[:nl.value].copy())

@@ -1,0 +1,112 @@
+"""GPU parity of the level-of-detail generation (gpcc_lod_build, replacing
+AttributeLods::generate): predictor structure, weights, coding order and LoD
+sizes against the CPU oracle (itself pinned to the compiled reference), and
+against the compiled reference directly where it travelled.  Bit-exact."""
+import numpy as np
+import pytest
+
+import lod_helpers as lh
+import oracle_loader as ol
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from mpeg_pcc_tmc13_amd import context
+    c = context(0)
+    yield c
+    c.close()
+
+
+def clouds():
+    from mpeg_pcc_tmc13_amd import synth
+    return [("rand5", synth.random_cloud(5, seed=24, bits=2)[0]),
+            ("one", synth.random_cloud(1, seed=1, bits=3)[0]),
+            ("two", synth.random_cloud(2, seed=1, bits=3)[0]),
+            ("rand3k", synth.random_cloud(3000, seed=2, bits=5)[0]),
+            ("dups", synth.random_cloud(400, seed=9, bits=2, dup_fraction=0.3)[0]),
+            ("dense20k", synth.dense_cloud(20000, seed=4, bits=8)[0]),
+            ("lidar15k", synth.lidar_cloud(15000, seed=3)[0]),
+            ("sparse", synth.random_cloud(3000, seed=8, bits=20)[0])]
+
+
+VARIANTS = [dict(), dict(decimation=1), dict(distribution=False), dict(dist2=1),
+            dict(lifting=False, intra_range=64), dict(bias=(1, 2, 1)), dict(inter_range=8),
+            dict(neighbours=2), dict(levels=3), dict(decimation=1, sampling_period=2, levels=21)]
+
+
+def make_params(kw):
+    from mpeg_pcc_tmc13_amd import lod_params
+    lp = lod_params(**kw)
+    if kw.get("lifting") is False:
+        lp.intra_lod_prediction_skip_layers = 0
+    return lp
+
+
+@pytest.mark.parametrize("vi", range(len(VARIANTS)))
+def test_lod_build_vs_oracle(vi, ctx):
+    kw = VARIANTS[vi]
+    for name, xyz in clouds():
+        lp = make_params(kw)
+        o = lh.oracle_lod_generate(xyz, lp)
+        g = ctx.lod_build(lp, xyz)
+        np.testing.assert_array_equal(g["npl"], o["npl"], err_msg=f"{name} {kw}")
+        np.testing.assert_array_equal(g["indexes"], o["indexes"], err_msg=f"{name} {kw}")
+        np.testing.assert_array_equal(g["nc"], o["nc"], err_msg=f"{name} {kw}")
+        np.testing.assert_array_equal(g["ni"], o["ni"], err_msg=f"{name} {kw}")
+        np.testing.assert_array_equal(g["w"].astype(np.uint64), o["w"], err_msg=f"{name} {kw}")
+
+
+@pytest.mark.parametrize("kind,n", [("dense", 300000), ("lidar", 200000)])
+def test_lod_build_large(kind, n, ctx):
+    from mpeg_pcc_tmc13_amd import lod_params, synth
+    xyz = (synth.dense_cloud(n, seed=41, bits=10) if kind == "dense" else synth.lidar_cloud(n, seed=41))[0]
+    lp = lod_params()
+    chk = lh.ref_lod_generate(xyz, lp) if ol.ref_available() else lh.oracle_lod_generate(xyz, lp)
+    g = ctx.lod_build(lp, xyz)
+    for k in ("npl", "indexes", "nc", "ni"):
+        np.testing.assert_array_equal(g[k], chk[k], err_msg=k)
+    np.testing.assert_array_equal(g["w"].astype(np.uint64), chk["w"])
+
+
+@pytest.mark.parametrize("seed,n,bits,kw", [
+    (3, 400000, 9, {}),                                   # very dense: most distances tie
+    (5, 250000, 10, dict(neighbours=2)),
+    (9, 250000, 10, dict(distribution=False)),
+    (11, 350000, 10, dict(bias=(1, 2, 1), inter_range=32)),
+])
+def test_lod_build_ties(seed, n, bits, kw, ctx):
+    """Dense integer grids make equal L1 distances the common case; the order
+    candidates are visited in then decides the spare-candidate ring."""
+    from mpeg_pcc_tmc13_amd import lod_params, synth
+    xyz = synth.dense_cloud(n, seed=seed, bits=bits)[0]
+    lp = lod_params(**kw)
+    chk = lh.oracle_lod_generate(xyz, lp)
+    g = ctx.lod_build(lp, xyz)
+    for k in ("npl", "indexes", "nc", "ni"):
+        np.testing.assert_array_equal(g[k], chk[k], err_msg=k)
+    np.testing.assert_array_equal(g["w"].astype(np.uint64), chk["w"])
+
+
+def test_lod_then_lift_end_to_end(ctx):
+    """LoD build and lifting both on the device == reference LoD + oracle lift."""
+    from mpeg_pcc_tmc13_amd import lift_params, lod_params, synth
+    xyz, col = synth.dense_cloud(60000, seed=43, bits=9)
+    lp = lod_params()
+    g = ctx.lod_build(lp, xyz)
+    lf = lift_params(g["npl"], qp=34)
+    co, rec, lcp = ctx.lift_forward(lf, g["nc"], g["ni"], g["w"], g["indexes"], col)
+    o = lh.oracle_lod_generate(xyz, lp)
+    o_co, o_rec, _ = lh.lift(ol.oracle(), True, lf, o, col)
+    np.testing.assert_array_equal(co, o_co)
+    np.testing.assert_array_equal(rec, o_rec)
+
+
+def test_lod_unsupported_modes(ctx):
+    from mpeg_pcc_tmc13_amd import lod_params
+    from mpeg_pcc_tmc13_amd._lib import GpccError
+    xyz = np.zeros((4, 3), np.int32)
+    with pytest.raises(GpccError) as ei:
+        ctx.lod_build(lod_params(decimation=2), xyz)
+    assert ei.value.code == -2
