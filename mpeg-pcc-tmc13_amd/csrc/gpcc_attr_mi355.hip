@@ -1591,4 +1591,17 @@ gpcc_lod_build(
   return r;
 }
 
+#ifdef GPCC_STATS
+int
+gpcc_debug_stats(unsigned long long* out, int reset)
+{
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(gpcc::g_stats), sizeof(unsigned long long) * 16);
+  if (reset) {
+    unsigned long long z[16] = {};
+    hipMemcpyToSymbol(HIP_SYMBOL(gpcc::g_stats), z, sizeof(z));
+  }
+  return 0;
+}
+#endif
+
 }  // extern "C"

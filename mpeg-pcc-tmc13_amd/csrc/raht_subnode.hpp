@@ -64,6 +64,15 @@ store_agent_i64(int64_t* p, int64_t v)
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+#ifdef GPCC_STATS
+__device__ unsigned long long g_stats[16];
+#define STAT(i, v) atomicAdd(&g_stats[i], (unsigned long long)(v))
+#define STATMAX(i, v) atomicMax(&g_stats[i], (unsigned long long)(v))
+#else
+#define STAT(i, v)
+#define STATMAX(i, v)
+#endif
+
 template<int C, int MODE>
 __global__ __launch_bounds__(256, 4) void
 raht_level_sub_kernel(LevelCtx ctx)
@@ -458,13 +467,21 @@ raht_level_sub_kernel(LevelCtx ctx)
     int32_t qc[C];          // tentative quantised coefficients (encoder)
     uint32_t dr = kDescZero;  // RDOQ descriptor of rank t (lossy encoder)
     bool l_published = false;
+    int outk = 0, outv = -1;  // outgoing RDOQ state: 0 unknown, 1 transparent, 2/3 final (= outv)
 #pragma unroll
     for (int k = 0; k < C; k++) {
       pt[k] = 0;
       qc[k] = 0;
     }
+#ifdef GPCC_STATS
+    unsigned n_iter = 0, n_lb = 0;
+    if (kLossy && lane == 0) STAT(0, 1);
+#endif
     while (__any(stage != 3)) {
       bool progressed = false;
+#ifdef GPCC_STATS
+      n_iter++;
+#endif
       // ---- (X) neighbour flags ------------------------------------------
       bool unmet = false;
 #pragma unroll
@@ -663,7 +680,10 @@ raht_level_sub_kernel(LevelCtx ctx)
             lhat = below ? cfirst + (31 - __clz(below)) : l0;
             const bool fail = isthr && !((resets >> t) & 1)
               && (uint32_t)(ci - lhat) <= rthr;
-            resets |= group8_or(fail ? 1u << t : 0u);
+            const uint32_t more = group8_or(fail ? 1u << t : 0u);
+            if (!more)
+              break;
+            resets |= more;
           }
           const uint32_t below = resets & ((1u << t) - 1);
           lhat = below ? cfirst + (31 - __clz(below)) : l0;
@@ -671,85 +691,164 @@ raht_level_sub_kernel(LevelCtx ctx)
           return ci - 1 - lhat;  // zero-run length seen by rank t
         };
         uint32_t resets = 0;
-        if (lin_known) {
-          const int tz = resolve(lin, &resets);
-          zero_r = rvalid && rthr != kDescNever && (uint32_t)tz >= rthr;
-        } else {
+        bool hyp_same = false;
+        if (stage == 1 && !lin_known) {
+          // the two extreme hypotheses for the incoming L
           uint32_t ra, rb;
           const int tza = resolve(-1, &ra);
           const int tzb = resolve(cfirst - 1, &rb);
           const bool fa = rvalid && rthr != kDescNever && (uint32_t)tza >= rthr;
           const bool fb = rvalid && rthr != kDescNever && (uint32_t)tzb >= rthr;
-          const bool same = group8_or((fa != fb) ? 1u : 0u) == 0 && ra == rb;
+          hyp_same = group8_or((fa != fb) ? 1u : 0u) == 0 && ra == rb;
           resets = rb;
           zero_r = fb;
-          // outgoing L known before the decisions are: both hypotheses end
-          // with the same last reset -> publish it now, successors go on
           const int la = ra ? 31 - __clz(ra) : -1, lb = rb ? 31 - __clz(rb) : -1;
-          if (stage == 1 && !l_published && ra && la == lb) {
-            if (t == 0)
-              __hip_atomic_store(
-                &ctx.rdoq_state[wi],
-                ((unsigned long long)epoch << 48) | (2ull << 32) | (uint32_t)(cfirst + lb),
-                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            l_published = true;
-            progressed = true;
+          if (ra && la == lb) {
+            outk = 2;  // outgoing L known before the decisions are
+            outv = cfirst + lb;
+          } else if (hyp_same && !ra) {
+            outk = 1;  // no reset either way: L passes through
           }
-          if (!same || last_of_slice)
-            can = false;
         }
-        // look-back for the groups that need L: up to 8 steps of 8 words
-        if (stage == 1 && !can && !lin_known) {
-          for (int step = 0; step < 8 && !lin_known; step++) {
-            const int k = look - t;
-            unsigned long long sv = 0;
-            bool boundary = k < 0;
-            if (!boundary)
-              boundary = ctx.worklist[k] < sp0;
-            if (!boundary)
-              sv = __hip_atomic_load(&ctx.rdoq_state[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const bool cur_ep = (sv >> 48) == (unsigned long long)epoch;
-            // kind: 0 pending, 1 transparent, 2 final, 3 slice boundary
-            const int kind = boundary ? 3 : (cur_ep ? (int)((sv >> 32) & 0xffff) : 0);
-            const uint32_t stop = group8_or((kind != 1) ? 1u << t : 0u);
-            if (!stop) {
-              look -= 8;
-              continue;
+        const unsigned long long lead = 0x0101010101010101ull;
+        const unsigned long long below = (1ull << gbase) - 1;
+        // ---- look-back through memory, by the whole wave ------------------
+        // Only a group with no undecided group of its slice before it in the
+        // wave has to look further back; the lowest such group is served:
+        // 256 predecessor words per round trip (runs of transparent blocks
+        // can be 10^5 long), nearest non-transparent one decides.
+        {
+          const unsigned long long nt = __ballot(outk != 1) & lead & below;
+          const int pl = nt ? 63 - __clzll((long long)nt) : 0;
+          const int ps = __shfl(s, pl);
+          const bool want = stage == 1 && !lin_known && (!hyp_same || last_of_slice);
+          const bool external = want && (nt == 0 || ps != s);
+          const unsigned long long needy = __ballot(external) & lead;
+          if (needy) {
+            const int gl = __ffsll((long long)needy) - 1;
+            const int g_sp0 = __shfl(sp0, gl), g_s = __shfl(s, gl);
+            int g_look = __shfl(look, gl);
+            bool g_found = false, g_stuck = false;
+            int g_lin = -1;
+            for (int step = 0; step < 2 && !g_found && !g_stuck; step++) {
+              int kind[4];
+              uint32_t val[4];
+#pragma unroll
+              for (int u = 0; u < 4; u++) {
+                const int k = g_look - lane - 64 * u;
+                // both loads are issued unconditionally: one round trip
+                const int kc = k < 0 ? 0 : k;
+                const unsigned long long sv =
+                  __hip_atomic_load(&ctx.rdoq_state[kc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool boundary = k < 0 || ctx.worklist[kc] < g_sp0;
+                const bool cur_ep = (sv >> 48) == (unsigned long long)epoch;
+                // kind: 0 pending, 1 transparent, 2 final, 3 slice boundary
+                kind[u] = boundary ? 3 : (cur_ep ? (int)((sv >> 32) & 0xffff) : 0);
+                val[u] = (uint32_t)sv;
+              }
+              STAT(4, lane == 0);
+#pragma unroll
+              for (int u = 0; u < 4; u++) {
+                if (g_found || g_stuck)
+                  continue;
+                const unsigned long long stop = __ballot(kind[u] != 1);
+                if (!stop) {
+                  g_look -= 64;
+                  continue;
+                }
+                const int first = __ffsll((long long)stop) - 1;  // nearest non-transparent
+                const int fkind = __shfl(kind[u], first);
+                const int fval = __shfl((int)val[u], first);
+                if (fkind == 2) {
+                  g_lin = fval;
+                  g_found = true;
+                } else if (fkind == 3) {
+                  g_lin = ctx.slice_l[g_s];
+                  g_found = true;
+                } else {
+                  g_look -= first;  // pending: everything nearer is transparent
+                  g_stuck = true;
+                }
+              }
             }
-            const int first = __ffs(stop) - 1;  // nearest predecessor that is not transparent
-            const int fkind = __shfl(kind, gbase | first);
-            const int fval = __shfl((int)(uint32_t)sv, gbase | first);
-            if (fkind == 2) {
-              lin = fval;
-              lin_known = true;
-            } else if (fkind == 3) {
-              lin = ctx.slice_l[s];
-              lin_known = true;
-            } else {
-              look -= first;  // pending: everything nearer is transparent
-              break;
+            // nothing else to do in this wave: stay on the pending word
+            if (g_stuck && !__any(stage == 0)) {
+              for (int spin = 0; spin < 64 && !g_found; spin++) {
+                const unsigned long long sv =
+                  __hip_atomic_load(&ctx.rdoq_state[g_look], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((sv >> 48) == (unsigned long long)epoch) {
+                  const int kind = (int)((sv >> 32) & 0xffff);
+                  if (kind == 2) {
+                    g_lin = (int)(uint32_t)sv;
+                    g_found = true;
+                  } else if (kind == 1) {
+                    g_look -= 1;
+                    break;
+                  }
+                } else {
+                  __builtin_amdgcn_s_sleep(1);
+                }
+              }
+            }
+            if ((lane & 56) == gl) {
+              if (look != g_look)
+                progressed = true;
+              look = g_look;
+              if (g_found) {
+                lin = g_lin;
+                lin_known = true;
+                progressed = true;
+              }
             }
           }
-          if (lin_known) {
-            progressed = true;
-            const int tz = resolve(lin, &resets);
-            zero_r = rvalid && rthr != kDescNever && (uint32_t)tz >= rthr;
-            can = true;
+        }
+        // ---- L handed from group to group inside the wave (registers, no
+        // memory round trip): the nearest predecessor group that is not
+        // transparent supplies L when it is final
+        for (int pass = 0; pass < 8; pass++) {
+          if (stage == 1 && lin_known && outk != 3) {
+            uint32_t rr;
+            resolve(lin, &rr);
+            outk = 3;  // final, decisions made with the true L
+            outv = rr ? cfirst + (31 - __clz(rr)) : lin;
           }
+          const unsigned long long nt = __ballot(outk != 1) & lead & below;
+          const int pl = nt ? 63 - __clzll((long long)nt) : 0;
+          const int pk = __shfl(outk, pl);
+          const int pv = __shfl(outv, pl);
+          const int ps = __shfl(s, pl);
+          const bool want = stage == 1 && !lin_known && (!hyp_same || last_of_slice);
+          const bool found = want && nt != 0 && pk >= 2 && ps == s;
+          if (!__any(found))
+            break;
+          if (found) {
+            lin = pv;
+            lin_known = true;
+          }
+        }
+        if (stage == 1 && lin_known) {
+          const int tz = resolve(lin, &resets);
+          zero_r = rvalid && rthr != kDescNever && (uint32_t)tz >= rthr;
+        } else if (!hyp_same || last_of_slice) {
+          can = false;
+        }
+        // publish an outgoing L that is known before the block can commit
+        if (stage == 1 && !can && !l_published && outk >= 2) {
+          if (t == 0)
+            __hip_atomic_store(
+              &ctx.rdoq_state[wi],
+              ((unsigned long long)epoch << 48) | (2ull << 32) | (uint32_t)outv,
+              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          l_published = true;
+          progressed = true;
         }
         if (can && t == 0) {
           // publish the outgoing RDOQ state of this block
           const unsigned long long ep = (unsigned long long)epoch << 48;
-          unsigned long long word;
-          if (resets)
-            word = ep | (2ull << 32) | (uint32_t)(cfirst + (31 - __clz(resets)));
-          else if (lin_known)
-            word = ep | (2ull << 32) | (uint32_t)lin;
-          else
-            word = ep | (1ull << 32);
+          const unsigned long long word = outk >= 2 ? ep | (2ull << 32) | (uint32_t)outv : ep | (1ull << 32);
           __hip_atomic_store(&ctx.rdoq_state[wi], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (last_of_slice)
-            ctx.slice_l[s] = resets ? cfirst + (31 - __clz(resets)) : lin;
+            ctx.slice_l[s] = outv;
         }
       }
 
@@ -830,6 +929,9 @@ raht_level_sub_kernel(LevelCtx ctx)
           stage = 3;
       }
 
+#ifdef GPCC_STATS
+      if (kLossy && !progressed && lane == 0) STAT(2, 1);
+#endif
       if (!progressed) {
         if (++spins > (1u << 24)) {
           if (lane == 0)
@@ -839,6 +941,12 @@ raht_level_sub_kernel(LevelCtx ctx)
         __builtin_amdgcn_s_sleep(4);
       }
     }
+#ifdef GPCC_STATS
+    if (kLossy) {
+      if (lane == 0) { STAT(1, n_iter); STATMAX(5, n_iter); }
+      if (t == 0) { STATMAX(6, n_lb); if (n_lb) STAT(7, 1); if (wi - look > 1) STATMAX(8, wi - look); }
+    }
+#endif
   }
 }
 
