@@ -7,8 +7,11 @@ coefficients + reconstruction) followed by RAHT inverse (decoder side) of
 every frame of the batch.  At N=1 the workload is BASELINE.json configs[1]:
 a 1M-point lidar-shaped cloud (S-lidar, 18-bit grid, reflectance, C=1),
 flags of cfg/octree-raht-ctc-lossless-geom-lossy-attrs.yaml (qp 34, search
-range 2500) with raht_subnode_prediction_enabled_flag as stated in
-`config`.  With N>1 every rank transforms its own frame(s) (weak scaling,
+range 2500) and the reference's defaults for everything else, i.e.
+raht_subnode_prediction_enabled_flag = 1 (TMC3.cpp:1307).  The same frames
+with sub-node prediction switched off (blocks of a level independent) and
+the lifting path (LoD build + lifting forward/inverse, configs[2] shape)
+are reported in extra objects of the same line.  With N>1 every rank transforms its own frame(s) (weak scaling,
 frames shard one-per-GPU) and the quantised coefficients are gathered on
 rank 0 with one RCCL gather inside the timed region.
 
@@ -38,12 +41,13 @@ def parse():
     ap.add_argument("--frames", type=int, default=1, help="frames (slices) per GPU per step")
     ap.add_argument("--cloud", choices=["lidar", "dense"], default="lidar")
     ap.add_argument("--qp", type=int, default=34)
-    ap.add_argument("--subnode", type=int, default=0)
+    ap.add_argument("--subnode", type=int, default=1)
     ap.add_argument("--haar", type=int, default=0)
     ap.add_argument("--direction", choices=["both", "inverse"], default="both",
                     help="inverse: decoder only (coefficients prepared on the CPU outside the timed region)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the alternative-flag and lifting legs")
     return ap.parse_args()
 
 
@@ -191,29 +195,30 @@ def main():
                 "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(kt.items(), key=lambda kv: -kv[1][0])},
                 "kernel_sum_ms_per_step": round(total_ms / args.steps, 4),
             }
-        # ---- the same frames with the reference's DEFAULT flags ------------
-        # (raht_subnode_prediction_enabled_flag = 1: blocks of a level depend
-        # on earlier blocks of the level -- latency-bound)
-        if not args.subnode and args.direction == "both":
+        # ---- the same frames with sub-node prediction switched OFF -----------
+        # (blocks of a level are then independent: no dependency chain)
+        if not args.no_extras and args.direction == "both":
             p1 = p.copy()
-            p1.raht_subnode_prediction_enabled_flag = 1
-            p_saved = p
+            p1.raht_subnode_prediction_enabled_flag = 0 if args.subnode else 1
             def step1():
                 d_attrs.copy_(src)
                 ctx.dev_raht_forward(p1, offsets, d_morton.data_ptr(), d_attrs.data_ptr(), d_coeffs.data_ptr(), c)
                 ctx.dev_raht_inverse(p1, offsets, d_morton.data_ptr(), d_dec.data_ptr(), d_coeffs.data_ptr(), c)
             step1()
             torch.cuda.synchronize(dev)
-            k1 = 3
+            k1 = 10 if args.subnode else 3
             t1 = time.perf_counter()
             for _ in range(k1):
                 step1()
             torch.cuda.synchronize(dev)
             dt1 = (time.perf_counter() - t1) / k1
-            out["ctc_default_flags"] = {
-                "raht_subnode_prediction": 1, "value": round(n / dt1 / 1e6, 3), "unit": "Mpoints/s",
+            out["alt_flags"] = {
+                "raht_subnode_prediction": int(p1.raht_subnode_prediction_enabled_flag),
+                "value": round(n / dt1 / 1e6, 3), "unit": "Mpoints/s",
                 "ms_per_step": round(dt1 * 1e3, 3), "steps": k1,
                 "roundtrip_decoder_equals_encoder_recon": bool(torch.equal(d_attrs, d_dec))}
+        if not args.no_extras:
+            out["lifting"] = lifting_leg(ctx, args)
         # ---- CPU baseline: the compiled reference on one host core --------
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames[0], p, c)
@@ -223,6 +228,47 @@ def main():
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def lifting_leg(ctx, args):
+    """BASELINE configs[2] shape on one GPU: LoD build (kNN predictor search)
+    + lifting forward + inverse of one dense colour cloud.  gpcc_lod_build and
+    gpcc_lift_* are host-tier calls (host buffers in, host buffers out), so
+    these rates include the PCIe copies and the per-call device allocations."""
+    from mpeg_pcc_tmc13_amd import lift_params, lod_params, synth
+    n = min(args.points, 1_000_000)
+    xyz, col = synth.dense_cloud(n, seed=77, bits=10)
+    n = len(xyz)
+    lp = lod_params()
+    ctx.lod_build(lp, xyz[:1000])  # warm-up (module load)
+    t0 = time.perf_counter()
+    g = ctx.lod_build(lp, xyz)
+    t_lod = time.perf_counter() - t0
+    lf = lift_params(g["npl"], qp=34)
+    ctx.lift_forward(lf, g["nc"], g["ni"], g["w"], g["indexes"], col)
+    t0 = time.perf_counter()
+    co, rec, lcp = ctx.lift_forward(lf, g["nc"], g["ni"], g["w"], g["indexes"], col)
+    t_fwd = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    dec = ctx.lift_inverse(lf, g["nc"], g["ni"], g["w"], g["indexes"], co, lcp)
+    t_inv = time.perf_counter() - t0
+    res = {"workload": f"{n}-point S-dense colour cloud, {len(g['npl'])} LoDs, distance sub-sampling, 3 neighbours, qp 34",
+           "lod_build_ms": round(t_lod * 1e3, 2), "lift_forward_ms": round(t_fwd * 1e3, 2),
+           "lift_inverse_ms": round(t_inv * 1e3, 2),
+           "value": round(n / (t_lod + t_fwd + t_inv) / 1e6, 3), "unit": "Mpoints/s (host buffers, PCIe inclusive)",
+           "roundtrip_decoder_equals_encoder_recon": bool(np.array_equal(np.asarray(dec), np.asarray(rec)))}
+    if not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import lod_helpers as lh
+        import oracle_loader as ol
+        m = min(n, 200_000)
+        kind = "reference" if ol.ref_available() else "port"
+        t0 = time.perf_counter()
+        o = (lh.ref_lod_generate if kind == "reference" else lh.oracle_lod_generate)(xyz[:m], lp)
+        t_ref = time.perf_counter() - t0
+        res["cpu_lod_build"] = {"value": round(m / t_ref / 1e6, 4), "unit": "Mpoints/s", "cores": 1, "kind": kind,
+                                "sample": f"AttributeLods::generate on the first {m} points, {t_ref:.2f} s"}
+    return res
 
 
 def cpu_baseline(frame, p, c):

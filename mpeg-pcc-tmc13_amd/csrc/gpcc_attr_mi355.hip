@@ -1393,8 +1393,8 @@ gpcc_lod_build(
     DM(uint8_t, d_heads, N + 1)
     DM(int32_t, d_positions, N + 1)
     DM(int32_t, d_cell_first, N + 2)
-    DM(int32_t, d_cell_ret, N + 1)
-    DM(int32_t, d_done, N + 1)
+    DM(int64_t, d_cell_key, N + 1)
+    DM(uint32_t, d_cell_state, 4 * (N + 1))
     DM(int32_t, d_small, 64)  // ticket[8], error, counts[2]
     DM(unsigned long long, d_scan, 1024)
     DM(long long, d_atlas_limit, 1)
@@ -1411,7 +1411,7 @@ gpcc_lod_build(
     int32_t* d_error = d_small + 8;
     int32_t* d_counts = d_small + 16;
     HIP_TRY(hipMemcpyAsync(d_xyz, xyz, sizeof(int32_t) * 3 * N, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemsetAsync(d_done, 0, sizeof(int32_t) * (N + 1), st));
+    HIP_TRY(hipMemsetAsync(d_cell_state, 0, sizeof(uint32_t) * 4 * (N + 1), st));
     HIP_TRY(hipMemsetAsync(d_small, 0, sizeof(int32_t) * 64, st));
     HIP_TRY(hipMemsetAsync(d_scan, 0, sizeof(unsigned long long) * 1024, st));
     // Morton order (code, then index)
@@ -1424,9 +1424,12 @@ gpcc_lod_build(
       if (r)
         return r;
     }
-    lod_gather_pos_kernel<<<grid_for(n, 256), 256, 0, st>>>(
-      n, d_xyz, d_order, lp->lod_neigh_bias[0], lp->lod_neigh_bias[1],
-      lp->lod_neigh_bias[2], d_pos, d_bpos, d_list_a);
+    {
+      Timer tm(ctx, "lod_gather");
+      lod_gather_pos_kernel<<<grid_for(n, 256), 256, 0, st>>>(
+        n, d_xyz, d_order, lp->lod_neigh_bias[0], lp->lod_neigh_bias[1],
+        lp->lod_neigh_bias[2], d_pos, d_bpos, d_list_a);
+    }
 
     // box storage: [list 0 = retained, 1 = refine][level][min/max]
     int32_t* box[2][3][2];
@@ -1442,12 +1445,21 @@ gpcc_lod_build(
     }
     auto build_boxes = [&](int which, const int32_t* list, int cnt) {
       const int c0 = (cnt + 31) >> 5, c1 = (c0 + 31) >> 5;
-      lod_box0_kernel<<<grid_for(std::max(c0, 1), 256), 256, 0, st>>>(
-        cnt, list, d_bpos, box[which][0][0], box[which][0][1]);
-      lod_box_up_kernel<<<grid_for(std::max(c1, 1), 256), 256, 0, st>>>(
-        c0, box[which][0][0], box[which][0][1], box[which][1][0], box[which][1][1]);
-      lod_box_up_kernel<<<1, 256, 0, st>>>(
-        c1, box[which][1][0], box[which][1][1], box[which][2][0], box[which][2][1]);
+      {
+        Timer tm(ctx, "lod_boxes");
+        lod_box0_kernel<<<grid_for(std::max(c0, 1), 256), 256, 0, st>>>(
+          cnt, list, d_bpos, box[which][0][0], box[which][0][1]);
+      }
+      {
+        Timer tm(ctx, "lod_boxes");
+        lod_box_up_kernel<<<grid_for(std::max(c1, 1), 256), 256, 0, st>>>(
+          c0, box[which][0][0], box[which][0][1], box[which][1][0], box[which][1][1]);
+      }
+      {
+        Timer tm(ctx, "lod_boxes");
+        lod_box_up_kernel<<<1, 256, 0, st>>>(
+          c1, box[which][1][0], box[which][1][1], box[which][2][0], box[which][2][1]);
+      }
     };
 
     int scan_epoch = 0;
@@ -1455,8 +1467,11 @@ gpcc_lod_build(
                          int32_t* out_true, int32_t* out_false, int* n_true) -> int {
       scan_epoch++;
       const int grid = (int)std::min<int64_t>(1024, ((int64_t)cnt + 1023) / 1024);
-      lod_partition_kernel<<<std::max(grid, 1), 256, 0, st>>>(
-        cnt, flags, list, out_true, out_false, d_counts, d_scan, scan_epoch);
+      {
+        Timer tm(ctx, "lod_partition");
+        lod_partition_kernel<<<std::max(grid, 1), 256, 0, st>>>(
+          cnt, flags, list, out_true, out_false, d_counts, d_scan, scan_epoch);
+      }
       int32_t h = 0;
       HIP_TRY(hipMemcpyAsync(&h, d_counts, sizeof(int32_t), hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
@@ -1496,13 +1511,16 @@ gpcc_lod_build(
           lc.boundary = std::min(63, lc.shift3 + 21);
           lc.radius2 = (int64_t)3 << (shift_bits0 << 1);
           lc.cell_first = d_cell_first;
-          lc.cell_ret = d_cell_ret;
-          lc.done = d_done;
+          lc.cell_key = d_cell_key;
+          lc.cell_state = d_cell_state;
           lc.ticket = d_ticket;
           lc.error = d_error;
           lc.epoch = lod + 1;
           lc.flags = d_flags;
-          lod_flag_cell_heads_kernel<<<grid_for(n_in, 256), 256, 0, st>>>(lc, d_heads, d_positions);
+          {
+            Timer tm(ctx, "lod_cell_heads");
+            lod_flag_cell_heads_kernel<<<grid_for(n_in, 256), 256, 0, st>>>(lc, d_heads, d_positions);
+          }
           int ncell = 0;
           int r = partition(n_in, d_heads, d_positions, d_cell_first, nullptr, &ncell);
           if (r)
@@ -1511,8 +1529,12 @@ gpcc_lod_build(
             d_cell_first + ncell, &n_in, sizeof(int32_t), hipMemcpyHostToDevice, st));
           HIP_TRY(hipMemsetAsync(d_ticket, 0, sizeof(int32_t) * 8, st));
           lc.ncell = ncell;
+          lod_cell_keys_kernel<<<grid_for(ncell, 256), 256, 0, st>>>(lc);
           const int grid = (int)std::min<int64_t>(512, ((int64_t)ncell + 255) / 256);
-          lod_subsample_distance_kernel<<<std::max(8, (grid + 7) / 8 * 8), 256, 0, st>>>(lc);
+          {
+            Timer tm(ctx, "lod_subsample");
+            lod_subsample_distance_kernel<<<std::max(8, (grid + 7) / 8 * 8), 256, 0, st>>>(lc);
+          }
         }
         int r = partition(n_in, d_flags, d_input, d_ret, d_refine + start, &n_ret);
         if (r)
@@ -1558,16 +1580,25 @@ gpcc_lod_build(
         const long long inf = INT64_MAX;
         HIP_TRY(hipMemcpyAsync(d_atlas_limit, &inf, sizeof(inf), hipMemcpyHostToDevice, st));
         if (n_ret > 0)
-          lod_atlas_limit_kernel<<<grid_for(n_ret, 256), 256, 0, st>>>(nc, d_atlas_limit);
-        lod_nn_search_kernel<<<grid_for(n_ref, 256), 256, 0, st>>>(nc);
+          {
+            Timer tm(ctx, "lod_atlas_limit");
+            lod_atlas_limit_kernel<<<grid_for(n_ret, 256), 256, 0, st>>>(nc, d_atlas_limit);
+          }
+        {
+          Timer tm(ctx, "lod_nn_search");
+          lod_nn_search_kernel<<<grid_for(n_ref, 256), 256, 0, st>>>(nc);
+        }
       }
       if (n_ret > 0)
         npl.push_back(n_ret);
       std::swap(d_input, d_ret);
       n_in = n_ret;
     }
-    lod_finalise_kernel<<<grid_for(n, 256), 256, 0, st>>>(
-      n, 0, d_pred_count, d_pred_point, d_pt2pred, d_pred_dist2, d_neigh_index);
+    {
+      Timer tm(ctx, "lod_finalise");
+      lod_finalise_kernel<<<grid_for(n, 256), 256, 0, st>>>(
+        n, 0, d_pred_count, d_pred_point, d_pt2pred, d_pred_dist2, d_neigh_index);
+    }
     lod_compute_weights_kernel<<<grid_for(n, 256), 256, 0, st>>>(
       n, d_pred_count, d_pred_dist2, d_weight);
     HIP_TRY(hipGetLastError());

@@ -219,16 +219,40 @@ lift_update_apply_kernel(LiftCtx cx, int start, int direct)
 __global__ __launch_bounds__(256) void
 lift_lcp_sums_kernel(LiftCtx cx)
 {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cx.n;
-       i += gridDim.x * blockDim.x) {
-    const int64_t k1 = cx.a[(size_t)i * 3 + 1], k2 = cx.a[(size_t)i * 3 + 2];
-    // NB: the reference truncates both products to int before summing
-    const long long m12 = (int32_t)(k1 * k2), m11 = (int32_t)(k1 * k1);
+  const int lane = threadIdx.x & 63;
+  // wave-uniform loop: every lane of a wavefront takes part in the shuffles
+  for (int64_t base = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63); base < cx.n;
+       base += (int64_t)gridDim.x * blockDim.x) {
+    const int i = (int)base + lane;
+    const bool valid = i < cx.n;
+    long long m12 = 0, m11 = 0;
     int l = 0;
-    while (l < cx.num_lods - 1 && i >= cx.npl[l])
-      l++;
-    atomicAdd((unsigned long long*)&cx.lcp_sums[2 * l], (unsigned long long)m12);
-    atomicAdd((unsigned long long*)&cx.lcp_sums[2 * l + 1], (unsigned long long)m11);
+    if (valid) {
+      const int64_t k1 = cx.a[(size_t)i * 3 + 1], k2 = cx.a[(size_t)i * 3 + 2];
+      // NB: the reference truncates both products to int before summing
+      m12 = (int32_t)(k1 * k2);
+      m11 = (int32_t)(k1 * k1);
+      while (l < cx.num_lods - 1 && i >= cx.npl[l])
+        l++;
+    }
+    // one atomic pair per wavefront when its lanes share the LoD (almost
+    // always: indices are LoD-ordered); integer sums, order irrelevant
+    const int l0 = __shfl(l, 0);
+    if (__all(!valid || l == l0)) {
+      long long s12 = m12, s11 = m11;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) {
+        s12 += __shfl_xor(s12, d);
+        s11 += __shfl_xor(s11, d);
+      }
+      if (lane == 0) {
+        atomicAdd((unsigned long long*)&cx.lcp_sums[2 * l0], (unsigned long long)s12);
+        atomicAdd((unsigned long long*)&cx.lcp_sums[2 * l0 + 1], (unsigned long long)s11);
+      }
+    } else if (valid) {
+      atomicAdd((unsigned long long*)&cx.lcp_sums[2 * l], (unsigned long long)m12);
+      atomicAdd((unsigned long long*)&cx.lcp_sums[2 * l + 1], (unsigned long long)m11);
+    }
   }
 }
 

@@ -45,8 +45,8 @@ struct LodCtx {
   // cells of the input list (sub-sampling by distance)
   int32_t* cell_first;       // [ncell + 1] position in `input`
   int32_t ncell;
-  int32_t* cell_ret;         // [ncell] packed index retained in the cell, -1 none
-  int32_t* done;             // [ncell] == epoch when decided
+  int64_t* cell_key;         // [ncell] code >> shift3 of each cell
+  uint32_t* cell_state;      // [ncell][4] {x, y, z, tag} of the retained point (16-B granule)
   int32_t* ticket;           // [8]
   int32_t* error;
   int32_t epoch;
@@ -185,23 +185,25 @@ lod_flag_cell_heads_kernel(LodCtx cx, uint8_t* heads, int32_t* positions)
   }
 }
 
-__device__ __forceinline__ int
-find_cell(const LodCtx& cx, int64_t key)
+// keys of the cells (one binary-search probe = one load)
+__global__ __launch_bounds__(256) void
+lod_cell_keys_kernel(LodCtx cx)
 {
-  int lo = 0, hi = cx.ncell;
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if ((cx.code[cx.input[cx.cell_first[mid]]] >> cx.shift3) < key)
-      lo = mid + 1;
-    else
-      hi = mid;
-  }
-  if (lo < cx.ncell && (cx.code[cx.input[cx.cell_first[lo]]] >> cx.shift3) == key)
-    return lo;
-  return -1;
+  for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < cx.ncell;
+       x += gridDim.x * blockDim.x)
+    cx.cell_key[x] = cx.code[cx.input[cx.cell_first[x]]] >> cx.shift3;
 }
 
-// subsampleByDistance: one lane per cell, dependency ordered
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// subsampleByDistance (:1984-2085).  At most one point per cell is retained
+// and the decision of a cell depends on the retained points of up to 19
+// neighbour cells that precede it (same 128^3-cell atlas block): a wavefront
+// of dependencies, one lane per cell, cells claimed in Morton order.  A cell
+// publishes ONE 16-byte write-through granule {x, y, z, tag} (tag = epoch
+// and "a point was retained"); consumers poll the granules of their
+// neighbours directly -- the data is the flag (cdna_hip_programming.md G16,
+// form R2), one memory round trip per dependency hop.
 __global__ __launch_bounds__(256, 2) void
 lod_subsample_distance_kernel(LodCtx cx)
 {
@@ -209,6 +211,16 @@ lod_subsample_distance_kernel(LodCtx cx)
                                 2, 1, 24, 40, 48, 32, 16, 8, 0};
   const int lane = lane_id();
   const int cls = blockIdx.x & 7;
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(
+    cx.cell_state, 0, (int)(((size_t)cx.ncell + 1) * 16), 0x00020000);
+  const uint32_t tag_none = (uint32_t)cx.epoch << 1, tag_has = tag_none | 1;
+  constexpr int kCellCache = 8;
+  // retained points of the 19 neighbour cells of every lane, [k][axis][lane]
+  // (lane-strided: conflict-free; an owner's row is a broadcast read)
+  __shared__ int32_t nbr_s[4][19 * 3][64];
+  int32_t (*nbr)[64] = nbr_s[threadIdx.x >> 6];
+  // cell edge 2^(shift3/3): neighbour points are < 2 edges away per axis
+  const bool small = cx.shift3 <= 3 * 13;
   for (;;) {
     int tk = 0;
     if (lane == 0)
@@ -219,84 +231,210 @@ lod_subsample_distance_kernel(LodCtx cx)
       break;
     const int x = (int)(wround * 64) + lane;
     const bool live = x < cx.ncell;
-    int deps[19];
-    int ndep = 0;
     int t0 = 0, t1 = 0;
+    // ---- the 19 neighbour cells: lower_bound in cell_key[0, x), all
+    //      searches of a lane advance in lock step (loads in flight together)
+    int lo[19], hi[19];
+    int64_t want[19];
+    uint32_t vmask = 0;
+#pragma unroll
+    for (int k = 0; k < 19; k++) {
+      lo[k] = hi[k] = 0;
+      want[k] = 0;
+    }
     if (live) {
       t0 = cx.cell_first[x];
       t1 = cx.cell_first[x + 1];
-      const int64_t cell = cx.code[cx.input[t0]] >> cx.shift3;
-      const int64_t atlas = cx.code[cx.input[t0]] >> cx.boundary;
+      const int64_t cell = cx.cell_key[x];
+      const int64_t atlas = cell >> kAtlasBits;
       const uint64_t base = morton3d_add((uint64_t)cell, ~0ull);
 #pragma unroll
       for (int k = 0; k < 19; k++) {
         const int64_t nb = (int64_t)morton3d_add(base, kOff[k]);
-        deps[k] = -1;
-        if ((nb >> kAtlasBits) != atlas || nb < 0)
-          continue;
-        const int c = find_cell(cx, nb);
         // only cells that precede this one hold retained points when it is
         // examined; later cells never matter
-        if (c >= 0 && c < x) {
-          deps[k] = c;
-          ndep++;
+        if ((nb >> kAtlasBits) == atlas && nb >= 0 && nb < cell) {
+          want[k] = nb;
+          hi[k] = x;
+          vmask |= 1u << k;
         }
       }
     }
+    for (;;) {
+      bool active = false;
+#pragma unroll
+      for (int k = 0; k < 19; k++)
+        active |= lo[k] < hi[k];
+      if (!__any(active))
+        break;
+      int64_t kv[19];
+#pragma unroll
+      for (int k = 0; k < 19; k++)
+        kv[k] = lo[k] < hi[k] ? cx.cell_key[lo[k] + ((hi[k] - lo[k]) >> 1)] : 0;
+#pragma unroll
+      for (int k = 0; k < 19; k++)
+        if (lo[k] < hi[k]) {
+          const int mid = lo[k] + ((hi[k] - lo[k]) >> 1);
+          if (kv[k] < want[k])
+            lo[k] = mid + 1;
+          else
+            hi[k] = mid;
+        }
+    }
+    uint32_t pend = 0;
+    if (live) {
+#pragma unroll
+      for (int k = 0; k < 19; k++)
+        if (((vmask >> k) & 1) && lo[k] < x && cx.cell_key[lo[k]] == want[k])
+          pend |= 1u << k;
+    }
+
+    // the cell's first points, fetched while the neighbours are pending
+    int32_t cpx[kCellCache], cpy[kCellCache], cpz[kCellCache], cidx[kCellCache];
+#pragma unroll
+    for (int u = 0; u < kCellCache; u++) {
+      cpx[u] = cpy[u] = cpz[u] = cidx[u] = 0;
+      if (t0 + u < t1) {
+        const int idx = cx.input[t0 + u];
+        cidx[u] = idx;
+        cpx[u] = cx.pos[3 * (size_t)idx];
+        cpy[u] = cx.pos[3 * (size_t)idx + 1];
+        cpz[u] = cx.pos[3 * (size_t)idx + 2];
+      }
+    }
+    int nr = 0;  // retained neighbour points received so far (rows of nbr)
     bool pending = live;
     unsigned spins = 0;
     while (__any(pending)) {
-      bool unmet = false;
-      if (pending) {
+      // cells complete roughly in index order: watch only the highest
+      // pending neighbour, sweep the others once it has arrived (keeps the
+      // polling traffic of the cells far ahead of the wavefront small)
+      int watch = -1;
 #pragma unroll
-        for (int k = 0; k < 19; k++)
-          if (deps[k] >= 0 && load_agent_i32(&cx.done[deps[k]]) != cx.epoch)
-            unmet = true;
+      for (int k = 0; k < 19; k++)
+        if (((pend >> k) & 1) && lo[k] > watch)
+          watch = lo[k];
+      bool go = true;
+      // few neighbours left: poll them directly (no extra round trip on the
+      // dependency chain)
+      if (watch >= 0 && __popc(pend) > 3) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, watch * 16, 0, /*sc1*/ 16);
+        go = (v.w >> 1) == (uint32_t)cx.epoch;
       }
-      const bool ready = pending && !unmet;
+#pragma unroll
+      for (int k = 0; k < 19; k++) {
+        if (!go || !((pend >> k) & 1))
+          continue;
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lo[k] * 16, 0, /*sc1*/ 16);
+        if ((v.w >> 1) == (uint32_t)cx.epoch) {
+          if (v.w & 1) {
+            nbr[3 * nr][lane] = (int32_t)v.x;
+            nbr[3 * nr + 1][lane] = (int32_t)v.y;
+            nbr[3 * nr + 2][lane] = (int32_t)v.z;
+            nr++;
+          }
+          pend &= ~(1u << k);
+        }
+      }
+      const bool ready = pending && pend == 0;
       if (!__any(ready)) {
-        if (++spins > (1u << 24)) {
+        if (++spins > (1u << 22)) {
           if (lane == 0)
             atomicExch(cx.error, 1);
           break;
         }
-        __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_s_sleep(1);
         continue;
       }
+      int kept = -1;
+      int32_t kp[3] = {0, 0, 0};
       if (ready) {
-        int32_t rp[19][3];
-        int nr = 0;
+        // the first points of the cell were fetched before the wait
 #pragma unroll
-        for (int k = 0; k < 19; k++) {
-          if (deps[k] < 0)
+        for (int u = 0; u < kCellCache; u++) {
+          if (kept >= 0 || t0 + u >= t1)
             continue;
-          const int r = load_agent_i32(&cx.cell_ret[deps[k]]);
-          if (r >= 0) {
-            rp[nr][0] = cx.pos[3 * (size_t)r];
-            rp[nr][1] = cx.pos[3 * (size_t)r + 1];
-            rp[nr][2] = cx.pos[3 * (size_t)r + 2];
-            nr++;
-          }
-        }
-        int kept = -1;
-        for (int t = t0; t < t1 && kept < 0; t++) {
-          const int idx = cx.input[t];
-          const int32_t* p = &cx.pos[3 * (size_t)idx];
           bool found = false;
-          for (int q = 0; q < nr && !found; q++)
-            found = norm2_i3(rp[q], p) <= cx.radius2;
+          if (small) {
+            // neighbours lie in adjacent cells: |d| < 2^14, squares fit 32 bits
+            for (int q = 0; q < nr && !found; q++) {
+              const int32_t dx = nbr[3 * q][lane] - cpx[u], dy = nbr[3 * q + 1][lane] - cpy[u],
+                            dz = nbr[3 * q + 2][lane] - cpz[u];
+              found = (int64_t)(dx * dx + dy * dy + dz * dz) <= cx.radius2;
+            }
+          } else {
+            for (int q = 0; q < nr && !found; q++) {
+              const int64_t dx = (int64_t)nbr[3 * q][lane] - cpx[u], dy = (int64_t)nbr[3 * q + 1][lane] - cpy[u],
+                            dz = (int64_t)nbr[3 * q + 2][lane] - cpz[u];
+              found = dx * dx + dy * dy + dz * dz <= cx.radius2;
+            }
+          }
           if (!found) {
-            kept = idx;
-            cx.flags[t] = 1;
+            kept = cidx[u];
+            kp[0] = cpx[u];
+            kp[1] = cpy[u];
+            kp[2] = cpz[u];
+            cx.flags[t0 + u] = 1;
           }
         }
-        __hip_atomic_store(&cx.cell_ret[x], kept, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (ready)
-        __hip_atomic_store(&cx.done[x], cx.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      pending = pending && !ready;
+      // cells with more points: the whole wavefront scans 64 points per
+      // round trip for one such cell at a time (the scan sits on the
+      // dependency chain of every later cell)
+      for (;;) {
+        const unsigned long long big = __ballot(ready && kept < 0 && t0 + kCellCache < t1);
+        if (!big)
+          break;
+        const int owner = __ffsll((long long)big) - 1;
+        const int o_t1 = __shfl(t1, owner);
+        const int o_nr = __shfl(nr, owner);
+        int o_kept = -1, o_t = 0;
+        int32_t okp[3] = {0, 0, 0};
+        for (int tb = __shfl(t0, owner) + kCellCache; tb < o_t1 && o_kept < 0; tb += 64) {
+          const int t = tb + lane;
+          bool cand = false;
+          int idx = 0;
+          int32_t px = 0, py = 0, pz = 0;
+          if (t < o_t1) {
+            idx = cx.input[t];
+            px = cx.pos[3 * (size_t)idx];
+            py = cx.pos[3 * (size_t)idx + 1];
+            pz = cx.pos[3 * (size_t)idx + 2];
+            bool found = false;
+            for (int q = 0; q < o_nr && !found; q++) {
+              const int64_t dx = (int64_t)nbr[3 * q][owner] - px, dy = (int64_t)nbr[3 * q + 1][owner] - py,
+                            dz = (int64_t)nbr[3 * q + 2][owner] - pz;
+              found = dx * dx + dy * dy + dz * dz <= cx.radius2;
+            }
+            cand = !found;
+          }
+          const unsigned long long m = __ballot(cand);
+          if (m) {
+            const int first = __ffsll((long long)m) - 1;
+            o_kept = __shfl(idx, first);
+            o_t = tb + first;
+            okp[0] = __shfl(px, first);
+            okp[1] = __shfl(py, first);
+            okp[2] = __shfl(pz, first);
+          }
+        }
+        if (lane == owner) {
+          if (o_kept >= 0) {
+            kept = o_kept;
+            kp[0] = okp[0];
+            kp[1] = okp[1];
+            kp[2] = okp[2];
+            cx.flags[o_t] = 1;
+          } else {
+            t1 = t0;  // nothing retained: leave the loop
+          }
+        }
+      }
+      if (ready) {
+        const u32x4 st = {(uint32_t)kp[0], (uint32_t)kp[1], (uint32_t)kp[2], kept >= 0 ? tag_has : tag_none};
+        __builtin_amdgcn_raw_buffer_store_b128(st, rsrc, x * 16, 0, /*sc1*/ 16);
+        pending = false;
+      }
     }
   }
 }
