@@ -187,8 +187,10 @@ def main():
             achieved = alg_bytes / dom_s / 1e9
             out["roofline"] = {
                 "bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
+                "traffic": pmc_traffic(args, name),
                 "launches_per_step": dom_launches / args.steps,
+                "algorithmic_bytes_per_launch": round(alg_bytes * args.steps / dom_launches),
                 "avg_launch_us": round(dom_ms * 1e3 / dom_launches, 2),
                 "pipeline_achieved": round(alg_bytes / (ms_per_step / 1e3) / 1e9, 2),
                 "pipeline_frac": round(alg_bytes / (ms_per_step / 1e3) / 1e9 / HBM_PEAK_GBPS, 5),
@@ -230,6 +232,19 @@ def main():
         dist.destroy_process_group()
 
 
+def pmc_traffic(args, kernel):
+    """HBM bytes per launch of the dominant kernel (FETCH_SIZE + WRITE_SIZE),
+    from the committed rocprofv3 PMC passes of this exact workload
+    (profiles/r01_pmc_traffic.json); None for any other workload."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    default = (args.cloud == "lidar" and args.points == 1_000_000 and args.frames == 1 and args.subnode == 1
+               and args.qp == 34 and not args.haar and args.direction == "both")
+    if not default or not os.path.exists(path):
+        return None
+    rec = json.load(open(path)).get(kernel)
+    return None if rec is None else rec["fetch_bytes_per_launch"] + rec["write_bytes_per_launch"]
+
+
 def lifting_leg(ctx, args):
     """BASELINE configs[2] shape on one GPU: LoD build (kNN predictor search)
     + lifting forward + inverse of one dense colour cloud.  gpcc_lod_build and
@@ -261,13 +276,15 @@ def lifting_leg(ctx, args):
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import lod_helpers as lh
         import oracle_loader as ol
-        m = min(n, 200_000)
         kind = "reference" if ol.ref_available() else "port"
         t0 = time.perf_counter()
-        o = (lh.ref_lod_generate if kind == "reference" else lh.oracle_lod_generate)(xyz[:m], lp)
+        o = (lh.ref_lod_generate if kind == "reference" else lh.oracle_lod_generate)(xyz, lp)
         t_ref = time.perf_counter() - t0
-        res["cpu_lod_build"] = {"value": round(m / t_ref / 1e6, 4), "unit": "Mpoints/s", "cores": 1, "kind": kind,
-                                "sample": f"AttributeLods::generate on the first {m} points, {t_ref:.2f} s"}
+        same = all(np.array_equal(np.asarray(g[k]).astype(np.int64), np.asarray(o[k]).astype(np.int64))
+                   for k in ("npl", "indexes", "nc", "ni", "w"))
+        res["cpu_lod_build"] = {"value": round(n / t_ref / 1e6, 4), "unit": "Mpoints/s", "cores": 1, "kind": kind,
+                                "sample": f"AttributeLods::generate on the same {n} points, {t_ref:.2f} s",
+                                "gpu_result_identical": bool(same)}
     return res
 
 
@@ -281,16 +298,17 @@ def cpu_baseline(frame, p, c):
     kind = "reference" if ol.ref_available() else "port"
     chk = ol.ref() if kind == "reference" else ol.oracle()
     n = len(morton)
-    # bounded sample: at most ~400k points of the frame (a prefix in Morton
-    # order is a spatially compact sub-cloud), about 1-3 s of CPU work
-    m = min(n, 400_000)
+    # bounded sample: the whole frame, repeated until about 10 s of CPU work
+    reps, dt = 0, 0.0
     t0 = time.perf_counter()
-    co, rec = chk.raht_forward(p, morton[:m], attrs[:m])
-    chk.raht_inverse(p, morton[:m], co, c)
-    dt = time.perf_counter() - t0
-    return {"value": round(m / dt / 1e6, 4), "unit": "Mpoints/s", "cores": 1, "kind": kind,
-            "sample": f"forward+inverse of the first {m} points (Morton order) of frame 0, same flags, "
-                      f"{dt:.2f} s wall, host {os.cpu_count()} logical cores, 1 used"}
+    while reps < 12 and dt < 10.0:
+        co, rec = chk.raht_forward(p, morton, attrs)
+        chk.raht_inverse(p, morton, co, c)
+        reps += 1
+        dt = time.perf_counter() - t0
+    return {"value": round(n * reps / dt / 1e6, 4), "unit": "Mpoints/s", "cores": 1, "kind": kind,
+            "sample": f"forward+inverse of frame 0 ({n} points, same flags) x {reps}, "
+                      f"{dt:.1f} s wall, host {os.cpu_count()} logical cores, 1 used"}
 
 
 if __name__ == "__main__":
