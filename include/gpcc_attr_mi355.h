@@ -281,6 +281,17 @@ int gpcc_ctx_set_profiling(gpcc_ctx* ctx, int enable);
 int gpcc_ctx_kernel_times(
   gpcc_ctx* ctx, gpcc_kernel_time* out, int32_t max_entries);
 
+/* estimateDist2 (tmc3/AttributeEncoder.cpp:1684-1720, called from
+ * tmc3/encoder.cpp:1203 to derive attr_dist2_delta): for every
+ * sampling_period-th point of xyz[n][3] (coded order) the squared distance to
+ * the nearest other point within +-search_range positions; the
+ * `percentile`-th of those minima picks the smallest shift with
+ * 3 << (2*shift) >= dist2.  The distance scan runs on the device, the
+ * selection (std::nth_element in the reference) on the host.  Host tier. */
+int gpcc_estimate_dist2(
+  gpcc_ctx* ctx, const int32_t* xyz, int32_t n, int32_t sampling_period,
+  int32_t search_range, float percentile, int32_t* shift_bits);
+
 #ifdef __cplusplus
 }
 #endif

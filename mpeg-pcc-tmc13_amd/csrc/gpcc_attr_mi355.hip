@@ -23,6 +23,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <cmath>
 #include <vector>
 
 #include "gpcc_attr_mi355.h"
@@ -1620,6 +1621,60 @@ gpcc_lod_build(
   hipStreamSynchronize(st);
   cleanup();
   return r;
+}
+
+int
+gpcc_estimate_dist2(
+  gpcc_ctx* ctx, const int32_t* xyz, int32_t n, int32_t sampling_period,
+  int32_t search_range, float percentile, int32_t* shift_bits)
+{
+  if (!ctx)
+    return fail(GPCC_ERR_INVALID_ARG, "ctx is null");
+  if (!xyz || !shift_bits || n < 0 || sampling_period < 1 || search_range < 0
+      || !(percentile >= 0.f && percentile < 1.f))
+    return fail(GPCC_ERR_INVALID_ARG, "bad argument");
+  *shift_bits = 0;
+  if (n < 2)
+    return GPCC_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const int ns = (n + sampling_period - 1) / sampling_period;
+  int32_t* d_xyz = nullptr;
+  long long* d_dist = nullptr;
+  std::vector<long long> dists((size_t)ns);
+  int rc = GPCC_OK;
+  do {
+    if (hipMalloc((void**)&d_xyz, sizeof(int32_t) * 3 * (size_t)n) != hipSuccess
+        || hipMalloc((void**)&d_dist, sizeof(long long) * (size_t)ns) != hipSuccess) {
+      rc = fail(GPCC_ERR_OUT_OF_MEMORY, "hipMalloc(estimate_dist2)");
+      break;
+    }
+    hipError_t e = hipMemcpyAsync(d_xyz, xyz, sizeof(int32_t) * 3 * (size_t)n, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+      Timer tm(ctx, "estimate_dist2");
+      estimate_dist2_kernel<<<grid_for(ns * 64, 256), 256, 0, st>>>(
+        n, d_xyz, sampling_period, search_range, ns, d_dist);
+    }
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(dists.data(), d_dist, sizeof(long long) * (size_t)ns, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess)
+      e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+      rc = fail(GPCC_ERR_HIP, hipGetErrorString(e));
+      break;
+    }
+    // int p = int(std::floor(dists.size() * percentileEstimate)), :1712
+    const int p = int(std::floor(dists.size() * percentile));
+    std::nth_element(dists.begin(), dists.begin() + p, dists.end());
+    const long long dist2 = dists[p];
+    int shift = 0;
+    while ((int64_t(3) << (shift << 1)) < dist2 && shift < 20)
+      ++shift;
+    *shift_bits = shift;
+  } while (0);
+  hipFree(d_xyz);
+  hipFree(d_dist);
+  return rc;
 }
 
 #ifdef GPCC_STATS

@@ -934,4 +934,37 @@ lod_finalise_kernel(
   }
 }
 
+// estimateDist2 (tmc3/AttributeEncoder.cpp:1698-1709): one wavefront per
+// sampled point, lanes stride the +-range window
+__global__ __launch_bounds__(256) void
+estimate_dist2_kernel(
+  int n, const int32_t* __restrict__ xyz, int period, int range, int num_samples,
+  long long* __restrict__ dists)
+{
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  for (int smp = wave; smp < num_samples; smp += nwaves) {
+    const int index = smp * period;
+    const int k0 = max(0, index - range), k1 = min(n - 1, index + range);
+    const int32_t px = xyz[3 * (size_t)index], py = xyz[3 * (size_t)index + 1], pz = xyz[3 * (size_t)index + 2];
+    long long best = INT64_MAX;
+    for (int k = k0 + lane; k <= k1; k += 64) {
+      if (k == index)
+        continue;
+      const long long dx = (long long)px - xyz[3 * (size_t)k], dy = (long long)py - xyz[3 * (size_t)k + 1],
+                      dz = (long long)pz - xyz[3 * (size_t)k + 2];
+      const long long d = dx * dx + dy * dy + dz * dz;
+      best = d < best ? d : best;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const long long o = __shfl_xor(best, d);
+      best = o < best ? o : best;
+    }
+    if (lane == 0)
+      dists[smp] = best;
+  }
+}
+
 }  // namespace gpcc

@@ -158,3 +158,11 @@ class Context:
                                             ni.ctypes.data, w.ctypes.data, idx.ctypes.data, npl.ctypes.data,
                                             C.byref(nl)))
         return dict(nc=nc, ni=ni, w=w, indexes=idx, npl=npl[:nl.value].copy())
+
+    def estimate_dist2(self, xyz, sampling_period=100, search_range=128, percentile=0.85):
+        """pcc::estimateDist2 (encoder.cpp:1203 uses period 100, range 128) -> shift bits"""
+        xyz = np.ascontiguousarray(xyz, dtype=np.int32)
+        out = C.c_int32()
+        _lib.check(self._lib.gpcc_estimate_dist2(self._h, xyz.ctypes.data, xyz.shape[0], sampling_period,
+                                                 search_range, C.c_float(percentile), C.byref(out)))
+        return out.value

@@ -8,7 +8,7 @@
 // with the reference's own signatures, flattens the reference's parameter
 // structs into the POD block of include/gpcc_attr_mi355.h and runs the slice
 // on the MI355X through the C ABI.  When the device path declines a slice
-// (GPCC_ERR_UNSUPPORTED: inter prediction, sub-node prediction this round)
+// (GPCC_ERR_UNSUPPORTED: inter prediction)
 // or no GPU is present it calls the reference's CPU implementation, which
 // the integrator keeps in the link under a suffixed name (see
 // RAHT.cpp is compiled with

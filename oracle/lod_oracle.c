@@ -19,6 +19,7 @@
  */
 #include <limits.h>
 #include <stdint.h>
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -790,4 +791,56 @@ oracle_lod_generate(
   free(pt2pred);
   free(preds);
   return 0;
+}
+
+/* estimateDist2, tmc3/AttributeEncoder.cpp:1684-1720: every samplingPeriod-th
+ * point (coded order), nearest other point inside a +-searchRange index
+ * window, percentile of those squared distances -> smallest shift with
+ * 3 << (2 shift) >= dist2.  dists_out (optional) receives the per-sample
+ * minima in sample order. */
+static int
+cmp_i64(const void* a, const void* b)
+{
+  const int64_t x = *(const int64_t*)a, y = *(const int64_t*)b;
+  return (x > y) - (x < y);
+}
+
+int
+oracle_estimate_dist2(
+  const int32_t* xyz, int32_t n, int32_t sampling_period, int32_t search_range,
+  float percentile, int64_t* dists_out)
+{
+  if (n < 2)
+    return 0;
+  const int ns = (n + sampling_period - 1) / sampling_period;
+  int64_t* d = (int64_t*)malloc(sizeof(int64_t) * (size_t)ns);
+  int m = 0;
+  for (int index = 0; index < n; index += sampling_period) {
+    const int k0 = index - search_range > 0 ? index - search_range : 0;
+    const int k1 = index + search_range < n - 1 ? index + search_range : n - 1;
+    int64_t best = INT64_MAX;
+    for (int k = k0; k <= k1; k++) {
+      if (k == index)
+        continue;
+      int64_t s = 0;
+      for (int c = 0; c < 3; c++) {
+        const int64_t t = (int64_t)xyz[3 * index + c] - xyz[3 * k + c];
+        s += t * t;
+      }
+      if (s < best)
+        best = s;
+    }
+    d[m++] = best;
+  }
+  if (dists_out)
+    memcpy(dists_out, d, sizeof(int64_t) * (size_t)m);
+  /* int p = int(std::floor(dists.size() * percentileEstimate)): size_t -> float product */
+  const int p = (int)floorf((float)(size_t)m * percentile);
+  qsort(d, (size_t)m, sizeof(int64_t), cmp_i64);
+  const int64_t dist2 = d[p];
+  free(d);
+  int shift = 0;
+  while (((int64_t)3 << (shift << 1)) < dist2 && shift < 20)
+    shift++;
+  return shift;
 }

@@ -84,3 +84,17 @@ def ref_operator_roundtrip(lp, transform, rp, qp, chroma, bitdepth, lcp, xyz, at
     ln = lib.ref_operator_roundtrip(C.addressof(lp), transform, C.addressof(rp), qp, chroma, bitdepth, int(lcp),
                                     xyz.reshape(-1), attrs.reshape(-1), n, c, re, rd, pay, pay.size)
     return pay[:ln].tobytes(), re.reshape(n, c), rd.reshape(n, c)
+
+
+def oracle_estimate_dist2(xyz, period=100, search_range=128, percentile=0.85):
+    lib = ol.oracle().lib
+    xyz = np.ascontiguousarray(xyz, dtype=np.int32)
+    lib.oracle_estimate_dist2.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p]
+    return lib.oracle_estimate_dist2(xyz.ctypes.data, xyz.shape[0], period, search_range, C.c_float(percentile), None)
+
+
+def ref_estimate_dist2(xyz, period=100, search_range=128, percentile=0.85):
+    lib = ol.ref().lib
+    xyz = np.ascontiguousarray(xyz, dtype=np.int32)
+    lib.ref_estimate_dist2.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float]
+    return lib.ref_estimate_dist2(xyz.ctypes.data, xyz.shape[0], period, search_range, C.c_float(percentile))

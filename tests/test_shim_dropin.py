@@ -35,3 +35,31 @@ def test_shim_on_gpu_matches_reference_cpu(n, subnode):
     assert r.returncode == 0, r.stdout + r.stderr
     assert "IDENTICAL" in r.stdout and "devices=0" not in r.stdout
     assert "falls back" not in r.stderr
+
+
+# ---- seam 2: AttributeLods::generate ----------------------------------------
+LOD_BIN = os.path.join(ROOT, "oracle", "_ref", "lod_shim_check")
+needs_lod_bin = pytest.mark.skipif(not os.path.exists(LOD_BIN), reason="lod_shim_check not built")
+
+
+def run_lod(n, lifting):
+    return subprocess.run([LOD_BIN, str(n), str(lifting)], capture_output=True, text=True, timeout=300)
+
+
+@needs_lod_bin
+def test_lod_shim_falls_back_to_cpu_without_gpu():
+    """No GPU: AttributeLods::generate (the shim) runs the renamed reference body."""
+    r = run_lod(5000, 1)
+    assert r.returncode == 0 and "identical" in r.stdout
+    if "cpu-fallback" in r.stdout:
+        assert "stays on the CPU" in r.stderr
+
+
+@needs_lod_bin
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,lifting", [(40000, 1), (40000, 0), (1, 1), (300000, 1)])
+def test_lod_shim_on_gpu_matches_reference_cpu(n, lifting):
+    r = run_lod(n, lifting)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "identical" in r.stdout and "path=device" in r.stdout
+    assert "falls back" not in r.stderr
