@@ -281,6 +281,26 @@ int gpcc_ctx_set_profiling(gpcc_ctx* ctx, int enable);
 int gpcc_ctx_kernel_times(
   gpcc_ctx* ctx, gpcc_kernel_time* out, int32_t max_entries);
 
+/* The whole RAHT driver of one slice minus the entropy loop --
+ * encodeColorsTransformRaht / encodeReflectancesTransformRaht
+ * (tmc3/AttributeEncoder.cpp:1306-1375 / 1214-1302) and
+ * decodeColorsRaht / decodeReflectancesRaht (tmc3/AttributeDecoder.cpp:613-674
+ * / 527-609): Morton codes of xyz[n][3], sort by (code, index), gather the
+ * attributes into that order, transform, clip the reconstruction to
+ * [0, 2^bitdepth - 1] and scatter it back by original point index -- one
+ * upload, one download, everything in between on the device.
+ *   attrs  [n][c] in POINT order: encode in: source, out: clipped
+ *          reconstruction; decode out: clipped reconstruction
+ *   coeffs planar [c][n] in Morton order, exactly what the entropy loop reads
+ * Region QP offsets (QpSet::regionQpOffset) are taken as zero, as in every CTC
+ * configuration; use gpcc_attr_morton_sort + gpcc_raht_forward for regions. */
+int gpcc_raht_encode_attr(
+  gpcc_ctx* ctx, const gpcc_raht_params* params, const int32_t* xyz,
+  int32_t* attrs, int32_t* coeffs, int32_t n, int32_t c, int32_t bitdepth);
+int gpcc_raht_decode_attr(
+  gpcc_ctx* ctx, const gpcc_raht_params* params, const int32_t* xyz,
+  int32_t* attrs, const int32_t* coeffs, int32_t n, int32_t c, int32_t bitdepth);
+
 /* estimateDist2 (tmc3/AttributeEncoder.cpp:1684-1720, called from
  * tmc3/encoder.cpp:1203 to derive attr_dist2_delta): for every
  * sampling_period-th point of xyz[n][3] (coded order) the squared distance to

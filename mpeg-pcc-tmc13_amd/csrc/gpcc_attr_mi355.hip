@@ -1623,6 +1623,103 @@ gpcc_lod_build(
   return r;
 }
 
+namespace {
+int
+slice_driver(
+  gpcc_ctx* ctx, const gpcc_raht_params* params, bool encoder, const int32_t* xyz,
+  int32_t* attrs, int32_t* coeffs, int32_t n, int32_t c, int32_t bitdepth)
+{
+  if (!ctx)
+    return fail(GPCC_ERR_INVALID_ARG, "ctx is null");
+  if (!xyz || !attrs || !coeffs || n <= 0 || bitdepth < 1 || bitdepth > 16)
+    return fail(GPCC_ERR_INVALID_ARG, "null buffer, n <= 0 or bitdepth outside [1, 16]");
+  int rcode = check_params(params, c, encoder);
+  if (rcode)
+    return rcode;
+  int32_t mx = 0;
+  for (int64_t i = 0; i < (int64_t)n * 3; i++) {
+    if (xyz[i] < 0 || xyz[i] >= (1 << 21))
+      return fail(GPCC_ERR_INVALID_ARG, "coordinate outside [0, 2^21)");
+    mx = std::max(mx, xyz[i]);
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const size_t N = (size_t)n;
+  int32_t *d_xyz = nullptr, *d_order = nullptr, *d_pt = nullptr, *d_a = nullptr, *d_c = nullptr;
+  int64_t* d_m = nullptr;
+  auto cleanup = [&]() {
+    hipFree(d_xyz);
+    hipFree(d_order);
+    hipFree(d_pt);
+    hipFree(d_a);
+    hipFree(d_c);
+    hipFree(d_m);
+  };
+  auto run = [&]() -> int {
+    HIP_TRY(hipMalloc((void**)&d_xyz, sizeof(int32_t) * 3 * N));
+    HIP_TRY(hipMalloc((void**)&d_order, sizeof(int32_t) * N));
+    HIP_TRY(hipMalloc((void**)&d_m, sizeof(int64_t) * N));
+    HIP_TRY(hipMalloc((void**)&d_pt, sizeof(int32_t) * N * c));
+    HIP_TRY(hipMalloc((void**)&d_a, sizeof(int32_t) * N * c));
+    HIP_TRY(hipMalloc((void**)&d_c, sizeof(int32_t) * N * c));
+    HIP_TRY(hipMemcpyAsync(d_xyz, xyz, sizeof(int32_t) * 3 * N, hipMemcpyHostToDevice, st));
+    const int bits = std::max(1, 3 * bitlen64((uint64_t)mx));
+    const int64_t offs[2] = {0, n};
+    {
+      const int saved = ctx->morton_bits;
+      ctx->morton_bits = bits;
+      int r = gpcc_dev_attr_morton_sort(ctx, 1, offs, d_xyz, d_m, d_order);
+      ctx->morton_bits = saved;
+      if (r)
+        return r;
+    }
+    if (encoder) {
+      HIP_TRY(hipMemcpyAsync(d_pt, attrs, sizeof(int32_t) * N * c, hipMemcpyHostToDevice, st));
+      {
+        Timer tm(ctx, "attr_gather");
+        attr_gather_kernel<<<grid_for(n, 256), 256, 0, st>>>(n, c, d_order, d_pt, d_a);
+      }
+      HIP_TRY(hipMemsetAsync(d_c, 0, sizeof(int32_t) * N * c, st));
+    } else {
+      HIP_TRY(hipMemcpyAsync(d_c, coeffs, sizeof(int32_t) * N * c, hipMemcpyHostToDevice, st));
+    }
+    int r = dev_transform(ctx, params, encoder, 1, offs, d_m, nullptr, d_a, d_c, c, bits);
+    if (r)
+      return r;
+    {
+      Timer tm(ctx, "attr_clip_scatter");
+      attr_clip_scatter_kernel<<<grid_for(n, 256), 256, 0, st>>>(
+        n, c, (1 << bitdepth) - 1, d_order, d_a, d_pt);
+    }
+    HIP_TRY(hipMemcpyAsync(attrs, d_pt, sizeof(int32_t) * N * c, hipMemcpyDeviceToHost, st));
+    if (encoder)
+      HIP_TRY(hipMemcpyAsync(coeffs, d_c, sizeof(int32_t) * N * c, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return check_device_error(ctx);
+  };
+  int r = run();
+  cleanup();
+  return r;
+}
+}  // namespace
+
+int
+gpcc_raht_encode_attr(
+  gpcc_ctx* ctx, const gpcc_raht_params* params, const int32_t* xyz,
+  int32_t* attrs, int32_t* coeffs, int32_t n, int32_t c, int32_t bitdepth)
+{
+  return slice_driver(ctx, params, true, xyz, attrs, coeffs, n, c, bitdepth);
+}
+
+int
+gpcc_raht_decode_attr(
+  gpcc_ctx* ctx, const gpcc_raht_params* params, const int32_t* xyz,
+  int32_t* attrs, const int32_t* coeffs, int32_t n, int32_t c, int32_t bitdepth)
+{
+  return slice_driver(
+    ctx, params, false, xyz, attrs, const_cast<int32_t*>(coeffs), n, c, bitdepth);
+}
+
 int
 gpcc_estimate_dist2(
   gpcc_ctx* ctx, const int32_t* xyz, int32_t n, int32_t sampling_period,

@@ -172,4 +172,33 @@ sort_scatter_kernel(SortCtx cx)
   }
 }
 
+// marshalling of the RAHT drivers (AttributeEncoder.cpp:1331-1338,
+// 1364-1375): attributes into Morton order / clipped reconstruction back by
+// original point index
+__global__ __launch_bounds__(256) void
+attr_gather_kernel(
+  int n, int c, const int32_t* __restrict__ order, const int32_t* __restrict__ src,
+  int32_t* __restrict__ dst)
+{
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const size_t o = (size_t)order[i] * c;
+    for (int k = 0; k < c; k++)
+      dst[(size_t)i * c + k] = src[o + k];
+  }
+}
+
+__global__ __launch_bounds__(256) void
+attr_clip_scatter_kernel(
+  int n, int c, int32_t clip_max, const int32_t* __restrict__ order,
+  const int32_t* __restrict__ src, int32_t* __restrict__ dst)
+{
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const size_t o = (size_t)order[i] * c;
+    for (int k = 0; k < c; k++) {
+      const int32_t v = src[(size_t)i * c + k];
+      dst[o + k] = v < 0 ? 0 : (v > clip_max ? clip_max : v);
+    }
+  }
+}
+
 }  // namespace gpcc

@@ -166,3 +166,25 @@ class Context:
         _lib.check(self._lib.gpcc_estimate_dist2(self._h, xyz.ctypes.data, xyz.shape[0], sampling_period,
                                                  search_range, C.c_float(percentile), C.byref(out)))
         return out.value
+
+    # ---- whole slice driver (sort + marshal + transform + clip + scatter) ----
+    def raht_encode_attr(self, params, xyz, attrs, bitdepth=8):
+        """encode{Colors,Reflectances}TransformRaht minus the entropy loop ->
+        (coeffs planar [c*n] Morton order, clipped recon [n,c] POINT order)"""
+        xyz = np.ascontiguousarray(xyz, dtype=np.int32)
+        a = np.ascontiguousarray(attrs, dtype=np.int32).copy()
+        n, c = a.shape
+        co = np.zeros(c * n, dtype=np.int32)
+        _lib.check(self._lib.gpcc_raht_encode_attr(self._h, C.byref(params), xyz.ctypes.data, a.ctypes.data,
+                                                   co.ctypes.data, n, c, bitdepth))
+        return co, a
+
+    def raht_decode_attr(self, params, xyz, coeffs, c, bitdepth=8):
+        """decode{Colors,Reflectances}Raht after the entropy decode -> clipped recon [n,c] POINT order"""
+        xyz = np.ascontiguousarray(xyz, dtype=np.int32)
+        n = xyz.shape[0]
+        co = np.ascontiguousarray(coeffs, dtype=np.int32)
+        a = np.zeros((n, c), dtype=np.int32)
+        _lib.check(self._lib.gpcc_raht_decode_attr(self._h, C.byref(params), xyz.ctypes.data, a.ctypes.data,
+                                                   co.ctypes.data, n, c, bitdepth))
+        return a
