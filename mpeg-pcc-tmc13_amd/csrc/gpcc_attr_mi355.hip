@@ -174,7 +174,8 @@ struct Plan {
   int32_t* worklist = nullptr;
   int32_t* work_count = nullptr;  // [kMaxLevels] then ticket[kMaxLevels*8], error[1] (one memset)
   unsigned long long* scan_state = nullptr;
-  int32_t* done = nullptr;
+  uint8_t* pocc = nullptr;
+  uint32_t* mbox = nullptr;
   unsigned long long* rdoq_state = nullptr;
   bool sub = false;
   int num_rtiles = 0;
@@ -215,7 +216,8 @@ carve(Arena& ar, Plan& pl)
   pl.worklist = ar.take<int32_t>((size_t)n + 1);
   pl.work_count = ar.take<int32_t>(kMaxLevels * 9 + 1);
   pl.scan_state = ar.take<unsigned long long>(1024);
-  pl.done = pl.sub ? ar.take<int32_t>((size_t)n + 1) : nullptr;
+  pl.pocc = pl.sub ? ar.take<uint8_t>((size_t)n + 1) : nullptr;
+  pl.mbox = pl.sub ? ar.take<uint32_t>((size_t)n * c * 4) : nullptr;
   pl.rdoq_state = (pl.sub && pl.lossy) ? ar.take<unsigned long long>((size_t)n + 1) : nullptr;
   pl.params = ar.take<gpcc_raht_params>(1);
   for (int i = 0; i < 2; i++) {
@@ -401,13 +403,14 @@ launch_transform(
   lc.worklist = pl.worklist;
   lc.work_count = pl.work_count;
   lc.scan_state = pl.scan_state;
-  lc.done = pl.done;
+  lc.pocc = pl.pocc;
+  lc.mbox = pl.mbox;
   lc.ticket = pl.work_count + kMaxLevels;
   lc.error = pl.work_count + kMaxLevels * 9;
   HIP_TRY(hipMemsetAsync(pl.work_count, 0, (kMaxLevels * 9 + 1) * sizeof(int32_t), st));
   HIP_TRY(hipMemsetAsync(pl.scan_state, 0, 1024 * sizeof(unsigned long long), st));
-  if (pl.done)
-    HIP_TRY(hipMemsetAsync(pl.done, 0, ((size_t)n + 1) * sizeof(int32_t), st));
+  if (pl.mbox)  // tags of a call are li + 1 >= 1
+    HIP_TRY(hipMemsetAsync(pl.mbox, 0, (size_t)n * C * 4 * sizeof(uint32_t), st));
   if (pl.rdoq_state)
     HIP_TRY(hipMemsetAsync(pl.rdoq_state, 0, ((size_t)n + 1) * sizeof(unsigned long long), st));
   lc.rdoq_state = pl.rdoq_state;
@@ -430,6 +433,7 @@ launch_transform(
 
   for (int li = nlev - 2; li >= 0; li--) {
     lc.li = li;
+    lc.mtag = (uint32_t)(li + 1);
     // many small workgroups: the cost of a round varies by an order of
     // magnitude (single-child copies vs predicted blocks), the hardware
     // dispatcher evens it out

@@ -194,7 +194,6 @@ lod_cell_keys_kernel(LodCtx cx)
     cx.cell_key[x] = cx.code[cx.input[cx.cell_first[x]]] >> cx.shift3;
 }
 
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // subsampleByDistance (:1984-2085).  At most one point per cell is retained
 // and the decision of a cell depends on the retained points of up to 19

@@ -32,6 +32,9 @@ constexpr int kMaxLevels = 22;   // ceil(63 / 3) + root
 constexpr int kTilePoints = 1024;  // points per wave in the tree build
 constexpr int kWave = 64;
 
+// payload of one 16-byte buffer load / store (mailbox granules)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
 struct TreeView {
   int32_t nlev;         // level arrays in use (top one has 1 node / slice)
   int32_t num_slices;

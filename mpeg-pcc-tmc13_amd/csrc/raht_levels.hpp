@@ -48,7 +48,10 @@ struct LevelCtx {
   int32_t* work_count;             // [nlev] entries of the worklist per level
   unsigned long long* scan_state;  // [<=1024] prepass look-back words
   // sub-node prediction (raht_subnode.hpp)
-  int32_t* done;                   // [cap] done[j] == li + 1: block j of this level is reconstructed
+  uint8_t* pocc;                   // [cap] child occupancy of every parent of this level (prepass)
+  uint32_t* mbox;                  // [N*C][4] 16-byte granules {value lo, hi, tag, 0}: the
+                                   // children reconstructed by THIS launch (data is the flag)
+  uint32_t mtag;                   // tag of this launch, never reused while mbox lives
   int32_t* ticket;                 // [nlev][8] wave-round tickets
   int32_t* error;                  // set when a bounded spin expires
   unsigned long long* rdoq_state;  // [cap] per worklist block: RDOQ hand-off word
@@ -328,6 +331,12 @@ raht_level_prepass_kernel(LevelCtx ctx)
       if (e.processed) {
         const int c0 = tv.fc[li + 1][j];
         const int nchild = tv.fc[li + 1][j + 1] - c0;
+        if (ctx.pocc) {
+          uint32_t o = 0;
+          for (int u = 0; u < nchild; u++)
+            o |= 1u << (int)(tv.key[li][c0 + u] & 7);
+          ctx.pocc[j] = (uint8_t)o;
+        }
         if (ext && nchild == 1) {
           const int pt0 = tv.pt_off[s];
           const int64_t prow = (int64_t)pt0 + (j - tv.soff[li + 1][s]);
@@ -343,8 +352,6 @@ raht_level_prepass_kernel(LevelCtx ctx)
             ctx.dqp[cp][crow * 2] = ctx.dqp[pp][prow * 2];
             ctx.dqp[cp][crow * 2 + 1] = ctx.dqp[pp][prow * 2 + 1];
           }
-          if (ctx.done)
-            ctx.done[j] = li + 1;  // visible to the block kernel (next launch)
         } else {
           real = true;
         }

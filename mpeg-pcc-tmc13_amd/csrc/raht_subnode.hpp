@@ -443,15 +443,89 @@ raht_level_sub_kernel(LevelCtx ctx)
       }
     }
 
-    // ---- dependencies: neighbour parents 7..18 that precede this block --
+    // ---- neighbours 7..18 (tmc3/RAHT.cpp:503-565): everything that does
+    //      not depend on this launch is settled here ------------------------
+    // Which term a (lane, neighbour) pair contributes is decided by the tree
+    // alone: the neighbour parent's value (absent or later block, or the
+    // needed child position unoccupied), a child written by the prepass
+    // (single-child parent), or a child reconstructed by THIS launch -- only
+    // the last kind is waited for, through its 16-byte mailbox granule.
     // lane t owns neighbours i = 1 + t + 8*slot (the lanes that searched them)
-    int dep[3] = {-1, -1, -1};
+    int nb_c0[3] = {0, 0, 0};
+    uint32_t nb_occ[3] = {0, 0, 0};
+    int nb_single[3] = {0, 0, 0};
+    int64_t nb_v[3][C];
 #pragma unroll
     for (int slot = 0; slot < 3; slot++) {
+#pragma unroll
+      for (int k = 0; k < C; k++)
+        nb_v[slot][k] = 0;
       const int i = 1 + t + 8 * slot;
-      if (run && i >= 7 && i < 19 && pn[slot] >= 0 && pn[slot] < j)
-        dep[slot] = pn[slot];
+      if (run && i >= 7 && i < 19 && pn[slot] >= 0) {
+        const int q = pn[slot];
+#pragma unroll
+        for (int k = 0; k < C; k++)
+          nb_v[slot][k] = prec[(rbase + q) * C + k];
+        if (q < j) {  // processed before this block: its children count
+          const int qc0 = tv.fc[li + 1][q];
+          nb_c0[slot] = qc0;
+          nb_occ[slot] = ctx.pocc[q];
+          nb_single[slot] = ext && tv.fc[li + 1][q + 1] - qc0 == 1;
+        }
+      }
     }
+    uint32_t pend = 0;       // neighbours whose child granule is awaited
+    int32_t nrow12[12];      // row of that child in rec / mbox
+#pragma unroll
+    for (int i12 = 0; i12 < 12; i12++) {
+      nrow12[i12] = 0;
+      const int i = 7 + i12;
+      const int owner = gbase | ((i - 1) & 7);
+      const int sl = (i - 1) >> 3;
+      const int q = __shfl(pn[sl], owner);
+      const int qc0 = __shfl(nb_c0[sl], owner);
+      const uint32_t qocc = __shfl(nb_occ[sl], owner);
+      const int single = __shfl(nb_single[sl], owner);
+      int64_t v[C];
+#pragma unroll
+      for (int k = 0; k < C; k++)
+        v[k] = shfl_i64(nb_v[sl][k], owner);
+      if (!run || q < 0)
+        continue;
+      if (10 * v[0] <= lim_lo || 10 * v[0] >= lim_hi)
+        continue;
+      if (has && ((neigh_mask(i) >> t) & 1)) {
+        const int sh = occu_shift(i12);
+        const int cpos = i12 < 9 ? t + sh : t - sh;
+        const bool child_ok = cpos >= 0 && cpos < 8 && ((qocc >> cpos) & 1);
+        if (child_ok) {
+          const int cidx_n = qc0 + popc32(qocc & ((1u << cpos) - 1));
+          const int64_t nrow = (int64_t)pt0 + (cidx_n - sc0);
+          const int64_t pwc = prm->pred_weight_child[i12];
+          wsum += (int)pwc;
+          if (single) {
+            // copied by the prepass launch: an ordinary load
+            const int64_t mul = ext ? pwc : (pwc << kFpFrac);
+#pragma unroll
+            for (int k = 0; k < C; k++)
+              pred[k] += ctx.rec[cur_par][nrow * C + k] * mul;
+          } else {
+            nrow12[i12] = (int32_t)nrow;
+            pend |= 1u << i12;
+          }
+        } else {
+          const int64_t pwp = prm->pred_weight_parent[i];
+          wsum += (int)pwp;
+          const int64_t mul = ext ? pwp : (pwp << kFpFrac);
+#pragma unroll
+          for (int k = 0; k < C; k++)
+            pred[k] += v[k] * mul;
+        }
+      }
+    }
+    const int64_t pdiv = pred_divisor(wsum > 0 ? wsum : 1);
+    const auto mrsrc = __builtin_amdgcn_make_buffer_rsrc(
+      ctx.mbox, 0, (int)((size_t)tv.n_total * C * 16), 0x00020000);
 
     // ---- the staged dependency loop -------------------------------------
     // stage 0: waiting for neighbour blocks   -> (P) predict + transform,
@@ -482,83 +556,45 @@ raht_level_sub_kernel(LevelCtx ctx)
 #ifdef GPCC_STATS
       n_iter++;
 #endif
-      // ---- (X) neighbour flags ------------------------------------------
-      bool unmet = false;
+      // ---- (X) awaited children: the granule is data and flag at once ----
+      if (stage == 0 && pend) {
 #pragma unroll
-      for (int slot = 0; slot < 3; slot++)
-        if (stage == 0 && dep[slot] >= 0
-            && load_agent_i32(&ctx.done[dep[slot]]) != epoch)
-          unmet = true;
-      const bool blocked = group8_or(unmet ? 1u : 0u) != 0;
+        for (int i12 = 0; i12 < 12; i12++) {
+          if (!((pend >> i12) & 1))
+            continue;
+          u32x4 g[C];
+#pragma unroll
+          for (int k = 0; k < C; k++)
+            g[k] = __builtin_amdgcn_raw_buffer_load_b128(
+              mrsrc, (nrow12[i12] * C + k) * 16, 0, /*sc1*/ 16);
+          bool ok = true;
+#pragma unroll
+          for (int k = 0; k < C; k++)
+            ok = ok && g[k].z == ctx.mtag;
+          if (ok) {
+            const int64_t pwc = prm->pred_weight_child[i12];
+            const int64_t mul = ext ? pwc : (pwc << kFpFrac);
+#pragma unroll
+            for (int k = 0; k < C; k++)
+              pred[k] += (int64_t)(((uint64_t)g[k].y << 32) | g[k].x) * mul;
+            pend &= ~(1u << i12);
+          }
+        }
+      }
+      const bool blocked = group8_or((stage == 0 && pend) ? 1u : 0u) != 0;
       const bool nready = stage == 0 && !blocked;
 
       if (__any(nready)) {
         progressed = true;
-        // ---- (P) prediction with child-level terms + transform -----------
-        int nb_c0[3] = {0, 0, 0};
-        uint32_t nb_occ[3] = {0, 0, 0};
-#pragma unroll
-        for (int slot = 0; slot < 3; slot++) {
-          if (nready && dep[slot] >= 0) {
-            const int q = dep[slot];
-            const int qc0 = tv.fc[li + 1][q];
-            const int qn = tv.fc[li + 1][q + 1] - qc0;
-            uint32_t o = 0;
-            for (int u = 0; u < qn; u++)
-              o |= 1u << (int)(tv.key[li][qc0 + u] & 7);
-            nb_c0[slot] = qc0;
-            nb_occ[slot] = o;
-          }
-        }
+        // ---- (P) normalise the prediction, transform -----------------------
         int64_t pw_[C];
-        int ws = wsum;
 #pragma unroll
         for (int k = 0; k < C; k++)
           pw_[k] = pred[k];
-        // intraDcPred, neighbours 7..18 (tmc3/RAHT.cpp:503-565)
-#pragma unroll
-        for (int i12 = 0; i12 < 12; i12++) {
-          const int i = 7 + i12;
-          const int owner = gbase | ((i - 1) & 7);
-          const int q = __shfl(pn[(i - 1) >> 3], owner);
-          const int qc0 = __shfl(nb_c0[(i - 1) >> 3], owner);
-          const uint32_t qocc = __shfl(nb_occ[(i - 1) >> 3], owner);
-          if (!(run && nready) || q < 0)
-            continue;
-          int64_t v[C];
-#pragma unroll
-          for (int k = 0; k < C; k++)
-            v[k] = prec[(rbase + q) * C + k];
-          if (10 * v[0] <= lim_lo || 10 * v[0] >= lim_hi)
-            continue;
-          if (has && ((neigh_mask(i) >> t) & 1)) {
-            const int sh = occu_shift(i12);
-            const int cpos = i12 < 9 ? t + sh : t - sh;
-            const bool child_ok = cpos >= 0 && cpos < 8 && ((qocc >> cpos) & 1);
-            if (child_ok) {
-              const int cidx_n = qc0 + popc32(qocc & ((1u << cpos) - 1));
-              const int64_t nrow = (int64_t)pt0 + (cidx_n - sc0);
-              const int64_t pwc = prm->pred_weight_child[i12];
-              ws += (int)pwc;
-              const int64_t mul = ext ? pwc : (pwc << kFpFrac);
-#pragma unroll
-              for (int k = 0; k < C; k++)
-                pw_[k] += load_agent_i64(&ctx.rec[cur_par][nrow * C + k]) * mul;
-            } else {
-              const int64_t pwp = prm->pred_weight_parent[i];
-              ws += (int)pwp;
-              const int64_t mul = ext ? pwp : (pwp << kFpFrac);
-#pragma unroll
-              for (int k = 0; k < C; k++)
-                pw_[k] += v[k] * mul;
-            }
-          }
-        }
         if (run && has) {
-          const int64_t div = pred_divisor(ws > 0 ? ws : 1);
 #pragma unroll
           for (int k = 0; k < C; k++) {
-            pw_[k] = fp_mul(pw_[k], div);
+            pw_[k] = fp_mul(pw_[k], pdiv);
             if (haar)
               pw_[k] = (pw_[k] >> kFpFrac) << kFpFrac;
           }
@@ -909,7 +945,9 @@ raht_level_sub_kernel(LevelCtx ctx)
             }
           }
         }
-        // children of the committing groups, write-through, then the flag
+        // children of the committing groups: the value later launches read
+        // (plain store) and the mailbox granule later blocks of THIS launch
+        // poll (one 16-byte write-through store: value + tag, untorn)
         if (can && has) {
 #pragma unroll
           for (int k = 0; k < C; k++) {
@@ -917,14 +955,13 @@ raht_level_sub_kernel(LevelCtx ctx)
             ctx.rec_us[cur_par][crow * C + k] = ext ? v : fp_round(v * 4);
             if (!haar && w > 1)
               v = scale_rsqrt(v, w, lut);
-            store_agent_i64(&ctx.rec[cur_par][crow * C + k], ext ? v : fp_round(v));
+            v = ext ? v : fp_round(v);
+            ctx.rec[cur_par][crow * C + k] = v;
+            const u32x4 gr = {(uint32_t)v, (uint32_t)((uint64_t)v >> 32), ctx.mtag, 0u};
+            __builtin_amdgcn_raw_buffer_store_b128(gr, mrsrc, (int)((crow * C + k) * 16), 0, /*sc1*/ 16);
           }
           ctx.nneigh[cur_par][crow] = inherit_dc ? neigh_count : 19;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (can && t == 0)
-          __hip_atomic_store(&ctx.done[j], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (can)
           stage = 3;
       }
