@@ -177,6 +177,8 @@ struct Plan {
   uint8_t* pocc = nullptr;
   uint32_t* mbox = nullptr;
   unsigned long long* rdoq_state = nullptr;
+  uint32_t* rdoq_desc = nullptr;
+  unsigned long long* rdoq_lin = nullptr;
   bool sub = false;
   int num_rtiles = 0;
   std::vector<int32_t*> haar_lf, asc_qp;
@@ -219,6 +221,8 @@ carve(Arena& ar, Plan& pl)
   pl.pocc = pl.sub ? ar.take<uint8_t>((size_t)n + 1) : nullptr;
   pl.mbox = pl.sub ? ar.take<uint32_t>((size_t)n * c * 4) : nullptr;
   pl.rdoq_state = (pl.sub && pl.lossy) ? ar.take<unsigned long long>((size_t)n + 1) : nullptr;
+  pl.rdoq_desc = (pl.sub && pl.lossy) ? ar.take<uint32_t>(((size_t)n + 1) * 12) : nullptr;
+  pl.rdoq_lin = (pl.sub && pl.lossy) ? ar.take<unsigned long long>((size_t)n + 1) : nullptr;
   pl.params = ar.take<gpcc_raht_params>(1);
   for (int i = 0; i < 2; i++) {
     pl.rec[i] = ar.take<int64_t>((size_t)n * c);
@@ -413,7 +417,13 @@ launch_transform(
     HIP_TRY(hipMemsetAsync(pl.mbox, 0, (size_t)n * C * 4 * sizeof(uint32_t), st));
   if (pl.rdoq_state)
     HIP_TRY(hipMemsetAsync(pl.rdoq_state, 0, ((size_t)n + 1) * sizeof(unsigned long long), st));
+  if (pl.rdoq_desc) {
+    HIP_TRY(hipMemsetAsync(pl.rdoq_desc, 0, ((size_t)n + 1) * 12 * sizeof(uint32_t), st));
+    HIP_TRY(hipMemsetAsync(pl.rdoq_lin, 0, ((size_t)n + 1) * sizeof(unsigned long long), st));
+  }
   lc.rdoq_state = pl.rdoq_state;
+  lc.rdoq_desc = pl.rdoq_desc;
+  lc.rdoq_lin = pl.rdoq_lin;
   lc.slice_l = pl.slice_l;
 
   RdoqCtx rc{};

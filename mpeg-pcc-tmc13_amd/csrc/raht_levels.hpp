@@ -55,6 +55,8 @@ struct LevelCtx {
   int32_t* ticket;                 // [nlev][8] wave-round tickets
   int32_t* error;                  // set when a bounded spin expires
   unsigned long long* rdoq_state;  // [cap] per worklist block: RDOQ hand-off word
+  uint32_t* rdoq_desc;             // [cap][3][4] descriptor granules of the blocks that need L
+  unsigned long long* rdoq_lin;    // [cap] {tag, incoming L} answered by the resolver
   int32_t* slice_l;                // [S] last RDOQ reset carried between levels
 };
 
