@@ -177,8 +177,6 @@ struct Plan {
   uint8_t* pocc = nullptr;
   uint32_t* mbox = nullptr;
   unsigned long long* rdoq_state = nullptr;
-  uint32_t* rdoq_desc = nullptr;
-  unsigned long long* rdoq_lin = nullptr;
   bool sub = false;
   int num_rtiles = 0;
   std::vector<int32_t*> haar_lf, asc_qp;
@@ -221,8 +219,6 @@ carve(Arena& ar, Plan& pl)
   pl.pocc = pl.sub ? ar.take<uint8_t>((size_t)n + 1) : nullptr;
   pl.mbox = pl.sub ? ar.take<uint32_t>((size_t)n * c * 4) : nullptr;
   pl.rdoq_state = (pl.sub && pl.lossy) ? ar.take<unsigned long long>((size_t)n + 1) : nullptr;
-  pl.rdoq_desc = (pl.sub && pl.lossy) ? ar.take<uint32_t>(((size_t)n + 1) * 12) : nullptr;
-  pl.rdoq_lin = (pl.sub && pl.lossy) ? ar.take<unsigned long long>((size_t)n + 1) : nullptr;
   pl.params = ar.take<gpcc_raht_params>(1);
   for (int i = 0; i < 2; i++) {
     pl.rec[i] = ar.take<int64_t>((size_t)n * c);
@@ -255,7 +251,7 @@ carve(Arena& ar, Plan& pl)
     pl.rtile_base = ar.take<int32_t>(s + 1);
     pl.rtile_sum = ar.take<int2>(pl.num_rtiles + 1);
     pl.rtile_lin = ar.take<int32_t>(pl.num_rtiles + 1);
-    pl.slice_l = ar.take<int32_t>(s);
+    pl.slice_l = ar.take<int32_t>(2 * (size_t)s);  // sub-node path: [level parity][S]
   }
 }
 
@@ -417,13 +413,7 @@ launch_transform(
     HIP_TRY(hipMemsetAsync(pl.mbox, 0, (size_t)n * C * 4 * sizeof(uint32_t), st));
   if (pl.rdoq_state)
     HIP_TRY(hipMemsetAsync(pl.rdoq_state, 0, ((size_t)n + 1) * sizeof(unsigned long long), st));
-  if (pl.rdoq_desc) {
-    HIP_TRY(hipMemsetAsync(pl.rdoq_desc, 0, ((size_t)n + 1) * 12 * sizeof(uint32_t), st));
-    HIP_TRY(hipMemsetAsync(pl.rdoq_lin, 0, ((size_t)n + 1) * sizeof(unsigned long long), st));
-  }
   lc.rdoq_state = pl.rdoq_state;
-  lc.rdoq_desc = pl.rdoq_desc;
-  lc.rdoq_lin = pl.rdoq_lin;
   lc.slice_l = pl.slice_l;
 
   RdoqCtx rc{};
@@ -438,7 +428,7 @@ launch_transform(
     rc.tile_lin = pl.rtile_lin;
     rc.slice_l = pl.slice_l;
     rc.c = C;
-    HIP_TRY(hipMemsetAsync(pl.slice_l, 0xff, s * sizeof(int32_t), st));
+    HIP_TRY(hipMemsetAsync(pl.slice_l, 0xff, 2 * (size_t)s * sizeof(int32_t), st));
   }
 
   for (int li = nlev - 2; li >= 0; li--) {

@@ -55,9 +55,7 @@ struct LevelCtx {
   int32_t* ticket;                 // [nlev][8] wave-round tickets
   int32_t* error;                  // set when a bounded spin expires
   unsigned long long* rdoq_state;  // [cap] per worklist block: RDOQ hand-off word
-  uint32_t* rdoq_desc;             // [cap][3][4] descriptor granules of the blocks that need L
-  unsigned long long* rdoq_lin;    // [cap] {tag, incoming L} answered by the resolver
-  int32_t* slice_l;                // [S] last RDOQ reset carried between levels
+  int32_t* slice_l;                // [2][S] last RDOQ reset carried between levels (sub-node path: by level parity)
 };
 
 // Small-weight tables.  Near the leaves almost every node weight is a
@@ -261,6 +259,11 @@ raht_level_prepass_kernel(LevelCtx ctx)
   const bool ext = ctx.params->raht_extension != 0;
   const int num_parents = tv.soff[li + 1][tv.num_slices];
   const int lane = lane_id(), wave = threadIdx.x >> 6;
+  // sub-node lossy encoder: this level accumulates its last reset on top of
+  // the value the previous level left (raht_subnode.hpp reads [prev], writes [cur])
+  if (ctx.rdoq_state && ctx.slice_l && blockIdx.x == 0)
+    for (int s = threadIdx.x; s < tv.num_slices; s += blockDim.x)
+      ctx.slice_l[(li & 1) * tv.num_slices + s] = ctx.slice_l[((li + 1) & 1) * tv.num_slices + s];
   // workgroup b owns the b-th contiguous range of 256-parent chunks, so the
   // worklist comes out in ascending block order (the dependency order of
   // sub-node prediction, and the coefficient order)

@@ -64,188 +64,6 @@ store_agent_i64(int64_t* p, int64_t v)
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// ---- RDOQ resolver ---------------------------------------------------------
-// The zero-run state of the lossy encoder (tmc3/RAHT.cpp:1618-1669) is one
-// serial chain through all coefficients of a slice.  Blocks whose decisions do
-// not depend on the incoming last-reset index L say so in their state word
-// (transparent / final L) and go on; the others publish their <= 8 threshold
-// descriptors.  ONE wavefront per slice walks the state words in coding
-// order, 64 per round trip, keeps L in a register, and resolves the published
-// blocks eight at a time with the ballot fixed point of raht_rdoq.hpp (8
-// blocks x 8 ranks = 64 lanes), answering each with its incoming L.  The
-// serial part of the chain is register-to-register; the memory latency of
-// descriptors and answers is pipelined, not serialised.
-template<int C>
-__device__ __forceinline__ void
-rdoq_resolver(const LevelCtx& ctx, int s, int num_work)
-{
-  const TreeView& tv = ctx.tv;
-  const int li = ctx.li;
-  const int lane = lane_id();
-  const LevelSched e = ctx.sched[s].lvl[li];
-  if (!e.processed)
-    return;
-  const int sp0 = tv.soff[li + 1][s], sp1 = tv.soff[li + 1][s + 1];
-  // worklist range of the slice
-  int w0, w1;
-  {
-    int lo = 0, hi = num_work;
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if (ctx.worklist[mid] < sp0)
-        lo = mid + 1;
-      else
-        hi = mid;
-    }
-    w0 = lo;
-    hi = num_work;
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if (ctx.worklist[mid] < sp1)
-        lo = mid + 1;
-      else
-        hi = mid;
-    }
-    w1 = lo;
-  }
-  const auto drsrc = __builtin_amdgcn_make_buffer_rsrc(
-    ctx.rdoq_desc, 0, (int)(((size_t)tv.n_total + 1) * 48), 0x00020000);
-  const unsigned long long epoch = (unsigned long long)(li + 1);
-  const unsigned long long lt = (1ull << lane) - 1;
-  int L = ctx.slice_l[s];
-  int cur = w0;
-  unsigned spins = 0;
-  while (cur < w1) {
-    // 4 x 64 state words per round trip (long runs of transparent blocks)
-    unsigned long long svq[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int wq = cur + 64 * u + lane;
-      svq[u] = __hip_atomic_load(
-        &ctx.rdoq_state[wq < w1 ? wq : cur], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    bool stalled = false;
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      if (stalled || cur >= w1)
-        continue;
-      const int wi = cur + lane;
-      const bool valid = wi < w1;
-      const int wc = valid ? wi : cur;
-      const unsigned long long sv = svq[u];
-      // kind: 0 pending, 1 transparent, 2 final, 4 descriptors published
-      int kind = (sv >> 48) == epoch ? (int)((sv >> 32) & 0xffff) : 0;
-      u32x4 g0 = {0, 0, 0, 0}, g1 = g0, g2 = g0;
-      if (__any(valid && kind == 4)) {
-        if (valid && kind == 4) {
-          g0 = __builtin_amdgcn_raw_buffer_load_b128(drsrc, (wc * 3) * 16, 0, 16);
-          g1 = __builtin_amdgcn_raw_buffer_load_b128(drsrc, (wc * 3 + 1) * 16, 0, 16);
-          g2 = __builtin_amdgcn_raw_buffer_load_b128(drsrc, (wc * 3 + 2) * 16, 0, 16);
-        }
-        if (kind == 4 && !(g0.w == ctx.mtag && g1.w == ctx.mtag && g2.w == ctx.mtag))
-          kind = 0;  // granules still on their way
-      }
-      const unsigned long long pendm = __ballot(!valid || kind == 0);
-      const int nready = pendm ? __ffsll((long long)pendm) - 1 : 64;
-      if (nready < 64)
-        stalled = true;  // the later sub-windows are re-read next time
-      if (nready == 0)
-        continue;
-      unsigned long long ev = __ballot(lane < nready && (kind == 2 || kind == 4));
-      int my_lin = -1;
-      while (ev) {
-        // the next (up to) eight events go to lane groups 0..7
-        int src = 0;       // window lane of the event served by this lane's group
-        bool slot = false;
-        {
-          unsigned long long m = ev;
-#pragma unroll
-          for (int k = 0; k < 8; k++) {
-            if (m) {
-              const int p = __ffsll((long long)m) - 1;
-              if ((lane >> 3) == k) {
-                src = p;
-                slot = true;
-              }
-              m &= m - 1;
-            }
-          }
-          ev = m;
-        }
-        const int r = lane & 7;
-        const int ekind = __shfl(kind, src);
-        const uint32_t fin = __shfl((uint32_t)sv, src);
-        const uint32_t v0 = __shfl(g0.x, src), v1 = __shfl(g0.y, src), v2 = __shfl(g0.z, src);
-        const uint32_t v3 = __shfl(g1.x, src), v4 = __shfl(g1.y, src), v5 = __shfl(g1.z, src);
-        const uint32_t v6 = __shfl(g2.x, src), v7 = __shfl(g2.y, src);
-        const int cfirst = (int)__shfl(g2.z, src);
-        uint32_t d = r == 0 ? v0 : r == 1 ? v1 : r == 2 ? v2 : r == 3 ? v3 : r == 4 ? v4 : r == 5 ? v5 : r == 6 ? v6 : v7;
-        int ci = cfirst + r;
-        if (ekind == 2) {
-          // an L-independent block is one definite reset at its final L
-          d = r == 0 ? kDescNever : kDescZero;
-          ci = (int)fin;
-        }
-        if (!slot)
-          d = kDescZero;
-        const bool rz = d >> 31;
-        const uint32_t rthr = d & kDescNever;
-        const bool isdef = !rz && rthr == kDescNever;
-        const bool isthr = !rz && rthr != kDescNever && rthr != 0;
-        unsigned long long resets = __ballot(isdef);
-        int lhat;
-        for (;;) {
-          const unsigned long long below = resets & lt;
-          const int lsrc = below ? 63 - __clzll((long long)below) : 0;
-          const int lci = __shfl(ci, lsrc);
-          lhat = below ? lci : L;
-          const bool fail = isthr && !((resets >> lane) & 1) && (uint32_t)(ci - lhat) <= rthr;
-          const unsigned long long m = __ballot(fail);
-          if (!m)
-            break;
-          resets |= m;
-        }
-        // incoming L of every event = last reset before its first lane
-        {
-          const unsigned long long gbelow = resets & ((1ull << (lane & 56)) - 1);
-          const int lsrc = gbelow ? 63 - __clzll((long long)gbelow) : 0;
-          const int lci = __shfl(ci, lsrc);
-          const int lin_g = gbelow ? lci : L;
-          // hand it to the window lane that owns the event
-#pragma unroll
-          for (int k = 0; k < 8; k++) {
-            const int o = __shfl(src, 8 * k);
-            const bool so = __shfl((int)slot, 8 * k);
-            const int lv = __shfl(lin_g, 8 * k);
-            if (so && lane == o)
-              my_lin = lv;
-          }
-        }
-        if (resets) {
-          const int lsrc = 63 - __clzll((long long)resets);
-          L = __shfl(ci, lsrc);
-        }
-      }
-      if (lane < nready && kind == 4)
-        __hip_atomic_store(
-          &ctx.rdoq_lin[wi], ((unsigned long long)ctx.mtag << 32) | (uint32_t)my_lin,
-          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      cur += nready;
-      spins = 0;
-    }
-    if (stalled) {
-      if (++spins > (1u << 24)) {
-        if (lane == 0)
-          atomicExch(ctx.error, 1);
-        return;
-      }
-      __builtin_amdgcn_s_sleep(1);
-    }
-  }
-  if (lane == 0)
-    ctx.slice_l[s] = L;
-}
-
 #ifdef GPCC_STATS
 __device__ unsigned long long g_stats[16];
 #define STAT(i, v) atomicAdd(&g_stats[i], (unsigned long long)(v))
@@ -279,16 +97,6 @@ raht_level_sub_kernel(LevelCtx ctx)
   const int cls = blockIdx.x & 7;
 
   const int num_work = ctx.work_count[li];
-  if (kLossy && (threadIdx.x >> 6) == 0) {
-    // wavefront 0 of the first workgroups: the RDOQ resolver of slice
-    // blockIdx.x (+ k gridDim.x); the other three wavefronts work as usual
-    if ((int)blockIdx.x < tv.num_slices) {
-      __builtin_amdgcn_s_setprio(3);  // the serial chain goes ahead of the pollers
-      for (int s = blockIdx.x; s < tv.num_slices; s += gridDim.x)
-        rdoq_resolver<C>(ctx, s, num_work);
-      return;
-    }
-  }
   for (;;) {
     int tk = 0;
     if (lane == 0)
@@ -714,8 +522,6 @@ raht_level_sub_kernel(LevelCtx ctx)
     const int64_t pdiv = pred_divisor(wsum > 0 ? wsum : 1);
     const auto mrsrc = __builtin_amdgcn_make_buffer_rsrc(
       ctx.mbox, 0, (int)((size_t)tv.n_total * C * 16), 0x00020000);
-    const auto drsrc = __builtin_amdgcn_make_buffer_rsrc(
-      ctx.rdoq_desc, 0, (int)(((size_t)tv.n_total + 1) * 48), 0x00020000);
 
     // ---- the staged dependency loop -------------------------------------
     // stage 0: waiting for neighbour blocks   -> (P) predict + transform,
@@ -730,7 +536,10 @@ raht_level_sub_kernel(LevelCtx ctx)
     int64_t pt[C];          // transformed prediction of this position
     int32_t qc[C];          // tentative quantised coefficients (encoder)
     uint32_t dr = kDescZero;  // RDOQ descriptor of rank t (lossy encoder)
-    bool d_published = false;  // descriptors handed to the resolver
+    bool hyp_done = false, hyp_same = false, zr_h = false;  // cached two-hypothesis outcome
+    uint32_t res_h = 0;
+    int need = 0;       // reach of the block's thresholds before its first coefficient
+    int look = wi - 1;  // look-back cursor
     int outk = 0, outv = -1;   // outgoing RDOQ state: 0 unknown, 1 transparent, 2 final (= outv)
 #pragma unroll
     for (int k = 0; k < C; k++) {
@@ -916,18 +725,19 @@ raht_level_sub_kernel(LevelCtx ctx)
           *resets_out = resets;
           return ci - 1 - lhat;  // zero-run length seen by rank t
         };
-        uint32_t resets = 0;
-        bool hyp_same = false;
-        if (stage == 1 && !lin_known) {
-          // the two extreme hypotheses for the incoming L
+        uint32_t resets = res_h;
+        zero_r = zr_h;
+        if (stage == 1 && !lin_known && !hyp_done) {
+          // the two extreme hypotheses for the incoming L (once per block)
           uint32_t ra, rb;
           const int tza = resolve(-1, &ra);
           const int tzb = resolve(cfirst - 1, &rb);
           const bool fa = rvalid && rthr != kDescNever && (uint32_t)tza >= rthr;
           const bool fb = rvalid && rthr != kDescNever && (uint32_t)tzb >= rthr;
           hyp_same = group8_or((fa != fb) ? 1u : 0u) == 0 && ra == rb;
-          resets = rb;
-          zero_r = fb;
+          hyp_done = true;
+          resets = res_h = rb;
+          zero_r = zr_h = fb;
           const int la = ra ? 31 - __clz(ra) : -1, lb = rb ? 31 - __clz(rb) : -1;
           if (ra && la == lb) {
             outk = 2;  // outgoing L known before the decisions are
@@ -935,27 +745,47 @@ raht_level_sub_kernel(LevelCtx ctx)
           } else if (hyp_same && !ra) {
             outk = 1;  // no reset either way: L passes through
           }
+          // how far before the block's first coefficient a reset still matters:
+          // rank t with threshold thr looks at [ci - thr, ci - 1]
+          int nd = isthr ? (int)rthr - t : 0;
+#pragma unroll
+          for (int d = 1; d < 8; d <<= 1) {
+            const int o = __shfl_xor(nd, d);
+            nd = o > nd ? o : nd;
+          }
+          need = nd;
+          if (!hyp_same && outk == 2 && t == 0)
+            // decisions still open, outgoing L already certain: successors go on
+            __hip_atomic_store(
+              &ctx.rdoq_state[wi], ((unsigned long long)epoch << 48) | (2ull << 32) | (uint32_t)outv,
+              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        // ---- L handed from group to group inside the wavefront (registers,
-        // no memory round trip): the nearest predecessor group of the slice
-        // that is not transparent supplies L once its own L is settled
-        {
+        // ---- a block whose decisions depend on L finds it by a BOUNDED
+        // look-back: only a reset within `need` coefficients before the block
+        // matters, so the walk over the predecessors' state words ends at the
+        // first block with a reset (exact L), at the slice start, or as soon
+        // as `need` coefficients of reset-free blocks have been passed
+        // (any older L gives the same decisions).  Predecessors that are
+        // themselves undecided are waited for -- that is the only chain.
+        const bool want = stage == 1 && !lin_known && !hyp_same;
+        // (a) predecessors inside the wavefront, from registers
+        if (__any(want)) {
           const unsigned long long lead = 0x0101010101010101ull;
           const unsigned long long below = (1ull << gbase) - 1;
           for (int pass = 0; pass < 8; pass++) {
             if (stage == 1 && lin_known && outk != 3) {
               uint32_t rr;
               resolve(lin, &rr);
-              outk = 3;  // final, decided with the true L
-              outv = rr ? cfirst + (31 - __clz(rr)) : lin;
+              outk = rr ? 3 : 1;  // settled with the true L: final, or reset-free
+              outv = rr ? cfirst + (31 - __clz(rr)) : outv;
             }
             const unsigned long long nt = __ballot(outk != 1) & lead & below;
             const int pl = nt ? 63 - __clzll((long long)nt) : 0;
             const int pk = __shfl(outk, pl);
             const int pv = __shfl(outv, pl);
             const int ps = __shfl(s, pl);
-            const bool want = stage == 1 && !lin_known && !hyp_same;
-            const bool found = want && nt != 0 && pk >= 2 && ps == s;
+            const bool w2 = stage == 1 && !lin_known && !hyp_same;
+            const bool found = w2 && nt != 0 && pk >= 2 && ps == s;
             if (!__any(found))
               break;
             if (found) {
@@ -964,48 +794,63 @@ raht_level_sub_kernel(LevelCtx ctx)
             }
           }
         }
-        // ---- a block whose decisions depend on L hands its descriptors to
-        // the slice's resolver wavefront (rdoq_resolver above) and waits for
-        // its incoming L; everything else commits at once
-        const bool open = stage == 1 && !lin_known && !hyp_same;
-        if (open && !d_published) {
-          // three tagged 16-byte granules: ranks 0-2, 3-5, {6, 7, cfirst}
-          const uint32_t e0 = __shfl(dr, gbase | (t < 3 ? 3 * t : 0));
-          const uint32_t e1 = __shfl(dr, gbase | (t < 3 ? (3 * t + 1) & 7 : 0));
-          const uint32_t e2 = __shfl(dr, gbase | (t < 2 ? 3 * t + 2 : 0));
-          if (t < 3) {
-            const u32x4 gr = {e0, e1, t < 2 ? e2 : (uint32_t)cfirst, ctx.mtag};
-            __builtin_amdgcn_raw_buffer_store_b128(gr, drsrc, (wi * 3 + t) * 16, 0, /*sc1*/ 16);
+        // (b) the state words in memory, 8 predecessors per step
+        if (stage == 1 && !lin_known && !hyp_same) {
+          for (int step = 0; step < 4 && !lin_known; step++) {
+            const int k = look - t;
+            const int kc = k < 0 ? 0 : k;
+            const unsigned long long sv =
+              __hip_atomic_load(&ctx.rdoq_state[kc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool boundary = k < 0 || ctx.worklist[kc] < sp0;
+            const bool cur_ep = (sv >> 48) == (unsigned long long)epoch;
+            // kind: 0 pending, 1 reset-free (value = its first coefficient),
+            // 2 final (value = L), 3 slice start, 5 far enough
+            int kind = boundary ? 3 : (cur_ep ? (int)((sv >> 32) & 0xffff) : 0);
+            const int val = (int)(uint32_t)sv;
+            if (kind == 1 && cfirst - val >= need)
+              kind = 5;
+            const uint32_t stop = group8_or((kind != 1) ? 1u << t : 0u);
+            if (!stop) {
+              look -= 8;
+              continue;
+            }
+            const int first = __ffs(stop) - 1;  // nearest predecessor that decides
+            const int fkind = __shfl(kind, gbase | first);
+            const int fval = __shfl(val, gbase | first);
+            if (fkind == 2) {
+              lin = fval;
+              lin_known = true;
+            } else if (fkind == 3) {
+              lin = ctx.slice_l[((li + 1) & 1) * tv.num_slices + s];  // as the previous level left it
+              lin_known = true;
+            } else if (fkind == 5) {
+              lin = fval - 1;  // stands for "no reset within reach"
+              lin_known = true;
+            } else {
+              look -= first;  // undecided: everything nearer is reset-free
+              break;
+            }
           }
-          if (t == 0)
-            __hip_atomic_store(
-              &ctx.rdoq_state[wi], ((unsigned long long)epoch << 48) | (4ull << 32),
-              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          d_published = true;
-          progressed = true;
-        }
-        if (open) {
-          const unsigned long long lv =
-            __hip_atomic_load(&ctx.rdoq_lin[wi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if ((uint32_t)(lv >> 32) == ctx.mtag) {
-            lin = (int)(uint32_t)lv;
-            lin_known = true;
+          if (lin_known)
             progressed = true;
-          }
         }
         if (stage == 1 && lin_known) {
           const int tz = resolve(lin, &resets);
           zero_r = rvalid && rthr != kDescNever && (uint32_t)tz >= rthr;
-          outk = 3;
-          outv = resets ? cfirst + (31 - __clz(resets)) : lin;
+          outk = resets ? 3 : 1;
+          outv = resets ? cfirst + (31 - __clz(resets)) : outv;
         } else if (!hyp_same) {
           can = false;
         }
-        if (can && t == 0 && !d_published) {
-          // L-independent block: tell the resolver what it does to L
+        if (can && t == 0) {
+          // what this block does to L: its last reset, or nothing (then the
+          // word carries the block's first coefficient index for the walk)
           const unsigned long long ep = (unsigned long long)epoch << 48;
-          const unsigned long long word = outk >= 2 ? ep | (2ull << 32) | (uint32_t)outv : ep | (1ull << 32);
+          const unsigned long long word =
+            outk >= 2 ? ep | (2ull << 32) | (uint32_t)outv : ep | (1ull << 32) | (uint32_t)cfirst;
           __hip_atomic_store(&ctx.rdoq_state[wi], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (outk >= 2)
+            atomicMax(&ctx.slice_l[(li & 1) * tv.num_slices + s], outv);  // L carried to the next level
         }
       }
 
