@@ -340,11 +340,13 @@ raht_level_sub_kernel(LevelCtx ctx)
 
 
     Quantizer qa[2] = {{1, 1}, {1, 1}};
+    bool q_same = true;  // no AC offset here: the RDOQ quantiser is the coding quantiser
     if (coded) {
       int ac0 = 0, ac1 = 0;
       if (e.ac_layer < prm->num_ac_qp_layers && t) {
         ac0 = prm->ac_qp_offset[e.ac_layer][t - 1][0];
         ac1 = prm->ac_qp_offset[e.ac_layer][t - 1][1];
+        q_same = (ac0 | ac1) == 0;
       }
       qpset_quantizers(prm, e.qp_layer, nq0 + ac0, nq1 + ac1, qa);
     }
@@ -644,7 +646,7 @@ raht_level_sub_kernel(LevelCtx ctx)
             qn_[k] = (int32_t)quantize(qa[k ? 1 : 0], co * 256);
             if (kLossy) {
               dist2 += co * co;
-              int64_t aq = quantize(qr[k ? 1 : 0], co * 256);
+              int64_t aq = q_same ? (int64_t)qn_[k] : quantize(qr[k ? 1 : 0], co * 256);
               aq = aq < 0 ? -aq : aq;
               sum_coeff += aq;
               constexpr int lutlog[16] = {0,   256, 406, 512, 594, 662, 719, 768,
@@ -728,12 +730,19 @@ raht_level_sub_kernel(LevelCtx ctx)
         uint32_t resets = res_h;
         zero_r = zr_h;
         if (stage == 1 && !lin_known && !hyp_done) {
-          // the two extreme hypotheses for the incoming L (once per block)
+          // the two extreme hypotheses for the incoming L (once per block);
+          // a block without any run-dependent coefficient skips them
           uint32_t ra, rb;
-          const int tza = resolve(-1, &ra);
-          const int tzb = resolve(cfirst - 1, &rb);
-          const bool fa = rvalid && rthr != kDescNever && (uint32_t)tza >= rthr;
-          const bool fb = rvalid && rthr != kDescNever && (uint32_t)tzb >= rthr;
+          bool fa, fb;
+          if (group8_or((rvalid && rthr != kDescNever && rthr != 0) ? 1u : 0u) == 0) {
+            ra = rb = group8_or(isdef ? 1u << t : 0u);
+            fa = fb = rvalid && rthr == 0;
+          } else {
+            const int tza = resolve(-1, &ra);
+            const int tzb = resolve(cfirst - 1, &rb);
+            fa = rvalid && rthr != kDescNever && (uint32_t)tza >= rthr;
+            fb = rvalid && rthr != kDescNever && (uint32_t)tzb >= rthr;
+          }
           hyp_same = group8_or((fa != fb) ? 1u : 0u) == 0 && ra == rb;
           hyp_done = true;
           resets = res_h = rb;
@@ -747,7 +756,9 @@ raht_level_sub_kernel(LevelCtx ctx)
           }
           // how far before the block's first coefficient a reset still matters:
           // rank t with threshold thr looks at [ci - thr, ci - 1]
-          int nd = isthr ? (int)rthr - t : 0;
+          // (also the all-zero coefficients whose tentative value is non-zero:
+          // they never reset, but whether they are zeroed depends on the run)
+          int nd = (rvalid && rthr != kDescNever && rthr != 0) ? (int)rthr - t : 0;
 #pragma unroll
           for (int d = 1; d < 8; d <<= 1) {
             const int o = __shfl_xor(nd, d);
