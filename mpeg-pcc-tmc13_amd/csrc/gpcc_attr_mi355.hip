@@ -1535,7 +1535,8 @@ gpcc_lod_build(
           HIP_TRY(hipMemsetAsync(d_ticket, 0, sizeof(int32_t) * 8, st));
           lc.ncell = ncell;
           lod_cell_keys_kernel<<<grid_for(ncell, 256), 256, 0, st>>>(lc);
-          const int grid = (int)std::min<int64_t>(512, ((int64_t)ncell + 255) / 256);
+          static const int kSubsampleGrid = getenv("GPCC_SUBSAMPLE_GRID") ? atoi(getenv("GPCC_SUBSAMPLE_GRID")) : 512;
+          const int grid = (int)std::min<int64_t>(kSubsampleGrid, ((int64_t)ncell + 255) / 256);
           {
             Timer tm(ctx, "lod_subsample");
             lod_subsample_distance_kernel<<<std::max(8, (grid + 7) / 8 * 8), 256, 0, st>>>(lc);

@@ -316,7 +316,9 @@ lod_subsample_distance_kernel(LodCtx cx)
       bool go = true;
       // few neighbours left: poll them directly (no extra round trip on the
       // dependency chain)
-      if (watch >= 0 && __popc(pend) > 3) {
+      // (every fourth pass sweeps anyway, so that the early finishers are
+      // already collected when the last one arrives)
+      if (watch >= 0 && __popc(pend) > 3 && (spins & 3) != 3) {
         const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, watch * 16, 0, /*sc1*/ 16);
         go = (v.w >> 1) == (uint32_t)cx.epoch;
       }

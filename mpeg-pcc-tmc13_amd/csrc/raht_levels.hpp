@@ -639,19 +639,37 @@ raht_level_kernel(LevelCtx ctx)
       int64_t lim_lo = 0, lim_hi = 0;
       const int64_t* __restrict__ prec = ctx.rec[par_par];
       const int64_t rbase = (int64_t)pt0 - sp0;
+      // every lane fetches the values of the neighbours it searched (and of
+      // the parent itself) in ONE round trip; the 19-step loop below then
+      // runs on registers -- with the loads inside it, each step's outlier
+      // test serialised the next step's load
+      int64_t nb_v[3][C], own_v[C];
+#pragma unroll
+      for (int k = 0; k < C; k++)
+        own_v[k] = run ? prec[(rbase + j) * C + k] : 0;
+#pragma unroll
+      for (int slot = 0; slot < 3; slot++)
+#pragma unroll
+        for (int k = 0; k < C; k++)
+          nb_v[slot][k] = (run && pn[slot] >= 0) ? prec[(rbase + pn[slot]) * C + k] : 0;
 #pragma unroll
       for (int i = 0; i < 19; i++) {
         int q;
-        if (i == 0)
+        int64_t v[C];
+        if (i == 0) {
           q = j;
-        else
-          q = __shfl(pn[(i - 1) >> 3], (threadIdx.x & 56) | ((i - 1) & 7));
+#pragma unroll
+          for (int k = 0; k < C; k++)
+            v[k] = own_v[k];
+        } else {
+          const int owner = (threadIdx.x & 56) | ((i - 1) & 7);
+          q = __shfl(pn[(i - 1) >> 3], owner);
+#pragma unroll
+          for (int k = 0; k < C; k++)
+            v[k] = shfl_i64(nb_v[(i - 1) >> 3][k], owner);
+        }
         if (!run || q < 0)
           continue;
-        int64_t v[C];
-#pragma unroll
-        for (int k = 0; k < C; k++)
-          v[k] = prec[(rbase + q) * C + k];
         if (i) {
           if (10 * v[0] <= lim_lo || 10 * v[0] >= lim_hi)
             continue;
