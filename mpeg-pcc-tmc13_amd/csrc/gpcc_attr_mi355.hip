@@ -1349,12 +1349,12 @@ gpcc_lod_build(
       || !indexes || !num_points_in_lod || !num_lods)
     return fail(GPCC_ERR_INVALID_ARG, "null buffer or n <= 0");
   if (lp->scalable_lifting_enabled_flag || lp->canonical_point_order_flag
-      || lp->max_points_per_sort_log2_plus1 || lp->lod_decimation_type == 2
-      || lp->pred_weight_blending_enabled_flag)
+      || lp->max_points_per_sort_log2_plus1 || lp->pred_weight_blending_enabled_flag
+      || lp->lod_decimation_type < 0 || lp->lod_decimation_type > 2)
     return fail(
       GPCC_ERR_UNSUPPORTED,
-      "scalable lifting / canonical point order / centroid decimation / "
-      "weight blending stay on the reference CPU path");
+      "scalable lifting / canonical point order / weight blending stay on the "
+      "reference CPU path");
   const int max_levels = lp->num_detail_levels_minus1 + 1;
   if (max_levels < 1 || max_levels > GPCC_MAX_LODS - 1)
     return fail(GPCC_ERR_INVALID_ARG, "num_detail_levels out of range");
@@ -1398,6 +1398,7 @@ gpcc_lod_build(
     DM(uint8_t, d_heads, N + 1)
     DM(int32_t, d_positions, N + 1)
     DM(int32_t, d_cell_first, N + 2)
+    DM(int32_t, d_cent_tmp, N + 2)
     DM(int64_t, d_cell_key, N + 1)
     DM(uint32_t, d_cell_state, 4 * (N + 1))
     DM(int32_t, d_small, 64)  // ticket[8], error, counts[2]
@@ -1493,7 +1494,7 @@ gpcc_lod_build(
       const int start = n_idx;
       int n_ret = 0, n_ref = 0;
       const int shift_bits0 = lp->dist2 + lp->attr_dist2_delta + lod;
-      if (lod == max_levels - 1 || (lp->lod_decimation_type == 0 && n_in == 1)) {
+      if (lod == max_levels - 1 || (lp->lod_decimation_type != 1 && n_in == 1)) {
         HIP_TRY(hipMemcpyAsync(
           d_refine + start, d_input, sizeof(int32_t) * n_in, hipMemcpyDeviceToDevice, st));
         n_ref = n_in;
@@ -1503,6 +1504,32 @@ gpcc_lod_build(
           if (period < 1)
             return fail(GPCC_ERR_INVALID_ARG, "lod_sampling_period < 1");
           lod_flag_periodic_kernel<<<grid_for(n_in, 256), 256, 0, st>>>(n_in, period, d_flags);
+        } else if (lp->lod_decimation_type == 2) {
+          const int period = lp->lod_sampling_period[lod];
+          if (period < 1)
+            return fail(GPCC_ERR_INVALID_ARG, "lod_sampling_period < 1");
+          LodCtx lc{};
+          lc.code = d_code;
+          lc.pos = d_pos;
+          lc.input = d_input;
+          lc.n_in = n_in;
+          lc.shift3 = 3 * (shift_bits0 + 1);
+          lc.flags = d_flags;
+          // group starts = orbit of 0 under next(): pointer doubling
+          int32_t* nxt0 = d_cell_first;               // [n_in + 1]
+          int32_t* nj[2] = {d_positions, d_cent_tmp};  // squared pointers
+          Timer tm(ctx, "lod_centroid");
+          lod_centroid_next_kernel<<<grid_for(n_in + 1, 256), 256, 0, st>>>(lc, period, nxt0);
+          HIP_TRY(hipMemsetAsync(d_heads, 0, (size_t)n_in + 1, st));
+          HIP_TRY(hipMemsetAsync(d_heads, 1, 1, st));
+          const int32_t* cur = nxt0;
+          for (int r = 0, reach = 1; reach < n_in; r++, reach *= 2) {
+            lod_centroid_jump_kernel<<<grid_for(n_in + 1, 256), 256, 0, st>>>(
+              n_in, cur, nj[r & 1], d_heads);
+            cur = nj[r & 1];
+          }
+          lod_centroid_pick_kernel<<<grid_for(n_in, 256), 256, 0, st>>>(
+            lc, shift_bits0, nxt0, d_heads);
         } else {
           LodCtx lc{};
           lc.n = n;

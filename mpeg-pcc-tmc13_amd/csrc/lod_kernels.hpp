@@ -172,6 +172,95 @@ lod_flag_periodic_kernel(int n_in, int period, uint8_t* flags)
     flags[t] = (t % period) == 0;
 }
 
+// ---- subsampleByOctreeWithCentroid (lodDecimator 2, :2089-2194) ------------
+// The reference walks the list once: points accumulate until a cell boundary
+// is reached with at least `period` points, then the point closest to the
+// (masked) centroid of the group is retained.  The greedy grouping restated:
+// a group starting at g ends at the end of the cell that holds position
+// g + period - 1, so the group starts are the orbit of 0 under
+// next(g) = cell_end(min(g + period - 1, n - 1)) + 1 -- marked by pointer
+// doubling (log2 n launches), no serial walk.
+__global__ __launch_bounds__(256) void
+lod_centroid_next_kernel(LodCtx cx, int period, int32_t* __restrict__ nxt)
+{
+  for (int g = blockIdx.x * blockDim.x + threadIdx.x; g <= cx.n_in;
+       g += gridDim.x * blockDim.x) {
+    if (g == cx.n_in) {
+      nxt[g] = cx.n_in;
+      continue;
+    }
+    const int x = min(g + period - 1, cx.n_in - 1);
+    const int64_t key = cx.code[cx.input[x]] >> cx.shift3;
+    int lo = x, hi = cx.n_in;  // first position whose cell key is larger
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if ((cx.code[cx.input[mid]] >> cx.shift3) <= key)
+        lo = mid + 1;
+      else
+        hi = mid;
+    }
+    nxt[g] = lo;
+  }
+}
+
+// one doubling round: marked starts mark their 2^k-th successor, every
+// pointer is squared
+__global__ __launch_bounds__(256) void
+lod_centroid_jump_kernel(
+  int n_in, const int32_t* __restrict__ nxt_in, int32_t* __restrict__ nxt_out,
+  uint8_t* mark)
+{
+  for (int g = blockIdx.x * blockDim.x + threadIdx.x; g <= n_in;
+       g += gridDim.x * blockDim.x) {
+    const int n1 = nxt_in[g];
+    if (g < n_in && n1 < n_in && mark[g])
+      mark[n1] = 1;
+    nxt_out[g] = n1 < n_in ? nxt_in[n1] : n_in;
+  }
+}
+
+// one thread per group: centroid, nearest member (ties: the last one), flags
+__global__ __launch_bounds__(256) void
+lod_centroid_pick_kernel(
+  LodCtx cx, int node_log2, const int32_t* __restrict__ nxt0,
+  const uint8_t* __restrict__ mark)
+{
+  const uint32_t mask = node_log2 ? 0xffffffffu << node_log2 : 0xffffffffu;
+  for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < cx.n_in;
+       g += gridDim.x * blockDim.x) {
+    if (!mark[g])
+      continue;
+    const int e = nxt0[g];  // one past the group's last position
+    const int nv = e - g;
+    uint32_t cen[3] = {0, 0, 0};  // Vec3<int32_t> sums wrap like the reference's
+    for (int v = g; v < e; v++) {
+      const int idx = cx.input[v];
+#pragma unroll
+      for (int d = 0; d < 3; d++)
+        cen[d] += (uint32_t)cx.pos[3 * (size_t)idx + d] & mask;
+    }
+    int best = e - 1;
+    int64_t best_m = INT64_MAX;
+    for (int v = e - 1; v >= g; v--) {
+      const int idx = cx.input[v];
+      int64_t m = 0;
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+        const uint32_t p = ((uint32_t)cx.pos[3 * (size_t)idx + d] & mask) * (uint32_t)nv;
+        const int32_t df = (int32_t)(p - cen[d]);
+        m += df < 0 ? -(int64_t)df : (int64_t)df;
+      }
+      m = (int32_t)m;  // getNorm1 on Vec3<int32_t>
+      if (best_m > m) {
+        best_m = m;
+        best = v;
+      }
+    }
+    for (int v = g; v < e; v++)
+      cx.flags[v] = v == best;
+  }
+}
+
 // cell heads of the input list
 __global__ __launch_bounds__(256) void
 lod_flag_cell_heads_kernel(LodCtx cx, uint8_t* heads, int32_t* positions)

@@ -33,7 +33,8 @@ def clouds():
 
 VARIANTS = [dict(), dict(decimation=1), dict(distribution=False), dict(dist2=1),
             dict(lifting=False, intra_range=64), dict(bias=(1, 2, 1)), dict(inter_range=8),
-            dict(neighbours=2), dict(levels=3), dict(decimation=1, sampling_period=2, levels=21)]
+            dict(neighbours=2), dict(levels=3), dict(decimation=1, sampling_period=2, levels=21),
+            dict(decimation=2), dict(decimation=2, sampling_period=3, dist2=1), dict(decimation=2, sampling_period=1)]
 
 
 def make_params(kw):
@@ -58,11 +59,13 @@ def test_lod_build_vs_oracle(vi, ctx):
         np.testing.assert_array_equal(g["w"].astype(np.uint64), o["w"], err_msg=f"{name} {kw}")
 
 
-@pytest.mark.parametrize("kind,n", [("dense", 300000), ("lidar", 200000)])
-def test_lod_build_large(kind, n, ctx):
+@pytest.mark.parametrize("kind,n,kw", [("dense", 300000, {}), ("lidar", 200000, {}),
+                                       ("lidar", 250000, dict(decimation=2)), ("dense", 200000, dict(decimation=2)),
+                                       ("lidar", 250000, dict(decimation=1))])
+def test_lod_build_large(kind, n, kw, ctx):
     from mpeg_pcc_tmc13_amd import lod_params, synth
     xyz = (synth.dense_cloud(n, seed=41, bits=10) if kind == "dense" else synth.lidar_cloud(n, seed=41))[0]
-    lp = lod_params()
+    lp = lod_params(**kw)
     chk = lh.ref_lod_generate(xyz, lp) if ol.ref_available() else lh.oracle_lod_generate(xyz, lp)
     g = ctx.lod_build(lp, xyz)
     for k in ("npl", "indexes", "nc", "ni"):
@@ -107,6 +110,8 @@ def test_lod_unsupported_modes(ctx):
     from mpeg_pcc_tmc13_amd import lod_params
     from mpeg_pcc_tmc13_amd._lib import GpccError
     xyz = np.zeros((4, 3), np.int32)
+    lp = lod_params()
+    lp.scalable_lifting_enabled_flag = 1
     with pytest.raises(GpccError) as ei:
-        ctx.lod_build(lod_params(decimation=2), xyz)
-    assert ei.value.code == -2
+        ctx.lod_build(lp, xyz)
+    assert ei.value.code == -2  # GPCC_ERR_UNSUPPORTED: the shim keeps the reference CPU path
