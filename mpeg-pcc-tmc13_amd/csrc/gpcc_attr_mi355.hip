@@ -1349,12 +1349,11 @@ gpcc_lod_build(
       || !indexes || !num_points_in_lod || !num_lods)
     return fail(GPCC_ERR_INVALID_ARG, "null buffer or n <= 0");
   if (lp->scalable_lifting_enabled_flag || lp->canonical_point_order_flag
-      || lp->max_points_per_sort_log2_plus1 || lp->pred_weight_blending_enabled_flag
-      || lp->lod_decimation_type < 0 || lp->lod_decimation_type > 2)
+      || lp->max_points_per_sort_log2_plus1 || lp->lod_decimation_type < 0
+      || lp->lod_decimation_type > 2)
     return fail(
       GPCC_ERR_UNSUPPORTED,
-      "scalable lifting / canonical point order / weight blending stay on the "
-      "reference CPU path");
+      "scalable lifting / canonical point order stay on the reference CPU path");
   const int max_levels = lp->num_detail_levels_minus1 + 1;
   if (max_levels < 1 || max_levels > GPCC_MAX_LODS - 1)
     return fail(GPCC_ERR_INVALID_ARG, "num_detail_levels out of range");
@@ -1634,6 +1633,9 @@ gpcc_lod_build(
     }
     lod_compute_weights_kernel<<<grid_for(n, 256), 256, 0, st>>>(
       n, d_pred_count, d_pred_dist2, d_weight);
+    if (lp->attr_encoding == 1 && lp->pred_weight_blending_enabled_flag)
+      lod_blend_weights_kernel<<<grid_for(n, 256), 256, 0, st>>>(
+        n, d_pred_count, d_pred_point, d_xyz, d_weight);
     HIP_TRY(hipGetLastError());
     int32_t h_err = 0;
     HIP_TRY(hipMemcpyAsync(neigh_count, d_pred_count, sizeof(int32_t) * N, hipMemcpyDeviceToHost, st));

@@ -114,6 +114,42 @@ lod_compute_weights_kernel(
   }
 }
 
+// PCCPredictor::blendWeights (tmc3/PCCTMC3Common.h:635-693; predicting
+// transform only, AttributeCommon.cpp:66-69).  neigh_point holds the POINT
+// indices of the neighbours, xyz the positions in point order.
+__global__ __launch_bounds__(256) void
+lod_blend_weights_kernel(
+  int n, const int32_t* __restrict__ neigh_count, const int32_t* __restrict__ neigh_point,
+  const int32_t* __restrict__ xyz, int32_t* weight)
+{
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += gridDim.x * blockDim.x) {
+    if (neigh_count[i] != 3)
+      continue;
+    const int32_t* q0 = &xyz[3 * (size_t)neigh_point[3 * (size_t)i]];
+    const int32_t* q1 = &xyz[3 * (size_t)neigh_point[3 * (size_t)i + 1]];
+    const int32_t* q2 = &xyz[3 * (size_t)neigh_point[3 * (size_t)i + 2]];
+    int64_t d01 = 0, d02 = 0, d12 = 0;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const int64_t a = (int64_t)q0[c] - q1[c], b = (int64_t)q0[c] - q2[c], e = (int64_t)q1[c] - q2[c];
+      d01 += a * a;
+      d02 += b * b;
+      d12 += e * e;
+    }
+    constexpr int dd = 10, bb = 1, cc = 5;
+    const int b1 = d01 <= d02 ? bb : cc;
+    const int b2 = d01 <= d12 ? cc : bb;
+    const int b3 = d02 <= d12 ? bb : cc;
+    const int w0 = weight[3 * (size_t)i], w1 = weight[3 * (size_t)i + 1], w2 = weight[3 * (size_t)i + 2];
+    const int v0 = (w0 * dd + w1 * (16 - dd - b2) + w2 * b3) >> 4;
+    const int v1 = (w0 * b1 + w1 * dd + w2 * (16 - dd - b3)) >> 4;
+    weight[3 * (size_t)i] = v0;
+    weight[3 * (size_t)i + 1] = v1;
+    weight[3 * (size_t)i + 2] = 256 - v0 - v1;
+  }
+}
+
 __global__ __launch_bounds__(256) void
 lift_init_kernel(LiftCtx cx, int encoder)
 {

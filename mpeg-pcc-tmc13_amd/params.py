@@ -152,7 +152,7 @@ class LodParams(C.Structure):
 
 def lod_params(levels=12, decimation=0, dist2=0, dist2_delta=0, neighbours=3, lifting=True,
                distribution=True, bias=(1, 1, 1), inter_range=1100000, intra_range=0,
-               sampling_period=4):
+               sampling_period=4, blend=False):
     """cfg/octree-liftt-ctc-*.yaml after encoder.cpp:799-808 (search ranges
     of -1 become 1100000): 12 detail levels, distance decimation, three
     nearest neighbours, distribution-aware third neighbour."""
@@ -169,6 +169,7 @@ def lod_params(levels=12, decimation=0, dist2=0, dist2_delta=0, neighbours=3, li
     p.intra_lod_prediction_skip_layers = 0x7FFFFFFF
     p.dist2 = dist2
     p.attr_dist2_delta = dist2_delta
+    p.pred_weight_blending_enabled_flag = int(blend)
     for i in range(GPCC_MAX_LODS):
         p.lod_sampling_period[i] = sampling_period
     return p

@@ -13,8 +13,7 @@
 // AttributeLods::generate with the original signature.  The LoD fields of
 // the APS / ABH are flattened into gpcc_lod_params, the build runs on the
 // MI355X through the C ABI and the public vectors are filled; whenever the
-// device path declines (no GPU, inter prediction, scalable lifting, weight
-// blending, ...) the renamed reference body runs instead.
+// device path declines (no GPU, inter prediction, scalable lifting, ...) the renamed reference body runs instead.
 //
 // Built against the reference's headers; contains no reference code.
 #include <cstdio>

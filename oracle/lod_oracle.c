@@ -781,8 +781,38 @@ oracle_lod_generate(
   *num_lods = nl;
   for (int i = 0; i < nl; i++)
     num_points_in_lod[i] = npl[nl - 1 - i];
-  if (!raw)
+  if (!raw) {
     oracle_compute_weights(n, neigh_count, weight64);
+    /* PCCPredictor::blendWeights :635-693 (predicting transform only,
+     * AttributeCommon.cpp:66-69): positions of the three neighbours */
+    if (lp->attr_encoding == 1 && lp->pred_weight_blending_enabled_flag) {
+      for (int i = 0; i < n; i++) {
+        if (neigh_count[i] != 3)
+          continue;
+        const int32_t* q[3];
+        for (int k = 0; k < 3; k++)
+          q[k] = &xyz[3 * indexes_out[neigh_index[3 * i + k]]];
+        int64_t d01 = 0, d02 = 0, d12 = 0;
+        for (int c = 0; c < 3; c++) {
+          const int64_t a = (int64_t)q[0][c] - q[1][c], b = (int64_t)q[0][c] - q[2][c],
+                        e = (int64_t)q[1][c] - q[2][c];
+          d01 += a * a;
+          d02 += b * b;
+          d12 += e * e;
+        }
+        const int dd = 10, bb = 1, cc = 5;
+        const int b1 = d01 <= d02 ? bb : cc;
+        const int b2 = d01 <= d12 ? cc : bb;
+        const int b3 = d02 <= d12 ? bb : cc;
+        const int w0 = (int)weight64[3 * i], w1 = (int)weight64[3 * i + 1], w2 = (int)weight64[3 * i + 2];
+        const int v0 = (w0 * dd + w1 * (16 - dd - b2) + w2 * b3) >> 4;
+        const int v1 = (w0 * b1 + w1 * dd + w2 * (16 - dd - b3)) >> 4;
+        weight64[3 * i] = (uint64_t)(int64_t)v0;
+        weight64[3 * i + 1] = (uint64_t)(int64_t)v1;
+        weight64[3 * i + 2] = (uint64_t)(int64_t)(256 - v0 - v1);
+      }
+    }
+  }
   free(pv);
   free(bias_pos);
   free(input);

@@ -32,7 +32,7 @@ def clouds():
 
 
 VARIANTS = [dict(), dict(decimation=1), dict(distribution=False), dict(dist2=1),
-            dict(lifting=False, intra_range=64), dict(bias=(1, 2, 1)), dict(inter_range=8),
+            dict(lifting=False, intra_range=64), dict(lifting=False, intra_range=64, blend=True), dict(bias=(1, 2, 1)), dict(inter_range=8),
             dict(neighbours=2), dict(levels=3), dict(decimation=1, sampling_period=2, levels=21),
             dict(decimation=2), dict(decimation=2, sampling_period=3, dist2=1), dict(decimation=2, sampling_period=1)]
 
