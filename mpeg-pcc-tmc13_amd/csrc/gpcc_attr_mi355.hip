@@ -1561,8 +1561,9 @@ gpcc_lod_build(
           HIP_TRY(hipMemsetAsync(d_ticket, 0, sizeof(int32_t) * 8, st));
           lc.ncell = ncell;
           lod_cell_keys_kernel<<<grid_for(ncell, 256), 256, 0, st>>>(lc);
-          static const int kSubsampleGrid = getenv("GPCC_SUBSAMPLE_GRID") ? atoi(getenv("GPCC_SUBSAMPLE_GRID")) : 512;
-          const int grid = (int)std::min<int64_t>(kSubsampleGrid, ((int64_t)ncell + 255) / 256);
+          // 2 workgroups per CU stay resident (58 KB of LDS each); measured:
+          // the time grows like 1/sqrt(cells in flight), so take them all
+          const int grid = (int)std::min<int64_t>(512, ((int64_t)ncell + 255) / 256);
           {
             Timer tm(ctx, "lod_subsample");
             lod_subsample_distance_kernel<<<std::max(8, (grid + 7) / 8 * 8), 256, 0, st>>>(lc);
@@ -1807,18 +1808,5 @@ gpcc_estimate_dist2(
   hipFree(d_dist);
   return rc;
 }
-
-#ifdef GPCC_STATS
-int
-gpcc_debug_stats(unsigned long long* out, int reset)
-{
-  hipMemcpyFromSymbol(out, HIP_SYMBOL(gpcc::g_stats), sizeof(unsigned long long) * 16);
-  if (reset) {
-    unsigned long long z[16] = {};
-    hipMemcpyToSymbol(HIP_SYMBOL(gpcc::g_stats), z, sizeof(z));
-  }
-  return 0;
-}
-#endif
 
 }  // extern "C"

@@ -10,29 +10,31 @@
 // Execution model.  Wavefronts claim 8 consecutive worklist blocks with a
 // ticket (8 counters, workgroup index mod 8, so claiming is monotone per
 // counter and the lowest unfinished block can always run: every dependency
-// points to a lower block).  Everything that does not depend on neighbours
-// of the same level runs first for all 8 blocks (children gather, butterfly
-// coefficients, neighbour search, parent-level part of the prediction,
-// encoder-side forward transform of the source).  Then a wave-uniform loop
-// polls one `done` word per dependency (relaxed agent-scope loads), and for
-// the groups whose dependencies are complete finishes the block:
-// child-level prediction terms, transform, coefficients, inverse,
-// reconstruction.  The children's reconstruction that later blocks of the
-// SAME launch read is written write-through (agent-scope relaxed stores,
-// `sc1`) and read with agent-scope loads; the producer drains its stores
-// (`s_waitcnt vmcnt(0)`) before one lane publishes done[j] = epoch
-// (cdna_hip_programming.md G16, form R1).  Spins are bounded: a stuck launch
-// raises ctx.error instead of hanging the GPU.
+// points to a lower block).  Which term a (child lane, neighbour) pair
+// contributes is decided by the tree alone -- the neighbour parent's value,
+// a child copied by the prepass, or a child reconstructed by THIS launch --
+// so everything but the last kind (children gather, butterfly coefficients,
+// neighbour search, parent-level terms, weight sum, divisor, the encoder's
+// forward transform of the source) is settled before the wait.  A
+// reconstructed child is published as ONE 16-byte write-through (sc1) store
+// {value, tag} into a mailbox next to the plain store later launches read;
+// a wave-uniform loop polls exactly the granules a block still needs
+// (cdna_hip_programming.md G16, form R2: the data is the flag -- one memory
+// round trip per dependency hop, no flag word, no drain), and finishes the
+// groups whose values have all arrived: normalise, transform, coefficients,
+// inverse, reconstruction.  Spins are bounded: a stuck launch raises
+// ctx.error instead of hanging the GPU.
 //
 // Modes: kSynth (decoder), kFused (integer-Haar encoder) and kLossySub, the
 // lossy encoder.  There the RDOQ zero-run state (tmc3/RAHT.cpp:1618-1669)
 // is a second dependency: a block's decisions need L, the index of the last
 // reset before its first coefficient (raht_rdoq.hpp).  Each block evaluates
 // its <= 8 coefficients under the two extreme hypotheses for L; when both
-// agree it commits at once and publishes either its absolute outgoing L
-// ("final") or "transparent" (no reset inside, L passes through).  Only a
-// block whose outcome really depends on L looks back over its
-// predecessors' words (skipping transparent ones) and waits if needed.
+// agree it commits at once and publishes a state word (final L, or
+// "reset-free" + its first coefficient index).  Otherwise only a reset within
+// the reach of its thresholds matters, so it walks the predecessors' words
+// -- registers inside the wavefront, then memory, 8 per step -- until a
+// block with a reset, the slice start, or `reach` reset-free coefficients.
 #pragma once
 
 #include "raht_levels.hpp"
@@ -63,15 +65,6 @@ store_agent_i64(int64_t* p, int64_t v)
 {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-
-#ifdef GPCC_STATS
-__device__ unsigned long long g_stats[16];
-#define STAT(i, v) atomicAdd(&g_stats[i], (unsigned long long)(v))
-#define STATMAX(i, v) atomicMax(&g_stats[i], (unsigned long long)(v))
-#else
-#define STAT(i, v)
-#define STATMAX(i, v)
-#endif
 
 template<int C, int MODE>
 __global__ __launch_bounds__(256, 4) void
@@ -548,15 +541,8 @@ raht_level_sub_kernel(LevelCtx ctx)
       pt[k] = 0;
       qc[k] = 0;
     }
-#ifdef GPCC_STATS
-    unsigned n_iter = 0, n_lb = 0;
-    if (kLossy && lane == 0) STAT(0, 1);
-#endif
     while (__any(stage != 3)) {
       bool progressed = false;
-#ifdef GPCC_STATS
-      n_iter++;
-#endif
       // ---- (X) awaited children: the granule is data and flag at once ----
       if (stage == 0 && pend) {
 #pragma unroll
@@ -943,9 +929,6 @@ raht_level_sub_kernel(LevelCtx ctx)
           stage = 3;
       }
 
-#ifdef GPCC_STATS
-      if (kLossy && !progressed && lane == 0) STAT(2, 1);
-#endif
       if (!progressed) {
         if (++spins > (1u << 24)) {
           if (lane == 0)
@@ -955,11 +938,6 @@ raht_level_sub_kernel(LevelCtx ctx)
         __builtin_amdgcn_s_sleep(4);
       }
     }
-#ifdef GPCC_STATS
-    if (kLossy) {
-      if (lane == 0) { STAT(1, n_iter); STATMAX(5, n_iter); }
-    }
-#endif
   }
 }
 
