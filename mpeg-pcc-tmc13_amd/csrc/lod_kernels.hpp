@@ -317,6 +317,10 @@ lod_subsample_distance_kernel(LodCtx cx)
     const int64_t wround = (int64_t)tk * 8 + cls;
     if (wround * 64 >= cx.ncell)
       break;
+    // a bounded wait has expired somewhere: the result is discarded anyway,
+    // leave at once instead of spinning through every remaining round
+    if (__hip_atomic_load(cx.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      break;
     const int x = (int)(wround * 64) + lane;
     const bool live = x < cx.ncell;
     int t0 = 0, t1 = 0;
@@ -428,7 +432,7 @@ lod_subsample_distance_kernel(LodCtx cx)
       }
       const bool ready = pending && pend == 0;
       if (!__any(ready)) {
-        if (++spins > (1u << 22)) {
+        if (++spins > (1u << 20)) {
           if (lane == 0)
             atomicExch(cx.error, 1);
           break;

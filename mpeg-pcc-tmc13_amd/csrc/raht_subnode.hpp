@@ -98,6 +98,10 @@ raht_level_sub_kernel(LevelCtx ctx)
     const int64_t wround = (int64_t)tk * 8 + cls;
     if (wround * 8 >= num_work)
       break;
+    // a bounded wait has expired somewhere: the result is discarded anyway,
+    // leave at once instead of spinning through every remaining round
+    if (__hip_atomic_load(ctx.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      break;
     const int wi = (int)(wround * 8) + (lane >> 3);
     const bool live = wi < num_work;
     const int j = live ? ctx.worklist[wi] : 0;
@@ -930,7 +934,7 @@ raht_level_sub_kernel(LevelCtx ctx)
       }
 
       if (!progressed) {
-        if (++spins > (1u << 24)) {
+        if (++spins > (1u << 21)) {
           if (lane == 0)
             atomicExch(ctx.error, 1);  // fail loudly instead of hanging
           break;
