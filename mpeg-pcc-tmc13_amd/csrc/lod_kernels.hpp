@@ -398,36 +398,30 @@ lod_subsample_distance_kernel(LodCtx cx)
     bool pending = live;
     unsigned spins = 0;
     while (__any(pending)) {
-      // cells complete roughly in index order: watch only the highest
-      // pending neighbour, sweep the others once it has arrived (keeps the
-      // polling traffic of the cells far ahead of the wavefront small)
-      int watch = -1;
+      // poll every pending neighbour; the loads of a pass are issued
+      // together BEFORE any result is looked at (a loop that tests each
+      // result before issuing the next load costs one round trip per
+      // neighbour)
+      {
+        const uint32_t todo = pend;
+        u32x4 vv[19];
 #pragma unroll
-      for (int k = 0; k < 19; k++)
-        if (((pend >> k) & 1) && lo[k] > watch)
-          watch = lo[k];
-      bool go = true;
-      // few neighbours left: poll them directly (no extra round trip on the
-      // dependency chain)
-      // (every fourth pass sweeps anyway, so that the early finishers are
-      // already collected when the last one arrives)
-      if (watch >= 0 && __popc(pend) > 3 && (spins & 3) != 3) {
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, watch * 16, 0, /*sc1*/ 16);
-        go = (v.w >> 1) == (uint32_t)cx.epoch;
-      }
+        for (int k = 0; k < 19; k++) {
+          vv[k] = u32x4{0, 0, 0, 0};
+          if ((todo >> k) & 1)
+            vv[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lo[k] * 16, 0, /*sc1*/ 16);
+        }
 #pragma unroll
-      for (int k = 0; k < 19; k++) {
-        if (!go || !((pend >> k) & 1))
-          continue;
-        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lo[k] * 16, 0, /*sc1*/ 16);
-        if ((v.w >> 1) == (uint32_t)cx.epoch) {
-          if (v.w & 1) {
-            nbr[3 * nr][lane] = (int32_t)v.x;
-            nbr[3 * nr + 1][lane] = (int32_t)v.y;
-            nbr[3 * nr + 2][lane] = (int32_t)v.z;
-            nr++;
+        for (int k = 0; k < 19; k++) {
+          if (((todo >> k) & 1) && (vv[k].w >> 1) == (uint32_t)cx.epoch) {
+            if (vv[k].w & 1) {
+              nbr[3 * nr][lane] = (int32_t)vv[k].x;
+              nbr[3 * nr + 1][lane] = (int32_t)vv[k].y;
+              nbr[3 * nr + 2][lane] = (int32_t)vv[k].z;
+              nr++;
+            }
+            pend &= ~(1u << k);
           }
-          pend &= ~(1u << k);
         }
       }
       const bool ready = pending && pend == 0;
