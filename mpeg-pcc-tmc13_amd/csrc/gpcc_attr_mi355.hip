@@ -1399,6 +1399,7 @@ gpcc_lod_build(
     DM(int32_t, d_cell_first, N + 2)
     DM(int32_t, d_cent_tmp, N + 2)
     DM(int64_t, d_cell_key, N + 1)
+    DM(int64_t, d_ret_key, N + 1)
     DM(uint32_t, d_cell_state, 4 * (N + 1))
     DM(int32_t, d_small, 64)  // ticket[8], error, counts[2]
     DM(unsigned long long, d_scan, 1024)
@@ -1584,6 +1585,7 @@ gpcc_lod_build(
         nc.order = d_order;
         nc.bpos = d_bpos;
         nc.retained = d_ret;
+        nc.ret_key = d_ret_key;
         nc.n_ret = n_ret;
         nc.refine = d_refine + start;
         nc.n_ref = n_ref;
@@ -1606,8 +1608,11 @@ gpcc_lod_build(
         nc.pred_dist2 = d_pred_dist2;
         nc.pt2pred = d_pt2pred;
         nc.indexes = d_indexes;
-        if (n_ret > 0)
+        if (n_ret > 0) {
+          lod_ret_keys_kernel<<<grid_for(n_ret, 256), 256, 0, st>>>(
+            n_ret, d_ret, d_code, nc.shift3, d_ret_key);
           build_boxes(0, d_ret, n_ret);
+        }
         if (nc.intra)
           build_boxes(1, d_refine + start, n_ref);
         const long long inf = INT64_MAX;

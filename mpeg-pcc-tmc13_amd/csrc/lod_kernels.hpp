@@ -534,6 +534,7 @@ struct NnCtx {
   const int32_t* order;
   const int32_t* bpos;       // [n][3] biased positions, sorted order
   const int32_t* retained;   // [n_ret] packed indices (ascending codes)
+  const int64_t* ret_key;    // [n_ret] code >> shift3 of the retained entries
   int32_t n_ret;
   const int32_t* refine;     // [n_ref] packed indices of this LoD's points
   int32_t n_ref;
@@ -779,6 +780,16 @@ lod_box_up_kernel(
   }
 }
 
+// cell keys of the retained list (one probe of a neighbour-cell search = one load)
+__global__ __launch_bounds__(256) void
+lod_ret_keys_kernel(
+  int n_ret, const int32_t* __restrict__ retained, const int64_t* __restrict__ code,
+  int shift3, int64_t* __restrict__ ret_key)
+{
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n_ret; k += gridDim.x * blockDim.x)
+    ret_key[k] = code[retained[k]] >> shift3;
+}
+
 // The reference fills its atlas block by block from a cursor that only
 // advances over retained entries of the block being entered (:1349-1363): a
 // retained entry whose block holds no refinement point is never passed and
@@ -802,29 +813,6 @@ lod_atlas_limit_kernel(NnCtx cx, long long* atlas_limit)
     if (!present)
       atomicMin(atlas_limit, (long long)id);
   }
-}
-
-__device__ __forceinline__ void
-retained_cell_range(const NnCtx& cx, int64_t cell, int* r0, int* r1)
-{
-  int lo = 0, hi = cx.n_ret;
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if ((cx.code[cx.retained[mid]] >> cx.shift3) < cell)
-      lo = mid + 1;
-    else
-      hi = mid;
-  }
-  *r0 = lo;
-  hi = cx.n_ret;
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if ((cx.code[cx.retained[mid]] >> cx.shift3) <= cell)
-      lo = mid + 1;
-    else
-      hi = mid;
-  }
-  *r1 = lo;
 }
 
 __global__ __launch_bounds__(256) void
@@ -862,14 +850,48 @@ lod_nn_search_kernel(NnCtx cx)
       const int j = min(lo, cx.n_ret - 1);
       if (atlas_id < atlas_limit) {
         const uint64_t base = morton3d_add((uint64_t)cell, ~0ull);
-        for (int nn = 0; nn < 27; nn++) {
-          const int64_t nb = (int64_t)morton3d_add(base, kNeigh[nn]);
-          if ((nb >> kAtlasBits) != atlas_id)
-            continue;
-          int r0, r1;
-          retained_cell_range(cx, nb, &r0, &r1);
-          for (int k = r0; k < r1; k++)
-            nn_visit(s, distribution, false, norm1_i3(bp, &cx.bpos[3 * (size_t)cx.retained[k]]), k);
+        // the 27 neighbour cells, nine lower_bound searches in lock step at a
+        // time over the keys of the retained list (one load per probe, the
+        // nine probes of a step in flight together); cells are visited in the
+        // reference's order afterwards
+#pragma unroll
+        for (int nb0 = 0; nb0 < 27; nb0 += 9) {
+          int lo9[9], hi9[9];
+          int64_t want9[9];
+#pragma unroll
+          for (int u = 0; u < 9; u++) {
+            want9[u] = (int64_t)morton3d_add(base, kNeigh[nb0 + u]);
+            lo9[u] = 0;
+            hi9[u] = (want9[u] >> kAtlasBits) == atlas_id ? cx.n_ret : 0;
+          }
+          for (;;) {
+            bool active = false;
+#pragma unroll
+            for (int u = 0; u < 9; u++)
+              active |= lo9[u] < hi9[u];
+            if (!active)
+              break;
+            int64_t kv[9];
+#pragma unroll
+            for (int u = 0; u < 9; u++)
+              kv[u] = lo9[u] < hi9[u] ? cx.ret_key[lo9[u] + ((hi9[u] - lo9[u]) >> 1)] : 0;
+#pragma unroll
+            for (int u = 0; u < 9; u++)
+              if (lo9[u] < hi9[u]) {
+                const int mid = lo9[u] + ((hi9[u] - lo9[u]) >> 1);
+                if (kv[u] < want9[u])
+                  lo9[u] = mid + 1;
+                else
+                  hi9[u] = mid;
+              }
+          }
+#pragma unroll
+          for (int u = 0; u < 9; u++) {
+            if ((want9[u] >> kAtlasBits) != atlas_id)
+              continue;
+            for (int k = lo9[u]; k < cx.n_ret && cx.ret_key[k] == want9[u]; k++)
+              nn_visit(s, distribution, false, norm1_i3(bp, &cx.bpos[3 * (size_t)cx.retained[k]]), k);
+          }
         }
       }
       if (s.idx[2] == -1) {
