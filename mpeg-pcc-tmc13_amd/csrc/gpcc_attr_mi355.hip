@@ -1366,18 +1366,27 @@ gpcc_lod_build(
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
 
-  std::vector<void*> allocs;
+  // Workspace from the context's arena (no allocation per call once it has
+  // grown).  The Morton sort below carves its own scratch from the arena's
+  // start; everything that has to outlive it is placed behind that region.
+  const size_t sort_region = 32 * (size_t)n + ((size_t)1 << 20);
+  {
+    // 26 arrays, the largest 24 B per point (see the DM list below)
+    const size_t mine = (size_t)n * 232 + 64 * 1024;
+    int rc0 = ensure_arena(ctx, sort_region + mine);
+    if (rc0)
+      return rc0;
+  }
+  size_t ar_used = sort_region;
   auto dmalloc = [&](size_t bytes) -> void* {
-    void* p = nullptr;
-    if (hipMalloc(&p, std::max<size_t>(bytes, 256)) != hipSuccess)
+    const size_t b = (std::max<size_t>(bytes, 256) + 255) & ~size_t(255);
+    if (ar_used + b > ctx->arena.cap)
       return nullptr;
-    allocs.push_back(p);
+    void* p = ctx->arena.base + ar_used;
+    ar_used += b;
     return p;
   };
-  auto cleanup = [&]() {
-    for (void* p : allocs)
-      hipFree(p);
-  };
+  auto cleanup = [&]() {};
   auto run = [&]() -> int {
     const size_t N = (size_t)n;
     const int nb0 = (n + 31) >> 5, nb1 = (nb0 + 31) >> 5, nb2 = (nb1 + 31) >> 5;
