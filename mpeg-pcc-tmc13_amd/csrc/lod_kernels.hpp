@@ -394,6 +394,37 @@ lod_subsample_distance_kernel(LodCtx cx)
         cpz[u] = cx.pos[3 * (size_t)idx + 2];
       }
     }
+    // A neighbour cell none of whose voxels lies within the radius of ANY
+    // point of this cell cannot influence it, wherever its retained point
+    // is: drop it from the dependency set (shortens the chains; exact).
+    if (live && pend && t1 - t0 <= kCellCache) {
+      const int sh = cx.shift3 / 3;  // cell edge 2^sh
+      const int32_t edge = 1 << sh;
+      const int32_t ox = (cpx[0] >> sh) << sh, oy = (cpy[0] >> sh) << sh, oz = (cpz[0] >> sh) << sh;
+#pragma unroll
+      for (int k = 0; k < 19; k++) {
+        if (!((pend >> k) & 1))
+          continue;
+        // kOff = Morton code of (dx+1, dy+1, dz+1); x is the top bit of a triple
+        const int off = kOff[k];
+        const int dx = ((off >> 2) & 1) + 2 * ((off >> 5) & 1) - 1;
+        const int dy = ((off >> 1) & 1) + 2 * ((off >> 4) & 1) - 1;
+        const int dz = (off & 1) + 2 * ((off >> 3) & 1) - 1;
+        const int32_t lx = ox + dx * edge, ly = oy + dy * edge, lz = oz + dz * edge;
+        bool reach = false;
+#pragma unroll
+        for (int u = 0; u < kCellCache; u++) {
+          if (t0 + u >= t1)
+            continue;
+          const int64_t gx = max(max(lx - cpx[u], cpx[u] - (lx + edge - 1)), 0);
+          const int64_t gy = max(max(ly - cpy[u], cpy[u] - (ly + edge - 1)), 0);
+          const int64_t gz = max(max(lz - cpz[u], cpz[u] - (lz + edge - 1)), 0);
+          reach |= gx * gx + gy * gy + gz * gz <= cx.radius2;
+        }
+        if (!reach)
+          pend &= ~(1u << k);
+      }
+    }
     int nr = 0;  // retained neighbour points received so far (rows of nbr)
     bool pending = live;
     unsigned spins = 0;
