@@ -394,10 +394,18 @@ lod_subsample_distance_kernel(LodCtx cx)
         cpz[u] = cx.pos[3 * (size_t)idx + 2];
       }
     }
-    // A neighbour cell none of whose voxels lies within the radius of ANY
-    // point of this cell cannot influence it, wherever its retained point
-    // is: drop it from the dependency set (shortens the chains; exact).
-    if (live && pend && t1 - t0 <= kCellCache) {
+    // Which neighbour cells can matter to which point: a cell none of whose
+    // voxels lies within the radius of a point cannot eliminate it, wherever
+    // its retained point is (exact).  The points are examined in order and
+    // the first one that survives is retained, so point u is decidable as
+    // soon as the cells that can reach IT have arrived; cells that reach no
+    // point at all are dropped from the dependency set.  Shortens the chains.
+    const bool small_cell = t1 - t0 <= kCellCache;
+    uint32_t rm[kCellCache];
+#pragma unroll
+    for (int u = 0; u < kCellCache; u++)
+      rm[u] = 0;
+    if (live && pend && small_cell) {
       const int sh = cx.shift3 / 3;  // cell edge 2^sh
       const int32_t edge = 1 << sh;
       const int32_t ox = (cpx[0] >> sh) << sh, oy = (cpy[0] >> sh) << sh, oz = (cpz[0] >> sh) << sh;
@@ -419,12 +427,16 @@ lod_subsample_distance_kernel(LodCtx cx)
           const int64_t gx = max(max(lx - cpx[u], cpx[u] - (lx + edge - 1)), 0);
           const int64_t gy = max(max(ly - cpy[u], cpy[u] - (ly + edge - 1)), 0);
           const int64_t gz = max(max(lz - cpz[u], cpz[u] - (lz + edge - 1)), 0);
-          reach |= gx * gx + gy * gy + gz * gz <= cx.radius2;
+          if (gx * gx + gy * gy + gz * gz <= cx.radius2) {
+            rm[u] |= 1u << k;
+            reach = true;
+          }
         }
         if (!reach)
           pend &= ~(1u << k);
       }
     }
+    int ucur = 0;  // small cells: first point not yet decided
     int nr = 0;  // retained neighbour points received so far (rows of nbr)
     bool pending = live;
     unsigned spins = 0;
@@ -455,7 +467,51 @@ lod_subsample_distance_kernel(LodCtx cx)
           }
         }
       }
-      const bool ready = pending && pend == 0;
+      // ---- decide as far as the arrived neighbours allow -----------------
+      int kept = -1;
+      int32_t kp[3] = {0, 0, 0};
+      bool decided = false;
+      auto eliminated = [&](int32_t px, int32_t py, int32_t pz) -> bool {
+        bool found = false;
+        if (small) {
+          // neighbours lie in adjacent cells: |d| < 2^14, squares fit 32 bits
+          for (int q = 0; q < nr && !found; q++) {
+            const int32_t dx = nbr[3 * q][lane] - px, dy = nbr[3 * q + 1][lane] - py,
+                          dz = nbr[3 * q + 2][lane] - pz;
+            found = (int64_t)(dx * dx + dy * dy + dz * dz) <= cx.radius2;
+          }
+        } else {
+          for (int q = 0; q < nr && !found; q++) {
+            const int64_t dx = (int64_t)nbr[3 * q][lane] - px, dy = (int64_t)nbr[3 * q + 1][lane] - py,
+                          dz = (int64_t)nbr[3 * q + 2][lane] - pz;
+            found = dx * dx + dy * dy + dz * dz <= cx.radius2;
+          }
+        }
+        return found;
+      };
+      if (pending && small_cell) {
+        bool blocked = false;
+#pragma unroll
+        for (int u = 0; u < kCellCache; u++) {
+          if (decided || blocked || u != ucur || t0 + u >= t1)
+            continue;
+          if (rm[u] & pend) {
+            blocked = true;  // a cell that can reach this point is still out
+          } else if (!eliminated(cpx[u], cpy[u], cpz[u])) {
+            kept = cidx[u];
+            kp[0] = cpx[u];
+            kp[1] = cpy[u];
+            kp[2] = cpz[u];
+            cx.flags[t0 + u] = 1;
+            decided = true;
+          } else {
+            ucur++;
+          }
+        }
+        if (!decided && !blocked && t0 + ucur >= t1)
+          decided = true;  // every point eliminated: nothing retained
+      }
+      const bool ready = pending && (small_cell ? decided : pend == 0);
       if (!__any(ready)) {
         if (++spins > (1u << 20)) {
           if (lane == 0)
@@ -465,30 +521,13 @@ lod_subsample_distance_kernel(LodCtx cx)
         __builtin_amdgcn_s_sleep(1);
         continue;
       }
-      int kept = -1;
-      int32_t kp[3] = {0, 0, 0};
-      if (ready) {
+      if (ready && !small_cell) {
         // the first points of the cell were fetched before the wait
 #pragma unroll
         for (int u = 0; u < kCellCache; u++) {
           if (kept >= 0 || t0 + u >= t1)
             continue;
-          bool found = false;
-          if (small) {
-            // neighbours lie in adjacent cells: |d| < 2^14, squares fit 32 bits
-            for (int q = 0; q < nr && !found; q++) {
-              const int32_t dx = nbr[3 * q][lane] - cpx[u], dy = nbr[3 * q + 1][lane] - cpy[u],
-                            dz = nbr[3 * q + 2][lane] - cpz[u];
-              found = (int64_t)(dx * dx + dy * dy + dz * dz) <= cx.radius2;
-            }
-          } else {
-            for (int q = 0; q < nr && !found; q++) {
-              const int64_t dx = (int64_t)nbr[3 * q][lane] - cpx[u], dy = (int64_t)nbr[3 * q + 1][lane] - cpy[u],
-                            dz = (int64_t)nbr[3 * q + 2][lane] - cpz[u];
-              found = dx * dx + dy * dy + dz * dz <= cx.radius2;
-            }
-          }
-          if (!found) {
+          if (!eliminated(cpx[u], cpy[u], cpz[u])) {
             kept = cidx[u];
             kp[0] = cpx[u];
             kp[1] = cpy[u];
