@@ -219,10 +219,8 @@ int gpcc_lift_inverse(
 
 /* Flattened LoD-generation parameters: the AttributeParameterSet fields
  * buildPredictorsFast reads (hls.h:782-876) plus
- * AttributeBrickHeader::attr_dist2_delta.  The LoD structure itself
- * (sub-sampling + neighbour search, PCCTMC3Common.h:1147-2469) is still
- * built by the reference's AttributeLods::generate on the host this round;
- * the struct is the parameter block of that call for tests and tools. */
+ * AttributeBrickHeader::attr_dist2_delta: the parameter block of
+ * gpcc_lod_build below. */
 typedef struct gpcc_lod_params {
   int32_t attr_encoding;           /* 1 predicting, 2 lifting */
   int32_t lod_decimation_type;     /* LodDecimationMethod */
@@ -251,9 +249,10 @@ typedef struct gpcc_lod_params {
  *   neigh_count [n], neigh_index [n][3] (predictor indices), neigh_weight
  *   [n][3] (8-bit weights), indexes [n] (predictor -> point index),
  *   num_points_in_lod [GPCC_MAX_LODS] cumulative, *num_lods.
- * Sub-sampling by distance (lod_decimation_type 0) and periodic (1) run on
- * the device; centroid decimation (2), scalable lifting, canonical point
- * order and inter prediction return GPCC_ERR_UNSUPPORTED. */
+ * All three decimators (lod_decimation_type 0 distance, 1 periodic, 2
+ * centroid) and, for the predicting transform, blendWeights run on the
+ * device; scalable lifting, canonical point order and inter prediction
+ * return GPCC_ERR_UNSUPPORTED (the shim keeps them on the reference path). */
 int gpcc_lod_build(
   gpcc_ctx* ctx, const gpcc_lod_params* params, const int32_t* xyz, int32_t n,
   int32_t* neigh_count, int32_t* neigh_index, int32_t* neigh_weight,
