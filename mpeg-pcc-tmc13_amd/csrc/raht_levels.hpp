@@ -379,8 +379,11 @@ raht_level_prepass_kernel(LevelCtx ctx)
 // The block kernels are bound by dependent-load latency (rocprofv3: VALU
 // active 12 % of wave cycles), so residency is bought with registers:
 // GPCC_LEVEL_WAVES waves per SIMD (see DESIGN.md for the measured sweep).
+// (measured on 1M lidar / dense, forward+inverse: 4 waves 4.90 / 3.33 ms,
+// 5 waves 4.59 / 3.20 ms -- the C=1 kernels need 98-104 registers -- 6 and 8
+// waves spill and lose)
 #ifndef GPCC_LEVEL_WAVES
-#define GPCC_LEVEL_WAVES 4
+#define GPCC_LEVEL_WAVES 5
 #endif
 template<int C, int MODE>
 __global__ __launch_bounds__(256, GPCC_LEVEL_WAVES) void

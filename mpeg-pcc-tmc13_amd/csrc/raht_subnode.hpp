@@ -66,8 +66,15 @@ store_agent_i64(int64_t* p, int64_t v)
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// The lossy encoder needs more live state than 128 registers hold (83 spilled
+// VGPRs at 4 waves/SIMD); the kernel is bound by its dependency chains, not
+// by occupancy, so it trades a wave for registers: 1M dense C=3 forward
+// 46.2 -> 32.7 ms, 1M lidar 15.1 -> 14.6 ms (2 waves: 34.3 / 15.1).
+#ifndef GPCC_SUB_SYNTH3_WAVES
+#define GPCC_SUB_SYNTH3_WAVES 4
+#endif
 template<int C, int MODE>
-__global__ __launch_bounds__(256, 4) void
+__global__ __launch_bounds__(256, MODE == kLossySub ? 3 : (C == 3 ? GPCC_SUB_SYNTH3_WAVES : 4)) void
 raht_level_sub_kernel(LevelCtx ctx)
 {
   static_assert(MODE == kSynth || MODE == kFused || MODE == kLossySub, "mode");
