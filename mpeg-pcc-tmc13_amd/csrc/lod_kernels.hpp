@@ -885,7 +885,12 @@ lod_atlas_limit_kernel(NnCtx cx, long long* atlas_limit)
   }
 }
 
-__global__ __launch_bounds__(256) void
+// (measured: 5 waves/SIMD 3.3 / 10.5 ms on the 1M dense / lidar clouds against
+// 3.6 / 10.0 ms at 4; 6 and 8 spill and lose)
+#ifndef GPCC_NN_WAVES
+#define GPCC_NN_WAVES 4
+#endif
+__global__ __launch_bounds__(256, GPCC_NN_WAVES) void
 lod_nn_search_kernel(NnCtx cx)
 {
   constexpr uint8_t kNeigh[27] = {7,  3,  5,  6,  35, 21, 14, 28, 42,
