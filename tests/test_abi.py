@@ -59,3 +59,31 @@ def test_no_device_fails_loudly(lib):
     rc = lib.gpcc_ctx_create(0, None, C.byref(h))
     assert rc == -3 and not h.value
     assert b"device" in lib.gpcc_last_error().lower()
+
+
+def test_null_context_is_rejected_everywhere(lib):
+    """Every compute entry refuses a null context with GPCC_ERR_INVALID_ARG
+    (and says why) before touching any buffer -- CPU box included."""
+    from mpeg_pcc_tmc13_amd import LiftParams, LodParams, RahtParams
+    rp, lp, lf = RahtParams(), LodParams(), LiftParams()
+    z = None
+    off = (C.c_int64 * 2)(0, 1)
+    out = C.c_int32()
+    calls = [
+        lambda: lib.gpcc_raht_forward(z, C.byref(rp), z, z, z, z, 1, 1),
+        lambda: lib.gpcc_raht_inverse(z, C.byref(rp), z, z, z, z, 1, 1),
+        lambda: lib.gpcc_attr_morton_sort(z, z, 1, z, z),
+        lambda: lib.gpcc_dev_raht_forward(z, C.byref(rp), 1, off, z, z, z, z, 1),
+        lambda: lib.gpcc_dev_raht_inverse(z, C.byref(rp), 1, off, z, z, z, z, 1),
+        lambda: lib.gpcc_dev_attr_morton_sort(z, 1, off, z, z, z),
+        lambda: lib.gpcc_lift_forward(z, C.byref(lf), 1, 1, z, z, z, z, z, z, z, z),
+        lambda: lib.gpcc_lift_inverse(z, C.byref(lf), 1, 1, z, z, z, z, z, z, z, z),
+        lambda: lib.gpcc_lod_compute_weights(z, 1, z, z, z),
+        lambda: lib.gpcc_lod_build(z, C.byref(lp), z, 1, z, z, z, z, z, C.byref(out)),
+        lambda: lib.gpcc_estimate_dist2(z, z, 1, 100, 128, C.c_float(0.85), C.byref(out)),
+        lambda: lib.gpcc_raht_encode_attr(z, C.byref(rp), z, z, z, 1, 1, 8),
+        lambda: lib.gpcc_raht_decode_attr(z, C.byref(rp), z, z, z, 1, 1, 8),
+    ]
+    for i, f in enumerate(calls):
+        assert f() == -1, f"entry {i}"
+        assert lib.gpcc_last_error()
