@@ -300,6 +300,32 @@ int gpcc_raht_decode_attr(
   gpcc_ctx* ctx, const gpcc_raht_params* params, const int32_t* xyz,
   int32_t* attrs, const int32_t* coeffs, int32_t n, int32_t c, int32_t bitdepth);
 
+/* The lifting attribute coder of one slice minus the entropy loop: what
+ * AttributeEncoder::encode does for AttributeEncoding::kLiftingTransform --
+ * AttributeLods::generate (AttributeEncoder.cpp:575-579) followed by
+ * encodeColorsLift / encodeReflectancesLift (:1379-1648) -- resp.
+ * AttributeDecoder::decode (AttributeDecoder.cpp:292-296, 678-857), in one
+ * call: the LoD structure is built and consumed on the device and never
+ * crosses PCIe.
+ *   lod     LoD parameters (as for gpcc_lod_build)
+ *   lift    in: QP layers, bit depth, last_component_prediction flag;
+ *           out: num_lods / num_points_in_lod of the structure that was built
+ *   xyz     [n][3] positions, point order
+ *   attrs   [n][c] point order; encode in: source, out: clipped
+ *           reconstruction; decode out: clipped reconstruction
+ *   coeffs  [n][c] coding order (what the entropy loop codes / decoded)
+ *   lcp_coeffs [GPCC_MAX_LODS] last-component prediction coefficients
+ *   indexes [n] out, may be NULL: predictor -> point index (coding order)
+ */
+int gpcc_lift_encode_attr(
+  gpcc_ctx* ctx, const gpcc_lod_params* lod, gpcc_lift_params* lift,
+  const int32_t* xyz, int32_t* attrs, int32_t* coeffs, int8_t* lcp_coeffs,
+  int32_t* indexes, int32_t n, int32_t c);
+int gpcc_lift_decode_attr(
+  gpcc_ctx* ctx, const gpcc_lod_params* lod, gpcc_lift_params* lift,
+  const int32_t* xyz, int32_t* attrs, const int32_t* coeffs,
+  const int8_t* lcp_coeffs, int32_t* indexes, int32_t n, int32_t c);
+
 /* estimateDist2 (tmc3/AttributeEncoder.cpp:1684-1720, called from
  * tmc3/encoder.cpp:1203 to derive attr_dist2_delta): for every
  * sampling_period-th point of xyz[n][3] (coded order) the squared distance to

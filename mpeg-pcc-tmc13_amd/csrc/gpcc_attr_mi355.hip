@@ -1337,16 +1337,31 @@ gpcc_lod_compute_weights(
   return GPCC_OK;
 }
 
+}  // extern "C"
+
+namespace {
+
+// what the LoD build leaves on the device (valid until the arena is used again)
+struct LodDeviceOut {
+  int32_t* count = nullptr;        // [n]
+  int32_t* neigh_index = nullptr;  // [n][3] predictor indices
+  int32_t* weight = nullptr;       // [n][3]
+  int32_t* indexes = nullptr;      // [n] predictor -> point
+  int32_t* error = nullptr;        // device error word of the sub-sampling kernel
+  std::vector<int32_t> npl;        // cumulative LoD sizes, coarse to fine
+  size_t arena_end = 0;            // first free byte behind the build's workspace
+};
+
+// AttributeLods::generate on the device; results stay there.  `extra_bytes`
+// are reserved behind the workspace for the caller (same arena, no regrowth).
 int
-gpcc_lod_build(
+lod_build_core(
   gpcc_ctx* ctx, const gpcc_lod_params* lp, const int32_t* xyz, int32_t n,
-  int32_t* neigh_count, int32_t* neigh_index, int32_t* neigh_weight,
-  int32_t* indexes, int32_t* num_points_in_lod, int32_t* num_lods)
+  size_t extra_bytes, LodDeviceOut* out)
 {
   if (!ctx)
     return fail(GPCC_ERR_INVALID_ARG, "ctx is null");
-  if (!lp || !xyz || n <= 0 || !neigh_count || !neigh_index || !neigh_weight
-      || !indexes || !num_points_in_lod || !num_lods)
+  if (!lp || !xyz || n <= 0)
     return fail(GPCC_ERR_INVALID_ARG, "null buffer or n <= 0");
   if (lp->scalable_lifting_enabled_flag || lp->canonical_point_order_flag
       || lp->max_points_per_sort_log2_plus1 || lp->lod_decimation_type < 0
@@ -1373,7 +1388,7 @@ gpcc_lod_build(
   {
     // 26 arrays, the largest 24 B per point (see the DM list below)
     const size_t mine = (size_t)n * 232 + 64 * 1024;
-    int rc0 = ensure_arena(ctx, sort_region + mine);
+    int rc0 = ensure_arena(ctx, sort_region + mine + extra_bytes);
     if (rc0)
       return rc0;
   }
@@ -1652,24 +1667,144 @@ gpcc_lod_build(
       lod_blend_weights_kernel<<<grid_for(n, 256), 256, 0, st>>>(
         n, d_pred_count, d_pred_point, d_xyz, d_weight);
     HIP_TRY(hipGetLastError());
-    int32_t h_err = 0;
-    HIP_TRY(hipMemcpyAsync(neigh_count, d_pred_count, sizeof(int32_t) * N, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(neigh_index, d_neigh_index, sizeof(int32_t) * 3 * N, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(neigh_weight, d_weight, sizeof(int32_t) * 3 * N, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(indexes, d_indexes, sizeof(int32_t) * N, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(&h_err, d_error, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    if (h_err)
-      return fail(GPCC_ERR_HIP, "a dependency wait in the LoD sub-sampling kernel expired");
-    *num_lods = (int)npl.size();
-    for (size_t i = 0; i < npl.size(); i++)
-      num_points_in_lod[i] = npl[npl.size() - 1 - i];
+    out->count = d_pred_count;
+    out->neigh_index = d_neigh_index;
+    out->weight = d_weight;
+    out->indexes = d_indexes;
+    out->error = d_error;
+    out->npl.assign(npl.rbegin(), npl.rend());
+    out->arena_end = ar_used;
     return GPCC_OK;
   };
-  int r = run();
-  hipStreamSynchronize(st);
-  cleanup();
-  return r;
+  return run();
+}
+
+}  // namespace
+
+extern "C" {
+
+int
+gpcc_lod_build(
+  gpcc_ctx* ctx, const gpcc_lod_params* lp, const int32_t* xyz, int32_t n,
+  int32_t* neigh_count, int32_t* neigh_index, int32_t* neigh_weight,
+  int32_t* indexes, int32_t* num_points_in_lod, int32_t* num_lods)
+{
+  if (!neigh_count || !neigh_index || !neigh_weight || !indexes || !num_points_in_lod || !num_lods)
+    return fail(GPCC_ERR_INVALID_ARG, "null output buffer");
+  LodDeviceOut o;
+  int r = lod_build_core(ctx, lp, xyz, n, 0, &o);
+  if (r)
+    return r;
+  hipStream_t st = ctx->stream;
+  const size_t N = (size_t)n;
+  int32_t h_err = 0;
+  HIP_TRY(hipMemcpyAsync(neigh_count, o.count, sizeof(int32_t) * N, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(neigh_index, o.neigh_index, sizeof(int32_t) * 3 * N, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(neigh_weight, o.weight, sizeof(int32_t) * 3 * N, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(indexes, o.indexes, sizeof(int32_t) * N, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(&h_err, o.error, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (h_err)
+    return fail(GPCC_ERR_HIP, "a dependency wait in the LoD sub-sampling kernel expired");
+  *num_lods = (int)o.npl.size();
+  for (size_t i = 0; i < o.npl.size(); i++)
+    num_points_in_lod[i] = o.npl[i];
+  return GPCC_OK;
+}
+
+// The lifting attribute coder of one slice minus the entropy loop --
+// AttributeLods::generate + encodeColorsLift / encodeReflectancesLift
+// (AttributeEncoder.cpp:575-579, 1379-1648) resp. decode...Lift
+// (AttributeDecoder.cpp:292-296, 678-857): the predictors never leave the
+// device.
+static int
+lift_attr_driver(
+  gpcc_ctx* ctx, bool encoder, const gpcc_lod_params* lod, gpcc_lift_params* lift,
+  const int32_t* xyz, int32_t* attrs, int32_t* coeffs, int8_t* lcp, int32_t* indexes,
+  int32_t n, int32_t c)
+{
+  if (!ctx)
+    return fail(GPCC_ERR_INVALID_ARG, "ctx is null");
+  if (!lift || !attrs || !coeffs || c < 1 || c > 3)
+    return fail(GPCC_ERR_INVALID_ARG, "null buffer or attribute count not 1..3");
+  const bool lcp_on = c == 3 && lift->last_component_prediction_enabled_flag;
+  if (lcp_on && !lcp)
+    return fail(GPCC_ERR_INVALID_ARG, "lcp_coeffs is null");
+  const size_t N = (size_t)(n > 0 ? n : 0);
+  const size_t extra = ((N * c * sizeof(int32_t) + 255) & ~size_t(255)) * 2 + 256
+    + lift_scratch_bytes(n > 0 ? n : 1, c) + 1024;
+  LodDeviceOut o;
+  int r = lod_build_core(ctx, lod, xyz, n, extra, &o);
+  if (r)
+    return r;
+  lift->num_lods = (int)o.npl.size();
+  for (size_t i = 0; i < o.npl.size(); i++)
+    lift->num_points_in_lod[i] = o.npl[i];
+  r = check_lift_params(lift, n, c);
+  if (r)
+    return r;
+  hipStream_t st = ctx->stream;
+  Arena ar = ctx->arena;  // carve behind the LoD workspace
+  ar.used = o.arena_end;
+  LiftDev d{};
+  d.nc = o.count;
+  d.ni = o.neigh_index;
+  d.nw = o.weight;
+  d.indexes = o.indexes;
+  d.qp_off = nullptr;
+  d.attrs = ar.take<int32_t>(N * c);
+  d.coeffs = ar.take<int32_t>(N * c);
+  int8_t* d_lcp = ar.take<int8_t>(GPCC_MAX_LODS);
+  char* scratch = ar.base + ar.used;
+  if (ar.used + lift_scratch_bytes(n, c) > ctx->arena.cap)
+    return fail(GPCC_ERR_OUT_OF_MEMORY, "arena reservation too small");
+  if (encoder) {
+    HIP_TRY(hipMemcpyAsync(d.attrs, attrs, sizeof(int32_t) * N * c, hipMemcpyHostToDevice, st));
+  } else {
+    HIP_TRY(hipMemcpyAsync(d.coeffs, coeffs, sizeof(int32_t) * N * c, hipMemcpyHostToDevice, st));
+    if (lcp_on)
+      HIP_TRY(hipMemcpyAsync(d_lcp, lcp, GPCC_MAX_LODS, hipMemcpyHostToDevice, st));
+  }
+  switch (c) {
+  case 1: r = launch_lift<1>(ctx, encoder, lift, n, d, d_lcp, scratch); break;
+  case 2: r = launch_lift<2>(ctx, encoder, lift, n, d, d_lcp, scratch); break;
+  default: r = launch_lift<3>(ctx, encoder, lift, n, d, d_lcp, scratch); break;
+  }
+  if (r)
+    return r;
+  int32_t h_err = 0;
+  HIP_TRY(hipMemcpyAsync(attrs, d.attrs, sizeof(int32_t) * N * c, hipMemcpyDeviceToHost, st));
+  if (encoder) {
+    HIP_TRY(hipMemcpyAsync(coeffs, d.coeffs, sizeof(int32_t) * N * c, hipMemcpyDeviceToHost, st));
+    if (lcp_on)
+      HIP_TRY(hipMemcpyAsync(lcp, d_lcp, GPCC_MAX_LODS, hipMemcpyDeviceToHost, st));
+  }
+  if (indexes)
+    HIP_TRY(hipMemcpyAsync(indexes, o.indexes, sizeof(int32_t) * N, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(&h_err, o.error, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (h_err)
+    return fail(GPCC_ERR_HIP, "a dependency wait in the LoD sub-sampling kernel expired");
+  return GPCC_OK;
+}
+
+int
+gpcc_lift_encode_attr(
+  gpcc_ctx* ctx, const gpcc_lod_params* lod, gpcc_lift_params* lift, const int32_t* xyz,
+  int32_t* attrs, int32_t* coeffs, int8_t* lcp_coeffs, int32_t* indexes, int32_t n, int32_t c)
+{
+  return lift_attr_driver(ctx, true, lod, lift, xyz, attrs, coeffs, lcp_coeffs, indexes, n, c);
+}
+
+int
+gpcc_lift_decode_attr(
+  gpcc_ctx* ctx, const gpcc_lod_params* lod, gpcc_lift_params* lift, const int32_t* xyz,
+  int32_t* attrs, const int32_t* coeffs, const int8_t* lcp_coeffs, int32_t* indexes, int32_t n,
+  int32_t c)
+{
+  return lift_attr_driver(
+    ctx, false, lod, lift, xyz, attrs, const_cast<int32_t*>(coeffs),
+    const_cast<int8_t*>(lcp_coeffs), indexes, n, c);
 }
 
 namespace {

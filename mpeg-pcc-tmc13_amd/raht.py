@@ -188,3 +188,31 @@ class Context:
         _lib.check(self._lib.gpcc_raht_decode_attr(self._h, C.byref(params), xyz.ctypes.data, a.ctypes.data,
                                                    co.ctypes.data, n, c, bitdepth))
         return a
+
+    # ---- lifting coder of one slice: LoD build + transform, predictors stay on the device ----
+    def lift_encode_attr(self, lod_params, lift_params, xyz, attrs):
+        """AttributeLods::generate + encode{Colors,Reflectances}Lift minus the entropy loop ->
+        (coeffs [n,c] coding order, clipped recon [n,c] point order, lcp int8[32], indexes [n]);
+        lift_params.num_lods / num_points_in_lod are filled in."""
+        xyz = np.ascontiguousarray(xyz, dtype=np.int32)
+        a = np.ascontiguousarray(attrs, dtype=np.int32).copy()
+        n, c = a.shape
+        co = np.zeros((n, c), dtype=np.int32)
+        lcp = np.zeros(32, dtype=np.int8)
+        idx = np.zeros(n, dtype=np.int32)
+        _lib.check(self._lib.gpcc_lift_encode_attr(self._h, C.byref(lod_params), C.byref(lift_params),
+                                                   xyz.ctypes.data, a.ctypes.data, co.ctypes.data,
+                                                   lcp.ctypes.data, idx.ctypes.data, n, c))
+        return co, a, lcp, idx
+
+    def lift_decode_attr(self, lod_params, lift_params, xyz, coeffs, lcp=None):
+        """AttributeLods::generate + decode{Colors,Reflectances}Lift after the entropy decode -> recon [n,c]"""
+        xyz = np.ascontiguousarray(xyz, dtype=np.int32)
+        co = np.ascontiguousarray(coeffs, dtype=np.int32)
+        n, c = co.shape
+        a = np.zeros((n, c), dtype=np.int32)
+        l = np.zeros(32, dtype=np.int8) if lcp is None else np.ascontiguousarray(lcp, dtype=np.int8).copy()
+        _lib.check(self._lib.gpcc_lift_decode_attr(self._h, C.byref(lod_params), C.byref(lift_params),
+                                                   xyz.ctypes.data, a.ctypes.data, co.ctypes.data,
+                                                   l.ctypes.data, None, n, c))
+        return a

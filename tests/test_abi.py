@@ -83,6 +83,8 @@ def test_null_context_is_rejected_everywhere(lib):
         lambda: lib.gpcc_estimate_dist2(z, z, 1, 100, 128, C.c_float(0.85), C.byref(out)),
         lambda: lib.gpcc_raht_encode_attr(z, C.byref(rp), z, z, z, 1, 1, 8),
         lambda: lib.gpcc_raht_decode_attr(z, C.byref(rp), z, z, z, 1, 1, 8),
+        lambda: lib.gpcc_lift_encode_attr(z, C.byref(lp), C.byref(lf), z, z, z, z, z, 1, 1),
+        lambda: lib.gpcc_lift_decode_attr(z, C.byref(lp), C.byref(lf), z, z, z, z, z, 1, 1),
     ]
     for i, f in enumerate(calls):
         assert f() == -1, f"entry {i}"
