@@ -326,6 +326,22 @@ int gpcc_lift_decode_attr(
   const int32_t* xyz, int32_t* attrs, const int32_t* coeffs,
   const int8_t* lcp_coeffs, int32_t* indexes, int32_t n, int32_t c);
 
+/* Zero-run formation of a coefficient stream: the part of the reference's
+ * entropy loops that is not the arithmetic coder (AttributeEncoder.cpp:
+ * 1279-1291 / 1347-1362 RAHT, 1458-1474 / 1617-1633 lifting).  A position
+ * whose c values are all zero extends the current run; any other position
+ * emits (run, values).  The caller then issues
+ *   for k < *num_symbols: encodeRunLength(runs[k]); encode(values[k][0..c));
+ *   if (*trailing_run) encodeRunLength(*trailing_run);
+ * to the reference's PCCResidualsEncoder -- the bitstream is identical
+ * (tests/test_symbols.py) and only the non-zero symbols cross PCIe.
+ *   coeffs  planar != 0: [c][n] (RAHT);  planar == 0: [n][c] (lifting)
+ *   runs    [n] out (num_symbols used), values [n][c] out
+ * Host tier. */
+int gpcc_zero_run_pack(
+  gpcc_ctx* ctx, const int32_t* coeffs, int32_t n, int32_t c, int32_t planar,
+  int32_t* runs, int32_t* values, int32_t* num_symbols, int32_t* trailing_run);
+
 /* estimateDist2 (tmc3/AttributeEncoder.cpp:1684-1720, called from
  * tmc3/encoder.cpp:1203 to derive attr_dist2_delta): for every
  * sampling_period-th point of xyz[n][3] (coded order) the squared distance to

@@ -1905,6 +1905,64 @@ gpcc_raht_decode_attr(
 }
 
 int
+gpcc_zero_run_pack(
+  gpcc_ctx* ctx, const int32_t* coeffs, int32_t n, int32_t c, int32_t planar,
+  int32_t* runs, int32_t* values, int32_t* num_symbols, int32_t* trailing_run)
+{
+  if (!ctx)
+    return fail(GPCC_ERR_INVALID_ARG, "ctx is null");
+  if (!coeffs || !runs || !values || !num_symbols || !trailing_run || n <= 0 || c < 1 || c > 3)
+    return fail(GPCC_ERR_INVALID_ARG, "null buffer, n <= 0 or attribute count not 1..3");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const size_t N = (size_t)n;
+  Arena m;
+  int32_t *d_co, *d_pos, *d_nz, *d_runs, *d_vals, *d_small;
+  uint8_t* d_flags;
+  unsigned long long* d_scan;
+  auto carve = [&](Arena& ar) {
+    ar.reset();
+    d_co = ar.take<int32_t>(N * c);
+    d_pos = ar.take<int32_t>(N);
+    d_nz = ar.take<int32_t>(N + 1);
+    d_runs = ar.take<int32_t>(N);
+    d_vals = ar.take<int32_t>(N * c);
+    d_flags = ar.take<uint8_t>(N);
+    d_small = ar.take<int32_t>(64);
+    d_scan = ar.take<unsigned long long>(1024);
+  };
+  carve(m);
+  int rcode = ensure_arena(ctx, m.used);
+  if (rcode)
+    return rcode;
+  carve(ctx->arena);
+  HIP_TRY(hipMemcpyAsync(d_co, coeffs, sizeof(int32_t) * N * c, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemsetAsync(d_small, 0, sizeof(int32_t) * 64, st));
+  HIP_TRY(hipMemsetAsync(d_scan, 0, sizeof(unsigned long long) * 1024, st));
+  {
+    Timer tm(ctx, "zero_run_pack");
+    zero_run_flags_kernel<<<grid_for(n, 256), 256, 0, st>>>(n, c, planar, d_co, d_flags, d_pos);
+    const int grid = (int)std::min<int64_t>(1024, ((int64_t)n + 1023) / 1024);
+    lod_partition_kernel<<<std::max(grid, 1), 256, 0, st>>>(
+      n, d_flags, d_pos, d_nz, nullptr, d_small, d_scan, 1);
+    zero_run_emit_kernel<<<grid_for(n, 256), 256, 0, st>>>(
+      n, c, planar, d_co, d_nz, d_small, d_runs, d_vals, d_small + 1);
+  }
+  int32_t h[2] = {0, 0};
+  HIP_TRY(hipMemcpyAsync(h, d_small, sizeof(h), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  // only the symbols cross PCIe
+  if (h[0] > 0) {
+    HIP_TRY(hipMemcpyAsync(runs, d_runs, sizeof(int32_t) * (size_t)h[0], hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(values, d_vals, sizeof(int32_t) * (size_t)h[0] * c, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  *num_symbols = h[0];
+  *trailing_run = h[1];
+  return GPCC_OK;
+}
+
+int
 gpcc_estimate_dist2(
   gpcc_ctx* ctx, const int32_t* xyz, int32_t n, int32_t sampling_period,
   int32_t search_range, float percentile, int32_t* shift_bits)

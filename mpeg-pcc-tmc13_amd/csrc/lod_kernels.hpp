@@ -1175,4 +1175,40 @@ estimate_dist2_kernel(
   }
 }
 
+// ---- zero-run formation of a coefficient stream ------------------------------
+// (the non-arithmetic part of the entropy loops, AttributeEncoder.cpp:1279-1291
+// / 1347-1362 RAHT, :1458-1474 / 1617-1633 lifting): a position whose c values
+// are all zero extends the run, any other emits (run, values).  Flags ->
+// stable compaction of the non-zero positions (lod_partition_kernel) -> runs
+// are differences of consecutive positions.
+__global__ __launch_bounds__(256) void
+zero_run_flags_kernel(
+  int n, int c, int planar, const int32_t* __restrict__ coeffs, uint8_t* flags, int32_t* positions)
+{
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    bool any = false;
+    for (int d = 0; d < c; d++)
+      any |= (planar ? coeffs[(size_t)n * d + i] : coeffs[(size_t)i * c + d]) != 0;
+    flags[i] = any;
+    positions[i] = i;
+  }
+}
+
+__global__ __launch_bounds__(256) void
+zero_run_emit_kernel(
+  int n, int c, int planar, const int32_t* __restrict__ coeffs,
+  const int32_t* __restrict__ nzpos, const int32_t* __restrict__ count, int32_t* runs,
+  int32_t* values, int32_t* trailing)
+{
+  const int m = count[0];
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < m; k += gridDim.x * blockDim.x) {
+    const int pos = nzpos[k];
+    runs[k] = pos - (k ? nzpos[k - 1] : -1) - 1;
+    for (int d = 0; d < c; d++)
+      values[(size_t)k * c + d] = planar ? coeffs[(size_t)n * d + pos] : coeffs[(size_t)pos * c + d];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    trailing[0] = m ? n - 1 - nzpos[m - 1] : n;
+}
+
 }  // namespace gpcc

@@ -216,3 +216,13 @@ class Context:
                                                    xyz.ctypes.data, a.ctypes.data, co.ctypes.data,
                                                    l.ctypes.data, None, n, c))
         return a
+
+    def zero_run_pack(self, coeffs, n, c, planar):
+        """zero-run formation of the entropy loops -> (runs [m], values [m,c], trailing_run)"""
+        co = np.ascontiguousarray(coeffs, dtype=np.int32).reshape(-1)
+        runs = np.zeros(n, np.int32)
+        vals = np.zeros(n * c, np.int32)
+        m, tr = C.c_int32(), C.c_int32()
+        _lib.check(self._lib.gpcc_zero_run_pack(self._h, co.ctypes.data, n, c, int(planar), runs.ctypes.data,
+                                                vals.ctypes.data, C.byref(m), C.byref(tr)))
+        return runs[:m.value].copy(), vals[:m.value * c].reshape(m.value, c).copy(), tr.value

@@ -98,3 +98,45 @@ def ref_estimate_dist2(xyz, period=100, search_range=128, percentile=0.85):
     xyz = np.ascontiguousarray(xyz, dtype=np.int32)
     lib.ref_estimate_dist2.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float]
     return lib.ref_estimate_dist2(xyz.ctypes.data, xyz.shape[0], period, search_range, C.c_float(percentile))
+
+
+def ref_last_abh_size():
+    """size of the brick header at the start of the last ref_operator_roundtrip payload"""
+    return ol.ref().lib.ref_last_abh_size()
+
+
+def oracle_zero_run_pack(coeffs, n, c, planar):
+    """-> (runs [m], values [m, c], trailing_run)"""
+    lib = ol.oracle().lib
+    co = np.ascontiguousarray(coeffs, dtype=np.int32).reshape(-1)
+    runs = np.zeros(n, np.int32)
+    vals = np.zeros(n * c, np.int32)
+    tr = C.c_int32()
+    lib.oracle_zero_run_pack.argtypes = [i32p, C.c_int32, C.c_int32, C.c_int32, i32p, i32p, C.POINTER(C.c_int32)]
+    m = lib.oracle_zero_run_pack(co, n, c, int(planar), runs, vals, C.byref(tr))
+    return runs[:m].copy(), vals[:m * c].reshape(m, c).copy(), tr.value
+
+
+_entropy = {}
+
+
+def entropy_available():
+    import os
+    return os.path.exists(os.path.join(ol.ORACLE_DIR, "_ref", "libtmc3_entropy.so"))
+
+
+def ref_entropy_encode_symbols(c, num_points, runs, values, trailing):
+    """the reference's own PCCResidualsEncoder on a symbol stream -> arithmetic-coded bytes"""
+    import os
+    if "lib" not in _entropy:
+        _entropy["lib"] = C.CDLL(os.path.join(ol.ORACLE_DIR, "_ref", "libtmc3_entropy.so"))
+    lib = _entropy["lib"]
+    runs = np.ascontiguousarray(runs, dtype=np.int32)
+    values = np.ascontiguousarray(values, dtype=np.int32).reshape(-1)
+    out = np.zeros(num_points * 3 * 2 + 2048, np.uint8)
+    lib.ref_entropy_encode_symbols.argtypes = [C.c_int32, C.c_int32, i32p, i32p, C.c_int32, C.c_int32, u8p, C.c_int32]
+    ln = lib.ref_entropy_encode_symbols(c, num_points, runs if len(runs) else np.zeros(1, np.int32),
+                                        values if len(values) else np.zeros(1, np.int32), len(runs), trailing,
+                                        out, out.size)
+    assert ln >= 0
+    return out[:ln].tobytes()

@@ -85,6 +85,7 @@ def test_null_context_is_rejected_everywhere(lib):
         lambda: lib.gpcc_raht_decode_attr(z, C.byref(rp), z, z, z, 1, 1, 8),
         lambda: lib.gpcc_lift_encode_attr(z, C.byref(lp), C.byref(lf), z, z, z, z, z, 1, 1),
         lambda: lib.gpcc_lift_decode_attr(z, C.byref(lp), C.byref(lf), z, z, z, z, z, 1, 1),
+        lambda: lib.gpcc_zero_run_pack(z, z, 1, 1, 1, z, z, C.byref(out), C.byref(out)),
     ]
     for i, f in enumerate(calls):
         assert f() == -1, f"entry {i}"
