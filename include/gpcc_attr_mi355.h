@@ -326,6 +326,15 @@ int gpcc_lift_decode_attr(
   const int32_t* xyz, int32_t* attrs, const int32_t* coeffs,
   const int8_t* lcp_coeffs, int32_t* indexes, int32_t n, int32_t c);
 
+/* gpcc_raht_encode_attr whose result is the symbol stream of the entropy
+ * loop (see gpcc_zero_run_pack) instead of the coefficient array: runs [n],
+ * values [n][c] (only *num_symbols entries are written and copied), the
+ * zero-run formation runs on the device where the coefficients are. */
+int gpcc_raht_encode_attr_packed(
+  gpcc_ctx* ctx, const gpcc_raht_params* params, const int32_t* xyz,
+  int32_t* attrs, int32_t* runs, int32_t* values, int32_t* num_symbols,
+  int32_t* trailing_run, int32_t n, int32_t c, int32_t bitdepth);
+
 /* Zero-run formation of a coefficient stream: the part of the reference's
  * entropy loops that is not the arithmetic coder (AttributeEncoder.cpp:
  * 1279-1291 / 1347-1362 RAHT, 1458-1474 / 1617-1633 lifting).  A position

@@ -1811,11 +1811,17 @@ namespace {
 int
 slice_driver(
   gpcc_ctx* ctx, const gpcc_raht_params* params, bool encoder, const int32_t* xyz,
-  int32_t* attrs, int32_t* coeffs, int32_t n, int32_t c, int32_t bitdepth)
+  int32_t* attrs, int32_t* coeffs, int32_t n, int32_t c, int32_t bitdepth,
+  int32_t* runs = nullptr, int32_t* values = nullptr, int32_t* num_symbols = nullptr,
+  int32_t* trailing_run = nullptr)
 {
+  // packed: the encoder hands back (zero run, values) symbols instead of the
+  // coefficient array
+  const bool packed = runs != nullptr;
   if (!ctx)
     return fail(GPCC_ERR_INVALID_ARG, "ctx is null");
-  if (!xyz || !attrs || !coeffs || n <= 0 || bitdepth < 1 || bitdepth > 16)
+  if (!xyz || !attrs || (!coeffs && !packed) || n <= 0 || bitdepth < 1 || bitdepth > 16
+      || (packed && (!values || !num_symbols || !trailing_run || !encoder)))
     return fail(GPCC_ERR_INVALID_ARG, "null buffer, n <= 0 or bitdepth outside [1, 16]");
   int rcode = check_params(params, c, encoder);
   if (rcode)
@@ -1831,7 +1837,9 @@ slice_driver(
   const size_t N = (size_t)n;
   int32_t *d_xyz = nullptr, *d_order = nullptr, *d_pt = nullptr, *d_a = nullptr, *d_c = nullptr;
   int64_t* d_m = nullptr;
+  char* d_pack = nullptr;
   auto cleanup = [&]() {
+    hipFree(d_pack);
     hipFree(d_xyz);
     hipFree(d_order);
     hipFree(d_pt);
@@ -1876,8 +1884,49 @@ slice_driver(
         n, c, (1 << bitdepth) - 1, d_order, d_a, d_pt);
     }
     HIP_TRY(hipMemcpyAsync(attrs, d_pt, sizeof(int32_t) * N * c, hipMemcpyDeviceToHost, st));
-    if (encoder)
+    if (encoder && !packed)
       HIP_TRY(hipMemcpyAsync(coeffs, d_c, sizeof(int32_t) * N * c, hipMemcpyDeviceToHost, st));
+    if (packed) {
+      // zero-run formation where the coefficients are: only symbols cross PCIe
+      Arena ar;
+      ar.take<int32_t>(N);          // positions
+      ar.take<int32_t>(N + 1);      // non-zero positions
+      ar.take<int32_t>(N);          // runs
+      ar.take<int32_t>(N * c);      // values
+      ar.take<uint8_t>(N);          // flags
+      ar.take<int32_t>(64);
+      ar.take<unsigned long long>(1024);
+      HIP_TRY(hipMalloc((void**)&d_pack, ar.used));
+      ar.base = d_pack;
+      ar.reset();
+      int32_t* d_pos = ar.take<int32_t>(N);
+      int32_t* d_nz = ar.take<int32_t>(N + 1);
+      int32_t* d_runs = ar.take<int32_t>(N);
+      int32_t* d_vals = ar.take<int32_t>(N * c);
+      uint8_t* d_flags = ar.take<uint8_t>(N);
+      int32_t* d_small = ar.take<int32_t>(64);
+      unsigned long long* d_scan = ar.take<unsigned long long>(1024);
+      HIP_TRY(hipMemsetAsync(d_small, 0, sizeof(int32_t) * 64, st));
+      HIP_TRY(hipMemsetAsync(d_scan, 0, sizeof(unsigned long long) * 1024, st));
+      {
+        Timer tm(ctx, "zero_run_pack");
+        zero_run_flags_kernel<<<grid_for(n, 256), 256, 0, st>>>(n, c, 1, d_c, d_flags, d_pos);
+        const int grid = (int)std::min<int64_t>(1024, ((int64_t)n + 1023) / 1024);
+        lod_partition_kernel<<<std::max(grid, 1), 256, 0, st>>>(
+          n, d_flags, d_pos, d_nz, nullptr, d_small, d_scan, 1);
+        zero_run_emit_kernel<<<grid_for(n, 256), 256, 0, st>>>(
+          n, c, 1, d_c, d_nz, d_small, d_runs, d_vals, d_small + 1);
+      }
+      int32_t h[2] = {0, 0};
+      HIP_TRY(hipMemcpyAsync(h, d_small, sizeof(h), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      if (h[0] > 0) {
+        HIP_TRY(hipMemcpyAsync(runs, d_runs, sizeof(int32_t) * (size_t)h[0], hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(values, d_vals, sizeof(int32_t) * (size_t)h[0] * c, hipMemcpyDeviceToHost, st));
+      }
+      *num_symbols = h[0];
+      *trailing_run = h[1];
+    }
     HIP_TRY(hipStreamSynchronize(st));
     return check_device_error(ctx);
   };
@@ -1886,6 +1935,18 @@ slice_driver(
   return r;
 }
 }  // namespace
+
+int
+gpcc_raht_encode_attr_packed(
+  gpcc_ctx* ctx, const gpcc_raht_params* params, const int32_t* xyz, int32_t* attrs,
+  int32_t* runs, int32_t* values, int32_t* num_symbols, int32_t* trailing_run, int32_t n,
+  int32_t c, int32_t bitdepth)
+{
+  if (!runs)
+    return fail(GPCC_ERR_INVALID_ARG, "runs is null");
+  return slice_driver(
+    ctx, params, true, xyz, attrs, nullptr, n, c, bitdepth, runs, values, num_symbols, trailing_run);
+}
 
 int
 gpcc_raht_encode_attr(

@@ -226,3 +226,17 @@ class Context:
         _lib.check(self._lib.gpcc_zero_run_pack(self._h, co.ctypes.data, n, c, int(planar), runs.ctypes.data,
                                                 vals.ctypes.data, C.byref(m), C.byref(tr)))
         return runs[:m.value].copy(), vals[:m.value * c].reshape(m.value, c).copy(), tr.value
+
+    def raht_encode_attr_packed(self, params, xyz, attrs, bitdepth=8):
+        """raht_encode_attr handing back the entropy loop's symbol stream ->
+        (runs [m], values [m,c], trailing_run, clipped recon [n,c] point order)"""
+        xyz = np.ascontiguousarray(xyz, dtype=np.int32)
+        a = np.ascontiguousarray(attrs, dtype=np.int32).copy()
+        n, c = a.shape
+        runs = np.zeros(n, np.int32)
+        vals = np.zeros(n * c, np.int32)
+        m, tr = C.c_int32(), C.c_int32()
+        _lib.check(self._lib.gpcc_raht_encode_attr_packed(self._h, C.byref(params), xyz.ctypes.data, a.ctypes.data,
+                                                          runs.ctypes.data, vals.ctypes.data, C.byref(m),
+                                                          C.byref(tr), n, c, bitdepth))
+        return runs[:m.value].copy(), vals[:m.value * c].reshape(m.value, c).copy(), tr.value, a

@@ -86,6 +86,7 @@ def test_null_context_is_rejected_everywhere(lib):
         lambda: lib.gpcc_lift_encode_attr(z, C.byref(lp), C.byref(lf), z, z, z, z, z, 1, 1),
         lambda: lib.gpcc_lift_decode_attr(z, C.byref(lp), C.byref(lf), z, z, z, z, z, 1, 1),
         lambda: lib.gpcc_zero_run_pack(z, z, 1, 1, 1, z, z, C.byref(out), C.byref(out)),
+        lambda: lib.gpcc_raht_encode_attr_packed(z, C.byref(rp), z, z, C.byref(out), z, C.byref(out), C.byref(out), 1, 1, 8),
     ]
     for i, f in enumerate(calls):
         assert f() == -1, f"entry {i}"

@@ -102,6 +102,12 @@ def test_device_raht_bitstream_identical_to_reference_operator(case, ctx):
     assert trailing == o_tr
     assert lh.ref_entropy_encode_symbols(c, len(xyz), runs, vals, trailing) == want
     np.testing.assert_array_equal(rec, want_rec)
+    # the one-call form: symbols straight from the device
+    p_runs, p_vals, p_tr, p_rec = ctx.raht_encode_attr_packed(rp, xyz, attrs, bitdepth)
+    np.testing.assert_array_equal(p_runs, runs)
+    np.testing.assert_array_equal(p_vals, vals)
+    assert p_tr == trailing
+    np.testing.assert_array_equal(p_rec, rec)
 
 
 @pytest.mark.gpu
