@@ -74,13 +74,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # RCCL ("nccl") is the backend of every real run; GPCC_BENCH_BACKEND=gloo
+    # exists only to exercise the multi-rank control flow on a one-GPU box
+    # (several ranks share the device, the gather goes through host memory)
+    backend = os.environ.get("GPCC_BENCH_BACKEND", "nccl")
+    local_rank %= max(torch.cuda.device_count(), 1)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE {world}"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    xdev = dev if backend == "nccl" else torch.device("cpu")  # where collectives operate
 
     if args.haar:
         p = raht_params(qp=4, haar=True, chroma_offset=0, subnode=bool(args.subnode), search_range=2500)
@@ -99,7 +108,8 @@ def main():
     d_attrs = torch.empty_like(src)
     d_coeffs = torch.zeros(c * n, dtype=torch.int32, device=dev)
     d_dec = torch.empty_like(src)
-    gathered = [torch.empty_like(d_coeffs) for _ in range(world)] if (world > 1 and rank == 0) else None
+    gathered = ([torch.empty_like(d_coeffs, device=xdev) for _ in range(world)]
+                if (world > 1 and rank == 0) else None)
 
     stream = torch.cuda.current_stream(dev)
     ctx = context(local_rank, stream=stream.cuda_stream)
@@ -121,7 +131,7 @@ def main():
             ctx.dev_raht_forward(p, offsets, d_morton.data_ptr(), d_attrs.data_ptr(), d_coeffs.data_ptr(), c)
         ctx.dev_raht_inverse(p, offsets, d_morton.data_ptr(), d_dec.data_ptr(), d_coeffs.data_ptr(), c)
         if world > 1:
-            dist.gather(d_coeffs, gathered, dst=0)
+            dist.gather(d_coeffs if backend == "nccl" else d_coeffs.cpu(), gathered, dst=0)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -138,7 +148,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
