@@ -1,0 +1,39 @@
+"""bench.py with two ranks: the driver launches it under torch.distributed.run,
+one rank per GPU over RCCL.  On a one-GPU box the same control flow (rendezvous
+on 127.0.0.1, per-rank frames, gather of the coefficient buffers on rank 0,
+barrier, MAX over ranks, one JSON line from rank 0) is exercised with both ranks
+sharing the device and the gather going through host memory
+(GPCC_BENCH_BACKEND=gloo)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_one_json_line():
+    env = dict(os.environ, GPCC_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--points", "200000"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 2
+    assert d["config"]["points_per_gpu_per_step"] == 200000
+    assert d["config"]["roundtrip_decoder_equals_encoder_recon"] is True
+    assert d["value"] > 0 and "roofline" not in d  # per-kernel figures are an N=1 report
