@@ -16,6 +16,9 @@
  *   - device tier (gpcc_dev_*): the same operations on buffers already
  *     resident in HBM, batched over slices, asynchronous on a HIP stream.
  *     The host tier is implemented on top of it.
+ *
+ * Limits: at most GPCC_MAX_POINTS points per call (per batch for the device
+ * tier) and coordinates in [0, 2^21); beyond them GPCC_ERR_INVALID_ARG.
  */
 #ifndef GPCC_ATTR_MI355_H
 #define GPCC_ATTR_MI355_H
@@ -28,6 +31,7 @@ extern "C" {
 #endif
 
 #define GPCC_ABI_VERSION 1
+#define GPCC_MAX_POINTS (1 << 29) /* 32-bit device indices, stride <= 3 */
 
 #define GPCC_MAX_QP_LAYERS 32
 #define GPCC_MAX_AC_QP_LAYERS 32

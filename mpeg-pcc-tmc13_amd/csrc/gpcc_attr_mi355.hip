@@ -59,6 +59,8 @@ fail(int code, const std::string& msg)
         std::string(#expr) + ": " + hipGetErrorString(e_));                  \
   } while (0)
 
+// Device indices are 32-bit and attribute arrays are strided by up to 3.
+constexpr int32_t kMaxPoints = GPCC_MAX_POINTS;
 constexpr int kGridMax = 2048;  // 256 CUs x 8 workgroups of 256 threads
 constexpr int kLevelGridMax = 1 << 16;
 constexpr int kSubGrid = 1024;      // sub-node kernel: 4 workgroups per CU, resident
@@ -545,8 +547,8 @@ dev_transform(
   for (int i = 0; i < s; i++)
     if (offsets[i + 1] <= offsets[i])
       return fail(GPCC_ERR_INVALID_ARG, "empty or unordered slice");
-  if (offsets[s] >= (int64_t)1 << 30)
-    return fail(GPCC_ERR_INVALID_ARG, "more than 2^30 points per batch");
+  if (offsets[s] > kMaxPoints)
+    return fail(GPCC_ERR_INVALID_ARG, "more than 2^29 points per batch");
   if (!d_morton || !d_attrs || !d_coeffs)
     return fail(GPCC_ERR_INVALID_ARG, "null device buffer");
   HIP_TRY(hipSetDevice(ctx->device));
@@ -602,6 +604,8 @@ host_transform(
     return fail(GPCC_ERR_INVALID_ARG, "ctx is null");
   if (!morton || !attrs || !coeffs || n <= 0)
     return fail(GPCC_ERR_INVALID_ARG, "null buffer or n <= 0");
+  if (n > kMaxPoints)
+    return fail(GPCC_ERR_INVALID_ARG, "more than 2^29 points per call");
   int rcode = check_params(params, c, encoder);
   if (rcode)
     return rcode;
@@ -667,6 +671,8 @@ check_lift_params(const gpcc_lift_params* p, int n, int c)
     return fail(GPCC_ERR_INVALID_ARG, "params is null");
   if (n <= 0 || c < 1 || c > 3)
     return fail(GPCC_ERR_INVALID_ARG, "n <= 0 or attribute count not 1..3");
+  if (n > kMaxPoints)
+    return fail(GPCC_ERR_INVALID_ARG, "more than 2^29 points per call");
   if (p->num_lods < 1 || p->num_lods > GPCC_MAX_LODS)
     return fail(GPCC_ERR_INVALID_ARG, "num_lods out of range");
   if (p->num_points_in_lod[p->num_lods - 1] != n)
@@ -1131,8 +1137,8 @@ gpcc_dev_attr_morton_sort(
   for (int i = 0; i < num_slices; i++)
     if (offsets[i + 1] <= offsets[i])
       return fail(GPCC_ERR_INVALID_ARG, "empty or unordered slice");
-  if (offsets[num_slices] >= (int64_t)1 << 30)
-    return fail(GPCC_ERR_INVALID_ARG, "more than 2^30 points per batch");
+  if (offsets[num_slices] > kMaxPoints)
+    return fail(GPCC_ERR_INVALID_ARG, "more than 2^29 points per batch");
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   const int n = (int)offsets[num_slices];
@@ -1242,6 +1248,8 @@ gpcc_attr_morton_sort(
     return fail(GPCC_ERR_INVALID_ARG, "ctx is null");
   if (!xyz || !morton || !order || n <= 0)
     return fail(GPCC_ERR_INVALID_ARG, "null buffer or n <= 0");
+  if (n > kMaxPoints)
+    return fail(GPCC_ERR_INVALID_ARG, "more than 2^29 points per call");
   int32_t mx = 0;
   for (int64_t i = 0; i < (int64_t)n * 3; i++) {
     if (xyz[i] < 0 || xyz[i] >= (1 << 21))
@@ -1313,6 +1321,8 @@ gpcc_lod_compute_weights(
     return fail(GPCC_ERR_INVALID_ARG, "ctx is null");
   if (n <= 0 || !neigh_count || !dist2 || !neigh_weight)
     return fail(GPCC_ERR_INVALID_ARG, "null buffer or n <= 0");
+  if (n > kMaxPoints)
+    return fail(GPCC_ERR_INVALID_ARG, "more than 2^29 points per call");
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   Arena m;
@@ -1363,6 +1373,8 @@ lod_build_core(
     return fail(GPCC_ERR_INVALID_ARG, "ctx is null");
   if (!lp || !xyz || n <= 0)
     return fail(GPCC_ERR_INVALID_ARG, "null buffer or n <= 0");
+  if (n > kMaxPoints)
+    return fail(GPCC_ERR_INVALID_ARG, "more than 2^29 points per call");
   if (lp->scalable_lifting_enabled_flag || lp->canonical_point_order_flag
       || lp->max_points_per_sort_log2_plus1 || lp->lod_decimation_type < 0
       || lp->lod_decimation_type > 2)
@@ -1823,6 +1835,8 @@ slice_driver(
   if (!xyz || !attrs || (!coeffs && !packed) || n <= 0 || bitdepth < 1 || bitdepth > 16
       || (packed && (!values || !num_symbols || !trailing_run || !encoder)))
     return fail(GPCC_ERR_INVALID_ARG, "null buffer, n <= 0 or bitdepth outside [1, 16]");
+  if (n > kMaxPoints)
+    return fail(GPCC_ERR_INVALID_ARG, "more than 2^29 points per call");
   int rcode = check_params(params, c, encoder);
   if (rcode)
     return rcode;
@@ -1974,6 +1988,8 @@ gpcc_zero_run_pack(
     return fail(GPCC_ERR_INVALID_ARG, "ctx is null");
   if (!coeffs || !runs || !values || !num_symbols || !trailing_run || n <= 0 || c < 1 || c > 3)
     return fail(GPCC_ERR_INVALID_ARG, "null buffer, n <= 0 or attribute count not 1..3");
+  if (n > kMaxPoints)
+    return fail(GPCC_ERR_INVALID_ARG, "more than 2^29 points per call");
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   const size_t N = (size_t)n;
@@ -2033,6 +2049,8 @@ gpcc_estimate_dist2(
   if (!xyz || !shift_bits || n < 0 || sampling_period < 1 || search_range < 0
       || !(percentile >= 0.f && percentile < 1.f))
     return fail(GPCC_ERR_INVALID_ARG, "bad argument");
+  if (n > kMaxPoints)
+    return fail(GPCC_ERR_INVALID_ARG, "more than 2^29 points per call");
   *shift_bits = 0;
   if (n < 2)
     return GPCC_OK;

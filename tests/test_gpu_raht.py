@@ -156,6 +156,22 @@ def test_error_paths(ctx):
         ctx.raht_forward(p, np.array([1, 2], dtype=np.int64), np.zeros((2, 4), np.int32))
 
 
+def test_point_count_limit(ctx):
+    """More than GPCC_MAX_POINTS points: refused before any buffer is read."""
+    import ctypes as C
+    from mpeg_pcc_tmc13_amd import lod_params, raht_params
+    lib, h = ctx._lib, ctx._h
+    big = (1 << 29) + 1
+    buf = np.zeros(16, np.int64)
+    ptr = buf.ctypes.data
+    p, lp = raht_params(), lod_params()
+    assert lib.gpcc_raht_forward(h, C.byref(p), ptr, None, ptr, ptr, big, 1) == -1
+    assert b"2^29" in lib.gpcc_last_error()
+    assert lib.gpcc_attr_morton_sort(h, ptr, big, ptr, ptr) == -1
+    assert lib.gpcc_lod_build(h, C.byref(lp), ptr, big, ptr, ptr, ptr, ptr, ptr, C.byref(C.c_int32())) == -1
+    assert lib.gpcc_lod_compute_weights(h, big, ptr, ptr, ptr) == -1
+
+
 @pytest.mark.parametrize("seed", range(3))
 def test_subnode_inverse_random_vs_oracle(seed, ctx):
     """CTC-default flags (sub-node prediction on): decoder on the device."""
