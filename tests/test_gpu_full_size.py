@@ -1,0 +1,87 @@
+"""BASELINE.json's full-size configurations on one MI355X.  Where the CPU
+checker finishes in seconds the comparison is direct and bit-exact (LoD
+structure at 5 M points, RAHT at 2 M); beyond that, size-independent
+properties: decoder(encoder coefficients) == encoder reconstruction, integer
+Haar at qp 4 is lossless, the coding order is a permutation, every predictor
+precedes the point it predicts."""
+import numpy as np
+import pytest
+
+import lod_helpers as lh
+import oracle_loader as ol
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from mpeg_pcc_tmc13_amd import context
+    c = context(0)
+    yield c
+    c.close()
+
+
+def test_lifting_coder_5M_dense(ctx):
+    """configs[2]: lifting transform with the LoD build on a 5 M-point dense cloud."""
+    from mpeg_pcc_tmc13_amd import lift_params, lod_params, synth
+    n = 5_000_000
+    xyz, col = synth.dense_cloud(n, seed=71, bits=12)
+    assert len(xyz) == n
+    lp = lod_params()
+    g = ctx.lod_build(lp, xyz)
+    npl = g["npl"]
+    assert npl[-1] == n and np.all(np.diff(npl) > 0)
+    assert np.array_equal(np.sort(g["indexes"]), np.arange(n, dtype=g["indexes"].dtype))
+    nc, ni = g["nc"], g["ni"]
+    assert nc.min() >= 0 and nc.max() <= 3 and np.all(nc[npl[0]:] >= 1)
+    pos = np.arange(n)[:, None]
+    used = np.arange(3)[None, :] < nc[:, None]
+    assert np.all(ni[used] < np.broadcast_to(pos, ni.shape)[used])
+    if ol.ref_available():          # the compiled reference: ~10 s of CPU at this size
+        r = lh.ref_lod_generate(xyz, lp)
+        for k in ("npl", "indexes", "nc", "ni"):
+            np.testing.assert_array_equal(g[k], r[k], err_msg=k)
+        np.testing.assert_array_equal(g["w"].astype(np.uint64), r["w"])
+    lf = lift_params([n], qp=34)
+    co, rec, lcp, idx = ctx.lift_encode_attr(lp, lf, xyz, col)
+    np.testing.assert_array_equal(idx, g["indexes"])
+    assert list(lf.num_points_in_lod[:lf.num_lods]) == list(npl)
+    assert rec.min() >= 0 and rec.max() <= 255 and np.abs(rec - col).max() < 128
+    lf2 = lift_params([n], qp=34)
+    dec = ctx.lift_decode_attr(lp, lf2, xyz, co, lcp)
+    np.testing.assert_array_equal(dec, rec)
+
+
+def test_raht_10M_colour_and_reflectance(ctx):
+    """configs[4]: 10 M points carrying colour and reflectance, reference default flags."""
+    from mpeg_pcc_tmc13_amd import raht_params, synth
+    n = 10_000_000
+    xyz, col = synth.dense_cloud(n, seed=72, bits=13)
+    assert len(xyz) == n
+    refl = np.ascontiguousarray((col[:, :1] * 3 + col[:, 1:2]) % 251)
+    p = raht_params(qp=34)
+    for attrs in (col, refl):
+        c = attrs.shape[1]
+        co, rec = ctx.raht_encode_attr(p, xyz, attrs, 8)
+        assert rec.min() >= 0 and rec.max() <= 255 and np.abs(rec - attrs).max() < 128
+        dec = ctx.raht_decode_attr(p, xyz, co, c, 8)
+        np.testing.assert_array_equal(dec, rec)
+    ph = raht_params(qp=4, haar=True, chroma_offset=0)
+    co, rec = ctx.raht_encode_attr(ph, xyz, col, 8)
+    np.testing.assert_array_equal(rec, col)
+    np.testing.assert_array_equal(ctx.raht_decode_attr(ph, xyz, co, 3, 8), col)
+
+
+def test_raht_2M_frame_vs_checker(ctx):
+    """configs[3]: one 2 M-point frame (the unit sharded one per GPU) against
+    the compiled reference (oracle where it did not travel), default flags."""
+    from mpeg_pcc_tmc13_amd import raht_params, synth
+    xyz, refl = synth.lidar_cloud(2_000_000, seed=73)
+    morton, attrs, _ = synth.sort_by_morton(xyz, refl)
+    p = raht_params(qp=34, search_range=2500)
+    chk = ol.ref() if ol.ref_available() else ol.oracle()
+    want_co, want_rec = chk.raht_forward(p, morton, attrs)
+    co, rec = ctx.raht_forward(p, morton, attrs)
+    np.testing.assert_array_equal(co, want_co)
+    np.testing.assert_array_equal(rec, want_rec)
+    np.testing.assert_array_equal(ctx.raht_inverse(p, morton, co, 1), want_rec)
