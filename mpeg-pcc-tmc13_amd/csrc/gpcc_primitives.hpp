@@ -44,12 +44,24 @@ GPCC_HD int64_t fp_mul(int64_t a, int64_t b)
   return round_shift_sym((int64_t)((uint64_t)a * (uint64_t)b), kFpFrac);
 }
 
-// The same with a coefficient known to fit 32 bits (butterfly a/b, 1/sqrt(w),
-// sqrt(w) < 2^26, prediction divisor): a 64x32 multiply is two
-// v_mad_u64_u32 instead of the 64x64 sequence.
-GPCC_HD int64_t fp_mul32(int64_t a, int32_t b)
+// a * c for a multiplier known to lie in [0, 2^32): two 32-bit multiplies
+// instead of the three of a 64 x 64 product (32-bit integer multiplies are
+// quarter rate, and these sit on the dependency chains).  Every constant of
+// the transform qualifies: butterfly a/b <= 2^15, 1/sqrt(w) <= 2^15,
+// sqrt(w) < 2^30 for w <= GPCC_MAX_POINTS, the prediction divisor, the
+// quantiser step and reciprocal.
+GPCC_HD int64_t mul_i64_u32(int64_t a, int64_t c)
 {
-  return round_shift_sym(a * (int64_t)b, kFpFrac);
+  const uint32_t cl = (uint32_t)c;
+  const uint64_t lo = (uint64_t)(uint32_t)a * cl;
+  const uint32_t hi = (uint32_t)((uint64_t)a >> 32) * cl + (uint32_t)(lo >> 32);
+  return (int64_t)(((uint64_t)hi << 32) | (uint32_t)lo);
+}
+
+// FixedPoint::operator*= by such a constant
+GPCC_HD int64_t fp_mul_c(int64_t a, int64_t c)
+{
+  return round_shift_sym(mul_i64_u32(a, c), kFpFrac);
 }
 
 // ---- bit helpers --------------------------------------------------------
@@ -213,14 +225,14 @@ GPCC_HD int64_t quantize(Quantizer q, int64_t x)
   //                                  == (x r + 2^26 - 1 - off) >> 26
   constexpr int64_t off = ((int64_t)1 << 26) / 3;
   constexpr int64_t noff = ((int64_t)1 << 26) - 1 - off;
-  return (x * (int64_t)q.recip + (x < 0 ? noff : off)) >> 26;
+  return (mul_i64_u32(x, q.recip) + (x < 0 ? noff : off)) >> 26;
 }
 
 GPCC_HD int64_t dequantize(Quantizer q, int64_t c)
 {
   // Quantizer::scale followed by divExp2RoundHalfUp(.., 8)
   // (tmc3/RAHT.cpp:1702-1703)
-  return (c * q.step + 128) >> 8;
+  return (mul_i64_u32(c, q.step) + 128) >> 8;
 }
 
 GPCC_HD int clip(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }

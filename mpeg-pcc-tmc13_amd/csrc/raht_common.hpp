@@ -87,11 +87,31 @@ find_slice(const int32_t* __restrict__ off, int num_slices, int idx)
 // ---- wave / 8-lane group helpers --------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
 
+// Exchange with lane ^ mask inside an 8-lane group (mask 1, 2 or 4) as DPP
+// moves: quad permutes, and lane ^ 4 = 7 - (lane ^ 3) = half-row mirror then
+// quad reverse.  A few cycles each, where __shfl_xor compiles to
+// ds_bpermute_b32 -- an LDS-crossbar round trip (~100 cycles with its
+// s_waitcnt) that would sit on every hop of the dependency chains.  `mask`
+// folds to a constant once the caller's stage loop is unrolled.
+__device__ __forceinline__ int
+lane_xor8(int v, int mask)
+{
+  if (mask == 1)
+    return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false);  // quad_perm:[1,0,3,2]
+  if (mask == 2)
+    return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false);  // quad_perm:[2,3,0,1]
+  if (mask == 4) {
+    const int m = __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false);  // row_half_mirror
+    return __builtin_amdgcn_update_dpp(m, m, 0x1B, 0xF, 0xF, false);          // quad_perm:[3,2,1,0]
+  }
+  return __shfl_xor(v, mask);
+}
+
 __device__ __forceinline__ int64_t
 shfl_xor_i64(int64_t v, int mask)
 {
-  int lo = __shfl_xor((int)(uint32_t)v, mask);
-  int hi = __shfl_xor((int)(v >> 32), mask);
+  int lo = lane_xor8((int)(uint32_t)v, mask);
+  int hi = lane_xor8((int)(v >> 32), mask);
   return ((int64_t)hi << 32) | (uint32_t)lo;
 }
 
@@ -103,22 +123,44 @@ shfl_i64(int64_t v, int src)
   return ((int64_t)hi << 32) | (uint32_t)lo;
 }
 
-// OR / sum over the 8 lanes of a group (lanes g*8 .. g*8+7)
+// OR / sum / max over the 8 lanes of a group (lanes g*8 .. g*8+7)
 __device__ __forceinline__ uint32_t
 group8_or(uint32_t v)
 {
-  v |= __shfl_xor(v, 1);
-  v |= __shfl_xor(v, 2);
-  v |= __shfl_xor(v, 4);
+  v |= (uint32_t)lane_xor8((int)v, 1);
+  v |= (uint32_t)lane_xor8((int)v, 2);
+  v |= (uint32_t)lane_xor8((int)v, 4);
   return v;
 }
 __device__ __forceinline__ int
 group8_sum(int v)
 {
-  v += __shfl_xor(v, 1);
-  v += __shfl_xor(v, 2);
-  v += __shfl_xor(v, 4);
+  v += lane_xor8(v, 1);
+  v += lane_xor8(v, 2);
+  v += lane_xor8(v, 4);
   return v;
+}
+__device__ __forceinline__ int
+group8_max(int v)
+{
+#pragma unroll
+  for (int d = 1; d < 8; d <<= 1) {
+    const int o = lane_xor8(v, d);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+// bit u = p of lane (group base | u): one compare into an SGPR pair and a
+// shift.  The lanes of a group are active together wherever this is used.
+__device__ __forceinline__ uint32_t
+group8_bits(bool p)
+{
+  return (uint32_t)(__ballot(p) >> (lane_id() & 56)) & 0xffu;
+}
+__device__ __forceinline__ bool
+group8_any(bool p)
+{
+  return group8_bits(p) != 0;
 }
 
 __device__ __forceinline__ uint32_t

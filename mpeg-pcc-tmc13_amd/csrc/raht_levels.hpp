@@ -140,11 +140,11 @@ __device__ __forceinline__ int64_t
 scale_rsqrt(int64_t v, int32_t weight, const SharedLut& L)
 {
   if (weight < kSmallN)
-    return fp_mul(v, L.norm_rs[weight]);
+    return fp_mul_c(v, L.norm_rs[weight]);
   const uint64_t w = (uint64_t)weight;
   const int shift = w > 1024 ? ilog2_u64(w - 1) >> 1 : 0;
   const int64_t rs = (int64_t)(irsqrt(w, L.rsqrt) >> (40 - shift - kFpFrac));
-  return fp_mul(v >> shift, rs);
+  return fp_mul_c(v >> shift, rs);
 }
 
 // sqrt(weight) in Q15 (tmc3/RAHT.cpp:1487-1488)
@@ -489,8 +489,8 @@ raht_level_kernel(LevelCtx ctx)
 #pragma unroll
       for (int st = 0; st < 3; st++) {
         const int bit = 1 << st;
-        const int32_t pw = __shfl_xor(wa, bit);
-        const int32_t p0 = __shfl_xor(b0, bit), p1 = __shfl_xor(b1, bit);
+        const int32_t pw = lane_xor8(wa, bit);
+        const int32_t p0 = lane_xor8(b0, bit), p1 = lane_xor8(b1, bit);
         st_w[st] = wa;
         st_a0[st] = b0;
         st_a1[st] = b1;
@@ -533,7 +533,7 @@ raht_level_kernel(LevelCtx ctx)
 #pragma unroll
     for (int st = 0; st < 3; st++) {
       const int bit = 1 << st;
-      const int32_t pw = __shfl_xor(cw, bit);
+      const int32_t pw = lane_xor8(cw, bit);
       const bool left = !(t & bit);
       wl[st] = left ? cw : pw;
       wr[st] = left ? pw : cw;
@@ -694,7 +694,7 @@ raht_level_kernel(LevelCtx ctx)
         const int64_t div = pred_divisor(wsum);
 #pragma unroll
         for (int k = 0; k < C; k++) {
-          pred[k] = fp_mul(pred[k], div);
+          pred[k] = fp_mul_c(pred[k], div);
           if (haar)
             pred[k] = (pred[k] >> kFpFrac) << kFpFrac;
         }
@@ -712,7 +712,7 @@ raht_level_kernel(LevelCtx ctx)
         const int64_t sq = sqrt_weight(w, lut);
 #pragma unroll
         for (int k = 0; k < C; k++)
-          pred[k] = fp_mul(pred[k], sq);
+          pred[k] = fp_mul_c(pred[k], sq);
       }
     }
 
@@ -733,8 +733,8 @@ raht_level_kernel(LevelCtx ctx)
               const int64_t hf = left ? oth - own : own - oth;
               src[k] = left ? own + ((hf >> (1 + kFpFrac)) << kFpFrac) : hf;
             } else {
-              src[k] = left ? fp_mul(oth, cb[st]) + fp_mul(ca[st], own)
-                            : fp_mul(own, ca[st]) - fp_mul(cb[st], oth);
+              src[k] = left ? fp_mul_c(oth, cb[st]) + fp_mul_c(own, ca[st])
+                            : fp_mul_c(own, ca[st]) - fp_mul_c(oth, cb[st]);
             }
           } else if (swap) {
             src[k] = oth;
@@ -748,8 +748,8 @@ raht_level_kernel(LevelCtx ctx)
                 const int64_t hf = left ? oth - own : own - oth;
                 pred[k] = left ? own + ((hf >> (1 + kFpFrac)) << kFpFrac) : hf;
               } else {
-                pred[k] = left ? fp_mul(oth, cb[st]) + fp_mul(ca[st], own)
-                               : fp_mul(own, ca[st]) - fp_mul(cb[st], oth);
+                pred[k] = left ? fp_mul_c(oth, cb[st]) + fp_mul_c(own, ca[st])
+                               : fp_mul_c(own, ca[st]) - fp_mul_c(oth, cb[st]);
               }
             } else if (swap) {
               pred[k] = oth;
@@ -760,7 +760,7 @@ raht_level_kernel(LevelCtx ctx)
     }
 
     // ---- coefficient slot of this position (scanBlock :776-791) --------
-    const uint32_t present = group8_or((on && cw != 0) ? 1u << t : 0u) | (on ? 1u : 0u);
+    const uint32_t present = group8_bits(on && cw != 0) | (on ? 1u : 0u);
     // scan order 0,4,2,1,6,5,3,7 -> scan position of t
     const int spos = (0x74516230u >> (4 * t)) & 7;
     const uint32_t pscan = ((present >> 0) & 1) | (((present >> 4) & 1) << 1)
@@ -865,8 +865,8 @@ raht_level_kernel(LevelCtx ctx)
             const int64_t lv = lf - ((hf >> (1 + kFpFrac)) << kFpFrac);
             pred[k] = left ? lv : hf + lv;
           } else {
-            pred[k] = left ? fp_mul(own, ca[st]) - fp_mul(cb[st], oth)
-                           : fp_mul(oth, cb[st]) + fp_mul(ca[st], own);
+            pred[k] = left ? fp_mul_c(own, ca[st]) - fp_mul_c(oth, cb[st])
+                           : fp_mul_c(oth, cb[st]) + fp_mul_c(own, ca[st]);
           }
         } else if (swap) {
           pred[k] = oth;

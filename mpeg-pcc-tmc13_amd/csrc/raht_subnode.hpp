@@ -179,8 +179,8 @@ raht_level_sub_kernel(LevelCtx ctx)
 #pragma unroll
       for (int st = 0; st < 3; st++) {
         const int bit = 1 << st;
-        const int32_t pw = __shfl_xor(wa, bit);
-        const int32_t p0 = __shfl_xor(b0, bit), p1 = __shfl_xor(b1, bit);
+        const int32_t pw = lane_xor8(wa, bit);
+        const int32_t p0 = lane_xor8(b0, bit), p1 = lane_xor8(b1, bit);
         st_w[st] = wa;
         st_a0[st] = b0;
         st_a1[st] = b1;
@@ -223,7 +223,7 @@ raht_level_sub_kernel(LevelCtx ctx)
 #pragma unroll
     for (int st = 0; st < 3; st++) {
       const int bit = 1 << st;
-      const int32_t pw = __shfl_xor(cw, bit);
+      const int32_t pw = lane_xor8(cw, bit);
       const bool left = !(t & bit);
       wl[st] = left ? cw : pw;
       wr[st] = left ? pw : cw;
@@ -328,7 +328,7 @@ raht_level_sub_kernel(LevelCtx ctx)
     // ---- everything that does not wait: coefficient slots, quantisers,
     //      the encoder's source transform, parent-level prediction terms ---
     // ---- coefficient slot of this position (scanBlock :776-791) --------
-    const uint32_t present = group8_or((on && cw != 0) ? 1u << t : 0u) | (on ? 1u : 0u);
+    const uint32_t present = group8_bits(on && cw != 0) | (on ? 1u : 0u);
     // scan order 0,4,2,1,6,5,3,7 -> scan position of t
     const int spos = (0x74516230u >> (4 * t)) & 7;
     const uint32_t pscan = ((present >> 0) & 1) | (((present >> 4) & 1) << 1)
@@ -375,8 +375,8 @@ raht_level_sub_kernel(LevelCtx ctx)
               const int64_t hf = left ? oth - own : own - oth;
               src[k] = left ? own + ((hf >> (1 + kFpFrac)) << kFpFrac) : hf;
             } else {
-              src[k] = left ? fp_mul(oth, cb[st]) + fp_mul(ca[st], own)
-                            : fp_mul(own, ca[st]) - fp_mul(cb[st], oth);
+              src[k] = left ? fp_mul_c(oth, cb[st]) + fp_mul_c(own, ca[st])
+                            : fp_mul_c(own, ca[st]) - fp_mul_c(oth, cb[st]);
             }
           } else if (swap) {
             src[k] = oth;
@@ -386,10 +386,19 @@ raht_level_sub_kernel(LevelCtx ctx)
     }
     // RDOQ bookkeeping of the lossy encoder: rank of this lane's coefficient
     // among the block's coded coefficients, first coefficient index
-    const uint32_t coded_mask = group8_or(coded ? 1u << t : 0u);
+    const uint32_t coded_mask = group8_bits(coded);
     const int ncoef = popc32(coded_mask);
     const int crank = inherit_dc ? rank - 1 : rank;         // valid when coded
     const int cfirst = e.coeff_base + (inherit_dc ? (c0 - sc0) - pj : 0);
+    int rank_src = 0;  // lane of the group whose coefficient has rank t (t < ncoef)
+    if (kLossy) {
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int ru = __shfl(crank, gbase | u);
+        if (((coded_mask >> u) & 1) && ru == t)
+          rank_src = u;
+      }
+    }
     Quantizer qr[2] = {{1, 1}, {1, 1}};
     if (kLossy && coded)
       qpset_quantizers(prm, e.qp_layer, nq0, nq1, qr);
@@ -579,7 +588,7 @@ raht_level_sub_kernel(LevelCtx ctx)
           }
         }
       }
-      const bool blocked = group8_or((stage == 0 && pend) ? 1u : 0u) != 0;
+      const bool blocked = group8_any(stage == 0 && pend);
       const bool nready = stage == 0 && !blocked;
 
       if (__any(nready)) {
@@ -592,7 +601,7 @@ raht_level_sub_kernel(LevelCtx ctx)
         if (run && has) {
 #pragma unroll
           for (int k = 0; k < C; k++) {
-            pw_[k] = fp_mul(pw_[k], pdiv);
+            pw_[k] = fp_mul_c(pw_[k], pdiv);
             if (haar)
               pw_[k] = (pw_[k] >> kFpFrac) << kFpFrac;
           }
@@ -601,7 +610,7 @@ raht_level_sub_kernel(LevelCtx ctx)
           const int64_t sq = sqrt_weight(w, lut);
 #pragma unroll
           for (int k = 0; k < C; k++)
-            pw_[k] = fp_mul(pw_[k], sq);
+            pw_[k] = fp_mul_c(pw_[k], sq);
         }
 #pragma unroll
         for (int st = 0; st < 3; st++) {
@@ -618,8 +627,8 @@ raht_level_sub_kernel(LevelCtx ctx)
                   const int64_t hf = left ? oth - own : own - oth;
                   pw_[k] = left ? own + ((hf >> (1 + kFpFrac)) << kFpFrac) : hf;
                 } else {
-                  pw_[k] = left ? fp_mul(oth, cb[st]) + fp_mul(ca[st], own)
-                                : fp_mul(own, ca[st]) - fp_mul(cb[st], oth);
+                  pw_[k] = left ? fp_mul_c(oth, cb[st]) + fp_mul_c(own, ca[st])
+                                : fp_mul_c(own, ca[st]) - fp_mul_c(oth, cb[st]);
                 }
               } else if (swap) {
                 pw_[k] = oth;
@@ -674,13 +683,8 @@ raht_level_sub_kernel(LevelCtx ctx)
         uint32_t drn = kDescZero;
         if (kLossy) {
           // descriptors in coding order: lane r of the group gets rank r
-#pragma unroll
-          for (int u = 0; u < 8; u++) {
-            const uint32_t du = __shfl(d, gbase | u);
-            const int ru = __shfl(crank, gbase | u);
-            if (((coded_mask >> u) & 1) && ru == t)
-              drn = du;
-          }
+          const uint32_t du = __shfl(d, gbase | rank_src);
+          drn = t < ncoef ? du : kDescZero;
         }
         if (nready) {
 #pragma unroll
@@ -706,7 +710,7 @@ raht_level_sub_kernel(LevelCtx ctx)
         // least fixed point of "fails iff a reset lies in its window" for an
         // incoming last-reset index l0 (see raht_rdoq.hpp)
         auto resolve = [&](int l0, uint32_t* resets_out) -> int {
-          uint32_t resets = group8_or(isdef ? 1u << t : 0u);
+          uint32_t resets = group8_bits(isdef);
           int lhat = l0;
 #pragma unroll
           for (int it = 0; it < 8; it++) {
@@ -714,7 +718,7 @@ raht_level_sub_kernel(LevelCtx ctx)
             lhat = below ? cfirst + (31 - __clz(below)) : l0;
             const bool fail = isthr && !((resets >> t) & 1)
               && (uint32_t)(ci - lhat) <= rthr;
-            const uint32_t more = group8_or(fail ? 1u << t : 0u);
+            const uint32_t more = group8_bits(fail);
             if (!more)
               break;
             resets |= more;
@@ -731,8 +735,8 @@ raht_level_sub_kernel(LevelCtx ctx)
           // a block without any run-dependent coefficient skips them
           uint32_t ra, rb;
           bool fa, fb;
-          if (group8_or((rvalid && rthr != kDescNever && rthr != 0) ? 1u : 0u) == 0) {
-            ra = rb = group8_or(isdef ? 1u << t : 0u);
+          if (!group8_any(rvalid && rthr != kDescNever && rthr != 0)) {
+            ra = rb = group8_bits(isdef);
             fa = fb = rvalid && rthr == 0;
           } else {
             const int tza = resolve(-1, &ra);
@@ -740,7 +744,7 @@ raht_level_sub_kernel(LevelCtx ctx)
             fa = rvalid && rthr != kDescNever && (uint32_t)tza >= rthr;
             fb = rvalid && rthr != kDescNever && (uint32_t)tzb >= rthr;
           }
-          hyp_same = group8_or((fa != fb) ? 1u : 0u) == 0 && ra == rb;
+          hyp_same = !group8_any(fa != fb) && ra == rb;
           hyp_done = true;
           resets = res_h = rb;
           zero_r = zr_h = fb;
@@ -755,13 +759,7 @@ raht_level_sub_kernel(LevelCtx ctx)
           // rank t with threshold thr looks at [ci - thr, ci - 1]
           // (also the all-zero coefficients whose tentative value is non-zero:
           // they never reset, but whether they are zeroed depends on the run)
-          int nd = (rvalid && rthr != kDescNever && rthr != 0) ? (int)rthr - t : 0;
-#pragma unroll
-          for (int d = 1; d < 8; d <<= 1) {
-            const int o = __shfl_xor(nd, d);
-            nd = o > nd ? o : nd;
-          }
-          need = nd;
+          need = group8_max((rvalid && rthr != kDescNever && rthr != 0) ? (int)rthr - t : 0);
           if (!hyp_same && outk == 2 && t == 0)
             // decisions still open, outgoing L already certain: successors go on
             __hip_atomic_store(
@@ -817,7 +815,7 @@ raht_level_sub_kernel(LevelCtx ctx)
             const int val = (int)(uint32_t)sv;
             if (kind == 1 && cfirst - val >= need)
               kind = 5;
-            const uint32_t stop = group8_or((kind != 1) ? 1u << t : 0u);
+            const uint32_t stop = group8_bits(kind != 1);
             if (!stop) {
               look -= 8;
               continue;
@@ -870,14 +868,8 @@ raht_level_sub_kernel(LevelCtx ctx)
         for (int k = 0; k < C; k++)
           pw_[k] = pt[k];
         bool zero_me = false;
-        if (kLossy) {
-#pragma unroll
-          for (int u = 0; u < 8; u++) {
-            const bool zu = __shfl((int)zero_r, gbase | u);
-            if (coded && crank == u)
-              zero_me = zu;
-          }
-        }
+        if (kLossy)
+          zero_me = __shfl((int)zero_r, gbase | (crank & 7)) != 0 && coded;
         if (coded && can) {
 #pragma unroll
           for (int k = 0; k < C; k++) {
@@ -911,8 +903,8 @@ raht_level_sub_kernel(LevelCtx ctx)
                 const int64_t lv = lf - ((hf >> (1 + kFpFrac)) << kFpFrac);
                 pw_[k] = left ? lv : hf + lv;
               } else {
-                pw_[k] = left ? fp_mul(own, ca[st]) - fp_mul(cb[st], oth)
-                              : fp_mul(oth, cb[st]) + fp_mul(ca[st], own);
+                pw_[k] = left ? fp_mul_c(own, ca[st]) - fp_mul_c(oth, cb[st])
+                              : fp_mul_c(oth, cb[st]) + fp_mul_c(own, ca[st]);
               }
             } else if (swap) {
               pw_[k] = oth;
@@ -923,16 +915,22 @@ raht_level_sub_kernel(LevelCtx ctx)
         // (plain store) and the mailbox granule later blocks of THIS launch
         // poll (one 16-byte write-through store: value + tag, untorn)
         if (can && has) {
+          // the granules first: they are what the next hop of the chain waits for
+          int64_t vn[C];
 #pragma unroll
           for (int k = 0; k < C; k++) {
             int64_t v = pw_[k];
-            ctx.rec_us[cur_par][crow * C + k] = ext ? v : fp_round(v * 4);
             if (!haar && w > 1)
               v = scale_rsqrt(v, w, lut);
             v = ext ? v : fp_round(v);
-            ctx.rec[cur_par][crow * C + k] = v;
+            vn[k] = v;
             const u32x4 gr = {(uint32_t)v, (uint32_t)((uint64_t)v >> 32), ctx.mtag, 0u};
             __builtin_amdgcn_raw_buffer_store_b128(gr, mrsrc, (int)((crow * C + k) * 16), 0, /*sc1*/ 16);
+          }
+#pragma unroll
+          for (int k = 0; k < C; k++) {
+            ctx.rec_us[cur_par][crow * C + k] = ext ? pw_[k] : fp_round(pw_[k] * 4);
+            ctx.rec[cur_par][crow * C + k] = vn[k];
           }
           ctx.nneigh[cur_par][crow] = inherit_dc ? neigh_count : 19;
         }
