@@ -2096,3 +2096,18 @@ gpcc_estimate_dist2(
 }
 
 }  // extern "C"
+
+#ifdef GPCC_SUB_PROF
+extern "C" int
+gpcc_debug_sub_prof(unsigned long long* out, int reset)
+{
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gpcc::g_sub_prof), sizeof(gpcc::g_sub_prof)) != hipSuccess)
+    return -1;
+  if (reset) {
+    unsigned long long z[16 + 32 * 4] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(gpcc::g_sub_prof), z, sizeof(z)) != hipSuccess)
+      return -1;
+  }
+  return 0;
+}
+#endif

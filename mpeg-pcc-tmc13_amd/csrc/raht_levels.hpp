@@ -29,6 +29,13 @@ enum LevelMode { kAnalyze = 0, kSynth = 1, kFused = 2, kLossySub = 3 };
 constexpr uint32_t kDescNever = 0x7fffffffu;  // threshold that never passes
 constexpr uint32_t kDescZero = 0x80000000u;   // all components quantise to 0
 
+// The parameter block is read-only for the whole call: addressed through the
+// constant address space its fields are scalar loads (s_load, scalar cache,
+// lgkmcnt).  Through a generic pointer they are VECTOR loads of a uniform
+// value whose s_waitcnt vmcnt(0) also waits for every store in flight -- on
+// the sub-node kernel's dependency chain, behind its write-through stores.
+typedef const __attribute__((address_space(4))) gpcc_raht_params* ParamsConst;
+
 struct LevelCtx {
   TreeView tv;
   const gpcc_raht_params* params;  // device copy
@@ -57,6 +64,23 @@ struct LevelCtx {
   unsigned long long* rdoq_state;  // [cap] per worklist block: RDOQ hand-off word
   int32_t* slice_l;                // [2][S] last RDOQ reset carried between levels (sub-node path: by level parity)
 };
+
+// ctx.X[parity] with a per-lane parity, as a select between the two kernel
+// arguments.  Indexing the argument array with a vector value makes the
+// compiler fetch the pointer from the kernarg segment with a vector load in
+// front of every access: a dependent memory round trip, whose s_waitcnt
+// vmcnt(0) on gfx9 also waits for every store still in flight (10 us per
+// commit of the sub-node kernel, behind its write-through granule stores).
+template<typename T>
+__device__ __forceinline__ T*
+par2(T* const (&a)[2], int p)
+{
+  // base + offset keeps it an address computation on a kernel-argument
+  // pointer (a plain select is folded back into one vector load of the
+  // selected argument slot); both buffers of a pair come from one arena
+  const ptrdiff_t d = a[1] - a[0];
+  return a[0] + (p ? d : (ptrdiff_t)0);
+}
 
 // Small-weight tables.  Near the leaves almost every node weight is a
 // small integer, so the butterfly coefficients (a, b) of a (wl, wr) pair
@@ -157,9 +181,10 @@ sqrt_weight(int32_t weight, const SharedLut& L)
 }
 
 // QpSet::quantizers (tmc3/quantization.cpp:165-174)
+template<typename ParamsP>
 __device__ __forceinline__ void
 qpset_quantizers(
-  const gpcc_raht_params* p, int layer, int off0, int off1, Quantizer q[2])
+  ParamsP p, int layer, int off0, int off1, Quantizer q[2])
 {
   const int qp0 = clip(p->layer_qp[layer][0] + off0, 4, p->max_qp);
   const int qp1 = clip(p->layer_qp[layer][1] + off1 + qp0, 4, p->max_qp);
@@ -349,13 +374,13 @@ raht_level_prepass_kernel(LevelCtx ctx)
           const int pp = e.parity ^ 1, cp = e.parity;
 #pragma unroll
           for (int k = 0; k < C; k++) {
-            ctx.rec_us[cp][crow * C + k] = ctx.rec_us[pp][prow * C + k];
-            ctx.rec[cp][crow * C + k] = ctx.rec[pp][prow * C + k];
+            par2(ctx.rec_us, cp)[crow * C + k] = par2(ctx.rec_us, pp)[prow * C + k];
+            par2(ctx.rec, cp)[crow * C + k] = par2(ctx.rec, pp)[prow * C + k];
           }
-          ctx.nneigh[cp][crow] = 19;
+          par2(ctx.nneigh, cp)[crow] = 19;
           if (ctx.asc_qp) {
-            ctx.dqp[cp][crow * 2] = ctx.dqp[pp][prow * 2];
-            ctx.dqp[cp][crow * 2 + 1] = ctx.dqp[pp][prow * 2 + 1];
+            par2(ctx.dqp, cp)[crow * 2] = par2(ctx.dqp, pp)[prow * 2];
+            par2(ctx.dqp, cp)[crow * 2 + 1] = par2(ctx.dqp, pp)[prow * 2 + 1];
           }
         } else {
           real = true;
@@ -404,7 +429,7 @@ raht_level_kernel(LevelCtx ctx)
   constexpr bool kEnc = MODE != kSynth;
   constexpr bool kRecon = MODE != kAnalyze;
   const TreeView& tv = ctx.tv;
-  const gpcc_raht_params* __restrict__ prm = ctx.params;
+  const ParamsConst prm = (ParamsConst)ctx.params;
   const int li = ctx.li;
   const int t = threadIdx.x & 7;
   const bool haar = prm->integer_haar_enable_flag != 0;
@@ -506,8 +531,8 @@ raht_level_kernel(LevelCtx ctx)
       }
       // descend: the sub-tree containing this position is the RIGHT one
       // of a real pair -> its own ascent average, otherwise inherit
-      int32_t d0 = on ? ctx.dqp[par_par][prow * 2] : 0;
-      int32_t d1 = on ? ctx.dqp[par_par][prow * 2 + 1] : 0;
+      int32_t d0 = on ? par2(ctx.dqp, par_par)[prow * 2] : 0;
+      int32_t d1 = on ? par2(ctx.dqp, par_par)[prow * 2 + 1] : 0;
 #pragma unroll
       for (int st = 2; st >= 0; st--) {
         const int bit = 1 << st;
@@ -520,8 +545,8 @@ raht_level_kernel(LevelCtx ctx)
         nq0 = d0 >> 4;
         nq1 = d1 >> 4;
         if (kRecon) {
-          ctx.dqp[cur_par][crow * 2] = d0;
-          ctx.dqp[cur_par][crow * 2 + 1] = d1;
+          par2(ctx.dqp, cur_par)[crow * 2] = d0;
+          par2(ctx.dqp, cur_par)[crow * 2 + 1] = d1;
         }
       }
     }
@@ -563,7 +588,7 @@ raht_level_kernel(LevelCtx ctx)
       if (ext && nchild == 1) {
         enable_pred = false;
         neigh_count = 19;
-      } else if (ctx.nneigh[par_par][prow] < prm->raht_prediction_threshold0) {
+      } else if (par2(ctx.nneigh, par_par)[prow] < prm->raht_prediction_threshold0) {
         enable_pred = false;
       } else {
         do_search = true;
@@ -640,7 +665,7 @@ raht_level_kernel(LevelCtx ctx)
       int wsum = 0;
       if (__any(run)) {
       int64_t lim_lo = 0, lim_hi = 0;
-      const int64_t* __restrict__ prec = ctx.rec[par_par];
+      const int64_t* __restrict__ prec = par2(ctx.rec, par_par);
       const int64_t rbase = (int64_t)pt0 - sp0;
       // every lane fetches the values of the neighbours it searched (and of
       // the parent itself) in ONE round trip; the 19-step loop below then
@@ -840,7 +865,7 @@ raht_level_kernel(LevelCtx ctx)
     if (on && inherit_dc && t == 0) {
 #pragma unroll
       for (int k = 0; k < C; k++) {
-        const int64_t val = ctx.rec_us[par_par][prow * C + k];
+        const int64_t val = par2(ctx.rec_us, par_par)[prow * C + k];
         if (ext)
           pred[k] = val;
         else
@@ -879,12 +904,12 @@ raht_level_kernel(LevelCtx ctx)
 #pragma unroll
       for (int k = 0; k < C; k++) {
         int64_t v = pred[k];
-        ctx.rec_us[cur_par][crow * C + k] = ext ? v : fp_round(v * 4);
+        par2(ctx.rec_us, cur_par)[crow * C + k] = ext ? v : fp_round(v * 4);
         if (!haar && w > 1)
           v = scale_rsqrt(v, w, lut);
-        ctx.rec[cur_par][crow * C + k] = ext ? v : fp_round(v);
+        par2(ctx.rec, cur_par)[crow * C + k] = ext ? v : fp_round(v);
       }
-      ctx.nneigh[cur_par][crow] = inherit_dc ? neigh_count : 19;
+      par2(ctx.nneigh, cur_par)[crow] = inherit_dc ? neigh_count : 19;
     }
   }
 }

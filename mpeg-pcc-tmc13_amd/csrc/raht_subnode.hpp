@@ -41,6 +41,16 @@
 
 namespace gpcc {
 
+#ifdef GPCC_SUB_PROF
+// experiment only: where a wavefront's time goes (cycles of s_memtime)
+__device__ unsigned long long g_sub_prof[16 + 32 * 4];
+#define SUB_PROF_NOW() __builtin_amdgcn_s_memtime()
+#define SUB_PROF_ADD(i, v) do { if (lane == 0) atomicAdd(&g_sub_prof[i], (unsigned long long)(v)); } while (0)
+#else
+#define SUB_PROF_NOW() 0ull
+#define SUB_PROF_ADD(i, v) do { } while (0)
+#endif
+
 constexpr uint8_t kOccuShiftTab[12] = {6, 5, 4, 3, 2, 1, 3, 1, 2, 1, 2, 3};
 
 __device__ __forceinline__ int
@@ -70,6 +80,9 @@ store_agent_i64(int64_t* p, int64_t v)
 // VGPRs at 4 waves/SIMD); the kernel is bound by its dependency chains, not
 // by occupancy, so it trades a wave for registers: 1M dense C=3 forward
 // 46.2 -> 32.7 ms, 1M lidar 15.1 -> 14.6 ms (2 waves: 34.3 / 15.1).
+#ifndef GPCC_SUB_SLEEP
+#define GPCC_SUB_SLEEP 4
+#endif
 #ifndef GPCC_SUB_SYNTH3_WAVES
 #define GPCC_SUB_SYNTH3_WAVES 4
 #endif
@@ -86,7 +99,7 @@ raht_level_sub_kernel(LevelCtx ctx)
   constexpr bool kEnc = MODE != kSynth;
   constexpr bool kRecon = true;
   const TreeView& tv = ctx.tv;
-  const gpcc_raht_params* __restrict__ prm = ctx.params;
+  const ParamsConst prm = (ParamsConst)ctx.params;
   const int li = ctx.li;
   const int t = threadIdx.x & 7;
   const int lane = lane_id();
@@ -105,6 +118,8 @@ raht_level_sub_kernel(LevelCtx ctx)
     const int64_t wround = (int64_t)tk * 8 + cls;
     if (wround * 8 >= num_work)
       break;
+    const unsigned long long pr_t0 = SUB_PROF_NOW();
+    unsigned long long pr_x = 0, pr_p = 0, pr_z = 0, pr_w = 0, pr_s = 0, pr_it = 0;
     // a bounded wait has expired somewhere: the result is discarded anyway,
     // leave at once instead of spinning through every remaining round
     if (__hip_atomic_load(ctx.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
@@ -196,8 +211,8 @@ raht_level_sub_kernel(LevelCtx ctx)
       }
       // descend: the sub-tree containing this position is the RIGHT one
       // of a real pair -> its own ascent average, otherwise inherit
-      int32_t d0 = on ? ctx.dqp[par_par][prow * 2] : 0;
-      int32_t d1 = on ? ctx.dqp[par_par][prow * 2 + 1] : 0;
+      int32_t d0 = on ? par2(ctx.dqp, par_par)[prow * 2] : 0;
+      int32_t d1 = on ? par2(ctx.dqp, par_par)[prow * 2 + 1] : 0;
 #pragma unroll
       for (int st = 2; st >= 0; st--) {
         const int bit = 1 << st;
@@ -210,8 +225,8 @@ raht_level_sub_kernel(LevelCtx ctx)
         nq0 = d0 >> 4;
         nq1 = d1 >> 4;
         if (kRecon) {
-          ctx.dqp[cur_par][crow * 2] = d0;
-          ctx.dqp[cur_par][crow * 2 + 1] = d1;
+          par2(ctx.dqp, cur_par)[crow * 2] = d0;
+          par2(ctx.dqp, cur_par)[crow * 2 + 1] = d1;
         }
       }
     }
@@ -253,7 +268,7 @@ raht_level_sub_kernel(LevelCtx ctx)
       if (ext && nchild == 1) {
         enable_pred = false;
         neigh_count = 19;
-      } else if (ctx.nneigh[par_par][prow] < prm->raht_prediction_threshold0) {
+      } else if (par2(ctx.nneigh, par_par)[prow] < prm->raht_prediction_threshold0) {
         enable_pred = false;
       } else {
         do_search = true;
@@ -411,14 +426,14 @@ raht_level_sub_kernel(LevelCtx ctx)
     if (on && inherit_dc && t == 0) {
 #pragma unroll
       for (int k = 0; k < C; k++) {
-        const int64_t val = ctx.rec_us[par_par][prow * C + k];
+        const int64_t val = par2(ctx.rec_us, par_par)[prow * C + k];
         dc[k] = ext ? val
                     : (val > 0 ? val << (kFpFrac - 2) : -((-val) << (kFpFrac - 2)));
       }
     }
 
     const bool run = do_search && enable_pred;
-    const int64_t* __restrict__ prec = ctx.rec[par_par];
+    const int64_t* __restrict__ prec = par2(ctx.rec, par_par);
     const int64_t rbase = (int64_t)pt0 - sp0;
     int wsum = 0;
     int64_t lim_lo = 0, lim_hi = 0;
@@ -487,6 +502,15 @@ raht_level_sub_kernel(LevelCtx ctx)
     }
     uint32_t pend = 0;       // neighbours whose child granule is awaited
     int32_t nrow12[12];      // row of that child in rec / mbox
+    // A neighbour block claimed by THIS wavefront in this round (about 70 % of
+    // the hops on the longest chains: Morton-adjacent blocks) hands its
+    // children over through registers instead of a memory round trip:
+    // inw = awaited neighbours of that kind, wsrc = their group, 3 bits each.
+    uint32_t inw = 0, wsrc_a = 0, wsrc_b = 0;
+    int jg[8];
+#pragma unroll
+    for (int g = 0; g < 8; g++)
+      jg[g] = __shfl(on ? j : -1, g << 3);
 #pragma unroll
     for (int i12 = 0; i12 < 12; i12++) {
       nrow12[i12] = 0;
@@ -519,10 +543,21 @@ raht_level_sub_kernel(LevelCtx ctx)
             const int64_t mul = ext ? pwc : (pwc << kFpFrac);
 #pragma unroll
             for (int k = 0; k < C; k++)
-              pred[k] += ctx.rec[cur_par][nrow * C + k] * mul;
+              pred[k] += par2(ctx.rec, cur_par)[nrow * C + k] * mul;
           } else {
             nrow12[i12] = (int32_t)nrow;
             pend |= 1u << i12;
+            int pg = -1;
+#pragma unroll
+            for (int g = 0; g < 7; g++)
+              pg = q == jg[g] ? g : pg;
+            if (pg >= 0) {
+              inw |= 1u << i12;
+              if (i12 < 10)
+                wsrc_a |= (uint32_t)pg << (3 * i12);
+              else
+                wsrc_b |= (uint32_t)pg << (3 * (i12 - 10));
+            }
           }
         } else {
           const int64_t pwp = prm->pred_weight_parent[i];
@@ -549,7 +584,7 @@ raht_level_sub_kernel(LevelCtx ctx)
     int stage = on ? 0 : 3;
     unsigned spins = 0;
     int64_t pt[C];          // transformed prediction of this position
-    int32_t qc[C];          // tentative quantised coefficients (encoder)
+    int32_t qc[C];          // tentative quantised coefficients (encoder) / coded ones (decoder)
     uint32_t dr = kDescZero;  // RDOQ descriptor of rank t (lossy encoder)
     bool hyp_done = false, hyp_same = false, zr_h = false;  // cached two-hypothesis outcome
     uint32_t res_h = 0;
@@ -559,35 +594,75 @@ raht_level_sub_kernel(LevelCtx ctx)
 #pragma unroll
     for (int k = 0; k < C; k++) {
       pt[k] = 0;
-      qc[k] = 0;
+      // decoder: the coded coefficients are input -- fetched here, not on the chain
+      qc[k] = (!kEnc && coded) ? cplane[(size_t)k * n_s] : 0;
     }
+    const unsigned long long pr_t1 = SUB_PROF_NOW();
     while (__any(stage != 3)) {
       bool progressed = false;
-      // ---- (X) awaited children: the granule is data and flag at once ----
-      if (stage == 0 && pend) {
+      const unsigned long long pr_a = SUB_PROF_NOW();
+      pr_it++;
+      // ---- (X) awaited children of blocks of this wavefront: registers ----
+      if (__any(stage == 0 && inw)) {
 #pragma unroll
         for (int i12 = 0; i12 < 12; i12++) {
-          if (!((pend >> i12) & 1))
+          const bool mine = stage == 0 && ((inw >> i12) & 1);
+          if (!__any(mine))
             continue;
-          u32x4 g[C];
+          const int pg = (i12 < 10 ? wsrc_a >> (3 * i12) : wsrc_b >> (3 * (i12 - 10))) & 7;
+          const int sh = occu_shift(i12);
+          const int srcl = (pg << 3) | ((i12 < 9 ? t + sh : t - sh) & 7);
+          const int pst = __shfl(stage, srcl);
+          int64_t v[C];
 #pragma unroll
           for (int k = 0; k < C; k++)
-            g[k] = __builtin_amdgcn_raw_buffer_load_b128(
-              mrsrc, (nrow12[i12] * C + k) * 16, 0, /*sc1*/ 16);
-          bool ok = true;
-#pragma unroll
-          for (int k = 0; k < C; k++)
-            ok = ok && g[k].z == ctx.mtag;
-          if (ok) {
+            v[k] = shfl_i64(pt[k], srcl);
+          if (mine && pst == 3) {
             const int64_t pwc = prm->pred_weight_child[i12];
             const int64_t mul = ext ? pwc : (pwc << kFpFrac);
 #pragma unroll
             for (int k = 0; k < C; k++)
-              pred[k] += (int64_t)(((uint64_t)g[k].y << 32) | g[k].x) * mul;
+              pred[k] += v[k] * mul;
             pend &= ~(1u << i12);
+            inw &= ~(1u << i12);
           }
         }
       }
+      // ---- (X) the others: the granule is data and flag at once -----------
+      // One granule per lane and iteration -- the lowest awaited one -- so an
+      // iteration costs ONE memory round trip however many different
+      // neighbours the 64 lanes wait for (polling slot after slot made it
+      // as many round trips as there were slots in use).
+      const uint32_t pm = stage == 0 ? (pend & ~inw) : 0u;
+      if (pm) {
+        const int slot = __ffs(pm) - 1;
+        int32_t row = 0;
+        int64_t pwc = 0;
+#pragma unroll
+        for (int i12 = 0; i12 < 12; i12++) {
+          if (slot == i12) {
+            row = nrow12[i12];
+            pwc = prm->pred_weight_child[i12];
+          }
+        }
+        u32x4 g[C];
+#pragma unroll
+        for (int k = 0; k < C; k++)
+          g[k] = __builtin_amdgcn_raw_buffer_load_b128(mrsrc, (row * C + k) * 16, 0, /*sc1*/ 16);
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < C; k++)
+          ok = ok && g[k].z == ctx.mtag;
+        if (ok) {
+          const int64_t mul = ext ? pwc : (pwc << kFpFrac);
+#pragma unroll
+          for (int k = 0; k < C; k++)
+            pred[k] += (int64_t)(((uint64_t)g[k].y << 32) | g[k].x) * mul;
+          pend &= ~(1u << slot);
+        }
+      }
+      const unsigned long long pr_b = SUB_PROF_NOW();
+      pr_x += pr_b - pr_a;
       const bool blocked = group8_any(stage == 0 && pend);
       const bool nready = stage == 0 && !blocked;
 
@@ -690,7 +765,8 @@ raht_level_sub_kernel(LevelCtx ctx)
 #pragma unroll
           for (int k = 0; k < C; k++) {
             pt[k] = pw_[k];
-            qc[k] = qn_[k];
+            if (kEnc)
+              qc[k] = qn_[k];
           }
           dr = drn;
           stage = 1;
@@ -698,6 +774,8 @@ raht_level_sub_kernel(LevelCtx ctx)
       }
 
       // ---- (Z) RDOQ state: can the stage-1 groups commit? ----------------
+      const unsigned long long pr_c = SUB_PROF_NOW();
+      pr_p += pr_c - pr_b;
       bool can = stage == 1;
       bool zero_r = false;
       if (kLossy) {
@@ -860,6 +938,8 @@ raht_level_sub_kernel(LevelCtx ctx)
         }
       }
 
+      const unsigned long long pr_d = SUB_PROF_NOW();
+      pr_z += pr_d - pr_c;
       if (__any(can)) {
         progressed = true;
         // ---- (W) coefficients, DC, inverse transform, commit ---------------
@@ -878,7 +958,7 @@ raht_level_sub_kernel(LevelCtx ctx)
               co = zero_me ? 0 : qc[k];
               cplane[(size_t)k * n_s] = (int32_t)co;
             } else {
-              co = cplane[(size_t)k * n_s];
+              co = qc[k];
             }
             pw_[k] += fp_from_int(dequantize(qa[k ? 1 : 0], co));
           }
@@ -924,28 +1004,48 @@ raht_level_sub_kernel(LevelCtx ctx)
               v = scale_rsqrt(v, w, lut);
             v = ext ? v : fp_round(v);
             vn[k] = v;
+            pt[k] = v;  // read by later groups of this wavefront once stage == 3
             const u32x4 gr = {(uint32_t)v, (uint32_t)((uint64_t)v >> 32), ctx.mtag, 0u};
             __builtin_amdgcn_raw_buffer_store_b128(gr, mrsrc, (int)((crow * C + k) * 16), 0, /*sc1*/ 16);
           }
 #pragma unroll
           for (int k = 0; k < C; k++) {
-            ctx.rec_us[cur_par][crow * C + k] = ext ? pw_[k] : fp_round(pw_[k] * 4);
-            ctx.rec[cur_par][crow * C + k] = vn[k];
+            par2(ctx.rec_us, cur_par)[crow * C + k] = ext ? pw_[k] : fp_round(pw_[k] * 4);
+            par2(ctx.rec, cur_par)[crow * C + k] = vn[k];
           }
-          ctx.nneigh[cur_par][crow] = inherit_dc ? neigh_count : 19;
+          par2(ctx.nneigh, cur_par)[crow] = inherit_dc ? neigh_count : 19;
         }
         if (can)
           stage = 3;
       }
 
+      const unsigned long long pr_e = SUB_PROF_NOW();
+      pr_w += pr_e - pr_d;
       if (!progressed) {
+        pr_s++;
         if (++spins > (1u << 21)) {
           if (lane == 0)
             atomicExch(ctx.error, 1);  // fail loudly instead of hanging
           break;
         }
-        __builtin_amdgcn_s_sleep(4);
+        __builtin_amdgcn_s_sleep(GPCC_SUB_SLEEP);
       }
+    }
+    {
+      const unsigned long long pr_t2 = SUB_PROF_NOW();
+      SUB_PROF_ADD(0, 1);
+      SUB_PROF_ADD(1, pr_t1 - pr_t0);
+      SUB_PROF_ADD(2, pr_t2 - pr_t1);
+      SUB_PROF_ADD(3, pr_x);
+      SUB_PROF_ADD(4, pr_p);
+      SUB_PROF_ADD(5, pr_z);
+      SUB_PROF_ADD(6, pr_w);
+      SUB_PROF_ADD(7, pr_it);
+      SUB_PROF_ADD(8, pr_s);
+      SUB_PROF_ADD(16 + li * 4 + 0, 1);
+      SUB_PROF_ADD(16 + li * 4 + 1, pr_t1 - pr_t0);
+      SUB_PROF_ADD(16 + li * 4 + 2, pr_t2 - pr_t1);
+      SUB_PROF_ADD(16 + li * 4 + 3, pr_it);
     }
   }
 }
