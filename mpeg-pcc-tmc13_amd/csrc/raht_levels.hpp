@@ -240,6 +240,16 @@ neigh_offset(int i)
   return o[i];
 }
 
+// LUT_LOG[min(|q|, 15)] of the rate estimate (tmc3/RAHT.cpp:1601-1606) as
+// selects.  The estimate is only consulted when the magnitudes of a
+// coefficient sum to < 3, i.e. for |q| <= 2; a table indexed by a lane value
+// would be a vector load from constant memory on the dependency chain.
+__device__ __forceinline__ int
+rate_log_small(int64_t aq)
+{
+  return aq == 0 ? 0 : (aq == 1 ? 256 : 406);
+}
+
 // Smallest zero-run length for which RDOQ zeroes a coefficient
 // (tmc3/RAHT.cpp:1617-1637).  The rate term is a non-decreasing step
 // function of trainZeros: LUTbins for 0..10, then 12 + 2*bitlen(tz - 10).
@@ -248,13 +258,18 @@ rdoq_threshold(int64_t dist2, int64_t lambda, int rate_coeff, uint32_t limit)
 {
   const int64_t d = (int64_t)((uint64_t)dist2 << 26);
   const int rc = (rate_coeff + 128) >> 8;
-  // (first trainZeros of the class, rate of the class)
-  constexpr uint8_t tz0[7] = {0, 1, 2, 3, 5, 7, 9};
-  constexpr uint8_t rt0[7] = {1, 2, 3, 5, 7, 9, 11};
-#pragma unroll
-  for (int i = 0; i < 7; i++)
-    if (d < lambda * (rt0[i] + rc))
-      return tz0[i];
+  // (rate of the class, first trainZeros of the class) -- literal, no table
+#define GPCC_RDOQ_CLASS(rate, tz) \
+  if (d < lambda * ((rate) + rc))  \
+    return (tz);
+  GPCC_RDOQ_CLASS(1, 0)
+  GPCC_RDOQ_CLASS(2, 1)
+  GPCC_RDOQ_CLASS(3, 2)
+  GPCC_RDOQ_CLASS(5, 3)
+  GPCC_RDOQ_CLASS(7, 5)
+  GPCC_RDOQ_CLASS(9, 7)
+  GPCC_RDOQ_CLASS(11, 9)
+#undef GPCC_RDOQ_CLASS
   for (int b = 1; b < 31; b++) {
     const uint32_t tz = 10u + (1u << (b - 1));
     if (tz > limit)
@@ -827,10 +842,7 @@ raht_level_kernel(LevelCtx ctx)
             int64_t aq = quantize(qr[k ? 1 : 0], co * 256);
             aq = aq < 0 ? -aq : aq;
             sum_coeff += aq;
-            constexpr int lutlog[16] = {0,   256, 406, 512, 594, 662, 719, 768,
-                                        812, 850, 886, 918, 947, 975, 1000,
-                                        1024};
-            rate_coeff += lutlog[aq < 15 ? (int)aq : 15];
+            rate_coeff += rate_log_small(aq);
           }
           uint32_t d = kDescNever;
           if (sum_coeff < 3) {

@@ -730,10 +730,7 @@ raht_level_sub_kernel(LevelCtx ctx)
               int64_t aq = q_same ? (int64_t)qn_[k] : quantize(qr[k ? 1 : 0], co * 256);
               aq = aq < 0 ? -aq : aq;
               sum_coeff += aq;
-              constexpr int lutlog[16] = {0,   256, 406, 512, 594, 662, 719, 768,
-                                          812, 850, 886, 918, 947, 975, 1000,
-                                          1024};
-              rate_coeff += lutlog[aq < 15 ? (int)aq : 15];
+              rate_coeff += rate_log_small(aq);
             }
           }
           if (kLossy) {
