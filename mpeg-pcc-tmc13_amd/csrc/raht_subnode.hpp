@@ -18,12 +18,16 @@
 // forward transform of the source) is settled before the wait.  A
 // reconstructed child is published as ONE 16-byte write-through (sc1) store
 // {value, tag} into a mailbox next to the plain store later launches read;
-// a wave-uniform loop polls exactly the granules a block still needs
-// (cdna_hip_programming.md G16, form R2: the data is the flag -- one memory
-// round trip per dependency hop, no flag word, no drain), and finishes the
-// groups whose values have all arrived: normalise, transform, coefficients,
-// inverse, reconstruction.  Spins are bounded: a stuck launch raises
-// ctx.error instead of hanging the GPU.
+// a wave-uniform loop polls the granules a block still needs, one per lane
+// and iteration (cdna_hip_programming.md G16, form R2: the data is the flag
+// -- one memory round trip per dependency hop, no flag word, no drain), and
+// finishes the groups whose values have all arrived: normalise, transform,
+// coefficients, inverse, reconstruction.  Children of a neighbour claimed by
+// the SAME wavefront (Morton-adjacent blocks: most hops of the longest
+// chains) are taken from its registers instead.  The poll is the only
+// vector-memory wait inside the loop -- on gfx9 any s_waitcnt vmcnt(0) also
+// waits for the write-through stores in flight.  Spins
+// are bounded: a stuck launch raises ctx.error instead of hanging the GPU.
 //
 // Modes: kSynth (decoder), kFused (integer-Haar encoder) and kLossySub, the
 // lossy encoder.  There the RDOQ zero-run state (tmc3/RAHT.cpp:1618-1669)
