@@ -199,6 +199,7 @@ def main():
                 "bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
                 "traffic": pmc_traffic(args, name),
+                "traffic_collected_at_launch_us": pmc_traffic(args, name, "avg_launch_us_at_collection"),
                 "launches_per_step": dom_launches / args.steps,
                 "algorithmic_bytes_per_launch": round(alg_bytes * args.steps / dom_launches),
                 "avg_launch_us": round(dom_ms * 1e3 / dom_launches, 2),
@@ -242,17 +243,24 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic(args, kernel):
+def pmc_traffic(args, kernel, field=None):
     """HBM bytes per launch of the dominant kernel (FETCH_SIZE + WRITE_SIZE),
     from the committed rocprofv3 PMC passes of this exact workload
-    (profiles/r01_pmc_traffic.json); None for any other workload."""
+    (profiles/r01_pmc_traffic.json); None for any other workload.  `field`
+    returns another recorded value instead, e.g. the kernel's average launch
+    duration when the counters were collected (PMC passes cannot run inside
+    this process: compare it with avg_launch_us to see how current they are)."""
     path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     default = (args.cloud == "lidar" and args.points == 1_000_000 and args.frames == 1 and args.subnode == 1
                and args.qp == 34 and not args.haar and args.direction == "both")
     if not default or not os.path.exists(path):
         return None
     rec = json.load(open(path)).get(kernel)
-    return None if rec is None else rec["fetch_bytes_per_launch"] + rec["write_bytes_per_launch"]
+    if rec is None:
+        return None
+    if field:
+        return rec.get(field)
+    return rec["fetch_bytes_per_launch"] + rec["write_bytes_per_launch"]
 
 
 def lifting_leg(ctx, args):
