@@ -1413,7 +1413,6 @@ lod_build_core(
     ar_used += b;
     return p;
   };
-  auto cleanup = [&]() {};
   auto run = [&]() -> int {
     const size_t N = (size_t)n;
     const int nb0 = (n + 31) >> 5, nb1 = (nb0 + 31) >> 5, nb2 = (nb1 + 31) >> 5;

@@ -45,17 +45,43 @@
 
 namespace gpcc {
 
+// Where a wavefront's time goes (experiment builds only, -DGPCC_SUB_PROF:
+// s_memtime around the stages of the loop, summed per launch and per level
+// into g_sub_prof, read back with gpcc_debug_sub_prof).  Empty otherwise.
 #ifdef GPCC_SUB_PROF
-// experiment only: where a wavefront's time goes (cycles of s_memtime)
 __device__ unsigned long long g_sub_prof[16 + 32 * 4];
-#define SUB_PROF_NOW() __builtin_amdgcn_s_memtime()
-#define SUB_PROF_ADD(i, v) do { if (lane == 0) atomicAdd(&g_sub_prof[i], (unsigned long long)(v)); } while (0)
+struct SubProf {
+  unsigned long long t0 = 0, t1 = 0, last = 0, acc[4] = {0, 0, 0, 0}, iters = 0, idle_iters = 0;
+  __device__ static unsigned long long now() { return __builtin_amdgcn_s_memtime(); }
+  __device__ void round_begin() { t0 = now(); }
+  __device__ void loop_begin() { t1 = now(); }
+  __device__ void iter_begin() { last = now(); iters++; }
+  template<int STAGE> __device__ void mark() { const unsigned long long t = now(); acc[STAGE] += t - last; last = t; }
+  __device__ void idle() { idle_iters++; }
+  __device__ void round_end(int lane, int li)
+  {
+    if (lane != 0)
+      return;
+    const unsigned long long t2 = now();
+    const unsigned long long v[9] = {1, t1 - t0, t2 - t1, acc[0], acc[1], acc[2], acc[3], iters, idle_iters};
+    for (int i = 0; i < 9; i++)
+      atomicAdd(&g_sub_prof[i], v[i]);
+    atomicAdd(&g_sub_prof[16 + li * 4 + 0], 1ull);
+    atomicAdd(&g_sub_prof[16 + li * 4 + 1], t1 - t0);
+    atomicAdd(&g_sub_prof[16 + li * 4 + 2], t2 - t1);
+    atomicAdd(&g_sub_prof[16 + li * 4 + 3], iters);
+  }
+};
 #else
-#define SUB_PROF_NOW() 0ull
-#define SUB_PROF_ADD(i, v) do { } while (0)
+struct SubProf {
+  __device__ void round_begin() {}
+  __device__ void loop_begin() {}
+  __device__ void iter_begin() {}
+  template<int STAGE> __device__ void mark() {}
+  __device__ void idle() {}
+  __device__ void round_end(int, int) {}
+};
 #endif
-
-constexpr uint8_t kOccuShiftTab[12] = {6, 5, 4, 3, 2, 1, 3, 1, 2, 1, 2, 3};
 
 __device__ __forceinline__ int
 occu_shift(int i12)
@@ -122,8 +148,8 @@ raht_level_sub_kernel(LevelCtx ctx)
     const int64_t wround = (int64_t)tk * 8 + cls;
     if (wround * 8 >= num_work)
       break;
-    const unsigned long long pr_t0 = SUB_PROF_NOW();
-    unsigned long long pr_x = 0, pr_p = 0, pr_z = 0, pr_w = 0, pr_s = 0, pr_it = 0;
+    SubProf prof;
+    prof.round_begin();
     // a bounded wait has expired somewhere: the result is discarded anyway,
     // leave at once instead of spinning through every remaining round
     if (__hip_atomic_load(ctx.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
@@ -601,11 +627,10 @@ raht_level_sub_kernel(LevelCtx ctx)
       // decoder: the coded coefficients are input -- fetched here, not on the chain
       qc[k] = (!kEnc && coded) ? cplane[(size_t)k * n_s] : 0;
     }
-    const unsigned long long pr_t1 = SUB_PROF_NOW();
+    prof.loop_begin();
     while (__any(stage != 3)) {
       bool progressed = false;
-      const unsigned long long pr_a = SUB_PROF_NOW();
-      pr_it++;
+      prof.iter_begin();
       // ---- (X) awaited children of blocks of this wavefront: registers ----
       if (__any(stage == 0 && inw)) {
 #pragma unroll
@@ -665,8 +690,7 @@ raht_level_sub_kernel(LevelCtx ctx)
           pend &= ~(1u << slot);
         }
       }
-      const unsigned long long pr_b = SUB_PROF_NOW();
-      pr_x += pr_b - pr_a;
+      prof.mark<0>();
       const bool blocked = group8_any(stage == 0 && pend);
       const bool nready = stage == 0 && !blocked;
 
@@ -775,8 +799,7 @@ raht_level_sub_kernel(LevelCtx ctx)
       }
 
       // ---- (Z) RDOQ state: can the stage-1 groups commit? ----------------
-      const unsigned long long pr_c = SUB_PROF_NOW();
-      pr_p += pr_c - pr_b;
+      prof.mark<1>();
       bool can = stage == 1;
       bool zero_r = false;
       if (kLossy) {
@@ -939,8 +962,7 @@ raht_level_sub_kernel(LevelCtx ctx)
         }
       }
 
-      const unsigned long long pr_d = SUB_PROF_NOW();
-      pr_z += pr_d - pr_c;
+      prof.mark<2>();
       if (__any(can)) {
         progressed = true;
         // ---- (W) coefficients, DC, inverse transform, commit ---------------
@@ -1020,10 +1042,9 @@ raht_level_sub_kernel(LevelCtx ctx)
           stage = 3;
       }
 
-      const unsigned long long pr_e = SUB_PROF_NOW();
-      pr_w += pr_e - pr_d;
+      prof.mark<3>();
       if (!progressed) {
-        pr_s++;
+        prof.idle();
         if (++spins > (1u << 21)) {
           if (lane == 0)
             atomicExch(ctx.error, 1);  // fail loudly instead of hanging
@@ -1032,22 +1053,7 @@ raht_level_sub_kernel(LevelCtx ctx)
         __builtin_amdgcn_s_sleep(GPCC_SUB_SLEEP);
       }
     }
-    {
-      const unsigned long long pr_t2 = SUB_PROF_NOW();
-      SUB_PROF_ADD(0, 1);
-      SUB_PROF_ADD(1, pr_t1 - pr_t0);
-      SUB_PROF_ADD(2, pr_t2 - pr_t1);
-      SUB_PROF_ADD(3, pr_x);
-      SUB_PROF_ADD(4, pr_p);
-      SUB_PROF_ADD(5, pr_z);
-      SUB_PROF_ADD(6, pr_w);
-      SUB_PROF_ADD(7, pr_it);
-      SUB_PROF_ADD(8, pr_s);
-      SUB_PROF_ADD(16 + li * 4 + 0, 1);
-      SUB_PROF_ADD(16 + li * 4 + 1, pr_t1 - pr_t0);
-      SUB_PROF_ADD(16 + li * 4 + 2, pr_t2 - pr_t1);
-      SUB_PROF_ADD(16 + li * 4 + 3, pr_it);
-    }
+    prof.round_end(lane, li);
   }
 }
 
