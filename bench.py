@@ -8,12 +8,28 @@ every frame of the batch.  At N=1 the workload is BASELINE.json configs[1]:
 a 1M-point lidar-shaped cloud (S-lidar, 18-bit grid, reflectance, C=1),
 flags of cfg/octree-raht-ctc-lossless-geom-lossy-attrs.yaml (qp 34, search
 range 2500) and the reference's defaults for everything else, i.e.
-raht_subnode_prediction_enabled_flag = 1 (TMC3.cpp:1307).  The same frames
-with sub-node prediction switched off (blocks of a level independent) and
-the lifting path (LoD build + lifting forward/inverse, configs[2] shape)
-are reported in extra objects of the same line.  With N>1 every rank transforms its own frame(s) (weak scaling,
-frames shard one-per-GPU) and the quantised coefficients are gathered on
-rank 0 with one RCCL gather inside the timed region.
+raht_subnode_prediction_enabled_flag = 1 (TMC3.cpp:1307).
+
+Extra objects of the same JSON line (rank 0, N=1):
+  roofline          dominant kernel of the headline step, priced with the
+                    algorithmic bytes of ITS direction (SURVEY.md 8(d):
+                    forward 8+12C, inverse 8+8C bytes per point)
+  raht_forward_10M  the north-star target configuration: RAHT FORWARD of 10
+                    slices x 1M points in one batch, both states of the
+                    sub-node prediction flag, with its own roofline
+  alt_flags         the headline frames with the sub-node flag flipped
+  hbm_calibration   a device copy on this box next to the nominal 8 TB/s
+  lifting           LoD build + lifting (configs[2] shape)
+  cpu_baseline      the compiled reference on one host core and on all of
+                    them (one process per frame)
+
+With N>1 every rank transforms its own frame(s) (weak scaling: per-GPU work
+is fixed, frames shard one-per-GPU) and the quantised coefficients are
+gathered on rank 0 with one RCCL gather inside the timed region; the line
+then also carries `configs3`, the same measurement on BASELINE configs[3]'s
+2M-point dense frames.  What scales is transform + gather: the arithmetic
+coder that consumes the coefficients is the reference's CPU code and is not
+in the loop.
 
 Prints ONE JSON line (see the driver contract).  value = points entering
 the forward+inverse pass per second, whole job.
@@ -29,7 +45,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured with a float4 copy)
 
 
 def parse():
@@ -43,24 +59,89 @@ def parse():
     ap.add_argument("--qp", type=int, default=34)
     ap.add_argument("--subnode", type=int, default=1)
     ap.add_argument("--haar", type=int, default=0)
-    ap.add_argument("--direction", choices=["both", "inverse"], default="both",
+    ap.add_argument("--direction", choices=["both", "forward", "inverse"], default="both",
                     help="inverse: decoder only (coefficients prepared on the CPU outside the timed region)")
+    ap.add_argument("--configs3-points", type=int, default=2_000_000,
+                    help="points per frame of the N>1 configs[3] leg")
+    ap.add_argument("--verify-gather", action="store_true",
+                    help="N>1: rank 0 recomputes every rank's frames itself and compares with what it gathered")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the alternative-flag and lifting legs")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the alternative-flag, 10M-forward, calibration and lifting legs")
     return ap.parse_args()
 
 
-def make_frame(args, seed):
+def make_frame(cloud, points, seed):
     from mpeg_pcc_tmc13_amd import synth
-    if args.cloud == "lidar":
-        xyz, attrs = synth.lidar_cloud(args.points, seed=seed)
+    if cloud == "lidar":
+        xyz, attrs = synth.lidar_cloud(points, seed=seed)
         bits = 18
     else:
-        bits = 10 if args.points <= 1_500_000 else 12
-        xyz, attrs = synth.dense_cloud(args.points, seed=seed, bits=bits)
+        bits = 10 if points <= 1_500_000 else 12
+        xyz, attrs = synth.dense_cloud(points, seed=seed, bits=bits)
     morton, attrs, _ = synth.sort_by_morton(xyz, attrs)
     return morton, attrs, 3 * bits
+
+
+class Batch:
+    """Frames of one rank, resident in HBM, and the step over them."""
+
+    def __init__(self, torch, dev, ctx, frames, params):
+        self.torch, self.ctx, self.p = torch, ctx, params
+        self.c = frames[0][1].shape[1]
+        sizes = [len(f[0]) for f in frames]
+        self.offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        self.n = int(self.offsets[-1])
+        self.bits = frames[0][2]
+        self.d_morton = torch.from_numpy(np.concatenate([f[0] for f in frames])).to(dev)
+        self.src = torch.from_numpy(np.concatenate([f[1] for f in frames]).reshape(-1)).to(dev)
+        self.d_attrs = torch.empty_like(self.src)
+        self.d_coeffs = torch.zeros(self.c * self.n, dtype=torch.int32, device=dev)
+        self.d_dec = torch.empty_like(self.src)
+
+    def forward(self, p=None):
+        self.d_attrs.copy_(self.src)  # the transform overwrites its input with the reconstruction
+        self.ctx.set_morton_bits(self.bits)
+        self.ctx.dev_raht_forward(p or self.p, self.offsets, self.d_morton.data_ptr(),
+                                  self.d_attrs.data_ptr(), self.d_coeffs.data_ptr(), self.c)
+
+    def inverse(self, p=None):
+        self.ctx.set_morton_bits(self.bits)
+        self.ctx.dev_raht_inverse(p or self.p, self.offsets, self.d_morton.data_ptr(),
+                                  self.d_dec.data_ptr(), self.d_coeffs.data_ptr(), self.c)
+
+    def roundtrip_ok(self):
+        return bool(self.torch.equal(self.d_attrs, self.d_dec))
+
+    def bytes_forward(self):
+        return self.n * (8 + 12 * self.c)
+
+    def bytes_inverse(self):
+        return self.n * (8 + 8 * self.c)
+
+
+def timed(torch, dev, fn, steps, warmup=1):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize(dev)
+    return (time.perf_counter() - t0) / steps
+
+
+def kernel_profile(torch, dev, ctx, fn, steps):
+    """{kernel: (ms per step, launches per step)}: HIP events on the context's stream."""
+    ctx.set_profiling(True)
+    ctx.kernel_times()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize(dev)
+    kt = ctx.kernel_times()
+    ctx.set_profiling(False)
+    return {k: (v[0] / steps, v[1] / steps) for k, v in kt.items()}
 
 
 def main():
@@ -91,73 +172,79 @@ def main():
     dev = torch.device("cuda", local_rank)
     xdev = dev if backend == "nccl" else torch.device("cpu")  # where collectives operate
 
-    if args.haar:
-        p = raht_params(qp=4, haar=True, chroma_offset=0, subnode=bool(args.subnode), search_range=2500)
-    else:
-        p = raht_params(qp=args.qp, subnode=bool(args.subnode),
-                        search_range=2500 if args.cloud == "lidar" else 50000)
+    def params_for(cloud, subnode, haar=False, qp=args.qp):
+        if haar:
+            return raht_params(qp=4, haar=True, chroma_offset=0, subnode=bool(subnode), search_range=2500)
+        return raht_params(qp=qp, subnode=bool(subnode), search_range=2500 if cloud == "lidar" else 50000)
 
-    # ---- synthetic frames of this rank, resident in HBM -------------------
-    frames = [make_frame(args, seed=1 + rank * args.frames + f) for f in range(args.frames)]
-    c = frames[0][1].shape[1]
-    sizes = [len(f[0]) for f in frames]
-    offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
-    n = int(offsets[-1])
-    d_morton = torch.from_numpy(np.concatenate([f[0] for f in frames])).to(dev)
-    src = torch.from_numpy(np.concatenate([f[1] for f in frames]).reshape(-1)).to(dev)
-    d_attrs = torch.empty_like(src)
-    d_coeffs = torch.zeros(c * n, dtype=torch.int32, device=dev)
-    d_dec = torch.empty_like(src)
-    gathered = ([torch.empty_like(d_coeffs, device=xdev) for _ in range(world)]
-                if (world > 1 and rank == 0) else None)
+    p = params_for(args.cloud, args.subnode, bool(args.haar))
 
-    stream = torch.cuda.current_stream(dev)
+    # One non-default stream carries everything -- torch's copies, the
+    # library's kernels, the collective -- so the step is ordered by the
+    # stream, not by host synchronisation.
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
     ctx = context(local_rank, stream=stream.cuda_stream)
-    ctx.set_morton_bits(frames[0][2])
+
+    frames = [make_frame(args.cloud, args.points, seed=1 + rank * args.frames + f) for f in range(args.frames)]
+    b = Batch(torch, dev, ctx, frames, p)
+    c, n = b.c, b.n
 
     if args.direction == "inverse":
-        # decoder-only run (e.g. CTC flags with sub-node prediction, whose lossy
-        # forward is not on the device yet): coefficients from the CPU checker
+        # decoder-only run: coefficients from the CPU checker, outside the timed region
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_loader as ol
         chk = ol.ref() if ol.ref_available() else ol.oracle()
         cos, recs = zip(*[chk.raht_forward(p, f[0], f[1]) for f in frames])
-        d_coeffs.copy_(torch.from_numpy(np.concatenate(cos)).to(dev))
-        d_attrs.copy_(torch.from_numpy(np.concatenate(recs).reshape(-1)).to(dev))
+        b.d_coeffs.copy_(torch.from_numpy(np.concatenate(cos)).to(dev))
+        b.d_attrs.copy_(torch.from_numpy(np.concatenate(recs).reshape(-1)).to(dev))
 
-    def step():
-        if args.direction == "both":
-            d_attrs.copy_(src)  # the transform overwrites its input with the reconstruction
-            ctx.dev_raht_forward(p, offsets, d_morton.data_ptr(), d_attrs.data_ptr(), d_coeffs.data_ptr(), c)
-        ctx.dev_raht_inverse(p, offsets, d_morton.data_ptr(), d_dec.data_ptr(), d_coeffs.data_ptr(), c)
+    def gather_step(batch, gathered):
         if world > 1:
-            dist.gather(d_coeffs if backend == "nccl" else d_coeffs.cpu(), gathered, dst=0)
+            dist.gather(batch.d_coeffs if backend == "nccl" else batch.d_coeffs.cpu(), gathered, dst=0)
 
-    def fence():
-        torch.cuda.synchronize(dev)
+    def make_gather_buffers(batch):
+        return ([torch.empty_like(batch.d_coeffs, device=xdev) for _ in range(world)]
+                if (world > 1 and rank == 0) else None)
+
+    def run_timed(batch, direction, steps, warmup):
+        gathered = make_gather_buffers(batch)
+
+        def step():
+            if direction in ("both", "forward"):
+                batch.forward()
+            if direction in ("both", "inverse"):
+                batch.inverse()
+            gather_step(batch, gathered)
+
+        def fence():
+            torch.cuda.synchronize(dev)
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
+
+        for _ in range(warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        fence()
+        elapsed = time.perf_counter() - t0
+        ctx.synchronize()  # raises if any launch of the loop reported a device-side error
         if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+            t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, gathered
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
+    elapsed, gathered = run_timed(b, args.direction, args.steps, args.warmup)
     # in-run sanity: decoder output == encoder reconstruction (the
     # reference's own conformance criterion)
-    roundtrip_ok = bool(torch.equal(d_attrs, d_dec))
-
+    roundtrip_ok = b.roundtrip_ok() if args.direction != "forward" else None
     ms_per_step = elapsed / args.steps * 1e3
     value = n * world * args.steps / elapsed / 1e6
+    dir_name = {"both": "forward+inverse", "forward": "forward only", "inverse": "inverse only"}[args.direction]
 
     out = {
         "metric": "RAHT forward+inverse attribute-transform Mpoints/s (bit-exact vs CPU reference)",
@@ -166,7 +253,7 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "int64 (Q15 fixed point), int32 I/O",
         "data": "synthetic",
         "config": {
-            "workload": f"RAHT {'forward+inverse' if args.direction == 'both' else 'inverse only'}, {args.frames}x{args.points}-point Morton-sorted "
+            "workload": f"RAHT {dir_name}, {args.frames}x{args.points}-point Morton-sorted "
                         f"S-{args.cloud} frame(s) per GPU, C={c}, "
                         + ("integer Haar qp 4" if args.haar else f"qp {args.qp}")
                         + f", raht_prediction=1, raht_subnode_prediction={int(args.subnode)}, raht_extension=1",
@@ -174,65 +261,60 @@ def main():
             "roundtrip_decoder_equals_encoder_recon": roundtrip_ok,
         },
     }
+    if world > 1:
+        out["config"]["scaling_scope"] = ("transform + one RCCL gather of the coefficient buffers; the CPU "
+                                          "arithmetic coder that consumes them is not in the loop")
+
+    if world > 1 and args.verify_gather and rank == 0 and args.direction != "inverse":
+        # what rank 0 gathered is what a single GPU computes for the same frames
+        same = True
+        for r in range(world):
+            fr = [make_frame(args.cloud, args.points, seed=1 + r * args.frames + f) for f in range(args.frames)]
+            br = Batch(torch, dev, ctx, fr, p)
+            br.forward()
+            torch.cuda.synchronize(dev)
+            same = same and bool(torch.equal(br.d_coeffs.to(xdev), gathered[r]))
+            del br
+        out["config"]["gathered_equals_single_rank"] = same
+
+    if world > 1 and not args.no_extras:
+        # ---- BASELINE configs[3]: 2M-point dense frames, one per GPU ------
+        f3 = [make_frame("dense", args.configs3_points, seed=101 + rank)]
+        b3 = Batch(torch, dev, ctx, f3, params_for("dense", 1))
+        k3 = 5
+        el3, _ = run_timed(b3, "both", k3, 1)
+        npts = torch.tensor([b3.n], dtype=torch.float64, device=xdev)
+        dist.all_reduce(npts, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            out["configs3"] = {
+                "workload": f"{world} x {args.configs3_points}-point S-dense colour frames (C=3, default flags), one per GPU, "
+                            "forward+inverse + RCCL gather of the coefficients",
+                "value": round(float(npts.item()) * k3 / el3 / 1e6, 3), "unit": "Mpoints/s",
+                "ms_per_step": round(el3 / k3 * 1e3, 3), "steps": k3,
+                "roundtrip_decoder_equals_encoder_recon": b3.roundtrip_ok()}
+        del b3
 
     if rank == 0 and world == 1:
-        # ---- per-kernel durations: HIP events on the context's stream -----
         if not args.no_profile:
-            ctx.set_profiling(True)
-            ctx.kernel_times()
-            for _ in range(args.steps):
-                step()
-            torch.cuda.synchronize(dev)
-            kt = ctx.kernel_times()
-            ctx.set_profiling(False)
-            total_ms = sum(v[0] for v in kt.values())
-            name, (dom_ms, dom_launches) = max(kt.items(), key=lambda kv: kv[1][0])
-            # algorithmic bytes of one step: forward
-            # (8 + 12 C) B/pt + inverse (8 + 8 C) B/pt; the level kernels
-            # are where attributes and coefficients are consumed/produced,
-            # so one step's launches of the dominant kernel are priced as
-            # one pass over those bytes
-            alg_bytes = n * (((8 + 12 * c) if args.direction == 'both' else 0) + (8 + 8 * c))
-            dom_s = dom_ms / 1e3 / args.steps
-            achieved = alg_bytes / dom_s / 1e9
-            out["roofline"] = {
-                "bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
-                "traffic": pmc_traffic(args, name),
-                "traffic_collected_at_launch_us": pmc_traffic(args, name, "avg_launch_us_at_collection"),
-                "launches_per_step": dom_launches / args.steps,
-                "algorithmic_bytes_per_launch": round(alg_bytes * args.steps / dom_launches),
-                "avg_launch_us": round(dom_ms * 1e3 / dom_launches, 2),
-                "pipeline_achieved": round(alg_bytes / (ms_per_step / 1e3) / 1e9, 2),
-                "pipeline_frac": round(alg_bytes / (ms_per_step / 1e3) / 1e9 / HBM_PEAK_GBPS, 5),
-                "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(kt.items(), key=lambda kv: -kv[1][0])},
-                "kernel_sum_ms_per_step": round(total_ms / args.steps, 4),
-            }
-        # ---- the same frames with sub-node prediction switched OFF -----------
-        # (blocks of a level are then independent: no dependency chain)
+            out["roofline"] = roofline(torch, dev, ctx, b, args)
         if not args.no_extras and args.direction == "both":
-            p1 = p.copy()
-            p1.raht_subnode_prediction_enabled_flag = 0 if args.subnode else 1
+            # ---- the same frames with the sub-node flag flipped ------------
+            p1 = params_for(args.cloud, 0 if args.subnode else 1, bool(args.haar))
+
             def step1():
-                d_attrs.copy_(src)
-                ctx.dev_raht_forward(p1, offsets, d_morton.data_ptr(), d_attrs.data_ptr(), d_coeffs.data_ptr(), c)
-                ctx.dev_raht_inverse(p1, offsets, d_morton.data_ptr(), d_dec.data_ptr(), d_coeffs.data_ptr(), c)
-            step1()
-            torch.cuda.synchronize(dev)
-            k1 = 10 if args.subnode else 3
-            t1 = time.perf_counter()
-            for _ in range(k1):
-                step1()
-            torch.cuda.synchronize(dev)
-            dt1 = (time.perf_counter() - t1) / k1
+                b.forward(p1)
+                b.inverse(p1)
+            k1 = 10
+            dt1 = timed(torch, dev, step1, k1)
             out["alt_flags"] = {
                 "raht_subnode_prediction": int(p1.raht_subnode_prediction_enabled_flag),
                 "value": round(n / dt1 / 1e6, 3), "unit": "Mpoints/s",
                 "ms_per_step": round(dt1 * 1e3, 3), "steps": k1,
-                "roundtrip_decoder_equals_encoder_recon": bool(torch.equal(d_attrs, d_dec))}
+                "roundtrip_decoder_equals_encoder_recon": b.roundtrip_ok()}
         if not args.no_extras:
+            out["raht_forward_10M"] = forward_10m(torch, dev, ctx, params_for, frames)
+            out["hbm_calibration"] = hbm_calibration(torch, dev)
             out["lifting"] = lifting_leg(ctx, args)
-        # ---- CPU baseline: the compiled reference on one host core --------
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames[0], p, c)
 
@@ -243,14 +325,102 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic(args, kernel, field=None):
+def roofline(torch, dev, ctx, b, args):
+    """Dominant kernel of the headline step.  Forward and inverse are profiled
+    separately (HIP events on the context's stream), so every kernel is priced
+    with the algorithmic bytes of its own direction; one launch is credited
+    with that direction's bytes / its launches per pass."""
+    steps = max(3, min(args.steps, 10))
+    prof = {}
+    if args.direction in ("both", "forward"):
+        prof["forward"] = (kernel_profile(torch, dev, ctx, b.forward, steps), b.bytes_forward())
+    if args.direction in ("both", "inverse"):
+        if args.direction == "inverse":
+            pass
+        else:
+            b.forward()
+        prof["inverse"] = (kernel_profile(torch, dev, ctx, b.inverse, steps), b.bytes_inverse())
+    dom = None
+    for direction, (kt, nbytes) in prof.items():
+        for k, (ms, launches) in kt.items():
+            if dom is None or ms > dom[2]:
+                dom = (direction, k, ms, launches, nbytes)
+    direction, name, ms, launches, nbytes = dom
+    achieved = nbytes / (ms / 1e3) / 1e9
+    total_ms = sum(ms_ for kt, _ in prof.values() for ms_, _ in kt.values())
+    total_bytes = sum(nb for _, nb in prof.values())
+    res = {
+        "bound": "hbm", "kernel": name, "direction": direction,
+        "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBPS, 5),
+        "traffic": pmc_traffic(args, name),
+        "launches_per_step": round(launches, 2),
+        "algorithmic_bytes_per_launch": round(nbytes / launches),
+        "avg_launch_us": round(ms * 1e3 / launches, 2),
+        "pipeline_achieved": round(total_bytes / (total_ms / 1e3) / 1e9, 2),
+        "pipeline_frac": round(total_bytes / (total_ms / 1e3) / 1e9 / HBM_PEAK_GBPS, 5),
+    }
+    for direction, (kt, nbytes) in prof.items():
+        res[f"{direction}_kernel_ms"] = {k: round(v[0], 4) for k, v in sorted(kt.items(), key=lambda kv: -kv[1][0])}
+        res[f"{direction}_launches"] = round(sum(v[1] for v in kt.values()), 1)
+    return res
+
+
+def forward_10m(torch, dev, ctx, params_for, first_frames):
+    """The north-star target configuration: RAHT FORWARD of 10 slices of 1M
+    points (a 10M-point frame as the reference would slice it) in
+    one batch, inputs resident in HBM; reference default flags and the
+    sub-node flag off."""
+    frames = list(first_frames[:1]) if len(first_frames[0][0]) >= 900_000 and first_frames[0][1].shape[1] == 1 else []
+    while len(frames) < 10:
+        frames.append(make_frame("lidar", 1_000_000, seed=1 + len(frames)))
+    res = {"workload": "RAHT forward (coefficients + reconstruction), 10 x 1M-point S-lidar slices in one batch, "
+                       "C=1, qp 34, search range 2500", "bytes_per_point": 20}
+    for sub in (1, 0):
+        p = params_for("lidar", sub)
+        b = Batch(torch, dev, ctx, frames, p)
+        k = 5
+        dt = timed(torch, dev, b.forward, k, warmup=2)
+        ctx.synchronize()
+        kt = kernel_profile(torch, dev, ctx, b.forward, 3)
+        name, (ms, launches) = max(kt.items(), key=lambda kv: kv[1][0])
+        nbytes = b.bytes_forward()
+        achieved = nbytes / (ms / 1e3) / 1e9
+        res[f"subnode_{sub}"] = {
+            "value": round(b.n / dt / 1e6, 2), "unit": "Mpoints/s", "ms_per_forward": round(dt * 1e3, 3),
+            "steps": k, "launches_per_forward": round(sum(v[1] for v in kt.values()), 1),
+            "roofline": {
+                "bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
+                "launches_per_forward": round(launches, 1),
+                "algorithmic_bytes_per_launch": round(nbytes / launches),
+                "avg_launch_us": round(ms * 1e3 / launches, 2),
+                "pipeline_achieved": round(nbytes / dt / 1e9, 2),
+                "pipeline_frac": round(nbytes / dt / 1e9 / HBM_PEAK_GBPS, 5)},
+            "kernel_ms": {k_: round(v[0], 4) for k_, v in sorted(kt.items(), key=lambda kv: -kv[1][0])},
+        }
+        del b
+    return res
+
+
+def hbm_calibration(torch, dev):
+    """What a plain device copy reaches on THIS box (read + write bytes / time,
+    1 GiB), next to the nominal peak the roofline fractions are quoted against."""
+    nbytes = 1 << 30
+    a = torch.empty(nbytes // 4, dtype=torch.int32, device=dev).fill_(1)
+    c = torch.empty_like(a)
+    dt = timed(torch, dev, lambda: c.copy_(a), 10, warmup=2)
+    return {"copy_GBps": round(2 * nbytes / dt / 1e9, 1), "bytes": nbytes,
+            "nominal_peak_GBps": HBM_PEAK_GBPS,
+            "note": "torch device-to-device copy, read + write bytes; roofline.frac uses the nominal peak"}
+
+
+def pmc_traffic(args, kernel):
     """HBM bytes per launch of the dominant kernel (FETCH_SIZE + WRITE_SIZE),
     from the committed rocprofv3 PMC passes of this exact workload
-    (profiles/r01_pmc_traffic.json); None for any other workload.  `field`
-    returns another recorded value instead, e.g. the kernel's average launch
-    duration when the counters were collected (PMC passes cannot run inside
-    this process: compare it with avg_launch_us to see how current they are)."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    (profiles/r02_pmc_traffic.json); None for any other workload or kernel.
+    PMC passes cannot run inside this process."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     default = (args.cloud == "lidar" and args.points == 1_000_000 and args.frames == 1 and args.subnode == 1
                and args.qp == 34 and not args.haar and args.direction == "both")
     if not default or not os.path.exists(path):
@@ -258,8 +428,6 @@ def pmc_traffic(args, kernel, field=None):
     rec = json.load(open(path)).get(kernel)
     if rec is None:
         return None
-    if field:
-        return rec.get(field)
     return rec["fetch_bytes_per_launch"] + rec["write_bytes_per_launch"]
 
 
@@ -311,27 +479,83 @@ def lifting_leg(ctx, args):
     return res
 
 
+_CPU = {}
+
+
+def _cpu_init(path):
+    """Start-up of one process of the all-cores CPU baseline (outside the
+    timing): load the checker library and the frame."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import __graft_entry__ as ge
+    ge.load_package()
+    import oracle_loader as ol
+    from mpeg_pcc_tmc13_amd import raht_params
+    z = np.load(path)
+    _CPU["p"] = raht_params(qp=int(z["qp"]), subnode=bool(z["subnode"]), search_range=int(z["search_range"]))
+    _CPU["chk"] = ol.ref() if ol.ref_available() else ol.oracle()
+    _CPU["morton"], _CPU["attrs"] = np.ascontiguousarray(z["morton"]), np.ascontiguousarray(z["attrs"])
+
+
+def _cpu_worker(_):
+    """forward + inverse of the frame with the compiled reference (or the C port)"""
+    t0 = time.perf_counter()
+    co, rec = _CPU["chk"].raht_forward(_CPU["p"], _CPU["morton"], _CPU["attrs"])
+    _CPU["chk"].raht_inverse(_CPU["p"], _CPU["morton"], co, _CPU["attrs"].shape[1])
+    return time.perf_counter() - t0
+
+
 def cpu_baseline(frame, p, c):
     """oracle/_ref (the reference's own RAHT.cpp, -O3) forward+inverse on the
-    same frame, one core; falls back to the C oracle port if the compiled
-    reference did not travel."""
+    same frame: one core, then every host core (one process per frame -- the
+    reference is serial code, slices / frames are its unit of parallelism);
+    falls back to the C oracle port if the compiled reference did not travel."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_loader as ol
     morton, attrs, _ = frame
     kind = "reference" if ol.ref_available() else "port"
     chk = ol.ref() if kind == "reference" else ol.oracle()
     n = len(morton)
-    # bounded sample: the whole frame, repeated until about 10 s of CPU work
+    # bounded sample: the whole frame, repeated until about 8 s of CPU work
     reps, dt = 0, 0.0
     t0 = time.perf_counter()
-    while reps < 12 and dt < 10.0:
+    while reps < 12 and dt < 8.0:
         co, rec = chk.raht_forward(p, morton, attrs)
         chk.raht_inverse(p, morton, co, c)
         reps += 1
         dt = time.perf_counter() - t0
-    return {"value": round(n * reps / dt / 1e6, 4), "unit": "Mpoints/s", "cores": 1, "kind": kind,
-            "sample": f"forward+inverse of frame 0 ({n} points, same flags) x {reps}, "
-                      f"{dt:.1f} s wall, host {os.cpu_count()} logical cores, 1 used"}
+    res = {"value": round(n * reps / dt / 1e6, 4), "unit": "Mpoints/s", "cores": 1, "kind": kind,
+           "sample": f"forward+inverse of frame 0 ({n} points, same flags) x {reps}, "
+                     f"{dt:.1f} s wall, host {os.cpu_count()} logical cores, 1 used"}
+    # all cores: one process per core, each transforming the same frame
+    try:
+        import multiprocessing as mp
+        import tempfile
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            cores = os.cpu_count() or 1
+        try:  # the reference keeps ~0.5 GB per 1M-point frame: stay far inside the host's memory
+            import psutil
+            cores = max(1, min(cores, int(psutil.virtual_memory().available // (2 << 30))))
+        except ImportError:
+            cores = min(cores, 32)
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, "frame.npz")
+            np.savez(path, morton=morton, attrs=attrs, qp=p.layer_qp[0][0],
+                     subnode=p.raht_subnode_prediction_enabled_flag,
+                     search_range=p.raht_prediction_search_range)
+            mpc = mp.get_context("spawn")  # a fresh interpreter per worker: no HIP state is inherited
+            with mpc.Pool(cores, initializer=_cpu_init, initargs=(path,)) as pool:
+                t0 = time.perf_counter()
+                busy = pool.map(_cpu_worker, range(cores), chunksize=1)
+                wall = time.perf_counter() - t0
+        res["all_cores"] = {"value": round(n * cores / wall / 1e6, 3), "unit": "Mpoints/s", "cores": cores,
+                            "sample": f"{cores} processes x 1 forward+inverse of the same frame, {wall:.1f} s wall "
+                                      f"(mean {np.mean(busy):.1f} s per process)"}
+    except Exception as e:  # the one-core figure stands on its own
+        res["all_cores"] = {"error": repr(e)}
+    return res
 
 
 if __name__ == "__main__":

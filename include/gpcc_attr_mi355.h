@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GPCC_ABI_VERSION 1
+#define GPCC_ABI_VERSION 2
 #define GPCC_MAX_POINTS (1 << 29) /* 32-bit device indices, stride <= 3 */
 
 #define GPCC_MAX_QP_LAYERS 32
@@ -88,8 +88,12 @@ int gpcc_device_count(void);
 typedef struct gpcc_ctx gpcc_ctx; /* opaque: device, stream, workspace */
 
 /* Create a context bound to HIP device `device`.  `stream` is a
- * hipStream_t passed as void* (NULL = the library creates its own
- * non-blocking stream).  Workspace grows on demand and is reused. */
+ * hipStream_t passed as void*: NULL = the library creates its own
+ * non-blocking stream; to run on the legacy default stream (the one a null
+ * hipStream_t means in a launch) pass GPCC_STREAM_LEGACY, HIP's
+ * hipStreamLegacy handle.  Work the caller queues on ANOTHER stream is not
+ * ordered against the context's.  Workspace grows on demand and is reused. */
+#define GPCC_STREAM_LEGACY ((void*)1)
 int gpcc_ctx_create(int device, void* stream, gpcc_ctx** out);
 void gpcc_ctx_destroy(gpcc_ctx* ctx);
 /* Block until all work queued by this context has completed. */
@@ -100,6 +104,19 @@ size_t gpcc_ctx_workspace_bytes(const gpcc_ctx* ctx);
  * bits) of the batches that follow; 0 = unknown (63).  Bounds the number of
  * octree levels that are launched; the host tier derives it itself. */
 int gpcc_ctx_set_morton_bits(gpcc_ctx* ctx, int32_t bits);
+
+/* What the context's entries have done since it was created -- lets an
+ * integrator (and tests/test_shim_dropin.py) tell the device path from a
+ * fallback to the reference's CPU function: the replacement translation
+ * units (the files under shim/) call the reference only when an entry returns non-zero,
+ * and every such return is counted here. */
+typedef struct gpcc_ctx_stats_t {
+  int64_t calls_ok;          /* entries that returned GPCC_OK                 */
+  int64_t calls_unsupported; /* returned GPCC_ERR_UNSUPPORTED (CPU keeps it)  */
+  int64_t calls_failed;      /* returned any other error                      */
+  int64_t points_ok;         /* points processed by the successful entries    */
+} gpcc_ctx_stats_t;
+int gpcc_ctx_stats(const gpcc_ctx* ctx, gpcc_ctx_stats_t* out);
 
 /* ------------------------------------------------------------------ */
 /* host tier: one slice, host buffers, synchronous                      */

@@ -15,7 +15,7 @@ ABI_SYMBOLS = [
     "gpcc_ctx_synchronize", "gpcc_ctx_workspace_bytes", "gpcc_ctx_set_morton_bits",
     "gpcc_raht_forward", "gpcc_raht_inverse", "gpcc_attr_morton_sort",
     "gpcc_dev_raht_forward", "gpcc_dev_raht_inverse", "gpcc_dev_attr_morton_sort",
-    "gpcc_ctx_set_profiling", "gpcc_ctx_kernel_times",
+    "gpcc_ctx_set_profiling", "gpcc_ctx_kernel_times", "gpcc_ctx_stats",
     "gpcc_lift_forward", "gpcc_lift_inverse", "gpcc_lod_compute_weights", "gpcc_lod_build", "gpcc_estimate_dist2", "gpcc_raht_encode_attr", "gpcc_raht_decode_attr",
     "gpcc_lift_encode_attr", "gpcc_lift_decode_attr", "gpcc_zero_run_pack", "gpcc_raht_encode_attr_packed",
 ]
@@ -25,6 +25,11 @@ class GpccError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"gpcc error {code}: {msg}")
         self.code = code
+
+
+class CtxStats(C.Structure):
+    _fields_ = [("calls_ok", C.c_int64), ("calls_unsupported", C.c_int64),
+                ("calls_failed", C.c_int64), ("points_ok", C.c_int64)]
 
 
 class KernelTime(C.Structure):
@@ -65,6 +70,7 @@ def load():
     lib.gpcc_ctx_set_morton_bits.argtypes = [vp, i32]
     lib.gpcc_ctx_set_profiling.argtypes = [vp, C.c_int]
     lib.gpcc_ctx_kernel_times.argtypes = [vp, C.POINTER(KernelTime), i32]
+    lib.gpcc_ctx_stats.argtypes = [vp, C.POINTER(CtxStats)]
     lib.gpcc_raht_set_prediction_weights.argtypes = [pp, C.POINTER(i32)]
     lib.gpcc_raht_set_prediction_weights.restype = None
     for name in ("gpcc_raht_forward", "gpcc_raht_inverse"):

@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -32,6 +33,7 @@
 #include "raht_levels.hpp"
 #include "raht_rdoq.hpp"
 #include "raht_subnode.hpp"
+#include "raht_tile.hpp"
 #include "raht_tree.hpp"
 #include "lift_kernels.hpp"
 #include "lod_kernels.hpp"
@@ -99,7 +101,21 @@ struct gpcc_ctx {
   Arena arena;
   int morton_bits = 0;  // hint for the device tier, 0 = unknown
   SharedLut* d_lut = nullptr;  // small-weight tables, built once
-  int32_t* h_error = nullptr;  // pinned: device-side error word of the last call
+  int32_t* h_error = nullptr;  // pinned: copy of the sticky device-side error word
+  int32_t* d_error = nullptr;  // device: set by a kernel whose bounded wait expired, cleared
+                               // only when the error has been reported (check_device_error)
+  TreeStats* h_stats = nullptr;   // pinned: what schedule_kernel tells the host about the tree
+  hipEvent_t ev_stats = nullptr;  // recorded behind schedule_kernel
+  bool legacy_levels = false;     // GPCC_LEGACY_LEVELS=1: the round-1 level kernels (A/B timing)
+  // what the entries did since the context was created (gpcc_ctx_stats)
+  gpcc_ctx_stats_t stats{};
+  // device buffers of the host tiers, kept between calls (pool_malloc)
+  struct PoolBlock {
+    void* ptr;
+    size_t cap;
+    bool used;
+  };
+  std::vector<PoolBlock> pool;
   // host staging for the host tier
   void* h_pinned = nullptr;
   size_t h_pinned_cap = 0;
@@ -169,6 +185,7 @@ struct Plan {
   SliceSched* sched = nullptr;
   gpcc_raht_params* params = nullptr;
   uint32_t* desc = nullptr;
+  int64_t* ptrans = nullptr;
   int32_t* rtile_base = nullptr;
   int2* rtile_sum = nullptr;
   int32_t* rtile_lin = nullptr;
@@ -202,6 +219,7 @@ carve(Arena& ar, Plan& pl)
       cap = std::min<int64_t>(cap, full);
     }
     pl.cap[li] = cap;
+    pl.tv.cap[li] = (int32_t)cap;
     pl.tv.key[li] = ar.take<int64_t>(cap + 1);
     pl.tv.fp[li] = ar.take<int32_t>(cap + 2);
     pl.tv.fc[li] = ar.take<int32_t>(cap + 2);
@@ -216,7 +234,7 @@ carve(Arena& ar, Plan& pl)
   pl.tile_attr = ar.take<int32_t>((size_t)pl.tv.num_tiles * c);
   pl.sched = ar.take<SliceSched>(s);
   pl.worklist = ar.take<int32_t>((size_t)n + 1);
-  pl.work_count = ar.take<int32_t>(kMaxLevels * 9 + 1);
+  pl.work_count = ar.take<int32_t>(kMaxLevels * 9);
   pl.scan_state = ar.take<unsigned long long>(1024);
   pl.pocc = pl.sub ? ar.take<uint8_t>((size_t)n + 1) : nullptr;
   pl.mbox = pl.sub ? ar.take<uint32_t>((size_t)n * c * 4) : nullptr;
@@ -248,13 +266,63 @@ carve(Arena& ar, Plan& pl)
       pl.asc_qp[li] = ar.take<int32_t>((size_t)(pl.cap[li] + 1) * 2);
   }
   pl.desc = nullptr;
+  pl.ptrans = nullptr;
   if (pl.lossy) {
     pl.desc = ar.take<uint32_t>(n);
+    pl.ptrans = pl.sub ? nullptr : ar.take<int64_t>((size_t)n * c);
     pl.rtile_base = ar.take<int32_t>(s + 1);
     pl.rtile_sum = ar.take<int2>(pl.num_rtiles + 1);
     pl.rtile_lin = ar.take<int32_t>(pl.num_rtiles + 1);
     pl.slice_l = ar.take<int32_t>(2 * (size_t)s);  // sub-node path: [level parity][S]
   }
+}
+
+// Device buffers of the host tiers (uploads, downloads, scratch): a caching
+// allocator instead of hipMalloc / hipFree per call -- in a steady state
+// (slice after slice of similar size) no call allocates.  Reuse is safe without
+// a synchronisation: all work of a context is ordered on its one stream.
+hipError_t
+pool_malloc(gpcc_ctx* ctx, void** out, size_t bytes)
+{
+  bytes = std::max<size_t>(bytes, 256);
+  gpcc_ctx::PoolBlock* best = nullptr;
+  for (auto& b : ctx->pool)
+    if (!b.used && b.cap >= bytes && b.cap <= 2 * bytes + (1 << 20)
+        && (!best || b.cap < best->cap))
+      best = &b;
+  if (best) {
+    best->used = true;
+    *out = best->ptr;
+    return hipSuccess;
+  }
+  // a miss: the sizes have changed, drop what is idle before growing
+  hipStreamSynchronize(ctx->stream);
+  for (size_t i = 0; i < ctx->pool.size();) {
+    if (!ctx->pool[i].used) {
+      hipFree(ctx->pool[i].ptr);
+      ctx->pool.erase(ctx->pool.begin() + i);
+    } else {
+      i++;
+    }
+  }
+  const size_t cap = bytes + bytes / 8;
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, cap);
+  if (e != hipSuccess)
+    return e;
+  ctx->pool.push_back({p, cap, true});
+  *out = p;
+  return hipSuccess;
+}
+
+void
+pool_free(gpcc_ctx* ctx, void* p)
+{
+  if (!p)
+    return;
+  for (auto& b : ctx->pool)
+    if (b.ptr == p)
+      b.used = false;
 }
 
 int
@@ -337,6 +405,7 @@ launch_transform(
     HIP_TRY(stage(pl.asc_qp.data(), nlev * sizeof(void*), pl.asc_qp_tab));
 
   pl.tv.pos = d_morton;
+  pl.tv.error = ctx->d_error;
   const TreeView tv = pl.tv;
 
   // ---- tree ------------------------------------------------------------
@@ -356,11 +425,15 @@ launch_transform(
     tree_emit_kernel<C><<<grid_for(tv.num_tiles, 4), 256, 0, st>>>(
       tv, sum_attrs, pl.tile_cnt, pl.tile_attr, pl.attr_prefix);
   }
+  // levels the coarse kernel may take: a slice's top levels with at most
+  // kCoarseTiles tiles of parents each (sub-node prediction has its own path)
+  const bool tiles = !pl.sub && !ctx->legacy_levels;
   {
     Timer t(ctx, "schedule");
-    schedule_kernel<<<(s + 63) / 64, 64, 0, st>>>(
-      tv, pl.sched, hp->num_qp_layers);
+    schedule_kernel<<<1, 256, 0, st>>>(
+      tv, pl.sched, hp->num_qp_layers, tiles ? kCoarseTiles * kTileT : 0, ctx->h_stats);
   }
+  HIP_TRY(hipEventRecord(ctx->ev_stats, st));
 
   // ---- non-associative ascent (integer Haar / region QP) ----------------
   if ((encoder && pl.haar) || pl.has_qp) {
@@ -401,6 +474,7 @@ launch_transform(
   }
   lc.coeffs = d_coeffs;
   lc.desc = pl.desc;
+  lc.ptrans = pl.ptrans;
   lc.lut = ctx->d_lut;
   lc.worklist = pl.worklist;
   lc.work_count = pl.work_count;
@@ -408,8 +482,8 @@ launch_transform(
   lc.pocc = pl.pocc;
   lc.mbox = pl.mbox;
   lc.ticket = pl.work_count + kMaxLevels;
-  lc.error = pl.work_count + kMaxLevels * 9;
-  HIP_TRY(hipMemsetAsync(pl.work_count, 0, (kMaxLevels * 9 + 1) * sizeof(int32_t), st));
+  lc.error = ctx->d_error;
+  HIP_TRY(hipMemsetAsync(pl.work_count, 0, kMaxLevels * 9 * sizeof(int32_t), st));
   HIP_TRY(hipMemsetAsync(pl.scan_state, 0, 1024 * sizeof(unsigned long long), st));
   if (pl.mbox)  // tags of a call are li + 1 >= 1
     HIP_TRY(hipMemsetAsync(pl.mbox, 0, (size_t)n * C * 4 * sizeof(uint32_t), st));
@@ -433,18 +507,80 @@ launch_transform(
     HIP_TRY(hipMemsetAsync(pl.slice_l, 0xff, 2 * (size_t)s * sizeof(int32_t), st));
   }
 
-  for (int li = nlev - 2; li >= 0; li--) {
+  // ---- the coarse levels of every slice: one launch ----------------------
+  if (tiles) {
+    lc.li = 0;
+    const int cgrid = std::min(s, 2048);
+    if (!encoder) {
+      Timer t(ctx, "coarse_synth");
+      raht_coarse_kernel<C, kCoarseDecode><<<cgrid, 1024, 0, st>>>(lc);
+    } else if (pl.haar) {
+      Timer t(ctx, "coarse_fused");
+      raht_coarse_kernel<C, kCoarseHaar><<<cgrid, 1024, 0, st>>>(lc);
+    } else {
+      Timer t(ctx, "coarse_lossy");
+      raht_coarse_kernel<C, kCoarseLossy><<<cgrid, 1024, 0, st>>>(lc);
+    }
+  }
+
+  // The host learns the shape of the tree while the coarse kernel runs: the
+  // remaining launches are sized by the real node counts and levels no slice
+  // needs are not launched at all.
+  HIP_TRY(hipEventSynchronize(ctx->ev_stats));
+  const TreeStats ts = *ctx->h_stats;
+  const int first_level = std::min(nlev - 1, tiles ? ts.fine_levels : ts.max_top);
+
+  for (int li = first_level - 1; li >= 0; li--) {
     lc.li = li;
     lc.mtag = (uint32_t)(li + 1);
+    const int64_t parents = ts.nodes[li + 1];
+    if (tiles) {
+      const int ntiles = (int)((parents + kTileT - 1) / kTileT);
+      const int tgrid = std::min((ntiles + 7) / 8 * 8, kLevelGridMax);
+      if (!encoder) {
+        Timer t(ctx, "tile_synth");
+        raht_tile_kernel<C, kSynth><<<tgrid, 256, 0, st>>>(lc);
+      } else if (pl.haar) {
+        Timer t(ctx, "tile_fused");
+        raht_tile_kernel<C, kFused><<<tgrid, 256, 0, st>>>(lc);
+      } else {
+        {
+          Timer t(ctx, "tile_analyze");
+          raht_tile_kernel<C, kAnalyze><<<tgrid, 256, 0, st>>>(lc);
+        }
+        rc.li = li;
+        // tiles that can intersect this level's coefficients
+        const int64_t lvl_coeffs = ts.nodes[li];
+        const int rgrid =
+          grid_for(std::min<int64_t>(pl.num_rtiles, lvl_coeffs / kRdoqTile + 2 * s), 4);
+        {
+          Timer t(ctx, "rdoq_classify");
+          rdoq_classify_kernel<<<rgrid, 256, 0, st>>>(rc);
+        }
+        {
+          Timer t(ctx, "rdoq_carry");
+          rdoq_carry_kernel<<<std::min(s, 1024), 64, 0, st>>>(rc);
+        }
+        {
+          Timer t(ctx, "rdoq_apply");
+          rdoq_apply_kernel<<<rgrid, 256, 0, st>>>(rc);
+        }
+        {
+          Timer t(ctx, "tile_synth_rec");
+          raht_tile_kernel<C, kSynthRec><<<tgrid, 256, 0, st>>>(lc);
+        }
+      }
+      continue;
+    }
     // many small workgroups: the cost of a round varies by an order of
     // magnitude (single-child copies vs predicted blocks), the hardware
     // dispatcher evens it out
     const int grid = (int)std::min<int64_t>(
       kLevelGridMax,
-      ((pl.cap[li + 1] + 32 * kRoundsPerGroup - 1) / (32 * kRoundsPerGroup) + 7) / 8 * 8);
+      ((parents + 32 * kRoundsPerGroup - 1) / (32 * kRoundsPerGroup) + 7) / 8 * 8);
     {
       Timer t(ctx, "level_prepass");
-      raht_level_prepass_kernel<C><<<(int)std::min<int64_t>((pl.cap[li + 1] + 1023) / 1024, 1024), 256, 0, st>>>(lc);
+      raht_level_prepass_kernel<C><<<(int)std::min<int64_t>((parents + 1023) / 1024, 1024), 256, 0, st>>>(lc);
     }
     if (pl.sub && !encoder) {
       Timer t(ctx, "level_sub_synth");
@@ -467,8 +603,7 @@ launch_transform(
         raht_level_kernel<C, kAnalyze><<<grid, 256, 0, st>>>(lc);
       }
       rc.li = li;
-      // tiles that can intersect this level's coefficients
-      const int64_t lvl_coeffs = pl.cap[li];
+      const int64_t lvl_coeffs = ts.nodes[li];
       const int rgrid =
         grid_for(std::min<int64_t>(pl.num_rtiles, lvl_coeffs / kRdoqTile + 2 * s), 4);
       {
@@ -513,7 +648,7 @@ launch_transform(
     finish_kernel<C><<<grid_for(pl.cap[0], 256), 256, 0, st>>>(fc);
   }
   if (ctx->h_error)
-    HIP_TRY(hipMemcpyAsync(ctx->h_error, lc.error, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(ctx->h_error, ctx->d_error, sizeof(int32_t), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipGetLastError());
   return GPCC_OK;
 }
@@ -522,7 +657,17 @@ int
 check_device_error(gpcc_ctx* ctx)
 {
   if (ctx->h_error && *ctx->h_error) {
+    // sticky on the device: every call since the failure copied the same word;
+    // reported once, then cleared on both sides
+    const int code = *ctx->h_error;
     *ctx->h_error = 0;
+    hipMemsetAsync(ctx->d_error, 0, sizeof(int32_t), ctx->stream);
+    if (code == 2)
+      return fail(
+        GPCC_ERR_INVALID_ARG,
+        "the Morton codes are wider than gpcc_ctx_set_morton_bits said (or a "
+        "slice is not sorted): more than one node at the top level; the result "
+        "is invalid");
     return fail(
       GPCC_ERR_HIP,
       "a dependency wait in the sub-node prediction kernel expired; the "
@@ -619,18 +764,18 @@ host_transform(
   int64_t* d_m = nullptr;
   int32_t *d_q = nullptr, *d_a = nullptr, *d_c = nullptr;
   auto cleanup = [&]() {
-    hipFree(d_m);
-    hipFree(d_q);
-    hipFree(d_a);
-    hipFree(d_c);
+    pool_free(ctx, d_m);
+    pool_free(ctx, d_q);
+    pool_free(ctx, d_a);
+    pool_free(ctx, d_c);
   };
   auto run = [&]() -> int {
-    HIP_TRY(hipMalloc((void**)&d_m, sizeof(int64_t) * n));
-    HIP_TRY(hipMalloc((void**)&d_a, sizeof(int32_t) * n * c));
-    HIP_TRY(hipMalloc((void**)&d_c, sizeof(int32_t) * n * c));
+    HIP_TRY(pool_malloc(ctx, (void**)&d_m, sizeof(int64_t) * n));
+    HIP_TRY(pool_malloc(ctx, (void**)&d_a, sizeof(int32_t) * n * c));
+    HIP_TRY(pool_malloc(ctx, (void**)&d_c, sizeof(int32_t) * n * c));
     HIP_TRY(hipMemcpyAsync(d_m, morton, sizeof(int64_t) * n, hipMemcpyHostToDevice, st));
     if (qp_off) {
-      HIP_TRY(hipMalloc((void**)&d_q, sizeof(int32_t) * n * 2));
+      HIP_TRY(pool_malloc(ctx, (void**)&d_q, sizeof(int32_t) * n * 2));
       HIP_TRY(hipMemcpyAsync(d_q, qp_off, sizeof(int32_t) * n * 2, hipMemcpyHostToDevice, st));
     }
     if (encoder) {
@@ -645,11 +790,18 @@ host_transform(
       ctx, params, encoder, 1, offs, d_m, d_q, d_a, d_c, c, std::max(bits, 1));
     if (r)
       return r;
+    // the caller's buffers are written only once the transform is known to
+    // have succeeded: on any failure `attrs` still holds the source, so the
+    // caller can hand the slice to the reference CPU function
+    HIP_TRY(hipStreamSynchronize(st));
+    r = check_device_error(ctx);
+    if (r)
+      return r;
     HIP_TRY(hipMemcpyAsync(attrs, d_a, sizeof(int32_t) * n * c, hipMemcpyDeviceToHost, st));
     if (encoder)
       HIP_TRY(hipMemcpyAsync(coeffs, d_c, sizeof(int32_t) * n * c, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    return check_device_error(ctx);
+    return GPCC_OK;
   };
   int r = run();
   cleanup();
@@ -982,10 +1134,18 @@ gpcc_ctx_create(int device, void* stream, gpcc_ctx** out)
     return fail(GPCC_ERR_OUT_OF_MEMORY, "hipMalloc(lut)");
   }
   lut_init_kernel<<<1, 256, 0, ctx->stream>>>(ctx->d_lut);
-  if (hipHostMalloc((void**)&ctx->h_error, sizeof(int32_t)) == hipSuccess)
-    *ctx->h_error = 0;
-  else
-    ctx->h_error = nullptr;
+  if (hipMalloc((void**)&ctx->d_error, sizeof(int32_t)) != hipSuccess
+      || hipMemsetAsync(ctx->d_error, 0, sizeof(int32_t), ctx->stream) != hipSuccess
+      || hipHostMalloc((void**)&ctx->h_error, sizeof(int32_t)) != hipSuccess
+      || hipHostMalloc((void**)&ctx->h_stats, sizeof(TreeStats)) != hipSuccess
+      || hipEventCreateWithFlags(&ctx->ev_stats, hipEventDisableTiming) != hipSuccess) {
+    gpcc_ctx_destroy(ctx);
+    return fail(GPCC_ERR_OUT_OF_MEMORY, "context bookkeeping allocations failed");
+  }
+  *ctx->h_error = 0;
+  memset(ctx->h_stats, 0, sizeof(TreeStats));
+  const char* legacy = getenv("GPCC_LEGACY_LEVELS");
+  ctx->legacy_levels = legacy && legacy[0] == '1';
   *out = ctx;
   return GPCC_OK;
 }
@@ -1005,10 +1165,19 @@ gpcc_ctx_destroy(gpcc_ctx* ctx)
     hipEventDestroy(e);
   if (ctx->arena.base)
     hipFree(ctx->arena.base);
+  for (auto& b : ctx->pool)
+    hipFree(b.ptr);
+  ctx->pool.clear();
   if (ctx->d_lut)
     hipFree(ctx->d_lut);
   if (ctx->h_error)
     hipHostFree(ctx->h_error);
+  if (ctx->d_error)
+    hipFree(ctx->d_error);
+  if (ctx->h_stats)
+    hipHostFree(ctx->h_stats);
+  if (ctx->ev_stats)
+    hipEventDestroy(ctx->ev_stats);
   if (ctx->h_pinned)
     hipHostFree(ctx->h_pinned);
   if (ctx->own_stream)
@@ -1023,6 +1192,15 @@ gpcc_ctx_synchronize(gpcc_ctx* ctx)
     return fail(GPCC_ERR_INVALID_ARG, "ctx is null");
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return check_device_error(ctx);
+}
+
+int
+gpcc_ctx_stats(const gpcc_ctx* ctx, gpcc_ctx_stats_t* out)
+{
+  if (!ctx || !out)
+    return fail(GPCC_ERR_INVALID_ARG, "ctx / out is null");
+  *out = ctx->stats;
+  return GPCC_OK;
 }
 
 size_t
@@ -1085,16 +1263,16 @@ gpcc_ctx_kernel_times(gpcc_ctx* ctx, gpcc_kernel_time* out, int32_t max_entries)
   return nout;
 }
 
-int
-gpcc_raht_forward(
+static int
+gpcc_raht_forward_impl(
   gpcc_ctx* ctx, const gpcc_raht_params* params, const int64_t* morton,
   const int32_t* qp_off, int32_t* attrs, int32_t* coeffs, int32_t n, int32_t c)
 {
   return host_transform(ctx, params, true, morton, qp_off, attrs, coeffs, n, c);
 }
 
-int
-gpcc_raht_inverse(
+static int
+gpcc_raht_inverse_impl(
   gpcc_ctx* ctx, const gpcc_raht_params* params, const int64_t* morton,
   const int32_t* qp_off, int32_t* attrs, const int32_t* coeffs, int32_t n,
   int32_t c)
@@ -1103,8 +1281,8 @@ gpcc_raht_inverse(
     ctx, params, false, morton, qp_off, attrs, const_cast<int32_t*>(coeffs), n, c);
 }
 
-int
-gpcc_dev_raht_forward(
+static int
+gpcc_dev_raht_forward_impl(
   gpcc_ctx* ctx, const gpcc_raht_params* params, int32_t num_slices,
   const int64_t* offsets, const void* d_morton, const void* d_qp_off,
   void* d_attrs, void* d_coeffs, int32_t c)
@@ -1114,8 +1292,8 @@ gpcc_dev_raht_forward(
     d_coeffs, c, ctx ? ctx->morton_bits : 0);
 }
 
-int
-gpcc_dev_raht_inverse(
+static int
+gpcc_dev_raht_inverse_impl(
   gpcc_ctx* ctx, const gpcc_raht_params* params, int32_t num_slices,
   const int64_t* offsets, const void* d_morton, const void* d_qp_off,
   void* d_attrs, const void* d_coeffs, int32_t c)
@@ -1125,8 +1303,8 @@ gpcc_dev_raht_inverse(
     const_cast<void*>(d_coeffs), c, ctx ? ctx->morton_bits : 0);
 }
 
-int
-gpcc_dev_attr_morton_sort(
+static int
+gpcc_dev_attr_morton_sort_impl(
   gpcc_ctx* ctx, int32_t num_slices, const int64_t* offsets, const void* d_xyz,
   void* d_morton, void* d_order)
 {
@@ -1240,8 +1418,8 @@ gpcc_dev_attr_morton_sort(
   return GPCC_OK;
 }
 
-int
-gpcc_attr_morton_sort(
+static int
+gpcc_attr_morton_sort_impl(
   gpcc_ctx* ctx, const int32_t* xyz, int32_t n, int64_t* morton, int32_t* order)
 {
   if (!ctx)
@@ -1262,19 +1440,19 @@ gpcc_attr_morton_sort(
   int64_t* d_m = nullptr;
   int32_t* d_o = nullptr;
   auto cleanup = [&]() {
-    hipFree(d_x);
-    hipFree(d_m);
-    hipFree(d_o);
+    pool_free(ctx, d_x);
+    pool_free(ctx, d_m);
+    pool_free(ctx, d_o);
   };
   auto run = [&]() -> int {
-    HIP_TRY(hipMalloc((void**)&d_x, sizeof(int32_t) * 3 * n));
-    HIP_TRY(hipMalloc((void**)&d_m, sizeof(int64_t) * n));
-    HIP_TRY(hipMalloc((void**)&d_o, sizeof(int32_t) * n));
+    HIP_TRY(pool_malloc(ctx, (void**)&d_x, sizeof(int32_t) * 3 * n));
+    HIP_TRY(pool_malloc(ctx, (void**)&d_m, sizeof(int64_t) * n));
+    HIP_TRY(pool_malloc(ctx, (void**)&d_o, sizeof(int32_t) * n));
     HIP_TRY(hipMemcpyAsync(d_x, xyz, sizeof(int32_t) * 3 * n, hipMemcpyHostToDevice, st));
     const int saved = ctx->morton_bits;
     ctx->morton_bits = std::max(1, 3 * bitlen64((uint64_t)mx));
     const int64_t offs[2] = {0, n};
-    int r = gpcc_dev_attr_morton_sort(ctx, 1, offs, d_x, d_m, d_o);
+    int r = gpcc_dev_attr_morton_sort_impl(ctx, 1, offs, d_x, d_m, d_o);
     ctx->morton_bits = saved;
     if (r)
       return r;
@@ -1288,8 +1466,8 @@ gpcc_attr_morton_sort(
   return r;
 }
 
-int
-gpcc_lift_forward(
+static int
+gpcc_lift_forward_impl(
   gpcc_ctx* ctx, const gpcc_lift_params* params, int32_t n, int32_t c,
   const int32_t* neigh_count, const int32_t* neigh_index,
   const int32_t* neigh_weight, const int32_t* indexes, const int32_t* qp_off,
@@ -1300,8 +1478,8 @@ gpcc_lift_forward(
     qp_off, attrs, coeffs, lcp_coeffs);
 }
 
-int
-gpcc_lift_inverse(
+static int
+gpcc_lift_inverse_impl(
   gpcc_ctx* ctx, const gpcc_lift_params* params, int32_t n, int32_t c,
   const int32_t* neigh_count, const int32_t* neigh_index,
   const int32_t* neigh_weight, const int32_t* indexes, const int32_t* qp_off,
@@ -1312,8 +1490,8 @@ gpcc_lift_inverse(
     qp_off, attrs, const_cast<int32_t*>(coeffs), const_cast<int8_t*>(lcp_coeffs));
 }
 
-int
-gpcc_lod_compute_weights(
+static int
+gpcc_lod_compute_weights_impl(
   gpcc_ctx* ctx, int32_t n, int32_t* neigh_count, const uint64_t* dist2,
   int32_t* neigh_weight)
 {
@@ -1460,7 +1638,7 @@ lod_build_core(
       const int saved = ctx->morton_bits;
       ctx->morton_bits = std::max(1, 3 * bitlen64((uint64_t)mx));
       const int64_t offs[2] = {0, n};
-      int r = gpcc_dev_attr_morton_sort(ctx, 1, offs, d_xyz, d_code, d_order);
+      int r = gpcc_dev_attr_morton_sort_impl(ctx, 1, offs, d_xyz, d_code, d_order);
       ctx->morton_bits = saved;
       if (r)
         return r;
@@ -1694,8 +1872,8 @@ lod_build_core(
 
 extern "C" {
 
-int
-gpcc_lod_build(
+static int
+gpcc_lod_build_impl(
   gpcc_ctx* ctx, const gpcc_lod_params* lp, const int32_t* xyz, int32_t n,
   int32_t* neigh_count, int32_t* neigh_index, int32_t* neigh_weight,
   int32_t* indexes, int32_t* num_points_in_lod, int32_t* num_lods)
@@ -1799,16 +1977,16 @@ lift_attr_driver(
   return GPCC_OK;
 }
 
-int
-gpcc_lift_encode_attr(
+static int
+gpcc_lift_encode_attr_impl(
   gpcc_ctx* ctx, const gpcc_lod_params* lod, gpcc_lift_params* lift, const int32_t* xyz,
   int32_t* attrs, int32_t* coeffs, int8_t* lcp_coeffs, int32_t* indexes, int32_t n, int32_t c)
 {
   return lift_attr_driver(ctx, true, lod, lift, xyz, attrs, coeffs, lcp_coeffs, indexes, n, c);
 }
 
-int
-gpcc_lift_decode_attr(
+static int
+gpcc_lift_decode_attr_impl(
   gpcc_ctx* ctx, const gpcc_lod_params* lod, gpcc_lift_params* lift, const int32_t* xyz,
   int32_t* attrs, const int32_t* coeffs, const int8_t* lcp_coeffs, int32_t* indexes, int32_t n,
   int32_t c)
@@ -1852,28 +2030,28 @@ slice_driver(
   int64_t* d_m = nullptr;
   char* d_pack = nullptr;
   auto cleanup = [&]() {
-    hipFree(d_pack);
-    hipFree(d_xyz);
-    hipFree(d_order);
-    hipFree(d_pt);
-    hipFree(d_a);
-    hipFree(d_c);
-    hipFree(d_m);
+    pool_free(ctx, d_pack);
+    pool_free(ctx, d_xyz);
+    pool_free(ctx, d_order);
+    pool_free(ctx, d_pt);
+    pool_free(ctx, d_a);
+    pool_free(ctx, d_c);
+    pool_free(ctx, d_m);
   };
   auto run = [&]() -> int {
-    HIP_TRY(hipMalloc((void**)&d_xyz, sizeof(int32_t) * 3 * N));
-    HIP_TRY(hipMalloc((void**)&d_order, sizeof(int32_t) * N));
-    HIP_TRY(hipMalloc((void**)&d_m, sizeof(int64_t) * N));
-    HIP_TRY(hipMalloc((void**)&d_pt, sizeof(int32_t) * N * c));
-    HIP_TRY(hipMalloc((void**)&d_a, sizeof(int32_t) * N * c));
-    HIP_TRY(hipMalloc((void**)&d_c, sizeof(int32_t) * N * c));
+    HIP_TRY(pool_malloc(ctx, (void**)&d_xyz, sizeof(int32_t) * 3 * N));
+    HIP_TRY(pool_malloc(ctx, (void**)&d_order, sizeof(int32_t) * N));
+    HIP_TRY(pool_malloc(ctx, (void**)&d_m, sizeof(int64_t) * N));
+    HIP_TRY(pool_malloc(ctx, (void**)&d_pt, sizeof(int32_t) * N * c));
+    HIP_TRY(pool_malloc(ctx, (void**)&d_a, sizeof(int32_t) * N * c));
+    HIP_TRY(pool_malloc(ctx, (void**)&d_c, sizeof(int32_t) * N * c));
     HIP_TRY(hipMemcpyAsync(d_xyz, xyz, sizeof(int32_t) * 3 * N, hipMemcpyHostToDevice, st));
     const int bits = std::max(1, 3 * bitlen64((uint64_t)mx));
     const int64_t offs[2] = {0, n};
     {
       const int saved = ctx->morton_bits;
       ctx->morton_bits = bits;
-      int r = gpcc_dev_attr_morton_sort(ctx, 1, offs, d_xyz, d_m, d_order);
+      int r = gpcc_dev_attr_morton_sort_impl(ctx, 1, offs, d_xyz, d_m, d_order);
       ctx->morton_bits = saved;
       if (r)
         return r;
@@ -1896,9 +2074,6 @@ slice_driver(
       attr_clip_scatter_kernel<<<grid_for(n, 256), 256, 0, st>>>(
         n, c, (1 << bitdepth) - 1, d_order, d_a, d_pt);
     }
-    HIP_TRY(hipMemcpyAsync(attrs, d_pt, sizeof(int32_t) * N * c, hipMemcpyDeviceToHost, st));
-    if (encoder && !packed)
-      HIP_TRY(hipMemcpyAsync(coeffs, d_c, sizeof(int32_t) * N * c, hipMemcpyDeviceToHost, st));
     if (packed) {
       // zero-run formation where the coefficients are: only symbols cross PCIe
       Arena ar;
@@ -1909,7 +2084,7 @@ slice_driver(
       ar.take<uint8_t>(N);          // flags
       ar.take<int32_t>(64);
       ar.take<unsigned long long>(1024);
-      HIP_TRY(hipMalloc((void**)&d_pack, ar.used));
+      HIP_TRY(pool_malloc(ctx, (void**)&d_pack, ar.used));
       ar.base = d_pack;
       ar.reset();
       int32_t* d_pos = ar.take<int32_t>(N);
@@ -1940,8 +2115,17 @@ slice_driver(
       *num_symbols = h[0];
       *trailing_run = h[1];
     }
+    // the caller's attributes are overwritten only after the device result is
+    // known to be valid (on failure they still hold the source)
     HIP_TRY(hipStreamSynchronize(st));
-    return check_device_error(ctx);
+    r = check_device_error(ctx);
+    if (r)
+      return r;
+    HIP_TRY(hipMemcpyAsync(attrs, d_pt, sizeof(int32_t) * N * c, hipMemcpyDeviceToHost, st));
+    if (encoder && !packed)
+      HIP_TRY(hipMemcpyAsync(coeffs, d_c, sizeof(int32_t) * N * c, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return GPCC_OK;
   };
   int r = run();
   cleanup();
@@ -1949,8 +2133,8 @@ slice_driver(
 }
 }  // namespace
 
-int
-gpcc_raht_encode_attr_packed(
+static int
+gpcc_raht_encode_attr_packed_impl(
   gpcc_ctx* ctx, const gpcc_raht_params* params, const int32_t* xyz, int32_t* attrs,
   int32_t* runs, int32_t* values, int32_t* num_symbols, int32_t* trailing_run, int32_t n,
   int32_t c, int32_t bitdepth)
@@ -1961,16 +2145,16 @@ gpcc_raht_encode_attr_packed(
     ctx, params, true, xyz, attrs, nullptr, n, c, bitdepth, runs, values, num_symbols, trailing_run);
 }
 
-int
-gpcc_raht_encode_attr(
+static int
+gpcc_raht_encode_attr_impl(
   gpcc_ctx* ctx, const gpcc_raht_params* params, const int32_t* xyz,
   int32_t* attrs, int32_t* coeffs, int32_t n, int32_t c, int32_t bitdepth)
 {
   return slice_driver(ctx, params, true, xyz, attrs, coeffs, n, c, bitdepth);
 }
 
-int
-gpcc_raht_decode_attr(
+static int
+gpcc_raht_decode_attr_impl(
   gpcc_ctx* ctx, const gpcc_raht_params* params, const int32_t* xyz,
   int32_t* attrs, const int32_t* coeffs, int32_t n, int32_t c, int32_t bitdepth)
 {
@@ -1978,8 +2162,8 @@ gpcc_raht_decode_attr(
     ctx, params, false, xyz, attrs, const_cast<int32_t*>(coeffs), n, c, bitdepth);
 }
 
-int
-gpcc_zero_run_pack(
+static int
+gpcc_zero_run_pack_impl(
   gpcc_ctx* ctx, const int32_t* coeffs, int32_t n, int32_t c, int32_t planar,
   int32_t* runs, int32_t* values, int32_t* num_symbols, int32_t* trailing_run)
 {
@@ -2038,8 +2222,8 @@ gpcc_zero_run_pack(
   return GPCC_OK;
 }
 
-int
-gpcc_estimate_dist2(
+static int
+gpcc_estimate_dist2_impl(
   gpcc_ctx* ctx, const int32_t* xyz, int32_t n, int32_t sampling_period,
   int32_t search_range, float percentile, int32_t* shift_bits)
 {
@@ -2061,8 +2245,8 @@ gpcc_estimate_dist2(
   std::vector<long long> dists((size_t)ns);
   int rc = GPCC_OK;
   do {
-    if (hipMalloc((void**)&d_xyz, sizeof(int32_t) * 3 * (size_t)n) != hipSuccess
-        || hipMalloc((void**)&d_dist, sizeof(long long) * (size_t)ns) != hipSuccess) {
+    if (pool_malloc(ctx, (void**)&d_xyz, sizeof(int32_t) * 3 * (size_t)n) != hipSuccess
+        || pool_malloc(ctx, (void**)&d_dist, sizeof(long long) * (size_t)ns) != hipSuccess) {
       rc = fail(GPCC_ERR_OUT_OF_MEMORY, "hipMalloc(estimate_dist2)");
       break;
     }
@@ -2089,8 +2273,8 @@ gpcc_estimate_dist2(
       ++shift;
     *shift_bits = shift;
   } while (0);
-  hipFree(d_xyz);
-  hipFree(d_dist);
+  pool_free(ctx, d_xyz);
+  pool_free(ctx, d_dist);
   return rc;
 }
 
@@ -2110,3 +2294,169 @@ gpcc_debug_sub_prof(unsigned long long* out, int reset)
   return 0;
 }
 #endif
+
+// every entry reports its outcome to the context's counters (gpcc_ctx_stats)
+static int
+counted(gpcc_ctx* ctx, int rc, int64_t points)
+{
+  if (ctx) {
+    if (rc == GPCC_OK) {
+      ctx->stats.calls_ok++;
+      ctx->stats.points_ok += points;
+    } else if (rc == GPCC_ERR_UNSUPPORTED) {
+      ctx->stats.calls_unsupported++;
+    } else {
+      ctx->stats.calls_failed++;
+    }
+  }
+  return rc;
+}
+
+extern "C" {
+
+int
+gpcc_raht_forward(
+  gpcc_ctx* ctx, const gpcc_raht_params* params, const int64_t* morton,
+  const int32_t* qp_off, int32_t* attrs, int32_t* coeffs, int32_t n, int32_t c)
+{
+  return counted(ctx, gpcc_raht_forward_impl(ctx, params, morton, qp_off, attrs, coeffs, n, c), n);
+}
+
+int
+gpcc_raht_inverse(
+  gpcc_ctx* ctx, const gpcc_raht_params* params, const int64_t* morton,
+  const int32_t* qp_off, int32_t* attrs, const int32_t* coeffs, int32_t n,
+  int32_t c)
+{
+  return counted(ctx, gpcc_raht_inverse_impl(ctx, params, morton, qp_off, attrs, coeffs, n, c), n);
+}
+
+int
+gpcc_dev_raht_forward(
+  gpcc_ctx* ctx, const gpcc_raht_params* params, int32_t num_slices,
+  const int64_t* offsets, const void* d_morton, const void* d_qp_off,
+  void* d_attrs, void* d_coeffs, int32_t c)
+{
+  return counted(ctx, gpcc_dev_raht_forward_impl(ctx, params, num_slices, offsets, d_morton, d_qp_off, d_attrs, d_coeffs, c), (offsets && num_slices > 0 ? offsets[num_slices] : 0));
+}
+
+int
+gpcc_dev_raht_inverse(
+  gpcc_ctx* ctx, const gpcc_raht_params* params, int32_t num_slices,
+  const int64_t* offsets, const void* d_morton, const void* d_qp_off,
+  void* d_attrs, const void* d_coeffs, int32_t c)
+{
+  return counted(ctx, gpcc_dev_raht_inverse_impl(ctx, params, num_slices, offsets, d_morton, d_qp_off, d_attrs, d_coeffs, c), (offsets && num_slices > 0 ? offsets[num_slices] : 0));
+}
+
+int
+gpcc_dev_attr_morton_sort(
+  gpcc_ctx* ctx, int32_t num_slices, const int64_t* offsets, const void* d_xyz,
+  void* d_morton, void* d_order)
+{
+  return counted(ctx, gpcc_dev_attr_morton_sort_impl(ctx, num_slices, offsets, d_xyz, d_morton, d_order), (offsets && num_slices > 0 ? offsets[num_slices] : 0));
+}
+
+int
+gpcc_attr_morton_sort(
+  gpcc_ctx* ctx, const int32_t* xyz, int32_t n, int64_t* morton, int32_t* order)
+{
+  return counted(ctx, gpcc_attr_morton_sort_impl(ctx, xyz, n, morton, order), n);
+}
+
+int
+gpcc_lift_forward(
+  gpcc_ctx* ctx, const gpcc_lift_params* params, int32_t n, int32_t c,
+  const int32_t* neigh_count, const int32_t* neigh_index,
+  const int32_t* neigh_weight, const int32_t* indexes, const int32_t* qp_off,
+  int32_t* attrs, int32_t* coeffs, int8_t* lcp_coeffs)
+{
+  return counted(ctx, gpcc_lift_forward_impl(ctx, params, n, c, neigh_count, neigh_index, neigh_weight, indexes, qp_off, attrs, coeffs, lcp_coeffs), n);
+}
+
+int
+gpcc_lift_inverse(
+  gpcc_ctx* ctx, const gpcc_lift_params* params, int32_t n, int32_t c,
+  const int32_t* neigh_count, const int32_t* neigh_index,
+  const int32_t* neigh_weight, const int32_t* indexes, const int32_t* qp_off,
+  int32_t* attrs, const int32_t* coeffs, const int8_t* lcp_coeffs)
+{
+  return counted(ctx, gpcc_lift_inverse_impl(ctx, params, n, c, neigh_count, neigh_index, neigh_weight, indexes, qp_off, attrs, coeffs, lcp_coeffs), n);
+}
+
+int
+gpcc_lod_compute_weights(
+  gpcc_ctx* ctx, int32_t n, int32_t* neigh_count, const uint64_t* dist2,
+  int32_t* neigh_weight)
+{
+  return counted(ctx, gpcc_lod_compute_weights_impl(ctx, n, neigh_count, dist2, neigh_weight), n);
+}
+
+int
+gpcc_lod_build(
+  gpcc_ctx* ctx, const gpcc_lod_params* lp, const int32_t* xyz, int32_t n,
+  int32_t* neigh_count, int32_t* neigh_index, int32_t* neigh_weight,
+  int32_t* indexes, int32_t* num_points_in_lod, int32_t* num_lods)
+{
+  return counted(ctx, gpcc_lod_build_impl(ctx, lp, xyz, n, neigh_count, neigh_index, neigh_weight, indexes, num_points_in_lod, num_lods), n);
+}
+
+int
+gpcc_lift_encode_attr(
+  gpcc_ctx* ctx, const gpcc_lod_params* lod, gpcc_lift_params* lift, const int32_t* xyz,
+  int32_t* attrs, int32_t* coeffs, int8_t* lcp_coeffs, int32_t* indexes, int32_t n, int32_t c)
+{
+  return counted(ctx, gpcc_lift_encode_attr_impl(ctx, lod, lift, xyz, attrs, coeffs, lcp_coeffs, indexes, n, c), n);
+}
+
+int
+gpcc_lift_decode_attr(
+  gpcc_ctx* ctx, const gpcc_lod_params* lod, gpcc_lift_params* lift, const int32_t* xyz,
+  int32_t* attrs, const int32_t* coeffs, const int8_t* lcp_coeffs, int32_t* indexes, int32_t n,
+  int32_t c)
+{
+  return counted(ctx, gpcc_lift_decode_attr_impl(ctx, lod, lift, xyz, attrs, coeffs, lcp_coeffs, indexes, n, c), n);
+}
+
+int
+gpcc_raht_encode_attr_packed(
+  gpcc_ctx* ctx, const gpcc_raht_params* params, const int32_t* xyz, int32_t* attrs,
+  int32_t* runs, int32_t* values, int32_t* num_symbols, int32_t* trailing_run, int32_t n,
+  int32_t c, int32_t bitdepth)
+{
+  return counted(ctx, gpcc_raht_encode_attr_packed_impl(ctx, params, xyz, attrs, runs, values, num_symbols, trailing_run, n, c, bitdepth), n);
+}
+
+int
+gpcc_raht_encode_attr(
+  gpcc_ctx* ctx, const gpcc_raht_params* params, const int32_t* xyz,
+  int32_t* attrs, int32_t* coeffs, int32_t n, int32_t c, int32_t bitdepth)
+{
+  return counted(ctx, gpcc_raht_encode_attr_impl(ctx, params, xyz, attrs, coeffs, n, c, bitdepth), n);
+}
+
+int
+gpcc_raht_decode_attr(
+  gpcc_ctx* ctx, const gpcc_raht_params* params, const int32_t* xyz,
+  int32_t* attrs, const int32_t* coeffs, int32_t n, int32_t c, int32_t bitdepth)
+{
+  return counted(ctx, gpcc_raht_decode_attr_impl(ctx, params, xyz, attrs, coeffs, n, c, bitdepth), n);
+}
+
+int
+gpcc_zero_run_pack(
+  gpcc_ctx* ctx, const int32_t* coeffs, int32_t n, int32_t c, int32_t planar,
+  int32_t* runs, int32_t* values, int32_t* num_symbols, int32_t* trailing_run)
+{
+  return counted(ctx, gpcc_zero_run_pack_impl(ctx, coeffs, n, c, planar, runs, values, num_symbols, trailing_run), n);
+}
+
+int
+gpcc_estimate_dist2(
+  gpcc_ctx* ctx, const int32_t* xyz, int32_t n, int32_t sampling_period,
+  int32_t search_range, float percentile, int32_t* shift_bits)
+{
+  return counted(ctx, gpcc_estimate_dist2_impl(ctx, xyz, n, sampling_period, search_range, percentile, shift_bits), n);
+}
+
+}  // extern "C"

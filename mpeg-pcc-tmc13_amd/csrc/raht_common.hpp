@@ -46,7 +46,18 @@ struct TreeView {
   int32_t* fp[kMaxLevels];
   int32_t* fc[kMaxLevels];
   int32_t* soff[kMaxLevels];
+  int32_t cap[kMaxLevels];  // nodes the arrays of each level were sized for
+  int32_t* error;           // the context's sticky error word (0 = fine)
 };
+
+// A kernel of a call whose tree does not fit its arrays (or of any call behind
+// an unreported failure) must not touch memory through that tree's indices:
+// every kernel behind tree_scan leaves at once while the error word is set.
+__device__ __forceinline__ bool
+tree_failed(const TreeView& tv)
+{
+  return __hip_atomic_load(tv.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+}
 
 // Per (slice, level) processing schedule, derived on the device from the
 // node counts (tmc3/RAHT.cpp:1165-1265: which levels run the block loop,
@@ -58,7 +69,17 @@ struct LevelSched {
   uint8_t qp_layer;
   int8_t ac_layer;
   uint8_t parity;      // reconstruction buffer written by this level
-  uint8_t pad[3];
+  uint8_t coarse;      // processed inside raht_coarse_kernel (raht_tile.hpp), not by a level launch
+  uint8_t pad[2];
+};
+
+// What the host needs from the tree to size and skip the level launches,
+// written by schedule_kernel into pinned host memory (the host waits for an
+// event recorded right behind it while the coarse kernel runs).
+struct TreeStats {
+  int32_t fine_levels;       // levels li < fine_levels still need a launch for some slice
+  int32_t max_top;           // largest top_level of a slice
+  int32_t nodes[kMaxLevels]; // nodes per level, all slices
 };
 
 struct SliceSched {

@@ -30,6 +30,8 @@ __global__ __launch_bounds__(256) void
 ascend_leaf_kernel(AscendCtx cx)
 {
   const TreeView& tv = cx.tv;
+  if (tree_failed(tv))
+    return;
   const int m = tv.soff[0][tv.num_slices];
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < m;
        j += gridDim.x * blockDim.x) {
@@ -59,6 +61,8 @@ __global__ __launch_bounds__(256) void
 ascend_level_kernel(AscendCtx cx)
 {
   const TreeView& tv = cx.tv;
+  if (tree_failed(tv))
+    return;
   const int li = cx.li;
   const int m = tv.soff[li][tv.num_slices];
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < m;
@@ -137,7 +141,7 @@ qp_root_kernel(AscendCtx cx, const SliceSched* sched)
 {
   const TreeView& tv = cx.tv;
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= tv.num_slices)
+  if (s >= tv.num_slices || tree_failed(tv))
     return;
   const int top = sched[s].top_level;
   const int node = tv.soff[top][s];
@@ -168,6 +172,8 @@ __global__ __launch_bounds__(256) void
 finish_kernel(FinishCtx cx)
 {
   __shared__ SharedLut lut_s;
+  if (tree_failed(cx.tv))
+    return;
   load_lut(&lut_s, cx.lut);
   const SharedLut& lut = lut_s;
   const TreeView& tv = cx.tv;

@@ -49,6 +49,8 @@ struct LevelCtx {
   int32_t* dqp[2];                 // descent-time node qp    [N][2]
   int32_t* coeffs;                 // planar per slice
   uint32_t* desc;                  // RDOQ descriptors, one per coefficient
+  int64_t* ptrans;                 // [N][C] transformed prediction per coefficient position
+                                   // (analyze -> synthesis record, raht_tile.hpp)
   int32_t li;                      // children level of this launch
   const struct SharedLut* lut;     // tables built by lut_init_kernel
   int32_t* worklist;               // [cap] parents with >= 2 children (or non-ext)
@@ -294,6 +296,8 @@ raht_level_prepass_kernel(LevelCtx ctx)
 {
   __shared__ int wave_cnt[4];
   __shared__ int base_s;
+  if (tree_failed(ctx.tv))
+    return;
   const TreeView& tv = ctx.tv;
   const int li = ctx.li;
   const bool ext = ctx.params->raht_extension != 0;
@@ -430,6 +434,8 @@ __global__ __launch_bounds__(256, GPCC_LEVEL_WAVES) void
 raht_level_kernel(LevelCtx ctx)
 {
   __shared__ SharedLut lut_s;
+  if (tree_failed(ctx.tv))
+    return;
   {
     // the grid is sized from a host-side bound; workgroups beyond the
     // level's real work leave before touching anything

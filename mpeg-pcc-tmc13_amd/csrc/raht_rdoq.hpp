@@ -56,7 +56,7 @@ __device__ __forceinline__ bool
 level_coeff_range(const RdoqCtx& cx, int s, int* a, int* b)
 {
   const LevelSched e = cx.sched[s].lvl[cx.li];
-  if (!e.processed)
+  if (!e.processed || e.coarse)  // coarse levels resolve their state inside raht_coarse_kernel
     return false;
   const int m = cx.tv.soff[cx.li][s + 1] - cx.tv.soff[cx.li][s];
   const int mp = cx.tv.soff[cx.li + 1][s + 1] - cx.tv.soff[cx.li + 1][s];
@@ -113,6 +113,8 @@ tile_range(const RdoqCtx& cx, int gt, int* s_out, int* a, int* b)
 __global__ __launch_bounds__(256) void
 rdoq_classify_kernel(RdoqCtx cx)
 {
+  if (tree_failed(cx.tv))
+    return;
   const int lane = lane_id();
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / kWave;
   const int nwaves = gridDim.x * blockDim.x / kWave;
@@ -153,6 +155,8 @@ rdoq_classify_kernel(RdoqCtx cx)
 __global__ __launch_bounds__(64) void
 rdoq_carry_kernel(RdoqCtx cx)
 {
+  if (tree_failed(cx.tv))
+    return;
   const int lane = lane_id();
   for (int s = blockIdx.x; s < cx.tv.num_slices; s += gridDim.x) {
     int la, lb;
@@ -202,6 +206,8 @@ rdoq_carry_kernel(RdoqCtx cx)
 __global__ __launch_bounds__(256) void
 rdoq_apply_kernel(RdoqCtx cx)
 {
+  if (tree_failed(cx.tv))
+    return;
   const int lane = lane_id();
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / kWave;
   const int nwaves = gridDim.x * blockDim.x / kWave;

@@ -123,6 +123,8 @@ raht_level_sub_kernel(LevelCtx ctx)
   static_assert(MODE == kSynth || MODE == kFused || MODE == kLossySub, "mode");
   constexpr bool kLossy = MODE == kLossySub;
   __shared__ SharedLut lut_s;
+  if (tree_failed(ctx.tv))
+    return;
   load_lut(&lut_s, ctx.lut);
   const SharedLut& lut = lut_s;
 

@@ -113,7 +113,14 @@ tree_scan_kernel(
         running += __shfl(inc, kWave - 1);
       }
       if (lane == 0) {
-        const int m = (int)running;
+        int m = (int)running;
+        // more nodes than the level's arrays hold: the Morton-bits hint was
+        // smaller than the codes' width (the top levels are sized from it).
+        // tree_emit and everything behind it leave on the error word.
+        if (m > tv.cap[col]) {
+          atomicExch(tv.error, 2);
+          m = tv.cap[col];
+        }
         tv.soff[col][tv.num_slices] = m;
         tv.fp[col][m] = tv.n_total;
       }
@@ -146,6 +153,8 @@ tree_emit_kernel(
   const uint32_t* __restrict__ tile_cnt, const int32_t* __restrict__ tile_attr,
   int32_t* attr_prefix)
 {
+  if (tree_failed(tv))
+    return;
   const int lane = lane_id();
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / kWave;
   const int nwaves = gridDim.x * blockDim.x / kWave;
@@ -207,50 +216,89 @@ tree_emit_kernel(
 }
 
 // One thread per slice: which levels run, their layers and coefficient
-// bases (tmc3/RAHT.cpp:1165-1217,1264-1265).
-__global__ void
-schedule_kernel(TreeView tv, SliceSched* sched, int num_qp_layers)
+// bases (tmc3/RAHT.cpp:1165-1217,1264-1265), and which of them the coarse
+// kernel takes: the top levels of the slice down to the last one whose
+// parents number at most `coarse_max_parents`.  One workgroup; the summary the
+// host sizes its launches from goes to `stats` (pinned host memory) when given.
+__global__ __launch_bounds__(256) void
+schedule_kernel(
+  TreeView tv, SliceSched* sched, int num_qp_layers, int coarse_max_parents,
+  TreeStats* stats)
 {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= tv.num_slices)
+  __shared__ int s_fine, s_top;
+  if (tree_failed(tv)) {
+    if (stats && threadIdx.x == 0) {
+      stats->fine_levels = 0;
+      stats->max_top = 0;
+    }
     return;
-  SliceSched sc;
-  int m[kMaxLevels];
-  for (int li = 0; li < tv.nlev; li++)
-    m[li] = tv.soff[li][s + 1] - tv.soff[li][s];
-  int top = tv.nlev - 1;
-  while (top > 0 && m[top - 1] == 1)
-    top--;
-  sc.num_unique = m[0];
-  sc.top_level = top;
-  int qp_layer = 0, ac_layer = -1, parity = 1, coeff = 0;
-  for (int li = 0; li < kMaxLevels; li++) {
-    sc.lvl[li].processed = 0;
-    sc.lvl[li].is_root = 0;
-    sc.lvl[li].qp_layer = 0;
-    sc.lvl[li].ac_layer = -1;
-    sc.lvl[li].parity = 0;
-    sc.lvl[li].coeff_base = 0;
   }
-  for (int li = top - 1; li >= 0; li--) {
-    const bool root = li == top - 1;
-    if (!root && m[li] == m[li + 1])
-      continue;
-    qp_layer = qp_layer + 1 < num_qp_layers ? qp_layer + 1 : num_qp_layers - 1;
-    ac_layer++;
-    parity ^= 1;
-    LevelSched& e = sc.lvl[li];
-    e.processed = 1;
-    e.is_root = root;
-    e.qp_layer = (uint8_t)qp_layer;
-    e.ac_layer = (int8_t)(ac_layer > 127 ? 127 : ac_layer);
-    e.parity = (uint8_t)parity;
-    e.coeff_base = coeff;
-    coeff += root ? m[li] : m[li] - m[li + 1];
+  if (threadIdx.x == 0)
+    s_fine = s_top = 0;
+  __syncthreads();
+  for (int s = threadIdx.x; s < tv.num_slices; s += blockDim.x) {
+    SliceSched sc;
+    int m[kMaxLevels];
+    for (int li = 0; li < tv.nlev; li++)
+      m[li] = tv.soff[li][s + 1] - tv.soff[li][s];
+    int top = tv.nlev - 1;
+    // the level arrays were sized for ONE node per slice at the top level: a
+    // Morton-bits hint smaller than the codes' real width breaks that (and
+    // tree_emit has then written past the top levels' arrays, inside the
+    // workspace) -- report it instead of returning a wrong result
+    if (m[top] != 1)
+      atomicExch(tv.error, 2);
+    while (top > 0 && m[top - 1] == 1)
+      top--;
+    sc.num_unique = m[0];
+    sc.top_level = top;
+    int coarse_from = top;  // levels li >= coarse_from belong to the coarse kernel
+    for (int li = top - 1; li >= 0 && m[li + 1] <= coarse_max_parents; li--)
+      coarse_from = li;
+    int qp_layer = 0, ac_layer = -1, parity = 1, coeff = 0;
+    for (int li = 0; li < kMaxLevels; li++) {
+      sc.lvl[li].processed = 0;
+      sc.lvl[li].is_root = 0;
+      sc.lvl[li].qp_layer = 0;
+      sc.lvl[li].ac_layer = -1;
+      sc.lvl[li].parity = 0;
+      sc.lvl[li].coarse = 0;
+      sc.lvl[li].pad[0] = sc.lvl[li].pad[1] = 0;
+      sc.lvl[li].coeff_base = 0;
+    }
+    for (int li = top - 1; li >= 0; li--) {
+      const bool root = li == top - 1;
+      sc.lvl[li].coarse = li >= coarse_from;
+      if (!root && m[li] == m[li + 1])
+        continue;
+      qp_layer = qp_layer + 1 < num_qp_layers ? qp_layer + 1 : num_qp_layers - 1;
+      ac_layer++;
+      parity ^= 1;
+      LevelSched& e = sc.lvl[li];
+      e.processed = 1;
+      e.is_root = root;
+      e.qp_layer = (uint8_t)qp_layer;
+      e.ac_layer = (int8_t)(ac_layer > 127 ? 127 : ac_layer);
+      e.parity = (uint8_t)parity;
+      e.coeff_base = coeff;
+      coeff += root ? m[li] : m[li] - m[li + 1];
+    }
+    sc.final_qp_layer = qp_layer;
+    sc.final_parity = parity;
+    sched[s] = sc;
+    atomicMax(&s_fine, coarse_from);
+    atomicMax(&s_top, top);
   }
-  sc.final_qp_layer = qp_layer;
-  sc.final_parity = parity;
-  sched[s] = sc;
+  __syncthreads();
+  if (stats) {
+    if (threadIdx.x == 0) {
+      stats->fine_levels = s_fine;
+      stats->max_top = s_top;
+    }
+    if ((int)threadIdx.x < kMaxLevels)
+      stats->nodes[threadIdx.x] =
+        (int)threadIdx.x < tv.nlev ? tv.soff[threadIdx.x][tv.num_slices] : 0;
+  }
 }
 
 }  // namespace gpcc

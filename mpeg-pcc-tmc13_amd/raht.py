@@ -18,9 +18,14 @@ class Context:
     """gpcc_ctx: one HIP device + stream + workspace."""
 
     def __init__(self, device=0, stream=None):
+        """stream: None = the library creates its own stream; a hipStream_t
+        handle (e.g. torch.cuda.Stream().cuda_stream) = run there; 0 = the
+        legacy default stream (GPCC_STREAM_LEGACY), which is what a torch
+        default stream's handle means."""
         self._lib = _lib.load()
         h = C.c_void_p()
-        _lib.check(self._lib.gpcc_ctx_create(device, C.c_void_p(stream or 0), C.byref(h)))
+        handle = 0 if stream is None else (1 if stream == 0 else stream)
+        _lib.check(self._lib.gpcc_ctx_create(device, C.c_void_p(handle), C.byref(h)))
         self._h = h
         self.device = device
 
@@ -46,6 +51,12 @@ class Context:
 
     def set_profiling(self, on):
         _lib.check(self._lib.gpcc_ctx_set_profiling(self._h, int(bool(on))))
+
+    def stats(self):
+        """gpcc_ctx_stats: {calls_ok, calls_unsupported, calls_failed, points_ok}."""
+        st = _lib.CtxStats()
+        _lib.check(self._lib.gpcc_ctx_stats(self._h, C.byref(st)))
+        return {k: int(getattr(st, k)) for k, _ in st._fields_}
 
     def kernel_times(self):
         """{kernel name: (total ms, launches)} since the last call."""

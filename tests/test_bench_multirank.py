@@ -27,7 +27,7 @@ def test_bench_two_ranks_one_json_line():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--points", "200000"]
+           "--points", "200000", "--configs3-points", "150000", "--verify-gather"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -37,3 +37,7 @@ def test_bench_two_ranks_one_json_line():
     assert d["config"]["points_per_gpu_per_step"] == 200000
     assert d["config"]["roundtrip_decoder_equals_encoder_recon"] is True
     assert d["value"] > 0 and "roofline" not in d  # per-kernel figures are an N=1 report
+    # the coefficient buffers rank 0 gathered are what one GPU computes for the same frames
+    assert d["config"]["gathered_equals_single_rank"] is True
+    # BASELINE configs[3] shape (dense colour frames, one per rank) in the same line
+    assert d["configs3"]["roundtrip_decoder_equals_encoder_recon"] is True and d["configs3"]["value"] > 0

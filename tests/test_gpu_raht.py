@@ -24,42 +24,15 @@ def golden():
     return np.load(os.path.join(os.path.dirname(__file__), "golden", "raht_golden.npz"))
 
 
-def on_device_path(params):
-    """Every intra parameter combination runs on the device."""
-    return True
-
-
-def golden_or_oracle_coeffs(name, golden, p, morton, attrs, qp):
-    if name + "/coeffs" in golden:
-        return golden[name + "/coeffs"]
-    return ol.oracle().raht_forward(p, morton, attrs, qp)[0]
-
-
 @pytest.mark.parametrize("name", rc.CASE_NAMES)
 def test_case_vs_golden_and_oracle(name, ctx, golden):
-    from mpeg_pcc_tmc13_amd._lib import GpccError
+    """Every intra parameter combination runs on the device, forward and inverse."""
     case = rc.CASES[rc.CASE_NAMES.index(name)]
     p, morton, attrs, qp = rc.make_inputs(case)
     n, c = attrs.shape
-    if not on_device_path(p):
-        with pytest.raises(GpccError) as ei:
-            ctx.raht_forward(p, morton, attrs, qp)
-        assert ei.value.code == -2  # GPCC_ERR_UNSUPPORTED: caller keeps the CPU path
-        # ... but the DECODER side of the same case runs on the device: the
-        # reference's coefficients in, the reference's reconstruction out
-        inv = ctx.raht_inverse(p, morton, golden_or_oracle_coeffs(name, golden, p, morton, attrs, qp), c, qp)
-        o_coeffs, o_rec = ol.oracle().raht_forward(p, morton, attrs, qp)
-        np.testing.assert_array_equal(inv, o_rec)
-        # and the forward case with the flag off is compared with the oracle below
-        p = p.copy()
-        p.raht_subnode_prediction_enabled_flag = 0
-        native = False
-    else:
-        native = True
     coeffs, rec = ctx.raht_forward(p, morton, attrs, qp)
     inv = ctx.raht_inverse(p, morton, coeffs, c, qp)
-    if native:
-        assert str(golden[name + "/sha"]) == rc.digest(coeffs) + rc.digest(rec) + rc.digest(inv)
+    assert str(golden[name + "/sha"]) == rc.digest(coeffs) + rc.digest(rec) + rc.digest(inv)
     o_coeffs, o_rec = ol.oracle().raht_forward(p, morton, attrs, qp)
     np.testing.assert_array_equal(coeffs, o_coeffs)
     np.testing.assert_array_equal(rec, o_rec)
