@@ -6,7 +6,8 @@ import os
 from .params import LiftParams, LodParams, RahtParams
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "libgpcc_attr_mi355.so")
+# GPCC_LIB_PATH: an experiment build of the same library (tools/, parameter sweeps)
+LIB_PATH = os.environ.get("GPCC_LIB_PATH") or os.path.join(PKG_DIR, "libgpcc_attr_mi355.so")
 
 # every symbol the header declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [

@@ -431,7 +431,7 @@ launch_transform(
   {
     Timer t(ctx, "schedule");
     schedule_kernel<<<1, 256, 0, st>>>(
-      tv, pl.sched, hp->num_qp_layers, tiles ? kCoarseTiles * kTileT : 0, ctx->h_stats);
+      tv, pl.sched, hp->num_qp_layers, tiles ? kCoarseParents : 0, ctx->h_stats);
   }
   HIP_TRY(hipEventRecord(ctx->ev_stats, st));
 
@@ -539,14 +539,14 @@ launch_transform(
       const int tgrid = std::min((ntiles + 7) / 8 * 8, kLevelGridMax);
       if (!encoder) {
         Timer t(ctx, "tile_synth");
-        raht_tile_kernel<C, kSynth><<<tgrid, 256, 0, st>>>(lc);
+        raht_tile_kernel<C, kSynth><<<tgrid, kTileThreads, 0, st>>>(lc);
       } else if (pl.haar) {
         Timer t(ctx, "tile_fused");
-        raht_tile_kernel<C, kFused><<<tgrid, 256, 0, st>>>(lc);
+        raht_tile_kernel<C, kFused><<<tgrid, kTileThreads, 0, st>>>(lc);
       } else {
         {
           Timer t(ctx, "tile_analyze");
-          raht_tile_kernel<C, kAnalyze><<<tgrid, 256, 0, st>>>(lc);
+          raht_tile_kernel<C, kAnalyze><<<tgrid, kTileThreads, 0, st>>>(lc);
         }
         rc.li = li;
         // tiles that can intersect this level's coefficients
@@ -567,7 +567,7 @@ launch_transform(
         }
         {
           Timer t(ctx, "tile_synth_rec");
-          raht_tile_kernel<C, kSynthRec><<<tgrid, 256, 0, st>>>(lc);
+          raht_tile_kernel<C, kSynthRec><<<tgrid, kTileThreads, 0, st>>>(lc);
         }
       }
       continue;
@@ -2289,6 +2289,21 @@ gpcc_debug_sub_prof(unsigned long long* out, int reset)
   if (reset) {
     unsigned long long z[16 + 32 * 4] = {};
     if (hipMemcpyToSymbol(HIP_SYMBOL(gpcc::g_sub_prof), z, sizeof(z)) != hipSuccess)
+      return -1;
+  }
+  return 0;
+}
+#endif
+
+#ifdef GPCC_TILE_PROF
+extern "C" int
+gpcc_debug_tile_prof(unsigned long long* out, int reset)
+{
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gpcc::g_tile_prof), sizeof(gpcc::g_tile_prof)) != hipSuccess)
+    return -1;
+  if (reset) {
+    static unsigned long long z[5 * 24 * 8] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(gpcc::g_tile_prof), z, sizeof(z)) != hipSuccess)
       return -1;
   }
   return 0;

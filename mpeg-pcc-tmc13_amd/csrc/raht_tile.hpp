@@ -52,11 +52,60 @@ namespace gpcc {
 #ifndef GPCC_TILE_WAVES
 #define GPCC_TILE_WAVES 4
 #endif
-constexpr int kTileT = 1024;       // parents per tile
-constexpr int kTileW = 768;        // staged key window on either side
+#ifndef GPCC_TILE_FAST2
+#define GPCC_TILE_FAST2 0
+#endif
+#ifndef GPCC_TILE_T
+#define GPCC_TILE_T 256
+#endif
+#ifndef GPCC_TILE_W
+#define GPCC_TILE_W 512
+#endif
+#ifndef GPCC_TILE_THREADS
+#define GPCC_TILE_THREADS 256
+#endif
+constexpr int kTileT = GPCC_TILE_T;  // parents per tile
+constexpr int kTileW = GPCC_TILE_W;  // staged key window on either side
+constexpr int kTileThreads = GPCC_TILE_THREADS;
+constexpr int kTileCC = 4 * kTileT;  // children staged at a time (a tile with more is worked in parts)
+// hash table over the staged key window: 16-bit window indices, load <= 0.4
+constexpr int kTabSlots = (kTileT + 2 * kTileW) * 5 / 2 <= 2048 ? 2048
+  : ((kTileT + 2 * kTileW) * 5 / 2 <= 4096 ? 4096 : 8192);
+constexpr uint32_t kTabEmpty = 0xffffu;
+static_assert(kTileT + 2 * kTileW < 0xffff, "window indices are 16 bit");
 constexpr int kTileSlices = 8;     // slices a tile may span with their info in LDS
-constexpr int kCoarseTiles = 4;    // a level is coarse if a slice has <= 4 tiles of parents
+constexpr int kCoarseParents = 4096;  // a level is coarse while a slice has at most this many parents
 constexpr int kSynthRec = 4;       // LevelMode: synthesis from the analyze pass's record
+
+// Where a tile's time goes (experiment builds only, -DGPCC_TILE_PROF: s_memtime
+// at the phase boundaries, thread 0, summed per mode and level into g_tile_prof;
+// read back with gpcc_debug_tile_prof).  Empty otherwise.
+#ifdef GPCC_TILE_PROF
+__device__ unsigned long long g_tile_prof[5 * 24 * 8];
+struct TileProf {
+  unsigned long long last;
+  int mode, li;
+  __device__ TileProf(int m, int l) : mode(m), li(l) { last = __builtin_amdgcn_s_memtime(); }
+  __device__ void mark(int phase)
+  {
+    const unsigned long long t = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0)
+      atomicAdd(&g_tile_prof[(mode * 24 + li) * 8 + phase], t - last);
+    last = t;
+  }
+  __device__ void count(int slot, int n)
+  {
+    if (threadIdx.x == 0)
+      atomicAdd(&g_tile_prof[(mode * 24 + li) * 8 + slot], (unsigned long long)n);
+  }
+};
+#else
+struct TileProf {
+  __device__ TileProf(int, int) {}
+  __device__ void mark(int) {}
+  __device__ void count(int, int) {}
+};
+#endif
 
 struct TileSlice {
   int32_t sp0, sp1;  // the slice's parents  [sp0, sp1) in level li+1
@@ -65,14 +114,23 @@ struct TileSlice {
   LevelSched e;
 };
 
-template<bool kSearch>
+// kSearch: the parent key window (every mode but kSynthRec); SUMC: components
+// of the children's source sums (encoder passes), 0 = none
+template<bool kSearch, int SUMC>
 struct TileSmem {
   SharedLut lut;
   int64_t key[kSearch ? kTileT + 2 * kTileW : 1];
+  uint32_t tab[kSearch ? kTabSlots / 2 : 1];  // two 16-bit entries per word
   int32_t fc[kTileT + 1];
   uint16_t blocks[kTileT];
+  // the children of the parents being worked on: first points (weights are
+  // differences), octants, and what the encoder's source sums come from --
+  // the attribute prefix sum at every first point, or the Haar low-pass value
+  int32_t cfp[kTileCC + 1];
+  uint8_t coct[kTileCC];
+  int32_t cpre[SUMC ? (kTileCC + 1) * SUMC : 1];
   TileSlice sl[kTileSlices];
-  int32_t nblocks, s_lo, ns, nsl;
+  int32_t nblocks, nblocks2, s_lo, ns, nsl;
 };
 
 __device__ __forceinline__ TileSlice
@@ -100,6 +158,402 @@ tile_slice(const Smem& sm, int j)
   return sm.sl[u];
 }
 
+// ---- neighbour lookup in the staged key window -----------------------------------
+// findNeighbour (tmc3/RAHT.cpp:272-293) is a lower_bound in the parent key
+// array limited to raht_prediction_search_range entries either side: it finds
+// the parent with key `want` iff that parent exists at an index in [ga, gb).
+// The window's keys sit in LDS behind a hash table (open addressing, 16-bit
+// window indices): one or two probes instead of eleven dependent bisection
+// steps -- the bisection was a quarter of the block pass's instructions.
+__device__ __forceinline__ uint32_t
+tile_hash(int64_t key)
+{
+  const uint32_t x = (uint32_t)key ^ (uint32_t)((uint64_t)key >> 29);
+  return (x * 0x9E3779B1u) >> (32 - (kTabSlots == 2048 ? 11 : (kTabSlots == 4096 ? 12 : 13)));
+}
+
+template<typename Smem>
+__device__ __forceinline__ uint32_t
+tile_tab_get(const Smem& sm, uint32_t h)
+{
+  return (sm.tab[h >> 1] >> ((h & 1) * 16)) & 0xffffu;
+}
+
+// all threads: clear (before the barrier that also covers the key staging) ...
+template<typename Smem>
+__device__ __forceinline__ void
+tile_tab_clear(Smem& sm)
+{
+  for (int i = threadIdx.x; i < kTabSlots / 2; i += blockDim.x)
+    sm.tab[i] = 0xffffffffu;
+}
+// ... and insert the window's keys (after it)
+template<typename Smem>
+__device__ __forceinline__ void
+tile_tab_build(Smem& sm, int nwin)
+{
+  for (int i = threadIdx.x; i < nwin; i += blockDim.x) {
+    uint32_t h = tile_hash(sm.key[i]);
+    for (;;) {
+      const uint32_t sh = (h & 1) * 16;
+      const uint32_t old = sm.tab[h >> 1];
+      if (((old >> sh) & 0xffffu) == kTabEmpty) {
+        const uint32_t nw = (old & ~(0xffffu << sh)) | ((uint32_t)i << sh);
+        if (atomicCAS(&sm.tab[h >> 1], old, nw) == old)
+          break;
+      } else {
+        h = (h + 1) & (kTabSlots - 1);
+      }
+    }
+  }
+}
+
+// index of the parent with key `want` in [ga, gb), -1 if there is none;
+// *outside = the staged window [wlo, whi) cannot tell (the key may lie in the
+// part of [ga, gb) that is not staged)
+template<typename Smem>
+__device__ __forceinline__ int
+window_lookup(const Smem& sm, int64_t want, int ga, int gb, int wlo, int whi, bool* outside)
+{
+  *outside = false;
+  uint32_t h = tile_hash(want);
+  for (;;) {
+    const uint32_t i = tile_tab_get(sm, h);
+    if (i == kTabEmpty)
+      break;
+    if (sm.key[i] == want) {
+      // (the window may hold other slices of the batch with equal keys)
+      const int q = wlo + (int)i;
+      if (q >= ga && q < gb)
+        return q;
+    }
+    h = (h + 1) & (kTabSlots - 1);
+  }
+  // ga < wlo implies wlo is inside the searching block's slice, likewise whi
+  const bool below = ga < wlo && want < sm.key[0];
+  const bool above = gb > whi && want > sm.key[whi - wlo - 1];
+  *outside = below || above;
+  return -1;
+}
+
+// ---- two-child blocks: ONE THREAD per block ------------------------------------------
+// In a sparse cloud most blocks with a coefficient have exactly two children
+// (a lidar sweep: 75 %).  With children at positions a < b that first differ
+// in bit d, the three butterfly stages of fwd/invTransformBlock222 reduce to
+// moves and ONE real butterfly at stage d (mkWeightTree, tmc3/RAHT.cpp:742):
+// the low-pass value ends at position 0 -- where the inherited DC replaces it
+// -- and the single coefficient at position 1 << d.  Spending eight lanes and
+// three exchange stages on that block wastes most of the wavefront, so these
+// blocks are taken off the 8-lane list: one lane walks the (at most 18)
+// neighbours the two occupied positions use, and 64 blocks share a wavefront.
+// Only the common configuration takes this path (extension mode, no region QP,
+// DC inherited); everything else stays on the general path.
+template<int C, int MODE, typename Smem>
+__device__ __forceinline__ void
+tile_block2(
+  const LevelCtx& ctx, const int li, const Smem& sm, const int j, const int c0,
+  const int cb, const int wlo, const int whi)
+{
+  constexpr bool kSearch = MODE != kSynthRec;
+  constexpr bool kEnc = MODE == kAnalyze || MODE == kFused;
+  const TreeView& tv = ctx.tv;
+  const ParamsConst prm = (ParamsConst)ctx.params;
+  const SharedLut& lut = sm.lut;
+  const bool haar = prm->integer_haar_enable_flag != 0;
+  const TileSlice sl = tile_slice(sm, j);
+  const LevelSched e = sl.e;
+  const int sp0 = sl.sp0, sp1 = sl.sp1, sc0 = sl.sc0, pt0 = sl.pt0, n_s = sl.n_s;
+  const int pj = j - sp0;
+  const int par_par = e.parity ^ 1, cur_par = e.parity;
+  const int64_t prow = (int64_t)pt0 + pj;
+  const int64_t crow = (int64_t)pt0 + (c0 - sc0);  // child a; child b is the next row
+
+  const int lc0 = c0 - cb;
+  const int oa = sm.coct[lc0], ob = sm.coct[lc0 + 1];  // octants, oa < ob
+  const uint32_t occ = (1u << oa) | (1u << ob);
+  const int fa = sm.cfp[lc0], fm = sm.cfp[lc0 + 1], fz = sm.cfp[lc0 + 2];
+  const int32_t wa = fm - fa, wb = fz - fm;
+  const int cpos = 1 << (31 - clz32((uint32_t)(oa ^ ob)));  // position of the coefficient
+
+  int64_t sa[C], sb[C];
+#pragma unroll
+  for (int k = 0; k < C; k++)
+    sa[k] = sb[k] = 0;
+  if (kEnc) {
+    if (haar) {
+#pragma unroll
+      for (int k = 0; k < C; k++) {
+        sa[k] = fp_from_int(sm.cpre[lc0 * C + k]);
+        sb[k] = fp_from_int(sm.cpre[(lc0 + 1) * C + k]);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < C; k++) {
+        const uint32_t p0 = (uint32_t)sm.cpre[lc0 * C + k], p1 = (uint32_t)sm.cpre[(lc0 + 1) * C + k],
+                       p2 = (uint32_t)sm.cpre[(lc0 + 2) * C + k];
+        sa[k] = fp_from_int((int32_t)(p1 - p0));
+        sb[k] = fp_from_int((int32_t)(p2 - p1));
+      }
+    }
+  }
+
+  // ---- prediction (tmc3/RAHT.cpp:1391-1432, 299-368, 421-589) -----------------
+  bool enable_pred = false;
+  int neigh_count = 0;
+  int64_t pa_[C], pb_[C];  // prediction of child a / child b
+#pragma unroll
+  for (int k = 0; k < C; k++)
+    pa_[k] = pb_[k] = 0;
+  if (kSearch && prm->raht_prediction_enabled_flag != 0) {
+    if (par2(ctx.nneigh, par_par)[prow] >= prm->raht_prediction_threshold0) {
+      const int64_t cur_pos = sm.key[j - wlo];
+      const uint64_t base = morton3d_add((uint64_t)cur_pos, ~0ull);
+      const int64_t range = prm->raht_prediction_search_range;
+      const int64_t* __restrict__ pkey = tv.key[li + 1];
+      int pn[18];
+      int found = 0;
+#pragma unroll
+      for (int i = 1; i < 19; i++) {
+        pn[i - 1] = -1;
+        if (!(occ & neigh_mask(i)))
+          continue;
+        const int64_t np = (int64_t)morton3d_add(base, neigh_offset(i));
+        int64_t d = np - cur_pos;
+        int ga, gb;
+        if (d >= 0) {
+          d = d >= range ? range : d;
+          ga = j;
+          gb = (d + 1 < (int64_t)(sp1 - j)) ? j + (int)(d + 1) : sp1;
+        } else {
+          d = (-d) >= range ? range : -d;
+          gb = j;
+          ga = (d < (int64_t)(j - sp0)) ? j - (int)d : sp0;
+        }
+        if (ga >= gb)
+          continue;
+        bool outside;
+        int q = window_lookup(sm, np, ga, gb, wlo, whi, &outside);
+        if (outside) {
+          // left the staged window: the global lower_bound (rare)
+          int l2 = ga, h2 = gb;
+          while (l2 < h2) {
+            const int mid = l2 + ((h2 - l2) >> 1);
+            if (pkey[mid] < np)
+              l2 = mid + 1;
+            else
+              h2 = mid;
+          }
+          if (l2 < gb && pkey[l2] == np)
+            q = l2;
+        }
+        pn[i - 1] = q;
+        found += q >= 0;
+      }
+      neigh_count = found + 1;
+      enable_pred = neigh_count >= prm->raht_prediction_threshold1;
+      if (enable_pred) {
+        const int64_t* __restrict__ prec = par2(ctx.rec, par_par);
+        const int64_t rbase = (int64_t)pt0 - sp0;
+        int wsa = 0, wsb = 0;
+        int64_t own[C];
+#pragma unroll
+        for (int k = 0; k < C; k++)
+          own[k] = prec[(rbase + j) * C + k];
+        const int64_t lim_lo = 2 * own[0], lim_hi = 25 * own[0];
+        {
+          const int64_t pw = prm->pred_weight_parent[0];
+          wsa = wsb = (int)pw;
+#pragma unroll
+          for (int k = 0; k < C; k++)
+            pa_[k] = pb_[k] = own[k] * pw;
+        }
+        // the neighbours' values six at a time (one round trip each batch)
+#pragma unroll
+        for (int g = 0; g < 3; g++) {
+          int64_t v[6][C];
+#pragma unroll
+          for (int u = 0; u < 6; u++) {
+            const int q = pn[6 * g + u];
+#pragma unroll
+            for (int k = 0; k < C; k++)
+              v[u][k] = q >= 0 ? prec[(rbase + q) * C + k] : 0;
+          }
+#pragma unroll
+          for (int u = 0; u < 6; u++) {
+            const int i = 1 + 6 * g + u;
+            if (pn[i - 1] < 0)
+              continue;
+            if (10 * v[u][0] <= lim_lo || 10 * v[u][0] >= lim_hi)
+              continue;
+            const int64_t pw = prm->pred_weight_parent[i];
+            if ((neigh_mask(i) >> oa) & 1) {
+              wsa += (int)pw;
+#pragma unroll
+              for (int k = 0; k < C; k++)
+                pa_[k] += v[u][k] * pw;
+            }
+            if ((neigh_mask(i) >> ob) & 1) {
+              wsb += (int)pw;
+#pragma unroll
+              for (int k = 0; k < C; k++)
+                pb_[k] += v[u][k] * pw;
+            }
+          }
+        }
+        const int64_t da = pred_divisor(wsa), db = pred_divisor(wsb);
+#pragma unroll
+        for (int k = 0; k < C; k++) {
+          pa_[k] = fp_mul_c(pa_[k], da);
+          pb_[k] = fp_mul_c(pb_[k], db);
+          if (haar) {
+            pa_[k] = (pa_[k] >> kFpFrac) << kFpFrac;
+            pb_[k] = (pb_[k] >> kFpFrac) << kFpFrac;
+          }
+        }
+      }
+    }
+  }
+
+  // ---- normalise, the one butterfly (high-pass half only: the low-pass value
+  //      is the DC, which is inherited) ---------------------------------------
+  int64_t ca = 0, cbf = 0;
+  if (!haar) {
+    raht_coeffs(wa, wb, lut, &ca, &cbf);
+    if (kEnc) {
+      if (wa > 1) {
+#pragma unroll
+        for (int k = 0; k < C; k++)
+          sa[k] = scale_rsqrt(sa[k], wa, lut);
+      }
+      if (wb > 1) {
+#pragma unroll
+        for (int k = 0; k < C; k++)
+          sb[k] = scale_rsqrt(sb[k], wb, lut);
+      }
+    }
+    if (kSearch && enable_pred) {
+      if (wa > 1) {
+        const int64_t sq = sqrt_weight(wa, lut);
+#pragma unroll
+        for (int k = 0; k < C; k++)
+          pa_[k] = fp_mul_c(pa_[k], sq);
+      }
+      if (wb > 1) {
+        const int64_t sq = sqrt_weight(wb, lut);
+#pragma unroll
+        for (int k = 0; k < C; k++)
+          pb_[k] = fp_mul_c(pb_[k], sq);
+      }
+    }
+  }
+  int64_t hp[C];  // transformed prediction at the coefficient's position
+#pragma unroll
+  for (int k = 0; k < C; k++)
+    hp[k] = 0;
+  const int64_t trow = crow + 1;  // record row of scan rank 1
+  if (kSearch) {
+    if (enable_pred) {
+#pragma unroll
+      for (int k = 0; k < C; k++)
+        hp[k] = haar ? pb_[k] - pa_[k] : fp_mul_c(pb_[k], ca) - fp_mul_c(pa_[k], cbf);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < C; k++)
+      hp[k] = ctx.ptrans[trow * C + k];
+  }
+  if (MODE == kAnalyze) {
+#pragma unroll
+    for (int k = 0; k < C; k++)
+      ctx.ptrans[trow * C + k] = hp[k];
+  }
+
+  // ---- the coefficient (scanBlock, tmc3/RAHT.cpp:1558-1724) -------------------
+  const int cidx = e.coeff_base + (c0 - sc0) - pj;  // scan rank 1, DC not coded
+  int32_t* __restrict__ cplane = ctx.coeffs + (size_t)pt0 * C + cidx;
+  int ac0 = 0, ac1 = 0;
+  if (e.ac_layer < prm->num_ac_qp_layers) {
+    ac0 = prm->ac_qp_offset[e.ac_layer][cpos - 1][0];
+    ac1 = prm->ac_qp_offset[e.ac_layer][cpos - 1][1];
+  }
+  Quantizer qa[2];
+  qpset_quantizers(prm, e.qp_layer, ac0, ac1, qa);
+  if (kEnc) {
+    int64_t res[C];
+#pragma unroll
+    for (int k = 0; k < C; k++) {
+      const int64_t sh = haar ? sb[k] - sa[k] : fp_mul_c(sb[k], ca) - fp_mul_c(sa[k], cbf);
+      res[k] = sh - hp[k];  // hp is zero without prediction
+    }
+    if (MODE == kAnalyze) {
+      Quantizer qr[2];
+      qpset_quantizers(prm, e.qp_layer, 0, 0, qr);
+      int64_t sum_coeff = 0, dist2 = 0;
+      int rate_coeff = 0;
+#pragma unroll
+      for (int k = 0; k < C; k++) {
+        const int64_t co = fp_round(res[k]);
+        dist2 += co * co;
+        int64_t aq = quantize(qr[k ? 1 : 0], co * 256);
+        aq = aq < 0 ? -aq : aq;
+        sum_coeff += aq;
+        rate_coeff += rate_log_small(aq);
+      }
+      uint32_t d = kDescNever;
+      if (sum_coeff < 3) {
+        const int64_t l0 = qr[0].step;
+        d = rdoq_threshold(dist2, l0 * l0 * (C == 1 ? 25 : 35), rate_coeff, (uint32_t)n_s);
+        if (sum_coeff == 0)
+          d |= kDescZero;
+      }
+      ctx.desc[(size_t)pt0 + cidx] = d;
+    }
+#pragma unroll
+    for (int k = 0; k < C; k++) {
+      const int64_t co = quantize(qa[k ? 1 : 0], fp_round(res[k]) * 256);
+      cplane[(size_t)k * n_s] = (int32_t)co;
+      if (MODE == kFused)
+        hp[k] += fp_from_int(dequantize(qa[k ? 1 : 0], co));
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < C; k++)
+      hp[k] += fp_from_int(dequantize(qa[k ? 1 : 0], (int64_t)cplane[(size_t)k * n_s]));
+  }
+  if (MODE == kAnalyze) {
+    par2(ctx.nneigh, cur_par)[crow] = neigh_count;
+    par2(ctx.nneigh, cur_par)[crow + 1] = neigh_count;
+    return;
+  }
+
+  // ---- DC from the parent, inverse butterfly, reconstruction (:1727-1806) -------
+#pragma unroll
+  for (int k = 0; k < C; k++) {
+    const int64_t lf = par2(ctx.rec_us, par_par)[prow * C + k];
+    const int64_t hf = hp[k];
+    int64_t va, vb;
+    if (haar) {
+      va = lf - ((hf >> (1 + kFpFrac)) << kFpFrac);
+      vb = hf + va;
+    } else {
+      va = fp_mul_c(lf, ca) - fp_mul_c(hf, cbf);
+      vb = fp_mul_c(lf, cbf) + fp_mul_c(hf, ca);
+    }
+    par2(ctx.rec_us, cur_par)[crow * C + k] = va;
+    par2(ctx.rec_us, cur_par)[(crow + 1) * C + k] = vb;
+    if (!haar && wa > 1)
+      va = scale_rsqrt(va, wa, lut);
+    if (!haar && wb > 1)
+      vb = scale_rsqrt(vb, wb, lut);
+    par2(ctx.rec, cur_par)[crow * C + k] = va;
+    par2(ctx.rec, cur_par)[(crow + 1) * C + k] = vb;
+  }
+  if (MODE != kSynthRec) {
+    par2(ctx.nneigh, cur_par)[crow] = neigh_count;
+    par2(ctx.nneigh, cur_par)[crow + 1] = neigh_count;
+  }
+}
+
 // One tile [j0, j1) of the parents of level li + 1 (children in level li).
 // All threads of the workgroup call it together.  `honor_coarse`: skip the
 // (slice, level) pairs the coarse kernel owns.
@@ -122,23 +576,44 @@ tile_process(
   const int gbase = lane & 56;
   const bool haar = prm->integer_haar_enable_flag != 0;
   const bool ext = prm->raht_extension != 0;
+  // blocks of two children take the thread-per-block path (tile_block2) in the
+  // common configuration
+  const bool fast2 = GPCC_TILE_FAST2 && ext && !ctx.asc_qp;
   const int S = tv.num_slices;
   const int32_t* __restrict__ soffP = tv.soff[li + 1];
   const int nt = j1 - j0;
 
-  // ---- stage ----------------------------------------------------------------
+  // ---- stage: everything the tile needs that is known up front, in ONE round
+  //      of coalesced loads -- child ranges, the parent key window, the slices
+  //      the tile lies in, and (when they fit) the children's first points and
+  //      octants; the encoder's source sums follow (they need the first points).
+  //      A tile's fixed cost is what most tiles of a sparse level consist of. ------
   __syncthreads();  // the previous tile's readers are done with the LDS arrays
-  if (tid == 0) {
-    const int a = find_slice(soffP, S, j0);
-    const int b = find_slice(soffP, S, j1 - 1);
-    sm.s_lo = a;
-    sm.ns = b - a + 1;
+  TileProf prof(MODE, li);
+  const int32_t* __restrict__ pfc = tv.fc[li + 1];
+  const int c_lo = pfc[j0], c_hi = pfc[j1];  // (uniform addresses: scalar loads)
+  const bool one_part = c_hi - c_lo <= kTileCC;
+  TileSlice mine;
+  bool have = false;
+  if (S <= nthr) {
+    // one thread per slice: which slices hold the tile's first / last parent
+    if (tid < S) {
+      const int a = soffP[tid], b = soffP[tid + 1];
+      if (a <= j0 && j0 < b)
+        sm.s_lo = tid;
+      if (a < j1 && j1 <= b)
+        sm.ns = tid;  // last slice, turned into a count below
+      if (b > j0 && a < j1) {
+        have = true;
+        mine = load_tile_slice(ctx, li, tid);
+      }
+    }
+  } else if (tid == 0) {
+    sm.s_lo = find_slice(soffP, S, j0);
+    sm.ns = find_slice(soffP, S, j1 - 1);
   }
-  {
-    const int32_t* __restrict__ pfc = tv.fc[li + 1];
-    for (int i = tid; i <= nt; i += nthr)
-      sm.fc[i] = pfc[j0 + i];
-  }
+  for (int i = tid; i <= nt; i += nthr)
+    sm.fc[i] = pfc[j0 + i];
   int wlo = 0, whi = 0;
   if (kSearch) {
     const int np_all = soffP[S];
@@ -147,34 +622,117 @@ tile_process(
     const int64_t* __restrict__ pk = tv.key[li + 1];
     for (int i = tid; i < whi - wlo; i += nthr)
       sm.key[i] = pk[wlo + i];
+    tile_tab_clear(sm);
+  }
+  const int32_t* __restrict__ pfp = tv.fp[li];
+  const int64_t* __restrict__ pck = tv.key[li];
+  if (one_part) {
+    const int cn = c_hi - c_lo;
+    for (int i = tid; i <= cn; i += nthr)
+      sm.cfp[i] = pfp[c_lo + i];
+    for (int i = tid; i < cn; i += nthr)
+      sm.coct[i] = (uint8_t)(pck[c_lo + i] & 7);
   }
   __syncthreads();
-  const int ns = sm.ns, s_lo = sm.s_lo;
+  prof.mark(0);  // first round of staging
+  const int s_lo = sm.s_lo, ns = sm.ns - s_lo + 1;
+  // second round: the slices' plans into LDS, the source sums
+  auto stage_sums = [&](int cb, int cn) {
+    if (!kEnc)
+      return;
+    if (haar) {
+      const int32_t* __restrict__ lf = ctx.haar_lf[li];
+      for (int i = tid; i < cn * C; i += nthr)
+        sm.cpre[i] = lf[(size_t)cb * C + i];
+    } else {
+      for (int i = tid; i <= cn; i += nthr) {
+        const size_t f = (size_t)sm.cfp[i];
+#pragma unroll
+        for (int k = 0; k < C; k++)
+          sm.cpre[i * C + k] = ctx.attr_prefix[f * C + k];
+      }
+    }
+  };
+  if (S <= nthr) {
+    if (have && tid - s_lo < kTileSlices)
+      sm.sl[tid - s_lo] = mine;
+  } else if (tid < ns && tid < kTileSlices) {
+    sm.sl[tid] = load_tile_slice(ctx, li, s_lo + tid);
+  }
+  if (one_part)
+    stage_sums(c_lo, c_hi - c_lo);
+  if (kSearch)
+    tile_tab_build(sm, whi - wlo);
+  if (tid == 0) {
+    sm.nsl = ns < kTileSlices ? ns : kTileSlices;
+    sm.nblocks = 0;
+    sm.nblocks2 = 0;
+  }
+  __syncthreads();
+  prof.mark(1);  // second round (plans, source sums)
 
   // A tile normally lies inside one slice; one over many small slices is
   // worked through kTileSlices slices at a time (their offsets and level
   // plan sit in LDS).
+  bool first_round = true;  // the LDS state above is the first (window, part)'s
   for (int sb = 0; sb < ns; sb += kTileSlices) {
-  if (sb)
-    __syncthreads();  // the previous window's block list has been consumed
   const int nsl = ns - sb < kTileSlices ? ns - sb : kTileSlices;
-  if (tid < nsl)
-    sm.sl[tid] = load_tile_slice(ctx, li, s_lo + sb + tid);
-  if (tid == 0) {
-    sm.nsl = nsl;
-    sm.nblocks = 0;
+  if (sb) {
+    __syncthreads();  // the previous window has been consumed
+    if (tid < nsl)
+      sm.sl[tid] = load_tile_slice(ctx, li, s_lo + sb + tid);
+    if (tid == 0) {
+      sm.nsl = nsl;
+      sm.nblocks = 0;
+      sm.nblocks2 = 0;
+    }
+    __syncthreads();
+    first_round = one_part;  // with the children staged once nothing else changes
   }
-  __syncthreads();
   // parents of this window of slices inside the tile
   const int ja = sm.sl[0].sp0 > j0 ? sm.sl[0].sp0 : j0;
   const int jz = sm.sl[nsl - 1].sp1 < j1 ? sm.sl[nsl - 1].sp1 : j1;
 
+  // The children of a run of parents are a contiguous range of level li; when
+  // a tile has more than kTileCC of them they are staged a part at a time.
+  for (int pa = ja; pa < jz;) {
+  int pb = jz, cb = c_lo;
+  if (!one_part) {
+    const int cb0 = sm.fc[pa - j0];
+    int lo = pa + 1, hi = jz;  // a parent has at most 8 children: at least one fits
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (sm.fc[mid - j0] - cb0 <= kTileCC)
+        lo = mid;
+      else
+        hi = mid - 1;
+    }
+    pb = lo;
+    cb = cb0;
+    const int cn = sm.fc[pb - j0] - cb;
+    __syncthreads();  // whatever used the child arrays and the block lists is done
+    if (tid == 0) {
+      sm.nblocks = 0;
+      sm.nblocks2 = 0;
+    }
+    for (int i = tid; i <= cn; i += nthr)
+      sm.cfp[i] = pfp[cb + i];
+    for (int i = tid; i < cn; i += nthr)
+      sm.coct[i] = (uint8_t)(pck[cb + i] & 7);
+    __syncthreads();
+    if (kEnc) {
+      stage_sums(cb, cn);
+      __syncthreads();
+    }
+  }
+  (void)first_round;
+
   // ---- classify: one thread per parent ----------------------------------------
-  for (int jb = ja; jb < jz; jb += nthr) {
+  for (int jb = pa; jb < pb; jb += nthr) {
     const int j = jb + tid;
     const int jl = j - j0;
-    bool real = false;
-    if (j < jz) {
+    bool real = false, two = false;
+    if (j < pb) {
       const TileSlice sl = tile_slice(sm, j);
       const LevelSched e = sl.e;
       if (e.processed && !(honor_coarse && e.coarse)) {
@@ -199,23 +757,46 @@ tile_process(
               par2(ctx.dqp, cp)[crow * 2 + 1] = par2(ctx.dqp, pp)[prow * 2 + 1];
             }
           }
+        } else if (fast2 && nchild == 2 && !e.is_root) {
+          two = true;
         } else {
           real = true;
         }
       }
     }
-    const unsigned long long m = __ballot(real);
-    int at = 0;
+    // the 8-lane list grows from the front of blocks[], the two-child list
+    // from its back
+    const unsigned long long m = __ballot(real), m2 = __ballot(two);
+    int at = 0, at2 = 0;
     if (lane == 0 && m)
       at = atomicAdd(&sm.nblocks, __popcll(m));
+    if (lane == 0 && m2)
+      at2 = atomicAdd(&sm.nblocks2, __popcll(m2));
     at = __shfl(at, 0);
+    at2 = __shfl(at2, 0);
     if (real)
       sm.blocks[at + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)jl;
+    if (two)
+      sm.blocks[kTileT - 1 - (at2 + __popcll(m2 & ((1ull << lane) - 1)))] = (uint16_t)jl;
   }
   __syncthreads();
+  prof.mark(2);  // classification + single-child copies
 
+  // ---- two-child blocks: one thread each ------------------------------------------
+  if (GPCC_TILE_FAST2) {
+    const int nb2 = sm.nblocks2;
+    prof.count(6, nb2);
+    for (int bi = tid; bi < nb2; bi += nthr) {
+      const int jl = sm.blocks[kTileT - 1 - bi];
+      tile_block2<C, MODE>(ctx, li, sm, j0 + jl, sm.fc[jl], cb, wlo, whi);
+    }
+  }
+
+  prof.mark(3);  // two-child blocks
   // ---- blocks: 8 lanes each ------------------------------------------------------
   const int nblocks = sm.nblocks;
+  prof.count(7, nblocks);
+  prof.count(5, 1);
   const int gpp = nthr >> 3;  // groups per pass
   for (int b0 = 0; b0 < nblocks; b0 += gpp) {
     const int bi = b0 + (tid >> 3);
@@ -232,13 +813,34 @@ tile_process(
     const int par_par = e.parity ^ 1, cur_par = e.parity;
     const int64_t prow = (int64_t)pt0 + pj;  // parent row in the rec buffers
 
-    // ---- children: lane u < nchild fetches child c0 + u ----------------------
-    int64_t ckey = 0;
-    int f0u = 0, f1u = 0;
-    if (t < nchild) {
-      ckey = tv.key[li][c0 + t];
-      f0u = tv.fp[li][c0 + t];
-      f1u = tv.fp[li][c0 + t + 1];
+    // ---- children -> positions, from the staged arrays ------------------------
+    const int lc0 = c0 - cb;  // the block's first child in the staged range
+    const uint32_t occ = group8_or(t < nchild ? 1u << sm.coct[lc0 + t] : 0u);
+    const bool has = (occ >> t) & 1;
+    const int cu = popc32(occ & ((1u << t) - 1));
+    const int child = c0 + cu;
+    const int64_t crow = (int64_t)pt0 + (child - sc0);
+    int32_t w = 0;
+    int64_t src[C];
+#pragma unroll
+    for (int k = 0; k < C; k++)
+      src[k] = 0;
+    if (has) {
+      w = sm.cfp[lc0 + cu + 1] - sm.cfp[lc0 + cu];
+      if (kEnc) {
+        if (haar) {
+#pragma unroll
+          for (int k = 0; k < C; k++)
+            src[k] = fp_from_int(sm.cpre[(lc0 + cu) * C + k]);
+        } else {
+          // node sum = difference of the modular prefix sums: the reference
+          // accumulates these sums in `int` as well (tmc3/RAHT.cpp:131,196)
+#pragma unroll
+          for (int k = 0; k < C; k++)
+            src[k] = fp_from_int((int32_t)(
+              (uint32_t)sm.cpre[(lc0 + cu + 1) * C + k] - (uint32_t)sm.cpre[(lc0 + cu) * C + k]));
+        }
+      }
     }
     // parent values every mode needs
     const bool inherit_dc = !e.is_root;
@@ -256,22 +858,19 @@ tile_process(
     }
 
     // ---- neighbour search in the staged window (tmc3/RAHT.cpp:272-293,
-    //      299-368).  All 18 are looked up before the occupancy is known --
-    //      LDS work is cheap and it takes the search off the children's
-    //      load latency; only the ones some child position needs count. ------
+    //      299-368): the neighbours some occupied child position uses (:340) ------
     int pn[3] = {-1, -1, -1};  // neighbour i = 1 + t + 8*slot
     int fb_ga[3] = {0, 0, 0}, fb_gb[3] = {0, 0, 0};
     int64_t want[3] = {0, 0, 0};
     bool fb[3] = {false, false, false};
     if (kSearch) {
-      int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}, la[3] = {0, 0, 0}, lb[3] = {0, 0, 0};
       const int64_t cur_pos = on ? sm.key[j - wlo] : 0;
       const uint64_t base = morton3d_add((uint64_t)cur_pos, ~0ull);
       const int64_t range = prm->raht_prediction_search_range;
 #pragma unroll
       for (int slot = 0; slot < 3; slot++) {
         const int i = 1 + t + 8 * slot;
-        if (on && i < 19) {
+        if (on && i < 19 && (occ & neigh_mask(i))) {
           const int64_t np = (int64_t)morton3d_add(base, neigh_offset(i));
           int64_t d = np - cur_pos;
           int ga, gb;  // global index range findNeighbour may look at
@@ -287,79 +886,9 @@ tile_process(
           fb_ga[slot] = ga;
           fb_gb[slot] = gb;
           want[slot] = np;
-          la[slot] = ga > wlo ? ga : wlo;
-          lb[slot] = gb < whi ? gb : whi;
-          if (la[slot] < lb[slot]) {
-            lo[slot] = la[slot] - wlo;
-            hi[slot] = lb[slot] - wlo;
-          }
+          if (ga < gb)
+            pn[slot] = window_lookup(sm, np, ga, gb, wlo, whi, &fb[slot]);
         }
-      }
-      while (__any((lo[0] < hi[0]) | (lo[1] < hi[1]) | (lo[2] < hi[2]))) {
-        int mid[3];
-        int64_t kv[3];
-#pragma unroll
-        for (int slot = 0; slot < 3; slot++) {
-          mid[slot] = lo[slot] + ((hi[slot] - lo[slot]) >> 1);
-          kv[slot] = lo[slot] < hi[slot] ? sm.key[mid[slot]] : 0;
-        }
-#pragma unroll
-        for (int slot = 0; slot < 3; slot++) {
-          if (lo[slot] < hi[slot]) {
-            if (kv[slot] < want[slot])
-              lo[slot] = mid[slot] + 1;
-            else
-              hi[slot] = mid[slot];
-          }
-        }
-      }
-#pragma unroll
-      for (int slot = 0; slot < 3; slot++) {
-        const int i = 1 + t + 8 * slot;
-        if (!(on && i < 19) || fb_ga[slot] >= fb_gb[slot])
-          continue;
-        const bool overlap = la[slot] < lb[slot];
-        if (overlap && lo[slot] < lb[slot] - wlo && sm.key[lo[slot]] == want[slot]) {
-          pn[slot] = wlo + lo[slot];
-        } else {
-          // conclusive only if the part of the allowed range outside the
-          // window cannot hold the key
-          const bool below = fb_ga[slot] < wlo
-            && (!overlap || want[slot] < sm.key[la[slot] - wlo]);
-          const bool above = fb_gb[slot] > whi
-            && (!overlap || want[slot] > sm.key[lb[slot] - 1 - wlo]);
-          fb[slot] = below || above;
-        }
-      }
-    }
-
-    // ---- children -> positions -----------------------------------------------------
-    const uint32_t occ = group8_or(t < nchild ? 1u << (int)(ckey & 7) : 0u);
-    const bool has = (occ >> t) & 1;
-    const int cu = popc32(occ & ((1u << t) - 1));
-    const int child = c0 + cu;
-    const int64_t crow = (int64_t)pt0 + (child - sc0);
-    const int f0 = __shfl(f0u, gbase | (cu & 7));
-    const int f1 = __shfl(f1u, gbase | (cu & 7));
-    const int32_t w = has ? f1 - f0 : 0;
-    int64_t src[C];
-#pragma unroll
-    for (int k = 0; k < C; k++)
-      src[k] = 0;
-    if (kEnc && has) {
-      if (haar) {
-        const int32_t* lf = ctx.haar_lf[li];
-#pragma unroll
-        for (int k = 0; k < C; k++)
-          src[k] = fp_from_int(lf[(size_t)child * C + k]);
-      } else {
-        // node sum = difference of the modular prefix sums: the reference
-        // accumulates these sums in `int` as well (tmc3/RAHT.cpp:196)
-#pragma unroll
-        for (int k = 0; k < C; k++)
-          src[k] = fp_from_int((int32_t)(
-            (uint32_t)ctx.attr_prefix[(size_t)f1 * C + k]
-            - (uint32_t)ctx.attr_prefix[(size_t)f0 * C + k]));
       }
     }
 
@@ -773,6 +1302,9 @@ tile_process(
         par2(ctx.nneigh, cur_par)[crow] = inherit_dc ? neigh_count : 19;
     }
   }
+  prof.mark(4);  // 8-lane blocks
+  pa = pb;
+  }  // part of the window's parents
   }  // slice window
 }
 
@@ -781,10 +1313,10 @@ tile_process(
 // XCD gets one contiguous eighth of the tiles, so the key windows of
 // neighbouring tiles meet in the same L2.
 template<int C, int MODE>
-__global__ __launch_bounds__(256, MODE == kSynthRec ? 6 : GPCC_TILE_WAVES) void
+__global__ __launch_bounds__(kTileThreads, MODE == kSynthRec ? 6 : GPCC_TILE_WAVES) void
 raht_tile_kernel(LevelCtx ctx)
 {
-  __shared__ TileSmem<MODE != kSynthRec> sm;
+  __shared__ TileSmem<MODE != kSynthRec, (MODE == kAnalyze || MODE == kFused) ? C : 0> sm;
   if (tree_failed(ctx.tv))
     return;
   const int li = ctx.li;
@@ -812,7 +1344,7 @@ template<int C, int KIND>
 __global__ __launch_bounds__(1024) void
 raht_coarse_kernel(LevelCtx ctx)
 {
-  __shared__ TileSmem<true> sm;
+  __shared__ TileSmem<true, KIND == kCoarseDecode ? 0 : C> sm;
   const TreeView& tv = ctx.tv;
   if (tree_failed(tv))
     return;
@@ -833,9 +1365,11 @@ raht_coarse_kernel(LevelCtx ctx)
           tile_process<C, kAnalyze>(ctx, li, j0, j0 + kTileT < p1 ? j0 + kTileT : p1, sm, false);
         __syncthreads();
         // the zero-run state, walked in coding order by one wavefront: with
-        // the incoming L known no hypothesis is needed (tmc3/RAHT.cpp:1618-1669)
-        if (threadIdx.x < kWave) {
-          const int lane = lane_id();
+        // the incoming L known no hypothesis is needed (tmc3/RAHT.cpp:1618-1669).
+        // The descriptors are brought into LDS by the whole workgroup first (the
+        // key window is free between the passes): the walk is a chain of
+        // dependent steps and must not wait for memory at each of them.
+        {
           const int m = tv.soff[li][s + 1] - tv.soff[li][s];
           const int a = e.coeff_base;
           const int b = a + (e.is_root ? m : m - (p1 - p0));
@@ -843,17 +1377,29 @@ raht_coarse_kernel(LevelCtx ctx)
           const int n_s = tv.pt_off[s + 1] - pt0;
           const uint32_t* __restrict__ desc = ctx.desc + pt0;
           int32_t* __restrict__ co = ctx.coeffs + (size_t)pt0 * C;
-          for (int i0 = a; i0 < b; i0 += kWave) {
-            const int i = i0 + lane;
-            const bool valid = i < b;
-            const uint32_t d = valid ? desc[i] : kDescZero;
-            int tz;
-            l = rdoq_chunk(d, i, valid, l, i0, &tz);
-            const uint32_t thr = d & kDescNever;
-            if (valid && thr != kDescNever && (uint32_t)tz >= thr) {
+          uint32_t* dl = reinterpret_cast<uint32_t*>(sm.key);
+          constexpr int kChunk = (int)(sizeof(sm.key) / sizeof(uint32_t)) / kWave * kWave;
+          for (int c0 = a; c0 < b; c0 += kChunk) {
+            const int c1 = c0 + kChunk < b ? c0 + kChunk : b;
+            __syncthreads();
+            for (int i = c0 + (int)threadIdx.x; i < c1; i += blockDim.x)
+              dl[i - c0] = desc[i];
+            __syncthreads();
+            if (threadIdx.x < kWave) {
+              const int lane = lane_id();
+              for (int i0 = c0; i0 < c1; i0 += kWave) {
+                const int i = i0 + lane;
+                const bool valid = i < c1;
+                const uint32_t d = valid ? dl[i - c0] : kDescZero;
+                int tz;
+                l = rdoq_chunk(d, i, valid, l, i0, &tz);
+                const uint32_t thr = d & kDescNever;
+                if (valid && thr != kDescNever && (uint32_t)tz >= thr) {
 #pragma unroll
-              for (int k = 0; k < C; k++)
-                co[(size_t)k * n_s + i] = 0;
+                  for (int k = 0; k < C; k++)
+                    co[(size_t)k * n_s + i] = 0;
+                }
+              }
             }
           }
         }
