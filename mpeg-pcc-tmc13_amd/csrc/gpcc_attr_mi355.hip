@@ -66,7 +66,9 @@ constexpr int32_t kMaxPoints = GPCC_MAX_POINTS;
 constexpr int kGridMax = 2048;  // 256 CUs x 8 workgroups of 256 threads
 constexpr int kLevelGridMax = 1 << 16;
 constexpr int kSubGrid = 1024;      // sub-node kernel: 4 workgroups per CU, resident
-constexpr int kRoundsPerGroup = 4;  // level kernels: rounds of 32 blocks per workgroup
+#ifndef GPCC_SUB_BLOCKS_PER_WG
+#define GPCC_SUB_BLOCKS_PER_WG 64   // parents of the level per workgroup when sizing its grid
+#endif
 
 int
 grid_for(int64_t items, int per_block)
@@ -106,7 +108,6 @@ struct gpcc_ctx {
                                // only when the error has been reported (check_device_error)
   TreeStats* h_stats = nullptr;   // pinned: what schedule_kernel tells the host about the tree
   hipEvent_t ev_stats = nullptr;  // recorded behind schedule_kernel
-  bool legacy_levels = false;     // GPCC_LEGACY_LEVELS=1: the round-1 level kernels (A/B timing)
   // what the entries did since the context was created (gpcc_ctx_stats)
   gpcc_ctx_stats_t stats{};
   // device buffers of the host tiers, kept between calls (pool_malloc)
@@ -131,6 +132,24 @@ struct gpcc_ctx {
 };
 
 namespace {
+
+// "<kernel>@<level>" names for per-level timings (GPCC_PROFILE_LEVELS=1); the
+// strings live for the life of the process
+const char*
+level_name(const char* base, int li)
+{
+  static std::map<std::string, std::string> pool;
+  static const bool on = [] {
+    const char* e = getenv("GPCC_PROFILE_LEVELS");
+    return e && e[0] == '1';
+  }();
+  if (!on)
+    return base;
+  char buf[96];
+  snprintf(buf, sizeof buf, "%s@%02d", base, li);
+  auto it = pool.emplace(buf, buf).first;
+  return it->second.c_str();
+}
 
 struct Timer {
   gpcc_ctx* ctx;
@@ -187,8 +206,7 @@ struct Plan {
   uint32_t* desc = nullptr;
   int64_t* ptrans = nullptr;
   int32_t* rtile_base = nullptr;
-  int2* rtile_sum = nullptr;
-  int32_t* rtile_lin = nullptr;
+  unsigned long long* rtile_state = nullptr;
   int32_t* slice_l = nullptr;
   int32_t* worklist = nullptr;
   int32_t* work_count = nullptr;  // [kMaxLevels] then ticket[kMaxLevels*8], error[1] (one memset)
@@ -271,8 +289,7 @@ carve(Arena& ar, Plan& pl)
     pl.desc = ar.take<uint32_t>(n);
     pl.ptrans = pl.sub ? nullptr : ar.take<int64_t>((size_t)n * c);
     pl.rtile_base = ar.take<int32_t>(s + 1);
-    pl.rtile_sum = ar.take<int2>(pl.num_rtiles + 1);
-    pl.rtile_lin = ar.take<int32_t>(pl.num_rtiles + 1);
+    pl.rtile_state = ar.take<unsigned long long>(pl.num_rtiles + 1);
     pl.slice_l = ar.take<int32_t>(2 * (size_t)s);  // sub-node path: [level parity][S]
   }
 }
@@ -427,7 +444,7 @@ launch_transform(
   }
   // levels the coarse kernel may take: a slice's top levels with at most
   // kCoarseTiles tiles of parents each (sub-node prediction has its own path)
-  const bool tiles = !pl.sub && !ctx->legacy_levels;
+  const bool tiles = !pl.sub;
   {
     Timer t(ctx, "schedule");
     schedule_kernel<<<1, 256, 0, st>>>(
@@ -500,10 +517,10 @@ launch_transform(
     rc.num_tiles = pl.num_rtiles;
     rc.desc = pl.desc;
     rc.coeffs = d_coeffs;
-    rc.tile_sum = pl.rtile_sum;
-    rc.tile_lin = pl.rtile_lin;
     rc.slice_l = pl.slice_l;
+    rc.state = pl.rtile_state;
     rc.c = C;
+    HIP_TRY(hipMemsetAsync(pl.rtile_state, 0, ((size_t)pl.num_rtiles + 1) * sizeof(unsigned long long), st));
     HIP_TRY(hipMemsetAsync(pl.slice_l, 0xff, 2 * (size_t)s * sizeof(int32_t), st));
   }
 
@@ -538,90 +555,47 @@ launch_transform(
       const int ntiles = (int)((parents + kTileT - 1) / kTileT);
       const int tgrid = std::min((ntiles + 7) / 8 * 8, kLevelGridMax);
       if (!encoder) {
-        Timer t(ctx, "tile_synth");
+        Timer t(ctx, level_name("tile_synth", li));
         raht_tile_kernel<C, kSynth><<<tgrid, kTileThreads, 0, st>>>(lc);
       } else if (pl.haar) {
-        Timer t(ctx, "tile_fused");
+        Timer t(ctx, level_name("tile_fused", li));
         raht_tile_kernel<C, kFused><<<tgrid, kTileThreads, 0, st>>>(lc);
       } else {
         {
-          Timer t(ctx, "tile_analyze");
+          Timer t(ctx, level_name("tile_analyze", li));
           raht_tile_kernel<C, kAnalyze><<<tgrid, kTileThreads, 0, st>>>(lc);
         }
         rc.li = li;
-        // tiles that can intersect this level's coefficients
-        const int64_t lvl_coeffs = ts.nodes[li];
-        const int rgrid =
-          grid_for(std::min<int64_t>(pl.num_rtiles, lvl_coeffs / kRdoqTile + 2 * s), 4);
         {
-          Timer t(ctx, "rdoq_classify");
-          rdoq_classify_kernel<<<rgrid, 256, 0, st>>>(rc);
+          // one wavefront per 2048-coefficient tile of the batch, in order
+          Timer t(ctx, "rdoq_resolve");
+          rdoq_resolve_kernel<<<(pl.num_rtiles + 3) / 4, 256, 0, st>>>(rc);
         }
         {
-          Timer t(ctx, "rdoq_carry");
-          rdoq_carry_kernel<<<std::min(s, 1024), 64, 0, st>>>(rc);
-        }
-        {
-          Timer t(ctx, "rdoq_apply");
-          rdoq_apply_kernel<<<rgrid, 256, 0, st>>>(rc);
-        }
-        {
-          Timer t(ctx, "tile_synth_rec");
+          Timer t(ctx, level_name("tile_synth_rec", li));
           raht_tile_kernel<C, kSynthRec><<<tgrid, kTileThreads, 0, st>>>(lc);
         }
       }
       continue;
     }
-    // many small workgroups: the cost of a round varies by an order of
-    // magnitude (single-child copies vs predicted blocks), the hardware
-    // dispatcher evens it out
-    const int grid = (int)std::min<int64_t>(
-      kLevelGridMax,
-      ((parents + 32 * kRoundsPerGroup - 1) / (32 * kRoundsPerGroup) + 7) / 8 * 8);
     {
-      Timer t(ctx, "level_prepass");
+      Timer t(ctx, level_name("level_prepass", li));
       raht_level_prepass_kernel<C><<<(int)std::min<int64_t>((parents + 1023) / 1024, 1024), 256, 0, st>>>(lc);
     }
-    if (pl.sub && !encoder) {
-      Timer t(ctx, "level_sub_synth");
-      raht_level_sub_kernel<C, kSynth><<<kSubGrid, 256, 0, st>>>(lc);
-    } else if (pl.sub && pl.haar) {
-      Timer t(ctx, "level_sub_fused");
-      raht_level_sub_kernel<C, kFused><<<kSubGrid, 256, 0, st>>>(lc);
-    } else if (pl.sub) {
-      Timer t(ctx, "level_sub_lossy");
-      raht_level_sub_kernel<C, kLossySub><<<kSubGrid, 256, 0, st>>>(lc);
-    } else if (!encoder) {
-      Timer t(ctx, "level_synth");
-      raht_level_kernel<C, kSynth><<<grid, 256, 0, st>>>(lc);
+    // sub-node kernel: resident workgroups claim rounds of 8 blocks per wave by
+    // ticket; a level with few parents gets few workgroups (measured: neutral
+    // from 1 workgroup per 32 parents to the full grid, slower beyond 1 per 128)
+    const int sgrid = (int)std::min<int64_t>(
+      kSubGrid, std::max<int64_t>(8, (parents / (GPCC_SUB_BLOCKS_PER_WG) + 7) / 8 * 8));
+    if (!encoder) {
+      Timer t(ctx, level_name("level_sub_synth", li));
+      raht_level_sub_kernel<C, kSynth><<<sgrid, 256, 0, st>>>(lc);
     } else if (pl.haar) {
-      Timer t(ctx, "level_fused");
-      raht_level_kernel<C, kFused><<<grid, 256, 0, st>>>(lc);
+      Timer t(ctx, level_name("level_sub_fused", li));
+      raht_level_sub_kernel<C, kFused><<<sgrid, 256, 0, st>>>(lc);
     } else {
-      {
-        Timer t(ctx, "level_analyze");
-        raht_level_kernel<C, kAnalyze><<<grid, 256, 0, st>>>(lc);
-      }
-      rc.li = li;
-      const int64_t lvl_coeffs = ts.nodes[li];
-      const int rgrid =
-        grid_for(std::min<int64_t>(pl.num_rtiles, lvl_coeffs / kRdoqTile + 2 * s), 4);
-      {
-        Timer t(ctx, "rdoq_classify");
-        rdoq_classify_kernel<<<rgrid, 256, 0, st>>>(rc);
-      }
-      {
-        Timer t(ctx, "rdoq_carry");
-        rdoq_carry_kernel<<<std::min(s, 1024), 64, 0, st>>>(rc);
-      }
-      {
-        Timer t(ctx, "rdoq_apply");
-        rdoq_apply_kernel<<<rgrid, 256, 0, st>>>(rc);
-      }
-      {
-        Timer t(ctx, "level_synth");
-        raht_level_kernel<C, kSynth><<<grid, 256, 0, st>>>(lc);
-      }
+      Timer t(ctx, level_name("level_sub_lossy", li));
+      raht_level_sub_kernel<C, kLossySub><<<sgrid, 256, 0, st>>>(lc);
     }
   }
 
@@ -1144,8 +1118,6 @@ gpcc_ctx_create(int device, void* stream, gpcc_ctx** out)
   }
   *ctx->h_error = 0;
   memset(ctx->h_stats, 0, sizeof(TreeStats));
-  const char* legacy = getenv("GPCC_LEGACY_LEVELS");
-  ctx->legacy_levels = legacy && legacy[0] == '1';
   *out = ctx;
   return GPCC_OK;
 }

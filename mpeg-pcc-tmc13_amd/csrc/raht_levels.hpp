@@ -9,14 +9,20 @@
 // blocks per wavefront advance in lock step, and no LDS or scratch array
 // holds the block.
 //
-// Modes (template parameter):
+// This header holds what the two families of level kernels share -- the
+// context, the small-weight tables, the neighbour tables, the quantiser set-up,
+// the RDOQ threshold -- and the prepass of the sub-node family.  The kernels
+// themselves: raht_tile.hpp (blocks of a level independent) and
+// raht_subnode.hpp (sub-node prediction: blocks depend on earlier ones).
+//
+// Modes (template parameter of those kernels):
 //   kAnalyze : lossy encoder, first pass.  Forward-transforms source and
 //              prediction, writes the TENTATIVE quantised coefficients and
 //              one RDOQ descriptor per coefficient (the zero-run state of
-//              tmc3/RAHT.cpp:1576-1670 is resolved by rdoq.hpp afterwards).
-//   kSynth   : decoder, and encoder last pass.  Transforms the prediction,
-//              adds the de-quantised coefficients, inherits the DC, inverse
-//              transforms and stores the children's reconstruction.
+//              tmc3/RAHT.cpp:1576-1670 is resolved by raht_rdoq.hpp afterwards).
+//   kSynth   : decoder.  Transforms the prediction, adds the de-quantised
+//              coefficients, inherits the DC, inverse transforms and stores
+//              the children's reconstruction.
 //   kFused   : integer-Haar encoder (no RDOQ): both in one pass.
 #pragma once
 
@@ -417,518 +423,6 @@ raht_level_prepass_kernel(LevelCtx ctx)
     if (real)
       ctx.worklist[off + __popcll(m & ((1ull << lane) - 1))] = j;
     running += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-  }
-}
-
-// The block kernels are bound by dependent-load latency (rocprofv3: VALU
-// active 12 % of wave cycles), so residency is bought with registers:
-// GPCC_LEVEL_WAVES waves per SIMD (see DESIGN.md for the measured sweep).
-// (measured on 1M lidar / dense, forward+inverse: 4 waves 4.90 / 3.33 ms,
-// 5 waves 4.59 / 3.20 ms -- the C=1 kernels need 98-104 registers -- 6 and 8
-// waves spill and lose)
-#ifndef GPCC_LEVEL_WAVES
-#define GPCC_LEVEL_WAVES 5
-#endif
-template<int C, int MODE>
-__global__ __launch_bounds__(256, GPCC_LEVEL_WAVES) void
-raht_level_kernel(LevelCtx ctx)
-{
-  __shared__ SharedLut lut_s;
-  if (tree_failed(ctx.tv))
-    return;
-  {
-    // the grid is sized from a host-side bound; workgroups beyond the
-    // level's real work leave before touching anything
-    int64_t b0, b1;
-    xcd_chunk(((int64_t)ctx.work_count[ctx.li] + 31) >> 5, &b0, &b1);
-    if (b0 >= b1)
-      return;
-  }
-  load_lut(&lut_s, ctx.lut);
-  const SharedLut& lut = lut_s;
-
-  constexpr bool kEnc = MODE != kSynth;
-  constexpr bool kRecon = MODE != kAnalyze;
-  const TreeView& tv = ctx.tv;
-  const ParamsConst prm = (ParamsConst)ctx.params;
-  const int li = ctx.li;
-  const int t = threadIdx.x & 7;
-  const bool haar = prm->integer_haar_enable_flag != 0;
-  const bool ext = prm->raht_extension != 0;
-
-  const int num_work = ctx.work_count[li];
-  int64_t gbeg, gend;
-  {
-    // blocks are dealt out in XCD-contiguous chunks of 32 (one workgroup
-    // iteration), see xcd_chunk()
-    const int64_t rounds = ((int64_t)num_work + 31) >> 5;
-    xcd_chunk(rounds, &gbeg, &gend);
-  }
-  for (int64_t round = gbeg; round < gend; round++) {
-    const int wi = (int)(round * 32) + (threadIdx.x >> 3);
-    const bool live = wi < num_work;
-    const int j = live ? ctx.worklist[wi] : 0;
-    // ---- locate the block -------------------------------------------
-    int s = 0;
-    LevelSched e;
-    e.processed = 0;
-    if (live) {
-      s = find_slice(tv.soff[li + 1], tv.num_slices, j);
-      e = ctx.sched[s].lvl[li];
-    }
-    // all shuffles below run in wave-uniform control flow; lanes of dead
-    // groups carry zeros and store nothing
-    const bool on = live && e.processed;
-    const int sp0 = on ? tv.soff[li + 1][s] : 0;      // slice's parents
-    const int sp1 = on ? tv.soff[li + 1][s + 1] : 0;
-    const int sc0 = on ? tv.soff[li][s] : 0;          // slice's children
-    const int pt0 = on ? tv.pt_off[s] : 0;
-    const int n_s = on ? tv.pt_off[s + 1] - pt0 : 0;
-    const int c0 = on ? tv.fc[li + 1][j] : 0;
-    const int nchild = on ? tv.fc[li + 1][j + 1] - c0 : 0;
-    const int pj = j - sp0;
-    const int par_par = e.parity ^ 1, cur_par = e.parity;
-    const int64_t prow = (int64_t)pt0 + pj;  // parent row in rec buffers
-
-    // ---- children -> positions ---------------------------------------
-    const int64_t ckey = t < nchild ? tv.key[li][c0 + t] : 0;
-    const uint32_t occ = group8_or(t < nchild ? 1u << (int)(ckey & 7) : 0u);
-    const bool has = (occ >> t) & 1;
-    const int child = c0 + popc32(occ & ((1u << t) - 1));
-    const int64_t crow = (int64_t)pt0 + (child - sc0);
-    int32_t w = 0;
-    int64_t src[C];
-#pragma unroll
-    for (int k = 0; k < C; k++)
-      src[k] = 0;
-    if (has) {
-      const int f0 = tv.fp[li][child], f1 = tv.fp[li][child + 1];
-      w = f1 - f0;
-      if (kEnc) {
-        if (haar) {
-          const int32_t* lf = ctx.haar_lf[li];
-#pragma unroll
-          for (int k = 0; k < C; k++)
-            src[k] = fp_from_int(lf[(size_t)child * C + k]);
-        } else {
-#pragma unroll
-          for (int k = 0; k < C; k++)
-            src[k] = fp_from_int((int32_t)(
-              (uint32_t)ctx.attr_prefix[(size_t)f1 * C + k]
-              - (uint32_t)ctx.attr_prefix[(size_t)f0 * C + k]));
-        }
-      }
-    }
-
-    // ---- node qp on the way down (see oracle/raht_oracle.c,
-    //      descend_block_qp; tmc3/RAHT.cpp:185-189 vs :246-253) ----------
-    int32_t nq0 = 0, nq1 = 0;
-    if (ctx.asc_qp) {
-      int32_t a0 = 0, a1 = 0;
-      if (has) {
-        a0 = ctx.asc_qp[li][(size_t)child * 2];
-        a1 = ctx.asc_qp[li][(size_t)child * 2 + 1];
-      }
-      // ascent averages of the pair / quad this position belongs to
-      int32_t wa = w, b0 = a0, b1 = a1;   // current sub-tree weight, avg
-      int32_t st_w[3], st_a0[3], st_a1[3], st_pw[3];
-#pragma unroll
-      for (int st = 0; st < 3; st++) {
-        const int bit = 1 << st;
-        const int32_t pw = lane_xor8(wa, bit);
-        const int32_t p0 = lane_xor8(b0, bit), p1 = lane_xor8(b1, bit);
-        st_w[st] = wa;
-        st_a0[st] = b0;
-        st_a1[st] = b1;
-        st_pw[st] = pw;
-        if (wa && pw) {
-          b0 = (b0 + p0) >> 1;
-          b1 = (b1 + p1) >> 1;
-        } else if (pw) {
-          b0 = p0;
-          b1 = p1;
-        }
-        wa += pw;
-      }
-      // descend: the sub-tree containing this position is the RIGHT one
-      // of a real pair -> its own ascent average, otherwise inherit
-      int32_t d0 = on ? par2(ctx.dqp, par_par)[prow * 2] : 0;
-      int32_t d1 = on ? par2(ctx.dqp, par_par)[prow * 2 + 1] : 0;
-#pragma unroll
-      for (int st = 2; st >= 0; st--) {
-        const int bit = 1 << st;
-        if ((t & bit) && st_w[st] && st_pw[st]) {
-          d0 = st_a0[st];
-          d1 = st_a1[st];
-        }
-      }
-      if (has) {
-        nq0 = d0 >> 4;
-        nq1 = d1 >> 4;
-        if (kRecon) {
-          par2(ctx.dqp, cur_par)[crow * 2] = d0;
-          par2(ctx.dqp, cur_par)[crow * 2 + 1] = d1;
-        }
-      }
-    }
-
-    // ---- butterfly weights + coefficients (mkWeightTree :742) ----------
-    int32_t wl[3], wr[3];
-    int64_t ca[3], cb[3];
-    int32_t cw = w;
-#pragma unroll
-    for (int st = 0; st < 3; st++) {
-      const int bit = 1 << st;
-      const int32_t pw = lane_xor8(cw, bit);
-      const bool left = !(t & bit);
-      wl[st] = left ? cw : pw;
-      wr[st] = left ? pw : cw;
-      ca[st] = cb[st] = 0;
-      if (wl[st] && wr[st]) {
-        if (!haar)
-          raht_coeffs(wl[st], wr[st], lut, &ca[st], &cb[st]);
-        cw = wl[st] + wr[st];
-      } else {
-        cw = left ? wl[st] + wr[st] : 0;
-      }
-    }
-
-    // ---- inter-level prediction (tmc3/RAHT.cpp:1391-1432) --------------
-    const bool inherit_dc = !e.is_root;
-    const bool pred_in_level =
-      on && inherit_dc && prm->raht_prediction_enabled_flag != 0;
-    bool enable_pred = pred_in_level;
-    int neigh_count = 0;
-    int64_t pred[C];
-#pragma unroll
-    for (int k = 0; k < C; k++)
-      pred[k] = 0;
-
-    bool do_search = false;
-    if (pred_in_level) {
-      if (ext && nchild == 1) {
-        enable_pred = false;
-        neigh_count = 19;
-      } else if (par2(ctx.nneigh, par_par)[prow] < prm->raht_prediction_threshold0) {
-        enable_pred = false;
-      } else {
-        do_search = true;
-      }
-    }
-    // (group-uniform; other groups of the wave idle through the shuffles)
-    int pn[3] = {-1, -1, -1};  // neighbour i = 1 + t + 8*slot
-    {
-      // the three lower_bound searches of a lane advance in lock step, so
-      // their probes are in flight together (12 dependent steps, not 36)
-      int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}, end[3] = {0, 0, 0};
-      int64_t want[3] = {0, 0, 0};
-      if (do_search) {
-        const int64_t cur_pos = tv.key[li + 1][j];
-        const uint64_t base = morton3d_add((uint64_t)cur_pos, ~0ull);
-        const int64_t range = prm->raht_prediction_search_range;
-#pragma unroll
-        for (int slot = 0; slot < 3; slot++) {
-          const int i = 1 + t + 8 * slot;
-          if (i < 19 && (occ & neigh_mask(i))) {
-            const int64_t np = (int64_t)morton3d_add(base, neigh_offset(i));
-            int64_t d = np - cur_pos;
-            if (d >= 0) {
-              d = d >= range ? range : d;
-              lo[slot] = j;
-              end[slot] = (d + 1 < (int64_t)(sp1 - j)) ? j + (int)(d + 1) : sp1;
-            } else {
-              d = (-d) >= range ? range : -d;
-              end[slot] = j;
-              lo[slot] = (d < (int64_t)(j - sp0)) ? j - (int)d : sp0;
-            }
-            hi[slot] = end[slot];
-            want[slot] = np;
-          }
-        }
-      }
-      const int64_t* __restrict__ pkey = tv.key[li + 1];
-      while (__any((lo[0] < hi[0]) | (lo[1] < hi[1]) | (lo[2] < hi[2]))) {
-        int mid[3];
-        int64_t kv[3];
-#pragma unroll
-        for (int slot = 0; slot < 3; slot++) {
-          mid[slot] = lo[slot] + ((hi[slot] - lo[slot]) >> 1);
-          kv[slot] = lo[slot] < hi[slot] ? pkey[mid[slot]] : 0;
-        }
-#pragma unroll
-        for (int slot = 0; slot < 3; slot++) {
-          if (lo[slot] < hi[slot]) {
-            if (kv[slot] < want[slot])
-              lo[slot] = mid[slot] + 1;
-            else
-              hi[slot] = mid[slot];
-          }
-        }
-      }
-#pragma unroll
-      for (int slot = 0; slot < 3; slot++) {
-        if (lo[slot] < end[slot] && pkey[lo[slot]] == want[slot])
-          pn[slot] = lo[slot];
-      }
-    }
-    {
-      int found = (pn[0] >= 0) + (pn[1] >= 0) + (pn[2] >= 0);
-      found = group8_sum(found);
-      if (do_search) {
-        neigh_count = found + 1;
-        if (neigh_count < prm->raht_prediction_threshold1)
-          enable_pred = false;
-      }
-    }
-    // intraDcPred (tmc3/RAHT.cpp:421-589), parent-level neighbours
-    {
-      const bool run = do_search && enable_pred;
-      int wsum = 0;
-      if (__any(run)) {
-      int64_t lim_lo = 0, lim_hi = 0;
-      const int64_t* __restrict__ prec = par2(ctx.rec, par_par);
-      const int64_t rbase = (int64_t)pt0 - sp0;
-      // every lane fetches the values of the neighbours it searched (and of
-      // the parent itself) in ONE round trip; the 19-step loop below then
-      // runs on registers -- with the loads inside it, each step's outlier
-      // test serialised the next step's load
-      int64_t nb_v[3][C], own_v[C];
-#pragma unroll
-      for (int k = 0; k < C; k++)
-        own_v[k] = run ? prec[(rbase + j) * C + k] : 0;
-#pragma unroll
-      for (int slot = 0; slot < 3; slot++)
-#pragma unroll
-        for (int k = 0; k < C; k++)
-          nb_v[slot][k] = (run && pn[slot] >= 0) ? prec[(rbase + pn[slot]) * C + k] : 0;
-#pragma unroll
-      for (int i = 0; i < 19; i++) {
-        int q;
-        int64_t v[C];
-        if (i == 0) {
-          q = j;
-#pragma unroll
-          for (int k = 0; k < C; k++)
-            v[k] = own_v[k];
-        } else {
-          const int owner = (threadIdx.x & 56) | ((i - 1) & 7);
-          q = __shfl(pn[(i - 1) >> 3], owner);
-#pragma unroll
-          for (int k = 0; k < C; k++)
-            v[k] = shfl_i64(nb_v[(i - 1) >> 3][k], owner);
-        }
-        if (!run || q < 0)
-          continue;
-        if (i) {
-          if (10 * v[0] <= lim_lo || 10 * v[0] >= lim_hi)
-            continue;
-        } else {
-          lim_lo = 2 * v[0];
-          lim_hi = 25 * v[0];
-        }
-        if (has && ((neigh_mask(i) >> t) & 1)) {
-          const int64_t pw = prm->pred_weight_parent[i];
-          wsum += (int)pw;
-          const int64_t mul = ext ? pw : (pw << kFpFrac);
-#pragma unroll
-          for (int k = 0; k < C; k++)
-            pred[k] += v[k] * mul;
-        }
-      }
-      }
-      if (run && has) {
-        const int64_t div = pred_divisor(wsum);
-#pragma unroll
-        for (int k = 0; k < C; k++) {
-          pred[k] = fp_mul_c(pred[k], div);
-          if (haar)
-            pred[k] = (pred[k] >> kFpFrac) << kFpFrac;
-        }
-      }
-    }
-
-    // ---- normalise (tmc3/RAHT.cpp:1445-1499) ---------------------------
-    if (!haar && w > 1) {
-      if (kEnc) {
-#pragma unroll
-        for (int k = 0; k < C; k++)
-          src[k] = scale_rsqrt(src[k], w, lut);
-      }
-      if (enable_pred) {
-        const int64_t sq = sqrt_weight(w, lut);
-#pragma unroll
-        for (int k = 0; k < C; k++)
-          pred[k] = fp_mul_c(pred[k], sq);
-      }
-    }
-
-    // ---- forward butterflies (tmc3/RAHT.cpp:671-701) -------------------
-    // (group-uniform decision which buffers to transform, :1504-1533)
-#pragma unroll
-    for (int st = 0; st < 3; st++) {
-      const int bit = 1 << st;
-      const bool left = !(t & bit);
-      const bool both = wl[st] && wr[st];
-      const bool swap = !wl[st] && wr[st];
-#pragma unroll
-      for (int k = 0; k < C; k++) {
-        if (kEnc) {
-          const int64_t own = src[k], oth = shfl_xor_i64(own, bit);
-          if (both) {
-            if (haar) {
-              const int64_t hf = left ? oth - own : own - oth;
-              src[k] = left ? own + ((hf >> (1 + kFpFrac)) << kFpFrac) : hf;
-            } else {
-              src[k] = left ? fp_mul_c(oth, cb[st]) + fp_mul_c(own, ca[st])
-                            : fp_mul_c(own, ca[st]) - fp_mul_c(oth, cb[st]);
-            }
-          } else if (swap) {
-            src[k] = oth;
-          }
-        }
-        {
-          const int64_t own = pred[k], oth = shfl_xor_i64(own, bit);
-          if (enable_pred) {
-            if (both) {
-              if (haar) {
-                const int64_t hf = left ? oth - own : own - oth;
-                pred[k] = left ? own + ((hf >> (1 + kFpFrac)) << kFpFrac) : hf;
-              } else {
-                pred[k] = left ? fp_mul_c(oth, cb[st]) + fp_mul_c(own, ca[st])
-                               : fp_mul_c(own, ca[st]) - fp_mul_c(oth, cb[st]);
-              }
-            } else if (swap) {
-              pred[k] = oth;
-            }
-          }
-        }
-      }
-    }
-
-    // ---- coefficient slot of this position (scanBlock :776-791) --------
-    const uint32_t present = group8_bits(on && cw != 0) | (on ? 1u : 0u);
-    // scan order 0,4,2,1,6,5,3,7 -> scan position of t
-    const int spos = (0x74516230u >> (4 * t)) & 7;
-    const uint32_t pscan = ((present >> 0) & 1) | (((present >> 4) & 1) << 1)
-      | (((present >> 2) & 1) << 2) | (((present >> 1) & 1) << 3)
-      | (((present >> 6) & 1) << 4) | (((present >> 5) & 1) << 5)
-      | (((present >> 3) & 1) << 6) | (((present >> 7) & 1) << 7);
-    const int rank = popc32(pscan & ((1u << spos) - 1));
-    const bool coded = on && ((present >> t) & 1) && (t != 0 || !inherit_dc);
-    // slice-relative coefficient index
-    const int cidx = e.coeff_base
-      + (inherit_dc ? (c0 - sc0) - pj + rank - 1 : rank);
-    int32_t* __restrict__ cplane = ctx.coeffs + (size_t)pt0 * C + cidx;
-
-    if (coded) {
-      int ac0 = 0, ac1 = 0;
-      if (e.ac_layer < prm->num_ac_qp_layers && t) {
-        ac0 = prm->ac_qp_offset[e.ac_layer][t - 1][0];
-        ac1 = prm->ac_qp_offset[e.ac_layer][t - 1][1];
-      }
-      Quantizer qa[2];
-      qpset_quantizers(prm, e.qp_layer, nq0 + ac0, nq1 + ac1, qa);
-
-      if (kEnc) {
-        if (enable_pred) {
-#pragma unroll
-          for (int k = 0; k < C; k++)
-            src[k] -= pred[k];
-        }
-        if (MODE == kAnalyze) {
-          // RDOQ statistics (tmc3/RAHT.cpp:1584-1616)
-          Quantizer qr[2];
-          qpset_quantizers(prm, e.qp_layer, nq0, nq1, qr);
-          int64_t sum_coeff = 0, dist2 = 0;
-          int rate_coeff = 0;
-#pragma unroll
-          for (int k = 0; k < C; k++) {
-            const int64_t co = fp_round(src[k]);
-            dist2 += co * co;
-            int64_t aq = quantize(qr[k ? 1 : 0], co * 256);
-            aq = aq < 0 ? -aq : aq;
-            sum_coeff += aq;
-            rate_coeff += rate_log_small(aq);
-          }
-          uint32_t d = kDescNever;
-          if (sum_coeff < 3) {
-            const int64_t l0 = qr[0].step;
-            const int64_t lambda = l0 * l0 * (C == 1 ? 25 : 35);
-            d = rdoq_threshold(dist2, lambda, rate_coeff, (uint32_t)n_s);
-            if (sum_coeff == 0)
-              d |= kDescZero;
-          }
-          ctx.desc[(size_t)pt0 + cidx] = d;
-        }
-#pragma unroll
-        for (int k = 0; k < C; k++) {
-          const int64_t co = quantize(qa[k ? 1 : 0], fp_round(src[k]) * 256);
-          cplane[(size_t)k * n_s] = (int32_t)co;
-          if (MODE == kFused)
-            pred[k] += fp_from_int(dequantize(qa[k ? 1 : 0], co));
-        }
-      } else {
-#pragma unroll
-        for (int k = 0; k < C; k++) {
-          const int64_t co = cplane[(size_t)k * n_s];
-          pred[k] += fp_from_int(dequantize(qa[k ? 1 : 0], co));
-        }
-      }
-    }
-
-    if (!kRecon)
-      continue;
-
-    // ---- DC inheritance (tmc3/RAHT.cpp:1727-1742) ----------------------
-    if (on && inherit_dc && t == 0) {
-#pragma unroll
-      for (int k = 0; k < C; k++) {
-        const int64_t val = par2(ctx.rec_us, par_par)[prow * C + k];
-        if (ext)
-          pred[k] = val;
-        else
-          pred[k] = val > 0 ? val << (kFpFrac - 2) : -((-val) << (kFpFrac - 2));
-      }
-    }
-
-    // ---- inverse butterflies (tmc3/RAHT.cpp:707-737) -------------------
-#pragma unroll
-    for (int st = 2; st >= 0; st--) {
-      const int bit = 1 << st;
-      const bool left = !(t & bit);
-      const bool both = wl[st] && wr[st];
-      const bool swap = !wl[st] && wr[st];
-#pragma unroll
-      for (int k = 0; k < C; k++) {
-        const int64_t own = pred[k], oth = shfl_xor_i64(own, bit);
-        if (both) {
-          if (haar) {
-            // left lane holds lf, right lane hf
-            const int64_t lf = left ? own : oth, hf = left ? oth : own;
-            const int64_t lv = lf - ((hf >> (1 + kFpFrac)) << kFpFrac);
-            pred[k] = left ? lv : hf + lv;
-          } else {
-            pred[k] = left ? fp_mul_c(own, ca[st]) - fp_mul_c(oth, cb[st])
-                           : fp_mul_c(oth, cb[st]) + fp_mul_c(own, ca[st]);
-          }
-        } else if (swap) {
-          pred[k] = oth;
-        }
-      }
-    }
-
-    // ---- store the children's reconstruction (:1754-1806) -------------
-    if (has) {
-#pragma unroll
-      for (int k = 0; k < C; k++) {
-        int64_t v = pred[k];
-        par2(ctx.rec_us, cur_par)[crow * C + k] = ext ? v : fp_round(v * 4);
-        if (!haar && w > 1)
-          v = scale_rsqrt(v, w, lut);
-        par2(ctx.rec, cur_par)[crow * C + k] = ext ? v : fp_round(v);
-      }
-      par2(ctx.nneigh, cur_par)[crow] = inherit_dc ? neigh_count : 19;
-    }
   }
 }
 

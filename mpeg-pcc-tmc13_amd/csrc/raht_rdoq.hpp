@@ -24,8 +24,8 @@
 // are first evaluated under the two extreme hypotheses (L as old / as
 // recent as possible); when both agree on the tile's outgoing L the tile
 // is "closed", when neither produces a reset it is "transparent", and only
-// the rare remaining tiles are re-evaluated in order by the per-slice
-// carry pass.
+// the rare remaining ("open") tiles wait for their predecessor
+// (rdoq_resolve_kernel: one launch per level).
 #pragma once
 
 #include "raht_common.hpp"
@@ -42,9 +42,8 @@ struct RdoqCtx {
   int32_t num_tiles;
   const uint32_t* desc;      // [N], slice s at pt_off[s]
   int32_t* coeffs;
-  int2* tile_sum;            // [num_tiles] {status, l_out}
-  int32_t* tile_lin;         // [num_tiles] incoming L of each tile
   int32_t* slice_l;          // [S] L carried from level to level
+  unsigned long long* state; // [num_tiles] look-back words of rdoq_resolve_kernel
   int32_t li;
   int32_t c;
 };
@@ -109,124 +108,152 @@ tile_range(const RdoqCtx& cx, int gt, int* s_out, int* a, int* b)
   return ta < tb;
 }
 
-// pass 1: classify tiles
+// ---- classify, carry and apply in ONE launch: decoupled look-back over the tiles ----
+// One wavefront per tile, tiles in launch order.  A tile first evaluates itself
+// under the two extreme hypotheses (as rdoq_classify_kernel does) and publishes
+// what it can: "transparent" (no reset either way: L passes through) or
+// "closed" (its outgoing L is the same either way).  Its own incoming L is the
+// outgoing L of the nearest predecessor that is not transparent -- found by
+// reading 64 predecessors' words at a time -- or what the previous level left
+// (slice_l) when the walk reaches the slice's first tile of the level.  Only
+// an OPEN predecessor (hypotheses disagree: rare) has to be waited for; it
+// publishes its outgoing L once it has its own incoming one.  Words carry the
+// level as an epoch, data and flag in one 8-byte relaxed agent-scope access.
+// Predecessors have lower wave indices and workgroups are dispatched in
+// order, so the tile being waited for is always resident or done.
 __global__ __launch_bounds__(256) void
-rdoq_classify_kernel(RdoqCtx cx)
+rdoq_resolve_kernel(RdoqCtx cx)
 {
   if (tree_failed(cx.tv))
     return;
   const int lane = lane_id();
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / kWave;
-  const int nwaves = gridDim.x * blockDim.x / kWave;
-  for (int gt = wave; gt < cx.num_tiles; gt += nwaves) {
-    int s, a, b;
-    if (!tile_range(cx, gt, &s, &a, &b))
+  const int gt = (blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+  if (gt >= cx.num_tiles)
+    return;
+  int s, a, b;
+  if (!tile_range(cx, gt, &s, &a, &b))
+    return;
+  const unsigned long long ep = (unsigned long long)(cx.li + 1) << 48;
+  const int pt0 = cx.tv.pt_off[s];
+  const int n_s = cx.tv.pt_off[s + 1] - pt0;
+  const uint32_t* __restrict__ desc = cx.desc + pt0;
+  int32_t* __restrict__ co = cx.coeffs + (size_t)pt0 * cx.c;
+  int la_lvl, lb_lvl;
+  level_coeff_range(cx, s, &la_lvl, &lb_lvl);
+  const int gt_first = cx.tile_base[s] + la_lvl / kRdoqTile;  // the slice's first tile of this level
+  const int gt_last = cx.tile_base[s] + (lb_lvl - 1) / kRdoqTile;
+
+  // 1. the tile under the two hypotheses; its descriptors stay in registers
+  // (2048 / 64 = 32 per lane)
+  uint32_t dreg[kRdoqTile / kWave];
+  const int la0 = -1, lb0 = a - 1;
+  int la = la0, lb = lb0;
+#pragma unroll
+  for (int r = 0; r < kRdoqTile / kWave; r++) {
+    const int i0 = a + r * kWave;
+    const int i = i0 + lane;
+    const bool valid = i < b;
+    dreg[r] = valid ? desc[i] : kDescZero;
+  }
+#pragma unroll
+  for (int r = 0; r < kRdoqTile / kWave; r++) {
+    const int i0 = a + r * kWave;
+    if (i0 >= b)
+      break;
+    const int i = i0 + lane;
+    int tz;
+    la = rdoq_chunk(dreg[r], i, i < b, la, i0, &tz);
+    lb = rdoq_chunk(dreg[r], i, i < b, lb, i0, &tz);
+  }
+  int status, l_out = 0;
+  if (lb == lb0) {
+    status = kTileTransparent;
+  } else if (la == lb) {
+    status = kTileClosed;
+    l_out = la;
+  } else {
+    status = kTileOpen;
+  }
+  if (lane == 0 && status != kTileOpen)
+    __hip_atomic_store(
+      &cx.state[gt], ep | ((unsigned long long)(status == kTileClosed ? 2 : 1) << 32) | (uint32_t)l_out,
+      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+  // 2. incoming L: nearest predecessor that is not transparent
+  int l_in = 0;
+  bool have = false;
+  int k0 = gt - 1;  // lane u looks at tile k0 - u
+  unsigned spins = 0;
+  while (!have) {
+    const int k = k0 - lane;
+    unsigned long long w = 0;
+    if (k >= gt_first)
+      w = __hip_atomic_load(&cx.state[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool in = k >= gt_first;
+    const bool ready = !in || (w >> 48) == (unsigned long long)(cx.li + 1);
+    const int kind = in ? (int)((w >> 32) & 0xffff) : 0;
+    // lanes from the first not-ready one on are ignored this round
+    const unsigned long long notready = __ballot(!ready);
+    const unsigned long long decides = __ballot(in && ready && kind >= 2);
+    const unsigned long long outside = __ballot(!in);
+    const unsigned long long stop = notready | decides | outside;
+    if (!stop) {
+      k0 -= kWave;  // 64 transparent tiles: further back
       continue;
-    const uint32_t* __restrict__ desc = cx.desc + cx.tv.pt_off[s];
-    // hypothesis A: no reset since the slice began; B: reset just before
-    const int la0 = -1, lb0 = a - 1;
-    int la = la0, lb = lb0;
-    for (int i0 = a; i0 < b; i0 += kWave) {
-      const int i = i0 + lane;
-      const bool valid = i < b;
-      const uint32_t d = valid ? desc[i] : kDescZero;
-      int tz;
-      la = rdoq_chunk(d, i, valid, la, i0, &tz);
-      lb = rdoq_chunk(d, i, valid, lb, i0, &tz);
     }
-    if (lane == 0) {
-      int2 r;
-      if (lb == lb0) {
-        r.x = kTileTransparent;  // no reset even in the most-reset case
-        r.y = 0;
-      } else if (la == lb) {
-        r.x = kTileClosed;
-        r.y = la;
-      } else {
-        r.x = kTileOpen;
-        r.y = 0;
+    const int first = __ffsll((long long)stop) - 1;
+    if ((decides >> first) & 1) {
+      l_in = (int)(uint32_t)__shfl((int)(uint32_t)w, first);
+      have = true;
+    } else if ((outside >> first) & 1) {
+      l_in = cx.slice_l[s];  // as the previous level (or the coarse kernel) left it
+      have = true;
+    } else {
+      // an undecided predecessor: everything nearer is transparent
+      k0 -= first;
+      if (++spins > (1u << 22)) {
+        if (lane == 0)
+          atomicExch(cx.tv.error, 1);
+        return;
       }
-      cx.tile_sum[gt] = r;
+      __builtin_amdgcn_s_sleep(2);
     }
   }
-}
 
-// pass 2: one wave per slice carries L through the tile summaries
-__global__ __launch_bounds__(64) void
-rdoq_carry_kernel(RdoqCtx cx)
-{
-  if (tree_failed(cx.tv))
-    return;
-  const int lane = lane_id();
-  for (int s = blockIdx.x; s < cx.tv.num_slices; s += gridDim.x) {
-    int la, lb;
-    if (!level_coeff_range(cx, s, &la, &lb) || la >= lb)
-      continue;
-    const uint32_t* __restrict__ desc = cx.desc + cx.tv.pt_off[s];
-    const int gt0 = cx.tile_base[s] + la / kRdoqTile;
-    const int gt1 = cx.tile_base[s] + (lb - 1) / kRdoqTile;
-    int l = cx.slice_l[s];
-    for (int g0 = gt0; g0 <= gt1; g0 += kWave) {
-      const int g = g0 + lane;
-      int2 sum = make_int2(kTileTransparent, 0);
-      if (g <= gt1)
-        sum = cx.tile_sum[g];
-      int lin_mine = 0;
-      const int cnt = gt1 - g0 + 1 < kWave ? gt1 - g0 + 1 : kWave;
-      for (int u = 0; u < cnt; u++) {
-        const int st = __shfl(sum.x, u);
-        const int lo = __shfl(sum.y, u);
-        if (lane == u)
-          lin_mine = l;
-        if (st == kTileClosed) {
-          l = lo;
-        } else if (st == kTileOpen) {
-          // rare: evaluate the tile with its real incoming state
-          const int t0 = (g0 + u - cx.tile_base[s]) * kRdoqTile;
-          const int a = t0 > la ? t0 : la;
-          const int b = t0 + kRdoqTile < lb ? t0 + kRdoqTile : lb;
-          for (int i0 = a; i0 < b; i0 += kWave) {
-            const int i = i0 + lane;
-            const bool valid = i < b;
-            const uint32_t d = valid ? desc[i] : kDescZero;
-            int tz;
-            l = rdoq_chunk(d, i, valid, l, i0, &tz);
-          }
-        }
-      }
-      if (g <= gt1)
-        cx.tile_lin[g] = lin_mine;
+  // 3. an open tile now knows its outgoing L ...
+  if (status == kTileOpen) {
+    int l = l_in;
+#pragma unroll
+    for (int r = 0; r < kRdoqTile / kWave; r++) {
+      const int i0 = a + r * kWave;
+      if (i0 >= b)
+        break;
+      int tz;
+      l = rdoq_chunk(dreg[r], i0 + lane, i0 + lane < b, l, i0, &tz);
     }
+    l_out = l;
     if (lane == 0)
-      cx.slice_l[s] = l;
+      __hip_atomic_store(
+        &cx.state[gt], ep | (3ull << 32) | (uint32_t)l_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else if (status == kTileTransparent) {
+    l_out = l_in;
   }
-}
+  if (gt == gt_last && lane == 0)
+    cx.slice_l[s] = l_out;  // carried to the next level's launch
 
-// pass 3: apply -- zero the coefficients RDOQ drops
-__global__ __launch_bounds__(256) void
-rdoq_apply_kernel(RdoqCtx cx)
-{
-  if (tree_failed(cx.tv))
-    return;
-  const int lane = lane_id();
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) / kWave;
-  const int nwaves = gridDim.x * blockDim.x / kWave;
-  for (int gt = wave; gt < cx.num_tiles; gt += nwaves) {
-    int s, a, b;
-    if (!tile_range(cx, gt, &s, &a, &b))
-      continue;
-    const int pt0 = cx.tv.pt_off[s];
-    const int n_s = cx.tv.pt_off[s + 1] - pt0;
-    const uint32_t* __restrict__ desc = cx.desc + pt0;
-    int32_t* __restrict__ co = cx.coeffs + (size_t)pt0 * cx.c;
-    int l = cx.tile_lin[gt];
-    for (int i0 = a; i0 < b; i0 += kWave) {
+  // 4. ... and every tile applies its decisions
+  {
+    int l = l_in;
+#pragma unroll
+    for (int r = 0; r < kRdoqTile / kWave; r++) {
+      const int i0 = a + r * kWave;
+      if (i0 >= b)
+        break;
       const int i = i0 + lane;
       const bool valid = i < b;
-      const uint32_t d = valid ? desc[i] : kDescZero;
       int tz;
-      l = rdoq_chunk(d, i, valid, l, i0, &tz);
-      const uint32_t thr = d & kDescNever;
+      l = rdoq_chunk(dreg[r], i, valid, l, i0, &tz);
+      const uint32_t thr = dreg[r] & kDescNever;
       if (valid && thr != kDescNever && (uint32_t)tz >= thr) {
         for (int k = 0; k < cx.c; k++)
           co[(size_t)k * n_s + i] = 0;

@@ -60,8 +60,8 @@ class Context:
 
     def kernel_times(self):
         """{kernel name: (total ms, launches)} since the last call."""
-        buf = (_lib.KernelTime * 64)()
-        n = self._lib.gpcc_ctx_kernel_times(self._h, buf, 64)
+        buf = (_lib.KernelTime * 256)()
+        n = self._lib.gpcc_ctx_kernel_times(self._h, buf, 256)
         if n < 0:
             _lib.check(n)
         return {buf[i].name.decode(): (buf[i].total_ms, buf[i].launches) for i in range(n)}

@@ -33,6 +33,9 @@ void lods_generate_cpu(
   int minGeomNodeSizeLog2, const pcc::PCCPointSet3& cloud,
   const pcc::AttributeInterPredParams& attrInterPredParams);
 
+// what this TU did (gpcc_shim_lod_counters)
+long long g_lod_device_calls = 0, g_lod_cpu_calls = 0;
+
 gpcc_ctx*
 lod_device_context()
 {
@@ -131,10 +134,19 @@ AttributeLods::generate(
       }
       indexes.assign(idx.begin(), idx.end());
       numPointsInLod.assign(npl, npl + nl);
+      gpcc_shim::g_lod_device_calls++;
       return;
     }
     if (rc != GPCC_ERR_UNSUPPORTED)
       std::fprintf(stderr, "gpcc: %s; LoD build falls back to the CPU\n", gpcc_last_error());
+  }
+  gpcc_shim::g_lod_cpu_calls++;
+  {
+    const char* strict = std::getenv("GPCC_STRICT");
+    if (strict && strict[0] == '1') {
+      std::fprintf(stderr, "gpcc: GPCC_STRICT=1 and AttributeLods::generate did not run on the device (%s)\n", gpcc_last_error());
+      std::abort();
+    }
   }
   gpcc_shim::lods_generate_cpu(
     *this, aps, abh, geom_num_points_minus1, minGeomNodeSizeLog2, cloud,
@@ -142,3 +154,11 @@ AttributeLods::generate(
 }
 
 }  // namespace pcc
+
+// {LoD builds that ran on the device, builds handed to the reference's CPU body}
+extern "C" void
+gpcc_shim_lod_counters(long long out[2])
+{
+  out[0] = gpcc_shim::g_lod_device_calls;
+  out[1] = gpcc_shim::g_lod_cpu_calls;
+}

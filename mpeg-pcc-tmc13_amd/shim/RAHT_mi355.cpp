@@ -44,6 +44,23 @@ void regionAdaptiveHierarchicalInverseTransformCpu(
 
 namespace {
 
+// What this TU did, for an integrator's log and for the drop-in tests: a
+// silent fallback must not be mistaken for the device path.
+long long g_device_calls = 0, g_cpu_calls = 0;
+
+// GPCC_STRICT=1: a slice that cannot run on the device is an error, not a
+// CPU fallback (CI on a GPU box)
+void
+cpu_fallback(const char* what)
+{
+  g_cpu_calls++;
+  const char* strict = std::getenv("GPCC_STRICT");
+  if (strict && strict[0] == '1') {
+    std::fprintf(stderr, "gpcc: GPCC_STRICT=1 and %s did not run on the device (%s)\n", what, gpcc_last_error());
+    std::abort();
+  }
+}
+
 gpcc_ctx*
 device_context()
 {
@@ -140,11 +157,14 @@ regionAdaptiveHierarchicalTransform(
     int rc = gpcc_raht_forward(
       ctx, &p, mortonCode, qp_offsets_or_null(pointQpOffsets, voxelCount),
       attributes, coefficients, voxelCount, attribCount);
-    if (rc == GPCC_OK)
+    if (rc == GPCC_OK) {
+      g_device_calls++;
       return;
+    }
     if (rc != GPCC_ERR_UNSUPPORTED)
       std::fprintf(stderr, "gpcc: %s; slice falls back to the CPU\n", gpcc_last_error());
   }
+  cpu_fallback("regionAdaptiveHierarchicalTransform");
   regionAdaptiveHierarchicalTransformCpu(
     rahtPredParams, qpset, pointQpOffsets, mortonCode, attributes,
     attribCount, voxelCount, coefficients, rahtExtension, attrInterPredParams);
@@ -165,14 +185,25 @@ regionAdaptiveHierarchicalInverseTransform(
     int rc = gpcc_raht_inverse(
       ctx, &p, mortonCode, qp_offsets_or_null(pointQpOffsets, voxelCount),
       attributes, coefficients, voxelCount, attribCount);
-    if (rc == GPCC_OK)
+    if (rc == GPCC_OK) {
+      g_device_calls++;
       return;
+    }
     if (rc != GPCC_ERR_UNSUPPORTED)
       std::fprintf(stderr, "gpcc: %s; slice falls back to the CPU\n", gpcc_last_error());
   }
+  cpu_fallback("regionAdaptiveHierarchicalInverseTransform");
   regionAdaptiveHierarchicalInverseTransformCpu(
     rahtPredParams, qpset, pointQpOffsets, mortonCode, attributes,
     attribCount, voxelCount, coefficients, rahtExtension, attrInterPredParams);
 }
 
 }  // namespace pcc
+
+// {calls that ran on the device, calls handed to the reference's CPU function}
+extern "C" void
+gpcc_shim_raht_counters(long long out[2])
+{
+  out[0] = pcc::g_device_calls;
+  out[1] = pcc::g_cpu_calls;
+}

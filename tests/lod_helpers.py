@@ -69,10 +69,11 @@ def lift(checker, forward, lf, lod, attrs, coeffs=None, lcp=None, qp_off=None):
     return co, a, np.array(list(l), dtype=np.int8)
 
 
-def ref_operator_roundtrip(lp, transform, rp, qp, chroma, bitdepth, lcp, xyz, attrs):
+def ref_operator_roundtrip(lp, transform, rp, qp, chroma, bitdepth, lcp, xyz, attrs, lib=None):
     """reference AttributeEncoder::encode + AttributeDecoder::decode ->
-    (payload bytes, recon_enc, recon_dec)"""
-    lib = ol.ref().lib
+    (payload bytes, recon_enc, recon_dec).  `lib`: another build of the same
+    harness (oracle/_ref/libtmc3_shim.so: the operator with the device inside)."""
+    lib = lib or ol.ref().lib
     lib.ref_operator_roundtrip.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                            C.c_int32, i32p, i32p, C.c_int32, C.c_int32, i32p, i32p, u8p, C.c_int32]
     xyz = np.ascontiguousarray(xyz, dtype=np.int32)

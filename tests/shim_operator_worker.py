@@ -1,0 +1,59 @@
+"""Runs the reference's whole attribute operator (AttributeEncoder::encode +
+AttributeDecoder::decode) out of oracle/_ref/libtmc3_shim.so -- the reference
+objects with the two link seams replaced by the shim TUs, i.e. with the MI355X
+library inside -- and prints what tests/test_shim_operator.py compares with
+the unmodified build: md5 of the payload (the attribute brick of the
+bitstream) and of the two reconstructions, and the shims' call counters.
+
+    python tests/shim_operator_worker.py <case json>
+
+A process of its own so that only ONE copy of the reference's symbols is ever
+loaded next to the HIP library.  TEST INFRASTRUCTURE."""
+import ctypes as C
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def make_case(case):
+    from mpeg_pcc_tmc13_amd import lod_params, raht_params, synth
+    if case["cloud"] == "dense":
+        xyz, attrs = synth.dense_cloud(case["n"], seed=case["seed"], bits=case.get("bits", 9))
+    else:
+        xyz, attrs = synth.lidar_cloud(case["n"], seed=case["seed"])
+    rp = raht_params(qp=case["qp"], chroma_offset=case["chroma"], subnode=bool(case["subnode"]),
+                     haar=bool(case.get("haar", 0)), search_range=case["search_range"])
+    lp = lod_params(lifting=case["transform"] == 2) if case["transform"] else lod_params()
+    return xyz, attrs, rp, lp
+
+
+def digest(a):
+    return hashlib.md5(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def main():
+    import conftest  # noqa: F401  (loads the package under its alias)
+    import lod_helpers as lh
+    case = json.loads(sys.argv[1])
+    xyz, attrs, rp, lp = make_case(case)
+    import torch  # noqa: F401  (one HIP runtime per process: torch's, see _lib.load)
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libtmc3_shim.so"))
+    payload, rec_enc, rec_dec = lh.ref_operator_roundtrip(
+        lp, case["transform"], rp, case["qp"], case["chroma"], 8, 1, xyz, attrs, lib=lib)
+    raht, lod = (C.c_longlong * 2)(), (C.c_longlong * 2)()
+    lib.gpcc_shim_raht_counters(raht)
+    lib.gpcc_shim_lod_counters(lod)
+    print(json.dumps({"payload_md5": hashlib.md5(payload).hexdigest(), "payload_len": len(payload),
+                      "rec_enc_md5": digest(rec_enc), "rec_dec_md5": digest(rec_dec),
+                      "raht_device": raht[0], "raht_cpu": raht[1], "lod_device": lod[0], "lod_cpu": lod[1]}))
+
+
+if __name__ == "__main__":
+    main()

@@ -14,8 +14,11 @@ BIN = os.path.join(ROOT, "oracle", "_ref", "shim_check")
 needs_bin = pytest.mark.skipif(not os.path.exists(BIN), reason="shim_check not built")
 
 
-def run(n, subnode):
-    return subprocess.run([BIN, str(n), str(subnode)], capture_output=True, text=True, timeout=300)
+def run(n, subnode, strict=False):
+    # GPCC_STRICT=1: the shim aborts instead of falling back to the CPU, so a
+    # green GPU test cannot be a silent fallback
+    env = dict(os.environ, GPCC_STRICT="1") if strict else None
+    return subprocess.run([BIN, str(n), str(subnode)], capture_output=True, text=True, timeout=300, env=env)
 
 
 @needs_bin
@@ -31,7 +34,7 @@ def test_shim_falls_back_to_cpu_without_gpu():
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,subnode", [(50000, 0), (1, 0), (200000, 0), (20000, 1)])
 def test_shim_on_gpu_matches_reference_cpu(n, subnode):
-    r = run(n, subnode)
+    r = run(n, subnode, strict=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "IDENTICAL" in r.stdout and "devices=0" not in r.stdout
     assert "falls back" not in r.stderr
@@ -42,8 +45,9 @@ LOD_BIN = os.path.join(ROOT, "oracle", "_ref", "lod_shim_check")
 needs_lod_bin = pytest.mark.skipif(not os.path.exists(LOD_BIN), reason="lod_shim_check not built")
 
 
-def run_lod(n, lifting):
-    return subprocess.run([LOD_BIN, str(n), str(lifting)], capture_output=True, text=True, timeout=300)
+def run_lod(n, lifting, strict=False):
+    env = dict(os.environ, GPCC_STRICT="1") if strict else None
+    return subprocess.run([LOD_BIN, str(n), str(lifting)], capture_output=True, text=True, timeout=300, env=env)
 
 
 @needs_lod_bin
@@ -59,7 +63,7 @@ def test_lod_shim_falls_back_to_cpu_without_gpu():
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,lifting", [(40000, 1), (40000, 0), (1, 1), (300000, 1)])
 def test_lod_shim_on_gpu_matches_reference_cpu(n, lifting):
-    r = run_lod(n, lifting)
+    r = run_lod(n, lifting, strict=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "identical" in r.stdout and "path=device" in r.stdout
     assert "falls back" not in r.stderr
