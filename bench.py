@@ -431,49 +431,91 @@ def pmc_traffic(args, kernel):
     return rec["fetch_bytes_per_launch"] + rec["write_bytes_per_launch"]
 
 
-def lifting_leg(ctx, args):
-    """BASELINE configs[2] shape on one GPU: the lifting attribute coder of one
-    dense colour cloud minus the entropy loop -- encoder side = LoD build (kNN
-    predictor search) + lifting forward, decoder side = LoD build + lifting
-    inverse, each ONE call whose predictors stay on the device
-    (gpcc_lift_encode_attr / gpcc_lift_decode_attr).  Host tier: positions and
-    attributes come from and go to host buffers, so these rates include the
-    PCIe copies."""
+def lifting_leg(ctx, args, torch=None, dev=None):
+    """BASELINE configs[2] on one GPU: the lifting attribute coder of a 5M-point
+    dense colour cloud in 5 slices of 1M points minus the entropy loop --
+    encoder side = LoD build (kNN predictor search) + lifting forward, decoder
+    side = LoD build + lifting inverse -- through the DEVICE tier: positions,
+    attributes, coefficients and the LoD structure stay in HBM
+    (gpcc_dev_lift_encode_attr / gpcc_dev_lift_decode_attr).  Algorithmic bytes
+    (SURVEY.md 8(d)): LoD build 40 B/pt, lifting encode 28 + 12C, decode 28 + 8C."""
     from mpeg_pcc_tmc13_amd import lift_params, lod_params, synth
-    n = min(args.points, 1_000_000)
-    xyz, col = synth.dense_cloud(n, seed=77, bits=10)
-    n = len(xyz)
+    import torch
+    dev = torch.device("cuda", torch.cuda.current_device())
+    slices = 5 if args.points >= 1_000_000 else 2
+    per = min(args.points, 1_000_000)
+    clouds = [synth.dense_cloud(per, seed=77 + i, bits=10) for i in range(slices)]
+    sizes = [len(c[0]) for c in clouds]
+    offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    n, c = int(offsets[-1]), 3
     lp = lod_params()
-    ctx.lift_encode_attr(lp, lift_params([1000], qp=34), xyz[:1000], col[:1000])  # warm-up (module load, arena)
-    ctx.lift_encode_attr(lp, lift_params([n], qp=34), xyz, col)
-    lf = lift_params([n], qp=34)
-    t0 = time.perf_counter()
-    co, rec, lcp, idx = ctx.lift_encode_attr(lp, lf, xyz, col)
-    t_enc = time.perf_counter() - t0
-    lf2 = lift_params([n], qp=34)
-    t0 = time.perf_counter()
-    dec = ctx.lift_decode_attr(lp, lf2, xyz, co, lcp)
-    t_dec = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    g = ctx.lod_build(lp, xyz)
-    t_lod = time.perf_counter() - t0
-    res = {"workload": f"{n}-point S-dense colour cloud, {lf.num_lods} LoDs, distance sub-sampling, 3 neighbours, qp 34",
+    d_xyz = torch.from_numpy(np.concatenate([x for x, _ in clouds])).to(dev)
+    src = torch.from_numpy(np.concatenate([a for _, a in clouds]).reshape(-1)).to(dev)
+    d_attrs, d_dec = torch.empty_like(src), torch.empty_like(src)
+    d_co = torch.zeros(c * n, dtype=torch.int32, device=dev)
+    d_lod = [torch.zeros(k * n, dtype=torch.int32, device=dev) for k in (1, 3, 3, 1)]
+    ctx.set_morton_bits(30)
+
+    def encode():
+        d_attrs.copy_(src)
+        torch.cuda.synchronize(dev)
+        lfs = [lift_params([s], qp=34) for s in sizes]
+        t0 = time.perf_counter()
+        lcp = ctx.dev_lift_attr(True, lp, lfs, offsets, d_xyz.data_ptr(), d_attrs.data_ptr(), d_co.data_ptr(), c)
+        return time.perf_counter() - t0, lcp, lfs
+
+    def decode(lcp):
+        lfs = [lift_params([s], qp=34) for s in sizes]
+        t0 = time.perf_counter()
+        ctx.dev_lift_attr(False, lp, lfs, offsets, d_xyz.data_ptr(), d_dec.data_ptr(), d_co.data_ptr(), c, lcp=lcp)
+        return time.perf_counter() - t0
+
+    def lod_only():
+        t0 = time.perf_counter()
+        ctx.dev_lod_build(lp, offsets, d_xyz.data_ptr(), *[t.data_ptr() for t in d_lod])
+        return time.perf_counter() - t0
+
+    encode()  # warm-up: arena, code objects
+    t_enc, lcp, lfs = min((encode() for _ in range(2)), key=lambda r: r[0])
+    t_dec = min(decode(lcp) for _ in range(2))
+    t_lod = min(lod_only() for _ in range(2))
+    ok = bool(torch.equal(d_attrs, d_dec))
+    ctx.set_profiling(True)
+    ctx.kernel_times()
+    lod_only()
+    kt = ctx.kernel_times()
+    ctx.set_profiling(False)
+    name, (ms, launches) = max(kt.items(), key=lambda kv: kv[1][0])
+    res = {"workload": f"{slices} x {per}-point S-dense colour slices resident in HBM, {lfs[0].num_lods} LoDs, "
+                       "distance sub-sampling, 3 neighbours, qp 34 (device tier)",
            "encode_ms": round(t_enc * 1e3, 2), "decode_ms": round(t_dec * 1e3, 2),
            "lod_build_alone_ms": round(t_lod * 1e3, 2),
-           "value": round(n / (t_enc + t_dec) / 1e6, 3), "unit": "Mpoints/s (encode + decode, host buffers, PCIe inclusive)",
-           "roundtrip_decoder_equals_encoder_recon": bool(np.array_equal(np.asarray(dec), np.asarray(rec)))}
+           "lod_build_ms_per_Mpoint": round(t_lod * 1e3 / (n / 1e6), 2),
+           "value": round(n / (t_enc + t_dec) / 1e6, 3), "unit": "Mpoints/s (encode + decode)",
+           "roundtrip_decoder_equals_encoder_recon": ok,
+           "roofline": {"bound": "hbm", "kernel": name,
+                        "achieved": round(40 * n / (ms / 1e3) / 1e9, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": round(40 * n / (ms / 1e3) / 1e9 / HBM_PEAK_GBPS, 5),
+                        "algorithmic_bytes_per_point": {"lod_build": 40, "lift_encode": 28 + 12 * c, "lift_decode": 28 + 8 * c},
+                        "pipeline_achieved": {"lod_build": round(40 * n / t_lod / 1e9, 2),
+                                              "encode": round((40 + 28 + 12 * c) * n / t_enc / 1e9, 2),
+                                              "decode": round((40 + 28 + 8 * c) * n / t_dec / 1e9, 2)},
+                        "lod_kernel_ms": {k: round(v[0], 3) for k, v in sorted(kt.items(), key=lambda kv: -kv[1][0])[:8]}}}
+    ctx.set_morton_bits(0)
     if not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import lod_helpers as lh
         import oracle_loader as ol
         kind = "reference" if ol.ref_available() else "port"
+        xyz0 = clouds[0][0]
         t0 = time.perf_counter()
-        o = (lh.ref_lod_generate if kind == "reference" else lh.oracle_lod_generate)(xyz, lp)
+        o = (lh.ref_lod_generate if kind == "reference" else lh.oracle_lod_generate)(xyz0, lp)
         t_ref = time.perf_counter() - t0
+        g = ctx.lod_build(lp, xyz0)
         same = all(np.array_equal(np.asarray(g[k]).astype(np.int64), np.asarray(o[k]).astype(np.int64))
                    for k in ("npl", "indexes", "nc", "ni", "w"))
-        res["cpu_lod_build"] = {"value": round(n / t_ref / 1e6, 4), "unit": "Mpoints/s", "cores": 1, "kind": kind,
-                                "sample": f"AttributeLods::generate on the same {n} points, {t_ref:.2f} s "
+        res["cpu_lod_build"] = {"value": round(len(xyz0) / t_ref / 1e6, 4), "unit": "Mpoints/s", "cores": 1, "kind": kind,
+                                "sample": f"AttributeLods::generate on slice 0 ({len(xyz0)} points), {t_ref:.2f} s "
                                           "(needed once by the encoder and once by the decoder)",
                                 "gpu_result_identical": bool(same)}
     return res

@@ -383,6 +383,45 @@ int gpcc_estimate_dist2(
   gpcc_ctx* ctx, const int32_t* xyz, int32_t n, int32_t sampling_period,
   int32_t search_range, float percentile, int32_t* shift_bits);
 
+/* ------------------------------------------------------------------ */
+/* device tier of the LoD build and the lifting coder                   */
+/* The same operations on buffers resident in HBM, num_slices slices back to
+ * back (offsets[0] = 0 .. offsets[num_slices] = total points): nothing is
+ * allocated per call (workspace from the context's arena) and nothing crosses
+ * PCIe except, per level of detail, the size of the retained list the host
+ * needs to size the next launches.  Positions are not inspected on the host
+ * (coordinates must lie in [0, 2^21)); gpcc_ctx_set_morton_bits bounds the
+ * radix passes of the Morton sort.  The slices are processed one after the
+ * other on the context's stream; the calls return when the batch is done.
+ *
+ * gpcc_dev_lod_build: AttributeLods::generate for every slice.
+ *   d_xyz [N][3]; out d_neigh_count [N], d_neigh_index [N][3], d_neigh_weight
+ *   [N][3], d_indexes [N] -- each slice's in its own predictor order, indices
+ *   slice relative; host: num_points_in_lod [num_slices][GPCC_MAX_LODS],
+ *   num_lods [num_slices]. */
+int gpcc_dev_lod_build(
+  gpcc_ctx* ctx, const gpcc_lod_params* params, int32_t num_slices,
+  const int64_t* offsets, const void* d_xyz, void* d_neigh_count,
+  void* d_neigh_index, void* d_neigh_weight, void* d_indexes,
+  int32_t* num_points_in_lod, int32_t* num_lods);
+
+/* gpcc_dev_lift_encode_attr / _decode_attr: gpcc_lift_encode_attr /
+ * gpcc_lift_decode_attr for every slice, attributes and coefficients in place
+ * in the caller's device buffers.
+ *   lift   [num_slices] parameter blocks (in: QP layers etc.; out: the LoD
+ *          structure of each slice)
+ *   d_attrs [N][c] point order; d_coeffs [N][c] coding order per slice
+ *   lcp_coeffs host [num_slices][GPCC_MAX_LODS] (c == 3 and the flag set)
+ *   d_indexes [N] out, may be NULL */
+int gpcc_dev_lift_encode_attr(
+  gpcc_ctx* ctx, const gpcc_lod_params* lod, gpcc_lift_params* lift,
+  int32_t num_slices, const int64_t* offsets, const void* d_xyz, void* d_attrs,
+  void* d_coeffs, int8_t* lcp_coeffs, void* d_indexes, int32_t c);
+int gpcc_dev_lift_decode_attr(
+  gpcc_ctx* ctx, const gpcc_lod_params* lod, gpcc_lift_params* lift,
+  int32_t num_slices, const int64_t* offsets, const void* d_xyz, void* d_attrs,
+  const void* d_coeffs, const int8_t* lcp_coeffs, void* d_indexes, int32_t c);
+
 #ifdef __cplusplus
 }
 #endif

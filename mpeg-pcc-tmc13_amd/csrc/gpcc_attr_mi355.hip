@@ -1517,7 +1517,7 @@ struct LodDeviceOut {
 int
 lod_build_core(
   gpcc_ctx* ctx, const gpcc_lod_params* lp, const int32_t* xyz, int32_t n,
-  size_t extra_bytes, LodDeviceOut* out)
+  size_t extra_bytes, LodDeviceOut* out, bool xyz_on_device = false)
 {
   if (!ctx)
     return fail(GPCC_ERR_INVALID_ARG, "ctx is null");
@@ -1535,10 +1535,16 @@ lod_build_core(
   if (max_levels < 1 || max_levels > GPCC_MAX_LODS - 1)
     return fail(GPCC_ERR_INVALID_ARG, "num_detail_levels out of range");
   int32_t mx = 0;
-  for (int64_t i = 0; i < (int64_t)n * 3; i++) {
-    if (xyz[i] < 0 || xyz[i] >= (1 << 21))
-      return fail(GPCC_ERR_INVALID_ARG, "coordinate outside [0, 2^21)");
-    mx = std::max(mx, xyz[i]);
+  if (xyz_on_device) {
+    // device tier: the positions are not inspected on the host; the Morton-bits
+    // hint bounds the sort's passes (gpcc_ctx_set_morton_bits, 0 = all 63)
+    mx = ctx->morton_bits > 0 ? (1 << std::min(21, (ctx->morton_bits + 2) / 3)) - 1 : (1 << 21) - 1;
+  } else {
+    for (int64_t i = 0; i < (int64_t)n * 3; i++) {
+      if (xyz[i] < 0 || xyz[i] >= (1 << 21))
+        return fail(GPCC_ERR_INVALID_ARG, "coordinate outside [0, 2^21)");
+      mx = std::max(mx, xyz[i]);
+    }
   }
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
@@ -1570,7 +1576,8 @@ lod_build_core(
   type* name = (type*)dmalloc(sizeof(type) * (count));          \
   if (!name)                                                    \
     return fail(GPCC_ERR_OUT_OF_MEMORY, "hipMalloc(" #name ")");
-    DM(int32_t, d_xyz, 3 * N)
+    DM(int32_t, d_xyz_own, 3 * N)
+    const int32_t* d_xyz = xyz_on_device ? xyz : d_xyz_own;
     DM(int64_t, d_code, N)
     DM(int32_t, d_order, N)
     DM(int32_t, d_pos, 3 * N)
@@ -1601,7 +1608,8 @@ lod_build_core(
     int32_t* d_ticket = d_small;
     int32_t* d_error = d_small + 8;
     int32_t* d_counts = d_small + 16;
-    HIP_TRY(hipMemcpyAsync(d_xyz, xyz, sizeof(int32_t) * 3 * N, hipMemcpyHostToDevice, st));
+    if (!xyz_on_device)
+      HIP_TRY(hipMemcpyAsync(d_xyz_own, xyz, sizeof(int32_t) * 3 * N, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(d_cell_state, 0, sizeof(uint32_t) * 4 * (N + 1), st));
     HIP_TRY(hipMemsetAsync(d_small, 0, sizeof(int32_t) * 64, st));
     HIP_TRY(hipMemsetAsync(d_scan, 0, sizeof(unsigned long long) * 1024, st));
@@ -2444,6 +2452,185 @@ gpcc_estimate_dist2(
   int32_t search_range, float percentile, int32_t* shift_bits)
 {
   return counted(ctx, gpcc_estimate_dist2_impl(ctx, xyz, n, sampling_period, search_range, percentile, shift_bits), n);
+}
+
+}  // extern "C"
+
+// ---- device tier of the LoD build and the lifting coder -----------------------------
+// Slices back to back in HBM, results left in HBM, workspace from the context's
+// arena: no allocation, no PCIe traffic but the few integers per level of detail
+// the host needs to enqueue the next launch (the sizes of the retained lists).
+namespace {
+
+int
+check_slices(gpcc_ctx* ctx, int32_t num_slices, const int64_t* offsets)
+{
+  if (!ctx)
+    return fail(GPCC_ERR_INVALID_ARG, "ctx is null");
+  if (num_slices < 1 || !offsets || offsets[0] != 0)
+    return fail(GPCC_ERR_INVALID_ARG, "bad slice offsets");
+  for (int i = 0; i < num_slices; i++)
+    if (offsets[i + 1] <= offsets[i])
+      return fail(GPCC_ERR_INVALID_ARG, "empty or unordered slice");
+  if (offsets[num_slices] > kMaxPoints)
+    return fail(GPCC_ERR_INVALID_ARG, "more than 2^29 points per batch");
+  return GPCC_OK;
+}
+
+int
+lod_error_word(gpcc_ctx* ctx, const LodDeviceOut& o)
+{
+  int32_t h_err = 0;
+  HIP_TRY(hipMemcpyAsync(&h_err, o.error, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (h_err)
+    return fail(GPCC_ERR_HIP, "a dependency wait in the LoD sub-sampling kernel expired");
+  return GPCC_OK;
+}
+
+int
+dev_lod_build(
+  gpcc_ctx* ctx, const gpcc_lod_params* lp, int32_t num_slices, const int64_t* offsets,
+  const int32_t* d_xyz, int32_t* d_count, int32_t* d_index, int32_t* d_weight,
+  int32_t* d_indexes, int32_t* num_points_in_lod, int32_t* num_lods)
+{
+  int r = check_slices(ctx, num_slices, offsets);
+  if (r)
+    return r;
+  if (!d_xyz || !d_count || !d_index || !d_weight || !d_indexes || !num_points_in_lod || !num_lods)
+    return fail(GPCC_ERR_INVALID_ARG, "null buffer");
+  hipStream_t st = ctx->stream;
+  for (int s = 0; s < num_slices; s++) {
+    const size_t b = (size_t)offsets[s], N = (size_t)(offsets[s + 1] - offsets[s]);
+    LodDeviceOut o;
+    r = lod_build_core(ctx, lp, d_xyz + 3 * b, (int32_t)N, 0, &o, true);
+    if (r)
+      return r;
+    HIP_TRY(hipMemcpyAsync(d_count + b, o.count, sizeof(int32_t) * N, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_index + 3 * b, o.neigh_index, sizeof(int32_t) * 3 * N, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_weight + 3 * b, o.weight, sizeof(int32_t) * 3 * N, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_indexes + b, o.indexes, sizeof(int32_t) * N, hipMemcpyDeviceToDevice, st));
+    r = lod_error_word(ctx, o);  // (the arena is reused by the next slice: the copies are done)
+    if (r)
+      return r;
+    num_lods[s] = (int)o.npl.size();
+    for (size_t i = 0; i < o.npl.size(); i++)
+      num_points_in_lod[(size_t)s * GPCC_MAX_LODS + i] = o.npl[i];
+  }
+  return GPCC_OK;
+}
+
+int
+dev_lift_attr(
+  gpcc_ctx* ctx, bool encoder, const gpcc_lod_params* lod, gpcc_lift_params* lift,
+  int32_t num_slices, const int64_t* offsets, const int32_t* d_xyz, int32_t* d_attrs,
+  int32_t* d_coeffs, int8_t* lcp, int32_t* d_indexes, int32_t c)
+{
+  int r = check_slices(ctx, num_slices, offsets);
+  if (r)
+    return r;
+  if (!lift || !d_xyz || !d_attrs || !d_coeffs || c < 1 || c > 3)
+    return fail(GPCC_ERR_INVALID_ARG, "null buffer or attribute count not 1..3");
+  hipStream_t st = ctx->stream;
+  for (int s = 0; s < num_slices; s++) {
+    gpcc_lift_params* lf = lift + s;
+    const bool lcp_on = c == 3 && lf->last_component_prediction_enabled_flag;
+    if (lcp_on && !lcp)
+      return fail(GPCC_ERR_INVALID_ARG, "lcp_coeffs is null");
+    const size_t b = (size_t)offsets[s], N = (size_t)(offsets[s + 1] - offsets[s]);
+    const int32_t n = (int32_t)N;
+    const size_t extra = 512 + lift_scratch_bytes(n, c) + 1024;
+    LodDeviceOut o;
+    r = lod_build_core(ctx, lod, d_xyz + 3 * b, n, extra, &o, true);
+    if (r)
+      return r;
+    lf->num_lods = (int)o.npl.size();
+    for (size_t i = 0; i < o.npl.size(); i++)
+      lf->num_points_in_lod[i] = o.npl[i];
+    r = check_lift_params(lf, n, c);
+    if (r)
+      return r;
+    Arena ar = ctx->arena;  // carve behind the LoD workspace
+    ar.used = o.arena_end;
+    LiftDev d{};
+    d.nc = o.count;
+    d.ni = o.neigh_index;
+    d.nw = o.weight;
+    d.indexes = o.indexes;
+    d.qp_off = nullptr;
+    d.attrs = d_attrs + b * c;    // the caller's buffers, in place
+    d.coeffs = d_coeffs + b * c;
+    int8_t* d_lcp = ar.take<int8_t>(GPCC_MAX_LODS);
+    char* scratch = ar.base + ar.used;
+    if (ar.used + lift_scratch_bytes(n, c) > ctx->arena.cap)
+      return fail(GPCC_ERR_OUT_OF_MEMORY, "arena reservation too small");
+    int8_t* h_lcp = lcp ? lcp + (size_t)s * GPCC_MAX_LODS : nullptr;
+    if (!encoder && lcp_on)
+      HIP_TRY(hipMemcpyAsync(d_lcp, h_lcp, GPCC_MAX_LODS, hipMemcpyHostToDevice, st));
+    switch (c) {
+    case 1: r = launch_lift<1>(ctx, encoder, lf, n, d, d_lcp, scratch); break;
+    case 2: r = launch_lift<2>(ctx, encoder, lf, n, d, d_lcp, scratch); break;
+    default: r = launch_lift<3>(ctx, encoder, lf, n, d, d_lcp, scratch); break;
+    }
+    if (r)
+      return r;
+    if (encoder && lcp_on)
+      HIP_TRY(hipMemcpyAsync(h_lcp, d_lcp, GPCC_MAX_LODS, hipMemcpyDeviceToHost, st));
+    if (d_indexes)
+      HIP_TRY(hipMemcpyAsync(d_indexes + b, o.indexes, sizeof(int32_t) * N, hipMemcpyDeviceToDevice, st));
+    r = lod_error_word(ctx, o);
+    if (r)
+      return r;
+  }
+  return GPCC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int
+gpcc_dev_lod_build(
+  gpcc_ctx* ctx, const gpcc_lod_params* params, int32_t num_slices, const int64_t* offsets,
+  const void* d_xyz, void* d_neigh_count, void* d_neigh_index, void* d_neigh_weight,
+  void* d_indexes, int32_t* num_points_in_lod, int32_t* num_lods)
+{
+  return counted(
+    ctx,
+    dev_lod_build(
+      ctx, params, num_slices, offsets, (const int32_t*)d_xyz, (int32_t*)d_neigh_count,
+      (int32_t*)d_neigh_index, (int32_t*)d_neigh_weight, (int32_t*)d_indexes,
+      num_points_in_lod, num_lods),
+    offsets && num_slices > 0 ? offsets[num_slices] : 0);
+}
+
+int
+gpcc_dev_lift_encode_attr(
+  gpcc_ctx* ctx, const gpcc_lod_params* lod, gpcc_lift_params* lift, int32_t num_slices,
+  const int64_t* offsets, const void* d_xyz, void* d_attrs, void* d_coeffs,
+  int8_t* lcp_coeffs, void* d_indexes, int32_t c)
+{
+  return counted(
+    ctx,
+    dev_lift_attr(
+      ctx, true, lod, lift, num_slices, offsets, (const int32_t*)d_xyz, (int32_t*)d_attrs,
+      (int32_t*)d_coeffs, lcp_coeffs, (int32_t*)d_indexes, c),
+    offsets && num_slices > 0 ? offsets[num_slices] : 0);
+}
+
+int
+gpcc_dev_lift_decode_attr(
+  gpcc_ctx* ctx, const gpcc_lod_params* lod, gpcc_lift_params* lift, int32_t num_slices,
+  const int64_t* offsets, const void* d_xyz, void* d_attrs, const void* d_coeffs,
+  const int8_t* lcp_coeffs, void* d_indexes, int32_t c)
+{
+  return counted(
+    ctx,
+    dev_lift_attr(
+      ctx, false, lod, lift, num_slices, offsets, (const int32_t*)d_xyz, (int32_t*)d_attrs,
+      (int32_t*)const_cast<void*>(d_coeffs), const_cast<int8_t*>(lcp_coeffs),
+      (int32_t*)d_indexes, c),
+    offsets && num_slices > 0 ? offsets[num_slices] : 0);
 }
 
 }  // extern "C"

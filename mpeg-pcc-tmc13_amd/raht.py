@@ -228,6 +228,34 @@ class Context:
                                                    l.ctypes.data, None, n, c))
         return a
 
+    # ---- device tier of the LoD build / lifting coder (buffers are raw device pointers) ----
+    def dev_lod_build(self, lod_params, offsets, d_xyz, d_count, d_index, d_weight, d_indexes):
+        """gpcc_dev_lod_build -> list of cumulative LoD sizes per slice"""
+        offs = np.ascontiguousarray(offsets, dtype=np.int64)
+        s = len(offs) - 1
+        npl = np.zeros((s, 32), dtype=np.int32)
+        nl = np.zeros(s, dtype=np.int32)
+        _lib.check(self._lib.gpcc_dev_lod_build(
+            self._h, C.byref(lod_params), s, offs.ctypes.data_as(C.POINTER(C.c_int64)), d_xyz, d_count, d_index,
+            d_weight, d_indexes, npl.ctypes.data, nl.ctypes.data))
+        return [list(npl[i, :nl[i]]) for i in range(s)]
+
+    def dev_lift_attr(self, encode, lod_params, lift_params_list, offsets, d_xyz, d_attrs, d_coeffs, c, lcp=None,
+                      d_indexes=None):
+        """gpcc_dev_lift_encode_attr / _decode_attr on device buffers; lift_params_list: one
+        LiftParams per slice (filled with the LoD structure); -> lcp int8 [slices, 32]"""
+        from .params import LiftParams
+        offs = np.ascontiguousarray(offsets, dtype=np.int64)
+        s = len(offs) - 1
+        arr = (LiftParams * s)(*lift_params_list)
+        l = np.zeros((s, 32), dtype=np.int8) if lcp is None else np.ascontiguousarray(lcp, dtype=np.int8).copy()
+        fn = self._lib.gpcc_dev_lift_encode_attr if encode else self._lib.gpcc_dev_lift_decode_attr
+        _lib.check(fn(self._h, C.byref(lod_params), arr, s, offs.ctypes.data_as(C.POINTER(C.c_int64)), d_xyz,
+                      d_attrs, d_coeffs, l.ctypes.data, d_indexes, c))
+        for i in range(s):
+            C.memmove(C.byref(lift_params_list[i]), C.byref(arr[i]), C.sizeof(LiftParams))
+        return l
+
     def zero_run_pack(self, coeffs, n, c, planar):
         """zero-run formation of the entropy loops -> (runs [m], values [m,c], trailing_run)"""
         co = np.ascontiguousarray(coeffs, dtype=np.int32).reshape(-1)

@@ -85,3 +85,45 @@ def test_raht_2M_frame_vs_checker(ctx):
     np.testing.assert_array_equal(co, want_co)
     np.testing.assert_array_equal(rec, want_rec)
     np.testing.assert_array_equal(ctx.raht_inverse(p, morton, co, 1), want_rec)
+
+
+def test_raht_10M_as_slices_vs_checker(ctx):
+    """configs[4] the way the reference would code it: a 10 M-point frame is
+    partitioned into slices of at most ~1.1 M points and every
+    (slice, attribute) is one transform call.  Here the ten slices go through
+    the device tier as ONE batch -- colour, then reflectance -- and every
+    slice is compared with the compiled reference (oracle where it did not
+    travel), reference default flags."""
+    import torch
+    from mpeg_pcc_tmc13_amd import raht_params, synth
+    n = 10_000_000
+    xyz, col = synth.dense_cloud(n, seed=74, bits=13)
+    refl = np.ascontiguousarray((col[:, :1] * 5 + col[:, 2:3]) % 253)
+    # ten slabs of equal point count along x (the reference's partitioners cut
+    # along the longest axis; any partition into <= 1.1 M points will do here)
+    order = np.argsort(xyz[:, 0], kind="stable")
+    slabs = np.array_split(order, 10)
+    chk = ol.ref() if ol.ref_available() else ol.oracle()
+    dev = torch.device("cuda:0")
+    p = raht_params(qp=34)
+    for attrs in (col, refl):
+        c = attrs.shape[1]
+        frames = [synth.sort_by_morton(xyz[s], attrs[s]) for s in slabs]
+        offsets = np.concatenate([[0], np.cumsum([len(f[0]) for f in frames])]).astype(np.int64)
+        d_m = torch.from_numpy(np.concatenate([f[0] for f in frames])).to(dev)
+        d_a = torch.from_numpy(np.concatenate([f[1] for f in frames]).reshape(-1)).to(dev)
+        d_c = torch.zeros(c * n, dtype=torch.int32, device=dev)
+        d_d = torch.zeros_like(d_a)
+        torch.cuda.synchronize()
+        ctx.set_morton_bits(39)
+        ctx.dev_raht_forward(p, offsets, d_m.data_ptr(), d_a.data_ptr(), d_c.data_ptr(), c)
+        ctx.dev_raht_inverse(p, offsets, d_m.data_ptr(), d_d.data_ptr(), d_c.data_ptr(), c)
+        ctx.synchronize()
+        ctx.set_morton_bits(0)
+        co, rec, dec = d_c.cpu().numpy(), d_a.cpu().numpy().reshape(-1, c), d_d.cpu().numpy().reshape(-1, c)
+        np.testing.assert_array_equal(dec, rec)
+        for i, f in enumerate(frames):
+            a, b = int(offsets[i]), int(offsets[i + 1])
+            want_co, want_rec = chk.raht_forward(p, f[0], f[1])
+            np.testing.assert_array_equal(co[c * a:c * b], want_co, err_msg=f"slice {i}, C={c}")
+            np.testing.assert_array_equal(rec[a:b], want_rec, err_msg=f"slice {i}, C={c}")
