@@ -422,6 +422,34 @@ int gpcc_dev_lift_decode_attr(
   int32_t num_slices, const int64_t* offsets, const void* d_xyz, void* d_attrs,
   const void* d_coeffs, const int8_t* lcp_coeffs, void* d_indexes, int32_t c);
 
+/* ------------------------------------------------------------------ */
+/* several GPUs from one host process                                   */
+/* Slices are the reference's independent units (tmc3/encoder.cpp:544-571): a
+ * single-process C++ host (the reference is one) shards a batch of slices over
+ * the GPUs of a node with these entries.  gpcc_multi owns one context per
+ * listed device; a call gives every device a contiguous, size-balanced run of
+ * the slices, runs the transforms concurrently and gathers reconstructions and
+ * coefficients on devices[0] -- RCCL send / receive over xGMI (librccl is
+ * loaded on first use) -- from where one download fills the host buffers.
+ * Listing one physical device several times is allowed (the gather is then a
+ * device copy): it exercises the sharding on a one-GPU box.
+ *   offsets [num_slices + 1], morton [N] (ascending per slice), attrs [N][c]
+ *   (forward: in source, out reconstruction; inverse: out), coeffs planar per
+ *   slice as for gpcc_dev_raht_forward.  Region QP offsets are taken as zero. */
+typedef struct gpcc_multi gpcc_multi;
+int gpcc_multi_create(const int32_t* devices, int32_t num_devices, gpcc_multi** out);
+void gpcc_multi_destroy(gpcc_multi* m);
+int gpcc_multi_num_devices(const gpcc_multi* m);
+int gpcc_multi_uses_rccl(const gpcc_multi* m); /* 1: the gather goes through RCCL */
+int gpcc_multi_raht_forward(
+  gpcc_multi* m, const gpcc_raht_params* params, int32_t num_slices,
+  const int64_t* offsets, const int64_t* morton, int32_t* attrs,
+  int32_t* coeffs, int32_t c);
+int gpcc_multi_raht_inverse(
+  gpcc_multi* m, const gpcc_raht_params* params, int32_t num_slices,
+  const int64_t* offsets, const int64_t* morton, int32_t* attrs,
+  const int32_t* coeffs, int32_t c);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,6 +20,8 @@ ABI_SYMBOLS = [
     "gpcc_lift_forward", "gpcc_lift_inverse", "gpcc_lod_compute_weights", "gpcc_lod_build", "gpcc_estimate_dist2", "gpcc_raht_encode_attr", "gpcc_raht_decode_attr",
     "gpcc_lift_encode_attr", "gpcc_lift_decode_attr", "gpcc_zero_run_pack", "gpcc_raht_encode_attr_packed",
     "gpcc_dev_lod_build", "gpcc_dev_lift_encode_attr", "gpcc_dev_lift_decode_attr",
+    "gpcc_multi_create", "gpcc_multi_destroy", "gpcc_multi_num_devices", "gpcc_multi_uses_rccl",
+    "gpcc_multi_raht_forward", "gpcc_multi_raht_inverse",
 ]
 
 
@@ -95,6 +97,13 @@ def load():
     lib.gpcc_dev_lod_build.argtypes = [vp, C.POINTER(LodParams), i32, i64p, vp, vp, vp, vp, vp, vp, vp]
     for name in ("gpcc_dev_lift_encode_attr", "gpcc_dev_lift_decode_attr"):
         getattr(lib, name).argtypes = [vp, C.POINTER(LodParams), vp, i32, i64p, vp, vp, vp, vp, vp, i32]
+    lib.gpcc_multi_create.argtypes = [C.POINTER(i32), i32, C.POINTER(vp)]
+    lib.gpcc_multi_destroy.argtypes = [vp]
+    lib.gpcc_multi_destroy.restype = None
+    lib.gpcc_multi_num_devices.argtypes = [vp]
+    lib.gpcc_multi_uses_rccl.argtypes = [vp]
+    for name in ("gpcc_multi_raht_forward", "gpcc_multi_raht_inverse"):
+        getattr(lib, name).argtypes = [vp, pp, i32, i64p, vp, vp, vp, i32]
     _lib = lib
     return lib
 

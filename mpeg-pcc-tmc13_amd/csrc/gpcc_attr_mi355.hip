@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <dlfcn.h>
 #include <cstring>
 #include <map>
 #include <string>
@@ -2631,6 +2632,295 @@ gpcc_dev_lift_decode_attr(
       (int32_t*)const_cast<void*>(d_coeffs), const_cast<int8_t*>(lcp_coeffs),
       (int32_t*)d_indexes, c),
     offsets && num_slices > 0 ? offsets[num_slices] : 0);
+}
+
+}  // extern "C"
+
+// ---- several GPUs from one host process ----------------------------------------------
+// The reference is one single-threaded process that codes slice after slice;
+// slices are independent units (tmc3/encoder.cpp:544-571).  gpcc_multi owns one
+// context per device, gives every device a contiguous, size-balanced run of the
+// batch's slices, runs the transforms concurrently (every device on its own
+// stream; the host only enqueues), and brings the coefficient and
+// reconstruction buffers together on the first device -- RCCL send / receive
+// over xGMI when the devices are distinct -- from where one download hands
+// them to the host's entropy coder.  RCCL is loaded on first use (dlopen), the
+// rest of the library does not depend on it.
+namespace {
+
+typedef struct ncclComm* ncclComm_t;
+struct RcclApi {
+  void* handle = nullptr;
+  int (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  int (*CommDestroy)(ncclComm_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  int (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  bool load()
+  {
+    if (handle)
+      return true;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (handle)
+        break;
+    }
+    if (!handle)
+      return false;
+#define RCCL_SYM(field, sym) \
+  field = reinterpret_cast<decltype(field)>(dlsym(handle, sym)); \
+  if (!field)                                                     \
+    return false;
+    RCCL_SYM(CommInitAll, "ncclCommInitAll")
+    RCCL_SYM(CommDestroy, "ncclCommDestroy")
+    RCCL_SYM(GroupStart, "ncclGroupStart")
+    RCCL_SYM(GroupEnd, "ncclGroupEnd")
+    RCCL_SYM(Send, "ncclSend")
+    RCCL_SYM(Recv, "ncclRecv")
+    RCCL_SYM(GetErrorString, "ncclGetErrorString")
+#undef RCCL_SYM
+    return true;
+  }
+};
+constexpr int kNcclInt32 = 2;  // ncclInt32 (rccl.h)
+
+}  // namespace
+
+struct gpcc_multi {
+  std::vector<int> devices;
+  std::vector<gpcc_ctx*> ctx;
+  std::vector<ncclComm_t> comm;  // empty: the devices are not distinct (or one): plain copies
+  RcclApi rccl;
+  // per device: its part of the batch in HBM (pooled buffers of its context)
+  struct Part {
+    int s0 = 0, s1 = 0;  // slices [s0, s1)
+    int64_t* d_m = nullptr;
+    int32_t *d_a = nullptr, *d_c = nullptr;
+  };
+  std::vector<Part> part;
+};
+
+namespace {
+
+// contiguous runs of slices: device d's run ends at the slice boundary nearest
+// to its share (d + 1) / nd of the points (a run may be empty when there are
+// fewer slices than devices)
+void
+shard_slices(int num_slices, const int64_t* offsets, int nd, std::vector<gpcc_multi::Part>* part)
+{
+  part->assign(nd, gpcc_multi::Part());
+  const int64_t total = offsets[num_slices];
+  int s = 0;
+  for (int d = 0; d < nd; d++) {
+    (*part)[d].s0 = s;
+    if (d == nd - 1) {
+      s = num_slices;
+    } else {
+      const int64_t target = total * (d + 1) / nd;
+      while (s < num_slices
+             && std::llabs(offsets[s + 1] - target) <= std::llabs(offsets[s] - target))
+        s++;
+    }
+    (*part)[d].s1 = s;
+  }
+}
+
+int
+multi_transform(
+  gpcc_multi* m, const gpcc_raht_params* params, bool encoder, int32_t num_slices,
+  const int64_t* offsets, const int64_t* morton, int32_t* attrs, int32_t* coeffs, int32_t c)
+{
+  if (!m)
+    return fail(GPCC_ERR_INVALID_ARG, "multi context is null");
+  int r = check_slices(m->ctx[0], num_slices, offsets);
+  if (r)
+    return r;
+  if (!morton || !attrs || !coeffs || c < 1 || c > 3)
+    return fail(GPCC_ERR_INVALID_ARG, "null buffer or attribute count not 1..3");
+  const int nd = (int)m->devices.size();
+  shard_slices(num_slices, offsets, nd, &m->part);
+  const int64_t n_total = offsets[num_slices];
+  int bits = 1;
+  for (int s = 0; s < num_slices; s++)
+    bits = std::max(bits, bitlen64((uint64_t)(morton[offsets[s]] ^ morton[offsets[s + 1] - 1])));
+  auto release = [&]() {
+    for (int d = 0; d < nd; d++) {
+      auto& p = m->part[d];
+      pool_free(m->ctx[d], p.d_m);
+      pool_free(m->ctx[d], p.d_a);
+      pool_free(m->ctx[d], p.d_c);
+      p.d_m = nullptr;
+      p.d_a = p.d_c = nullptr;
+    }
+  };
+  auto run = [&]() -> int {
+    // upload + enqueue, device after device: the host never waits for a kernel
+    for (int d = 0; d < nd; d++) {
+      auto& p = m->part[d];
+      gpcc_ctx* ctx = m->ctx[d];
+      HIP_TRY(hipSetDevice(ctx->device));
+      // device 0 holds the gathered batch, the others their own part
+      const int64_t b = offsets[p.s0];
+      const int64_t np = offsets[p.s1] - b;
+      const int64_t nbuf = d == 0 ? n_total : np;
+      if (nbuf == 0)
+        continue;
+      HIP_TRY(pool_malloc(ctx, (void**)&p.d_a, sizeof(int32_t) * nbuf * c));
+      HIP_TRY(pool_malloc(ctx, (void**)&p.d_c, sizeof(int32_t) * nbuf * c));
+      if (np == 0)
+        continue;
+      HIP_TRY(pool_malloc(ctx, (void**)&p.d_m, sizeof(int64_t) * np));
+      hipStream_t st = ctx->stream;
+      // (device 0's part is the head of the batch: its buffers start at offset 0)
+      HIP_TRY(hipMemcpyAsync(p.d_m, morton + b, sizeof(int64_t) * np, hipMemcpyHostToDevice, st));
+      if (encoder) {
+        HIP_TRY(hipMemcpyAsync(p.d_a, attrs + b * c, sizeof(int32_t) * np * c, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemsetAsync(p.d_c, 0, sizeof(int32_t) * np * c, st));
+      } else {
+        HIP_TRY(hipMemcpyAsync(p.d_c, coeffs + b * c, sizeof(int32_t) * np * c, hipMemcpyHostToDevice, st));
+      }
+      std::vector<int64_t> offs(p.s1 - p.s0 + 1);
+      for (int s = p.s0; s <= p.s1; s++)
+        offs[s - p.s0] = offsets[s] - b;
+      r = dev_transform(ctx, params, encoder, p.s1 - p.s0, offs.data(), p.d_m, nullptr, p.d_a, p.d_c, c, bits);
+      if (r)
+        return r;
+    }
+    // gather on device 0 (behind each device's transform, on its stream)
+    auto& root = m->part[0];
+    hipStream_t st0 = m->ctx[0]->stream;
+    if (!m->comm.empty())
+      m->rccl.GroupStart();
+    for (int d = 1; d < nd; d++) {
+      auto& p = m->part[d];
+      const int64_t b = offsets[p.s0], np = offsets[p.s1] - b;
+      if (np == 0)
+        continue;
+      hipStream_t st = m->ctx[d]->stream;
+      if (!m->comm.empty()) {
+        m->rccl.Send(p.d_a, (size_t)np * c, kNcclInt32, 0, m->comm[d], st);
+        m->rccl.Recv(root.d_a + b * c, (size_t)np * c, kNcclInt32, d, m->comm[0], st0);
+        if (encoder) {
+          m->rccl.Send(p.d_c, (size_t)np * c, kNcclInt32, 0, m->comm[d], st);
+          m->rccl.Recv(root.d_c + b * c, (size_t)np * c, kNcclInt32, d, m->comm[0], st0);
+        }
+      } else {
+        // one physical device behind several entries: a copy on the producer's stream
+        HIP_TRY(hipSetDevice(m->ctx[d]->device));
+        HIP_TRY(hipMemcpyAsync(root.d_a + b * c, p.d_a, sizeof(int32_t) * np * c, hipMemcpyDeviceToDevice, st));
+        if (encoder)
+          HIP_TRY(hipMemcpyAsync(root.d_c + b * c, p.d_c, sizeof(int32_t) * np * c, hipMemcpyDeviceToDevice, st));
+      }
+    }
+    if (!m->comm.empty()) {
+      const int e = m->rccl.GroupEnd();
+      if (e)
+        return fail(GPCC_ERR_HIP, std::string("RCCL gather: ") + m->rccl.GetErrorString(e));
+    }
+    // every device done and error free, then one download from device 0
+    for (int d = nd - 1; d >= 0; d--) {
+      HIP_TRY(hipSetDevice(m->ctx[d]->device));
+      HIP_TRY(hipStreamSynchronize(m->ctx[d]->stream));
+      r = check_device_error(m->ctx[d]);
+      if (r)
+        return r;
+    }
+    HIP_TRY(hipMemcpyAsync(attrs, root.d_a, sizeof(int32_t) * n_total * c, hipMemcpyDeviceToHost, st0));
+    if (encoder)
+      HIP_TRY(hipMemcpyAsync(coeffs, root.d_c, sizeof(int32_t) * n_total * c, hipMemcpyDeviceToHost, st0));
+    HIP_TRY(hipStreamSynchronize(st0));
+    return GPCC_OK;
+  };
+  r = run();
+  release();
+  return r;
+}
+
+}  // namespace
+
+extern "C" {
+
+int
+gpcc_multi_create(const int32_t* devices, int32_t num_devices, gpcc_multi** out)
+{
+  if (!out || !devices || num_devices < 1 || num_devices > 64)
+    return fail(GPCC_ERR_INVALID_ARG, "bad device list");
+  *out = nullptr;
+  gpcc_multi* m = new gpcc_multi();
+  bool distinct = true;
+  for (int i = 0; i < num_devices; i++) {
+    for (int k = 0; k < i; k++)
+      distinct = distinct && devices[i] != devices[k];
+    gpcc_ctx* ctx = nullptr;
+    int r = gpcc_ctx_create(devices[i], nullptr, &ctx);
+    if (r) {
+      gpcc_multi_destroy(m);
+      return r;
+    }
+    m->devices.push_back(devices[i]);
+    m->ctx.push_back(ctx);
+  }
+  if (num_devices > 1 && distinct) {
+    if (!m->rccl.load()) {
+      gpcc_multi_destroy(m);
+      return fail(GPCC_ERR_NO_DEVICE, "librccl.so could not be loaded for the multi-GPU gather");
+    }
+    m->comm.resize(num_devices);
+    std::vector<int> devs(devices, devices + num_devices);
+    const int e = m->rccl.CommInitAll(m->comm.data(), num_devices, devs.data());
+    if (e) {
+      m->comm.clear();
+      const std::string msg = std::string("ncclCommInitAll: ") + m->rccl.GetErrorString(e);
+      gpcc_multi_destroy(m);
+      return fail(GPCC_ERR_HIP, msg);
+    }
+  }
+  *out = m;
+  return GPCC_OK;
+}
+
+void
+gpcc_multi_destroy(gpcc_multi* m)
+{
+  if (!m)
+    return;
+  for (auto c : m->comm)
+    if (c)
+      m->rccl.CommDestroy(c);
+  for (auto ctx : m->ctx)
+    gpcc_ctx_destroy(ctx);
+  delete m;
+}
+
+int
+gpcc_multi_num_devices(const gpcc_multi* m)
+{
+  return m ? (int)m->devices.size() : 0;
+}
+
+int
+gpcc_multi_uses_rccl(const gpcc_multi* m)
+{
+  return m && !m->comm.empty();
+}
+
+int
+gpcc_multi_raht_forward(
+  gpcc_multi* m, const gpcc_raht_params* params, int32_t num_slices, const int64_t* offsets,
+  const int64_t* morton, int32_t* attrs, int32_t* coeffs, int32_t c)
+{
+  return multi_transform(m, params, true, num_slices, offsets, morton, attrs, coeffs, c);
+}
+
+int
+gpcc_multi_raht_inverse(
+  gpcc_multi* m, const gpcc_raht_params* params, int32_t num_slices, const int64_t* offsets,
+  const int64_t* morton, int32_t* attrs, const int32_t* coeffs, int32_t c)
+{
+  return multi_transform(
+    m, params, false, num_slices, offsets, morton, attrs, const_cast<int32_t*>(coeffs), c);
 }
 
 }  // extern "C"

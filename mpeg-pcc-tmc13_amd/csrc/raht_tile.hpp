@@ -52,9 +52,6 @@ namespace gpcc {
 #ifndef GPCC_TILE_WAVES
 #define GPCC_TILE_WAVES 4
 #endif
-#ifndef GPCC_TILE_FAST2
-#define GPCC_TILE_FAST2 0
-#endif
 #ifndef GPCC_TILE_T
 #define GPCC_TILE_T 256
 #endif
@@ -130,7 +127,7 @@ struct TileSmem {
   uint8_t coct[kTileCC];
   int32_t cpre[SUMC ? (kTileCC + 1) * SUMC : 1];
   TileSlice sl[kTileSlices];
-  int32_t nblocks, nblocks2, s_lo, ns, nsl;
+  int32_t nblocks, s_lo, ns, nsl;
 };
 
 __device__ __forceinline__ TileSlice
@@ -236,324 +233,6 @@ window_lookup(const Smem& sm, int64_t want, int ga, int gb, int wlo, int whi, bo
   return -1;
 }
 
-// ---- two-child blocks: ONE THREAD per block ------------------------------------------
-// In a sparse cloud most blocks with a coefficient have exactly two children
-// (a lidar sweep: 75 %).  With children at positions a < b that first differ
-// in bit d, the three butterfly stages of fwd/invTransformBlock222 reduce to
-// moves and ONE real butterfly at stage d (mkWeightTree, tmc3/RAHT.cpp:742):
-// the low-pass value ends at position 0 -- where the inherited DC replaces it
-// -- and the single coefficient at position 1 << d.  Spending eight lanes and
-// three exchange stages on that block wastes most of the wavefront, so these
-// blocks are taken off the 8-lane list: one lane walks the (at most 18)
-// neighbours the two occupied positions use, and 64 blocks share a wavefront.
-// Only the common configuration takes this path (extension mode, no region QP,
-// DC inherited); everything else stays on the general path.
-template<int C, int MODE, typename Smem>
-__device__ __forceinline__ void
-tile_block2(
-  const LevelCtx& ctx, const int li, const Smem& sm, const int j, const int c0,
-  const int cb, const int wlo, const int whi)
-{
-  constexpr bool kSearch = MODE != kSynthRec;
-  constexpr bool kEnc = MODE == kAnalyze || MODE == kFused;
-  const TreeView& tv = ctx.tv;
-  const ParamsConst prm = (ParamsConst)ctx.params;
-  const SharedLut& lut = sm.lut;
-  const bool haar = prm->integer_haar_enable_flag != 0;
-  const TileSlice sl = tile_slice(sm, j);
-  const LevelSched e = sl.e;
-  const int sp0 = sl.sp0, sp1 = sl.sp1, sc0 = sl.sc0, pt0 = sl.pt0, n_s = sl.n_s;
-  const int pj = j - sp0;
-  const int par_par = e.parity ^ 1, cur_par = e.parity;
-  const int64_t prow = (int64_t)pt0 + pj;
-  const int64_t crow = (int64_t)pt0 + (c0 - sc0);  // child a; child b is the next row
-
-  const int lc0 = c0 - cb;
-  const int oa = sm.coct[lc0], ob = sm.coct[lc0 + 1];  // octants, oa < ob
-  const uint32_t occ = (1u << oa) | (1u << ob);
-  const int fa = sm.cfp[lc0], fm = sm.cfp[lc0 + 1], fz = sm.cfp[lc0 + 2];
-  const int32_t wa = fm - fa, wb = fz - fm;
-  const int cpos = 1 << (31 - clz32((uint32_t)(oa ^ ob)));  // position of the coefficient
-
-  int64_t sa[C], sb[C];
-#pragma unroll
-  for (int k = 0; k < C; k++)
-    sa[k] = sb[k] = 0;
-  if (kEnc) {
-    if (haar) {
-#pragma unroll
-      for (int k = 0; k < C; k++) {
-        sa[k] = fp_from_int(sm.cpre[lc0 * C + k]);
-        sb[k] = fp_from_int(sm.cpre[(lc0 + 1) * C + k]);
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < C; k++) {
-        const uint32_t p0 = (uint32_t)sm.cpre[lc0 * C + k], p1 = (uint32_t)sm.cpre[(lc0 + 1) * C + k],
-                       p2 = (uint32_t)sm.cpre[(lc0 + 2) * C + k];
-        sa[k] = fp_from_int((int32_t)(p1 - p0));
-        sb[k] = fp_from_int((int32_t)(p2 - p1));
-      }
-    }
-  }
-
-  // ---- prediction (tmc3/RAHT.cpp:1391-1432, 299-368, 421-589) -----------------
-  bool enable_pred = false;
-  int neigh_count = 0;
-  int64_t pa_[C], pb_[C];  // prediction of child a / child b
-#pragma unroll
-  for (int k = 0; k < C; k++)
-    pa_[k] = pb_[k] = 0;
-  if (kSearch && prm->raht_prediction_enabled_flag != 0) {
-    if (par2(ctx.nneigh, par_par)[prow] >= prm->raht_prediction_threshold0) {
-      const int64_t cur_pos = sm.key[j - wlo];
-      const uint64_t base = morton3d_add((uint64_t)cur_pos, ~0ull);
-      const int64_t range = prm->raht_prediction_search_range;
-      const int64_t* __restrict__ pkey = tv.key[li + 1];
-      int pn[18];
-      int found = 0;
-#pragma unroll
-      for (int i = 1; i < 19; i++) {
-        pn[i - 1] = -1;
-        if (!(occ & neigh_mask(i)))
-          continue;
-        const int64_t np = (int64_t)morton3d_add(base, neigh_offset(i));
-        int64_t d = np - cur_pos;
-        int ga, gb;
-        if (d >= 0) {
-          d = d >= range ? range : d;
-          ga = j;
-          gb = (d + 1 < (int64_t)(sp1 - j)) ? j + (int)(d + 1) : sp1;
-        } else {
-          d = (-d) >= range ? range : -d;
-          gb = j;
-          ga = (d < (int64_t)(j - sp0)) ? j - (int)d : sp0;
-        }
-        if (ga >= gb)
-          continue;
-        bool outside;
-        int q = window_lookup(sm, np, ga, gb, wlo, whi, &outside);
-        if (outside) {
-          // left the staged window: the global lower_bound (rare)
-          int l2 = ga, h2 = gb;
-          while (l2 < h2) {
-            const int mid = l2 + ((h2 - l2) >> 1);
-            if (pkey[mid] < np)
-              l2 = mid + 1;
-            else
-              h2 = mid;
-          }
-          if (l2 < gb && pkey[l2] == np)
-            q = l2;
-        }
-        pn[i - 1] = q;
-        found += q >= 0;
-      }
-      neigh_count = found + 1;
-      enable_pred = neigh_count >= prm->raht_prediction_threshold1;
-      if (enable_pred) {
-        const int64_t* __restrict__ prec = par2(ctx.rec, par_par);
-        const int64_t rbase = (int64_t)pt0 - sp0;
-        int wsa = 0, wsb = 0;
-        int64_t own[C];
-#pragma unroll
-        for (int k = 0; k < C; k++)
-          own[k] = prec[(rbase + j) * C + k];
-        const int64_t lim_lo = 2 * own[0], lim_hi = 25 * own[0];
-        {
-          const int64_t pw = prm->pred_weight_parent[0];
-          wsa = wsb = (int)pw;
-#pragma unroll
-          for (int k = 0; k < C; k++)
-            pa_[k] = pb_[k] = own[k] * pw;
-        }
-        // the neighbours' values six at a time (one round trip each batch)
-#pragma unroll
-        for (int g = 0; g < 3; g++) {
-          int64_t v[6][C];
-#pragma unroll
-          for (int u = 0; u < 6; u++) {
-            const int q = pn[6 * g + u];
-#pragma unroll
-            for (int k = 0; k < C; k++)
-              v[u][k] = q >= 0 ? prec[(rbase + q) * C + k] : 0;
-          }
-#pragma unroll
-          for (int u = 0; u < 6; u++) {
-            const int i = 1 + 6 * g + u;
-            if (pn[i - 1] < 0)
-              continue;
-            if (10 * v[u][0] <= lim_lo || 10 * v[u][0] >= lim_hi)
-              continue;
-            const int64_t pw = prm->pred_weight_parent[i];
-            if ((neigh_mask(i) >> oa) & 1) {
-              wsa += (int)pw;
-#pragma unroll
-              for (int k = 0; k < C; k++)
-                pa_[k] += v[u][k] * pw;
-            }
-            if ((neigh_mask(i) >> ob) & 1) {
-              wsb += (int)pw;
-#pragma unroll
-              for (int k = 0; k < C; k++)
-                pb_[k] += v[u][k] * pw;
-            }
-          }
-        }
-        const int64_t da = pred_divisor(wsa), db = pred_divisor(wsb);
-#pragma unroll
-        for (int k = 0; k < C; k++) {
-          pa_[k] = fp_mul_c(pa_[k], da);
-          pb_[k] = fp_mul_c(pb_[k], db);
-          if (haar) {
-            pa_[k] = (pa_[k] >> kFpFrac) << kFpFrac;
-            pb_[k] = (pb_[k] >> kFpFrac) << kFpFrac;
-          }
-        }
-      }
-    }
-  }
-
-  // ---- normalise, the one butterfly (high-pass half only: the low-pass value
-  //      is the DC, which is inherited) ---------------------------------------
-  int64_t ca = 0, cbf = 0;
-  if (!haar) {
-    raht_coeffs(wa, wb, lut, &ca, &cbf);
-    if (kEnc) {
-      if (wa > 1) {
-#pragma unroll
-        for (int k = 0; k < C; k++)
-          sa[k] = scale_rsqrt(sa[k], wa, lut);
-      }
-      if (wb > 1) {
-#pragma unroll
-        for (int k = 0; k < C; k++)
-          sb[k] = scale_rsqrt(sb[k], wb, lut);
-      }
-    }
-    if (kSearch && enable_pred) {
-      if (wa > 1) {
-        const int64_t sq = sqrt_weight(wa, lut);
-#pragma unroll
-        for (int k = 0; k < C; k++)
-          pa_[k] = fp_mul_c(pa_[k], sq);
-      }
-      if (wb > 1) {
-        const int64_t sq = sqrt_weight(wb, lut);
-#pragma unroll
-        for (int k = 0; k < C; k++)
-          pb_[k] = fp_mul_c(pb_[k], sq);
-      }
-    }
-  }
-  int64_t hp[C];  // transformed prediction at the coefficient's position
-#pragma unroll
-  for (int k = 0; k < C; k++)
-    hp[k] = 0;
-  const int64_t trow = crow + 1;  // record row of scan rank 1
-  if (kSearch) {
-    if (enable_pred) {
-#pragma unroll
-      for (int k = 0; k < C; k++)
-        hp[k] = haar ? pb_[k] - pa_[k] : fp_mul_c(pb_[k], ca) - fp_mul_c(pa_[k], cbf);
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < C; k++)
-      hp[k] = ctx.ptrans[trow * C + k];
-  }
-  if (MODE == kAnalyze) {
-#pragma unroll
-    for (int k = 0; k < C; k++)
-      ctx.ptrans[trow * C + k] = hp[k];
-  }
-
-  // ---- the coefficient (scanBlock, tmc3/RAHT.cpp:1558-1724) -------------------
-  const int cidx = e.coeff_base + (c0 - sc0) - pj;  // scan rank 1, DC not coded
-  int32_t* __restrict__ cplane = ctx.coeffs + (size_t)pt0 * C + cidx;
-  int ac0 = 0, ac1 = 0;
-  if (e.ac_layer < prm->num_ac_qp_layers) {
-    ac0 = prm->ac_qp_offset[e.ac_layer][cpos - 1][0];
-    ac1 = prm->ac_qp_offset[e.ac_layer][cpos - 1][1];
-  }
-  Quantizer qa[2];
-  qpset_quantizers(prm, e.qp_layer, ac0, ac1, qa);
-  if (kEnc) {
-    int64_t res[C];
-#pragma unroll
-    for (int k = 0; k < C; k++) {
-      const int64_t sh = haar ? sb[k] - sa[k] : fp_mul_c(sb[k], ca) - fp_mul_c(sa[k], cbf);
-      res[k] = sh - hp[k];  // hp is zero without prediction
-    }
-    if (MODE == kAnalyze) {
-      Quantizer qr[2];
-      qpset_quantizers(prm, e.qp_layer, 0, 0, qr);
-      int64_t sum_coeff = 0, dist2 = 0;
-      int rate_coeff = 0;
-#pragma unroll
-      for (int k = 0; k < C; k++) {
-        const int64_t co = fp_round(res[k]);
-        dist2 += co * co;
-        int64_t aq = quantize(qr[k ? 1 : 0], co * 256);
-        aq = aq < 0 ? -aq : aq;
-        sum_coeff += aq;
-        rate_coeff += rate_log_small(aq);
-      }
-      uint32_t d = kDescNever;
-      if (sum_coeff < 3) {
-        const int64_t l0 = qr[0].step;
-        d = rdoq_threshold(dist2, l0 * l0 * (C == 1 ? 25 : 35), rate_coeff, (uint32_t)n_s);
-        if (sum_coeff == 0)
-          d |= kDescZero;
-      }
-      ctx.desc[(size_t)pt0 + cidx] = d;
-    }
-#pragma unroll
-    for (int k = 0; k < C; k++) {
-      const int64_t co = quantize(qa[k ? 1 : 0], fp_round(res[k]) * 256);
-      cplane[(size_t)k * n_s] = (int32_t)co;
-      if (MODE == kFused)
-        hp[k] += fp_from_int(dequantize(qa[k ? 1 : 0], co));
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < C; k++)
-      hp[k] += fp_from_int(dequantize(qa[k ? 1 : 0], (int64_t)cplane[(size_t)k * n_s]));
-  }
-  if (MODE == kAnalyze) {
-    par2(ctx.nneigh, cur_par)[crow] = neigh_count;
-    par2(ctx.nneigh, cur_par)[crow + 1] = neigh_count;
-    return;
-  }
-
-  // ---- DC from the parent, inverse butterfly, reconstruction (:1727-1806) -------
-#pragma unroll
-  for (int k = 0; k < C; k++) {
-    const int64_t lf = par2(ctx.rec_us, par_par)[prow * C + k];
-    const int64_t hf = hp[k];
-    int64_t va, vb;
-    if (haar) {
-      va = lf - ((hf >> (1 + kFpFrac)) << kFpFrac);
-      vb = hf + va;
-    } else {
-      va = fp_mul_c(lf, ca) - fp_mul_c(hf, cbf);
-      vb = fp_mul_c(lf, cbf) + fp_mul_c(hf, ca);
-    }
-    par2(ctx.rec_us, cur_par)[crow * C + k] = va;
-    par2(ctx.rec_us, cur_par)[(crow + 1) * C + k] = vb;
-    if (!haar && wa > 1)
-      va = scale_rsqrt(va, wa, lut);
-    if (!haar && wb > 1)
-      vb = scale_rsqrt(vb, wb, lut);
-    par2(ctx.rec, cur_par)[crow * C + k] = va;
-    par2(ctx.rec, cur_par)[(crow + 1) * C + k] = vb;
-  }
-  if (MODE != kSynthRec) {
-    par2(ctx.nneigh, cur_par)[crow] = neigh_count;
-    par2(ctx.nneigh, cur_par)[crow + 1] = neigh_count;
-  }
-}
-
 // One tile [j0, j1) of the parents of level li + 1 (children in level li).
 // All threads of the workgroup call it together.  `honor_coarse`: skip the
 // (slice, level) pairs the coarse kernel owns.
@@ -576,9 +255,6 @@ tile_process(
   const int gbase = lane & 56;
   const bool haar = prm->integer_haar_enable_flag != 0;
   const bool ext = prm->raht_extension != 0;
-  // blocks of two children take the thread-per-block path (tile_block2) in the
-  // common configuration
-  const bool fast2 = GPCC_TILE_FAST2 && ext && !ctx.asc_qp;
   const int S = tv.num_slices;
   const int32_t* __restrict__ soffP = tv.soff[li + 1];
   const int nt = j1 - j0;
@@ -666,7 +342,6 @@ tile_process(
   if (tid == 0) {
     sm.nsl = ns < kTileSlices ? ns : kTileSlices;
     sm.nblocks = 0;
-    sm.nblocks2 = 0;
   }
   __syncthreads();
   prof.mark(1);  // second round (plans, source sums)
@@ -674,7 +349,6 @@ tile_process(
   // A tile normally lies inside one slice; one over many small slices is
   // worked through kTileSlices slices at a time (their offsets and level
   // plan sit in LDS).
-  bool first_round = true;  // the LDS state above is the first (window, part)'s
   for (int sb = 0; sb < ns; sb += kTileSlices) {
   const int nsl = ns - sb < kTileSlices ? ns - sb : kTileSlices;
   if (sb) {
@@ -684,10 +358,8 @@ tile_process(
     if (tid == 0) {
       sm.nsl = nsl;
       sm.nblocks = 0;
-      sm.nblocks2 = 0;
     }
     __syncthreads();
-    first_round = one_part;  // with the children staged once nothing else changes
   }
   // parents of this window of slices inside the tile
   const int ja = sm.sl[0].sp0 > j0 ? sm.sl[0].sp0 : j0;
@@ -713,7 +385,6 @@ tile_process(
     __syncthreads();  // whatever used the child arrays and the block lists is done
     if (tid == 0) {
       sm.nblocks = 0;
-      sm.nblocks2 = 0;
     }
     for (int i = tid; i <= cn; i += nthr)
       sm.cfp[i] = pfp[cb + i];
@@ -725,13 +396,12 @@ tile_process(
       __syncthreads();
     }
   }
-  (void)first_round;
 
   // ---- classify: one thread per parent ----------------------------------------
   for (int jb = pa; jb < pb; jb += nthr) {
     const int j = jb + tid;
     const int jl = j - j0;
-    bool real = false, two = false;
+    bool real = false;
     if (j < pb) {
       const TileSlice sl = tile_slice(sm, j);
       const LevelSched e = sl.e;
@@ -757,42 +427,22 @@ tile_process(
               par2(ctx.dqp, cp)[crow * 2 + 1] = par2(ctx.dqp, pp)[prow * 2 + 1];
             }
           }
-        } else if (fast2 && nchild == 2 && !e.is_root) {
-          two = true;
         } else {
           real = true;
         }
       }
     }
-    // the 8-lane list grows from the front of blocks[], the two-child list
-    // from its back
-    const unsigned long long m = __ballot(real), m2 = __ballot(two);
-    int at = 0, at2 = 0;
+    const unsigned long long m = __ballot(real);
+    int at = 0;
     if (lane == 0 && m)
       at = atomicAdd(&sm.nblocks, __popcll(m));
-    if (lane == 0 && m2)
-      at2 = atomicAdd(&sm.nblocks2, __popcll(m2));
     at = __shfl(at, 0);
-    at2 = __shfl(at2, 0);
     if (real)
       sm.blocks[at + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)jl;
-    if (two)
-      sm.blocks[kTileT - 1 - (at2 + __popcll(m2 & ((1ull << lane) - 1)))] = (uint16_t)jl;
   }
   __syncthreads();
   prof.mark(2);  // classification + single-child copies
 
-  // ---- two-child blocks: one thread each ------------------------------------------
-  if (GPCC_TILE_FAST2) {
-    const int nb2 = sm.nblocks2;
-    prof.count(6, nb2);
-    for (int bi = tid; bi < nb2; bi += nthr) {
-      const int jl = sm.blocks[kTileT - 1 - bi];
-      tile_block2<C, MODE>(ctx, li, sm, j0 + jl, sm.fc[jl], cb, wlo, whi);
-    }
-  }
-
-  prof.mark(3);  // two-child blocks
   // ---- blocks: 8 lanes each ------------------------------------------------------
   const int nblocks = sm.nblocks;
   prof.count(7, nblocks);
@@ -1302,7 +952,7 @@ tile_process(
         par2(ctx.nneigh, cur_par)[crow] = inherit_dc ? neigh_count : 19;
     }
   }
-  prof.mark(4);  // 8-lane blocks
+  prof.mark(3);  // 8-lane blocks
   pa = pb;
   }  // part of the window's parents
   }  // slice window

@@ -279,3 +279,45 @@ class Context:
                                                           runs.ctypes.data, vals.ctypes.data, C.byref(m),
                                                           C.byref(tr), n, c, bitdepth))
         return runs[:m.value].copy(), vals[:m.value * c].reshape(m.value, c).copy(), tr.value, a
+
+
+class MultiContext:
+    """gpcc_multi: one context per listed device, slices sharded across them, one
+    gather (RCCL over xGMI when the devices are distinct) onto the first."""
+
+    def __init__(self, devices):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        arr = (C.c_int32 * len(devices))(*devices)
+        _lib.check(self._lib.gpcc_multi_create(arr, len(devices), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.gpcc_multi_destroy(self._h)
+            self._h = None
+
+    def uses_rccl(self):
+        return bool(self._lib.gpcc_multi_uses_rccl(self._h))
+
+    def raht_forward(self, params, offsets, morton, attrs):
+        """-> (coeffs planar per slice [c*N], recon [N, c])"""
+        offs = np.ascontiguousarray(offsets, dtype=np.int64)
+        morton = np.ascontiguousarray(morton, dtype=np.int64)
+        rec = np.ascontiguousarray(attrs, dtype=np.int32).copy()
+        n, c = rec.shape
+        co = np.zeros(c * n, dtype=np.int32)
+        _lib.check(self._lib.gpcc_multi_raht_forward(
+            self._h, C.byref(params), len(offs) - 1, offs.ctypes.data_as(C.POINTER(C.c_int64)),
+            morton.ctypes.data, rec.ctypes.data, co.ctypes.data, c))
+        return co, rec
+
+    def raht_inverse(self, params, offsets, morton, coeffs, c):
+        offs = np.ascontiguousarray(offsets, dtype=np.int64)
+        morton = np.ascontiguousarray(morton, dtype=np.int64)
+        co = np.ascontiguousarray(coeffs, dtype=np.int32)
+        rec = np.zeros((len(morton), c), dtype=np.int32)
+        _lib.check(self._lib.gpcc_multi_raht_inverse(
+            self._h, C.byref(params), len(offs) - 1, offs.ctypes.data_as(C.POINTER(C.c_int64)),
+            morton.ctypes.data, rec.ctypes.data, co.ctypes.data, c))
+        return rec
