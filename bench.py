@@ -577,6 +577,12 @@ def cpu_baseline(frame, p, c):
             cores = len(os.sched_getaffinity(0))
         except AttributeError:
             cores = os.cpu_count() or 1
+        logical = cores
+        # one process per core up to 64: the reference is memory-bound when every
+        # logical core runs a frame (measured on this box: 256 processes take 46 s
+        # each against 1.6 s alone, 5.1 Mpoints/s in total) and the bench has to
+        # finish within minutes; GPCC_BENCH_CPU_PROCS overrides
+        cores = min(cores, int(os.environ.get("GPCC_BENCH_CPU_PROCS", "64")))
         try:  # the reference keeps ~0.5 GB per 1M-point frame: stay far inside the host's memory
             import psutil
             cores = max(1, min(cores, int(psutil.virtual_memory().available // (2 << 30))))
@@ -593,6 +599,7 @@ def cpu_baseline(frame, p, c):
                 busy = pool.map(_cpu_worker, range(cores), chunksize=1)
                 wall = time.perf_counter() - t0
         res["all_cores"] = {"value": round(n * cores / wall / 1e6, 3), "unit": "Mpoints/s", "cores": cores,
+                            "logical_cores": logical,
                             "sample": f"{cores} processes x 1 forward+inverse of the same frame, {wall:.1f} s wall "
                                       f"(mean {np.mean(busy):.1f} s per process)"}
     except Exception as e:  # the one-core figure stands on its own
