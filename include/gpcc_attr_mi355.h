@@ -383,6 +383,26 @@ int gpcc_estimate_dist2(
   gpcc_ctx* ctx, const int32_t* xyz, int32_t n, int32_t sampling_period,
   int32_t search_range, float percentile, int32_t* shift_bits);
 
+/* Binarisation of the residual symbols: the part of PCCResidualsEncoder
+ * (AttributeEncoder.cpp:57-307 -- encodeRunLength :227-254, encodeSymbol
+ * :259-272, encode :278-307, with the exp-Golomb binarisations of
+ * entropyutils.h:142-183) that is not the adaptive arithmetic coder.  For the
+ * symbol stream of gpcc_zero_run_pack / gpcc_raht_encode_attr_packed (runs,
+ * values, trailing run) it returns the binary decisions in coding order, one
+ * byte each: (context << 1) | bin with context = 0..4 ctxRunLen[5], 5..18
+ * ctxCoeffGtN[2][7], 19..24 ctxCoeffRemPrefix[2][3], 25..30
+ * ctxCoeffRemSuffix[2][3] (AttributeCommon.h:54-57), 31 = bypass.  Which
+ * context a decision uses depends on the symbol alone, so all symbols are
+ * binarised in parallel; the caller's loop is
+ *   for (b : bins) ctx(b) == 31 ? enc.encode(bin(b)) : enc.encode(bin(b), model[ctx(b)]);
+ * on the reference's own coder: the bitstream is identical (tests/test_bins.py).
+ *   c = 3 (colour) or 1;  bins [cap] out;  *num_bins out (also when cap is too
+ *   small: the call then fails with GPCC_ERR_INVALID_ARG).  Host tier. */
+int gpcc_binarise_symbols(
+  gpcc_ctx* ctx, const int32_t* runs, const int32_t* values,
+  int32_t num_symbols, int32_t trailing_run, int32_t c, uint8_t* bins,
+  int64_t cap, int64_t* num_bins);
+
 /* ------------------------------------------------------------------ */
 /* device tier of the LoD build and the lifting coder                   */
 /* The same operations on buffers resident in HBM, num_slices slices back to

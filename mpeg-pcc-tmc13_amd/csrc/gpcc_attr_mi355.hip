@@ -39,6 +39,7 @@
 #include "lift_kernels.hpp"
 #include "lod_kernels.hpp"
 #include "morton_sort.hpp"
+#include "residual_bins.hpp"
 
 using namespace gpcc;
 
@@ -2924,3 +2925,82 @@ gpcc_multi_raht_inverse(
 }
 
 }  // extern "C"
+
+// ---- binarisation of the residual symbols (residual_bins.hpp) -------------------------
+namespace {
+
+int
+binarise_symbols(
+  gpcc_ctx* ctx, const int32_t* runs, const int32_t* values, int32_t num_symbols,
+  int32_t trailing_run, int32_t c, uint8_t* bins, int64_t cap, int64_t* num_bins)
+{
+  if (!ctx)
+    return fail(GPCC_ERR_INVALID_ARG, "ctx is null");
+  if (num_symbols < 0 || (c != 1 && c != 3) || trailing_run < 0 || !num_bins
+      || (num_symbols > 0 && (!runs || !values)))
+    return fail(GPCC_ERR_INVALID_ARG, "bad symbol stream (c must be 1 or 3)");
+  if (num_symbols > kMaxPoints)
+    return fail(GPCC_ERR_INVALID_ARG, "more than 2^29 symbols");
+  *num_bins = 0;
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const size_t m = (size_t)num_symbols;
+  const int nblk = (num_symbols + 1 + kBinBlock - 1) / kBinBlock;
+  int32_t *d_runs = nullptr, *d_vals = nullptr, *d_cnt = nullptr, *d_blk = nullptr;
+  uint8_t* d_bins = nullptr;
+  auto cleanup = [&]() {
+    pool_free(ctx, d_runs);
+    pool_free(ctx, d_vals);
+    pool_free(ctx, d_cnt);
+    pool_free(ctx, d_blk);
+    pool_free(ctx, d_bins);
+  };
+  auto run = [&]() -> int {
+    HIP_TRY(pool_malloc(ctx, (void**)&d_runs, sizeof(int32_t) * (m + 1)));
+    HIP_TRY(pool_malloc(ctx, (void**)&d_vals, sizeof(int32_t) * (m + 1) * c));
+    HIP_TRY(pool_malloc(ctx, (void**)&d_cnt, sizeof(int32_t) * (m + 1)));
+    HIP_TRY(pool_malloc(ctx, (void**)&d_blk, sizeof(int32_t) * ((size_t)nblk + 1)));
+    if (m) {
+      HIP_TRY(hipMemcpyAsync(d_runs, runs, sizeof(int32_t) * m, hipMemcpyHostToDevice, st));
+      HIP_TRY(hipMemcpyAsync(d_vals, values, sizeof(int32_t) * m * c, hipMemcpyHostToDevice, st));
+    }
+    {
+      Timer t(ctx, "bins_count");
+      bins_count_kernel<<<nblk, kBinBlock, 0, st>>>(num_symbols, d_runs, d_vals, trailing_run, c, d_cnt, d_blk);
+      bins_scan_kernel<<<1, 1024, 0, st>>>(nblk, d_blk, d_blk + nblk);
+    }
+    int32_t total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, d_blk + nblk, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *num_bins = total;
+    if (total > cap)
+      return fail(GPCC_ERR_INVALID_ARG, "bins buffer too small (see *num_bins)");
+    if (total == 0)
+      return GPCC_OK;
+    if (!bins)
+      return fail(GPCC_ERR_INVALID_ARG, "bins is null");
+    HIP_TRY(pool_malloc(ctx, (void**)&d_bins, (size_t)total));
+    {
+      Timer t(ctx, "bins_emit");
+      bins_emit_kernel<<<nblk, kBinBlock, 0, st>>>(num_symbols, d_runs, d_vals, trailing_run, c, d_cnt, d_blk, d_bins);
+    }
+    HIP_TRY(hipMemcpyAsync(bins, d_bins, (size_t)total, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return GPCC_OK;
+  };
+  int r = run();
+  cleanup();
+  return r;
+}
+
+}  // namespace
+
+extern "C" int
+gpcc_binarise_symbols(
+  gpcc_ctx* ctx, const int32_t* runs, const int32_t* values, int32_t num_symbols,
+  int32_t trailing_run, int32_t c, uint8_t* bins, int64_t cap, int64_t* num_bins)
+{
+  return counted(
+    ctx, binarise_symbols(ctx, runs, values, num_symbols, trailing_run, c, bins, cap, num_bins),
+    num_symbols);
+}

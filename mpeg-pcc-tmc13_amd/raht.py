@@ -280,6 +280,25 @@ class Context:
                                                           C.byref(tr), n, c, bitdepth))
         return runs[:m.value].copy(), vals[:m.value * c].reshape(m.value, c).copy(), tr.value, a
 
+    def binarise_symbols(self, runs, values, trailing_run, c):
+        """gpcc_binarise_symbols -> uint8 array of (context << 1 | bin) decisions"""
+        runs = np.ascontiguousarray(runs, dtype=np.int32)
+        vals = np.ascontiguousarray(values, dtype=np.int32).reshape(-1)
+        m = len(runs)
+        nb = C.c_int64()
+        cap = 64 + 40 * (m + 1) * c
+        out = np.zeros(cap, dtype=np.uint8)
+        rc = self._lib.gpcc_binarise_symbols(self._h, runs.ctypes.data if m else None, vals.ctypes.data if m else None,
+                                             m, int(trailing_run), c, out.ctypes.data, cap, C.byref(nb))
+        if rc and nb.value > cap:  # very large magnitudes: once more with the exact size
+            cap = nb.value
+            out = np.zeros(cap, dtype=np.uint8)
+            rc = self._lib.gpcc_binarise_symbols(self._h, runs.ctypes.data if m else None,
+                                                 vals.ctypes.data if m else None, m, int(trailing_run), c,
+                                                 out.ctypes.data, cap, C.byref(nb))
+        _lib.check(rc)
+        return out[:nb.value].copy()
+
 
 class MultiContext:
     """gpcc_multi: one context per listed device, slices sharded across them, one

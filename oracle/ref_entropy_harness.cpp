@@ -53,4 +53,56 @@ ref_entropy_encode_symbols(
   return len;
 }
 
+
+// The reference's arithmetic coder and context models driven by a stream of
+// binary decisions, one byte each: (context << 1) | bin, contexts in the
+// declaration order of AttributeContexts (AttributeCommon.h:54-57), 31 = bypass
+// -- what gpcc_binarise_symbols / oracle_binarise_symbols produce.
+namespace {
+struct BinsEncoder : pcc::PCCResidualsEncoder {
+  using pcc::PCCResidualsEncoder::PCCResidualsEncoder;
+  pcc::AdaptiveBitModel& model(int id)
+  {
+    if (id < 5)
+      return ctxRunLen[id];
+    if (id < 19)
+      return ctxCoeffGtN[(id - 5) / 7][(id - 5) % 7];
+    if (id < 25)
+      return ctxCoeffRemPrefix[(id - 19) / 3][(id - 19) % 3];
+    return ctxCoeffRemSuffix[(id - 25) / 3][(id - 25) % 3];
+  }
+};
+}  // namespace
+
+int
+ref_entropy_encode_bins(
+  const uint8_t* bins, int64_t num_bins, int32_t num_points, uint8_t* out, int32_t cap)
+{
+  using namespace pcc;
+  SequenceParameterSet sps;
+  sps.cabac_bypass_stream_enabled_flag = false;
+  sps.entropy_continuation_enabled_flag = false;
+  sps.bypass_bin_coding_without_prob_update = false;
+  AttributeParameterSet aps;
+  aps.max_num_direct_predictors = 0;
+  aps.direct_avg_predictor_disabled_flag = false;
+  AttributeBrickHeader abh;
+  AttributeContexts ctx;
+  ctx.reset();
+  BinsEncoder encoder(aps, abh, ctx);
+  encoder.start(sps, num_points);
+  for (int64_t i = 0; i < num_bins; i++) {
+    const int id = bins[i] >> 1, bin = bins[i] & 1;
+    if (id == 31)
+      encoder.arithmeticEncoder.encode(bin);
+    else
+      encoder.arithmeticEncoder.encode(bin, encoder.model(id));
+  }
+  const int len = encoder.stop();
+  if (len > cap)
+    return -1;
+  memcpy(out, encoder.arithmeticEncoder.buffer(), size_t(len));
+  return len;
+}
+
 }  // extern "C"

@@ -141,3 +141,30 @@ def ref_entropy_encode_symbols(c, num_points, runs, values, trailing):
                                         out, out.size)
     assert ln >= 0
     return out[:ln].tobytes()
+
+
+def oracle_binarise_symbols(runs, values, trailing, c):
+    """oracle/symbols_oracle.c: the decisions of PCCResidualsEncoder for a symbol stream -> uint8 [(ctx << 1) | bin]"""
+    lib = ol.oracle().lib
+    runs = np.ascontiguousarray(runs, dtype=np.int32)
+    vals = np.ascontiguousarray(values, dtype=np.int32).reshape(-1)
+    lib.oracle_binarise_symbols.restype = C.c_int64
+    lib.oracle_binarise_symbols.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64]
+    n = lib.oracle_binarise_symbols(runs.ctypes.data, vals.ctypes.data, len(runs), int(trailing), c, None, 0)
+    out = np.zeros(max(n, 1), np.uint8)
+    lib.oracle_binarise_symbols(runs.ctypes.data, vals.ctypes.data, len(runs), int(trailing), c, out.ctypes.data, n)
+    return out[:n]
+
+
+def ref_entropy_encode_bins(bins, num_points):
+    """the reference's arithmetic coder + context models on a decision stream -> arithmetic-coded bytes"""
+    import os
+    if "lib" not in _entropy:
+        _entropy["lib"] = C.CDLL(os.path.join(ol.ORACLE_DIR, "_ref", "libtmc3_entropy.so"))
+    lib = _entropy["lib"]
+    bins = np.ascontiguousarray(bins, dtype=np.uint8)
+    out = np.zeros(num_points * 3 * 2 + 2048, np.uint8)
+    lib.ref_entropy_encode_bins.argtypes = [C.c_void_p, C.c_int64, C.c_int32, u8p, C.c_int32]
+    ln = lib.ref_entropy_encode_bins(bins.ctypes.data, len(bins), num_points, out, out.size)
+    assert ln >= 0
+    return out[:ln].tobytes()
