@@ -71,7 +71,10 @@ constexpr int kTabSlots = (kTileT + 2 * kTileW) * 5 / 2 <= 2048 ? 2048
 constexpr uint32_t kTabEmpty = 0xffffu;
 static_assert(kTileT + 2 * kTileW < 0xffff, "window indices are 16 bit");
 constexpr int kTileSlices = 8;     // slices a tile may span with their info in LDS
-constexpr int kCoarseParents = 4096;  // a level is coarse while a slice has at most this many parents
+#ifndef GPCC_COARSE_PARENTS
+#define GPCC_COARSE_PARENTS 1024
+#endif
+constexpr int kCoarseParents = GPCC_COARSE_PARENTS;  // a level is coarse while a slice has at most this many parents
 constexpr int kSynthRec = 4;       // LevelMode: synthesis from the analyze pass's record
 
 // Where a tile's time goes (experiment builds only, -DGPCC_TILE_PROF: s_memtime
