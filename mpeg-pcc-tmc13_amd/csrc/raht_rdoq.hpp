@@ -174,55 +174,7 @@ rdoq_resolve_kernel(RdoqCtx cx)
   } else {
     status = kTileOpen;
   }
-  if (lane == 0 && status != kTileOpen)
-    __hip_atomic_store(
-      &cx.state[gt], ep | ((unsigned long long)(status == kTileClosed ? 2 : 1) << 32) | (uint32_t)l_out,
-      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-
-  // 2. incoming L: nearest predecessor that is not transparent
-  int l_in = 0;
-  bool have = false;
-  int k0 = gt - 1;  // lane u looks at tile k0 - u
-  unsigned spins = 0;
-  while (!have) {
-    const int k = k0 - lane;
-    unsigned long long w = 0;
-    if (k >= gt_first)
-      w = __hip_atomic_load(&cx.state[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const bool in = k >= gt_first;
-    const bool ready = !in || (w >> 48) == (unsigned long long)(cx.li + 1);
-    const int kind = in ? (int)((w >> 32) & 0xffff) : 0;
-    // lanes from the first not-ready one on are ignored this round
-    const unsigned long long notready = __ballot(!ready);
-    const unsigned long long decides = __ballot(in && ready && kind >= 2);
-    const unsigned long long outside = __ballot(!in);
-    const unsigned long long stop = notready | decides | outside;
-    if (!stop) {
-      k0 -= kWave;  // 64 transparent tiles: further back
-      continue;
-    }
-    const int first = __ffsll((long long)stop) - 1;
-    if ((decides >> first) & 1) {
-      l_in = (int)(uint32_t)__shfl((int)(uint32_t)w, first);
-      have = true;
-    } else if ((outside >> first) & 1) {
-      l_in = cx.slice_l[s];  // as the previous level (or the coarse kernel) left it
-      have = true;
-    } else {
-      // an undecided predecessor: everything nearer is transparent
-      k0 -= first;
-      if (++spins > (1u << 22)) {
-        if (lane == 0)
-          atomicExch(cx.tv.error, 1);
-        return;
-      }
-      __builtin_amdgcn_s_sleep(2);
-    }
-  }
-
-  // 3. an open tile now knows its outgoing L ...
-  if (status == kTileOpen) {
-    int l = l_in;
+  auto replay = [&](int l) -> int {
 #pragma unroll
     for (int r = 0; r < kRdoqTile / kWave; r++) {
       const int i0 = a + r * kWave;
@@ -231,15 +183,86 @@ rdoq_resolve_kernel(RdoqCtx cx)
       int tz;
       l = rdoq_chunk(dreg[r], i0 + lane, i0 + lane < b, l, i0, &tz);
     }
-    l_out = l;
+    return l;
+  };
+
+  // 2. incoming L.  The slice's FIRST tile of the level is the only one that
+  // reads what the previous level left (slice_l) -- it knows its incoming L at
+  // once and always publishes a deciding word, so every walk ends there at the
+  // latest; the LAST tile overwrites slice_l for the next level, and only after
+  // it has seen the first tile's word (i.e. after that read).
+  int l_in = 0;
+  if (gt == gt_first) {
+    l_in = cx.slice_l[s];
+    l_out = status == kTileTransparent ? l_in : (status == kTileClosed ? l_out : replay(l_in));
     if (lane == 0)
       __hip_atomic_store(
         &cx.state[gt], ep | (3ull << 32) | (uint32_t)l_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  } else if (status == kTileTransparent) {
-    l_out = l_in;
+  } else {
+    if (lane == 0 && status != kTileOpen)
+      __hip_atomic_store(
+        &cx.state[gt], ep | ((unsigned long long)(status == kTileClosed ? 2 : 1) << 32) | (uint32_t)l_out,
+        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool have = false;
+    int k0 = gt - 1;  // lane u looks at tile k0 - u
+    unsigned spins = 0;
+    while (!have) {
+      const int k = k0 - lane;
+      const bool in = k >= gt_first;
+      unsigned long long w = 0;
+      if (in)
+        w = __hip_atomic_load(&cx.state[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const bool ready = in && (w >> 48) == (unsigned long long)(cx.li + 1);
+      const int kind = ready ? (int)((w >> 32) & 0xffff) : 0;
+      // the nearest lane that stops the walk: a deciding word, or a tile that
+      // has not published yet (everything nearer is transparent)
+      const unsigned long long decides = __ballot(ready && kind >= 2);
+      const unsigned long long notready = __ballot(in && !ready);
+      const unsigned long long stop = decides | notready;
+      if (!stop) {
+        k0 -= kWave;  // 64 transparent tiles: further back (the first tile always decides)
+        continue;
+      }
+      const int first = __ffsll((long long)stop) - 1;
+      if ((decides >> first) & 1) {
+        l_in = (int)(uint32_t)__shfl((int)(uint32_t)w, first);
+        have = true;
+      } else {
+        k0 -= first;
+        if (++spins > (1u << 22)) {
+          if (lane == 0)
+            atomicExch(cx.tv.error, 1);
+          return;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+    // 3. an open tile now knows its outgoing L
+    if (status == kTileOpen) {
+      l_out = replay(l_in);
+      if (lane == 0)
+        __hip_atomic_store(
+          &cx.state[gt], ep | (3ull << 32) | (uint32_t)l_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (status == kTileTransparent) {
+      l_out = l_in;
+    }
   }
-  if (gt == gt_last && lane == 0)
-    cx.slice_l[s] = l_out;  // carried to the next level's launch
+  if (gt == gt_last) {
+    if (gt != gt_first) {
+      unsigned spins = 0;
+      while ((__hip_atomic_load(&cx.state[gt_first], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 48)
+             != (unsigned long long)(cx.li + 1)) {
+        if (++spins > (1u << 22)) {
+          if (lane == 0)
+            atomicExch(cx.tv.error, 1);
+          return;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+    if (lane == 0)
+      cx.slice_l[s] = l_out;  // carried to the next level's launch
+  }
 
   // 4. ... and every tile applies its decisions
   {

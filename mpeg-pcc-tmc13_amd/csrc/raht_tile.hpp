@@ -291,26 +291,70 @@ tile_process(
     sm.s_lo = find_slice(soffP, S, j0);
     sm.ns = find_slice(soffP, S, j1 - 1);
   }
-  for (int i = tid; i <= nt; i += nthr)
-    sm.fc[i] = pfc[j0 + i];
+  // Every load of the round is issued before the first result is used: a loop
+  // "load, store to LDS, next" makes each of its iterations a round trip of its
+  // own (five for the key window), and the staging rounds are what most tiles
+  // of a sparse level consist of.  (Trip counts for 256 threads; the coarse
+  // kernel's 1 024 threads cover the ranges in fewer.)
+  constexpr int kRfc = (kTileT + 1 + 255) / 256;
+  constexpr int kRkey = (kTileT + 2 * kTileW + 255) / 256;
+  constexpr int kRcc = (kTileCC + 1 + 255) / 256;
   int wlo = 0, whi = 0;
-  if (kSearch) {
-    const int np_all = soffP[S];
-    wlo = j0 - kTileW > 0 ? j0 - kTileW : 0;
-    whi = j1 + kTileW < np_all ? j1 + kTileW : np_all;
-    const int64_t* __restrict__ pk = tv.key[li + 1];
-    for (int i = tid; i < whi - wlo; i += nthr)
-      sm.key[i] = pk[wlo + i];
-    tile_tab_clear(sm);
-  }
   const int32_t* __restrict__ pfp = tv.fp[li];
   const int64_t* __restrict__ pck = tv.key[li];
-  if (one_part) {
-    const int cn = c_hi - c_lo;
-    for (int i = tid; i <= cn; i += nthr)
-      sm.cfp[i] = pfp[c_lo + i];
-    for (int i = tid; i < cn; i += nthr)
-      sm.coct[i] = (uint8_t)(pck[c_lo + i] & 7);
+  {
+    int32_t r_fc[kRfc];
+#pragma unroll
+    for (int r = 0; r < kRfc; r++) {
+      const int i = tid + r * nthr;
+      r_fc[r] = pfc[j0 + (i <= nt ? i : nt)];  // (clamped, not predicated: a select of addresses would be a flat load)
+    }
+    int64_t r_key[kSearch ? kRkey : 1];
+    if (kSearch) {
+      const int np_all = soffP[S];
+      wlo = j0 - kTileW > 0 ? j0 - kTileW : 0;
+      whi = j1 + kTileW < np_all ? j1 + kTileW : np_all;
+      const int64_t* __restrict__ pk = tv.key[li + 1];
+#pragma unroll
+      for (int r = 0; r < kRkey; r++) {
+        const int i = tid + r * nthr;
+        r_key[r] = pk[wlo + (i < whi - wlo ? i : whi - wlo - 1)];
+      }
+    }
+    int32_t r_cfp[kRcc];
+    int64_t r_ck[kRcc];
+    const int cn = one_part ? c_hi - c_lo : -1;
+    const int cnl = cn > 0 ? cn : 0, ckl = cn > 1 ? cn - 1 : 0;
+#pragma unroll
+    for (int r = 0; r < kRcc; r++) {
+      const int i = tid + r * nthr;
+      r_cfp[r] = pfp[c_lo + (i <= cnl ? i : cnl)];
+      r_ck[r] = pck[c_lo + (i <= ckl ? i : ckl)];
+    }
+    if (kSearch)
+      tile_tab_clear(sm);
+#pragma unroll
+    for (int r = 0; r < kRfc; r++) {
+      const int i = tid + r * nthr;
+      if (i <= nt)
+        sm.fc[i] = r_fc[r];
+    }
+    if (kSearch) {
+#pragma unroll
+      for (int r = 0; r < kRkey; r++) {
+        const int i = tid + r * nthr;
+        if (i < whi - wlo)
+          sm.key[i] = r_key[r];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < kRcc; r++) {
+      const int i = tid + r * nthr;
+      if (i <= cn)
+        sm.cfp[i] = r_cfp[r];
+      if (i < cn)
+        sm.coct[i] = (uint8_t)(r_ck[r] & 7);
+    }
   }
   __syncthreads();
   prof.mark(0);  // first round of staging
@@ -321,14 +365,37 @@ tile_process(
       return;
     if (haar) {
       const int32_t* __restrict__ lf = ctx.haar_lf[li];
-      for (int i = tid; i < cn * C; i += nthr)
-        sm.cpre[i] = lf[(size_t)cb * C + i];
+      constexpr int kR = (kTileCC * C + 255) / 256;
+      int32_t v[kR];
+#pragma unroll
+      for (int r = 0; r < kR; r++) {
+        const int i = tid + r * nthr;
+        v[r] = lf[(size_t)cb * C + (i < cn * C ? i : 0)];
+      }
+#pragma unroll
+      for (int r = 0; r < kR; r++) {
+        const int i = tid + r * nthr;
+        if (i < cn * C)
+          sm.cpre[i] = v[r];
+      }
     } else {
-      for (int i = tid; i <= cn; i += nthr) {
-        const size_t f = (size_t)sm.cfp[i];
+      int32_t v[kRcc][C];
+#pragma unroll
+      for (int r = 0; r < kRcc; r++) {
+        const int i = tid + r * nthr;
+        const size_t f = (size_t)sm.cfp[i <= cn ? i : 0];
 #pragma unroll
         for (int k = 0; k < C; k++)
-          sm.cpre[i * C + k] = ctx.attr_prefix[f * C + k];
+          v[r][k] = ctx.attr_prefix[f * C + k];
+      }
+#pragma unroll
+      for (int r = 0; r < kRcc; r++) {
+        const int i = tid + r * nthr;
+        if (i <= cn) {
+#pragma unroll
+          for (int k = 0; k < C; k++)
+            sm.cpre[i * C + k] = v[r][k];
+        }
       }
     }
   };
@@ -389,10 +456,24 @@ tile_process(
     if (tid == 0) {
       sm.nblocks = 0;
     }
-    for (int i = tid; i <= cn; i += nthr)
-      sm.cfp[i] = pfp[cb + i];
-    for (int i = tid; i < cn; i += nthr)
-      sm.coct[i] = (uint8_t)(pck[cb + i] & 7);
+    {
+      int32_t r_cfp[kRcc];
+      int64_t r_ck[kRcc];
+#pragma unroll
+      for (int r = 0; r < kRcc; r++) {
+        const int i = tid + r * nthr;
+        r_cfp[r] = pfp[cb + (i <= cn ? i : cn)];
+        r_ck[r] = pck[cb + (i < cn ? i : cn - 1)];
+      }
+#pragma unroll
+      for (int r = 0; r < kRcc; r++) {
+        const int i = tid + r * nthr;
+        if (i <= cn)
+          sm.cfp[i] = r_cfp[r];
+        if (i < cn)
+          sm.coct[i] = (uint8_t)(r_ck[r] & 7);
+      }
+    }
     __syncthreads();
     if (kEnc) {
       stage_sums(cb, cn);
