@@ -554,18 +554,29 @@ launch_transform(
     lc.mtag = (uint32_t)(li + 1);
     const int64_t parents = ts.nodes[li + 1];
     if (tiles) {
-      const int ntiles = (int)((parents + kTileT - 1) / kTileT);
+      // a level where almost every parent has a single child takes the large
+      // tiles (raht_tile.hpp): the node counts tell
+      const bool sparse = ts.nodes[li] * 8 <= parents * 9 && parents >= 64 * kTileTSparse;
+      const int tile_t = sparse ? kTileTSparse : kTileT;
+      const int ntiles = (int)((parents + tile_t - 1) / tile_t);
       const int tgrid = std::min((ntiles + 7) / 8 * 8, kLevelGridMax);
+#define GPCC_TILE_LAUNCH(MODE)                                                  \
+  do {                                                                          \
+    if (sparse)                                                                 \
+      raht_tile_kernel<C, MODE, kTileTSparse><<<tgrid, kTileThreads, 0, st>>>(lc); \
+    else                                                                        \
+      raht_tile_kernel<C, MODE, kTileT><<<tgrid, kTileThreads, 0, st>>>(lc);    \
+  } while (0)
       if (!encoder) {
         Timer t(ctx, level_name("tile_synth", li));
-        raht_tile_kernel<C, kSynth><<<tgrid, kTileThreads, 0, st>>>(lc);
+        GPCC_TILE_LAUNCH(kSynth);
       } else if (pl.haar) {
         Timer t(ctx, level_name("tile_fused", li));
-        raht_tile_kernel<C, kFused><<<tgrid, kTileThreads, 0, st>>>(lc);
+        GPCC_TILE_LAUNCH(kFused);
       } else {
         {
           Timer t(ctx, level_name("tile_analyze", li));
-          raht_tile_kernel<C, kAnalyze><<<tgrid, kTileThreads, 0, st>>>(lc);
+          GPCC_TILE_LAUNCH(kAnalyze);
         }
         rc.li = li;
         {
@@ -575,9 +586,10 @@ launch_transform(
         }
         {
           Timer t(ctx, level_name("tile_synth_rec", li));
-          raht_tile_kernel<C, kSynthRec><<<tgrid, kTileThreads, 0, st>>>(lc);
+          GPCC_TILE_LAUNCH(kSynthRec);
         }
       }
+#undef GPCC_TILE_LAUNCH
       continue;
     }
     {

@@ -64,12 +64,16 @@ namespace gpcc {
 constexpr int kTileT = GPCC_TILE_T;  // parents per tile
 constexpr int kTileW = GPCC_TILE_W;  // staged key window on either side
 constexpr int kTileThreads = GPCC_TILE_THREADS;
-constexpr int kTileCC = 4 * kTileT;  // children staged at a time (a tile with more is worked in parts)
-// hash table over the staged key window: 16-bit window indices, load <= 0.4
-constexpr int kTabSlots = (kTileT + 2 * kTileW) * 5 / 2 <= 2048 ? 2048
-  : ((kTileT + 2 * kTileW) * 5 / 2 <= 4096 ? 4096 : 8192);
+// Two tile sizes: kTileT parents for the levels where blocks are many, and
+// kTileTSparse for the levels where almost every parent has one child (the
+// host picks per level from the node counts): there a tile's time is its
+// fixed phases -- staging rounds, classification, ONE block pass for a
+// handful of blocks -- and four times the parents cost about the same.
+#ifndef GPCC_TILE_T_SPARSE
+#define GPCC_TILE_T_SPARSE 1024
+#endif
+constexpr int kTileTSparse = GPCC_TILE_T_SPARSE;
 constexpr uint32_t kTabEmpty = 0xffffu;
-static_assert(kTileT + 2 * kTileW < 0xffff, "window indices are 16 bit");
 constexpr int kTileSlices = 8;     // slices a tile may span with their info in LDS
 #ifndef GPCC_COARSE_PARENTS
 #define GPCC_COARSE_PARENTS 1024
@@ -116,19 +120,28 @@ struct TileSlice {
 
 // kSearch: the parent key window (every mode but kSynthRec); SUMC: components
 // of the children's source sums (encoder passes), 0 = none
-template<bool kSearch, int SUMC>
+template<bool kSearch, int SUMC, int T = kTileT>
 struct TileSmem {
+  static constexpr int kT = T;  // parents per tile
+  // children staged at a time (a tile with more is worked in parts): a sparse
+  // level has hardly more children than parents
+  static constexpr int kCC = T >= 1024 ? T + T / 4 : 4 * T;
+  // hash table over the staged key window: 16-bit window indices, load <= 0.5
+  static constexpr int kWin = T + 2 * kTileW;
+  static constexpr int kSlots = kWin * 2 <= 2048 ? 2048 : (kWin * 2 <= 4096 ? 4096 : 8192);
+  static constexpr int kHashShift = 32 - (kSlots == 2048 ? 11 : (kSlots == 4096 ? 12 : 13));
+  static_assert(kWin < 0xffff && kWin * 2 <= 8192, "window indices are 16 bit, table load <= 0.5");
   SharedLut lut;
-  int64_t key[kSearch ? kTileT + 2 * kTileW : 1];
-  uint32_t tab[kSearch ? kTabSlots / 2 : 1];  // two 16-bit entries per word
-  int32_t fc[kTileT + 1];
-  uint16_t blocks[kTileT];
+  int64_t key[kSearch ? kWin : 1];
+  uint32_t tab[kSearch ? kSlots / 2 : 1];  // two 16-bit entries per word
+  int32_t fc[T + 1];
+  uint16_t blocks[T];
   // the children of the parents being worked on: first points (weights are
   // differences), octants, and what the encoder's source sums come from --
   // the attribute prefix sum at every first point, or the Haar low-pass value
-  int32_t cfp[kTileCC + 1];
-  uint8_t coct[kTileCC];
-  int32_t cpre[SUMC ? (kTileCC + 1) * SUMC : 1];
+  int32_t cfp[kCC + 1];
+  uint8_t coct[kCC];
+  int32_t cpre[SUMC ? (kCC + 1) * SUMC : 1];
   TileSlice sl[kTileSlices];
   int32_t nblocks, s_lo, ns, nsl;
 };
@@ -165,11 +178,12 @@ tile_slice(const Smem& sm, int j)
 // The window's keys sit in LDS behind a hash table (open addressing, 16-bit
 // window indices): one or two probes instead of eleven dependent bisection
 // steps -- the bisection was a quarter of the block pass's instructions.
+template<typename Smem>
 __device__ __forceinline__ uint32_t
 tile_hash(int64_t key)
 {
   const uint32_t x = (uint32_t)key ^ (uint32_t)((uint64_t)key >> 29);
-  return (x * 0x9E3779B1u) >> (32 - (kTabSlots == 2048 ? 11 : (kTabSlots == 4096 ? 12 : 13)));
+  return (x * 0x9E3779B1u) >> Smem::kHashShift;
 }
 
 template<typename Smem>
@@ -184,7 +198,7 @@ template<typename Smem>
 __device__ __forceinline__ void
 tile_tab_clear(Smem& sm)
 {
-  for (int i = threadIdx.x; i < kTabSlots / 2; i += blockDim.x)
+  for (int i = threadIdx.x; i < Smem::kSlots / 2; i += blockDim.x)
     sm.tab[i] = 0xffffffffu;
 }
 // ... and insert the window's keys (after it)
@@ -193,7 +207,7 @@ __device__ __forceinline__ void
 tile_tab_build(Smem& sm, int nwin)
 {
   for (int i = threadIdx.x; i < nwin; i += blockDim.x) {
-    uint32_t h = tile_hash(sm.key[i]);
+    uint32_t h = tile_hash<Smem>(sm.key[i]);
     for (;;) {
       const uint32_t sh = (h & 1) * 16;
       const uint32_t old = sm.tab[h >> 1];
@@ -202,7 +216,7 @@ tile_tab_build(Smem& sm, int nwin)
         if (atomicCAS(&sm.tab[h >> 1], old, nw) == old)
           break;
       } else {
-        h = (h + 1) & (kTabSlots - 1);
+        h = (h + 1) & (Smem::kSlots - 1);
       }
     }
   }
@@ -216,7 +230,7 @@ __device__ __forceinline__ int
 window_lookup(const Smem& sm, int64_t want, int ga, int gb, int wlo, int whi, bool* outside)
 {
   *outside = false;
-  uint32_t h = tile_hash(want);
+  uint32_t h = tile_hash<Smem>(want);
   for (;;) {
     const uint32_t i = tile_tab_get(sm, h);
     if (i == kTabEmpty)
@@ -227,7 +241,7 @@ window_lookup(const Smem& sm, int64_t want, int ga, int gb, int wlo, int whi, bo
       if (q >= ga && q < gb)
         return q;
     }
-    h = (h + 1) & (kTabSlots - 1);
+    h = (h + 1) & (Smem::kSlots - 1);
   }
   // ga < wlo implies wlo is inside the searching block's slice, likewise whi
   const bool below = ga < wlo && want < sm.key[0];
@@ -271,7 +285,7 @@ tile_process(
   TileProf prof(MODE, li);
   const int32_t* __restrict__ pfc = tv.fc[li + 1];
   const int c_lo = pfc[j0], c_hi = pfc[j1];  // (uniform addresses: scalar loads)
-  const bool one_part = c_hi - c_lo <= kTileCC;
+  const bool one_part = c_hi - c_lo <= Smem::kCC;
   TileSlice mine;
   bool have = false;
   if (S <= nthr) {
@@ -296,9 +310,9 @@ tile_process(
   // own (five for the key window), and the staging rounds are what most tiles
   // of a sparse level consist of.  (Trip counts for 256 threads; the coarse
   // kernel's 1 024 threads cover the ranges in fewer.)
-  constexpr int kRfc = (kTileT + 1 + 255) / 256;
-  constexpr int kRkey = (kTileT + 2 * kTileW + 255) / 256;
-  constexpr int kRcc = (kTileCC + 1 + 255) / 256;
+  constexpr int kRfc = (Smem::kT + 1 + 255) / 256;
+  constexpr int kRkey = (Smem::kWin + 255) / 256;
+  constexpr int kRcc = (Smem::kCC + 1 + 255) / 256;
   int wlo = 0, whi = 0;
   const int32_t* __restrict__ pfp = tv.fp[li];
   const int64_t* __restrict__ pck = tv.key[li];
@@ -365,7 +379,7 @@ tile_process(
       return;
     if (haar) {
       const int32_t* __restrict__ lf = ctx.haar_lf[li];
-      constexpr int kR = (kTileCC * C + 255) / 256;
+      constexpr int kR = (Smem::kCC * C + 255) / 256;
       int32_t v[kR];
 #pragma unroll
       for (int r = 0; r < kR; r++) {
@@ -436,7 +450,7 @@ tile_process(
   const int jz = sm.sl[nsl - 1].sp1 < j1 ? sm.sl[nsl - 1].sp1 : j1;
 
   // The children of a run of parents are a contiguous range of level li; when
-  // a tile has more than kTileCC of them they are staged a part at a time.
+  // a tile has more than Smem::kCC of them they are staged a part at a time.
   for (int pa = ja; pa < jz;) {
   int pb = jz, cb = c_lo;
   if (!one_part) {
@@ -444,7 +458,7 @@ tile_process(
     int lo = pa + 1, hi = jz;  // a parent has at most 8 children: at least one fits
     while (lo < hi) {
       const int mid = (lo + hi + 1) >> 1;
-      if (sm.fc[mid - j0] - cb0 <= kTileCC)
+      if (sm.fc[mid - j0] - cb0 <= Smem::kCC)
         lo = mid;
       else
         hi = mid - 1;
@@ -535,6 +549,11 @@ tile_process(
   for (int b0 = 0; b0 < nblocks; b0 += gpp) {
     const int bi = b0 + (tid >> 3);
     const bool on = bi < nblocks;
+    // a wavefront none of whose eight groups has a block skips the pass (no
+    // barrier and no cross-wave exchange inside it): at the sparse levels a
+    // tile has fewer blocks than one wavefront takes
+    if (!__any(on))
+      continue;
     const int jl = on ? sm.blocks[bi] : 0;
     const int j = j0 + jl;
     // (lanes of idle groups read the slice of j0: harmless, they store nothing)
@@ -1046,16 +1065,16 @@ tile_process(
 // Workgroup b runs on XCD b % 8 (observed dispatch; locality only): every
 // XCD gets one contiguous eighth of the tiles, so the key windows of
 // neighbouring tiles meet in the same L2.
-template<int C, int MODE>
-__global__ __launch_bounds__(kTileThreads, MODE == kSynthRec ? 6 : GPCC_TILE_WAVES) void
+template<int C, int MODE, int T>
+__global__ __launch_bounds__(kTileThreads, T > kTileT ? 3 : (MODE == kSynthRec ? 6 : GPCC_TILE_WAVES)) void
 raht_tile_kernel(LevelCtx ctx)
 {
-  __shared__ TileSmem<MODE != kSynthRec, (MODE == kAnalyze || MODE == kFused) ? C : 0> sm;
+  __shared__ TileSmem<MODE != kSynthRec, (MODE == kAnalyze || MODE == kFused) ? C : 0, T> sm;
   if (tree_failed(ctx.tv))
     return;
   const int li = ctx.li;
   const int np = ctx.tv.soff[li + 1][ctx.tv.num_slices];
-  const int ntiles = (np + kTileT - 1) / kTileT;
+  const int ntiles = (np + T - 1) / T;
   const int per = ((int)gridDim.x + 7) >> 3;
   const int slot = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
   const int stride = per * 8;
@@ -1065,8 +1084,8 @@ raht_tile_kernel(LevelCtx ctx)
   // (contiguous chunk per workgroup when the grid is smaller than the level)
   const int chunk = (ntiles + stride - 1) / stride;
   for (int tile = slot * chunk; tile < (slot + 1) * chunk && tile < ntiles; tile++) {
-    const int j0 = tile * kTileT;
-    const int j1 = j0 + kTileT < np ? j0 + kTileT : np;
+    const int j0 = tile * T;
+    const int j1 = j0 + T < np ? j0 + T : np;
     tile_process<C, MODE>(ctx, li, j0, j1, sm, true);
   }
 }
