@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GPCC_ABI_VERSION 2
+#define GPCC_ABI_VERSION 3
 #define GPCC_MAX_POINTS (1 << 29) /* 32-bit device indices, stride <= 3 */
 
 #define GPCC_MAX_QP_LAYERS 32
@@ -346,6 +346,79 @@ int gpcc_lift_decode_attr(
   gpcc_ctx* ctx, const gpcc_lod_params* lod, gpcc_lift_params* lift,
   const int32_t* xyz, int32_t* attrs, const int32_t* coeffs,
   const int8_t* lcp_coeffs, int32_t* indexes, int32_t n, int32_t c);
+
+/* ------------------------------------------------------------------ */
+/* predicting transform                                                  */
+
+/* What encode/decode{Colors,Reflectances}Pred (AttributeEncoder.cpp:749-853,
+ * 1075-1210, AttributeDecoder.cpp:328-523) read besides the LoD structure:
+ * the cumulative LoD sizes, the QpSet (fixed_point_qp_offset = 0 for this
+ * transform, quantization.cpp:151-158), the bit depth and the
+ * AttributeParameterSet fields of the prediction-mode and inter-component
+ * tools (hls.h:782-876). */
+typedef struct gpcc_pred_params {
+  int32_t num_lods;
+  int32_t num_points_in_lod[GPCC_MAX_LODS];
+  int32_t bitdepth;
+  int32_t num_qp_layers;
+  int32_t layer_qp[GPCC_MAX_QP_LAYERS][2];
+  int32_t max_qp;
+  int32_t max_num_direct_predictors;
+  int32_t direct_avg_predictor_disabled_flag;
+  int32_t adaptive_prediction_threshold; /* aps.adaptivePredictionThreshold(desc):
+                                          * the APS value << max(0, bitdepth - 8) */
+  int32_t inter_component_prediction_enabled_flag;
+  int32_t quant_neigh_weight[3];
+  int32_t max_num_detail_levels;         /* aps.maxNumDetailLevels(): icp_coeffs
+                                          * beyond it are zero */
+} gpcc_pred_params;
+
+/* Replaces decodeColorsPred / decodeReflectancesPred after the entropy decode
+ * (AttributeDecoder.cpp:328-523), predictors as for gpcc_lift_forward:
+ *   values [n][c] in: the decoded `values` of every predictor in coding order
+ *          (zero runs expanded; the prediction mode still hidden in their
+ *          parities, decodePredModeColor / decodePredModeRefl :288-323,
+ *          :404-447)
+ *   icp_coeffs [GPCC_MAX_LODS][3] in: AttributeBrickHeader::icpCoeffs (c == 3
+ *          and the flag set; otherwise ignored, may be NULL)
+ *   attrs  [n][c] out, point order: the reconstruction.
+ * A point depends on the reconstruction of its neighbours -- also of its own
+ * level of detail unless intra_lod_prediction_skip_layers excludes that: the
+ * device walks the dependency DAG (pred_kernels.hpp); the result is the
+ * reference's for every configuration, the time grows with the depth of the
+ * DAG (a single level of detail on a scan-ordered LiDAR frame is one chain). */
+int gpcc_pred_inverse(
+  gpcc_ctx* ctx, const gpcc_pred_params* params, int32_t n, int32_t c,
+  const int32_t* neigh_count, const int32_t* neigh_index,
+  const int32_t* neigh_weight, const int32_t* indexes, const int32_t* qp_off,
+  int32_t* attrs, const int32_t* values, const int8_t* icp_coeffs);
+
+/* Replaces the body of encodeColorsPred / encodeReflectancesPred minus the
+ * entropy calls for max_num_direct_predictors == 0: attrs in source / out
+ * reconstruction, values [n][c] out, icp_coeffs out
+ * (computeInterComponentPredictionCoeffs, AttributeEncoder.cpp:990-1071).
+ * With direct predictors the encoder's mode decision reads a rate model that
+ * every earlier point has updated (:136-222, 665-717, 894-947) -- one serial
+ * scan: GPCC_ERR_UNSUPPORTED, the caller keeps the reference's loop. */
+int gpcc_pred_forward(
+  gpcc_ctx* ctx, const gpcc_pred_params* params, int32_t n, int32_t c,
+  const int32_t* neigh_count, const int32_t* neigh_index,
+  const int32_t* neigh_weight, const int32_t* indexes, const int32_t* qp_off,
+  int32_t* attrs, int32_t* values, int8_t* icp_coeffs);
+
+/* The predicting attribute coder of one slice minus the entropy loop, as
+ * gpcc_lift_encode_attr / gpcc_lift_decode_attr: AttributeLods::generate
+ * (with blendWeights when the APS asks for it) and the transform in one call,
+ * the predictors never leave the device.  pred: in tools / QP; out num_lods,
+ * num_points_in_lod of the structure that was built. */
+int gpcc_pred_encode_attr(
+  gpcc_ctx* ctx, const gpcc_lod_params* lod, gpcc_pred_params* pred,
+  const int32_t* xyz, int32_t* attrs, int32_t* values, int8_t* icp_coeffs,
+  int32_t* indexes, int32_t n, int32_t c);
+int gpcc_pred_decode_attr(
+  gpcc_ctx* ctx, const gpcc_lod_params* lod, gpcc_pred_params* pred,
+  const int32_t* xyz, int32_t* attrs, const int32_t* values,
+  const int8_t* icp_coeffs, int32_t* indexes, int32_t n, int32_t c);
 
 /* gpcc_raht_encode_attr whose result is the symbol stream of the entropy
  * loop (see gpcc_zero_run_pack) instead of the coefficient array: runs [n],

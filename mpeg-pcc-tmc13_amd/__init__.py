@@ -5,7 +5,7 @@ loaded under the importable alias ``mpeg_pcc_tmc13_amd`` by
 ``__graft_entry__.load_package()`` / ``tests/conftest.py``.
 """
 from . import params, synth  # noqa: F401
-from .params import (LiftParams, LodParams, RahtParams, lift_params, lod_params,  # noqa: F401
+from .params import (LiftParams, LodParams, PredParams, RahtParams, lift_params, lod_params, pred_params,  # noqa: F401
                      raht_params)
 
 

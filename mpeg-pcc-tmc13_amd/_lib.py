@@ -3,7 +3,7 @@ if the HIP library is missing or a call fails this module raises."""
 import ctypes as C
 import os
 
-from .params import LiftParams, LodParams, RahtParams
+from .params import LiftParams, LodParams, PredParams, RahtParams
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # GPCC_LIB_PATH: an experiment build of the same library (tools/, parameter sweeps)
@@ -22,6 +22,7 @@ ABI_SYMBOLS = [
     "gpcc_dev_lod_build", "gpcc_dev_lift_encode_attr", "gpcc_dev_lift_decode_attr",
     "gpcc_multi_create", "gpcc_multi_destroy", "gpcc_multi_num_devices", "gpcc_multi_uses_rccl",
     "gpcc_multi_raht_forward", "gpcc_multi_raht_inverse", "gpcc_binarise_symbols",
+    "gpcc_pred_forward", "gpcc_pred_inverse", "gpcc_pred_encode_attr", "gpcc_pred_decode_attr",
 ]
 
 
@@ -85,6 +86,10 @@ def load():
     lib.gpcc_dev_attr_morton_sort.argtypes = [vp, i32, i64p, vp, vp, vp]
     for name in ("gpcc_lift_forward", "gpcc_lift_inverse"):
         getattr(lib, name).argtypes = [vp, C.POINTER(LiftParams), i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    for name in ("gpcc_pred_forward", "gpcc_pred_inverse"):
+        getattr(lib, name).argtypes = [vp, C.POINTER(PredParams), i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    for name in ("gpcc_pred_encode_attr", "gpcc_pred_decode_attr"):
+        getattr(lib, name).argtypes = [vp, C.POINTER(LodParams), C.POINTER(PredParams), vp, vp, vp, vp, vp, i32, i32]
     lib.gpcc_lod_compute_weights.argtypes = [vp, i32, vp, vp, vp]
     lib.gpcc_lod_build.argtypes = [vp, C.POINTER(LodParams), vp, i32, vp, vp, vp, vp, vp, C.POINTER(i32)]
     for name in ("gpcc_raht_encode_attr", "gpcc_raht_decode_attr"):

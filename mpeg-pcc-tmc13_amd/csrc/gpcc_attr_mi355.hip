@@ -38,6 +38,7 @@
 #include "raht_tree.hpp"
 #include "lift_kernels.hpp"
 #include "lod_kernels.hpp"
+#include "pred_kernels.hpp"
 #include "morton_sort.hpp"
 #include "residual_bins.hpp"
 
@@ -1048,6 +1049,258 @@ host_lift(
   return GPCC_OK;
 }
 
+
+// ---- predicting transform ------------------------------------------------
+struct PredDev {
+  const int32_t *nc, *ni, *nw, *indexes, *qp_off;
+  int32_t *attrs, *values;
+};
+
+int
+check_pred_params(const gpcc_pred_params* p, int n, int c, bool encoder)
+{
+  if (!p)
+    return fail(GPCC_ERR_INVALID_ARG, "params is null");
+  if (n <= 0 || (c != 1 && c != 3))
+    return fail(GPCC_ERR_INVALID_ARG, "n <= 0 or attribute count not 1 / 3");
+  if (n > (1 << 27))
+    return fail(GPCC_ERR_INVALID_ARG, "more than 2^27 points per call");
+  if (p->num_lods < 1 || p->num_lods > GPCC_MAX_LODS)
+    return fail(GPCC_ERR_INVALID_ARG, "num_lods out of range");
+  if (p->num_points_in_lod[p->num_lods - 1] != n)
+    return fail(GPCC_ERR_INVALID_ARG, "num_points_in_lod does not end at n");
+  for (int l = 1; l < p->num_lods; l++)
+    if (p->num_points_in_lod[l] < p->num_points_in_lod[l - 1])
+      return fail(GPCC_ERR_INVALID_ARG, "num_points_in_lod not ascending");
+  if (p->num_qp_layers < 1 || p->num_qp_layers > GPCC_MAX_QP_LAYERS)
+    return fail(GPCC_ERR_INVALID_ARG, "num_qp_layers out of range");
+  if (p->bitdepth < 1 || p->bitdepth > 16)
+    return fail(GPCC_ERR_INVALID_ARG, "bitdepth out of range");
+  if (p->max_num_direct_predictors < 0 || p->max_num_direct_predictors > 3)
+    return fail(GPCC_ERR_INVALID_ARG, "max_num_direct_predictors out of range");
+  if (p->max_num_detail_levels < p->num_lods || p->max_num_detail_levels > GPCC_MAX_LODS)
+    return fail(GPCC_ERR_INVALID_ARG, "max_num_detail_levels out of range");
+  if (encoder && p->max_num_direct_predictors)
+    return fail(
+      GPCC_ERR_UNSUPPORTED,
+      "the encoder's choice among direct predictors is a serial scan (running rate model): "
+      "it stays on the reference CPU path");
+  return GPCC_OK;
+}
+
+size_t
+pred_scratch_bytes(int n)
+{
+  Arena ar;
+  ar.take<int32_t>(n);
+  ar.take<int32_t>(n);
+  ar.take<unsigned long long>(n);
+  ar.take<unsigned long long>(n);
+  ar.take<uint32_t>((size_t)n * 4);
+  ar.take<int32_t>(64);
+  ar.take<unsigned long long>(GPCC_MAX_LODS * 18);
+  return ar.used;
+}
+
+template<int C>
+int
+launch_pred(
+  gpcc_ctx* ctx, bool encoder, const gpcc_pred_params* p, int n, const PredDev& d,
+  int8_t* d_icp, char* scratch)
+{
+  hipStream_t st = ctx->stream;
+  PredCtx cx{};
+  cx.n = n;
+  cx.c = C;
+  cx.num_lods = p->num_lods;
+  for (int l = 0; l < p->num_lods; l++)
+    cx.npl[l] = p->num_points_in_lod[l];
+  // The reference's running counters step when the predictor index meets
+  // numPointsInLod[counter] (one step per index, so a repeated boundary
+  // stalls them): quantLayer and `lod` of the coding loops
+  // (AttributeEncoder.cpp:1108-1121, AttributeDecoder.cpp:476-501) before the
+  // index is processed, `lod` of computeInterComponentPredictionCoeffs
+  // (:1033-1056) after index npl[lod] - 1.  Replayed over the distinct
+  // boundaries.
+  {
+    int ql = 0, lod = 0, est = 0, nr = 1;
+    std::vector<int> bs(p->num_points_in_lod, p->num_points_in_lod + p->num_lods);
+    std::sort(bs.begin(), bs.end());
+    bs.erase(std::unique(bs.begin(), bs.end()), bs.end());
+    cx.range_start[0] = 0;
+    for (int b : bs) {
+      if (b >= n)
+        break;
+      if (ql < p->num_lods && b == p->num_points_in_lod[ql])
+        ql = std::min(p->num_qp_layers - 1, ql + 1);
+      if (lod < p->num_lods && b == p->num_points_in_lod[lod])
+        lod++;
+      if (b > 0 && est < p->num_lods && b == p->num_points_in_lod[est])
+        est++;
+      if (b > 0) {
+        cx.range_start[nr] = b;
+        nr++;
+      }
+      cx.range_qlayer[nr - 1] = ql;
+      cx.range_lod[nr - 1] = std::min(lod, GPCC_MAX_LODS - 1);
+      cx.range_est[nr - 1] = std::min(est, GPCC_MAX_LODS - 1);
+    }
+    cx.num_ranges = nr;
+    cx.est_resolved = est < p->num_lods && p->num_points_in_lod[est] == n ? est + 1 : est;
+  }
+  cx.max_levels = p->max_num_detail_levels;
+  cx.bitdepth = p->bitdepth;
+  cx.num_qp_layers = p->num_qp_layers;
+  memcpy(cx.layer_qp, p->layer_qp, sizeof(cx.layer_qp));
+  cx.max_qp = p->max_qp;
+  cx.max_direct = p->max_num_direct_predictors;
+  cx.avg_disabled = p->direct_avg_predictor_disabled_flag != 0;
+  cx.threshold = p->adaptive_prediction_threshold;
+  cx.icp_enabled = C == 3 && p->inter_component_prediction_enabled_flag;
+  for (int k = 0; k < 3; k++)
+    cx.qnw[k] = p->quant_neigh_weight[k];
+  cx.nc = d.nc;
+  cx.ni = d.ni;
+  cx.nw = d.nw;
+  cx.indexes = d.indexes;
+  cx.qp_off = d.qp_off;
+  cx.attrs = d.attrs;
+  cx.values = d.values;
+  cx.icp = d_icp;
+  Arena ar;
+  ar.base = scratch;
+  ar.cap = ~size_t(0);
+  cx.indeg = ar.take<int32_t>(n);
+  cx.recv = ar.take<int32_t>(n);
+  cx.acc = ar.take<unsigned long long>(n);
+  cx.qw = ar.take<unsigned long long>(n);
+  cx.rec = ar.take<uint32_t>((size_t)n * 4);
+  int32_t* small = ar.take<int32_t>(64);
+  cx.ticket = small;
+  cx.error = small + 8;
+  cx.icp_sums = ar.take<unsigned long long>(GPCC_MAX_LODS * 18);
+  // indeg .. rec, tickets, sums: one clear
+  HIP_TRY(hipMemsetAsync(scratch, 0, ar.used, st));
+  auto grid = [&](int items) { return grid_for(std::max(items, 1), 256); };
+  // persistent kernels: as many wavefronts as the device keeps resident
+  const int pgrid = (int)std::min<int64_t>(2048, ((int64_t)n + 255) / 256);
+  {
+    Timer t(ctx, "pred_indegree");
+    pred_indegree_kernel<<<grid(n), 256, 0, st>>>(cx);
+  }
+  {
+    Timer t(ctx, "pred_quant_weights");
+    pred_quant_weights_kernel<<<std::max(pgrid, 1), 256, 0, st>>>(cx);
+  }
+  if (encoder && cx.icp_enabled) {
+    Timer t(ctx, "pred_icp");
+    pred_icp_sums_kernel<<<std::min(grid(n), 1024), 256, 0, st>>>(cx);
+    pred_icp_resolve_kernel<<<1, 64, 0, st>>>(cx);
+  }
+  {
+    Timer t(ctx, "pred_dag");
+    if (encoder)
+      pred_dag_kernel<C, true><<<std::max(pgrid, 1), 256, 0, st>>>(cx);
+    else
+      pred_dag_kernel<C, false><<<std::max(pgrid, 1), 256, 0, st>>>(cx);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(ctx->h_error, cx.error, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  return GPCC_OK;
+}
+
+int
+pred_check_error(gpcc_ctx* ctx)
+{
+  // after a stream synchronisation: launch_pred copied the kernels' error word
+  if (*ctx->h_error) {
+    *ctx->h_error = 0;
+    return fail(GPCC_ERR_HIP, "a dependency wait in the predicting transform expired");
+  }
+  return GPCC_OK;
+}
+
+int
+host_pred(
+  gpcc_ctx* ctx, bool encoder, const gpcc_pred_params* p, int n, int c, const int32_t* nc,
+  const int32_t* ni, const int32_t* nw, const int32_t* indexes, const int32_t* qp_off,
+  int32_t* attrs, int32_t* values, int8_t* icp)
+{
+  if (!ctx)
+    return fail(GPCC_ERR_INVALID_ARG, "ctx is null");
+  int rcode = check_pred_params(p, n, c, encoder);
+  if (rcode)
+    return rcode;
+  if (!nc || !ni || !nw || !indexes || !attrs || !values)
+    return fail(GPCC_ERR_INVALID_ARG, "null buffer");
+  const bool icp_on = c == 3 && p->inter_component_prediction_enabled_flag;
+  if (icp_on && !icp)
+    return fail(GPCC_ERR_INVALID_ARG, "icp_coeffs is null");
+  for (int i = 0; i < n; i++) {
+    if (nc[i] < 0 || nc[i] > 3 || indexes[i] < 0 || indexes[i] >= n)
+      return fail(GPCC_ERR_INVALID_ARG, "bad neighbour count / index table");
+    for (int j = 0; j < nc[i]; j++)
+      if (ni[3 * (size_t)i + j] < 0 || ni[3 * (size_t)i + j] >= i)
+        return fail(GPCC_ERR_INVALID_ARG, "a neighbour does not precede its predictor");
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const size_t N = (size_t)n;
+  PredDev d{};
+  int32_t *d_nc = nullptr, *d_ni = nullptr, *d_nw = nullptr, *d_ix = nullptr, *d_qp = nullptr;
+  int8_t* d_icp = nullptr;
+  char* scratch = nullptr;
+  auto carve = [&](Arena& ar) {
+    ar.reset();
+    d_nc = ar.take<int32_t>(N);
+    d_ni = ar.take<int32_t>(N * 3);
+    d_nw = ar.take<int32_t>(N * 3);
+    d_ix = ar.take<int32_t>(N);
+    d_qp = qp_off ? ar.take<int32_t>(N * 2) : nullptr;
+    d.attrs = ar.take<int32_t>(N * c);
+    d.values = ar.take<int32_t>(N * c);
+    d_icp = ar.take<int8_t>(GPCC_MAX_LODS * 3);
+    scratch = ar.base ? ar.base + ar.used : nullptr;
+    ar.used += pred_scratch_bytes(n);
+  };
+  Arena m;
+  carve(m);
+  rcode = ensure_arena(ctx, m.used);
+  if (rcode)
+    return rcode;
+  carve(ctx->arena);
+  d.nc = d_nc;
+  d.ni = d_ni;
+  d.nw = d_nw;
+  d.indexes = d_ix;
+  d.qp_off = d_qp;
+  HIP_TRY(hipMemcpyAsync(d_nc, nc, sizeof(int32_t) * N, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d_ni, ni, sizeof(int32_t) * N * 3, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d_nw, nw, sizeof(int32_t) * N * 3, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d_ix, indexes, sizeof(int32_t) * N, hipMemcpyHostToDevice, st));
+  if (qp_off)
+    HIP_TRY(hipMemcpyAsync(d_qp, qp_off, sizeof(int32_t) * N * 2, hipMemcpyHostToDevice, st));
+  if (encoder) {
+    HIP_TRY(hipMemcpyAsync(d.attrs, attrs, sizeof(int32_t) * N * c, hipMemcpyHostToDevice, st));
+  } else {
+    HIP_TRY(hipMemcpyAsync(d.values, values, sizeof(int32_t) * N * c, hipMemcpyHostToDevice, st));
+    if (icp_on)
+      HIP_TRY(hipMemcpyAsync(d_icp, icp, GPCC_MAX_LODS * 3, hipMemcpyHostToDevice, st));
+  }
+  rcode = c == 1 ? launch_pred<1>(ctx, encoder, p, n, d, d_icp, scratch)
+                 : launch_pred<3>(ctx, encoder, p, n, d, d_icp, scratch);
+  if (rcode)
+    return rcode;
+  HIP_TRY(hipMemcpyAsync(attrs, d.attrs, sizeof(int32_t) * N * c, hipMemcpyDeviceToHost, st));
+  if (encoder) {
+    HIP_TRY(hipMemcpyAsync(values, d.values, sizeof(int32_t) * N * c, hipMemcpyDeviceToHost, st));
+    if (icp_on)
+      HIP_TRY(hipMemcpyAsync(icp, d_icp, GPCC_MAX_LODS * 3, hipMemcpyDeviceToHost, st));
+  }
+  HIP_TRY(hipStreamSynchronize(st));
+  return pred_check_error(ctx);
+}
+
 }  // namespace
 
 // =========================================================================
@@ -1895,6 +2148,81 @@ gpcc_lod_build_impl(
   return GPCC_OK;
 }
 
+// The predicting attribute coder of one slice minus the entropy loop --
+// AttributeLods::generate + encodeColorsPred / encodeReflectancesPred
+// (AttributeEncoder.cpp:575-579, 749-853, 1075-1210) resp. decode...Pred
+// (AttributeDecoder.cpp:292-296, 328-523): the predictors never leave the
+// device.
+static int
+pred_attr_driver(
+  gpcc_ctx* ctx, bool encoder, const gpcc_lod_params* lod, gpcc_pred_params* pred,
+  const int32_t* xyz, int32_t* attrs, int32_t* values, int8_t* icp, int32_t* indexes,
+  int32_t n, int32_t c)
+{
+  if (!ctx)
+    return fail(GPCC_ERR_INVALID_ARG, "ctx is null");
+  if (!pred || !attrs || !values || (c != 1 && c != 3))
+    return fail(GPCC_ERR_INVALID_ARG, "null buffer or attribute count not 1 / 3");
+  if (encoder && pred->max_num_direct_predictors)
+    return check_pred_params(pred, 1, c, true);  // unsupported, before any work
+  const bool icp_on = c == 3 && pred->inter_component_prediction_enabled_flag;
+  if (icp_on && !icp)
+    return fail(GPCC_ERR_INVALID_ARG, "icp_coeffs is null");
+  const size_t N = (size_t)(n > 0 ? n : 0);
+  const size_t extra = ((N * c * sizeof(int32_t) + 255) & ~size_t(255)) * 2 + 512
+    + pred_scratch_bytes(n > 0 ? n : 1) + 1024;
+  LodDeviceOut o;
+  int r = lod_build_core(ctx, lod, xyz, n, extra, &o);
+  if (r)
+    return r;
+  pred->num_lods = (int)o.npl.size();
+  for (size_t i = 0; i < o.npl.size(); i++)
+    pred->num_points_in_lod[i] = o.npl[i];
+  r = check_pred_params(pred, n, c, encoder);
+  if (r)
+    return r;
+  hipStream_t st = ctx->stream;
+  Arena ar = ctx->arena;  // carve behind the LoD workspace
+  ar.used = o.arena_end;
+  PredDev d{};
+  d.nc = o.count;
+  d.ni = o.neigh_index;
+  d.nw = o.weight;
+  d.indexes = o.indexes;
+  d.qp_off = nullptr;
+  d.attrs = ar.take<int32_t>(N * c);
+  d.values = ar.take<int32_t>(N * c);
+  int8_t* d_icp = ar.take<int8_t>(GPCC_MAX_LODS * 3);
+  char* scratch = ar.base + ar.used;
+  if (ar.used + pred_scratch_bytes(n) > ctx->arena.cap)
+    return fail(GPCC_ERR_OUT_OF_MEMORY, "arena reservation too small");
+  if (encoder) {
+    HIP_TRY(hipMemcpyAsync(d.attrs, attrs, sizeof(int32_t) * N * c, hipMemcpyHostToDevice, st));
+  } else {
+    HIP_TRY(hipMemcpyAsync(d.values, values, sizeof(int32_t) * N * c, hipMemcpyHostToDevice, st));
+    if (icp_on)
+      HIP_TRY(hipMemcpyAsync(d_icp, icp, GPCC_MAX_LODS * 3, hipMemcpyHostToDevice, st));
+  }
+  r = c == 1 ? launch_pred<1>(ctx, encoder, pred, n, d, d_icp, scratch)
+             : launch_pred<3>(ctx, encoder, pred, n, d, d_icp, scratch);
+  if (r)
+    return r;
+  int32_t h_err = 0;
+  HIP_TRY(hipMemcpyAsync(attrs, d.attrs, sizeof(int32_t) * N * c, hipMemcpyDeviceToHost, st));
+  if (encoder) {
+    HIP_TRY(hipMemcpyAsync(values, d.values, sizeof(int32_t) * N * c, hipMemcpyDeviceToHost, st));
+    if (icp_on)
+      HIP_TRY(hipMemcpyAsync(icp, d_icp, GPCC_MAX_LODS * 3, hipMemcpyDeviceToHost, st));
+  }
+  if (indexes)
+    HIP_TRY(hipMemcpyAsync(indexes, o.indexes, sizeof(int32_t) * N, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(&h_err, o.error, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (h_err)
+    return fail(GPCC_ERR_HIP, "a dependency wait in the LoD sub-sampling kernel expired");
+  return pred_check_error(ctx);
+}
+
 // The lifting attribute coder of one slice minus the entropy loop --
 // AttributeLods::generate + encodeColorsLift / encodeReflectancesLift
 // (AttributeEncoder.cpp:575-579, 1379-1648) resp. decode...Lift
@@ -2425,6 +2753,43 @@ gpcc_lift_decode_attr(
   int32_t c)
 {
   return counted(ctx, gpcc_lift_decode_attr_impl(ctx, lod, lift, xyz, attrs, coeffs, lcp_coeffs, indexes, n, c), n);
+}
+
+int
+gpcc_pred_forward(
+  gpcc_ctx* ctx, const gpcc_pred_params* params, int32_t n, int32_t c,
+  const int32_t* neigh_count, const int32_t* neigh_index, const int32_t* neigh_weight,
+  const int32_t* indexes, const int32_t* qp_off, int32_t* attrs, int32_t* values,
+  int8_t* icp_coeffs)
+{
+  return counted(ctx, host_pred(ctx, true, params, n, c, neigh_count, neigh_index, neigh_weight, indexes, qp_off, attrs, values, icp_coeffs), n);
+}
+
+int
+gpcc_pred_inverse(
+  gpcc_ctx* ctx, const gpcc_pred_params* params, int32_t n, int32_t c,
+  const int32_t* neigh_count, const int32_t* neigh_index, const int32_t* neigh_weight,
+  const int32_t* indexes, const int32_t* qp_off, int32_t* attrs, const int32_t* values,
+  const int8_t* icp_coeffs)
+{
+  return counted(ctx, host_pred(ctx, false, params, n, c, neigh_count, neigh_index, neigh_weight, indexes, qp_off, attrs, const_cast<int32_t*>(values), const_cast<int8_t*>(icp_coeffs)), n);
+}
+
+int
+gpcc_pred_encode_attr(
+  gpcc_ctx* ctx, const gpcc_lod_params* lod, gpcc_pred_params* pred, const int32_t* xyz,
+  int32_t* attrs, int32_t* values, int8_t* icp_coeffs, int32_t* indexes, int32_t n, int32_t c)
+{
+  return counted(ctx, pred_attr_driver(ctx, true, lod, pred, xyz, attrs, values, icp_coeffs, indexes, n, c), n);
+}
+
+int
+gpcc_pred_decode_attr(
+  gpcc_ctx* ctx, const gpcc_lod_params* lod, gpcc_pred_params* pred, const int32_t* xyz,
+  int32_t* attrs, const int32_t* values, const int8_t* icp_coeffs, int32_t* indexes, int32_t n,
+  int32_t c)
+{
+  return counted(ctx, pred_attr_driver(ctx, false, lod, pred, xyz, attrs, const_cast<int32_t*>(values), const_cast<int8_t*>(icp_coeffs), indexes, n, c), n);
 }
 
 int

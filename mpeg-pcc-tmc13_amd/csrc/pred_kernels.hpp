@@ -1,0 +1,429 @@
+// pred_kernels.hpp -- the predicting transform on gfx950, given the LoD
+// structure (predictors in coding order).
+//
+// The reference walks the predictors one by one
+// (encode/decode{Colors,Reflectances}Pred, tmc3/AttributeEncoder.cpp:749-853,
+// 1075-1210, tmc3/AttributeDecoder.cpp:328-523): a point is predicted from the
+// RECONSTRUCTED values of up to three neighbours that precede it in coding
+// order -- of coarser levels of detail and, unless
+// intra_lod_prediction_skip_layers excludes it, of its own.  That is a
+// dependency DAG over the points, not a level-synchronous structure, so:
+//   * quantisation weights (computeQuantizationWeights, PCCTMC3Common.h:
+//     895-922): the DAG walked from the last predictor to the first; a point
+//     is final once every later point that references it has added its share
+//     (in-degree counted up front, 64-bit atomic adds commute);
+//   * reconstruction: the DAG walked forward; wavefronts claim 64 consecutive
+//     predictors in coding order (a ticket, so everything a claim waits for is
+//     owned by a wavefront that is already running), a lane publishes its
+//     reconstruction as ONE write-through granule {values, tag} that doubles
+//     as the done flag, neighbours inside the claim are handed over lane to
+//     lane (ds_bpermute) without touching memory.
+// The decoder is complete (prediction modes hidden in the coefficient
+// parities, inter-component prediction, QP layers, region offsets).  The
+// encoder's choice among direct predictors reads a running rate model that
+// every EARLIER point has updated (PCCResidualsEncoder::resStatUpdate*,
+// AttributeEncoder.cpp:136-159): that is one serial scan over the slice with a
+// double-precision log2 per candidate, so the device encoder covers
+// max_num_direct_predictors == 0 and returns GPCC_ERR_UNSUPPORTED otherwise
+// (the caller keeps the reference's loop).
+#pragma once
+
+#include "lift_kernels.hpp"
+
+namespace gpcc {
+
+struct PredCtx {
+  int32_t n, c;
+  int32_t num_lods;
+  int32_t npl[GPCC_MAX_LODS];
+  // the reference's running counters per range between distinct LoD
+  // boundaries (replayed on the host): quantLayer, the `lod` of the coding
+  // loop (icpCoeffs[lod]) and the `lod` of the coefficient estimation
+  int32_t num_ranges;
+  int32_t range_start[kMaxLodRanges];
+  int32_t range_qlayer[kMaxLodRanges];
+  int32_t range_lod[kMaxLodRanges];
+  int32_t range_est[kMaxLodRanges];
+  int32_t est_resolved;  // estimation: LoDs [0, est_resolved) reach their boundary
+  int32_t max_levels;
+  int32_t bitdepth;
+  int32_t num_qp_layers;
+  int32_t layer_qp[GPCC_MAX_QP_LAYERS][2];
+  int32_t max_qp;
+  int32_t max_direct, avg_disabled, threshold, icp_enabled;
+  int32_t qnw[3];
+  const int32_t* nc;
+  const int32_t* ni;
+  const int32_t* nw;
+  const int32_t* indexes;
+  const int32_t* qp_off;
+  int32_t* attrs;   // [n][c] point order
+  int32_t* values;  // [n][c] coding order
+  int8_t* icp;      // [GPCC_MAX_LODS][3]
+  int32_t* indeg;   // [n]
+  int32_t* recv;    // [n]
+  unsigned long long* acc;  // [n]
+  unsigned long long* qw;   // [n]
+  uint32_t* rec;    // [n][4] {r, g, b, tag}: one 16-byte granule per predictor
+  int32_t* ticket;  // [2]
+  int32_t* error;
+  unsigned long long* icp_sums;  // [GPCC_MAX_LODS][18]: 8 weights x {k=1,2}, orig x {1,2}
+};
+
+__device__ __forceinline__ int
+pred_range_of(const PredCtx& cx, int i)
+{
+  int r = 0;
+  for (int k = 1; k < cx.num_ranges; k++)
+    r += i >= cx.range_start[k];
+  return r;
+}
+
+__global__ __launch_bounds__(256) void
+pred_indegree_kernel(PredCtx cx)
+{
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cx.n; i += gridDim.x * blockDim.x) {
+    const int cnt = cx.nc[i];
+    for (int j = 0; j < cnt; j++)
+      atomicAdd(&cx.indeg[cx.ni[3 * (size_t)i + j]], 1);
+  }
+}
+
+// computeQuantizationWeights: predictors from the last to the first
+__global__ __launch_bounds__(256) void
+pred_quant_weights_kernel(PredCtx cx)
+{
+  const int lane = lane_id();
+  for (;;) {
+    int tk = 0;
+    if (lane == 0)
+      tk = atomicAdd(&cx.ticket[0], 1);
+    tk = __shfl(tk, 0);
+    const int64_t base = (int64_t)tk * 64;
+    if (base >= cx.n)
+      break;
+    if (__hip_atomic_load(cx.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      break;
+    const int i = cx.n - 1 - (int)(base + lane);
+    bool pending = i >= 0;
+    int cnt = 0, need = 0;
+    int nb[3] = {0, 0, 0};
+    if (pending) {
+      cnt = cx.nc[i];
+      need = cx.indeg[i];
+      for (int j = 0; j < 3; j++)
+        nb[j] = j < cnt ? cx.ni[3 * (size_t)i + j] : 0;
+    }
+    unsigned spins = 0;
+    while (__any(pending)) {
+      if (pending
+          && __hip_atomic_load(&cx.recv[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == need) {
+        const uint64_t w = 256
+          + __hip_atomic_load(&cx.acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        cx.qw[i] = w;
+        for (int j = 0; j < cnt; j++)
+          atomicAdd(
+            &cx.acc[nb[j]],
+            (unsigned long long)div_exp2_round_half_inf((int64_t)cx.qnw[j] * (int64_t)w, 8));
+        for (int j = 0; j < cnt; j++)
+          __hip_atomic_fetch_add(&cx.recv[nb[j]], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        pending = false;
+      }
+      if (++spins > (1u << 22)) {
+        if (lane == 0)
+          atomicExch(cx.error, 1);
+        break;
+      }
+    }
+  }
+}
+
+// ---- computeInterComponentPredictionCoeffs (encoder) -----------------------
+__global__ __launch_bounds__(256) void
+pred_icp_sums_kernel(PredCtx cx)
+{
+  __shared__ unsigned long long s[GPCC_MAX_LODS][18];
+  for (int t = threadIdx.x; t < GPCC_MAX_LODS * 18; t += blockDim.x)
+    (&s[0][0])[t] = 0;
+  __syncthreads();
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cx.n; i += gridDim.x * blockDim.x) {
+    const int lod = cx.range_est[pred_range_of(cx, i)];
+    int32_t resid[3];
+    const int32_t* me = &cx.attrs[3 * (size_t)cx.indexes[i]];
+    const bool has = cx.nc[i] >= 1;
+    const int32_t* nbp = has ? &cx.attrs[3 * (size_t)cx.indexes[cx.ni[3 * (size_t)i]]] : me;
+    for (int k = 0; k < 3; k++)
+      resid[k] = me[k] - (has ? nbp[k] : 0);
+    for (int w = 0; w < 8; w++)
+      for (int k = 1; k < 3; k++)
+        atomicAdd(
+          &s[lod][2 * w + k - 1],
+          (unsigned long long)abs(resid[k] - (((w + 1) * resid[0] + 2) >> 2)));
+    for (int k = 1; k < 3; k++)
+      atomicAdd(&s[lod][16 + k - 1], (unsigned long long)abs(resid[k]));
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < GPCC_MAX_LODS * 18; t += blockDim.x)
+    if ((&s[0][0])[t])
+      atomicAdd(&cx.icp_sums[t], (&s[0][0])[t]);
+}
+
+__global__ void
+pred_icp_resolve_kernel(PredCtx cx)
+{
+  const int lod = threadIdx.x;
+  if (lod >= GPCC_MAX_LODS)
+    return;
+  int8_t out[3] = {0, 0, 0};
+  if (lod < cx.est_resolved && lod < cx.max_levels) {
+    const unsigned long long* s = &cx.icp_sums[18 * lod];
+    for (int k = 1; k < 3; k++) {
+      int best = 0;
+      for (int w = 1; w < 8; w++)
+        if (s[2 * w + k - 1] < s[2 * best + k - 1])
+          best = w;
+      out[k] = s[2 * best + k - 1] > s[16 + k - 1] ? 0 : (int8_t)(1 + best);
+    }
+  }
+  for (int k = 0; k < 3; k++)
+    cx.icp[3 * lod + k] = out[k];
+}
+
+// ---- reconstruction: the DAG walked forward --------------------------------
+template<int C, bool ENC>
+__global__ __launch_bounds__(256) void
+pred_dag_kernel(PredCtx cx)
+{
+  const int lane = lane_id();
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(
+    cx.rec, 0, (int)((size_t)cx.n * 16), 0x00020000);
+  const int maxcand = cx.max_direct + !cx.avg_disabled;
+  const int64_t clip_max = ((int64_t)1 << cx.bitdepth) - 1;
+  for (;;) {
+    int tk = 0;
+    if (lane == 0)
+      tk = atomicAdd(&cx.ticket[1], 1);
+    tk = __shfl(tk, 0);
+    const int64_t base64 = (int64_t)tk * 64;
+    if (base64 >= cx.n)
+      break;
+    if (__hip_atomic_load(cx.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      break;
+    const int base = (int)base64;
+    const int i = base + lane;
+    const bool live = i < cx.n;
+    int cnt = 0, pt = 0;
+    int nidx[3] = {0, 0, 0};
+    int32_t nwt[3] = {0, 0, 0};
+    int32_t val[3] = {0, 0, 0};
+    int32_t col[3] = {0, 0, 0};
+    int64_t wgt[2] = {1, 1};
+    Quantizer q[2] = {make_quantizer(4), make_quantizer(4)};
+    int8_t icpc[3] = {0, 0, 0};
+    if (live) {
+      cnt = cx.nc[i];
+      pt = cx.indexes[i];
+      for (int j = 0; j < 3; j++) {
+        nidx[j] = j < cnt ? cx.ni[3 * (size_t)i + j] : 0;
+        nwt[j] = j < cnt ? cx.nw[3 * (size_t)i + j] : 0;
+      }
+      const int r = pred_range_of(cx, i);
+      const int layer = cx.range_qlayer[r];
+      const int o0 = cx.qp_off ? cx.qp_off[2 * (size_t)pt] : 0;
+      const int o1 = cx.qp_off ? cx.qp_off[2 * (size_t)pt + 1] : 0;
+      const int qp0 = clip(cx.layer_qp[layer][0] + o0, 4, cx.max_qp);
+      const int qp1 = clip(cx.layer_qp[layer][1] + o1 + qp0, 4, cx.max_qp);
+      q[0] = make_quantizer(qp0);
+      q[1] = make_quantizer(qp1);
+      const int64_t w = (int64_t)cx.qw[i];
+      wgt[0] = (w < q[0].step ? w : (int64_t)q[0].step) >> 8;
+      wgt[1] = (w < q[1].step ? w : (int64_t)q[1].step) >> 8;
+      if (C == 3 && cx.icp_enabled) {
+        const int l = cx.range_lod[r];
+        for (int k = 0; k < 3; k++)
+          icpc[k] = cx.icp[3 * l + k];
+      }
+      for (int k = 0; k < C; k++) {
+        if (ENC)
+          col[k] = cx.attrs[(size_t)pt * C + k];
+        else
+          val[k] = cx.values[(size_t)i * C + k];
+      }
+    }
+    int32_t nbv[3][C];
+    for (int j = 0; j < 3; j++)
+      for (int k = 0; k < C; k++)
+        nbv[j][k] = 0;
+    uint32_t have = 0;  // neighbours received
+    const uint32_t want = live ? (1u << cnt) - 1 : 0;
+    int32_t myrec[C];
+    for (int k = 0; k < C; k++)
+      myrec[k] = 0;
+    int mydone = 0;
+    bool pending = live;
+    unsigned spins = 0;
+    while (__any(pending)) {
+      // neighbours inside the claim: lane to lane
+      for (int j = 0; j < 3; j++) {
+        const int src = nidx[j] - base;
+        const bool inw = j < cnt && src >= 0;
+        const int sl = inw ? src : lane;
+        const int d = __shfl(mydone, sl);
+        int32_t v[C];
+        for (int k = 0; k < C; k++)
+          v[k] = __shfl(myrec[k], sl);
+        if (inw && d && !((have >> j) & 1)) {
+          for (int k = 0; k < C; k++)
+            nbv[j][k] = v[k];
+          have |= 1u << j;
+        }
+      }
+      // neighbours of earlier claims: poll their granules, loads first
+      {
+        const uint32_t todo = pending ? want & ~have : 0;
+        u32x4 g[3];
+        for (int j = 0; j < 3; j++) {
+          g[j] = u32x4{0, 0, 0, 0};
+          if (((todo >> j) & 1) && nidx[j] < base)
+            g[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, nidx[j] * 16, 0, /*sc1*/ 16);
+        }
+        for (int j = 0; j < 3; j++)
+          if (((todo >> j) & 1) && nidx[j] < base && g[j].w) {
+            nbv[j][0] = (int32_t)g[j].x;
+            nbv[j][1 % C] = C > 1 ? (int32_t)g[j].y : nbv[j][1 % C];
+            nbv[j][2 % C] = C > 2 ? (int32_t)g[j].z : nbv[j][2 % C];
+            have |= 1u << j;
+          }
+      }
+      const bool ready = pending && have == want;
+      if (ready) {
+        // predModeEligibleColor / ...Refl
+        bool elig = false;
+        if (cnt > 1 && cx.max_direct) {
+          int32_t best = 0;
+          for (int k = 0; k < C; k++) {
+            int32_t lo = nbv[0][k], hi = nbv[0][k];
+            for (int j = 1; j < 3; j++)
+              if (j < cnt) {
+                lo = min(lo, nbv[j][k]);
+                hi = max(hi, nbv[j][k]);
+              }
+            best = k == 0 ? hi - lo : max(best, hi - lo);
+          }
+          elig = best >= cx.threshold;
+        }
+        int mode = 0;
+        if (!ENC && elig) {
+          if (C == 1) {
+            // decodePredModeRefl
+            int a = abs(val[0]);
+            const int sg = val[0] < 0 ? -1 : 1;
+            if (maxcand == 4) {
+              mode = a & 3;
+              a >>= 2;
+            } else if (maxcand == 3) {
+              mode = a & 1;
+              a >>= 1;
+              if (mode > 0) {
+                mode += a & 1;
+                a >>= 1;
+              }
+            } else if (maxcand == 2) {
+              mode = a & 1;
+              a >>= 1;
+            }
+            val[0] = sg * a;
+          } else {
+            // decodePredModeColor
+            const int s1 = val[1 % C] < 0 ? -1 : 1, s2 = val[2 % C] < 0 ? -1 : 1;
+            const int a1 = abs(val[1 % C]), a2 = abs(val[2 % C]);
+            if (maxcand == 4) {
+              val[1 % C] = s1 * (a1 >> 1);
+              val[2 % C] = s2 * (a2 >> 1);
+              mode = ((a1 & 1) << 1) + (a2 & 1);
+            } else if (maxcand == 3) {
+              val[1 % C] = s1 * (a1 >> 1);
+              mode = a1 & 1;
+              if (a1 & 1) {
+                val[2 % C] = s2 * (a2 >> 1);
+                mode += a2 & 1;
+              }
+            } else if (maxcand == 2) {
+              val[1 % C] = s1 * (a1 >> 1);
+              mode = a1 & 1;
+            }
+          }
+          mode += cx.avg_disabled;
+        }
+        // PCCPredictor::predictColor / predictReflectance
+        int64_t pr[C];
+        for (int k = 0; k < C; k++)
+          pr[k] = 0;
+        if (mode > cnt) {
+        } else if (mode > 0) {
+          for (int k = 0; k < C; k++)
+            pr[k] = mode == 1 ? nbv[0][k] : (mode == 2 ? nbv[1][k] : nbv[2][k]);
+        } else {
+          for (int k = 0; k < C; k++) {
+            int64_t s = 0;
+            for (int j = 0; j < 3; j++)
+              if (j < cnt)
+                s += (int64_t)(uint32_t)nwt[j] * nbv[j][k];
+            pr[k] = (uint16_t)div_exp2_round_half_inf(s, 8);
+          }
+        }
+        int64_t residual0 = 0;
+        for (int k = 0; k < C; k++) {
+          const Quantizer qq = q[k ? 1 : 0];
+          const int64_t weight = wgt[k ? 1 : 0];
+          const int64_t icpterm = C == 3 ? ((int64_t)icpc[k] * residual0 + 2) >> 2 : 0;
+          int64_t rr;
+          if (ENC) {
+            int64_t residual = col[k] - pr[k];
+            int64_t rq = quantize(qq, (residual * weight) << 8);
+            rr = ((mul_i64_u32(rq, qq.step) + 128) >> 8) / weight;
+            if (C == 3 && cx.icp_enabled && k > 0) {
+              residual -= icpterm;
+              rq = quantize(qq, (residual * weight) << 8);
+              rr = ((mul_i64_u32(rq, qq.step) + 128) >> 8) / weight;
+              rr += icpterm;
+            }
+            val[k] = (int32_t)rq;
+            if (k == 0)
+              residual0 = rr;
+          } else {
+            rr = ((mul_i64_u32((int64_t)val[k], qq.step) + 128) >> 8) / weight;
+            const int64_t residual = rr;
+            rr += icpterm;
+            if (!k && cx.icp_enabled)
+              residual0 = residual;
+          }
+          int64_t v = pr[k] + rr;
+          v = v < 0 ? 0 : (v > clip_max ? clip_max : v);
+          myrec[k] = (int32_t)(uint16_t)v;
+        }
+        {
+          const u32x4 st = {(uint32_t)myrec[0], (uint32_t)myrec[1 % C], (uint32_t)myrec[2 % C], 1u};
+          __builtin_amdgcn_raw_buffer_store_b128(st, rsrc, i * 16, 0, /*sc1*/ 16);
+        }
+        for (int k = 0; k < C; k++) {
+          cx.attrs[(size_t)pt * C + k] = myrec[k];
+          if (ENC)
+            cx.values[(size_t)i * C + k] = val[k];
+        }
+        mydone = 1;
+        pending = false;
+      }
+      if (!__any(ready)) {
+        if (++spins > (1u << 22)) {
+          if (lane == 0)
+            atomicExch(cx.error, 1);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+  }
+}
+
+}  // namespace gpcc

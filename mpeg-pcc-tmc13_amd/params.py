@@ -125,6 +125,52 @@ def lift_params(num_points_in_lod, qp=34, chroma_offset=-1, bitdepth=8, lcp=True
     return p
 
 
+class PredParams(C.Structure):
+    """ctypes mirror of gpcc_pred_params."""
+    _fields_ = [
+        ("num_lods", C.c_int32),
+        ("num_points_in_lod", C.c_int32 * GPCC_MAX_LODS),
+        ("bitdepth", C.c_int32),
+        ("num_qp_layers", C.c_int32),
+        ("layer_qp", (C.c_int32 * 2) * GPCC_MAX_QP_LAYERS),
+        ("max_qp", C.c_int32),
+        ("max_num_direct_predictors", C.c_int32),
+        ("direct_avg_predictor_disabled_flag", C.c_int32),
+        ("adaptive_prediction_threshold", C.c_int32),
+        ("inter_component_prediction_enabled_flag", C.c_int32),
+        ("quant_neigh_weight", C.c_int32 * 3),
+        ("max_num_detail_levels", C.c_int32),
+    ]
+
+
+def pred_params(num_points_in_lod, qp=34, chroma_offset=0, bitdepth=8, direct=3, avg_disabled=False,
+                threshold=64, icp=True, quant_neigh_weight=(0, 0, 0), max_levels=None, layers=None):
+    """Effective values of cfg/octree-predt-ctc-lossless-geom-nearlossless-attrs.yaml
+    (transformType 1): three direct predictors, adaptivePredictionThreshold 64
+    (scaled by the bit depth, hls.h:808-811), inter-component prediction on."""
+    p = PredParams()
+    npl = [int(v) for v in num_points_in_lod]
+    assert 1 <= len(npl) <= GPCC_MAX_LODS
+    p.num_lods = len(npl)
+    for i, v in enumerate(npl):
+        p.num_points_in_lod[i] = v
+    p.bitdepth = bitdepth
+    lay = layers if layers is not None else [(qp, chroma_offset)]
+    p.num_qp_layers = len(lay)
+    for i, (a, b) in enumerate(lay):
+        p.layer_qp[i][0] = a
+        p.layer_qp[i][1] = b
+    p.max_qp = 51 + 6 * (bitdepth - 8)
+    p.max_num_direct_predictors = direct
+    p.direct_avg_predictor_disabled_flag = int(avg_disabled)
+    p.adaptive_prediction_threshold = threshold << max(0, bitdepth - 8)
+    p.inter_component_prediction_enabled_flag = int(icp)
+    for k in range(3):
+        p.quant_neigh_weight[k] = quant_neigh_weight[k]
+    p.max_num_detail_levels = max_levels if max_levels is not None else max(len(npl), 1)
+    return p
+
+
 class LodParams(C.Structure):
     """Flattened LoD-generation parameters (AttributeParameterSet LoD fields +
     AttributeBrickHeader::attr_dist2_delta) handed to AttributeLods::generate

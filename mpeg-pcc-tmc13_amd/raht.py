@@ -228,6 +228,64 @@ class Context:
                                                    l.ctypes.data, None, n, c))
         return a
 
+    # ---- predicting transform ----
+    def _pred(self, forward, params, nc, ni, nw, indexes, attrs, values, icp, qp_off):
+        nc = np.ascontiguousarray(nc, dtype=np.int32)
+        ni = np.ascontiguousarray(ni, dtype=np.int32)
+        nw = np.ascontiguousarray(nw, dtype=np.int32)
+        ix = np.ascontiguousarray(indexes, dtype=np.int32)
+        n = nc.shape[0]
+        if forward:
+            a = np.ascontiguousarray(attrs, dtype=np.int32).copy()
+            c = a.shape[1]
+            v = np.zeros((n, c), dtype=np.int32)
+            l = np.zeros((32, 3), dtype=np.int8)
+        else:
+            v = np.ascontiguousarray(values, dtype=np.int32)
+            c = v.shape[1]
+            a = np.zeros((n, c), dtype=np.int32)
+            l = np.zeros((32, 3), dtype=np.int8) if icp is None else np.ascontiguousarray(icp, dtype=np.int8).copy()
+        q = None if qp_off is None else np.ascontiguousarray(qp_off, dtype=np.int32)
+        f = self._lib.gpcc_pred_forward if forward else self._lib.gpcc_pred_inverse
+        _lib.check(f(self._h, C.byref(params), n, c, nc.ctypes.data, ni.ctypes.data, nw.ctypes.data, ix.ctypes.data,
+                     q.ctypes.data if q is not None else None, a.ctypes.data, v.ctypes.data, l.ctypes.data))
+        return v, a, l
+
+    def pred_forward(self, params, nc, ni, nw, indexes, attrs, qp_off=None):
+        """encodeColorsPred / encodeReflectancesPred minus the entropy calls (no direct
+        predictors) -> (values [n,c] coding order, recon [n,c] point order, icp int8[32,3])"""
+        return self._pred(True, params, nc, ni, nw, indexes, attrs, None, None, qp_off)
+
+    def pred_inverse(self, params, nc, ni, nw, indexes, values, icp=None, qp_off=None):
+        """decodeColorsPred / decodeReflectancesPred after the entropy decode -> recon [n,c]"""
+        return self._pred(False, params, nc, ni, nw, indexes, None, values, icp, qp_off)[1]
+
+    def pred_encode_attr(self, lod_params, pred_params, xyz, attrs):
+        """AttributeLods::generate + encode...Pred minus the entropy loop ->
+        (values, recon, icp int8[32,3], indexes); pred_params gets the LoD structure"""
+        xyz = np.ascontiguousarray(xyz, dtype=np.int32)
+        a = np.ascontiguousarray(attrs, dtype=np.int32).copy()
+        n, c = a.shape
+        v = np.zeros((n, c), dtype=np.int32)
+        l = np.zeros((32, 3), dtype=np.int8)
+        idx = np.zeros(n, dtype=np.int32)
+        _lib.check(self._lib.gpcc_pred_encode_attr(self._h, C.byref(lod_params), C.byref(pred_params),
+                                                   xyz.ctypes.data, a.ctypes.data, v.ctypes.data, l.ctypes.data,
+                                                   idx.ctypes.data, n, c))
+        return v, a, l, idx
+
+    def pred_decode_attr(self, lod_params, pred_params, xyz, values, icp=None):
+        """AttributeLods::generate + decode...Pred after the entropy decode -> recon [n,c]"""
+        xyz = np.ascontiguousarray(xyz, dtype=np.int32)
+        v = np.ascontiguousarray(values, dtype=np.int32)
+        n, c = v.shape
+        a = np.zeros((n, c), dtype=np.int32)
+        l = np.zeros((32, 3), dtype=np.int8) if icp is None else np.ascontiguousarray(icp, dtype=np.int8).copy()
+        _lib.check(self._lib.gpcc_pred_decode_attr(self._h, C.byref(lod_params), C.byref(pred_params),
+                                                   xyz.ctypes.data, a.ctypes.data, v.ctypes.data, l.ctypes.data,
+                                                   None, n, c))
+        return a
+
     # ---- device tier of the LoD build / lifting coder (buffers are raw device pointers) ----
     def dev_lod_build(self, lod_params, offsets, d_xyz, d_count, d_index, d_weight, d_indexes):
         """gpcc_dev_lod_build -> list of cumulative LoD sizes per slice"""

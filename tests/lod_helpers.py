@@ -168,3 +168,73 @@ def ref_entropy_encode_bins(bins, num_points):
     ln = lib.ref_entropy_encode_bins(bins.ctypes.data, len(bins), num_points, out, out.size)
     assert ln >= 0
     return out[:ln].tobytes()
+
+
+# ---- predicting transform ---------------------------------------------------
+def oracle_pred(forward, pp, lod, attrs=None, values=None, icp=None, qp_off=None):
+    """oracle/pred_oracle.c -> (values [n,c] coding order, recon [n,c] point order,
+    icp int8 [32,3], modes [n] (-1 = not eligible))"""
+    lib = ol.oracle().lib
+    f = lib.oracle_pred_forward if forward else lib.oracle_pred_inverse
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_int32, C.c_int32, i32p, i32p, i32p, i32p, C.c_void_p, i32p, i32p, C.c_void_p, i32p]
+    n = len(lod["nc"])
+    if forward:
+        a = np.ascontiguousarray(attrs, dtype=np.int32).copy()
+        c = a.shape[1]
+        v = np.zeros((n, c), np.int32)
+        l = np.zeros((32, 3), np.int8)
+    else:
+        v = np.ascontiguousarray(values, dtype=np.int32).copy()
+        c = v.shape[1]
+        a = np.zeros((n, c), np.int32)
+        l = np.zeros((32, 3), np.int8) if icp is None else np.ascontiguousarray(icp, dtype=np.int8).copy()
+    modes = np.zeros(n, np.int32)
+    q = None if qp_off is None else np.ascontiguousarray(qp_off, dtype=np.int32)
+    rc = f(C.addressof(pp), n, c, lod["nc"], np.ascontiguousarray(lod["ni"]).reshape(-1),
+           np.ascontiguousarray(lod["w"].astype(np.int32)).reshape(-1), lod["indexes"],
+           q.ctypes.data_as(C.c_void_p) if q is not None else None, a.reshape(-1), v.reshape(-1),
+           l.ctypes.data_as(C.c_void_p), modes)
+    assert rc == 0
+    return v, a, l, modes
+
+
+def ref_pred_roundtrip(lp, pp, aps_threshold, qp, chroma, xyz, attrs):
+    """reference AttributeEncoder::encode + AttributeDecoder::decode for the
+    predicting transform -> (payload, recon_enc, recon_dec, icp int8 [32,3])"""
+    lib = ol.ref().lib
+    lib.ref_pred_roundtrip.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, i32p, i32p, C.c_int32,
+                                       C.c_int32, i32p, i32p, u8p, C.c_int32, C.c_void_p]
+    xyz = np.ascontiguousarray(xyz, dtype=np.int32)
+    attrs = np.ascontiguousarray(attrs, dtype=np.int32)
+    n, c = attrs.shape
+    re = np.zeros(n * c, np.int32)
+    rd = np.zeros(n * c, np.int32)
+    pay = np.zeros(n * c * 8 + 4096, np.uint8)
+    icp = np.zeros((32, 3), np.int8)
+    ln = lib.ref_pred_roundtrip(C.addressof(lp), C.addressof(pp), aps_threshold, qp, chroma, xyz.reshape(-1),
+                                attrs.reshape(-1), n, c, re, rd, pay, pay.size, icp.ctypes.data_as(C.c_void_p))
+    return pay[:ln].tobytes(), re.reshape(n, c), rd.reshape(n, c), icp
+
+
+_entropy_dec = None
+
+
+def entropy_dec_available():
+    import os
+    return os.path.exists(os.path.join(ol.ORACLE_DIR, "_ref", "libtmc3_entropy_dec.so"))
+
+
+def ref_entropy_decode_symbols(payload, n, c):
+    """the reference's PCCResidualsDecoder over the arithmetic-coded part of a
+    payload -> values [n,c] in coding order (zero runs expanded)"""
+    global _entropy_dec
+    import os
+    if _entropy_dec is None:
+        _entropy_dec = C.CDLL(os.path.join(ol.ORACLE_DIR, "_ref", "libtmc3_entropy_dec.so"))
+        _entropy_dec.ref_entropy_decode_symbols.argtypes = [C.c_int32, C.c_int32, u8p, C.c_int32, i32p]
+    buf = np.frombuffer(payload, dtype=np.uint8).copy()
+    out = np.zeros(n * c, np.int32)
+    rc = _entropy_dec.ref_entropy_decode_symbols(c, n, buf, len(buf), out)
+    assert rc == 0
+    return out.reshape(n, c)

@@ -1,0 +1,95 @@
+"""The predicting transform's oracle (oracle/pred_oracle.c) pinned against the
+compiled reference at OPERATOR level: AttributeEncoder::encode writes a payload
+for the slice; its own entropy decoder gives back the symbol stream (`values`
+of every predictor, prediction modes hidden in the parities) and the brick
+header the inter-component coefficients.  The oracle's encoder -- including the
+mode decision with the running rate model -- must produce the same symbols,
+coefficients and reconstruction, and its decoder the reference decoder's
+output.  CPU only."""
+import numpy as np
+import pytest
+
+import conftest  # noqa: F401
+import lod_helpers as lh
+import oracle_loader as ol
+
+needs_ref = pytest.mark.skipif(not (ol.ref_available() and lh.entropy_dec_available()),
+                               reason="compiled reference / entropy decoder harness absent")
+
+# (cloud, n, bits, qp, lod overrides, pred overrides)
+CASES = {
+    "dense_ctc": ("dense", 12000, 8, 28, {}, {}),
+    "dense_qp10": ("dense", 6000, 7, 10, {}, {}),
+    "dense_qp46_noicp": ("dense", 6000, 7, 46, {}, dict(icp=False)),
+    "dense_direct1": ("dense", 5000, 7, 34, {}, dict(direct=1)),
+    "dense_direct2": ("dense", 5000, 7, 34, {}, dict(direct=2)),
+    "dense_avg_disabled": ("dense", 5000, 7, 34, {}, dict(direct=3, avg_disabled=True)),
+    "dense_avg_disabled2": ("dense", 5000, 7, 22, {}, dict(direct=2, avg_disabled=True)),
+    "dense_nodirect_qnw": ("dense", 8000, 7, 34, {}, dict(direct=0, quant_neigh_weight=(25, 12, 12))),
+    "dense_qnw_direct": ("dense", 8000, 7, 40, {}, dict(quant_neigh_weight=(25, 12, 12))),
+    "dense_skip_intra": ("dense", 6000, 7, 34, dict(skip=32), {}),
+    "dense_thr0": ("dense", 4000, 6, 34, {}, dict(threshold=0)),
+    "lidar_refl_ctc": ("lidar", 9000, 0, 28, dict(levels=1), dict(avg_disabled=True)),
+    "lidar_refl_lods": ("lidar", 9000, 0, 34, {}, {}),
+    "lidar_refl_direct2": ("lidar", 7000, 0, 16, {}, dict(direct=2)),
+    "lidar_refl_direct1_dis": ("lidar", 7000, 0, 22, dict(levels=1), dict(direct=1, avg_disabled=True)),
+    "random_sparse": ("random", 1500, 9, 34, {}, {}),
+    "tiny": ("random", 3, 4, 34, {}, {}),
+    "single": ("random", 1, 4, 34, {}, {}),
+}
+
+
+def make(name):
+    from mpeg_pcc_tmc13_amd import lod_params, pred_params, synth
+    kind, n, bits, qp, lo, po = CASES[name]
+    if kind == "dense":
+        xyz, attrs = synth.dense_cloud(n, seed=71, bits=bits)
+    elif kind == "lidar":
+        xyz, attrs = synth.lidar_cloud(n, seed=71)
+    else:
+        xyz, attrs = synth.random_cloud(n, seed=71, bits=bits)
+    c = attrs.shape[1]
+    bitdepth = 8 if c == 3 else 16
+    if c == 1 and attrs.max() < 256:
+        attrs = attrs * 257  # use the 16-bit range
+    # cfg/octree-predt-ctc-*.yaml: transformType 1, intraLodPredictionSkipLayers 0, both search
+    # ranges -1 (= 1100000 after encoder.cpp:799-808), predWeightBlending for colour; cat3: one LoD
+    lp = lod_params(levels=lo.get("levels", 12), lifting=False, intra_range=1100000, blend=(c == 3))
+    lp.intra_lod_prediction_skip_layers = lo.get("skip", 0)
+    thr = po.get("threshold", 64)
+    po = {k: v for k, v in po.items() if k != "threshold"}
+    return xyz, attrs.astype(np.int32), lp, qp, bitdepth, thr, po
+
+
+def run_reference(name):
+    from mpeg_pcc_tmc13_amd import pred_params
+    xyz, attrs, lp, qp, bitdepth, thr, po = make(name)
+    n, c = attrs.shape
+    lod = lh.ref_lod_generate(xyz, lp)
+    pp = pred_params(lod["npl"], qp=qp, chroma_offset=0, bitdepth=bitdepth, threshold=thr,
+                     max_levels=lp.num_detail_levels_minus1 + 1, **po)
+    payload, rec_enc, rec_dec, icp = lh.ref_pred_roundtrip(lp, pp, thr, qp, 0, xyz, attrs)
+    np.testing.assert_array_equal(rec_enc, rec_dec)  # the reference's own conformance criterion
+    values = lh.ref_entropy_decode_symbols(payload[lh.ref_last_abh_size():], n, c)
+    return xyz, attrs, lod, pp, values, rec_enc, icp
+
+
+@needs_ref
+@pytest.mark.parametrize("name", list(CASES))
+def test_oracle_encoder_symbols_and_reconstruction(name):
+    xyz, attrs, lod, pp, want_values, want_rec, want_icp = run_reference(name)
+    values, rec, icp, modes = lh.oracle_pred(True, pp, lod, attrs=attrs)
+    if attrs.shape[1] == 3 and pp.inter_component_prediction_enabled_flag:
+        np.testing.assert_array_equal(icp, want_icp)
+    np.testing.assert_array_equal(values, want_values)
+    np.testing.assert_array_equal(rec, want_rec)
+    if pp.max_num_direct_predictors and len(xyz) > 1000:
+        assert (modes > 0).any()  # direct predictors were chosen somewhere: the decision is exercised
+
+
+@needs_ref
+@pytest.mark.parametrize("name", list(CASES))
+def test_oracle_decoder_from_reference_symbols(name):
+    xyz, attrs, lod, pp, values, want_rec, icp = run_reference(name)
+    _, rec, _, _ = lh.oracle_pred(False, pp, lod, values=values, icp=icp)
+    np.testing.assert_array_equal(rec, want_rec)
