@@ -1102,6 +1102,13 @@ pred_scratch_bytes(int n)
   return ar.used;
 }
 
+__global__ __launch_bounds__(256) void
+fill_u64_kernel(unsigned long long* p, unsigned long long v, int n)
+{
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    p[i] = v;
+}
+
 template<int C>
 int
 launch_pred(
@@ -1178,6 +1185,8 @@ launch_pred(
   int32_t* small = ar.take<int32_t>(64);
   cx.ticket = small;
   cx.error = small + 8;
+  cx.wide = small + 16;
+  cx.packed_ok = cx.qnw[0] >= 0 && cx.qnw[1] >= 0 && cx.qnw[2] >= 0 && cx.qnw[0] + cx.qnw[1] + cx.qnw[2] < 256;
   cx.icp_sums = ar.take<unsigned long long>(GPCC_MAX_LODS * 18);
   // indeg .. rec, tickets, sums: one clear
   HIP_TRY(hipMemsetAsync(scratch, 0, ar.used, st));
@@ -1188,9 +1197,13 @@ launch_pred(
     Timer t(ctx, "pred_indegree");
     pred_indegree_kernel<<<grid(n), 256, 0, st>>>(cx);
   }
-  {
+  if (cx.qnw[0] || cx.qnw[1] || cx.qnw[2]) {
     Timer t(ctx, "pred_quant_weights");
     pred_quant_weights_kernel<<<std::max(pgrid, 1), 256, 0, st>>>(cx);
+  } else {
+    // no shares: every weight is 1 << kFixedPointWeightShift
+    Timer t(ctx, "pred_quant_weights");
+    fill_u64_kernel<<<grid(n), 256, 0, st>>>(cx.qw, 256ull, n);
   }
   if (encoder && cx.icp_enabled) {
     Timer t(ctx, "pred_icp");

@@ -66,6 +66,8 @@ struct PredCtx {
   unsigned long long* qw;   // [n]
   uint32_t* rec;    // [n][4] {r, g, b, tag}: one 16-byte granule per predictor
   int32_t* ticket;  // [2]
+  int32_t* wide;    // set by pred_indegree_kernel: an in-degree >= 2^20
+  int32_t packed_ok;  // quant_neigh_weight >= 0 and their sum < 256
   int32_t* error;
   unsigned long long* icp_sums;  // [GPCC_MAX_LODS][18]: 8 weights x {k=1,2}, orig x {1,2}
 };
@@ -79,21 +81,42 @@ pred_range_of(const PredCtx& cx, int i)
   return r;
 }
 
+constexpr int kPredCountShift = 44;  // packed share word: (count << 44) | sum
+
 __global__ __launch_bounds__(256) void
 pred_indegree_kernel(PredCtx cx)
 {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cx.n; i += gridDim.x * blockDim.x) {
     const int cnt = cx.nc[i];
     for (int j = 0; j < cnt; j++)
-      atomicAdd(&cx.indeg[cx.ni[3 * (size_t)i + j]], 1);
+      if (atomicAdd(&cx.indeg[cx.ni[3 * (size_t)i + j]], 1) + 1 >= (1 << (64 - kPredCountShift)))
+        atomicExch(cx.wide, 1);  // a count that does not fit the packed word
   }
 }
 
-// computeQuantizationWeights: predictors from the last to the first
-__global__ __launch_bounds__(256) void
-pred_quant_weights_kernel(PredCtx cx)
+// computeQuantizationWeights: predictors from the last to the first.  A
+// wavefront claims 64 consecutive predictors (descending).  A point's shares
+// and the number of referrers that have delivered travel in ONE 64-bit word,
+// (count << 44) | sum, so a delivery is a single fire-and-forget atomic add
+// and the word a consumer polls is complete when its count is (no fence, no
+// wait on the producer's side).  44 bits hold every sum when the three
+// quant_neigh_weights are non-negative and add up to < 256: the shares a point
+// hands on are then less than its own weight, so all weights together stay
+// below 2^16 n.  Shares for a point of the same claim go through the
+// wavefront's LDS slots, the rest through memory; a lane polls memory only
+// until the referrers OUTSIDE its claim have delivered (the in-degree minus the
+// referrers counted inside the claim), after that the claim iterates on LDS
+// alone.  In-degrees of 2^20 or more, or other weights: kWide, separate sum and
+// count words with release / acquire ordering.
+template<bool kWide>
+__device__ __forceinline__ void
+pred_quant_weights_body(const PredCtx& cx)
 {
-  const int lane = lane_id();
+  __shared__ unsigned long long lacc[4][64];
+  __shared__ int lrecv[4][64];
+  __shared__ int lneed[4][64];
+  constexpr unsigned long long kOne = 1ull << kPredCountShift, kSumMask = kOne - 1;
+  const int lane = lane_id(), wv = threadIdx.x >> 6;
   for (;;) {
     int tk = 0;
     if (lane == 0)
@@ -108,34 +131,98 @@ pred_quant_weights_kernel(PredCtx cx)
     bool pending = i >= 0;
     int cnt = 0, need = 0;
     int nb[3] = {0, 0, 0};
+    int tl[3] = {64, 64, 64};  // lane of a neighbour inside the claim (> own lane), 64 = outside
+    __hip_atomic_store(&lacc[wv][lane], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_store(&lrecv[wv][lane], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_store(&lneed[wv][lane], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (pending) {
       cnt = cx.nc[i];
       need = cx.indeg[i];
       for (int j = 0; j < 3; j++)
-        nb[j] = j < cnt ? cx.ni[3 * (size_t)i + j] : 0;
+        if (j < cnt) {
+          nb[j] = cx.ni[3 * (size_t)i + j];
+          const int64_t t = (int64_t)(cx.n - 1 - nb[j]) - base;
+          tl[j] = t < 64 ? (int)t : 64;
+        }
     }
+    for (int j = 0; j < 3; j++)
+      if (tl[j] < 64)
+        __hip_atomic_fetch_add(&lneed[wv][tl[j]], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const int need_l = __hip_atomic_load(&lneed[wv][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const int need_g = need - need_l;
+    bool gdone = !pending || need_g == 0;
+    unsigned long long gsum = 0;
     unsigned spins = 0;
     while (__any(pending)) {
-      if (pending
-          && __hip_atomic_load(&cx.recv[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == need) {
-        const uint64_t w = 256
-          + __hip_atomic_load(&cx.acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (pending && !gdone) {
+        if (kWide) {
+          gdone = __hip_atomic_load(&cx.recv[i], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == need_g;
+          if (gdone)
+            gsum = __hip_atomic_load(&cx.acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          const unsigned long long v =
+            __hip_atomic_load(&cx.acc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          gdone = (int)(v >> kPredCountShift) == need_g;
+          gsum = v & kSumMask;
+        }
+      }
+      bool ready = false;
+      unsigned long long lsum = 0;
+      if (pending && gdone) {
+        if (kWide) {
+          ready = __hip_atomic_load(&lrecv[wv][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == need_l;
+          if (ready)
+            lsum = __hip_atomic_load(&lacc[wv][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+          const unsigned long long v =
+            __hip_atomic_load(&lacc[wv][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          ready = (int)(v >> kPredCountShift) == need_l;
+          lsum = v & kSumMask;
+        }
+      }
+      if (ready) {
+        const uint64_t w = 256 + gsum + lsum;
         cx.qw[i] = w;
-        for (int j = 0; j < cnt; j++)
-          atomicAdd(
-            &cx.acc[nb[j]],
-            (unsigned long long)div_exp2_round_half_inf((int64_t)cx.qnw[j] * (int64_t)w, 8));
-        for (int j = 0; j < cnt; j++)
-          __hip_atomic_fetch_add(&cx.recv[nb[j]], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        for (int j = 0; j < 3; j++) {
+          if (j >= cnt)
+            continue;
+          unsigned long long share =
+            (unsigned long long)div_exp2_round_half_inf((int64_t)cx.qnw[j] * (int64_t)w, 8);
+          if (!kWide)
+            share += kOne;
+          if (tl[j] < 64)
+            __hip_atomic_fetch_add(&lacc[wv][tl[j]], share, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          else
+            atomicAdd(&cx.acc[nb[j]], share);
+        }
+        if (kWide)
+          for (int j = 0; j < 3; j++) {
+            if (j >= cnt)
+              continue;
+            if (tl[j] < 64)
+              __hip_atomic_fetch_add(&lrecv[wv][tl[j]], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else
+              __hip_atomic_fetch_add(&cx.recv[nb[j]], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+          }
         pending = false;
       }
-      if (++spins > (1u << 22)) {
+      if (++spins > (1u << 24)) {
         if (lane == 0)
           atomicExch(cx.error, 1);
         break;
       }
     }
   }
+}
+
+__global__ __launch_bounds__(256) void
+pred_quant_weights_kernel(PredCtx cx)
+{
+  // uniform: the flag was written by the kernel before this one
+  if (cx.packed_ok && !*cx.wide)
+    pred_quant_weights_body<false>(cx);
+  else
+    pred_quant_weights_body<true>(cx);
 }
 
 // ---- computeInterComponentPredictionCoeffs (encoder) -----------------------

@@ -27,6 +27,9 @@ CASES = {
     "dense_avg_disabled2": ("dense", 5000, 7, 22, {}, dict(direct=2, avg_disabled=True)),
     "dense_nodirect_qnw": ("dense", 8000, 7, 34, {}, dict(direct=0, quant_neigh_weight=(25, 12, 12))),
     "dense_qnw_direct": ("dense", 8000, 7, 40, {}, dict(quant_neigh_weight=(25, 12, 12))),
+    # shares that add up to more than the weight itself: the device's separate sum / count words
+    "dense_qnw_wide": ("dense", 6000, 7, 34, {}, dict(quant_neigh_weight=(120, 80, 60))),
+    "lidar_qnw_wide_1lod": ("lidar", 5000, 0, 28, dict(levels=1), dict(avg_disabled=True, quant_neigh_weight=(130, 90, 40))),
     "dense_skip_intra": ("dense", 6000, 7, 34, dict(skip=32), {}),
     "dense_thr0": ("dense", 4000, 6, 34, {}, dict(threshold=0)),
     "lidar_refl_ctc": ("lidar", 9000, 0, 28, dict(levels=1), dict(avg_disabled=True)),
