@@ -13,20 +13,27 @@
 // Here the node arrays of a level are what they are -- sorted -- so a tile of
 // consecutive parents reads CONSECUTIVE ranges of every array:
 //
-//   stage    fc[j0..j1] (child ranges) and key[j0-W .. j1+W) (the parents a
-//            neighbour can be, raht_prediction_search_range permitting) with
-//            coalesced loads into LDS;
+//   stage    fc[j0..j1] (child ranges), key[j0-W .. j1+W) (the parents a
+//            neighbour can be, raht_prediction_search_range permitting), the
+//            slices' plans, the children's first points / octants and the
+//            encoder's source sums: coalesced loads into LDS, every load of a
+//            phase issued before the first is consumed (clamped indices, not
+//            predicated loads); a hash table over the key window (open
+//            addressing, 16-bit window indices, load <= 0.5);
 //   classify one thread per parent: single-child parents are finished on the
 //            spot (the copy the old prepass kernel made), the others are
 //            appended to the tile's block list;
-//   blocks   8 lanes per block as before (DPP butterflies), but the 18
-//            neighbour searches run in LDS (12 x ~64 cycles, no miss tail);
-//            a neighbour outside the staged window falls back to the global
-//            search (rare: Morton neighbours are index neighbours except
-//            across large octant boundaries).
+//   blocks   8 lanes per block as before (DPP butterflies); the neighbour
+//            look-ups are one or two probes of the LDS table; a neighbour
+//            whose allowed index range leaves the staged window falls back to
+//            the global lower_bound (rare: Morton neighbours are index
+//            neighbours except across large octant boundaries).
 //
-// What is left per block are three dependent global steps: children (keys +
-// first points), then prefix sums || neighbour values, then the stores.
+// What is left per block in global memory: the parent's and the neighbours'
+// values (one round trip) and the stores.  The tile size is a template
+// parameter: levels where almost every parent has a single child (<= 1.125
+// nodes per parent) run kTileTSparse-parent tiles, their work being the
+// per-tile fixed phases.
 //
 // The lossy encoder still needs two passes around the RDOQ resolution
 // (raht_rdoq.hpp), but the second one no longer repeats the search and the
