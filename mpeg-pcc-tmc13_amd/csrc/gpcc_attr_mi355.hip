@@ -23,7 +23,9 @@
 #include <cstdlib>
 #include <dlfcn.h>
 #include <cstring>
+#include <atomic>
 #include <map>
+#include <thread>
 #include <string>
 #include <cmath>
 #include <vector>
@@ -132,6 +134,11 @@ struct gpcc_ctx {
   std::vector<Span> spans;
   std::vector<hipEvent_t> event_pool;
   std::vector<std::pair<const char*, std::pair<double, int>>> times;
+  // device tier of the LoD build / lifting coder: slices of a batch run
+  // concurrently, each on a lane (own stream + workspace); lane 0 is this context
+  std::vector<gpcc_ctx*> lanes;
+  hipEvent_t ev_lanes = nullptr;
+  int lod_grid = 512;  // workgroups of the sub-sampling kernel (fewer while lanes share the device)
 };
 
 namespace {
@@ -1409,6 +1416,11 @@ gpcc_ctx_destroy(gpcc_ctx* ctx)
     return;
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->stream);
+  for (auto* l : ctx->lanes)
+    gpcc_ctx_destroy(l);
+  ctx->lanes.clear();
+  if (ctx->ev_lanes)
+    hipEventDestroy(ctx->ev_lanes);
   for (auto& sp : ctx->spans) {
     hipEventDestroy(sp.a);
     hipEventDestroy(sp.b);
@@ -2036,10 +2048,13 @@ lod_build_core(
           lc.ncell = ncell;
           lod_cell_keys_kernel<<<grid_for(ncell, 256), 256, 0, st>>>(lc);
           // 2 workgroups per CU stay resident (58 KB of LDS each); measured:
-          // the time grows like 1/sqrt(cells in flight), so take them all
-          const int grid = (int)std::min<int64_t>(512, ((int64_t)ncell + 255) / 256);
+          // the time grows like 1/sqrt(cells in flight), so one slice alone takes
+          // them all; concurrent lanes (run_slices) take half each: 5 x 1 M
+          // points, 3-5 lanes: 15.9 / 12.6 / 11.8 / 13.4 ms per 1 M points with
+          // 64 / 128 / 256 / 512 workgroups
+          const int grid = (int)std::min<int64_t>(ctx->lod_grid, ((int64_t)ncell + 255) / 256);
           {
-            Timer tm(ctx, "lod_subsample");
+            Timer tm(ctx, level_name("lod_subsample", lod));
             lod_subsample_distance_kernel<<<std::max(8, (grid + 7) / 8 * 8), 256, 0, st>>>(lc);
           }
         }
@@ -2096,7 +2111,7 @@ lod_build_core(
             lod_atlas_limit_kernel<<<grid_for(n_ret, 256), 256, 0, st>>>(nc, d_atlas_limit);
           }
         {
-          Timer tm(ctx, "lod_nn_search");
+          Timer tm(ctx, level_name("lod_nn_search", lod));
           lod_nn_search_kernel<<<grid_for(n_ref, 256), 256, 0, st>>>(nc);
         }
       }
@@ -2854,6 +2869,104 @@ gpcc_estimate_dist2(
 // the host needs to enqueue the next launch (the sizes of the retained lists).
 namespace {
 
+// The slices of a batch are independent and the LoD build of one slice is a
+// chain of latency-bound launches with a host round trip per level of detail
+// (the size of the retained list), so several slices run CONCURRENTLY: each on
+// a lane -- a context of its own (stream, workspace arena) on the same device,
+// driven by a host thread of its own.  Lane 0 is the caller's context and
+// thread.  GPCC_LOD_LANES sets the number of lanes (default 4, 1 = one slice
+// after the other); with profiling on the slices run in turn so that the
+// per-kernel times stay attributable.
+int
+lod_lanes(gpcc_ctx* ctx, int num_slices)
+{
+  static const int want = [] {
+    const char* e = getenv("GPCC_LOD_LANES");
+    const int v = e ? atoi(e) : 4;
+    return v < 1 ? 1 : (v > 16 ? 16 : v);
+  }();
+  if (ctx->profiling)
+    return 1;
+  return std::min(want, num_slices);
+}
+
+template<class Body>
+int
+run_slices(gpcc_ctx* ctx, int num_slices, Body&& body)
+{
+  const int K = lod_lanes(ctx, num_slices);
+  if (K <= 1) {
+    for (int s = 0; s < num_slices; s++) {
+      const int r = body(ctx, s);
+      if (r)
+        return r;
+    }
+    return GPCC_OK;
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  while ((int)ctx->lanes.size() < K - 1) {
+    gpcc_ctx* l = nullptr;
+    const int r = gpcc_ctx_create(ctx->device, nullptr, &l);
+    if (r)
+      return r;
+    ctx->lanes.push_back(l);
+  }
+  if (!ctx->ev_lanes)
+    HIP_TRY(hipEventCreateWithFlags(&ctx->ev_lanes, hipEventDisableTiming));
+  // the caller's inputs are ordered on the context's stream
+  HIP_TRY(hipEventRecord(ctx->ev_lanes, ctx->stream));
+  for (int w = 1; w < K; w++) {
+    ctx->lanes[w - 1]->morton_bits = ctx->morton_bits;
+    HIP_TRY(hipStreamWaitEvent(ctx->lanes[w - 1]->stream, ctx->ev_lanes, 0));
+  }
+  // the lanes share the device's resident-workgroup slots
+  static const int lane_grid = [] {
+    const char* e = getenv("GPCC_LOD_GRID");
+    return e ? std::max(8, atoi(e)) : 256;
+  }();
+  struct GridGuard {
+    gpcc_ctx* c;
+    int saved;
+    ~GridGuard() { c->lod_grid = saved; }
+  } guard{ctx, ctx->lod_grid};
+  ctx->lod_grid = lane_grid;
+  for (int w = 1; w < K; w++)
+    ctx->lanes[w - 1]->lod_grid = lane_grid;
+  std::atomic<int> next{0};
+  std::vector<int> rc(K, GPCC_OK);
+  std::vector<std::string> msg(K);
+  auto work = [&](int w) {
+    gpcc_ctx* lane = w ? ctx->lanes[w - 1] : ctx;
+    if (hipSetDevice(ctx->device) != hipSuccess) {
+      rc[w] = GPCC_ERR_HIP;
+      msg[w] = "hipSetDevice failed on a lane";
+      return;
+    }
+    for (;;) {
+      const int s = next.fetch_add(1);
+      if (s >= num_slices)
+        break;
+      const int r = body(lane, s);
+      if (r) {
+        rc[w] = r;
+        msg[w] = g_last_error;
+        next.store(num_slices);  // the others stop at their next slice
+        break;
+      }
+    }
+  };
+  std::vector<std::thread> th;
+  for (int w = 1; w < K; w++)
+    th.emplace_back(work, w);
+  work(0);
+  for (auto& t : th)
+    t.join();
+  for (int w = 0; w < K; w++)
+    if (rc[w])
+      return fail(rc[w], msg[w]);
+  return GPCC_OK;
+}
+
 int
 check_slices(gpcc_ctx* ctx, int32_t num_slices, const int64_t* offsets)
 {
@@ -2891,25 +3004,25 @@ dev_lod_build(
     return r;
   if (!d_xyz || !d_count || !d_index || !d_weight || !d_indexes || !num_points_in_lod || !num_lods)
     return fail(GPCC_ERR_INVALID_ARG, "null buffer");
-  hipStream_t st = ctx->stream;
-  for (int s = 0; s < num_slices; s++) {
+  return run_slices(ctx, num_slices, [&](gpcc_ctx* lane, int s) -> int {
+    hipStream_t st = lane->stream;
     const size_t b = (size_t)offsets[s], N = (size_t)(offsets[s + 1] - offsets[s]);
     LodDeviceOut o;
-    r = lod_build_core(ctx, lp, d_xyz + 3 * b, (int32_t)N, 0, &o, true);
+    int r = lod_build_core(lane, lp, d_xyz + 3 * b, (int32_t)N, 0, &o, true);
     if (r)
       return r;
     HIP_TRY(hipMemcpyAsync(d_count + b, o.count, sizeof(int32_t) * N, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_index + 3 * b, o.neigh_index, sizeof(int32_t) * 3 * N, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_weight + 3 * b, o.weight, sizeof(int32_t) * 3 * N, hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_indexes + b, o.indexes, sizeof(int32_t) * N, hipMemcpyDeviceToDevice, st));
-    r = lod_error_word(ctx, o);  // (the arena is reused by the next slice: the copies are done)
+    r = lod_error_word(lane, o);  // (the arena is reused by the lane's next slice: the copies are done)
     if (r)
       return r;
     num_lods[s] = (int)o.npl.size();
     for (size_t i = 0; i < o.npl.size(); i++)
       num_points_in_lod[(size_t)s * GPCC_MAX_LODS + i] = o.npl[i];
-  }
-  return GPCC_OK;
+    return GPCC_OK;
+  });
 }
 
 int
@@ -2923,17 +3036,19 @@ dev_lift_attr(
     return r;
   if (!lift || !d_xyz || !d_attrs || !d_coeffs || c < 1 || c > 3)
     return fail(GPCC_ERR_INVALID_ARG, "null buffer or attribute count not 1..3");
-  hipStream_t st = ctx->stream;
-  for (int s = 0; s < num_slices; s++) {
+  for (int s = 0; s < num_slices; s++)
+    if (c == 3 && lift[s].last_component_prediction_enabled_flag && !lcp)
+      return fail(GPCC_ERR_INVALID_ARG, "lcp_coeffs is null");
+  return run_slices(ctx, num_slices, [&](gpcc_ctx* lane, int s) -> int {
+    hipStream_t st = lane->stream;
+    int r = GPCC_OK;
     gpcc_lift_params* lf = lift + s;
     const bool lcp_on = c == 3 && lf->last_component_prediction_enabled_flag;
-    if (lcp_on && !lcp)
-      return fail(GPCC_ERR_INVALID_ARG, "lcp_coeffs is null");
     const size_t b = (size_t)offsets[s], N = (size_t)(offsets[s + 1] - offsets[s]);
     const int32_t n = (int32_t)N;
     const size_t extra = 512 + lift_scratch_bytes(n, c) + 1024;
     LodDeviceOut o;
-    r = lod_build_core(ctx, lod, d_xyz + 3 * b, n, extra, &o, true);
+    r = lod_build_core(lane, lod, d_xyz + 3 * b, n, extra, &o, true);
     if (r)
       return r;
     lf->num_lods = (int)o.npl.size();
@@ -2942,7 +3057,7 @@ dev_lift_attr(
     r = check_lift_params(lf, n, c);
     if (r)
       return r;
-    Arena ar = ctx->arena;  // carve behind the LoD workspace
+    Arena ar = lane->arena;  // carve behind the LoD workspace
     ar.used = o.arena_end;
     LiftDev d{};
     d.nc = o.count;
@@ -2954,15 +3069,15 @@ dev_lift_attr(
     d.coeffs = d_coeffs + b * c;
     int8_t* d_lcp = ar.take<int8_t>(GPCC_MAX_LODS);
     char* scratch = ar.base + ar.used;
-    if (ar.used + lift_scratch_bytes(n, c) > ctx->arena.cap)
+    if (ar.used + lift_scratch_bytes(n, c) > lane->arena.cap)
       return fail(GPCC_ERR_OUT_OF_MEMORY, "arena reservation too small");
     int8_t* h_lcp = lcp ? lcp + (size_t)s * GPCC_MAX_LODS : nullptr;
     if (!encoder && lcp_on)
       HIP_TRY(hipMemcpyAsync(d_lcp, h_lcp, GPCC_MAX_LODS, hipMemcpyHostToDevice, st));
     switch (c) {
-    case 1: r = launch_lift<1>(ctx, encoder, lf, n, d, d_lcp, scratch); break;
-    case 2: r = launch_lift<2>(ctx, encoder, lf, n, d, d_lcp, scratch); break;
-    default: r = launch_lift<3>(ctx, encoder, lf, n, d, d_lcp, scratch); break;
+    case 1: r = launch_lift<1>(lane, encoder, lf, n, d, d_lcp, scratch); break;
+    case 2: r = launch_lift<2>(lane, encoder, lf, n, d, d_lcp, scratch); break;
+    default: r = launch_lift<3>(lane, encoder, lf, n, d, d_lcp, scratch); break;
     }
     if (r)
       return r;
@@ -2970,11 +3085,11 @@ dev_lift_attr(
       HIP_TRY(hipMemcpyAsync(h_lcp, d_lcp, GPCC_MAX_LODS, hipMemcpyDeviceToHost, st));
     if (d_indexes)
       HIP_TRY(hipMemcpyAsync(d_indexes + b, o.indexes, sizeof(int32_t) * N, hipMemcpyDeviceToDevice, st));
-    r = lod_error_word(ctx, o);
+    r = lod_error_word(lane, o);
     if (r)
       return r;
-  }
-  return GPCC_OK;
+    return GPCC_OK;
+  });
 }
 
 }  // namespace
