@@ -138,7 +138,7 @@ struct gpcc_ctx {
   // concurrently, each on a lane (own stream + workspace); lane 0 is this context
   std::vector<gpcc_ctx*> lanes;
   hipEvent_t ev_lanes = nullptr;
-  int lod_grid = 512;  // workgroups of the sub-sampling kernel (fewer while lanes share the device)
+  int lod_grid = 768;  // workgroups of the sub-sampling kernel (fewer while lanes share the device)
 };
 
 namespace {
@@ -2047,11 +2047,11 @@ lod_build_core(
           HIP_TRY(hipMemsetAsync(d_ticket, 0, sizeof(int32_t) * 8, st));
           lc.ncell = ncell;
           lod_cell_keys_kernel<<<grid_for(ncell, 256), 256, 0, st>>>(lc);
-          // 2 workgroups per CU stay resident (58 KB of LDS each); measured:
-          // the time grows like 1/sqrt(cells in flight), so one slice alone takes
-          // them all; concurrent lanes (run_slices) take half each: 5 x 1 M
-          // points, 3-5 lanes: 15.9 / 12.6 / 11.8 / 13.4 ms per 1 M points with
-          // 64 / 128 / 256 / 512 workgroups
+          // 3 workgroups per CU stay resident (168 registers, no LDS).  One slice
+          // alone takes them all (1 M dense points, the level with the most cells:
+          // 6.4 / 4.5 / 3.85 / 3.8 ms with 256 / 512 / 768 / 1 024 workgroups);
+          // concurrent lanes (run_slices) take 256 each (5 x 1 M points: 9.5-10 ms
+          // per 1 M points from 192 to 768)
           const int grid = (int)std::min<int64_t>(ctx->lod_grid, ((int64_t)ncell + 255) / 256);
           {
             Timer tm(ctx, level_name("lod_subsample", lod));

@@ -291,8 +291,15 @@ lod_cell_keys_kernel(LodCtx cx)
 // publishes ONE 16-byte write-through granule {x, y, z, tag} (tag = epoch
 // and "a point was retained"); consumers poll the granules of their
 // neighbours directly -- the data is the flag (cdna_hip_programming.md G16,
-// form R2), one memory round trip per dependency hop.
-__global__ __launch_bounds__(256, 2) void
+// form R2), one memory round trip per dependency hop.  The hop is one
+// ITERATION of the polling loop, so the loop body is what counts: an arriving
+// neighbour is folded into a bit mask of eliminated points at once and nothing
+// else is kept of it (no per-lane neighbour lists in LDS; 168 registers, three
+// waves per SIMD -- at four the prologue's 19 lock-step bisections spill).
+#ifndef GPCC_LOD_SUB_WAVES
+#define GPCC_LOD_SUB_WAVES 3
+#endif
+__global__ __launch_bounds__(256, GPCC_LOD_SUB_WAVES) void
 lod_subsample_distance_kernel(LodCtx cx)
 {
   constexpr uint8_t kOff[19] = {3, 5, 6, 12, 10, 17, 20, 34, 33, 4,
@@ -303,10 +310,6 @@ lod_subsample_distance_kernel(LodCtx cx)
     cx.cell_state, 0, (int)(((size_t)cx.ncell + 1) * 16), 0x00020000);
   const uint32_t tag_none = (uint32_t)cx.epoch << 1, tag_has = tag_none | 1;
   constexpr int kCellCache = 8;
-  // retained points of the 19 neighbour cells of every lane, [k][axis][lane]
-  // (lane-strided: conflict-free; an owner's row is a broadcast read)
-  __shared__ int32_t nbr_s[4][19 * 3][64];
-  int32_t (*nbr)[64] = nbr_s[threadIdx.x >> 6];
   // cell edge 2^(shift3/3): neighbour points are < 2 edges away per axis
   const bool small = cx.shift3 <= 3 * 13;
   for (;;) {
@@ -382,13 +385,12 @@ lod_subsample_distance_kernel(LodCtx cx)
     }
 
     // the cell's first points, fetched while the neighbours are pending
-    int32_t cpx[kCellCache], cpy[kCellCache], cpz[kCellCache], cidx[kCellCache];
+    int32_t cpx[kCellCache], cpy[kCellCache], cpz[kCellCache];
 #pragma unroll
     for (int u = 0; u < kCellCache; u++) {
-      cpx[u] = cpy[u] = cpz[u] = cidx[u] = 0;
+      cpx[u] = cpy[u] = cpz[u] = 0;
       if (t0 + u < t1) {
         const int idx = cx.input[t0 + u];
-        cidx[u] = idx;
         cpx[u] = cx.pos[3 * (size_t)idx];
         cpy[u] = cx.pos[3 * (size_t)idx + 1];
         cpz[u] = cx.pos[3 * (size_t)idx + 2];
@@ -436,82 +438,87 @@ lod_subsample_distance_kernel(LodCtx cx)
           pend &= ~(1u << k);
       }
     }
-    int ucur = 0;  // small cells: first point not yet decided
-    int nr = 0;  // retained neighbour points received so far (rows of nbr)
+    // ---- the wait.  What an arriving neighbour can change is which of the
+    //      cell's first points lie within the radius of a retained point: one
+    //      bit per cached point (`elim`), set when the neighbour ARRIVES (eight
+    //      distance tests, once), so the per-iteration decision is a few bit
+    //      operations: the first point not eliminated is retained as soon as no
+    //      cell that can reach it is still out.  The neighbours' points are not
+    //      kept (a cell with more than kCellCache points re-reads the granules
+    //      of its neighbours when it scans the rest: they have all arrived).
+    const int ncache = live ? (t1 - t0 < kCellCache ? t1 - t0 : kCellCache) : 0;
+    const uint32_t valid = (1u << ncache) - 1;
+    uint32_t elim = 0;
+    uint32_t hasmask = 0;  // neighbours that arrived with a retained point
     bool pending = live;
     unsigned spins = 0;
     while (__any(pending)) {
-      // poll every pending neighbour; the loads of a pass are issued
-      // together BEFORE any result is looked at (a loop that tests each
-      // result before issuing the next load costs one round trip per
-      // neighbour)
-      {
-        const uint32_t todo = pend;
-        u32x4 vv[19];
+      // poll every pending neighbour; the loads of a batch are issued together
+      // BEFORE any result is looked at (two batches bound the live registers)
+      const uint32_t todo = pending ? pend : 0;
 #pragma unroll
-        for (int k = 0; k < 19; k++) {
-          vv[k] = u32x4{0, 0, 0, 0};
-          if ((todo >> k) & 1)
-            vv[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lo[k] * 16, 0, /*sc1*/ 16);
+      for (int k0 = 0; k0 < 19; k0 += 10) {
+        u32x4 vv[10];
+#pragma unroll
+        for (int q = 0; q < 10; q++) {
+          const int k = k0 + q;
+          vv[q] = u32x4{0, 0, 0, 0};
+          if (k < 19 && ((todo >> k) & 1))
+            vv[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lo[k] * 16, 0, /*sc1*/ 16);
         }
 #pragma unroll
-        for (int k = 0; k < 19; k++) {
-          if (((todo >> k) & 1) && (vv[k].w >> 1) == (uint32_t)cx.epoch) {
-            if (vv[k].w & 1) {
-              nbr[3 * nr][lane] = (int32_t)vv[k].x;
-              nbr[3 * nr + 1][lane] = (int32_t)vv[k].y;
-              nbr[3 * nr + 2][lane] = (int32_t)vv[k].z;
-              nr++;
-            }
+        for (int q = 0; q < 10; q++) {
+          const int k = k0 + q;
+          if (k < 19 && ((todo >> k) & 1) && (vv[q].w >> 1) == (uint32_t)cx.epoch) {
             pend &= ~(1u << k);
+            if (vv[q].w & 1) {
+              hasmask |= 1u << k;
+              const int32_t nx = (int32_t)vv[q].x, ny = (int32_t)vv[q].y, nz = (int32_t)vv[q].z;
+#pragma unroll
+              for (int u = 0; u < kCellCache; u++) {
+                bool in;
+                if (small) {
+                  // neighbours lie in adjacent cells: |d| < 2^14, squares fit 32 bits
+                  const int32_t dx = nx - cpx[u], dy = ny - cpy[u], dz = nz - cpz[u];
+                  in = (int64_t)(dx * dx + dy * dy + dz * dz) <= cx.radius2;
+                } else {
+                  const int64_t dx = (int64_t)nx - cpx[u], dy = (int64_t)ny - cpy[u],
+                                dz = (int64_t)nz - cpz[u];
+                  in = dx * dx + dy * dy + dz * dz <= cx.radius2;
+                }
+                elim |= (uint32_t)in << u;
+              }
+            }
           }
         }
       }
       // ---- decide as far as the arrived neighbours allow -----------------
       int kept = -1;
       int32_t kp[3] = {0, 0, 0};
-      bool decided = false;
-      auto eliminated = [&](int32_t px, int32_t py, int32_t pz) -> bool {
-        bool found = false;
-        if (small) {
-          // neighbours lie in adjacent cells: |d| < 2^14, squares fit 32 bits
-          for (int q = 0; q < nr && !found; q++) {
-            const int32_t dx = nbr[3 * q][lane] - px, dy = nbr[3 * q + 1][lane] - py,
-                          dz = nbr[3 * q + 2][lane] - pz;
-            found = (int64_t)(dx * dx + dy * dy + dz * dz) <= cx.radius2;
-          }
-        } else {
-          for (int q = 0; q < nr && !found; q++) {
-            const int64_t dx = (int64_t)nbr[3 * q][lane] - px, dy = (int64_t)nbr[3 * q + 1][lane] - py,
-                          dz = (int64_t)nbr[3 * q + 2][lane] - pz;
-            found = dx * dx + dy * dy + dz * dz <= cx.radius2;
-          }
-        }
-        return found;
-      };
-      if (pending && small_cell) {
-        bool blocked = false;
+      int kt = 0;
+      bool ready = false, scan = false;
+      if (pending) {
+        const uint32_t cand = ~elim & valid;
+        if (small_cell) {
+          uint32_t blockmask = 0;
 #pragma unroll
-        for (int u = 0; u < kCellCache; u++) {
-          if (decided || blocked || u != ucur || t0 + u >= t1)
-            continue;
-          if (rm[u] & pend) {
-            blocked = true;  // a cell that can reach this point is still out
-          } else if (!eliminated(cpx[u], cpy[u], cpz[u])) {
-            kept = cidx[u];
-            kp[0] = cpx[u];
-            kp[1] = cpy[u];
-            kp[2] = cpz[u];
-            cx.flags[t0 + u] = 1;
-            decided = true;
+          for (int u = 0; u < kCellCache; u++)
+            blockmask |= (uint32_t)((rm[u] & pend) != 0) << u;
+          if (!cand) {
+            ready = true;  // every point eliminated: nothing retained
           } else {
-            ucur++;
+            const int u1 = __ffs((int)cand) - 1;
+            ready = !((blockmask >> u1) & 1);
+            kept = ready ? u1 : -1;
           }
+        } else if (pend == 0) {
+          ready = true;
+          if (cand)
+            kept = __ffs((int)cand) - 1;
+          else
+            scan = true;  // the first points are eliminated: the rest of the cell
         }
-        if (!decided && !blocked && t0 + ucur >= t1)
-          decided = true;  // every point eliminated: nothing retained
       }
-      const bool ready = pending && (small_cell ? decided : pend == 0);
       if (!__any(ready)) {
         if (++spins > (1u << 20)) {
           if (lane == 0)
@@ -521,31 +528,39 @@ lod_subsample_distance_kernel(LodCtx cx)
         __builtin_amdgcn_s_sleep(1);
         continue;
       }
-      if (ready && !small_cell) {
-        // the first points of the cell were fetched before the wait
+      if (kept >= 0) {
+        // the cached point `kept` (select chain: register arrays take no dynamic index)
 #pragma unroll
-        for (int u = 0; u < kCellCache; u++) {
-          if (kept >= 0 || t0 + u >= t1)
-            continue;
-          if (!eliminated(cpx[u], cpy[u], cpz[u])) {
-            kept = cidx[u];
+        for (int u = 0; u < kCellCache; u++)
+          if (u == kept) {
             kp[0] = cpx[u];
             kp[1] = cpy[u];
             kp[2] = cpz[u];
-            cx.flags[t0 + u] = 1;
           }
-        }
+        kt = t0 + kept;
+        cx.flags[kt] = 1;
       }
-      // cells with more points: the whole wavefront scans 64 points per
-      // round trip for one such cell at a time (the scan sits on the
-      // dependency chain of every later cell)
+      // cells with more points: the whole wavefront scans 64 points per round
+      // trip for one such cell at a time (the scan sits on the dependency
+      // chain of every later cell)
       for (;;) {
-        const unsigned long long big = __ballot(ready && kept < 0 && t0 + kCellCache < t1);
+        const unsigned long long big = __ballot(scan);
         if (!big)
           break;
         const int owner = __ffsll((long long)big) - 1;
+        // lane k < 19 fetches the retained point of the owner's neighbour k
+        const uint32_t o_has = __shfl(hasmask, owner);
+        int o_lo = 0;
+#pragma unroll
+        for (int k = 0; k < 19; k++) {
+          const int v = __shfl(lo[k], owner);
+          if (lane == k)
+            o_lo = v;
+        }
+        u32x4 g = u32x4{0, 0, 0, 0};
+        if (lane < 19 && ((o_has >> lane) & 1))
+          g = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o_lo * 16, 0, /*sc1*/ 16);
         const int o_t1 = __shfl(t1, owner);
-        const int o_nr = __shfl(nr, owner);
         int o_kept = -1, o_t = 0;
         int32_t okp[3] = {0, 0, 0};
         for (int tb = __shfl(t0, owner) + kCellCache; tb < o_t1 && o_kept < 0; tb += 64) {
@@ -558,14 +573,16 @@ lod_subsample_distance_kernel(LodCtx cx)
             px = cx.pos[3 * (size_t)idx];
             py = cx.pos[3 * (size_t)idx + 1];
             pz = cx.pos[3 * (size_t)idx + 2];
-            bool found = false;
-            for (int q = 0; q < o_nr && !found; q++) {
-              const int64_t dx = (int64_t)nbr[3 * q][owner] - px, dy = (int64_t)nbr[3 * q + 1][owner] - py,
-                            dz = (int64_t)nbr[3 * q + 2][owner] - pz;
-              found = dx * dx + dy * dy + dz * dz <= cx.radius2;
-            }
-            cand = !found;
           }
+          bool found = false;
+#pragma unroll
+          for (int k = 0; k < 19; k++) {
+            const int64_t dx = (int64_t)(int32_t)__shfl((int)g.x, k) - px,
+                          dy = (int64_t)(int32_t)__shfl((int)g.y, k) - py,
+                          dz = (int64_t)(int32_t)__shfl((int)g.z, k) - pz;
+            found |= ((o_has >> k) & 1) && dx * dx + dy * dy + dz * dz <= cx.radius2;
+          }
+          cand = t < o_t1 && !found;
           const unsigned long long m = __ballot(cand);
           if (m) {
             const int first = __ffsll((long long)m) - 1;
@@ -577,14 +594,13 @@ lod_subsample_distance_kernel(LodCtx cx)
           }
         }
         if (lane == owner) {
+          scan = false;
           if (o_kept >= 0) {
             kept = o_kept;
             kp[0] = okp[0];
             kp[1] = okp[1];
             kp[2] = okp[2];
             cx.flags[o_t] = 1;
-          } else {
-            t1 = t0;  // nothing retained: leave the loop
           }
         }
       }
