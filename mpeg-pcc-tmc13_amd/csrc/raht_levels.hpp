@@ -264,28 +264,44 @@ rate_log_small(int64_t aq)
 __device__ __forceinline__ uint32_t
 rdoq_threshold(int64_t dist2, int64_t lambda, int rate_coeff, uint32_t limit)
 {
-  const int64_t d = (int64_t)((uint64_t)dist2 << 26);
+  // Every class test is  d < lambda * (rate + rc)  with integers, i.e.
+  // floor(d / lambda) < rate + rc: ONE exact quotient q decides them all (the
+  // literal form walked up to 37 classes, a 64-bit multiply each, and sat on
+  // the dependency chain of the sub-node encoder).  q is capped where no
+  // class is left; below the cap d < 2^57, the double quotient is within one
+  // of the truth and two integer checks make it exact.
+  const uint64_t d = (uint64_t)dist2 << 26;
+  const uint64_t lam = (uint64_t)lambda;
   const int rc = (rate_coeff + 128) >> 8;
-  // (rate of the class, first trainZeros of the class) -- literal, no table
-#define GPCC_RDOQ_CLASS(rate, tz) \
-  if (d < lambda * ((rate) + rc))  \
-    return (tz);
-  GPCC_RDOQ_CLASS(1, 0)
-  GPCC_RDOQ_CLASS(2, 1)
-  GPCC_RDOQ_CLASS(3, 2)
-  GPCC_RDOQ_CLASS(5, 3)
-  GPCC_RDOQ_CLASS(7, 5)
-  GPCC_RDOQ_CLASS(9, 7)
-  GPCC_RDOQ_CLASS(11, 9)
-#undef GPCC_RDOQ_CLASS
-  for (int b = 1; b < 31; b++) {
-    const uint32_t tz = 10u + (1u << (b - 1));
-    if (tz > limit)
-      break;
-    if (d < lambda * (12 + 2 * b + rc))
-      return tz;
+  constexpr uint64_t kCap = 128;  // > 12 + 2 * 30 + rc for every rc the LUT can give (<= 12)
+  uint64_t q = kCap;
+  if (d < lam * kCap) {
+    q = (uint64_t)((double)d / (double)lam);
+    q -= q * lam > d;
+    q += (q + 1) * lam <= d;
   }
-  return kDescNever;
+  const int m = (int)q - rc + 1;  // smallest rate that passes
+  if (m <= 1)
+    return 0;
+  if (m <= 2)
+    return 1;
+  if (m <= 3)
+    return 2;
+  if (m <= 5)
+    return 3;
+  if (m <= 7)
+    return 5;
+  if (m <= 9)
+    return 7;
+  if (m <= 11)
+    return 9;
+  // rate 12 + 2 b for trainZeros in [10 + 2^(b-1), 10 + 2^b), b = 1 .. 30
+  int bb = (m - 12 + 1) >> 1;
+  bb = bb < 1 ? 1 : bb;
+  if (bb > 30)
+    return kDescNever;
+  const uint32_t tz = 10u + (1u << (bb - 1));
+  return tz > limit ? kDescNever : tz;
 }
 
 // Pre-pass of a level, ONE THREAD PER PARENT (64 blocks in flight per
