@@ -401,6 +401,21 @@ raht_level_sub_kernel(LevelCtx ctx)
       }
       qpset_quantizers(prm, e.qp_layer, nq0 + ac0, nq1 + ac1, qa);
     }
+    // the two normalisers of this position, settled before the wait (they
+    // depend on the weight alone; on the chain they were a table look-up or
+    // an irsqrt evaluation per hop): sqrt(w) for the prediction, the
+    // (shift, 1/sqrt(w)) pair of scale_rsqrt for the reconstruction
+    int32_t nrm_sq = 0, nrm_rs = 0, nrm_shift = 0;
+    if (!haar && w > 1) {
+      nrm_sq = (int32_t)sqrt_weight(w, lut);
+      if (w < kSmallN) {
+        nrm_rs = lut.norm_rs[w];
+      } else {
+        const uint64_t w64 = (uint64_t)w;
+        nrm_shift = w64 > 1024 ? ilog2_u64(w64 - 1) >> 1 : 0;
+        nrm_rs = (int32_t)(irsqrt(w64, lut.rsqrt) >> (40 - nrm_shift - kFpFrac));
+      }
+    }
     if (kEnc) {
       // forward butterflies of the source (normalised first unless Haar)
       if (!haar && w > 1) {
@@ -712,10 +727,9 @@ raht_level_sub_kernel(LevelCtx ctx)
           }
         }
         if (!haar && w > 1 && enable_pred) {
-          const int64_t sq = sqrt_weight(w, lut);
 #pragma unroll
           for (int k = 0; k < C; k++)
-            pw_[k] = fp_mul_c(pw_[k], sq);
+            pw_[k] = fp_mul_c(pw_[k], (int64_t)nrm_sq);
         }
 #pragma unroll
         for (int st = 0; st < 3; st++) {
@@ -1026,7 +1040,7 @@ raht_level_sub_kernel(LevelCtx ctx)
           for (int k = 0; k < C; k++) {
             int64_t v = pw_[k];
             if (!haar && w > 1)
-              v = scale_rsqrt(v, w, lut);
+              v = fp_mul_c(v >> nrm_shift, (int64_t)nrm_rs);
             v = ext ? v : fp_round(v);
             vn[k] = v;
             pt[k] = v;  // read by later groups of this wavefront once stage == 3
