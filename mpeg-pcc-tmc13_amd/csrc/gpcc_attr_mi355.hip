@@ -25,6 +25,7 @@
 #include <cstring>
 #include <atomic>
 #include <map>
+#include <mutex>
 #include <thread>
 #include <string>
 #include <cmath>
@@ -157,6 +158,8 @@ level_name(const char* base, int li)
     return base;
   char buf[96];
   snprintf(buf, sizeof buf, "%s@%02d", base, li);
+  static std::mutex mu;  // lanes of the device tier call this from their own threads
+  std::lock_guard<std::mutex> lock(mu);
   auto it = pool.emplace(buf, buf).first;
   return it->second.c_str();
 }
