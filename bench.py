@@ -315,6 +315,7 @@ def main():
             out["raht_forward_10M"] = forward_10m(torch, dev, ctx, params_for, frames)
             out["hbm_calibration"] = hbm_calibration(torch, dev)
             out["lifting"] = lifting_leg(ctx, args)
+            out["predicting"] = predicting_leg(ctx, args)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames[0], p, c)
 
@@ -518,6 +519,63 @@ def lifting_leg(ctx, args, torch=None, dev=None):
                                 "sample": f"AttributeLods::generate on slice 0 ({len(xyz0)} points), {t_ref:.2f} s "
                                           "(needed once by the encoder and once by the decoder)",
                                 "gpu_result_identical": bool(same)}
+    return res
+
+
+def predicting_leg(ctx, args):
+    """The other half of BASELINE configs[2]: the PREDICTING transform of a
+    1M-point dense colour slice, CTC tools (three direct predictors, inter-
+    component prediction, intra-LoD prediction, quantNeighWeight 16/8/4) --
+    the decoder (gpcc_pred_inverse: every tool on the device) and the encoder
+    without direct predictors (gpcc_pred_forward).  Host tier: the timings are
+    the kernels' (HIP events), the CPU figure is the same loop of the oracle
+    (pinned to the reference at symbol level) on one core."""
+    from mpeg_pcc_tmc13_amd import lod_params, pred_params, synth
+    n = min(args.points, 1_000_000)
+    xyz, attrs = synth.dense_cloud(n, seed=41, bits=10 if n >= 500_000 else 8)
+    n = len(xyz)
+    lp = lod_params(levels=12, lifting=False, intra_range=1100000, blend=True)
+    lp.intra_lod_prediction_skip_layers = 0
+    lod = ctx.lod_build(lp, xyz)
+    qnw = (16, 8, 4)
+    pp = pred_params(lod["npl"], qp=28, bitdepth=8, max_levels=12, quant_neigh_weight=qnw)
+    pp0 = pred_params(lod["npl"], qp=28, bitdepth=8, max_levels=12, quant_neigh_weight=qnw, direct=0)
+    res = {"workload": f"predicting transform, {n}-point S-dense colour slice, {len(lod['npl'])} LoDs, intra-LoD "
+                       "prediction, 3 direct predictors (decoder) / none (encoder), ICP, qp 28 (host tier, kernel times)"}
+    values = icp = want = None
+    if not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import lod_helpers as lh
+        t0 = time.perf_counter()
+        values, want, icp, modes = lh.oracle_pred(True, pp, lod, attrs=attrs)
+        t_enc = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        lh.oracle_pred(False, pp, lod, values=values, icp=icp)
+        t_dec = time.perf_counter() - t0
+        res["cpu_port"] = {"encode_ms": round(t_enc * 1e3, 1), "decode_ms": round(t_dec * 1e3, 1), "cores": 1,
+                           "kind": "port", "direct_modes_chosen": int((modes > 0).sum())}
+    # encoder without direct predictors, then the decoder on its symbols
+    ctx.pred_forward(pp0, lod["nc"], lod["ni"], lod["w"], lod["indexes"], attrs)  # warm-up
+    ctx.set_profiling(True)
+    ctx.kernel_times()
+    v0, rec0, icp0 = ctx.pred_forward(pp0, lod["nc"], lod["ni"], lod["w"], lod["indexes"], attrs)
+    kt_e = {k: v[0] for k, v in ctx.kernel_times().items() if k.startswith("pred")}
+    dec0 = ctx.pred_inverse(pp0, lod["nc"], lod["ni"], lod["w"], lod["indexes"], v0, icp=icp0)
+    kt_d = {k: v[0] for k, v in ctx.kernel_times().items() if k.startswith("pred")}
+    ok = bool(np.array_equal(dec0, rec0))
+    if values is not None:
+        # the CTC stream (direct predictors chosen by the reference's serial mode decision): decoder only
+        got = ctx.pred_inverse(pp, lod["nc"], lod["ni"], lod["w"], lod["indexes"], values, icp=icp)
+        kt_d = {k: v[0] for k, v in ctx.kernel_times().items() if k.startswith("pred")}
+        ok = ok and bool(np.array_equal(got, want))
+    ctx.set_profiling(False)
+    c = 3
+    res.update({"encode_kernels_ms": {k: round(v, 3) for k, v in kt_e.items()},
+                "decode_kernels_ms": {k: round(v, 3) for k, v in kt_d.items()},
+                "decode_value": round(n / (sum(kt_d.values()) / 1e3) / 1e6, 1), "unit": "Mpoints/s (kernels)",
+                "algorithmic_bytes_per_point": {"decode": 28 + 8 * c, "encode": 28 + 12 * c},
+                "decode_achieved_GBps": round((28 + 8 * c) * n / (sum(kt_d.values()) / 1e3) / 1e9, 2),
+                "results_identical": ok})
     return res
 
 
