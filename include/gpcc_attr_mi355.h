@@ -515,6 +515,23 @@ int gpcc_dev_lift_decode_attr(
   int32_t num_slices, const int64_t* offsets, const void* d_xyz, void* d_attrs,
   const void* d_coeffs, const int8_t* lcp_coeffs, void* d_indexes, int32_t c);
 
+/* gpcc_dev_pred_encode_attr / _decode_attr: gpcc_pred_encode_attr /
+ * gpcc_pred_decode_attr for every slice of a batch resident in HBM (slices
+ * concurrent on the context's lanes, as for the lifting coder).
+ *   pred   [num_slices] parameter blocks (in: tools, QP; out: the LoD structure)
+ *   d_attrs [N][c] point order; d_values [N][c] coding order per slice
+ *   icp_coeffs host [num_slices][GPCC_MAX_LODS][3] (c == 3 and the flag set)
+ *   d_indexes [N] out, may be NULL.  The encoder declines direct predictors
+ *   (GPCC_ERR_UNSUPPORTED), see gpcc_pred_forward. */
+int gpcc_dev_pred_encode_attr(
+  gpcc_ctx* ctx, const gpcc_lod_params* lod, gpcc_pred_params* pred,
+  int32_t num_slices, const int64_t* offsets, const void* d_xyz, void* d_attrs,
+  void* d_values, int8_t* icp_coeffs, void* d_indexes, int32_t c);
+int gpcc_dev_pred_decode_attr(
+  gpcc_ctx* ctx, const gpcc_lod_params* lod, gpcc_pred_params* pred,
+  int32_t num_slices, const int64_t* offsets, const void* d_xyz, void* d_attrs,
+  const void* d_values, const int8_t* icp_coeffs, void* d_indexes, int32_t c);
+
 /* ------------------------------------------------------------------ */
 /* several GPUs from one host process                                   */
 /* Slices are the reference's independent units (tmc3/encoder.cpp:544-571): a

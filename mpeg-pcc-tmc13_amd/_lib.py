@@ -23,6 +23,7 @@ ABI_SYMBOLS = [
     "gpcc_multi_create", "gpcc_multi_destroy", "gpcc_multi_num_devices", "gpcc_multi_uses_rccl",
     "gpcc_multi_raht_forward", "gpcc_multi_raht_inverse", "gpcc_binarise_symbols",
     "gpcc_pred_forward", "gpcc_pred_inverse", "gpcc_pred_encode_attr", "gpcc_pred_decode_attr",
+    "gpcc_dev_pred_encode_attr", "gpcc_dev_pred_decode_attr",
 ]
 
 
@@ -90,6 +91,8 @@ def load():
         getattr(lib, name).argtypes = [vp, C.POINTER(PredParams), i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     for name in ("gpcc_pred_encode_attr", "gpcc_pred_decode_attr"):
         getattr(lib, name).argtypes = [vp, C.POINTER(LodParams), C.POINTER(PredParams), vp, vp, vp, vp, vp, i32, i32]
+    for name in ("gpcc_dev_pred_encode_attr", "gpcc_dev_pred_decode_attr"):
+        getattr(lib, name).argtypes = [vp, C.POINTER(LodParams), vp, i32, i64p, vp, vp, vp, vp, vp, i32]
     lib.gpcc_lod_compute_weights.argtypes = [vp, i32, vp, vp, vp]
     lib.gpcc_lod_build.argtypes = [vp, C.POINTER(LodParams), vp, i32, vp, vp, vp, vp, vp, C.POINTER(i32)]
     for name in ("gpcc_raht_encode_attr", "gpcc_raht_decode_attr"):

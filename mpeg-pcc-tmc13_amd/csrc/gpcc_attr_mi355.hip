@@ -3095,6 +3095,72 @@ dev_lift_attr(
   });
 }
 
+int
+dev_pred_attr(
+  gpcc_ctx* ctx, bool encoder, const gpcc_lod_params* lod, gpcc_pred_params* pred,
+  int32_t num_slices, const int64_t* offsets, const int32_t* d_xyz, int32_t* d_attrs,
+  int32_t* d_values, int8_t* icp, int32_t* d_indexes, int32_t c)
+{
+  int r = check_slices(ctx, num_slices, offsets);
+  if (r)
+    return r;
+  if (!pred || !d_xyz || !d_attrs || !d_values || (c != 1 && c != 3))
+    return fail(GPCC_ERR_INVALID_ARG, "null buffer or attribute count not 1 / 3");
+  for (int s = 0; s < num_slices; s++) {
+    if (encoder && pred[s].max_num_direct_predictors)
+      return check_pred_params(pred + s, 1, c, true);  // unsupported, before any work
+    if (c == 3 && pred[s].inter_component_prediction_enabled_flag && !icp)
+      return fail(GPCC_ERR_INVALID_ARG, "icp_coeffs is null");
+  }
+  return run_slices(ctx, num_slices, [&](gpcc_ctx* lane, int s) -> int {
+    hipStream_t st = lane->stream;
+    gpcc_pred_params* pp = pred + s;
+    const bool icp_on = c == 3 && pp->inter_component_prediction_enabled_flag;
+    const size_t b = (size_t)offsets[s], N = (size_t)(offsets[s + 1] - offsets[s]);
+    const int32_t n = (int32_t)N;
+    const size_t extra = 1024 + pred_scratch_bytes(n) + 1024;
+    LodDeviceOut o;
+    int r = lod_build_core(lane, lod, d_xyz + 3 * b, n, extra, &o, true);
+    if (r)
+      return r;
+    pp->num_lods = (int)o.npl.size();
+    for (size_t i = 0; i < o.npl.size(); i++)
+      pp->num_points_in_lod[i] = o.npl[i];
+    r = check_pred_params(pp, n, c, encoder);
+    if (r)
+      return r;
+    Arena ar = lane->arena;  // carve behind the LoD workspace
+    ar.used = o.arena_end;
+    PredDev d{};
+    d.nc = o.count;
+    d.ni = o.neigh_index;
+    d.nw = o.weight;
+    d.indexes = o.indexes;
+    d.qp_off = nullptr;
+    d.attrs = d_attrs + b * c;  // the caller's buffers, in place
+    d.values = d_values + b * c;
+    int8_t* d_icp = ar.take<int8_t>(GPCC_MAX_LODS * 3);
+    char* scratch = ar.base + ar.used;
+    if (ar.used + pred_scratch_bytes(n) > lane->arena.cap)
+      return fail(GPCC_ERR_OUT_OF_MEMORY, "arena reservation too small");
+    int8_t* h_icp = icp ? icp + (size_t)s * GPCC_MAX_LODS * 3 : nullptr;
+    if (!encoder && icp_on)
+      HIP_TRY(hipMemcpyAsync(d_icp, h_icp, GPCC_MAX_LODS * 3, hipMemcpyHostToDevice, st));
+    r = c == 1 ? launch_pred<1>(lane, encoder, pp, n, d, d_icp, scratch)
+               : launch_pred<3>(lane, encoder, pp, n, d, d_icp, scratch);
+    if (r)
+      return r;
+    if (encoder && icp_on)
+      HIP_TRY(hipMemcpyAsync(h_icp, d_icp, GPCC_MAX_LODS * 3, hipMemcpyDeviceToHost, st));
+    if (d_indexes)
+      HIP_TRY(hipMemcpyAsync(d_indexes + b, o.indexes, sizeof(int32_t) * N, hipMemcpyDeviceToDevice, st));
+    r = lod_error_word(lane, o);
+    if (r)
+      return r;
+    return pred_check_error(lane);
+  });
+}
+
 }  // namespace
 
 extern "C" {
@@ -3139,6 +3205,35 @@ gpcc_dev_lift_decode_attr(
     dev_lift_attr(
       ctx, false, lod, lift, num_slices, offsets, (const int32_t*)d_xyz, (int32_t*)d_attrs,
       (int32_t*)const_cast<void*>(d_coeffs), const_cast<int8_t*>(lcp_coeffs),
+      (int32_t*)d_indexes, c),
+    offsets && num_slices > 0 ? offsets[num_slices] : 0);
+}
+
+int
+gpcc_dev_pred_encode_attr(
+  gpcc_ctx* ctx, const gpcc_lod_params* lod, gpcc_pred_params* pred, int32_t num_slices,
+  const int64_t* offsets, const void* d_xyz, void* d_attrs, void* d_values,
+  int8_t* icp_coeffs, void* d_indexes, int32_t c)
+{
+  return counted(
+    ctx,
+    dev_pred_attr(
+      ctx, true, lod, pred, num_slices, offsets, (const int32_t*)d_xyz, (int32_t*)d_attrs,
+      (int32_t*)d_values, icp_coeffs, (int32_t*)d_indexes, c),
+    offsets && num_slices > 0 ? offsets[num_slices] : 0);
+}
+
+int
+gpcc_dev_pred_decode_attr(
+  gpcc_ctx* ctx, const gpcc_lod_params* lod, gpcc_pred_params* pred, int32_t num_slices,
+  const int64_t* offsets, const void* d_xyz, void* d_attrs, const void* d_values,
+  const int8_t* icp_coeffs, void* d_indexes, int32_t c)
+{
+  return counted(
+    ctx,
+    dev_pred_attr(
+      ctx, false, lod, pred, num_slices, offsets, (const int32_t*)d_xyz, (int32_t*)d_attrs,
+      (int32_t*)const_cast<void*>(d_values), const_cast<int8_t*>(icp_coeffs),
       (int32_t*)d_indexes, c),
     offsets && num_slices > 0 ? offsets[num_slices] : 0);
 }

@@ -338,6 +338,22 @@ class Context:
                                                           C.byref(tr), n, c, bitdepth))
         return runs[:m.value].copy(), vals[:m.value * c].reshape(m.value, c).copy(), tr.value, a
 
+    def dev_pred_attr(self, encode, lod_params, pred_params_list, offsets, d_xyz, d_attrs, d_values, c, icp=None,
+                      d_indexes=None):
+        """gpcc_dev_pred_encode_attr / _decode_attr on device buffers; pred_params_list: one
+        PredParams per slice (filled with the LoD structure); -> icp int8 [slices, 32, 3]"""
+        from .params import PredParams
+        offs = np.ascontiguousarray(offsets, dtype=np.int64)
+        s = len(offs) - 1
+        arr = (PredParams * s)(*pred_params_list)
+        l = np.zeros((s, 32, 3), dtype=np.int8) if icp is None else np.ascontiguousarray(icp, dtype=np.int8).copy()
+        f = self._lib.gpcc_dev_pred_encode_attr if encode else self._lib.gpcc_dev_pred_decode_attr
+        _lib.check(f(self._h, C.byref(lod_params), C.cast(arr, C.c_void_p), s,
+                     offs.ctypes.data_as(C.POINTER(C.c_int64)), d_xyz, d_attrs, d_values, l.ctypes.data, d_indexes, c))
+        for i in range(s):
+            C.memmove(C.byref(pred_params_list[i]), C.byref(arr[i]), C.sizeof(PredParams))
+        return l
+
     def binarise_symbols(self, runs, values, trailing_run, c):
         """gpcc_binarise_symbols -> uint8 array of (context << 1 | bin) decisions"""
         runs = np.ascontiguousarray(runs, dtype=np.int32)
