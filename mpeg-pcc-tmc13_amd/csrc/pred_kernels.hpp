@@ -186,8 +186,9 @@ pred_quant_weights_body(const PredCtx& cx)
         for (int j = 0; j < 3; j++) {
           if (j >= cnt)
             continue;
-          unsigned long long share =
-            (unsigned long long)div_exp2_round_half_inf((int64_t)cx.qnw[j] * (int64_t)w, 8);
+          // int32 * uint64 -> uint64 in the reference: the unsigned overload of
+          // divExp2RoundHalfInf (PCCMath.h:678-685), modular product, logical shift
+          unsigned long long share = ((unsigned long long)(long long)cx.qnw[j] * w + 128ull) >> 8;
           if (!kWide)
             share += kOne;
           if (tl[j] < 64)

@@ -39,8 +39,11 @@ oracle_pred_quant_weights(
     qw[i] = 1u << 8;
   for (int i = n - 1; i >= 0; i--)
     for (int j = 0; j < nc[i]; j++)
-      qw[ni[3 * (size_t)i + j]] +=
-        (uint64_t)div_exp2_round_half_inf((int64_t)qnw[j] * (int64_t)qw[i], 8);
+      /* int32 * uint64 -> uint64: the reference lands in the UNSIGNED
+       * overload of divExp2RoundHalfInf (PCCMath.h:678-685): modular product,
+       * logical shift -- it matters once the weights wrap (shares that add up
+       * to more than the weight itself on a deep structure) */
+      qw[ni[3 * (size_t)i + j]] += ((uint64_t)(int64_t)qnw[j] * qw[i] + 128u) >> 8;
 }
 
 static void

@@ -30,6 +30,10 @@ CASES = {
     # shares that add up to more than the weight itself: the device's separate sum / count words
     "dense_qnw_wide": ("dense", 6000, 7, 34, {}, dict(quant_neigh_weight=(120, 80, 60))),
     "lidar_qnw_wide_1lod": ("lidar", 5000, 0, 28, dict(levels=1), dict(avg_disabled=True, quant_neigh_weight=(130, 90, 40))),
+    # ... and on a structure deep enough for the 64-bit weights to WRAP (the reference multiplies
+    # int32 by uint64 and rounds with the unsigned overload): found by the randomised stress
+    "lidar_qnw_wrap": ("lidar", 53693, 0, 57, dict(levels=7, decimation=2, intra=0, skip=2, neighbours=3, sampling=3),
+                       dict(direct=0, quant_neigh_weight=(130, 90, 40), threshold=4)),
     "dense_skip_intra": ("dense", 6000, 7, 34, dict(skip=32), {}),
     "dense_thr0": ("dense", 4000, 6, 34, {}, dict(threshold=0)),
     "lidar_refl_ctc": ("lidar", 9000, 0, 28, dict(levels=1), dict(avg_disabled=True)),
@@ -57,7 +61,9 @@ def make(name):
         attrs = attrs * 257  # use the 16-bit range
     # cfg/octree-predt-ctc-*.yaml: transformType 1, intraLodPredictionSkipLayers 0, both search
     # ranges -1 (= 1100000 after encoder.cpp:799-808), predWeightBlending for colour; cat3: one LoD
-    lp = lod_params(levels=lo.get("levels", 12), lifting=False, intra_range=1100000, blend=(c == 3))
+    lp = lod_params(levels=lo.get("levels", 12), lifting=False, intra_range=lo.get("intra", 1100000), blend=(c == 3),
+                    decimation=lo.get("decimation", 0), neighbours=lo.get("neighbours", 3),
+                    sampling_period=lo.get("sampling", 4))
     lp.intra_lod_prediction_skip_layers = lo.get("skip", 0)
     thr = po.get("threshold", 64)
     po = {k: v for k, v in po.items() if k != "threshold"}
