@@ -27,7 +27,7 @@ for seed in range(400):
     r=ctx.lod_build(lp,xyz)
     for k in ("npl","indexes","nc","ni"):
         assert np.array_equal(np.asarray(r[k]).astype(np.int64), np.asarray(o[k]).astype(np.int64)), (k,seed,kw,n)
-    assert np.array_equal(r["w"].astype(np.uint64), o["w"]), ("w",seed,kw,n)
+    assert np.array_equal(r["w"].astype(np.uint32), (o["w"] & 0xffffffff).astype(np.uint32)), ("w",seed,kw,n)  # slots beyond the count hold raw distances: compare the bits
     cases+=1
     if time.time()-t0>100: break
 print("lod stress ok", cases, "cases", round(time.time()-t0,1),"s")
