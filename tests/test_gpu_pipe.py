@@ -1,0 +1,60 @@
+"""The decoder with sub-node prediction has two device paths: the walk across
+levels in one launch (raht_pipe.hpp, default for slices without region QPs) and
+the level-by-level kernels (region QPs, GPCC_PIPE=0).  Every decoder test of
+the suite runs the first; this file runs the second on the same cases and pins
+the two against each other on batches."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def test_level_by_level_decoder_on_the_golden_and_subnode_cases():
+    env = dict(os.environ, GPCC_PIPE="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_raht.py"), "-x", "-q",
+                        "-m", "gpu", "-k", "golden or subnode"], capture_output=True, text=True, timeout=900, env=env,
+                       cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout
+
+
+WORKER = r"""
+import sys, json
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + '/tests')
+import __graft_entry__ as g; g.load_package()
+import numpy as np, hashlib
+from mpeg_pcc_tmc13_amd import raht_params, synth, context
+ctx = context(0)
+out = {}
+for name, sizes, c in (("lidar", [90000, 1, 4000, 250000, 17], 1), ("dense", [60000, 300, 120000], 3)):
+    frames = []
+    for i, n in enumerate(sizes):
+        xyz, a = (synth.lidar_cloud(n, seed=40 + i) if c == 1 else synth.dense_cloud(n, seed=40 + i, bits=9 if n > 1000 else 4))
+        frames.append(synth.sort_by_morton(xyz, a)[:2])
+    p = raht_params(qp=34, chroma_offset=-1 if c == 3 else 0, subnode=True, search_range=2500 if c == 1 else 50000)
+    h = hashlib.md5()
+    for morton, a in frames:
+        co, rec = ctx.raht_forward(p, morton, a)
+        dec = ctx.raht_inverse(p, morton, co, c)
+        assert np.array_equal(dec, rec)
+        h.update(dec.tobytes())
+    out[name] = h.hexdigest()
+print(json.dumps(out))
+"""
+
+
+def test_both_decoder_paths_give_the_encoder_reconstruction():
+    import json
+    res = {}
+    for flag in ("1", "0"):
+        env = dict(os.environ, GPCC_PIPE=flag)
+        r = subprocess.run([sys.executable, "-c", WORKER % dict(root=ROOT)], capture_output=True, text=True,
+                           timeout=900, env=env, cwd=ROOT)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        res[flag] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["1"] == res["0"]
