@@ -231,8 +231,6 @@ struct Plan {
   bool sub = false;
   // decoder with sub-node prediction: one launch over all levels (raht_pipe.hpp)
   bool pipe = false;
-  char* pipe_base = nullptr;
-  size_t pipe_bytes = 0;
   int num_rtiles = 0;
   std::vector<int32_t*> haar_lf, asc_qp;
 };
@@ -309,18 +307,6 @@ carve(Arena& ar, Plan& pl)
     pl.rtile_base = ar.take<int32_t>(s + 1);
     pl.rtile_state = ar.take<unsigned long long>(pl.num_rtiles + 1);
     pl.slice_l = ar.take<int32_t>(2 * (size_t)s);  // sub-node path: [level parity][S]
-  }
-  pl.pipe_base = nullptr;
-  pl.pipe_bytes = 0;
-  if (pl.pipe) {
-    // per node of every level: value source (4 B), occupancy (1 B), worklist
-    // entry (4 B), two 16-byte granules per component; reserved for the level
-    // capacities, laid out by the real node counts once the host has them
-    size_t nodes = 0;
-    for (int li = 0; li < nlev; li++)
-      nodes += (size_t)pl.cap[li] + 1;
-    pl.pipe_bytes = nodes * (size_t)(4 + 1 + 4 + 32 * c) + 4096;
-    pl.pipe_base = ar.take<char>(pl.pipe_bytes);
   }
 }
 
@@ -586,11 +572,15 @@ launch_transform(
       px.uoff[li] = (int32_t)total;
       total += ts.nodes[li];
     }
+    // the walk's node store, sized by the real node counts the host has just
+    // read: from the context's caching pool (the arena is carved from host-known
+    // bounds before the tree exists: 12 levels of N nodes for a lidar frame)
     const size_t need = (size_t)total * (4 + 1 + 4 + 32 * C) + 2048;
-    if (total * C * 16 < ((int64_t)1 << 31) && need <= pl.pipe_bytes) {
+    void* pipe_mem = nullptr;
+    if (total * C * 16 < ((int64_t)1 << 31) && pool_malloc(ctx, &pipe_mem, need) == hipSuccess) {
       Arena pa;
-      pa.base = pl.pipe_base;
-      pa.cap = pl.pipe_bytes;
+      pa.base = (char*)pipe_mem;
+      pa.cap = need;
       px.g = pa.take<uint32_t>((size_t)total * C * 4);
       px.u = pa.take<uint32_t>((size_t)total * C * 4);
       px.src = pa.take<int32_t>(total);
@@ -620,6 +610,7 @@ launch_transform(
         pipe_leaf_kernel<C><<<grid_for(ts.nodes[0], 256), 256, 0, st>>>(lc, px);
       }
       piped = true;
+      pool_free(ctx, pipe_mem);  // reuse is ordered on the context's stream
     }
   }
 
