@@ -2716,6 +2716,21 @@ gpcc_debug_sub_prof(unsigned long long* out, int reset)
 }
 #endif
 
+#ifdef GPCC_PIPE_PROF
+extern "C" int
+gpcc_debug_pipe_prof(unsigned long long* out, int reset)
+{
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gpcc::g_pipe_prof), sizeof(gpcc::g_pipe_prof)) != hipSuccess)
+    return -1;
+  if (reset) {
+    static unsigned long long z[32 * 8] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(gpcc::g_pipe_prof), z, sizeof(z)) != hipSuccess)
+      return -1;
+  }
+  return 0;
+}
+#endif
+
 #ifdef GPCC_TILE_PROF
 extern "C" int
 gpcc_debug_tile_prof(unsigned long long* out, int reset)

@@ -35,6 +35,32 @@
 
 namespace gpcc {
 
+// Where a round's wave time goes (experiment builds only, -DGPCC_PIPE_PROF:
+// s_memtime at the stages of a round, summed per level into g_pipe_prof and
+// read back with gpcc_debug_pipe_prof).  Empty otherwise.
+#ifdef GPCC_PIPE_PROF
+__device__ unsigned long long g_pipe_prof[32 * 8];
+struct PipeProf {
+  unsigned long long last = 0;
+  int li = 0;
+  __device__ void begin(int l) { li = l; last = __builtin_amdgcn_s_memtime(); }
+  __device__ void mark(int stage, int lane)
+  {
+    const unsigned long long t = __builtin_amdgcn_s_memtime();
+    if (lane == 0)
+      atomicAdd(&g_pipe_prof[li * 8 + stage], t - last);
+    last = t;
+  }
+  __device__ void round(int lane) { if (lane == 0) atomicAdd(&g_pipe_prof[li * 8 + 7], 1ull); }
+};
+#else
+struct PipeProf {
+  __device__ void begin(int) {}
+  __device__ void mark(int, int) {}
+  __device__ void round(int) {}
+};
+#endif
+
 struct PipeCtx {
   int32_t* src;        // [total] unified index of the node that holds a node's value
   uint32_t* g;         // [total * C][4]
@@ -244,6 +270,9 @@ raht_pipe_synth_kernel(LevelCtx ctx, PipeCtx px)
       break;
     if (__hip_atomic_load(ctx.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
       break;
+    PipeProf prof;
+    prof.begin(li);
+    prof.round(lane);
     const int num_work = ctx.work_count[li];
     const int wi = (int)((ground - rbase) * 8) + (lane >> 3);
     const bool live = wi < num_work;
@@ -275,6 +304,7 @@ raht_pipe_synth_kernel(LevelCtx ctx, PipeCtx px)
     if (has)
       w = tv.fp[li][child + 1] - tv.fp[li][child];
 
+    prof.mark(0, lane);  // block located, children, weights
     // ---- butterfly weights + coefficients (mkWeightTree :742) ----------
     int32_t wl[3], wr[3];
     int64_t ca[3], cb[3];
@@ -410,6 +440,7 @@ raht_pipe_synth_kernel(LevelCtx ctx, PipeCtx px)
       }
     }
 
+    prof.mark(1, lane);  // early look + neighbour search
     // ---- coefficient slot of this position (scanBlock :776-791) --------
     const uint32_t present = group8_bits(on && cw != 0) | (on ? 1u : 0u);
     const int spos = (0x74516230u >> (4 * t)) & 7;
@@ -453,6 +484,7 @@ raht_pipe_synth_kernel(LevelCtx ctx, PipeCtx px)
       if (pn[slot] >= 0)
         nsrc[slot] = px.src[pbase + pn[slot]] & kPipeIndex;
 
+    prof.mark(2, lane);  // slots, quantisers, coefficients, sources
     unsigned spins = 0;
     bool failed = false;
     // ---- stage A1: the block's own node (lane 0 of the group) ------------
@@ -514,6 +546,7 @@ raht_pipe_synth_kernel(LevelCtx ctx, PipeCtx px)
     }
     const bool run = do_search && enable_pred;
 
+    prof.mark(3, lane);  // stage A1
     // ---- stage A2: the neighbour parents this lane searched ----------------
     int64_t nbv[3][C];
 #pragma unroll
@@ -568,6 +601,7 @@ raht_pipe_synth_kernel(LevelCtx ctx, PipeCtx px)
       break;
     }
 
+    prof.mark(4, lane);  // stage A2
     int64_t dc[C];
 #pragma unroll
     for (int k = 0; k < C; k++) {
@@ -735,6 +769,7 @@ raht_pipe_synth_kernel(LevelCtx ctx, PipeCtx px)
     }
     const int64_t pdiv = pred_divisor(wsum > 0 ? wsum : 1);
 
+    prof.mark(5, lane);  // parent-level terms, children sources, first polls
     // ---- the dependency loop (raht_subnode.hpp, decoder) --------------------
     int stage = on ? 0 : 3;
     int64_t pt[C];
@@ -925,6 +960,7 @@ raht_pipe_synth_kernel(LevelCtx ctx, PipeCtx px)
         __builtin_amdgcn_s_sleep(GPCC_SUB_SLEEP);
       }
     }
+    prof.mark(6, lane);  // the loop
   }
 }
 
