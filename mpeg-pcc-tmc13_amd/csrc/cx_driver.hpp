@@ -1,0 +1,186 @@
+// cx_driver.hpp -- workspace layout and launch sequence of the compact level pass
+// (cx_tree.hpp, cx_level.hpp):
+//
+//   cx_count -> cx_scan -> cx_scan_fin -> cx_emit      level arrays + block lists
+//   schedule                                            per-slice level plan
+//   cx_level<C, ENC> x (levels with blocks)             ONE launch per level
+//   finish                                              duplicates, write-back
+//
+// Used for batches without sub-node prediction, with the RAHT extension, without
+// integer Haar and without region QP offsets; everything else keeps the tile
+// kernels (raht_tile.hpp).  The sequence is a template over how the host learns
+// the tree's shape (an event on pinned memory in the library) so that the same
+// code runs under the CPU wavefront emulator of the test tier (tests/emu).
+#pragma once
+
+#include <algorithm>
+
+#include "cx_level.hpp"
+#include "raht_edges.hpp"
+
+namespace gpcc {
+
+struct CxWork {
+  int n = 0, s = 0, c = 0, nlev = 0;
+  bool encoder = false;
+  TreeView tv{};
+  CxLists cl{};
+  int32_t* pt_off = nullptr;
+  SliceSched* sched = nullptr;
+  gpcc_raht_params* params = nullptr;
+  int32_t* attr_prefix = nullptr;
+  int64_t* val = nullptr;
+  int64_t* rec = nullptr;
+  int32_t* nn = nullptr;
+  unsigned long long* tstate = nullptr;
+  int32_t* slice_l = nullptr;
+  int max_tiles = 0;
+};
+
+inline bool
+cx_supported(const gpcc_raht_params* p, bool has_qp, int64_t n)
+{
+  return p->raht_extension != 0 && !p->integer_haar_enable_flag && !has_qp
+    && !(p->raht_prediction_enabled_flag && p->raht_subnode_prediction_enabled_flag)
+    && n <= kCxMaxPoints;
+}
+
+// `take(bytes)` hands out 256-byte aligned storage (or only counts)
+template<class Take>
+void
+cx_carve(Take&& take, CxWork& w)
+{
+  const int n = w.n, s = w.s, c = w.c, nlev = w.nlev;
+  auto arr = [&](size_t count, size_t elem) { return take(count * elem); };
+  w.pt_off = (int32_t*)arr(s + 1, 4);
+  for (int li = 0; li < nlev; li++) {
+    int64_t cap = n;
+    const int up = nlev - 1 - li;
+    if (up < 11) {
+      const int64_t full = (int64_t)s << (3 * up);
+      cap = cap < full ? cap : full;
+    }
+    w.tv.cap[li] = (int32_t)cap;
+    w.tv.key[li] = (int64_t*)arr(cap + 1, 8);
+    w.tv.fp[li] = (int32_t*)arr(cap + 2, 4);
+    w.tv.fc[li] = (int32_t*)arr(cap + 2, 4);
+    w.tv.soff[li] = (int32_t*)arr(s + 1, 4);
+    w.cl.hold[li] = (uint32_t*)arr(cap + 1, 4);
+  }
+  w.tv.nlev = nlev;
+  w.tv.num_slices = s;
+  w.tv.n_total = n;
+  w.tv.num_tiles = (n + kTilePoints - 1) / kTilePoints;
+  w.tv.pt_off = w.pt_off;
+  const int ncol = 3 * nlev + c;
+  w.cl.h = (uint8_t*)arr((size_t)n + 1, 1);
+  w.cl.bp = (int32_t*)arr((size_t)n + 1, 4);
+  w.cl.bq = (int32_t*)arr((size_t)n + nlev + 1, 4);
+  w.cl.rb = (int32_t*)arr(2 * (size_t)n + 1, 4);
+  w.cl.tab = (CxLevelTab*)arr(1, sizeof(CxLevelTab));
+  w.cl.tile_tab = (uint32_t*)arr((size_t)w.tv.num_tiles * ncol, 4);
+  w.cl.col_total = (uint32_t*)arr(ncol, 4);
+  w.sched = (SliceSched*)arr(s, sizeof(SliceSched));
+  w.params = (gpcc_raht_params*)arr(1, sizeof(gpcc_raht_params));
+  w.attr_prefix = w.encoder ? (int32_t*)arr(((size_t)n + 1) * c, 4) : nullptr;
+  w.val = (int64_t*)arr(2 * (size_t)n * c, 8);
+  w.rec = (int64_t*)arr(2 * (size_t)n * c, 8);
+  w.nn = (int32_t*)arr(2 * (size_t)n, 4);
+  w.max_tiles = n / kCxG + 2;
+  w.tstate = (unsigned long long*)arr((size_t)w.max_tiles + 1, 8);
+  w.slice_l = (int32_t*)arr(2 * (size_t)s, 4);
+}
+
+// Everything after the uploads of params / pt_off.  `prof(name)` returns a scoped
+// timer object; `fetch()` makes *stats and *tab (host copies) valid.
+template<int C, class Prof, class Fetch>
+hipError_t
+cx_run(
+  hipStream_t st, CxWork& w, const SharedLut* d_lut, int num_qp_layers, int32_t* d_attrs,
+  int32_t* d_coeffs, TreeStats* stats, CxLevelTab* tab, Prof&& prof, Fetch&& fetch)
+{
+  const TreeView tv = w.tv;
+  const CxLists cl = w.cl;
+  const int ncol = 3 * w.nlev + C;
+  const int32_t* sum_attrs = w.encoder ? d_attrs : nullptr;
+  const int tgrid = std::min(std::max((tv.num_tiles + 3) / 4, 1), 2048);
+  {
+    auto t = prof("cx_count");
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(cx_count_kernel<C>), dim3(tgrid), dim3(256), 0, st, tv, sum_attrs, cl);
+  }
+  {
+    auto t = prof("cx_scan");
+    hipLaunchKernelGGL(cx_scan_kernel, dim3(ncol), dim3(256), 0, st, tv, cl, ncol);
+    hipLaunchKernelGGL(
+      HIP_KERNEL_NAME(cx_scan_fin_kernel<C>), dim3(1), dim3(64), 0, st, tv, cl, w.attr_prefix,
+      sum_attrs != nullptr);
+  }
+  {
+    auto t = prof("cx_emit");
+    hipLaunchKernelGGL(
+      HIP_KERNEL_NAME(cx_emit_kernel<C>), dim3(tgrid), dim3(256), 0, st, tv, sum_attrs, cl, w.attr_prefix);
+  }
+  {
+    auto t = prof("schedule");
+    hipLaunchKernelGGL(schedule_kernel, dim3(1), dim3(256), 0, st, tv, w.sched, num_qp_layers, 0, stats);
+  }
+  hipError_t e = hipMemcpyAsync(tab, cl.tab, sizeof(CxLevelTab), hipMemcpyDeviceToHost, st);
+  if (e != hipSuccess)
+    return e;
+  e = hipMemsetAsync(w.tstate, 0, ((size_t)w.max_tiles + 1) * sizeof(unsigned long long), st);
+  if (e != hipSuccess)
+    return e;
+  e = hipMemsetAsync(w.slice_l, 0xff, 2 * (size_t)w.s * sizeof(int32_t), st);
+  if (e != hipSuccess)
+    return e;
+  e = fetch();
+  if (e != hipSuccess)
+    return e;
+
+  CxCtx cx{};
+  cx.tv = tv;
+  cx.cl = cl;
+  cx.params = w.params;
+  cx.sched = w.sched;
+  cx.attr_prefix = w.attr_prefix;
+  cx.val = w.val;
+  cx.rec = w.rec;
+  cx.nn = w.nn;
+  cx.coeffs = d_coeffs;
+  cx.lut = d_lut;
+  cx.tstate = w.tstate;
+  cx.slice_l = w.slice_l;
+  const int first_level = std::min(w.nlev - 1, (int)stats->max_top);
+  for (int li = first_level - 1; li >= 0; li--) {
+    const int nr = tab->nr[li];
+    if (nr <= 0)
+      continue;
+    cx.li = li;
+    const int ntiles = (nr + kCxG - 1) / kCxG;
+    auto t = prof(w.encoder ? "cx_level_enc" : "cx_level_dec");
+    if (w.encoder)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(cx_level_kernel<C, true>), dim3((ntiles + 3) / 4), dim3(256), 0, st, cx);
+    else
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(cx_level_kernel<C, false>), dim3((ntiles + 3) / 4), dim3(256), 0, st, cx);
+  }
+
+  FinishCtx fc{};
+  fc.tv = tv;
+  fc.params = w.params;
+  fc.sched = w.sched;
+  fc.attr_prefix = w.attr_prefix;
+  fc.slot_rec = w.rec;
+  fc.hold0 = cl.hold[0];
+  fc.attrs = d_attrs;
+  fc.coeffs = d_coeffs;
+  fc.encoder = w.encoder;
+  fc.lut = d_lut;
+  {
+    auto t = prof("finish");
+    const int fgrid = std::min(std::max((tv.cap[0] + 255) / 256, 1), 2048);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(finish_kernel<C>), dim3(fgrid), dim3(256), 0, st, fc);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace gpcc

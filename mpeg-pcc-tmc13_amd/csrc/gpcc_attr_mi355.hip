@@ -40,6 +40,7 @@
 #include "raht_pipe.hpp"
 #include "raht_tile.hpp"
 #include "raht_tree.hpp"
+#include "cx_driver.hpp"
 #include "lift_kernels.hpp"
 #include "lod_kernels.hpp"
 #include "pred_kernels.hpp"
@@ -114,6 +115,7 @@ struct gpcc_ctx {
   int32_t* d_error = nullptr;  // device: set by a kernel whose bounded wait expired, cleared
                                // only when the error has been reported (check_device_error)
   TreeStats* h_stats = nullptr;   // pinned: what schedule_kernel tells the host about the tree
+  CxLevelTab* h_cxtab = nullptr;  // pinned: blocks / real children per level (compact level pass)
   hipEvent_t ev_stats = nullptr;  // recorded behind schedule_kernel
   // what the entries did since the context was created (gpcc_ctx_stats)
   gpcc_ctx_stats_t stats{};
@@ -706,6 +708,51 @@ launch_transform(
   return GPCC_OK;
 }
 
+// ---- the compact level pass (cx_driver.hpp): batches without sub-node prediction,
+//      with the RAHT extension, without integer Haar and region QPs -------------------
+template<int C>
+int
+launch_cx(
+  gpcc_ctx* ctx, CxWork& w, const gpcc_raht_params* hp, const int64_t* offsets,
+  const int64_t* d_morton, int32_t* d_attrs, int32_t* d_coeffs)
+{
+  hipStream_t st = ctx->stream;
+  const int s = w.s;
+  std::vector<int32_t> h_off(s + 1);
+  for (int i = 0; i <= s; i++)
+    h_off[i] = (int32_t)offsets[i];
+  const size_t stage_bytes = sizeof(gpcc_raht_params) + (s + 1) * sizeof(int32_t) + 64;
+  if (ctx->h_pinned_cap < stage_bytes) {
+    HIP_TRY(hipStreamSynchronize(st));
+    if (ctx->h_pinned)
+      HIP_TRY(hipHostFree(ctx->h_pinned));
+    HIP_TRY(hipHostMalloc(&ctx->h_pinned, stage_bytes * 2));
+    ctx->h_pinned_cap = stage_bytes * 2;
+  } else {
+    HIP_TRY(hipStreamSynchronize(st));  // the previous call's async copies read this buffer
+  }
+  char* hp_base = (char*)ctx->h_pinned;
+  memcpy(hp_base, hp, sizeof(*hp));
+  HIP_TRY(hipMemcpyAsync(w.params, hp_base, sizeof(*hp), hipMemcpyHostToDevice, st));
+  const size_t o = (sizeof(*hp) + 15) & ~size_t(15);
+  memcpy(hp_base + o, h_off.data(), (s + 1) * sizeof(int32_t));
+  HIP_TRY(hipMemcpyAsync(w.pt_off, hp_base + o, (s + 1) * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  w.tv.pos = d_morton;
+  w.tv.error = ctx->d_error;
+  hipError_t e = cx_run<C>(
+    st, w, ctx->d_lut, hp->num_qp_layers, d_attrs, d_coeffs, ctx->h_stats, ctx->h_cxtab,
+    [&](const char* name) { return Timer(ctx, name); },
+    [&]() -> hipError_t {
+      hipError_t r = hipEventRecord(ctx->ev_stats, st);
+      return r != hipSuccess ? r : hipEventSynchronize(ctx->ev_stats);
+    });
+  if (e != hipSuccess)
+    return fail(GPCC_ERR_HIP, std::string("compact level pass: ") + hipGetErrorString(e));
+  if (ctx->h_error)
+    HIP_TRY(hipMemcpyAsync(ctx->h_error, ctx->d_error, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  return GPCC_OK;
+}
+
 int
 check_device_error(gpcc_ctx* ctx)
 {
@@ -751,11 +798,40 @@ dev_transform(
     return fail(GPCC_ERR_INVALID_ARG, "null device buffer");
   HIP_TRY(hipSetDevice(ctx->device));
 
+  const int bits = morton_bits > 0 ? std::min(morton_bits, 63) : 63;
+  {
+    static const bool cx_on = [] {
+      const char* e = getenv("GPCC_CX");
+      return !(e && e[0] == '0');
+    }();
+    if (cx_on && cx_supported(params, d_qp_off != nullptr, offsets[s])) {
+      CxWork w;
+      w.n = (int)offsets[s];
+      w.s = s;
+      w.c = c;
+      w.nlev = std::min((bits + 2) / 3 + 1, (int)kMaxLevels);
+      w.encoder = encoder;
+      size_t used = 0;
+      cx_carve([&](size_t bytes) { used += (bytes + 255) & ~size_t(255); return (char*)nullptr; }, w);
+      rcode = ensure_arena(ctx, used);
+      if (rcode)
+        return rcode;
+      ctx->arena.reset();
+      cx_carve([&](size_t bytes) { return ctx->arena.take<char>(bytes); }, w);
+      switch (c) {
+      case 1:
+        return launch_cx<1>(ctx, w, params, offsets, (const int64_t*)d_morton, (int32_t*)d_attrs, (int32_t*)d_coeffs);
+      case 2:
+        return launch_cx<2>(ctx, w, params, offsets, (const int64_t*)d_morton, (int32_t*)d_attrs, (int32_t*)d_coeffs);
+      default:
+        return launch_cx<3>(ctx, w, params, offsets, (const int64_t*)d_morton, (int32_t*)d_attrs, (int32_t*)d_coeffs);
+      }
+    }
+  }
   Plan pl;
   pl.n = (int)offsets[s];
   pl.s = s;
   pl.c = c;
-  const int bits = morton_bits > 0 ? std::min(morton_bits, 63) : 63;
   pl.nlev = std::min((bits + 2) / 3 + 1, (int)kMaxLevels);
   pl.encoder = encoder;
   pl.haar = params->integer_haar_enable_flag != 0;
@@ -1470,6 +1546,7 @@ gpcc_ctx_create(int device, void* stream, gpcc_ctx** out)
       || hipMemsetAsync(ctx->d_error, 0, sizeof(int32_t), ctx->stream) != hipSuccess
       || hipHostMalloc((void**)&ctx->h_error, sizeof(int32_t)) != hipSuccess
       || hipHostMalloc((void**)&ctx->h_stats, sizeof(TreeStats)) != hipSuccess
+      || hipHostMalloc((void**)&ctx->h_cxtab, sizeof(CxLevelTab)) != hipSuccess
       || hipEventCreateWithFlags(&ctx->ev_stats, hipEventDisableTiming) != hipSuccess) {
     gpcc_ctx_destroy(ctx);
     return fail(GPCC_ERR_OUT_OF_MEMORY, "context bookkeeping allocations failed");
@@ -1511,6 +1588,8 @@ gpcc_ctx_destroy(gpcc_ctx* ctx)
     hipFree(ctx->d_error);
   if (ctx->h_stats)
     hipHostFree(ctx->h_stats);
+  if (ctx->h_cxtab)
+    hipHostFree(ctx->h_cxtab);
   if (ctx->ev_stats)
     hipEventDestroy(ctx->ev_stats);
   if (ctx->h_pinned)

@@ -32,6 +32,11 @@ constexpr int kMaxLevels = 22;   // ceil(63 / 3) + root
 constexpr int kTilePoints = 1024;  // points per wave in the tree build
 constexpr int kWave = 64;
 
+// value slots of the compact level pass (cx_tree.hpp): hold = slot | top level << 27
+constexpr int kCxSlotBits = 27;
+constexpr uint32_t kCxSlotMask = (1u << kCxSlotBits) - 1;
+constexpr int32_t kCxMaxPoints = 1 << (kCxSlotBits - 1);
+
 // payload of one 16-byte buffer load / store (mailbox granules)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 

@@ -161,6 +161,9 @@ struct FinishCtx {
   const int32_t* qp_off;
   const int64_t* rec[2];
   const int32_t* dqp[2];
+  // compact level pass (cx_level.hpp): the leaves' values live in value slots
+  const int64_t* slot_rec;  // [2N][C] or null
+  const uint32_t* hold0;    // [M0] slot of every leaf
   int32_t* attrs;   // in: source (encoder), out: reconstruction
   int32_t* coeffs;
   int32_t encoder;
@@ -218,7 +221,9 @@ finish_kernel(FinishCtx cx)
     int64_t rec[C];
 #pragma unroll
     for (int k = 0; k < C; k++)
-      rec[k] = any_level ? cx.rec[par][row * C + k] : 0;
+      rec[k] = !any_level ? 0
+        : (cx.slot_rec ? cx.slot_rec[(size_t)(cx.hold0[j] & kCxSlotMask) * C + k]
+                       : cx.rec[par][row * C + k]);
 
     if (weight == 1) {
 #pragma unroll

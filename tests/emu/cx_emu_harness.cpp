@@ -1,0 +1,212 @@
+// tests/emu/cx_emu_harness.cpp -- TEST INFRASTRUCTURE: runs the compact level pass
+// (mpeg-pcc-tmc13_amd/csrc/cx_*.hpp) under the CPU wavefront emulator, through the
+// same launch sequence (cx_driver.hpp) the gfx950 library uses.
+#include <algorithm>
+#include <vector>
+
+#include "hip/hip_runtime.h"
+
+#include "cx_driver.hpp"
+
+using namespace gpcc;
+
+namespace {
+struct NoProf {
+  int operator()(const char*) const { return 0; }
+};
+}  // namespace
+
+extern "C" int
+cx_emu_supported(const gpcc_raht_params* p, int has_qp, int64_t n)
+{
+  return cx_supported(p, has_qp != 0, n) ? 1 : 0;
+}
+
+// attrs: in source (encoder) / out reconstruction; coeffs: planar per slice
+extern "C" int
+cx_emu_transform(
+  const gpcc_raht_params* params, int encoder, int32_t num_slices, const int64_t* offsets,
+  const int64_t* morton, int32_t* attrs, int32_t* coeffs, int32_t c, int32_t morton_bits,
+  int32_t* debug_tab)
+{
+  CxWork w;
+  w.n = (int)offsets[num_slices];
+  w.s = num_slices;
+  w.c = c;
+  const int bits = morton_bits > 0 ? std::min(morton_bits, 63) : 63;
+  w.nlev = std::min((bits + 2) / 3 + 1, (int)kMaxLevels);
+  w.encoder = encoder != 0;
+  std::vector<void*> blocks;
+  cx_carve(
+    [&](size_t bytes) {
+      bytes = (bytes + 255) & ~size_t(255);
+      void* p = malloc(bytes + 256);
+      memset(p, 0xCD, bytes + 256);  // the arena of the library is not cleared either
+      blocks.push_back(p);
+      return (char*)p;
+    },
+    w);
+  int32_t error = 0;
+  w.tv.pos = morton;
+  w.tv.error = &error;
+  std::vector<int32_t> off(num_slices + 1);
+  for (int i = 0; i <= num_slices; i++)
+    off[i] = (int32_t)offsets[i];
+  memcpy(w.pt_off, off.data(), off.size() * 4);
+  memcpy(w.params, params, sizeof(*params));
+  SharedLut* lut = (SharedLut*)malloc(sizeof(SharedLut));
+  hipLaunchKernelGGL(lut_init_kernel, dim3(1), dim3(256), 0, nullptr, lut);
+  TreeStats stats{};
+  CxLevelTab tab{};
+  hipError_t e;
+  auto fetch = [&]() { return hipSuccess; };
+  switch (c) {
+  case 1: e = cx_run<1>(nullptr, w, lut, params->num_qp_layers, attrs, coeffs, &stats, &tab, NoProf(), fetch); break;
+  case 2: e = cx_run<2>(nullptr, w, lut, params->num_qp_layers, attrs, coeffs, &stats, &tab, NoProf(), fetch); break;
+  default: e = cx_run<3>(nullptr, w, lut, params->num_qp_layers, attrs, coeffs, &stats, &tab, NoProf(), fetch); break;
+  }
+  if (debug_tab)
+    for (int l = 0; l < kMaxLevels; l++) {
+      debug_tab[l] = tab.nb[l];
+      debug_tab[kMaxLevels + l] = tab.nr[l];
+    }
+  for (void* p : blocks)
+    free(p);
+  free(lut);
+  if (e != hipSuccess)
+    return -5;
+  return error ? -100 - error : 0;
+}
+
+// ---- tree / list check against a direct computation ---------------------------------
+extern "C" int
+cx_emu_check_tree(int32_t num_slices, const int64_t* offsets, const int64_t* morton, int32_t morton_bits)
+{
+  CxWork w;
+  w.n = (int)offsets[num_slices];
+  w.s = num_slices;
+  w.c = 1;
+  const int bits = morton_bits > 0 ? std::min(morton_bits, 63) : 63;
+  w.nlev = std::min((bits + 2) / 3 + 1, (int)kMaxLevels);
+  w.encoder = false;
+  std::vector<void*> blocks;
+  cx_carve(
+    [&](size_t bytes) {
+      bytes = (bytes + 255) & ~size_t(255);
+      void* p = malloc(bytes + 256);
+      memset(p, 0xCD, bytes + 256);
+      blocks.push_back(p);
+      return (char*)p;
+    },
+    w);
+  int32_t error = 0;
+  w.tv.pos = morton;
+  w.tv.error = &error;
+  for (int i = 0; i <= num_slices; i++)
+    w.pt_off[i] = (int32_t)offsets[i];
+  const TreeView tv = w.tv;
+  const CxLists cl = w.cl;
+  const int ncol = 3 * w.nlev + 1;
+  const int tgrid = std::max((tv.num_tiles + 3) / 4, 1);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(cx_count_kernel<1>), dim3(tgrid), dim3(256), 0, nullptr, tv, (const int32_t*)nullptr, cl);
+  hipLaunchKernelGGL(cx_scan_kernel, dim3(ncol), dim3(256), 0, nullptr, tv, cl, ncol);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(cx_scan_fin_kernel<1>), dim3(1), dim3(64), 0, nullptr, tv, cl, (int32_t*)nullptr, 0);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(cx_emit_kernel<1>), dim3(tgrid), dim3(256), 0, nullptr, tv, (const int32_t*)nullptr, cl, (int32_t*)nullptr);
+  const int n = w.n, nlev = w.nlev;
+  int bad = 0;
+  auto fail = [&](const char* what, int l, int i, long long got, long long want) {
+    if (bad++ < 12)
+      fprintf(stderr, "tree check: %s level %d index %d: got %lld want %lld\n", what, l, i, got, want);
+  };
+  // head levels
+  std::vector<int> h(n + 1);
+  for (int s = 0; s < num_slices; s++)
+    for (int i = (int)offsets[s]; i < (int)offsets[s + 1]; i++) {
+      if (i == offsets[s]) {
+        h[i] = nlev;
+        continue;
+      }
+      const uint64_t x = (uint64_t)(morton[i] ^ morton[i - 1]);
+      int hh = x ? (64 - __builtin_clzll(x) + 2) / 3 : 0;
+      h[i] = hh < nlev ? hh : nlev;
+    }
+  h[n] = nlev;
+  for (int i = 0; i <= n; i++)
+    if (cl.h[i] != h[i])
+      fail("h", 0, i, cl.h[i], h[i]);
+  std::vector<std::vector<int>> heads(nlev);
+  for (int l = 0; l < nlev; l++) {
+    for (int i = 0; i < n; i++)
+      if (h[i] > l)
+        heads[l].push_back(i);
+    const int m = (int)heads[l].size();
+    if (tv.soff[l][num_slices] != m)
+      fail("node count", l, 0, tv.soff[l][num_slices], m);
+    for (int q = 0; q < m; q++) {
+      const int a = heads[l][q], b = q + 1 < m ? heads[l][q + 1] : n;
+      if (tv.fp[l][q] != a)
+        fail("fp", l, q, tv.fp[l][q], a);
+      if (tv.key[l][q] != (morton[a] >> (3 * l)))
+        fail("key", l, q, tv.key[l][q], morton[a] >> (3 * l));
+      const int slot = h[a] <= h[b] ? a : n + b;
+      const int t = std::min(h[a], h[b]) - 1;
+      const uint32_t want = (uint32_t)slot | ((uint32_t)t << kCxSlotBits);
+      if (cl.hold[l][q] != want)
+        fail("hold", l, q, cl.hold[l][q], want);
+    }
+    if (tv.fp[l][m] != n)
+      fail("fp sentinel", l, m, tv.fp[l][m], n);
+  }
+  for (int l = 1; l < nlev; l++) {
+    const int m = (int)heads[l].size();
+    size_t c = 0;
+    for (int q = 0; q <= m; q++) {
+      const int a = q < m ? heads[l][q] : n;
+      while (c < heads[l - 1].size() && heads[l - 1][c] < a)
+        c++;
+      if (tv.fc[l][q] != (int)c)
+        fail("fc", l, q, tv.fc[l][q], (long long)c);
+    }
+  }
+  // block lists of every children level
+  for (int l = 0; l + 1 < nlev; l++) {
+    const int mp = (int)heads[l + 1].size();
+    std::vector<int> ebp, ebq, erb;
+    int rank = 0;
+    for (int j = 0; j < mp; j++) {
+      const int k = tv.fc[l + 1][j + 1] - tv.fc[l + 1][j];
+      if (k < 2)
+        continue;
+      ebp.push_back(j);
+      ebq.push_back(rank);
+      for (int u = 0; u < k; u++)
+        erb.push_back((int)ebp.size() - 1);
+      rank += k;
+    }
+    ebq.push_back(rank);
+    const CxLevelTab* tab = cl.tab;
+    if (tab->nb[l] != (int)ebp.size())
+      fail("nb", l, 0, tab->nb[l], (long long)ebp.size());
+    if (tab->nr[l] != rank)
+      fail("nr", l, 0, tab->nr[l], rank);
+    if (tab->nb[l] != (int)ebp.size() || tab->nr[l] != rank)
+      continue;
+    const int32_t* bp = cl.bp + tab->boff[l];
+    const int32_t* bq = cl.bq + tab->boff[l] + l;
+    const int32_t* rb = cl.rb + tab->roff[l];
+    for (size_t b = 0; b < ebp.size(); b++) {
+      if (bp[b] != ebp[b])
+        fail("bp", l, (int)b, bp[b], ebp[b]);
+      if (bq[b] != ebq[b])
+        fail("bq", l, (int)b, bq[b], ebq[b]);
+    }
+    if (bq[ebp.size()] != rank)
+      fail("bq sentinel", l, (int)ebp.size(), bq[ebp.size()], rank);
+    for (int r = 0; r < rank; r++)
+      if (rb[r] != erb[r])
+        fail("rb", l, r, rb[r], erb[r]);
+  }
+  for (void* p : blocks)
+    free(p);
+  return bad;
+}
