@@ -63,7 +63,7 @@ cx_carve(Take&& take, CxWork& w)
     w.tv.cap[li] = (int32_t)cap;
     w.tv.key[li] = (int64_t*)arr(cap + 1, 8);
     w.tv.fp[li] = (int32_t*)arr(cap + 2, 4);
-    w.tv.fc[li] = (int32_t*)arr(cap + 2, 4);
+    w.tv.fc[li] = nullptr;  // (the block lists carry the first children)
     w.tv.soff[li] = (int32_t*)arr(s + 1, 4);
     w.cl.hold[li] = (uint32_t*)arr(cap + 1, 4);
   }
@@ -77,6 +77,7 @@ cx_carve(Take&& take, CxWork& w)
   w.cl.bp = (int32_t*)arr((size_t)n + 1, 4);
   w.cl.bq = (int32_t*)arr((size_t)n + nlev + 1, 4);
   w.cl.rb = (int32_t*)arr(2 * (size_t)n + 1, 4);
+  w.cl.bc = (int32_t*)arr((size_t)n + 1, 4);
   w.cl.tab = (CxLevelTab*)arr(1, sizeof(CxLevelTab));
   w.cl.tile_tab = (uint32_t*)arr((size_t)w.tv.num_tiles * ncol, 4);
   w.cl.col_total = (uint32_t*)arr(ncol, 4);
@@ -91,7 +92,7 @@ cx_carve(Take&& take, CxWork& w)
   w.slice_l = (int32_t*)arr(2 * (size_t)s, 4);
 }
 
-// Everything after the uploads of params / pt_off.  `prof(name)` returns a scoped
+// Everything after the uploads of params / pt_off.  `prof(name, level)` returns a scoped
 // timer object; `fetch()` makes *stats and *tab (host copies) valid.
 template<int C, class Prof, class Fetch>
 hipError_t
@@ -105,23 +106,23 @@ cx_run(
   const int32_t* sum_attrs = w.encoder ? d_attrs : nullptr;
   const int tgrid = std::min(std::max((tv.num_tiles + 3) / 4, 1), 2048);
   {
-    auto t = prof("cx_count");
+    auto t = prof("cx_count", -1);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(cx_count_kernel<C>), dim3(tgrid), dim3(256), 0, st, tv, sum_attrs, cl);
   }
   {
-    auto t = prof("cx_scan");
+    auto t = prof("cx_scan", -1);
     hipLaunchKernelGGL(cx_scan_kernel, dim3(ncol), dim3(256), 0, st, tv, cl, ncol);
     hipLaunchKernelGGL(
       HIP_KERNEL_NAME(cx_scan_fin_kernel<C>), dim3(1), dim3(64), 0, st, tv, cl, w.attr_prefix,
       sum_attrs != nullptr);
   }
   {
-    auto t = prof("cx_emit");
+    auto t = prof("cx_emit", -1);
     hipLaunchKernelGGL(
       HIP_KERNEL_NAME(cx_emit_kernel<C>), dim3(tgrid), dim3(256), 0, st, tv, sum_attrs, cl, w.attr_prefix);
   }
   {
-    auto t = prof("schedule");
+    auto t = prof("schedule", -1);
     hipLaunchKernelGGL(schedule_kernel, dim3(1), dim3(256), 0, st, tv, w.sched, num_qp_layers, 0, stats);
   }
   hipError_t e = hipMemcpyAsync(tab, cl.tab, sizeof(CxLevelTab), hipMemcpyDeviceToHost, st);
@@ -157,7 +158,7 @@ cx_run(
       continue;
     cx.li = li;
     const int ntiles = (nr + kCxG - 1) / kCxG;
-    auto t = prof(w.encoder ? "cx_level_enc" : "cx_level_dec");
+    auto t = prof(w.encoder ? "cx_level_enc" : "cx_level_dec", li);
     if (w.encoder)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(cx_level_kernel<C, true>), dim3((ntiles + 3) / 4), dim3(256), 0, st, cx);
     else
@@ -176,7 +177,7 @@ cx_run(
   fc.encoder = w.encoder;
   fc.lut = d_lut;
   {
-    auto t = prof("finish");
+    auto t = prof("finish", -1);
     const int fgrid = std::min(std::max((tv.cap[0] + 255) / 256, 1), 2048);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(finish_kernel<C>), dim3(fgrid), dim3(256), 0, st, fc);
   }

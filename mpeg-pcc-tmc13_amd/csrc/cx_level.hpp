@@ -54,13 +54,20 @@ struct CxSlice {
   LevelSched e;
 };
 
+// quantisers of a (slice, level): [0] the RDOQ statistics (no AC offset), [1 + p]
+// coefficient position p (tmc3/RAHT.cpp:1584-1616, quantization.cpp:165-174)
+struct CxQuant {
+  Quantizer q[9][2];
+  double inv_lambda;
+  int64_t lambda;
+};
+
 struct CxSmem {
   SharedLut lut;
   int32_t pw[19];
-  uint8_t noff[20];
-  uint8_t nid[8][8];  // the 6 neighbours of every octant
-  int32_t nsl;
+  uint8_t nid[8][8];  // the 6 neighbours of every octant: x, y, z face, xy, xz, yz edge
   CxSlice sl[kCxSlices];
+  CxQuant qt[kCxSlices];
   uint32_t occ[4][32];
   uint32_t found[4][32];
   uint32_t desc[4][64];
@@ -127,6 +134,177 @@ cx_bperm_i64(int src_lane, int64_t v)
   return ((int64_t)hi << 32) | (uint32_t)lo;
 }
 
+// the neighbours child octant o predicts from (tmc3/RAHT.cpp:314-326): the face
+// and edge neighbours of the parent on the child's side.  t = 0..2 faces across x,
+// y, z; 3..5 edges xy, xz, yz.
+__device__ __forceinline__ int
+cx_neigh_id(int o, int t)
+{
+  const int x = (o >> 2) & 1, y = (o >> 1) & 1, z = o & 1;
+  switch (t) {
+  case 0: return x ? 1 : 9;
+  case 1: return y ? 2 : 11;
+  case 2: return z ? 3 : 12;
+  case 3: return x ? (y ? 4 : 17) : (y ? 15 : 7);
+  case 4: return x ? (z ? 5 : 18) : (z ? 13 : 8);
+  default: return y ? (z ? 6 : 16) : (z ? 14 : 10);
+  }
+}
+
+// Morton key with one axis moved by +1 (up) or -1: the axis' bit field (mask m) is
+// incremented / decremented modulo its width, as morton3dAdd does (PCCMisc.h:245)
+__device__ __forceinline__ uint64_t
+cx_axis_step(uint64_t k, uint64_t m, bool up)
+{
+  const uint64_t t = up ? (k | ~m) + 1 : (k & m) - 1;
+  return (t & m) | (k & ~m);
+}
+
+// sqrt(w) in Q15 and the 1/sqrt(w) normaliser of a node weight from ONE irsqrt:
+// irsqrt(w << 30) == irsqrt(w) >> 15 (the normalisation shifts in bit pairs), so
+// isqrt(w << 30) follows from irsqrt(w) for w <= 2^16 (isqrt's first branch).
+struct CxNorm {
+  int64_t sq;   // isqrt(w << 30)                  (sqrt_weight)
+  int64_t rs;   // irsqrt(w) >> (25 - shift)       (scale_rsqrt)
+  int shift;
+};
+
+__device__ __forceinline__ int64_t
+cx_sqrt_from_rsqrt(uint64_t w, uint64_t rs40, const SharedLut& L)
+{
+  if (w <= 65536)
+    return (int64_t)(1 + (((w << 30) * (rs40 >> 15)) >> 40));
+  return (int64_t)isqrt(w << (2 * kFpFrac), L.rsqrt);
+}
+
+__device__ __forceinline__ CxNorm
+cx_norm(int32_t w, const SharedLut& L)
+{
+  CxNorm r;
+  if (w < kSmallN) {
+    r.sq = L.norm_sq[w];
+    r.rs = L.norm_rs[w];
+    r.shift = 0;
+    return r;
+  }
+  const uint64_t rs40 = irsqrt((uint64_t)w, L.rsqrt);
+  r.shift = w > 1024 ? ilog2_u64((uint64_t)w - 1) >> 1 : 0;
+  r.rs = (int64_t)(rs40 >> (40 - r.shift - kFpFrac));
+  r.sq = cx_sqrt_from_rsqrt((uint64_t)w, rs40, L);
+  return r;
+}
+
+__device__ __forceinline__ int64_t
+cx_scale(int64_t v, const CxNorm& nm)
+{
+  return fp_mul_c(v >> nm.shift, nm.rs);
+}
+
+// butterfly coefficients of (wl, wr) (RahtKernel, tmc3/RAHT.cpp:596-604) given the
+// square roots of the two weights, and the square root of their sum for the next stage
+__device__ __forceinline__ void
+cx_coeffs(
+  int32_t wl, int32_t wr, int64_t sql, int64_t sqr, const SharedLut& L, int64_t* a, int64_t* b,
+  int64_t* sqw)
+{
+  const uint64_t w = (uint64_t)wl + (uint64_t)wr;
+  if (wl < kSmallW && wr < kSmallW) {
+    *a = L.bfly_a[wl * kSmallW + wr];
+    *b = L.bfly_b[wl * kSmallW + wr];
+    *sqw = L.norm_sq[w];
+    return;
+  }
+  const uint64_t rs = irsqrt(w, L.rsqrt);
+  *a = (int64_t)(((uint64_t)sql * rs) >> 40);
+  *b = (int64_t)(((uint64_t)sqr * rs) >> 40);
+  *sqw = cx_sqrt_from_rsqrt(w, rs, L);
+}
+
+// rdoq_threshold() of raht_levels.hpp with the reciprocal of lambda at hand
+__device__ __forceinline__ uint32_t
+cx_rdoq_threshold(int64_t dist2, int64_t lambda, double inv_lambda, int rate_coeff, uint32_t limit)
+{
+  const uint64_t d = (uint64_t)dist2 << 26;
+  const uint64_t lam = (uint64_t)lambda;
+  const int rc = (rate_coeff + 128) >> 8;
+  constexpr uint64_t kCap = 128;
+  uint64_t q = kCap;
+  if (d < lam * kCap) {
+    q = (uint64_t)((double)d * inv_lambda);
+    q -= q * lam > d;
+    q += (q + 1) * lam <= d;
+  }
+  const int m = (int)q - rc + 1;  // smallest rate that passes
+  if (m <= 1)
+    return 0;
+  if (m <= 2)
+    return 1;
+  if (m <= 3)
+    return 2;
+  if (m <= 5)
+    return 3;
+  if (m <= 7)
+    return 5;
+  if (m <= 9)
+    return 7;
+  if (m <= 11)
+    return 9;
+  int bb = (m - 12 + 1) >> 1;
+  bb = bb < 1 ? 1 : bb;
+  if (bb > 30)
+    return kDescNever;
+  const uint32_t tz = 10u + (1u << (bb - 1));
+  return tz > limit ? kDescNever : tz;
+}
+
+__device__ __forceinline__ void
+cx_fill_quant(ParamsConst prm, const LevelSched& e, int c, CxQuant* qt, int entry)
+{
+  int a0 = 0, a1 = 0;
+  const int pos = entry - 1;
+  if (pos >= 1 && e.ac_layer < prm->num_ac_qp_layers) {
+    a0 = prm->ac_qp_offset[e.ac_layer][pos - 1][0];
+    a1 = prm->ac_qp_offset[e.ac_layer][pos - 1][1];
+  }
+  Quantizer q[2];
+  qpset_quantizers(prm, e.qp_layer, a0, a1, q);
+  qt->q[entry][0] = q[0];
+  qt->q[entry][1] = q[1];
+  if (entry == 0) {
+    const int64_t l0 = q[0].step;
+    qt->lambda = l0 * l0 * (c == 1 ? 25 : 35);
+    qt->inv_lambda = 1.0 / (double)qt->lambda;
+  }
+}
+
+// Where a wavefront's time goes (experiment builds only, -DGPCC_CX_PROF: s_memtime
+// at the phase boundaries, lane 0, summed over all tiles; gpcc_debug_cx_prof).
+#ifdef GPCC_CX_PROF
+__device__ unsigned long long g_cx_prof[16];
+__device__ unsigned long long g_cx_prof_n[4];
+struct CxProf {
+  unsigned long long last;
+  __device__ CxProf() { last = __builtin_amdgcn_s_memtime(); }
+  __device__ void mark(int phase)
+  {
+    const unsigned long long t = __builtin_amdgcn_s_memtime();
+    if (lane_id() == 0)
+      atomicAdd(&g_cx_prof[phase], t - last);
+    last = t;
+  }
+  __device__ void count(int slot, unsigned n)
+  {
+    if (lane_id() == 0)
+      atomicAdd(&g_cx_prof[slot], (unsigned long long)n);
+  }
+};
+#else
+struct CxProf {
+  __device__ void mark(int) {}
+  __device__ void count(int, unsigned) {}
+};
+#endif
+
 template<int C, bool ENC>
 __global__ __launch_bounds__(256) void
 cx_level_kernel(CxCtx cx)
@@ -149,19 +327,18 @@ cx_level_kernel(CxCtx cx)
     uint32_t* dst = reinterpret_cast<uint32_t*>(&sm.lut);
     for (int i = threadIdx.x; i < (int)(sizeof(SharedLut) / 4); i += blockDim.x)
       dst[i] = src[i];
-    if (threadIdx.x < 19) {
+    if (threadIdx.x < 19)
       sm.pw[threadIdx.x] = prm->pred_weight_parent[threadIdx.x];
-      sm.noff[threadIdx.x] = (uint8_t)neigh_offset(threadIdx.x);
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + 48) {
+      const int o = (threadIdx.x - 64) / 6, t = (threadIdx.x - 64) % 6;
+      sm.nid[o][t] = (uint8_t)cx_neigh_id(o, t);
     }
-    if (threadIdx.x >= 64 && threadIdx.x < 72) {
-      const int o = threadIdx.x - 64;
-      int cnt = 0;
-      for (int i = 1; i < 19; i++)
-        if ((neigh_mask(i) >> o) & 1)
-          sm.nid[o][cnt++] = (uint8_t)i;
+    if (S <= kCxSlices) {
+      if ((int)threadIdx.x >= 128 && (int)threadIdx.x < 128 + S)
+        sm.sl[threadIdx.x - 128] = cx_load_slice(cx, li, threadIdx.x - 128);
+      for (int i = threadIdx.x; i < S * 9; i += blockDim.x)
+        cx_fill_quant(prm, cx.sched[i / 9].lvl[li], C, &sm.qt[i / 9], i % 9);
     }
-    if (S <= kCxSlices && (int)threadIdx.x >= 128 && (int)threadIdx.x < 128 + S)
-      sm.sl[threadIdx.x - 128] = cx_load_slice(cx, li, threadIdx.x - 128);
     __syncthreads();
   }
   const SharedLut& lut = sm.lut;
@@ -173,7 +350,9 @@ cx_level_kernel(CxCtx cx)
   const int tile = (int)blockIdx.x * 4 + wave;
   if (tile >= ntiles)
     return;
+  CxProf prof;
   const int32_t* __restrict__ bp = cx.cl.bp + tab->boff[li];
+  const int32_t* __restrict__ bc = cx.cl.bc + tab->boff[li];
   const int32_t* __restrict__ bq = cx.cl.bq + tab->boff[li] + li;
   const int32_t* __restrict__ rb = cx.cl.rb + tab->roff[li];
 
@@ -222,7 +401,7 @@ cx_level_kernel(CxCtx cx)
   const int q0 = bq[b];
   const int u = r - q0;                  // ordinal among the block's children
   const int base_lane = q0 - r0;         // lane of the block's first child
-  const int c0 = tv.fc[L][j];
+  const int c0 = bc[b];
   const int64_t pkey = tv.key[L][j];
   const uint32_t phold = cx.cl.hold[L][j];
   int s;
@@ -278,23 +457,38 @@ cx_level_kernel(CxCtx cx)
 
   // ---- inter-level prediction gating (tmc3/RAHT.cpp:1391-1432) ----------------------
   const bool pred_in_level = on && inherit_dc && prm->raht_prediction_enabled_flag != 0;
+#ifdef CX_EXP_NOSEARCH  // (experiment builds: what the neighbour search costs)
+  const bool do_search = false;
+#else
   const bool do_search = pred_in_level && pneigh >= prm->raht_prediction_threshold0;
+#endif
 
+  prof.mark(0);  // tile and child set-up
   // ---- neighbour search: the parents at the 6 positions this octant predicts from
   //      (findNeighbours, tmc3/RAHT.cpp:299-368; findNeighbour :272-293 is a
   //      lower_bound limited to raht_prediction_search_range entries either side) -----
   int nq[6];
   {
     const int64_t* __restrict__ pk = tv.key[L];
-    const uint64_t mbase = morton3d_add((uint64_t)pkey, ~0ull);
+    constexpr uint64_t mz = 0x9249249249249249ull, my = mz << 1, mx = mz << 2;
     const int64_t range = prm->raht_prediction_search_range;
     int lo[6], hi[6], end[6];
     int64_t want[6];
+    {
+      const uint64_t k = (uint64_t)pkey;
+      const uint64_t kx = cx_axis_step(k, mx, (oct & 4) != 0);
+      const uint64_t ky = cx_axis_step(k, my, (oct & 2) != 0);
+      const uint64_t kz = cx_axis_step(k, mz, (oct & 1) != 0);
+      want[0] = (int64_t)kx;
+      want[1] = (int64_t)ky;
+      want[2] = (int64_t)kz;
+      want[3] = (int64_t)((kx & ~my) | (ky & my));
+      want[4] = (int64_t)((kx & ~mz) | (kz & mz));
+      want[5] = (int64_t)((ky & ~mz) | (kz & mz));
+    }
 #pragma unroll
     for (int t = 0; t < 6; t++) {
-      const int id = sm.nid[oct][t];
-      const int64_t np = (int64_t)morton3d_add(mbase, sm.noff[id]);
-      int64_t d = np - pkey;
+      int64_t d = want[t] - pkey;
       int ga, gb;
       if (d >= 0) {
         d = d >= range ? range : d;
@@ -305,10 +499,13 @@ cx_level_kernel(CxCtx cx)
         gb = j;
         ga = (d < (int64_t)(j - sl.sp0)) ? j - (int)d : sl.sp0;
       }
-      want[t] = np;
       lo[t] = do_search ? ga : 0;
       hi[t] = end[t] = do_search ? gb : 0;
     }
+    // six lower_bounds side by side, no branch inside
+    // (a window of the parent keys staged in LDS in front of this search was
+    // measured: 19 of 20 look-ups of a lidar frame end there, but its instructions
+    // and registers -- 4 waves per SIMD instead of 5 -- cost more than the loads)
     while (__any((lo[0] < hi[0]) | (lo[1] < hi[1]) | (lo[2] < hi[2]) | (lo[3] < hi[3])
                  | (lo[4] < hi[4]) | (lo[5] < hi[5]))) {
       int mid[6];
@@ -316,33 +513,31 @@ cx_level_kernel(CxCtx cx)
 #pragma unroll
       for (int t = 0; t < 6; t++) {
         mid[t] = lo[t] + ((hi[t] - lo[t]) >> 1);
-        kv[t] = lo[t] < hi[t] ? pk[mid[t]] : 0;
+        kv[t] = pk[mid[t]];  // (a finished search reloads key[lo]: the arrays have a sentinel entry)
       }
 #pragma unroll
       for (int t = 0; t < 6; t++) {
-        if (lo[t] < hi[t]) {
-          if (kv[t] < want[t])
-            lo[t] = mid[t] + 1;
-          else
-            hi[t] = mid[t];
-        }
+        const bool act = lo[t] < hi[t];
+        const bool less = kv[t] < want[t];
+        lo[t] = (act && less) ? mid[t] + 1 : lo[t];
+        hi[t] = (act && !less) ? mid[t] : hi[t];
       }
     }
     int64_t kf[6];
 #pragma unroll
     for (int t = 0; t < 6; t++)
-      kf[t] = lo[t] < end[t] ? pk[lo[t]] : -1;
+      kf[t] = pk[lo[t]];
     uint32_t fmask = 0;
 #pragma unroll
     for (int t = 0; t < 6; t++) {
       const bool hit = lo[t] < end[t] && kf[t] == want[t];
       nq[t] = hit ? lo[t] : -1;
-      if (hit)
-        fmask |= 1u << sm.nid[oct][t];
+      fmask |= hit ? 1u << sm.nid[oct][t] : 0u;
     }
     atomicOr(&wfound[bl], fmask);
     __builtin_amdgcn_wave_barrier();
   }
+  prof.mark(1);  // search
   int neigh_count = 0;
   bool enable_pred = false;
   if (do_search) {
@@ -390,18 +585,19 @@ cx_level_kernel(CxCtx cx)
     }
   }
 
+  prof.mark(2);  // prediction gathers + sums
   // ---- normalise (tmc3/RAHT.cpp:1445-1499) -------------------------------------------
+  const CxNorm nm = cx_norm(on ? w : 1, lut);
   if (on && w > 1) {
     if (ENC) {
 #pragma unroll
       for (int k = 0; k < C; k++)
-        src[k] = scale_rsqrt(src[k], w, lut);
+        src[k] = cx_scale(src[k], nm);
     }
     if (enable_pred) {
-      const int64_t sq = sqrt_weight(w, lut);
 #pragma unroll
       for (int k = 0; k < C; k++)
-        pred[k] = fp_mul_c(pred[k], sq);
+        pred[k] = fp_mul_c(pred[k], nm.sq);
     }
   }
 
@@ -420,6 +616,7 @@ cx_level_kernel(CxCtx cx)
   }
   int pos = oct;
   int32_t cw = on ? w : 0;
+  int32_t sqw = (int32_t)nm.sq;  // isqrt(cw << 30), < 2^30
   bool st_both[3], st_left[3];
   int st_lane[3];
   int32_t st_a[3], st_b[3];
@@ -433,10 +630,11 @@ cx_level_kernel(CxCtx cx)
     const int plane = base_lane + (int)((M >> (4 * pp)) & 15u);
     const int from = partner ? plane : lane;
     const int32_t ow = __builtin_amdgcn_ds_bpermute(from << 2, cw);
+    const int32_t osq = __builtin_amdgcn_ds_bpermute(from << 2, sqw);
     const int32_t wl = left ? cw : ow, wr = left ? ow : cw;
-    int64_t ca = 0, cb = 0;
+    int64_t ca = 0, cb = 0, nsq = sqw;
     if (partner)
-      raht_coeffs(wl, wr, lut, &ca, &cb);
+      cx_coeffs(wl, wr, left ? sqw : osq, left ? osq : sqw, lut, &ca, &cb, &nsq);
     st_both[st] = partner;
     st_left[st] = left;
     st_lane[st] = from;
@@ -456,8 +654,10 @@ cx_level_kernel(CxCtx cx)
           pred[k] = left ? fp_mul_c(oth, cb) + fp_mul_c(own, ca) : fp_mul_c(own, ca) - fp_mul_c(oth, cb);
       }
     }
-    if (partner)
+    if (partner) {
       cw = wl + wr;
+      sqw = (int32_t)nsq;
+    }
     // positions after the stage
     const uint32_t Pl = P & lm, Pr = (P >> bit) & lm;
     const uint32_t moved = cx_nibbles(Pr & ~Pl);
@@ -467,6 +667,7 @@ cx_level_kernel(CxCtx cx)
     P = (Pl | Pr) | ((Pl & Pr) << bit);
   }
 
+  prof.mark(3);  // normalise + forward butterflies
   // ---- coefficient slot of this lane's position (scanBlock :776-791) -------------------
   const uint32_t pscan = ((P >> 0) & 1) | (((P >> 4) & 1) << 1) | (((P >> 2) & 1) << 2)
     | (((P >> 1) & 1) << 3) | (((P >> 6) & 1) << 4) | (((P >> 5) & 1) << 5)
@@ -479,14 +680,28 @@ cx_level_kernel(CxCtx cx)
   int32_t* __restrict__ cplane = cx.coeffs + (size_t)sl.pt0 * C + cidx;
   const int cblock = cidx - (inherit_dc ? rank - 1 : rank);  // the block's first coefficient
 
-  Quantizer qa[2];
-  {
+  Quantizer qa[2], qr[2];
+  int64_t lambda;
+  double inv_lambda;
+  if (S <= kCxSlices) {
+    const CxQuant& qt = sm.qt[s];
+    qa[0] = qt.q[1 + pos][0];
+    qa[1] = qt.q[1 + pos][1];
+    qr[0] = qt.q[0][0];
+    qr[1] = qt.q[0][1];
+    lambda = qt.lambda;
+    inv_lambda = qt.inv_lambda;
+  } else {
     int ac0 = 0, ac1 = 0;
     if (e.ac_layer < prm->num_ac_qp_layers && pos) {
       ac0 = prm->ac_qp_offset[e.ac_layer][pos - 1][0];
       ac1 = prm->ac_qp_offset[e.ac_layer][pos - 1][1];
     }
     qpset_quantizers(prm, e.qp_layer, ac0, ac1, qa);
+    qpset_quantizers(prm, e.qp_layer, 0, 0, qr);
+    const int64_t l0 = qr[0].step;
+    lambda = l0 * l0 * (C == 1 ? 25 : 35);
+    inv_lambda = 1.0 / (double)lambda;
   }
 
   int32_t qco[C];
@@ -502,8 +717,6 @@ cx_level_kernel(CxCtx cx)
         for (int k = 0; k < C; k++)
           src[k] -= pred[k];
       }
-      Quantizer qr[2];
-      qpset_quantizers(prm, e.qp_layer, 0, 0, qr);
       int64_t sum_coeff = 0, dist2 = 0;
       int rate_coeff = 0;
 #pragma unroll
@@ -518,9 +731,7 @@ cx_level_kernel(CxCtx cx)
       }
       d = kDescNever;
       if (sum_coeff < 3) {
-        const int64_t l0 = qr[0].step;
-        const int64_t lambda = l0 * l0 * (C == 1 ? 25 : 35);
-        d = rdoq_threshold(dist2, lambda, rate_coeff, (uint32_t)sl.n_s);
+        d = cx_rdoq_threshold(dist2, lambda, inv_lambda, rate_coeff, (uint32_t)sl.n_s);
         if (sum_coeff == 0)
           d |= kDescZero;
       }
@@ -529,6 +740,7 @@ cx_level_kernel(CxCtx cx)
     // ---- the zero-run state (tmc3/RAHT.cpp:1618-1669): the tile's coefficients in
     //      coding order are one chunk per slice; the incoming last reset comes from
     //      the wavefront before (look-back) or from the level before (slice_l) -----------
+    prof.mark(4);  // quantisers, residual, RDOQ statistics
     const unsigned long long ep = (unsigned long long)(li + 1) << 48;
     unsigned long long todo = __ballot(coded);
     bool zero_me = false;
@@ -566,20 +778,38 @@ cx_level_kernel(CxCtx cx)
         published = published || last_seg;
       } else {
         // (only the tile's first segment continues a slice from the tile before)
+        // The incoming last reset lies in [-1, c_first - 1] and zeroing is monotone in
+        // it: when the two extremes zero the same coefficients, every value does, and
+        // the tile neither waits for its predecessor nor can it be open.  Only a tile
+        // with an undecided coefficient (1 in 80 coefficients at qp 34), or the one
+        // that hands a transparent state on to the next level, looks back.
         const int la0 = -1, lb0 = c_first - 1;
-        const int la = rdoq_chunk(dd, ci, valid, la0, c_first, &tz);
-        const int lb = rdoq_chunk(dd, ci, valid, lb0, c_first, &tz);
+        int tza, tzb;
+        const int la = rdoq_chunk(dd, ci, valid, la0, c_first, &tza);
+        const int lb = rdoq_chunk(dd, ci, valid, lb0, c_first, &tzb);
         const int status = lb == lb0 ? kTileTransparent : (la == lb ? kTileClosed : kTileOpen);
         if (last_seg && status != kTileOpen) {
           if (lane == 0)
             __hip_atomic_store(
               &cx.tstate[tile],
-              ep | ((unsigned long long)(status == kTileClosed ? 2 : 1) << 32) | (uint32_t)la,
+              ep | ((unsigned long long)(status == kTileClosed ? 2 : 1) << 32)
+                | (uint32_t)(status == kTileClosed ? la : ncoef),
               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           published = true;
         }
-        bool have = false;
-        int k0 = tile - 1;  // lane v looks at tile k0 - v
+        const uint32_t thr0 = dd & kDescNever;
+        const bool za = valid && thr0 != kDescNever && (uint32_t)tza >= thr0;
+        const bool zb = valid && thr0 != kDescNever && (uint32_t)tzb >= thr0;
+        const bool depends = __any(za != zb);
+        prof.mark(5);  // hypotheses
+        tz = tza;
+        l_out = la;  // (closed: the state this tile leaves)
+        bool have = !depends && status != kTileOpen && !(ends && status == kTileTransparent);
+        prof.count(13, have ? 0 : 1);
+        const bool waited = !have;
+        bool exact = false;   // the incoming state itself is known (not only bounded)
+        int k0 = tile - 1;    // lane v looks at tile k0 - v
+        int run = 0;          // coefficients of the transparent tiles right before this one
         unsigned spins = 0;
         while (!have) {
           const int kt = k0 - lane;
@@ -592,6 +822,14 @@ cx_level_kernel(CxCtx cx)
           const unsigned long long decides = __ballot(ready && kind >= 2);
           const unsigned long long notready = __ballot(in && !ready);
           const unsigned long long stop = decides | notready;
+          const int firstw = stop ? __ffsll((long long)stop) - 1 : kWave;
+          // a transparent word carries the tile's coefficient count: the zero run in
+          // front of this tile is at least as long as the transparent tiles before it
+          int add = (lane < firstw && kind == 1) ? (int)(uint32_t)wv : 0;
+#pragma unroll
+          for (int dd2 = 1; dd2 < kWave; dd2 <<= 1)
+            add += __shfl_xor(add, dd2);
+          run += add;
           if (!stop) {
             k0 -= kWave;  // 64 transparent tiles: further back (the slice's first tile decides)
             if (k0 < 0) {
@@ -602,22 +840,52 @@ cx_level_kernel(CxCtx cx)
             }
             continue;
           }
-          const int firstw = __ffsll((long long)stop) - 1;
+          k0 -= firstw;
           if ((decides >> firstw) & 1) {
             l_in = (int)(uint32_t)__shfl((int)(uint32_t)wv, firstw);
             have = true;
+            exact = true;
           } else {
-            k0 -= firstw;
-            if (++spins > (1u << 22)) {
-              if (lane == 0)
-                atomicExch(tv.error, 1);
-              return;
+            // the nearest tile that is not transparent has not published yet.  The last
+            // reset is at least `run` coefficients back: if that bound already settles
+            // every coefficient of this tile, the exact state is not needed (a smooth
+            // attribute leaves long zero runs, and the rate thresholds are short)
+            const int lbx = c_first - 1 - run;
+            int tzx;
+            const int lx = rdoq_chunk(dd, ci, valid, lbx, c_first, &tzx);
+            const bool zx = valid && thr0 != kDescNever && (uint32_t)tzx >= thr0;
+            const bool settled = !__any(za != zx);
+            const bool resets = lx != lbx;  // (then la == lx: the same coefficients reset)
+            if (settled && (resets || !ends)) {
+              have = true;
+              l_out = la;
+              if (last_seg && status == kTileOpen) {
+                if (lane == 0)
+                  __hip_atomic_store(
+                    &cx.tstate[tile],
+                    ep | ((unsigned long long)(resets ? 2 : 1) << 32) | (uint32_t)(resets ? la : ncoef),
+                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                published = true;
+              }
+            } else {
+              if (++spins > (1u << 22)) {
+                if (lane == 0)
+                  atomicExch(tv.error, 1);
+                return;
+              }
+              __builtin_amdgcn_s_sleep(1);
             }
-            __builtin_amdgcn_s_sleep(2);
           }
         }
-        l_out = rdoq_chunk(dd, ci, valid, l_in, c_first, &tz);
-        if (last_seg && status == kTileOpen) {
+        prof.mark(6);  // look-back wait
+        prof.count(10, spins);
+        prof.count(11, 1);
+        if (exact)
+          l_out = rdoq_chunk(dd, ci, valid, l_in, c_first, &tz);
+        // A tile that has walked back knows the state it leaves for good: publishing
+        // it ends every later walk here (most tiles of a smooth attribute hold no
+        // reset at all, and a walk over transparent words costs a round trip per 64).
+        if (last_seg && exact) {
           if (lane == 0)
             __hip_atomic_store(
               &cx.tstate[tile], ep | (3ull << 32) | (uint32_t)l_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -652,6 +920,7 @@ cx_level_kernel(CxCtx cx)
       qco[k] = cplane[(size_t)k * sl.n_s];
   }
 
+  prof.mark(7);  // decisions, coefficient stores
   // ---- reconstruction: prediction + de-quantised residual, inherited DC ---------------
   if (!enable_pred) {
 #pragma unroll
@@ -688,11 +957,13 @@ cx_level_kernel(CxCtx cx)
       int64_t v = pred[k];
       cx.val[(size_t)cslot * C + k] = v;
       if (w > 1)
-        v = scale_rsqrt(v, w, lut);
+        v = cx_scale(v, nm);
       cx.rec[(size_t)cslot * C + k] = v;
     }
     cx.nn[cslot] = inherit_dc ? neigh_count : 19;
   }
+  prof.mark(8);  // inverse butterflies, stores
+  prof.count(12, 1);
 }
 
 }  // namespace gpcc

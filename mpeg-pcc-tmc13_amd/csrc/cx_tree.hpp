@@ -18,10 +18,12 @@
 //               child is identified by the start b of its right sibling: slot
 //               N + b.  So slot(node) = h(a) <= h(b) ? a : N + b, and the level
 //               kernels never copy a value down a chain.  hold = slot | T << 27;
-//   bp / bq / rb the blocks of every children level l in Morton order: parent index
-//               in level l + 1, rank of the block's first real child, and the
-//               block of every real-child rank -- a wavefront of the level pass
-//               takes ~56 consecutive ranks (whole blocks), lane = child.
+//   bp / bc / bq / rb  the blocks of every children level l in Morton order: parent
+//               index in level l + 1, first child (node of level l), rank of the
+//               block's first real child, and the block of every real-child rank --
+//               a wavefront of the level pass takes ~56 consecutive ranks (whole
+//               blocks), lane = child.  (They replace the first-child array fc of
+//               raht_tree.hpp, which this build does not write.)
 //
 // A point i with h(i) == l + 1 is a non-first child at level l; it is the SECOND
 // child of its block iff the head of level l before it also heads level l + 1.
@@ -49,6 +51,7 @@ struct CxLists {
   int32_t* bp;                 // [N]         all levels, level l at tab->boff[l]
   int32_t* bq;                 // [N + nlev]  level l at tab->boff[l] + l, nb[l] + 1 entries
   int32_t* rb;                 // [2 N]       level l at tab->roff[l]
+  int32_t* bc;                 // [N]         first child (node of level l) of every block, at tab->boff[l]
   CxLevelTab* tab;
   // tile tables of the count / scan / emit passes: [tile][ncol], columns
   //   [0, nlev) heads per level, [nlev, 2 nlev) non-first children per level,
@@ -113,8 +116,8 @@ cx_row_levels(const TreeView& tv, int i, int h, CxRowState& st, Visit&& visit)
     const int p = below ? 63 - __clzll((long long)below) : 0;
     const int row_a = i - lane + p;
     const int row_h = __shfl(h, p);
-    const int car_a = __shfl(st.prev_a, l);
-    const int car_h = __shfl(st.prev_h, l);
+    const int car_a = wave_bcast(st.prev_a, l);
+    const int car_h = wave_bcast(st.prev_h, l);
     const int prev_a = below ? row_a : car_a;
     const int prev_h = below ? row_h : car_h;
     const bool is_head = h > l;
@@ -123,10 +126,10 @@ cx_row_levels(const TreeView& tv, int i, int h, CxRowState& st, Visit&& visit)
     const bool is_second = is_nf && prev_h > l + 1;
     const unsigned long long nfm = l + 1 < tv.nlev ? (mask & ~mask1) : 0ull;
     const unsigned long long secm = __ballot(is_second);
-    const uint32_t heads0 = __shfl(st.heads, l);
-    const uint32_t heads1 = l + 1 < tv.nlev ? __shfl(st.heads, l + 1) : 0u;
-    const uint32_t nf0 = __shfl(st.nf, l);
-    const uint32_t blk0 = __shfl(st.blk, l);
+    const uint32_t heads0 = (uint32_t)wave_bcast((int)st.heads, l);
+    const uint32_t heads1 = l + 1 < tv.nlev ? (uint32_t)wave_bcast((int)st.heads, l + 1) : 0u;
+    const uint32_t nf0 = (uint32_t)wave_bcast((int)st.nf, l);
+    const uint32_t blk0 = (uint32_t)wave_bcast((int)st.blk, l);
     const int idx = (int)heads0 + __popcll(mask & lt);
     const int nf_before = (int)nf0 + __popcll(nfm & lt);
     const int blocks_incl = (int)blk0 + __popcll(secm & le);
@@ -141,11 +144,45 @@ cx_row_levels(const TreeView& tv, int i, int h, CxRowState& st, Visit&& visit)
       st.blk += __popcll(secm);
     }
     // (every lane needs the last head's h: one more exchange, wave-uniform source)
-    const int last_h = __shfl(h, 63 - __clzll((long long)mask));
+    const int last_h = wave_bcast(h, 63 - __clzll((long long)mask));
     if (lane == l)
       st.prev_h = last_h;
     mask = mask1;
   }
+}
+
+// Which points of a tile start a slice: normally none, or the tile's first point.
+// Only a tile that holds a slice boundary in its middle looks every point up.
+struct CxTileSlices {
+  bool simple;
+  int s0;       // slice of the tile's first point
+  int start0;   // that slice's first point (a slice start inside the tile iff == base)
+};
+
+__device__ __forceinline__ CxTileSlices
+cx_tile_slices(const TreeView& tv, int base)
+{
+  CxTileSlices ts;
+  const int b = base < tv.n_total ? base : tv.n_total - 1;
+  ts.s0 = find_slice(tv.pt_off, tv.num_slices, b);
+  ts.start0 = tv.pt_off[ts.s0];
+  ts.simple = tv.pt_off[ts.s0 + 1] >= base + kTilePoints;
+  return ts;
+}
+
+// head_levels() of raht_tree.hpp without a slice search per point
+__device__ __forceinline__ int
+cx_head_levels(const TreeView& tv, const CxTileSlices& ts, int i)
+{
+  if (!ts.simple)
+    return head_levels(tv, i);
+  if (i == ts.start0)
+    return tv.nlev;
+  const uint64_t x = (uint64_t)(tv.pos[i] ^ tv.pos[i - 1]);
+  if (!x)
+    return 0;
+  const int h = (bitlen64(x) + 2) / 3;
+  return h < tv.nlev ? h : tv.nlev;
 }
 
 // carry of a tile's first row: lane l looks the previous head of level l up
@@ -177,6 +214,7 @@ cx_count_kernel(TreeView tv, const int32_t* __restrict__ attrs, CxLists cl)
     CxRowState st;
     st.heads = st.nf = st.blk = 0;
     cx_tile_carry(tv, base, st);
+    const CxTileSlices ts = cx_tile_slices(tv, base);
     int32_t asum[C];
 #pragma unroll
     for (int k = 0; k < C; k++)
@@ -185,7 +223,7 @@ cx_count_kernel(TreeView tv, const int32_t* __restrict__ attrs, CxLists cl)
       const int i = base + r * kWave + lane;
       int h = 0;
       if (i < tv.n_total) {
-        h = head_levels(tv, i);
+        h = cx_head_levels(tv, ts, i);
         if (attrs) {
 #pragma unroll
           for (int k = 0; k < C; k++)
@@ -276,7 +314,7 @@ cx_scan_fin_kernel(TreeView tv, CxLists cl, int32_t* attr_prefix, int has_attrs)
     tv.fp[lane][m] = tv.n_total;
   }
   const int below = __shfl_up(m, 1u);
-  if (lane >= 1 && lane < nlev)
+  if (lane >= 1 && lane < nlev && tv.fc[lane])
     tv.fc[lane][m] = below;
   // exclusive prefixes over the levels
   const uint32_t nbi = wave_incl_scan_u32((uint32_t)nb);
@@ -315,6 +353,7 @@ cx_emit_kernel(
     st.nf = lane < tv.nlev ? row[tv.nlev + lane] : 0;
     st.blk = lane < tv.nlev ? row[2 * tv.nlev + lane] : 0;
     cx_tile_carry(tv, base, st);
+    const CxTileSlices ts = cx_tile_slices(tv, base);
     int32_t run[C];
     if (attrs) {
 #pragma unroll
@@ -329,11 +368,11 @@ cx_emit_kernel(
       bool start = false;
       int s = 0;
       if (in) {
-        h = head_levels(tv, i);
+        h = cx_head_levels(tv, ts, i);
         p = tv.pos[i];
         cl.h[i] = (uint8_t)h;
         if (h == tv.nlev) {
-          s = find_slice(tv.pt_off, tv.num_slices, i);
+          s = ts.simple ? ts.s0 : find_slice(tv.pt_off, tv.num_slices, i);
           start = tv.pt_off[s] == i;
         }
       }
@@ -355,7 +394,7 @@ cx_emit_kernel(
           if (is_head) {
             tv.fp[l][idx] = i;
             tv.key[l][idx] = p >> (3 * l);
-            if (l)
+            if (l && tv.fc[l])
               tv.fc[l][idx] = prev_idx;
             if (start)
               tv.soff[l][s] = idx;
@@ -372,6 +411,7 @@ cx_emit_kernel(
             if (is_second) {
               cl.rb[roff + rank - 1] = b;
               cl.bp[boff + b] = parent_idx;
+              cl.bc[boff + b] = idx - 1;  // (the node before this one starts the block)
               cl.bq[boff + l + b] = rank - 1;
             }
           }

@@ -741,7 +741,7 @@ launch_cx(
   w.tv.error = ctx->d_error;
   hipError_t e = cx_run<C>(
     st, w, ctx->d_lut, hp->num_qp_layers, d_attrs, d_coeffs, ctx->h_stats, ctx->h_cxtab,
-    [&](const char* name) { return Timer(ctx, name); },
+    [&](const char* name, int li) { return Timer(ctx, li < 0 ? name : level_name(name, li)); },
     [&]() -> hipError_t {
       hipError_t r = hipEventRecord(ctx->ev_stats, st);
       return r != hipSuccess ? r : hipEventSynchronize(ctx->ev_stats);
@@ -2819,6 +2819,24 @@ gpcc_debug_tile_prof(unsigned long long* out, int reset)
   if (reset) {
     static unsigned long long z[5 * 24 * 8] = {};
     if (hipMemcpyToSymbol(HIP_SYMBOL(gpcc::g_tile_prof), z, sizeof(z)) != hipSuccess)
+      return -1;
+  }
+  return 0;
+}
+#endif
+
+#ifdef GPCC_CX_PROF
+extern "C" int
+gpcc_debug_cx_prof(unsigned long long* out, int reset)
+{
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gpcc::g_cx_prof), sizeof(gpcc::g_cx_prof)) != hipSuccess)
+    return -1;
+  if (hipMemcpyFromSymbol(out + 16, HIP_SYMBOL(gpcc::g_cx_prof_n), sizeof(gpcc::g_cx_prof_n)) != hipSuccess)
+    return -1;
+  if (reset) {
+    static unsigned long long z[16] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(gpcc::g_cx_prof), z, sizeof(z)) != hipSuccess
+        || hipMemcpyToSymbol(HIP_SYMBOL(gpcc::g_cx_prof_n), z, sizeof(gpcc::g_cx_prof_n)) != hipSuccess)
       return -1;
   }
   return 0;

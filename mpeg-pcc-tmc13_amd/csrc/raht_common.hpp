@@ -189,6 +189,14 @@ group8_any(bool p)
   return group8_bits(p) != 0;
 }
 
+// value of lane `src` (wave-uniform) in every lane: v_readlane, where __shfl is an
+// LDS-crossbar permute
+__device__ __forceinline__ int
+wave_bcast(int v, int src)
+{
+  return __builtin_amdgcn_readlane(v, src);
+}
+
 __device__ __forceinline__ uint32_t
 wave_incl_scan_u32(uint32_t v)
 {

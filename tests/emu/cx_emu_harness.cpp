@@ -12,7 +12,7 @@ using namespace gpcc;
 
 namespace {
 struct NoProf {
-  int operator()(const char*) const { return 0; }
+  int operator()(const char*, int) const { return 0; }
 };
 }  // namespace
 
@@ -157,6 +157,8 @@ cx_emu_check_tree(int32_t num_slices, const int64_t* offsets, const int64_t* mor
     if (tv.fp[l][m] != n)
       fail("fp sentinel", l, m, tv.fp[l][m], n);
   }
+  // first child of every node (the build itself keeps it for the blocks only)
+  std::vector<std::vector<int>> fcs(nlev);
   for (int l = 1; l < nlev; l++) {
     const int m = (int)heads[l].size();
     size_t c = 0;
@@ -164,8 +166,7 @@ cx_emu_check_tree(int32_t num_slices, const int64_t* offsets, const int64_t* mor
       const int a = q < m ? heads[l][q] : n;
       while (c < heads[l - 1].size() && heads[l - 1][c] < a)
         c++;
-      if (tv.fc[l][q] != (int)c)
-        fail("fc", l, q, tv.fc[l][q], (long long)c);
+      fcs[l].push_back((int)c);
     }
   }
   // block lists of every children level
@@ -173,11 +174,13 @@ cx_emu_check_tree(int32_t num_slices, const int64_t* offsets, const int64_t* mor
     const int mp = (int)heads[l + 1].size();
     std::vector<int> ebp, ebq, erb;
     int rank = 0;
+    std::vector<int> ebc;
     for (int j = 0; j < mp; j++) {
-      const int k = tv.fc[l + 1][j + 1] - tv.fc[l + 1][j];
+      const int k = fcs[l + 1][j + 1] - fcs[l + 1][j];
       if (k < 2)
         continue;
       ebp.push_back(j);
+      ebc.push_back(fcs[l + 1][j]);
       ebq.push_back(rank);
       for (int u = 0; u < k; u++)
         erb.push_back((int)ebp.size() - 1);
@@ -199,6 +202,8 @@ cx_emu_check_tree(int32_t num_slices, const int64_t* offsets, const int64_t* mor
         fail("bp", l, (int)b, bp[b], ebp[b]);
       if (bq[b] != ebq[b])
         fail("bq", l, (int)b, bq[b], ebq[b]);
+      if (cl.bc[tab->boff[l] + b] != ebc[b])
+        fail("bc", l, (int)b, cl.bc[tab->boff[l] + b], ebc[b]);
     }
     if (bq[ebp.size()] != rank)
       fail("bq sentinel", l, (int)ebp.size(), bq[ebp.size()], rank);
@@ -208,5 +213,52 @@ cx_emu_check_tree(int32_t num_slices, const int64_t* offsets, const int64_t* mor
   }
   for (void* p : blocks)
     free(p);
+  return bad;
+}
+
+// ---- the one-irsqrt forms of the weight constants against the reference forms ---------
+extern "C" int
+cx_emu_check_coeffs(int64_t max_exhaustive, int64_t num_random, uint64_t seed)
+{
+  SharedLut* lut = (SharedLut*)malloc(sizeof(SharedLut));
+  hipLaunchKernelGGL(lut_init_kernel, dim3(1), dim3(256), 0, nullptr, lut);
+  int bad = 0;
+  auto fail = [&](const char* what, long long w1, long long w2, long long got, long long want) {
+    if (bad++ < 10)
+      fprintf(stderr, "coeff check: %s (%lld, %lld): got %lld want %lld\n", what, w1, w2, got, want);
+  };
+  for (int64_t w = 1; w <= max_exhaustive; w++) {
+    const CxNorm nm = cx_norm((int32_t)w, *lut);
+    if (nm.sq != sqrt_weight((int32_t)w, *lut))
+      fail("sqrt_weight", w, 0, nm.sq, sqrt_weight((int32_t)w, *lut));
+    const int64_t v = 123456789 + 7919 * w;
+    if (w > 1 && cx_scale(v, nm) != scale_rsqrt(v, (int32_t)w, *lut))
+      fail("scale_rsqrt", w, 0, cx_scale(v, nm), scale_rsqrt(v, (int32_t)w, *lut));
+    if (w > 1 && cx_scale(-v, nm) != scale_rsqrt(-v, (int32_t)w, *lut))
+      fail("scale_rsqrt(-)", w, 0, cx_scale(-v, nm), scale_rsqrt(-v, (int32_t)w, *lut));
+  }
+  uint64_t x = seed | 1;
+  auto rnd = [&]() {
+    x ^= x << 13;
+    x ^= x >> 7;
+    x ^= x << 17;
+    return x;
+  };
+  for (int64_t it = 0; it < num_random; it++) {
+    // weights of every magnitude up to 2^28, small ones often
+    const int sh1 = (int)(rnd() % 28), sh2 = (int)(rnd() % 28);
+    const int32_t wl = (int32_t)(1 + rnd() % ((1ull << sh1) + 1));
+    const int32_t wr = (int32_t)(1 + rnd() % ((1ull << sh2) + 1));
+    if ((int64_t)wl + wr >= (1ll << 29))
+      continue;
+    int64_t a0, b0, a1, b1, sq;
+    raht_coeffs(wl, wr, *lut, &a0, &b0);
+    cx_coeffs(wl, wr, sqrt_weight(wl, *lut), sqrt_weight(wr, *lut), *lut, &a1, &b1, &sq);
+    if (a0 != a1 || b0 != b1)
+      fail("a/b", wl, wr, a1 * 100000 + b1, a0 * 100000 + b0);
+    if (sq != sqrt_weight(wl + wr, *lut))
+      fail("sqrt of the sum", wl, wr, sq, sqrt_weight(wl + wr, *lut));
+  }
+  free(lut);
   return bad;
 }

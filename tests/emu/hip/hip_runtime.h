@@ -197,6 +197,13 @@ inline int emu_builtin_amdgcn_ds_permute(int site, int addr, int v)
       r = (int)(uint32_t)s[i];
   return r;
 }
+inline int emu_builtin_amdgcn_readlane(int site, int v, int src)
+{
+  const uint64_t* s;
+  uint64_t act;
+  emu::wave_exchange(emu::kOpShfl | (site << 8), (uint32_t)v, &s, &act);
+  return (int)(uint32_t)s[src & 63];
+}
 inline int emu_builtin_amdgcn_readfirstlane(int site, int v)
 {
   const uint64_t* s;
@@ -239,6 +246,7 @@ inline int emu_builtin_amdgcn_update_dpp(int site, int old, int src, int ctrl, i
 #define __shfl_down(...) emu_shfl_down(__LINE__, __VA_ARGS__)
 #define __builtin_amdgcn_ds_bpermute(...) emu_builtin_amdgcn_ds_bpermute(__LINE__, __VA_ARGS__)
 #define __builtin_amdgcn_ds_permute(...) emu_builtin_amdgcn_ds_permute(__LINE__, __VA_ARGS__)
+#define __builtin_amdgcn_readlane(...) emu_builtin_amdgcn_readlane(__LINE__, __VA_ARGS__)
 #define __builtin_amdgcn_readfirstlane(...) emu_builtin_amdgcn_readfirstlane(__LINE__, __VA_ARGS__)
 #define __builtin_amdgcn_update_dpp(...) emu_builtin_amdgcn_update_dpp(__LINE__, __VA_ARGS__)
 // wave_barrier: a scheduling fence on hardware (the LDS executes a wavefront's

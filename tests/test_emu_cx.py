@@ -1,0 +1,106 @@
+"""CPU tier: the compact level pass (mpeg-pcc-tmc13_amd/csrc/cx_*.hpp) run under the
+lock-step wavefront emulator of tests/emu -- the same kernel sources and launch
+sequence the gfx950 library uses, every thread a fiber -- against the oracle and the
+committed golden vectors.  Pins the index arithmetic, the block lists, the in-pass
+RDOQ hand-off and the one-irsqrt weight constants before a GPU is involved; the
+`-m gpu` tests remain the parity tests proper (test_gpu_raht.py, test_gpu_tile.py)."""
+import numpy as np
+import pytest
+
+import emu_loader as emu
+import oracle_loader as ol
+import raht_cases as rc
+from mpeg_pcc_tmc13_amd import raht_params, synth
+
+ELIGIBLE = [c for c in rc.CASES
+            if c["qp_region"] is None and c["gen"][1].get("n", 0) <= 20000
+            and emu.supported(rc.make_inputs(c)[0], 1)]
+
+
+def test_case_table_has_eligible_cases():
+    assert len(ELIGIBLE) >= 6
+
+
+@pytest.mark.parametrize("case", ELIGIBLE, ids=[c["name"] for c in ELIGIBLE])
+def test_emulated_kernels_match_the_oracle(case):
+    p, morton, attrs, _ = rc.make_inputs(case)
+    o_co, o_rec = ol.oracle().raht_forward(p, morton, attrs)
+    co, rec = emu.forward(p, morton, attrs)
+    assert np.array_equal(co, o_co)
+    assert np.array_equal(rec, o_rec)
+    assert np.array_equal(emu.inverse(p, morton, o_co, attrs.shape[1]), o_rec)
+
+
+VARIANTS = [dict(search_range=8), dict(threshold0=4, threshold1=10), dict(weights=(4, 2, 1, 3, 1)),
+            dict(layers=[(30, -1), (34, -2), (38, 0), (28, 1)]),
+            dict(ac_offsets=[[(i - 3, 3 - i) for i in range(7)], [(2, 1)] * 7, [(-4, 0)] * 7]),
+            dict(qp=40, bitdepth=10), dict(qp=10), dict(prediction=False, qp=28)]
+
+
+@pytest.mark.parametrize("vi", range(len(VARIANTS)))
+@pytest.mark.parametrize("c", [1, 3])
+def test_parameter_variants(vi, c):
+    kw = dict(VARIANTS[vi])
+    kw.setdefault("subnode", False)
+    xyz, attrs = synth.random_cloud(n=1500 + 100 * vi, seed=20 + vi, bits=5, c=c,
+                                    dup_fraction=0.1 if vi % 2 else 0.0, bitdepth=kw.get("bitdepth", 8))
+    morton, attrs, _ = synth.sort_by_morton(xyz, attrs)
+    p = raht_params(**kw)
+    o_co, o_rec = ol.oracle().raht_forward(p, morton, attrs)
+    co, rec = emu.forward(p, morton, attrs)
+    assert np.array_equal(co, o_co) and np.array_equal(rec, o_rec)
+    assert np.array_equal(emu.inverse(p, morton, o_co, c), o_rec)
+
+
+def _batch(sizes, c, seed):
+    parts = []
+    for i, n in enumerate(sizes):
+        if c == 1 and i % 3 == 0:
+            xyz, a = synth.lidar_cloud(int(n), seed=seed + i)
+        else:
+            xyz, a = synth.random_cloud(n=int(n), seed=seed + i, bits=2 + i % 4, c=c,
+                                        dup_fraction=0.2 if i % 2 else 0.0)
+        m, a, _ = synth.sort_by_morton(xyz[:n], a[:n])
+        parts.append((m, a))
+    morton = np.concatenate([m for m, _ in parts])
+    attrs = np.concatenate([a for _, a in parts])
+    offs = np.concatenate([[0], np.cumsum([len(m) for m, _ in parts])])
+    return parts, morton, attrs, offs
+
+
+@pytest.mark.parametrize("sizes,c", [([1, 2, 3, 700, 57, 64, 5000, 1, 333, 9, 2100], 1),
+                                     (list(np.random.default_rng(5).integers(1, 40, size=150)), 3)],
+                         ids=["ragged11", "tiny150"])
+def test_ragged_batches(sizes, c):
+    """slices of 1..5000 points in one batch (more than 64 slices: the plans are read
+    from memory instead of LDS), every slice against the oracle"""
+    p = raht_params(subnode=False, search_range=2500)
+    parts, morton, attrs, offs = _batch(sizes, c, 30)
+    co, rec = emu.forward(p, morton, attrs, offsets=offs)
+    dec_in = np.zeros_like(co)
+    for i, (m, a) in enumerate(parts):
+        o_co, o_rec = ol.oracle().raht_forward(p, m, a)
+        s0, s1 = int(offs[i]), int(offs[i + 1])
+        assert np.array_equal(co[c * s0:c * s1], o_co), f"slice {i}"
+        assert np.array_equal(rec[s0:s1], o_rec), f"slice {i}"
+        dec_in[c * s0:c * s1] = o_co
+    assert np.array_equal(emu.inverse(p, morton, dec_in, c, offsets=offs), rec)
+
+
+@pytest.mark.parametrize("n,bits,slices", [(1000, 12, 1), (5000, 30, 1), (3000, 9, 3), (70000, 36, 2),
+                                           (2500, 54, 1), (5000, 20, 40), (4000, 10, 300)])
+def test_tree_and_block_lists(n, bits, slices):
+    """level arrays, head levels, value slots and the block lists of cx_tree.hpp against
+    a direct computation (random codes incl. duplicates, several slices)"""
+    rng = np.random.default_rng(n + bits)
+    m = rng.integers(0, 1 << bits, size=n, dtype=np.int64)
+    offs = [n * s // slices for s in range(slices + 1)]
+    for s in range(slices):
+        m[offs[s]:offs[s + 1]].sort()
+    assert emu.check_tree(m, offs, bits) == 0
+
+
+def test_weight_constants_from_one_irsqrt():
+    """cx_norm / cx_coeffs (one irsqrt per weight, irsqrt(w << 30) == irsqrt(w) >> 15)
+    against sqrt_weight / scale_rsqrt / raht_coeffs of raht_levels.hpp"""
+    assert emu.lib().cx_emu_check_coeffs(70000, 300000, 12345) == 0
