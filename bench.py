@@ -253,10 +253,10 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "int64 (Q15 fixed point), int32 I/O",
         "data": "synthetic",
         "config": {
-            "workload": f"RAHT {dir_name}, {args.frames}x{args.points}-point Morton-sorted "
-                        f"S-{args.cloud} frame(s) per GPU, C={c}, "
-                        + ("integer Haar qp 4" if args.haar else f"qp {args.qp}")
-                        + f", raht_prediction=1, raht_subnode_prediction={int(args.subnode)}, raht_extension=1",
+            # (flag state first, <= 120 characters: the driver's parsed copy keeps 128)
+            "workload": f"subnode={int(args.subnode)} pred=1 ext=1 "
+                        + ("haar qp4" if args.haar else f"qp{args.qp}")
+                        + f": RAHT {dir_name}, {args.frames}x{args.points} Morton-sorted S-{args.cloud}/GPU, C={c}",
             "points_per_gpu_per_step": n, "frames_per_gpu": args.frames,
             "roundtrip_decoder_equals_encoder_recon": roundtrip_ok,
         },
@@ -314,6 +314,14 @@ def main():
         if not args.no_extras:
             out["raht_forward_10M"] = forward_10m(torch, dev, ctx, params_for, frames)
             out["hbm_calibration"] = hbm_calibration(torch, dev)
+            # the same fractions against what a plain copy reaches on THIS box
+            cal = out["hbm_calibration"]["copy_GBps"]
+            rl = [out.get("roofline")] + [out["raht_forward_10M"].get(k, {}).get("roofline") for k in ("subnode_0", "subnode_1")]
+            for r in rl:
+                if r:
+                    r["frac_calibrated"] = round(r["achieved"] / cal, 5)
+                    r["pipeline_frac_calibrated"] = round(r["pipeline_achieved"] / cal, 5)
+            out["host_tier"] = host_tier_leg(ctx, frames[0], p)
             out["lifting"] = lifting_leg(ctx, args)
             out["predicting"] = predicting_leg(ctx, args)
         if not args.no_cpu_baseline:
@@ -401,7 +409,40 @@ def forward_10m(torch, dev, ctx, params_for, first_frames):
             "kernel_ms": {k_: round(v[0], 4) for k_, v in sorted(kt.items(), key=lambda kv: -kv[1][0])},
         }
         del b
+    # throughput against the number of slices in flight (the
+    # per-frame dependency chains overlap across slices; the asymptote is what a
+    # node full of slices sees)
+    curve = {}
+    for sub in (1, 0):
+        p = params_for("lidar", sub)
+        pts = []
+        for nf in (1, 2, 5, 10):
+            b = Batch(torch, dev, ctx, frames[:nf], p)
+            tf = timed(torch, dev, b.forward, 3, warmup=1)
+            ti = timed(torch, dev, b.inverse, 3, warmup=1)
+            pts.append({"slices": nf, "forward_ms": round(tf * 1e3, 3), "inverse_ms": round(ti * 1e3, 3),
+                        "forward_Mpts": round(b.n / tf / 1e6, 1), "inverse_Mpts": round(b.n / ti / 1e6, 1)})
+            del b
+        curve[f"subnode_{sub}"] = pts
+    res["batch_curve"] = curve
     return res
+
+
+def host_tier_leg(ctx, frame, p):
+    """What a caller of the reference's free functions sees (SURVEY.md 8(d) item i): the
+    HOST tier on the headline frame -- pageable host buffers in, host buffers out, PCIe
+    copies and the synchronisation included.  Never `value`."""
+    morton, attrs, _ = frame
+    ctx.raht_forward(p, morton, attrs)  # warm-up (pool, arena)
+    t0 = time.perf_counter()
+    co, rec = ctx.raht_forward(p, morton, attrs)
+    t1 = time.perf_counter()
+    ctx.raht_inverse(p, morton, co, attrs.shape[1])
+    t2 = time.perf_counter()
+    n = len(morton)
+    return {"forward_ms": round((t1 - t0) * 1e3, 3), "inverse_ms": round((t2 - t1) * 1e3, 3),
+            "Mpoints_per_s_fwd_inv": round(n / (t2 - t0) / 1e6, 2),
+            "note": "gpcc_raht_forward / gpcc_raht_inverse on host buffers: H2D + transform + D2H, synchronous"}
 
 
 def hbm_calibration(torch, dev):

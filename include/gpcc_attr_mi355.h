@@ -410,7 +410,10 @@ int gpcc_pred_forward(
  * gpcc_lift_encode_attr / gpcc_lift_decode_attr: AttributeLods::generate
  * (with blendWeights when the APS asks for it) and the transform in one call,
  * the predictors never leave the device.  pred: in tools / QP; out num_lods,
- * num_points_in_lod of the structure that was built. */
+ * num_points_in_lod of the structure that was built.  Region QP offsets are
+ * taken as zero by these one-call entries and by gpcc_dev_pred_* (a slice with a
+ * region QP box goes through gpcc_lod_build + gpcc_pred_forward / _inverse, which
+ * take qp_off).  The encoder with direct predictors: GPCC_ERR_UNSUPPORTED (above). */
 int gpcc_pred_encode_attr(
   gpcc_ctx* ctx, const gpcc_lod_params* lod, gpcc_pred_params* pred,
   const int32_t* xyz, int32_t* attrs, int32_t* values, int8_t* icp_coeffs,

@@ -1210,6 +1210,16 @@ struct PredDev {
   int32_t *attrs, *values;
 };
 
+// the one predicting-transform configuration the device encoder declines
+int
+pred_encoder_unsupported()
+{
+  return fail(
+    GPCC_ERR_UNSUPPORTED,
+    "the encoder's choice among direct predictors is a serial scan (running rate model): "
+    "it stays on the reference CPU path");
+}
+
 int
 check_pred_params(const gpcc_pred_params* p, int n, int c, bool encoder)
 {
@@ -1235,10 +1245,7 @@ check_pred_params(const gpcc_pred_params* p, int n, int c, bool encoder)
   if (p->max_num_detail_levels < p->num_lods || p->max_num_detail_levels > GPCC_MAX_LODS)
     return fail(GPCC_ERR_INVALID_ARG, "max_num_detail_levels out of range");
   if (encoder && p->max_num_direct_predictors)
-    return fail(
-      GPCC_ERR_UNSUPPORTED,
-      "the encoder's choice among direct predictors is a serial scan (running rate model): "
-      "it stays on the reference CPU path");
+    return pred_encoder_unsupported();
   return GPCC_OK;
 }
 
@@ -2342,7 +2349,7 @@ pred_attr_driver(
   if (!pred || !attrs || !values || (c != 1 && c != 3))
     return fail(GPCC_ERR_INVALID_ARG, "null buffer or attribute count not 1 / 3");
   if (encoder && pred->max_num_direct_predictors)
-    return check_pred_params(pred, 1, c, true);  // unsupported, before any work
+    return pred_encoder_unsupported();  // before any work (num_lods is an output here: not validated)
   const bool icp_on = c == 3 && pred->inter_component_prediction_enabled_flag;
   if (icp_on && !icp)
     return fail(GPCC_ERR_INVALID_ARG, "icp_coeffs is null");
@@ -3288,7 +3295,7 @@ dev_pred_attr(
     return fail(GPCC_ERR_INVALID_ARG, "null buffer or attribute count not 1 / 3");
   for (int s = 0; s < num_slices; s++) {
     if (encoder && pred[s].max_num_direct_predictors)
-      return check_pred_params(pred + s, 1, c, true);  // unsupported, before any work
+      return pred_encoder_unsupported();  // before any work
     if (c == 3 && pred[s].inter_component_prediction_enabled_flag && !icp)
       return fail(GPCC_ERR_INVALID_ARG, "icp_coeffs is null");
   }
@@ -3575,8 +3582,15 @@ multi_transform(
     // gather on device 0 (behind each device's transform, on its stream)
     auto& root = m->part[0];
     hipStream_t st0 = m->ctx[0]->stream;
+    // every ncclResult is kept: a failed enqueue (a communicator that went bad after a
+    // device error) must not let the host download an ungathered buffer as a result
+    int nccl_err = 0;
+    auto nccl = [&](int r) {
+      if (r && !nccl_err)
+        nccl_err = r;
+    };
     if (!m->comm.empty())
-      m->rccl.GroupStart();
+      nccl(m->rccl.GroupStart());
     for (int d = 1; d < nd; d++) {
       auto& p = m->part[d];
       const int64_t b = offsets[p.s0], np = offsets[p.s1] - b;
@@ -3584,11 +3598,11 @@ multi_transform(
         continue;
       hipStream_t st = m->ctx[d]->stream;
       if (!m->comm.empty()) {
-        m->rccl.Send(p.d_a, (size_t)np * c, kNcclInt32, 0, m->comm[d], st);
-        m->rccl.Recv(root.d_a + b * c, (size_t)np * c, kNcclInt32, d, m->comm[0], st0);
+        nccl(m->rccl.Send(p.d_a, (size_t)np * c, kNcclInt32, 0, m->comm[d], st));
+        nccl(m->rccl.Recv(root.d_a + b * c, (size_t)np * c, kNcclInt32, d, m->comm[0], st0));
         if (encoder) {
-          m->rccl.Send(p.d_c, (size_t)np * c, kNcclInt32, 0, m->comm[d], st);
-          m->rccl.Recv(root.d_c + b * c, (size_t)np * c, kNcclInt32, d, m->comm[0], st0);
+          nccl(m->rccl.Send(p.d_c, (size_t)np * c, kNcclInt32, 0, m->comm[d], st));
+          nccl(m->rccl.Recv(root.d_c + b * c, (size_t)np * c, kNcclInt32, d, m->comm[0], st0));
         }
       } else {
         // one physical device behind several entries: a copy on the producer's stream
@@ -3599,9 +3613,9 @@ multi_transform(
       }
     }
     if (!m->comm.empty()) {
-      const int e = m->rccl.GroupEnd();
-      if (e)
-        return fail(GPCC_ERR_HIP, std::string("RCCL gather: ") + m->rccl.GetErrorString(e));
+      nccl(m->rccl.GroupEnd());  // (the group is closed even after a failed enqueue)
+      if (nccl_err)
+        return fail(GPCC_ERR_HIP, std::string("RCCL gather: ") + m->rccl.GetErrorString(nccl_err));
     }
     // every device done and error free, then one download from device 0
     for (int d = nd - 1; d >= 0; d--) {
@@ -3731,11 +3745,13 @@ binarise_symbols(
   const int nblk = (num_symbols + 1 + kBinBlock - 1) / kBinBlock;
   int32_t *d_runs = nullptr, *d_vals = nullptr, *d_cnt = nullptr, *d_blk = nullptr;
   uint8_t* d_bins = nullptr;
+  long long* d_base = nullptr;
   auto cleanup = [&]() {
     pool_free(ctx, d_runs);
     pool_free(ctx, d_vals);
     pool_free(ctx, d_cnt);
     pool_free(ctx, d_blk);
+    pool_free(ctx, d_base);
     pool_free(ctx, d_bins);
   };
   auto run = [&]() -> int {
@@ -3743,6 +3759,7 @@ binarise_symbols(
     HIP_TRY(pool_malloc(ctx, (void**)&d_vals, sizeof(int32_t) * (m + 1) * c));
     HIP_TRY(pool_malloc(ctx, (void**)&d_cnt, sizeof(int32_t) * (m + 1)));
     HIP_TRY(pool_malloc(ctx, (void**)&d_blk, sizeof(int32_t) * ((size_t)nblk + 1)));
+    HIP_TRY(pool_malloc(ctx, (void**)&d_base, sizeof(long long) * ((size_t)nblk + 1)));
     if (m) {
       HIP_TRY(hipMemcpyAsync(d_runs, runs, sizeof(int32_t) * m, hipMemcpyHostToDevice, st));
       HIP_TRY(hipMemcpyAsync(d_vals, values, sizeof(int32_t) * m * c, hipMemcpyHostToDevice, st));
@@ -3750,10 +3767,10 @@ binarise_symbols(
     {
       Timer t(ctx, "bins_count");
       bins_count_kernel<<<nblk, kBinBlock, 0, st>>>(num_symbols, d_runs, d_vals, trailing_run, c, d_cnt, d_blk);
-      bins_scan_kernel<<<1, 1024, 0, st>>>(nblk, d_blk, d_blk + nblk);
+      bins_scan_kernel<<<1, 1024, 0, st>>>(nblk, d_blk, d_base);
     }
-    int32_t total = 0;
-    HIP_TRY(hipMemcpyAsync(&total, d_blk + nblk, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    long long total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, d_base + nblk, sizeof(long long), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     *num_bins = total;
     if (total > cap)
@@ -3765,7 +3782,7 @@ binarise_symbols(
     HIP_TRY(pool_malloc(ctx, (void**)&d_bins, (size_t)total));
     {
       Timer t(ctx, "bins_emit");
-      bins_emit_kernel<<<nblk, kBinBlock, 0, st>>>(num_symbols, d_runs, d_vals, trailing_run, c, d_cnt, d_blk, d_bins);
+      bins_emit_kernel<<<nblk, kBinBlock, 0, st>>>(num_symbols, d_runs, d_vals, trailing_run, c, d_cnt, d_base, d_bins);
     }
     HIP_TRY(hipMemcpyAsync(bins, d_bins, (size_t)total, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));

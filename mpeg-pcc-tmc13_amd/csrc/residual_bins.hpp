@@ -183,31 +183,32 @@ bins_count_kernel(
 
 // pass 2: exclusive scan of the block sums (one workgroup)
 __global__ __launch_bounds__(1024) void
-bins_scan_kernel(int nblocks, int32_t* block_sum, int32_t* total)
+bins_scan_kernel(int nblocks, const int32_t* __restrict__ block_sum, long long* __restrict__ block_base)
 {
-  __shared__ int part[1024];
+  // (a block holds at most 256 symbols' decisions: its sum fits 32 bits; the running
+  // total of a long colour stream does not -- offsets and total are 64 bit)
+  __shared__ long long part[1024];
   const int per = (nblocks + 1023) / 1024;
   const int b0 = threadIdx.x * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
-  int sum = 0;
+  long long sum = 0;
   for (int b = b0; b < b1; b++)
     sum += block_sum[b];
   part[threadIdx.x] = sum;
   __syncthreads();
   if (threadIdx.x == 0) {
-    int run = 0;
+    long long run = 0;
     for (int i = 0; i < 1024; i++) {
-      const int v = part[i];
+      const long long v = part[i];
       part[i] = run;
       run += v;
     }
-    *total = run;
+    block_base[nblocks] = run;  // the total
   }
   __syncthreads();
-  int run = part[threadIdx.x];
+  long long run = part[threadIdx.x];
   for (int b = b0; b < b1; b++) {
-    const int v = block_sum[b];
-    block_sum[b] = run;
-    run += v;
+    block_base[b] = run;
+    run += block_sum[b];
   }
 }
 
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(kBinBlock) void
 bins_emit_kernel(
   int num_symbols, const int32_t* __restrict__ runs, const int32_t* __restrict__ values,
   int trailing_run, int c, const int32_t* __restrict__ counts,
-  const int32_t* __restrict__ block_base, uint8_t* __restrict__ bins)
+  const long long* __restrict__ block_base, uint8_t* __restrict__ bins)
 {
   __shared__ int wsum[kBinBlock / 64];
   const int k = blockIdx.x * kBinBlock + threadIdx.x;
@@ -233,7 +234,7 @@ bins_emit_kernel(
   if (lane == 63)
     wsum[threadIdx.x >> 6] = inc;
   __syncthreads();
-  int off = block_base[blockIdx.x] + inc - cnt;
+  long long off = block_base[blockIdx.x] + inc - cnt;
   for (int w = 0; w < (int)(threadIdx.x >> 6); w++)
     off += wsum[w];
   if (k <= num_symbols && cnt) {
