@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define GPCC_ABI_VERSION 3
+#define GPCC_ABI_VERSION 4
 #define GPCC_MAX_POINTS (1 << 29) /* 32-bit device indices, stride <= 3 */
 
 #define GPCC_MAX_QP_LAYERS 32
@@ -562,6 +562,58 @@ int gpcc_multi_raht_inverse(
   gpcc_multi* m, const gpcc_raht_params* params, int32_t num_slices,
   const int64_t* offsets, const int64_t* morton, int32_t* attrs,
   const int32_t* coeffs, int32_t c);
+
+/* ------------------------------------------------------------------ */
+/* attribute transfer ("recolouring") onto a re-quantised geometry       */
+
+/* RecolourParams (tmc3/pointset_processing.h:47-63) + the attribute's bit depth
+ * (AttributeDescription::bitdepth, hls.h:286-299).  The reference's defaults
+ * (TMC3.cpp:1501-1550): search_range 1, 8 / 1 neighbours, distance-weighted
+ * averages, dist offsets 4, every max_*_dist2 1000 (>= 512 means "no limit"),
+ * skip_avg_if_identical_fwd 1, _bwd 0. */
+typedef struct gpcc_recolour_params {
+  double dist_offset_fwd, dist_offset_bwd;
+  double max_geometry_dist2_fwd, max_geometry_dist2_bwd;
+  double max_attribute_dist2_fwd, max_attribute_dist2_bwd;
+  int32_t search_range;
+  int32_t num_neighbours_fwd, num_neighbours_bwd; /* 1 .. 8 each */
+  int32_t use_dist_weighted_avg_fwd, use_dist_weighted_avg_bwd;
+  int32_t skip_avg_if_identical_fwd, skip_avg_if_identical_bwd;
+  int32_t bitdepth;
+} gpcc_recolour_params;
+
+/* Replaces pcc::recolour (pointset_processing.h:138-144,
+ * pointset_processing.cpp:926-957 -> recolourColour :253-594 for c == 3,
+ * recolourReflectance :618-916 for c == 1), called by the encoder after geometry
+ * quantisation (tmc3/encoder.cpp: the attributes of the source cloud are
+ * transferred to the points of the coded geometry).
+ *   src_xyz [ns][3], src_attrs [ns][c]   the source cloud (values 0 .. 65535)
+ *   tgt_xyz [nt][3]                      the target positions
+ *   tgt_attrs [nt][c]                    out
+ *   source_to_target_scale, target_to_source_offset[3]:
+ *     posInTgt = posInSrc * scale - offset (the reference passes the scale as float)
+ * Forward: the K nearest source points of every target point (exact, squared
+ * distances in double exactly as nanoflann's L2 adaptor sums them); backward:
+ * every source point is appended to the list of its nearest target points; then
+ * the blend and the +-search_range refinement of pointset_processing.cpp.
+ * PARITY: all arithmetic is the reference's (double, same order) and the
+ * neighbour SETS are exact; what differs is the choice among EQUIDISTANT
+ * candidates -- nanoflann keeps whichever its k-d tree visits first, std::sort
+ * leaves equal distances in an unspecified order; this library orders ties by
+ * point index.  Results are identical wherever no tie decides (K-th place of the
+ * forward search, nearest place of the backward search, truncation of a backward
+ * list) and within the spread of the tied candidates' attributes elsewhere;
+ * oracle/recolour_oracle.c is the bit-exact statement of this rule
+ * (tests/test_gpu_recolour.py).  Needs ns >= num_neighbours_fwd and
+ * nt >= num_neighbours_bwd (else GPCC_ERR_UNSUPPORTED); a finite
+ * max_geometry_dist2_fwd (< 512) is GPCC_ERR_UNSUPPORTED as well: the reference then
+ * shrinks its result vectors for every LATER target point too (they live outside
+ * its loop, :292-309), state that is not reproduced.  Host tier. */
+int gpcc_recolour(
+  gpcc_ctx* ctx, const gpcc_recolour_params* params, const int32_t* src_xyz,
+  const int32_t* src_attrs, int32_t ns, const int32_t* tgt_xyz, int32_t nt,
+  int32_t c, float source_to_target_scale, const int32_t target_to_source_offset[3],
+  int32_t* tgt_attrs);
 
 #ifdef __cplusplus
 }

@@ -5,8 +5,8 @@ loaded under the importable alias ``mpeg_pcc_tmc13_amd`` by
 ``__graft_entry__.load_package()`` / ``tests/conftest.py``.
 """
 from . import params, synth  # noqa: F401
-from .params import (LiftParams, LodParams, PredParams, RahtParams, lift_params, lod_params, pred_params,  # noqa: F401
-                     raht_params)
+from .params import (LiftParams, LodParams, PredParams, RahtParams, RecolourParams, lift_params,  # noqa: F401
+                     lod_params, pred_params, raht_params, recolour_params)
 
 
 def context(device=0, stream=None):

@@ -46,6 +46,7 @@
 #include "pred_kernels.hpp"
 #include "morton_sort.hpp"
 #include "residual_bins.hpp"
+#include "recolour_kernels.hpp"
 
 using namespace gpcc;
 
@@ -3803,4 +3804,217 @@ gpcc_binarise_symbols(
   return counted(
     ctx, binarise_symbols(ctx, runs, values, num_symbols, trailing_run, c, bins, cap, num_bins),
     num_symbols);
+}
+
+// ---- attribute transfer onto a re-quantised geometry (recolour_kernels.hpp) -----------
+namespace {
+
+// inclusive scan of a[0 .. n) in place
+int
+rc_scan(gpcc_ctx* ctx, int32_t* a, size_t n, long long* sums)
+{
+  hipStream_t st = ctx->stream;
+  const int nblk = (int)((n + kRcScanBlock - 1) / kRcScanBlock);
+  rc_scan_sums_kernel<<<nblk, 256, 0, st>>>(a, n, sums);
+  rc_scan_blocks_kernel<<<1, 1024, 0, st>>>(sums, nblk);
+  rc_scan_apply_kernel<<<nblk, 256, 0, st>>>(a, n, sums);
+  HIP_TRY(hipGetLastError());
+  return GPCC_OK;
+}
+
+// cell side of a cloud's table: the smallest for which it has at most ~4 cells per point
+void
+rc_plan_grid(const int32_t box[6], int n, RcGrid* g, size_t* cells_out)
+{
+  int shift = 0;
+  for (;; shift++) {
+    double cells = 1;
+    for (int k = 0; k < 3; k++)
+      cells *= (double)((box[3 + k] >> shift) - (box[k] >> shift) + 1);
+    if (cells <= 4.0 * n + 64)
+      break;
+  }
+  g->shift = shift;
+  g->n = n;
+  size_t cells = 1;
+  for (int k = 0; k < 3; k++) {
+    g->lo[k] = box[k] >> shift;
+    g->dim[k] = (box[3 + k] >> shift) - g->lo[k] + 1;
+    cells *= (size_t)g->dim[k];
+  }
+  *cells_out = cells;
+}
+
+int
+recolour_impl(
+  gpcc_ctx* ctx, const gpcc_recolour_params* p, const int32_t* src_xyz, const int32_t* src_attrs,
+  int32_t ns, const int32_t* tgt_xyz, int32_t nt, int32_t c, float scale, const int32_t* offset,
+  int32_t* tgt_attrs)
+{
+  if (!ctx)
+    return fail(GPCC_ERR_INVALID_ARG, "ctx is null");
+  if (!p || !src_xyz || !src_attrs || !tgt_xyz || !tgt_attrs || !offset || ns <= 0 || nt <= 0
+      || (c != 1 && c != 3))
+    return fail(GPCC_ERR_INVALID_ARG, "null buffer, empty cloud or attribute count not 1 / 3");
+  if (ns > (1 << 27) || nt > (1 << 27))
+    return fail(GPCC_ERR_INVALID_ARG, "more than 2^27 points");
+  const int kf = p->num_neighbours_fwd, kb = p->num_neighbours_bwd;
+  if (kf < 1 || kf > kRcMaxK || kb < 1 || kb > kRcMaxK || p->bitdepth < 1 || p->bitdepth > 16
+      || p->search_range < 0 || !(scale > 0))
+    return fail(GPCC_ERR_INVALID_ARG, "neighbour counts must be 1..8, bitdepth 1..16, scale > 0");
+  if (ns < kf || nt < kb)
+    return fail(GPCC_ERR_UNSUPPORTED, "fewer points than neighbours asked for");
+  if (p->max_geometry_dist2_fwd < 512)
+    return fail(
+      GPCC_ERR_UNSUPPORTED,
+      "a finite forward geometry limit makes the reference's result vectors shrink from point "
+      "to point (state carried across the loop): it stays on the reference CPU path");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+
+  int32_t *d_sx = nullptr, *d_sa = nullptr, *d_tx = nullptr, *d_out = nullptr, *d_box = nullptr;
+  int32_t *d_sstart = nullptr, *d_sitems = nullptr, *d_tstart = nullptr, *d_titems = nullptr, *d_cur = nullptr;
+  int32_t *d_ref1 = nullptr, *d_bt = nullptr, *d_lstart = nullptr, *d_lcur = nullptr, *d_lsrc = nullptr;
+  double *d_bd = nullptr, *d_ldist = nullptr;
+  long long* d_sums = nullptr;
+  auto cleanup = [&]() {
+    for (void* q : {(void*)d_sx, (void*)d_sa, (void*)d_tx, (void*)d_out, (void*)d_box, (void*)d_sstart,
+                    (void*)d_sitems, (void*)d_tstart, (void*)d_titems, (void*)d_cur, (void*)d_ref1,
+                    (void*)d_bt, (void*)d_lstart, (void*)d_lcur, (void*)d_lsrc, (void*)d_bd, (void*)d_ldist,
+                    (void*)d_sums})
+      pool_free(ctx, q);
+  };
+  auto run = [&]() -> int {
+    HIP_TRY(pool_malloc(ctx, (void**)&d_sx, sizeof(int32_t) * 3 * (size_t)ns));
+    HIP_TRY(pool_malloc(ctx, (void**)&d_sa, sizeof(int32_t) * (size_t)c * ns));
+    HIP_TRY(pool_malloc(ctx, (void**)&d_tx, sizeof(int32_t) * 3 * (size_t)nt));
+    HIP_TRY(pool_malloc(ctx, (void**)&d_out, sizeof(int32_t) * (size_t)c * nt));
+    HIP_TRY(pool_malloc(ctx, (void**)&d_box, sizeof(int32_t) * 12));
+    HIP_TRY(hipMemcpyAsync(d_sx, src_xyz, sizeof(int32_t) * 3 * (size_t)ns, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_sa, src_attrs, sizeof(int32_t) * (size_t)c * ns, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_tx, tgt_xyz, sizeof(int32_t) * 3 * (size_t)nt, hipMemcpyHostToDevice, st));
+    int32_t h_box[12];
+    for (int k = 0; k < 3; k++) {
+      h_box[k] = h_box[6 + k] = 0x7fffffff;
+      h_box[3 + k] = h_box[9 + k] = -0x7fffffff;
+    }
+    HIP_TRY(hipMemcpyAsync(d_box, h_box, sizeof(h_box), hipMemcpyHostToDevice, st));
+    {
+      Timer t(ctx, "rc_bbox");
+      rc_bbox_kernel<<<grid_for(ns, 256), 256, 0, st>>>(d_sx, ns, d_box);
+      rc_bbox_kernel<<<grid_for(nt, 256), 256, 0, st>>>(d_tx, nt, d_box + 6);
+    }
+    HIP_TRY(hipMemcpyAsync(h_box, d_box, sizeof(h_box), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int k = 0; k < 12; k++)
+      if (h_box[k] <= -(1 << 30) || h_box[k] >= (1 << 30))
+        return fail(GPCC_ERR_INVALID_ARG, "coordinates outside (-2^30, 2^30)");
+
+    RcCtx cx{};
+    cx.p = *p;
+    cx.c = c;
+    cx.s2t = (double)scale;
+    cx.t2s = 1.0 / (double)scale;
+    for (int k = 0; k < 3; k++)
+      cx.off[k] = offset[k];
+    size_t scells = 0, tcells = 0;
+    rc_plan_grid(h_box, ns, &cx.src, &scells);
+    rc_plan_grid(h_box + 6, nt, &cx.tgt, &tcells);
+    cx.src.xyz = d_sx;
+    cx.tgt.xyz = d_tx;
+    cx.src_attrs = d_sa;
+    const size_t mcells = std::max(scells, tcells);
+    const size_t total_cap = (size_t)ns * kb;
+    HIP_TRY(pool_malloc(ctx, (void**)&d_sstart, sizeof(int32_t) * (scells + 1)));
+    HIP_TRY(pool_malloc(ctx, (void**)&d_sitems, sizeof(int32_t) * (size_t)ns));
+    HIP_TRY(pool_malloc(ctx, (void**)&d_tstart, sizeof(int32_t) * (tcells + 1)));
+    HIP_TRY(pool_malloc(ctx, (void**)&d_titems, sizeof(int32_t) * (size_t)nt));
+    HIP_TRY(pool_malloc(ctx, (void**)&d_cur, sizeof(int32_t) * mcells));
+    HIP_TRY(pool_malloc(ctx, (void**)&d_ref1, sizeof(int32_t) * (size_t)c * nt));
+    HIP_TRY(pool_malloc(ctx, (void**)&d_bt, sizeof(int32_t) * total_cap));
+    HIP_TRY(pool_malloc(ctx, (void**)&d_bd, sizeof(double) * total_cap));
+    HIP_TRY(pool_malloc(ctx, (void**)&d_lstart, sizeof(int32_t) * ((size_t)nt + 1)));
+    HIP_TRY(pool_malloc(ctx, (void**)&d_lcur, sizeof(int32_t) * (size_t)nt));
+    HIP_TRY(pool_malloc(ctx, (void**)&d_ldist, sizeof(double) * total_cap));
+    HIP_TRY(pool_malloc(ctx, (void**)&d_lsrc, sizeof(int32_t) * total_cap));
+    const size_t max_scan = std::max<size_t>(mcells + 1, (size_t)nt + 1);
+    HIP_TRY(pool_malloc(ctx, (void**)&d_sums, sizeof(long long) * (max_scan / kRcScanBlock + 2)));
+    cx.src.start = d_sstart;
+    cx.src.items = d_sitems;
+    cx.tgt.start = d_tstart;
+    cx.tgt.items = d_titems;
+    cx.ref1 = d_ref1;
+    cx.bt = d_bt;
+    cx.bd = d_bd;
+    cx.lstart = d_lstart;
+    cx.lcur = d_lcur;
+    cx.ldist = d_ldist;
+    cx.lsrc = d_lsrc;
+    cx.out = d_out;
+
+    // ---- the two cell tables ----------------------------------------------------------
+    for (int which = 0; which < 2; which++) {
+      const RcGrid& g = which ? cx.tgt : cx.src;
+      const size_t cells = which ? tcells : scells;
+      Timer t(ctx, "rc_cells");
+      HIP_TRY(hipMemsetAsync(g.start, 0, sizeof(int32_t) * (cells + 1), st));
+      HIP_TRY(hipMemsetAsync(d_cur, 0, sizeof(int32_t) * cells, st));
+      rc_cell_count_kernel<<<grid_for(g.n, 256), 256, 0, st>>>(g);
+      int r = rc_scan(ctx, g.start, cells + 1, d_sums);
+      if (r)
+        return r;
+      rc_cell_fill_kernel<<<grid_for(g.n, 256), 256, 0, st>>>(g, d_cur);
+    }
+    // ---- forward, backward, lists, blend ------------------------------------------------
+    {
+      Timer t(ctx, "rc_forward");
+      if (c == 3)
+        rc_forward_kernel<3><<<(nt + 255) / 256, 256, 0, st>>>(cx);
+      else
+        rc_forward_kernel<1><<<(nt + 255) / 256, 256, 0, st>>>(cx);
+    }
+    HIP_TRY(hipMemsetAsync(d_lstart, 0, sizeof(int32_t) * ((size_t)nt + 1), st));
+    HIP_TRY(hipMemsetAsync(d_lcur, 0, sizeof(int32_t) * (size_t)nt, st));
+    {
+      Timer t(ctx, "rc_backward");
+      rc_backward_kernel<<<(ns + 255) / 256, 256, 0, st>>>(cx);
+    }
+    {
+      Timer t(ctx, "rc_lists");
+      int r = rc_scan(ctx, d_lstart, (size_t)nt + 1, d_sums);
+      if (r)
+        return r;
+      rc_list_fill_kernel<<<(ns + 255) / 256, 256, 0, st>>>(cx);
+    }
+    {
+      Timer t(ctx, "rc_blend");
+      if (c == 3)
+        rc_blend_kernel<3><<<(nt + 255) / 256, 256, 0, st>>>(cx);
+      else
+        rc_blend_kernel<1><<<(nt + 255) / 256, 256, 0, st>>>(cx);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(tgt_attrs, d_out, sizeof(int32_t) * (size_t)c * nt, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return GPCC_OK;
+  };
+  const int r = run();
+  cleanup();
+  return r;
+}
+
+}  // namespace
+
+extern "C" int
+gpcc_recolour(
+  gpcc_ctx* ctx, const gpcc_recolour_params* params, const int32_t* src_xyz,
+  const int32_t* src_attrs, int32_t ns, const int32_t* tgt_xyz, int32_t nt, int32_t c,
+  float source_to_target_scale, const int32_t target_to_source_offset[3], int32_t* tgt_attrs)
+{
+  return counted(
+    ctx,
+    recolour_impl(
+      ctx, params, src_xyz, src_attrs, ns, tgt_xyz, nt, c, source_to_target_scale,
+      target_to_source_offset, tgt_attrs),
+    nt);
 }

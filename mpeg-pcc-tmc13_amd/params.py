@@ -219,3 +219,33 @@ def lod_params(levels=12, decimation=0, dist2=0, dist2_delta=0, neighbours=3, li
     for i in range(GPCC_MAX_LODS):
         p.lod_sampling_period[i] = sampling_period
     return p
+
+
+class RecolourParams(C.Structure):
+    """ctypes mirror of gpcc_recolour_params."""
+    _fields_ = [
+        ("dist_offset_fwd", C.c_double), ("dist_offset_bwd", C.c_double),
+        ("max_geometry_dist2_fwd", C.c_double), ("max_geometry_dist2_bwd", C.c_double),
+        ("max_attribute_dist2_fwd", C.c_double), ("max_attribute_dist2_bwd", C.c_double),
+        ("search_range", C.c_int32),
+        ("num_neighbours_fwd", C.c_int32), ("num_neighbours_bwd", C.c_int32),
+        ("use_dist_weighted_avg_fwd", C.c_int32), ("use_dist_weighted_avg_bwd", C.c_int32),
+        ("skip_avg_if_identical_fwd", C.c_int32), ("skip_avg_if_identical_bwd", C.c_int32),
+        ("bitdepth", C.c_int32),
+    ]
+
+
+def recolour_params(bitdepth=8, search_range=1, k_fwd=8, k_bwd=1, weighted_fwd=True, weighted_bwd=True,
+                    skip_fwd=True, skip_bwd=False, dist_offset_fwd=4.0, dist_offset_bwd=4.0,
+                    max_geom_fwd=1000.0, max_geom_bwd=1000.0, max_attr_fwd=1000.0, max_attr_bwd=1000.0):
+    """The reference's defaults (TMC3.cpp:1501-1550)."""
+    p = RecolourParams()
+    p.dist_offset_fwd, p.dist_offset_bwd = dist_offset_fwd, dist_offset_bwd
+    p.max_geometry_dist2_fwd, p.max_geometry_dist2_bwd = max_geom_fwd, max_geom_bwd
+    p.max_attribute_dist2_fwd, p.max_attribute_dist2_bwd = max_attr_fwd, max_attr_bwd
+    p.search_range = search_range
+    p.num_neighbours_fwd, p.num_neighbours_bwd = k_fwd, k_bwd
+    p.use_dist_weighted_avg_fwd, p.use_dist_weighted_avg_bwd = int(weighted_fwd), int(weighted_bwd)
+    p.skip_avg_if_identical_fwd, p.skip_avg_if_identical_bwd = int(skip_fwd), int(skip_bwd)
+    p.bitdepth = bitdepth
+    return p

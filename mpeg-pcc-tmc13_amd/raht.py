@@ -178,6 +178,21 @@ class Context:
                                                  search_range, C.c_float(percentile), C.byref(out)))
         return out.value
 
+    def recolour(self, params, src_xyz, src_attrs, tgt_xyz, scale=1.0, offset=(0, 0, 0)):
+        """pcc::recolour (pointset_processing.cpp:926): the attributes of the source cloud
+        transferred to the target positions -> int32 [nt, c]"""
+        sx = np.ascontiguousarray(src_xyz, dtype=np.int32)
+        sa = np.ascontiguousarray(src_attrs, dtype=np.int32)
+        tx = np.ascontiguousarray(tgt_xyz, dtype=np.int32)
+        ns, c = sa.shape
+        nt = tx.shape[0]
+        out = np.zeros((nt, c), dtype=np.int32)
+        off = (C.c_int32 * 3)(*[int(v) for v in offset])
+        _lib.check(self._lib.gpcc_recolour(
+            self._h, C.byref(params), sx.ctypes.data, sa.ctypes.data, ns, tx.ctypes.data, nt, c,
+            C.c_float(scale), off, out.ctypes.data))
+        return out
+
     # ---- whole slice driver (sort + marshal + transform + clip + scatter) ----
     def raht_encode_attr(self, params, xyz, attrs, bitdepth=8):
         """encode{Colors,Reflectances}TransformRaht minus the entropy loop ->

@@ -70,6 +70,22 @@ class Checker:
         assert rc == 0, rc
         return rec
 
+    def recolour(self, params, src_xyz, src_attrs, tgt_xyz, scale=1.0, offset=(0, 0, 0)):
+        """pcc::recolour: attributes of the source cloud transferred to tgt_xyz -> [nt, c]"""
+        f = self.fn("recolour", C.c_int,
+                    [C.c_void_p, _i32p, _i32p, C.c_int32, _i32p, C.c_int32, C.c_int32, C.c_float, _i32p, _i32p])
+        sx = np.ascontiguousarray(src_xyz, dtype=np.int32)
+        sa = np.ascontiguousarray(src_attrs, dtype=np.int32)
+        tx = np.ascontiguousarray(tgt_xyz, dtype=np.int32)
+        ns, c = sa.shape
+        nt = tx.shape[0]
+        out = np.zeros((nt, c), dtype=np.int32)
+        off = np.ascontiguousarray(offset, dtype=np.int32)
+        rc = f(C.addressof(params), sx.reshape(-1), sa.reshape(-1), ns, tx.reshape(-1), nt, c,
+               float(scale), off, out.reshape(-1))
+        assert rc == 0, rc
+        return out
+
     def morton_sort(self, xyz):
         xyz = np.ascontiguousarray(xyz, dtype=np.int32)
         n = xyz.shape[0]

@@ -35,7 +35,7 @@ def test_header_symbols_exported(lib):
 
 def test_abi_version_and_struct_size(lib):
     from mpeg_pcc_tmc13_amd import RahtParams
-    assert lib.gpcc_abi_version() == 3
+    assert lib.gpcc_abi_version() == 4
     # 6 + 19 + 12 + 1 + 1 + 64 + 1 + 1 + 1 + 448 ints
     assert C.sizeof(RahtParams) == 4 * (6 + 19 + 12 + 1 + 1 + 64 + 3 + 32 * 7 * 2)
 
