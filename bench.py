@@ -324,6 +324,7 @@ def main():
             out["host_tier"] = host_tier_leg(ctx, frames[0], p)
             out["lifting"] = lifting_leg(ctx, args)
             out["predicting"] = predicting_leg(ctx, args)
+            out["recolour"] = recolour_leg(ctx, args)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames[0], p, c)
 
@@ -443,6 +444,43 @@ def host_tier_leg(ctx, frame, p):
     return {"forward_ms": round((t1 - t0) * 1e3, 3), "inverse_ms": round((t2 - t1) * 1e3, 3),
             "Mpoints_per_s_fwd_inv": round(n / (t2 - t0) / 1e6, 2),
             "note": "gpcc_raht_forward / gpcc_raht_inverse on host buffers: H2D + transform + D2H, synchronous"}
+
+
+def recolour_leg(ctx, args):
+    """SURVEY.md 8(f) rank 1, the step upstream of the transforms in BASELINE configs[4]: the
+    attributes of a 1M-point S-dense colour cloud transferred to its half-resolution geometry
+    (pcc::recolour, the reference's defaults: 8 forward / 1 backward neighbours, +-1 refinement).
+    Host tier (host buffers in and out).  Algorithmic bytes: source 12 + 4c, target 12 in, 4c out."""
+    from mpeg_pcc_tmc13_amd import recolour_params, synth
+    n = min(args.points, 1_000_000)
+    xyz, a = synth.dense_cloud(n, seed=1)
+    scale = 0.5
+    tgt = np.unique(np.rint(xyz.astype(np.float64) * scale).astype(np.int32), axis=0)
+    p = recolour_params(bitdepth=8)
+    ctx.recolour(p, xyz, a, tgt, scale=scale)  # warm-up (pool)
+    ctx.set_profiling(True)
+    ctx.kernel_times()
+    t0 = time.perf_counter()
+    got = ctx.recolour(p, xyz, a, tgt, scale=scale)
+    dt = time.perf_counter() - t0
+    kt = ctx.kernel_times()
+    ctx.set_profiling(False)
+    kms = sum(v[0] for v in kt.values())
+    nbytes = len(xyz) * (12 + 4 * 3) + len(tgt) * (12 + 4 * 3)
+    res = {"workload": f"pcc::recolour, {len(xyz)}-point S-dense colour source -> {len(tgt)} target points (scale 0.5), defaults",
+           "call_ms": round(dt * 1e3, 2), "kernel_ms": {k: round(v[0], 3) for k, v in sorted(kt.items(), key=lambda kv: -kv[1][0])},
+           "value": round(len(tgt) / dt / 1e6, 2), "unit": "M target points/s (host tier, PCIe included)",
+           "kernels_GBps": round(nbytes / (kms / 1e3) / 1e9, 2), "bytes": nbytes}
+    if not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_loader as ol
+        chk = ol.ref() if ol.ref_available() else ol.oracle()
+        t0 = time.perf_counter()
+        ref = chk.recolour(p, xyz, a, tgt, scale=scale)
+        res["cpu_baseline"] = {"value": round(len(tgt) / (time.perf_counter() - t0) / 1e6, 3), "unit": "M target points/s",
+                               "cores": 1, "kind": "reference" if ol.ref_available() else "port"}
+        res["identical_to_cpu_fraction"] = round(float(np.all(got == ref, axis=1).mean()), 4)
+    return res
 
 
 def hbm_calibration(torch, dev):

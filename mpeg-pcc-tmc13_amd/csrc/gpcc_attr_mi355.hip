@@ -3901,8 +3901,9 @@ recolour_impl(
     HIP_TRY(hipMemcpyAsync(d_box, h_box, sizeof(h_box), hipMemcpyHostToDevice, st));
     {
       Timer t(ctx, "rc_bbox");
-      rc_bbox_kernel<<<grid_for(ns, 256), 256, 0, st>>>(d_sx, ns, d_box);
-      rc_bbox_kernel<<<grid_for(nt, 256), 256, 0, st>>>(d_tx, nt, d_box + 6);
+      // (few workgroups: every wavefront ends with six atomics on the same words)
+      rc_bbox_kernel<<<std::min(grid_for(ns, 256), 128), 256, 0, st>>>(d_sx, ns, d_box);
+      rc_bbox_kernel<<<std::min(grid_for(nt, 256), 128), 256, 0, st>>>(d_tx, nt, d_box + 6);
     }
     HIP_TRY(hipMemcpyAsync(h_box, d_box, sizeof(h_box), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
