@@ -605,10 +605,11 @@ def predicting_leg(ctx, args):
     """The other half of BASELINE configs[2]: the PREDICTING transform of a
     1M-point dense colour slice, CTC tools (three direct predictors, inter-
     component prediction, intra-LoD prediction, quantNeighWeight 16/8/4) --
-    the decoder (gpcc_pred_inverse: every tool on the device) and the encoder
-    without direct predictors (gpcc_pred_forward).  Host tier: the timings are
-    the kernels' (HIP events), the CPU figure is the same loop of the oracle
-    (pinned to the reference at symbol level) on one core."""
+    the decoder (gpcc_pred_inverse) and the encoder (gpcc_pred_forward: the
+    choice among the direct predictors iterated to the sequential coder's fixed
+    point, `encode_passes` DAG passes).  Host tier: the timings are the kernels'
+    (HIP events), the CPU figure is the same loop of the oracle (pinned to the
+    reference at symbol level) on one core."""
     from mpeg_pcc_tmc13_amd import lod_params, pred_params, synth
     n = min(args.points, 1_000_000)
     xyz, attrs = synth.dense_cloud(n, seed=41, bits=10 if n >= 500_000 else 8)
@@ -618,9 +619,9 @@ def predicting_leg(ctx, args):
     lod = ctx.lod_build(lp, xyz)
     qnw = (16, 8, 4)
     pp = pred_params(lod["npl"], qp=28, bitdepth=8, max_levels=12, quant_neigh_weight=qnw)
-    pp0 = pred_params(lod["npl"], qp=28, bitdepth=8, max_levels=12, quant_neigh_weight=qnw, direct=0)
+    pp0 = pp  # (until round 3 the device encoder declined direct predictors and ran without)
     res = {"workload": f"predicting transform, {n}-point S-dense colour slice, {len(lod['npl'])} LoDs, intra-LoD "
-                       "prediction, 3 direct predictors (decoder) / none (encoder), ICP, qp 28 (host tier, kernel times)"}
+                       "prediction, 3 direct predictors, ICP, qp 28 (host tier, kernel times)"}
     values = icp = want = None
     if not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -638,7 +639,9 @@ def predicting_leg(ctx, args):
     ctx.set_profiling(True)
     ctx.kernel_times()
     v0, rec0, icp0 = ctx.pred_forward(pp0, lod["nc"], lod["ni"], lod["w"], lod["indexes"], attrs)
-    kt_e = {k: v[0] for k, v in ctx.kernel_times().items() if k.startswith("pred")}
+    kte_raw = ctx.kernel_times()
+    kt_e = {k: v[0] for k, v in kte_raw.items() if k.startswith("pred")}
+    res["encode_passes"] = int(round(kte_raw.get("pred_dag", (0, 0))[1]))
     dec0 = ctx.pred_inverse(pp0, lod["nc"], lod["ni"], lod["w"], lod["indexes"], v0, icp=icp0)
     kt_d = {k: v[0] for k, v in ctx.kernel_times().items() if k.startswith("pred")}
     ok = bool(np.array_equal(dec0, rec0))
@@ -646,12 +649,13 @@ def predicting_leg(ctx, args):
         # the CTC stream (direct predictors chosen by the reference's serial mode decision): decoder only
         got = ctx.pred_inverse(pp, lod["nc"], lod["ni"], lod["w"], lod["indexes"], values, icp=icp)
         kt_d = {k: v[0] for k, v in ctx.kernel_times().items() if k.startswith("pred")}
-        ok = ok and bool(np.array_equal(got, want))
+        ok = ok and bool(np.array_equal(got, want)) and bool(np.array_equal(v0, values)) and bool(np.array_equal(rec0, want))
     ctx.set_profiling(False)
     c = 3
     res.update({"encode_kernels_ms": {k: round(v, 3) for k, v in kt_e.items()},
                 "decode_kernels_ms": {k: round(v, 3) for k, v in kt_d.items()},
                 "decode_value": round(n / (sum(kt_d.values()) / 1e3) / 1e6, 1), "unit": "Mpoints/s (kernels)",
+                "encode_value": round(n / (sum(kt_e.values()) / 1e3) / 1e6, 1),
                 "algorithmic_bytes_per_point": {"decode": 28 + 8 * c, "encode": 28 + 12 * c},
                 "decode_achieved_GBps": round((28 + 8 * c) * n / (sum(kt_d.values()) / 1e3) / 1e9, 2),
                 "results_identical": ok})
@@ -670,7 +674,7 @@ def predicting_leg(ctx, args):
     d_vals = torch.zeros(3 * tot, dtype=torch.int32, device=dev)
     d_dec = torch.zeros(3 * tot, dtype=torch.int32, device=dev)
     ctx.set_morton_bits(30)
-    mk = lambda: [pred_params([sz], qp=28, bitdepth=8, max_levels=12, quant_neigh_weight=qnw, direct=0) for sz in sizes]
+    mk = lambda: [pred_params([sz], qp=28, bitdepth=8, max_levels=12, quant_neigh_weight=qnw) for sz in sizes]
 
     def enc():
         d_attrs.copy_(src)

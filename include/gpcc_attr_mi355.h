@@ -394,12 +394,18 @@ int gpcc_pred_inverse(
   int32_t* attrs, const int32_t* values, const int8_t* icp_coeffs);
 
 /* Replaces the body of encodeColorsPred / encodeReflectancesPred minus the
- * entropy calls for max_num_direct_predictors == 0: attrs in source / out
- * reconstruction, values [n][c] out, icp_coeffs out
- * (computeInterComponentPredictionCoeffs, AttributeEncoder.cpp:990-1071).
- * With direct predictors the encoder's mode decision reads a rate model that
- * every earlier point has updated (:136-222, 665-717, 894-947) -- one serial
- * scan: GPCC_ERR_UNSUPPORTED, the caller keeps the reference's loop. */
+ * entropy calls: attrs in source / out reconstruction, values [n][c] out (the
+ * prediction mode in the low bits of the magnitudes, encodePredModeColor /
+ * ...Refl), icp_coeffs out (computeInterComponentPredictionCoeffs,
+ * AttributeEncoder.cpp:990-1071).  With direct predictors the encoder's mode
+ * decision (decidePredModeColor :896-985, decidePredModeRefl :663-745) reads a
+ * rate model that every earlier point has updated (:136-222): the device runs
+ * the reconstruction pass with the model's states as an input, recomputes the
+ * states from the pass's values, and repeats until a pass changes no value --
+ * the sequential coder's result (a few passes per slice).  The estimate's log2
+ * values come from a table filled by the HOST's libm, so the doubles are the
+ * reference's.  A slice that has not settled after 64 passes returns
+ * GPCC_ERR_UNSUPPORTED with attrs restored (not observed). */
 int gpcc_pred_forward(
   gpcc_ctx* ctx, const gpcc_pred_params* params, int32_t n, int32_t c,
   const int32_t* neigh_count, const int32_t* neigh_index,
@@ -413,7 +419,7 @@ int gpcc_pred_forward(
  * num_points_in_lod of the structure that was built.  Region QP offsets are
  * taken as zero by these one-call entries and by gpcc_dev_pred_* (a slice with a
  * region QP box goes through gpcc_lod_build + gpcc_pred_forward / _inverse, which
- * take qp_off).  The encoder with direct predictors: GPCC_ERR_UNSUPPORTED (above). */
+ * take qp_off). */
 int gpcc_pred_encode_attr(
   gpcc_ctx* ctx, const gpcc_lod_params* lod, gpcc_pred_params* pred,
   const int32_t* xyz, int32_t* attrs, int32_t* values, int8_t* icp_coeffs,

@@ -117,6 +117,8 @@ struct gpcc_ctx {
                                // only when the error has been reported (check_device_error)
   TreeStats* h_stats = nullptr;   // pinned: what schedule_kernel tells the host about the tree
   CxLevelTab* h_cxtab = nullptr;  // pinned: blocks / real children per level (compact level pass)
+  double* d_log2 = nullptr;       // log2 of 0 .. 2^20 from the host's libm (predicting encoder's rate model)
+  int pred_passes = 0;            // passes the last predicting encode with direct predictors took
   hipEvent_t ev_stats = nullptr;  // recorded behind schedule_kernel
   // what the entries did since the context was created (gpcc_ctx_stats)
   gpcc_ctx_stats_t stats{};
@@ -1211,15 +1213,19 @@ struct PredDev {
   int32_t *attrs, *values;
 };
 
-// the one predicting-transform configuration the device encoder declines
+int rc_scan(gpcc_ctx* ctx, int32_t* a, size_t n, long long* sums);  // (inclusive scan, defined with the recolour entry)
+
+// the predicting encoder's mode decisions did not settle (see pred_kernels.hpp)
 int
-pred_encoder_unsupported()
+pred_encoder_unsettled()
 {
   return fail(
     GPCC_ERR_UNSUPPORTED,
-    "the encoder's choice among direct predictors is a serial scan (running rate model): "
-    "it stays on the reference CPU path");
+    "the encoder's choice among direct predictors did not settle within the pass limit: "
+    "this slice stays on the reference CPU path");
 }
+
+constexpr int kPredMaxPasses = 64;
 
 int
 check_pred_params(const gpcc_pred_params* p, int n, int c, bool encoder)
@@ -1245,8 +1251,6 @@ check_pred_params(const gpcc_pred_params* p, int n, int c, bool encoder)
     return fail(GPCC_ERR_INVALID_ARG, "max_num_direct_predictors out of range");
   if (p->max_num_detail_levels < p->num_lods || p->max_num_detail_levels > GPCC_MAX_LODS)
     return fail(GPCC_ERR_INVALID_ARG, "max_num_detail_levels out of range");
-  if (encoder && p->max_num_direct_predictors)
-    return pred_encoder_unsupported();
   return GPCC_OK;
 }
 
@@ -1261,6 +1265,15 @@ pred_scratch_bytes(int n)
   ar.take<uint32_t>((size_t)n * 4);
   ar.take<int32_t>(64);
   ar.take<unsigned long long>(GPCC_MAX_LODS * 18);
+  // encoder with direct predictors: rate model per predictor, source copy, previous values,
+  // ranks / events / event states of the probResGt1 recurrence, scan sums
+  ar.take<int32_t>((size_t)n * 6);
+  ar.take<int32_t>((size_t)n * 3);
+  ar.take<int32_t>((size_t)n * 3);
+  ar.take<int32_t>((size_t)n + 1);
+  ar.take<uint8_t>((size_t)n + 1);
+  ar.take<int32_t>((size_t)n + 1);
+  ar.take<long long>((size_t)n / kRcScanBlock + 2);
   return ar.used;
 }
 
@@ -1352,6 +1365,30 @@ launch_pred(
   cx.icp_sums = ar.take<unsigned long long>(GPCC_MAX_LODS * 18);
   // indeg .. rec, tickets, sums: one clear
   HIP_TRY(hipMemsetAsync(scratch, 0, ar.used, st));
+  cx.tag = 1;
+  const bool deciding = encoder && cx.max_direct > 0;
+  int32_t* rm = ar.take<int32_t>((size_t)n * 6);
+  int32_t* src_copy = ar.take<int32_t>((size_t)n * 3);
+  int32_t* prev_values = ar.take<int32_t>((size_t)n * 3);
+  int32_t* ev_rank = ar.take<int32_t>((size_t)n + 1);
+  uint8_t* ev_up = ar.take<uint8_t>((size_t)n + 1);
+  int32_t* ev_state = ar.take<int32_t>((size_t)n + 1);
+  long long* scan_sums = ar.take<long long>((size_t)n / kRcScanBlock + 2);
+  if (deciding) {
+    // log2 of every integer the rate estimate can ask for, from THIS host's libm (the
+    // reference's own log2): once per context
+    if (!ctx->d_log2) {
+      std::vector<double> tab((size_t)kRateScale + 1);
+      for (int v = 0; v <= kRateScale; v++)
+        tab[v] = log2((double)v);
+      HIP_TRY(hipMalloc((void**)&ctx->d_log2, tab.size() * sizeof(double)));
+      HIP_TRY(hipMemcpy(ctx->d_log2, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMemcpyAsync(src_copy, d.attrs, sizeof(int32_t) * (size_t)n * C, hipMemcpyDeviceToDevice, st));
+    cx.src = src_copy;
+    cx.rm = rm;
+    cx.log2tab = ctx->d_log2;
+  }
   auto grid = [&](int items) { return grid_for(std::max(items, 1), 256); };
   // persistent kernels: as many wavefronts as the device keeps resident
   const int pgrid = (int)std::min<int64_t>(2048, ((int64_t)n + 255) / 256);
@@ -1372,12 +1409,64 @@ launch_pred(
     pred_icp_sums_kernel<<<std::min(grid(n), 1024), 256, 0, st>>>(cx);
     pred_icp_resolve_kernel<<<1, 64, 0, st>>>(cx);
   }
-  {
+  if (!deciding) {
     Timer t(ctx, "pred_dag");
     if (encoder)
       pred_dag_kernel<C, true><<<std::max(pgrid, 1), 256, 0, st>>>(cx);
     else
       pred_dag_kernel<C, false><<<std::max(pgrid, 1), 256, 0, st>>>(cx);
+  } else {
+    // the DAG pass and the rate model's trajectory, iterated to their fixed point
+    int32_t* flag = small + 24;
+    {
+      Timer t(ctx, "pred_rate");
+      pred_rate_init_kernel<<<grid(n), 256, 0, st>>>(rm, n);
+    }
+    bool settled = false;
+    int passes = 0;
+    for (int pass = 0; pass < kPredMaxPasses && !settled; pass++) {
+      passes++;
+      cx.tag = (uint32_t)(pass + 1);
+      HIP_TRY(hipMemsetAsync(cx.ticket, 0, 8 * sizeof(int32_t), st));
+      HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int32_t), st));
+      {
+        Timer t(ctx, "pred_dag");
+        pred_dag_kernel<C, true><<<std::max(pgrid, 1), 256, 0, st>>>(cx);
+      }
+      int32_t changed = 1;
+      {
+        Timer t(ctx, "pred_rate");
+        pred_values_diff_kernel<<<grid(n), 256, 0, st>>>(cx.values, prev_values, (size_t)n * C, flag);
+        if (pass > 0) {
+          HIP_TRY(hipMemcpyAsync(&changed, flag, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+          HIP_TRY(hipStreamSynchronize(st));
+        }
+        if (pass > 0 && !changed) {
+          settled = true;
+        } else {
+          const int chunks = n / kRateChunk + 1;
+          for (int k = 0; k < C; k++) {
+            // probResGt0: an event at every predictor
+            pred_rate_scan_kernel<<<(chunks + 63) / 64, 64, 0, st>>>(cx.values + k, C, nullptr, n, nullptr, rm + k, 6, 0);
+            // probResGt1: the non-zero values, compacted
+            pred_rate_flags_kernel<<<grid(n), 256, 0, st>>>(cx.values, n, C, k, ev_rank);
+            int r = rc_scan(ctx, ev_rank, (size_t)n + 1, scan_sums);
+            if (r)
+              return r;
+            pred_rate_events_kernel<<<grid(n), 256, 0, st>>>(cx.values, n, C, k, ev_rank, ev_up);
+            pred_rate_scan_kernel<<<(chunks + 63) / 64, 64, 0, st>>>(nullptr, 0, ev_up, n, ev_rank + n, ev_state, 1, 1);
+            pred_rate_gather_kernel<<<grid(n), 256, 0, st>>>(ev_rank, ev_state, n, k, rm);
+          }
+        }
+      }
+    }
+    ctx->pred_passes = passes;
+    if (!settled) {
+      // the caller's attrs hold a reconstruction that is not the reference's: restore the source
+      HIP_TRY(hipMemcpyAsync(d.attrs, src_copy, sizeof(int32_t) * (size_t)n * C, hipMemcpyDeviceToDevice, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      return pred_encoder_unsettled();
+    }
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(ctx->h_error, cx.error, sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -1598,6 +1687,8 @@ gpcc_ctx_destroy(gpcc_ctx* ctx)
     hipHostFree(ctx->h_stats);
   if (ctx->h_cxtab)
     hipHostFree(ctx->h_cxtab);
+  if (ctx->d_log2)
+    hipFree(ctx->d_log2);
   if (ctx->ev_stats)
     hipEventDestroy(ctx->ev_stats);
   if (ctx->h_pinned)
@@ -2349,8 +2440,6 @@ pred_attr_driver(
     return fail(GPCC_ERR_INVALID_ARG, "ctx is null");
   if (!pred || !attrs || !values || (c != 1 && c != 3))
     return fail(GPCC_ERR_INVALID_ARG, "null buffer or attribute count not 1 / 3");
-  if (encoder && pred->max_num_direct_predictors)
-    return pred_encoder_unsupported();  // before any work (num_lods is an output here: not validated)
   const bool icp_on = c == 3 && pred->inter_component_prediction_enabled_flag;
   if (icp_on && !icp)
     return fail(GPCC_ERR_INVALID_ARG, "icp_coeffs is null");
@@ -3295,8 +3384,6 @@ dev_pred_attr(
   if (!pred || !d_xyz || !d_attrs || !d_values || (c != 1 && c != 3))
     return fail(GPCC_ERR_INVALID_ARG, "null buffer or attribute count not 1 / 3");
   for (int s = 0; s < num_slices; s++) {
-    if (encoder && pred[s].max_num_direct_predictors)
-      return pred_encoder_unsupported();  // before any work
     if (c == 3 && pred[s].inter_component_prediction_enabled_flag && !icp)
       return fail(GPCC_ERR_INVALID_ARG, "icp_coeffs is null");
   }

@@ -70,6 +70,11 @@ struct PredCtx {
   // sees the three values of the same store (MI355X_MICROARCH.md, hand-off section);
   // there is no release / acquire pair around it.
   uint32_t* rec;
+  uint32_t tag;       // tag of this pass's granules (the encoder's mode decision iterates passes)
+  // encoder with direct predictors (pred_rate_* below)
+  const int32_t* src;       // [n][c] source attributes, point order (attrs then only takes the reconstruction)
+  const int32_t* rm;        // [n][6] rate model before every predictor: probResGt0[3], probResGt1[3]
+  const double* log2tab;    // [2^20 + 1] log2 of every integer, computed by the HOST's libm
   int32_t* ticket;  // [2]
   int32_t* wide;    // set by pred_indegree_kernel: an in-degree >= 2^20
   int32_t packed_ok;  // quant_neigh_weight >= 0 and their sum < 256
@@ -282,6 +287,257 @@ pred_icp_resolve_kernel(PredCtx cx)
     cx.icp[3 * lod + k] = out[k];
 }
 
+// ---- the encoder's rate model (PCCResidualsEncoder, AttributeEncoder.cpp:81-222) -------
+// The choice among direct predictors (decidePredModeRefl :663-745, decidePredModeColor
+// :896-985) scores every candidate with an estimate of its coded size from two running
+// probabilities per component, updated after every predictor in coding order
+// (resStatUpdate :137-165): the one loop-carried state of the encoder that is not a
+// neighbour value.  Here the state BEFORE every predictor is an input of the DAG pass
+// (cx.rm), recomputed from the pass's values by pred_rate_scan_kernel, and the two are
+// iterated: a pass whose values equal the previous pass's has used exactly the states the
+// sequential coder would have had (induction over the coding order), so the fixed point IS
+// the reference's result.  Each pass is exact up to its first wrong decision, and a wrong
+// state decays by 1/64 per predictor, so a handful of passes settle a slice.
+// The estimate takes log2 of integers below 2^20: the table is filled by the host's libm
+// (the reference's own log2), the sums are evaluated in the reference's order without
+// contraction -- identical doubles, identical decisions.
+constexpr int kRateScale = 1 << 20, kRateWindowLog2 = 6;
+
+__device__ __forceinline__ double
+pred_log2i(const PredCtx& cx, int64_t v)
+{
+  return v >= 0 && v <= kRateScale ? cx.log2tab[v] : log2((double)v);
+}
+
+__device__ __forceinline__ double
+pred_rate_component(const PredCtx& cx, const int32_t* rm, int k, int32_t value)
+{
+#pragma clang fp contract(off)
+  const int l2 = 20;  // ilog2(scaleRes)
+  double bits = 0;
+  bits += value ? l2 - pred_log2i(cx, rm[k]) : l2 - pred_log2i(cx, kRateScale - rm[k]);
+  const int mag = value < 0 ? -value : value;
+  if (mag) {
+    bits += mag > 1 ? l2 - pred_log2i(cx, rm[3 + k]) : l2 - pred_log2i(cx, kRateScale - rm[3 + k]);
+    bits += 1;
+    if (mag > 1)
+      bits += 2.0 * pred_log2i(cx, (int64_t)mag - 1) + 1.0;
+  }
+  return bits;
+}
+
+// bitsPtRefl (:203-222)
+__device__ __forceinline__ double
+pred_rate_refl(const PredCtx& cx, const int32_t* rm, int avail, int32_t value, int mode)
+{
+#pragma clang fp contract(off)
+  const int a = value < 0 ? -value : value;
+  if (avail == 4) {
+    value = (a << 2) + mode;
+  } else if (avail == 3) {
+    int v = a;
+    if (mode > 0)
+      v = (v << 1) + (mode - 1);
+    value = (v << 1) + (mode > 0);
+  } else if (avail == 2) {
+    value = (a << 1) + (mode & 1);
+  }
+  double bits = 0;
+  bits += pred_rate_component(cx, rm, 0, value);
+  return bits;
+}
+
+// bitsPtColor (:168-199)
+__device__ __forceinline__ double
+pred_rate_colour(const PredCtx& cx, const int32_t* rm, int avail, const int64_t r[3], int mode)
+{
+#pragma clang fp contract(off)
+  int32_t v[3] = {(int32_t)r[0], (int32_t)r[1], (int32_t)r[2]};
+  const int a1 = v[1] < 0 ? -v[1] : v[1], a2 = v[2] < 0 ? -v[2] : v[2];
+  if (avail == 4) {
+    v[1] = 2 * a1 + (mode >> 1);
+    v[2] = 2 * a2 + (mode & 1);
+  } else if (avail == 3) {
+    v[1] = 2 * a1 + (mode > 0);
+    if (mode > 0)
+      v[2] = 2 * a2 + (mode - 1);
+  } else if (avail == 2) {
+    v[1] = 2 * a1 + (mode & 1);
+  }
+  double bits = 0;
+  for (int k = 0; k < 3; k++)
+    bits += pred_rate_component(cx, rm, k, v[k]);
+  return bits;
+}
+
+__device__ __forceinline__ int64_t
+pred_half_up8(int64_t x)
+{
+  return (x + 128) >> 8;
+}
+
+// computeColorResiduals (:858-890)
+__device__ __forceinline__ void
+pred_colour_residuals(
+  bool icp_on, const int32_t col[3], const int64_t pred[3], const int8_t icp[3], const Quantizer q[2],
+  int64_t r[3])
+{
+  r[0] = quantize(q[0], ((int64_t)col[0] - pred[0]) << 8);
+  const int64_t residual0 = pred_half_up8(mul_i64_u32(r[0], q[0].step));
+  for (int k = 1; k < 3; k++) {
+    int64_t err = (int64_t)col[k] - pred[k];
+    if (icp_on)
+      err -= ((int64_t)icp[k] * residual0 + 2) >> 2;
+    r[k] = quantize(q[1], err << 8);
+  }
+}
+
+// computeColorDistortions (:792-823)
+__device__ __forceinline__ int
+pred_colour_distortion(int64_t clip_max, const int32_t col[3], const int64_t pred[3], const Quantizer q[2])
+{
+  int d = 0;
+  for (int k = 0; k < 3; k++) {
+    const Quantizer qq = q[k ? 1 : 0];
+    const int64_t rq = quantize(qq, ((int64_t)col[k] - pred[k]) << 8);
+    int64_t rec = pred[k] + pred_half_up8(mul_i64_u32(rq, qq.step));
+    rec = rec < 0 ? 0 : (rec > clip_max ? clip_max : rec);
+    const int e = (int)((int64_t)col[k] - (int64_t)(uint16_t)rec);
+    d += e < 0 ? -e : e;
+  }
+  return d;
+}
+
+__device__ __forceinline__ int
+pred_rate_step(int x, bool up)
+{
+  return up ? x + ((kRateScale - x) >> kRateWindowLog2) : x - (x >> kRateWindowLog2);
+}
+
+__global__ __launch_bounds__(256) void
+pred_rate_init_kernel(int32_t* rm, int n)
+{
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)n * 6; i += (size_t)gridDim.x * blockDim.x)
+    rm[i] = kRateScale >> 1;
+}
+
+// The states before every predictor from the values of a pass.  probResGt0 steps at
+// every predictor (up when the value is non-zero); probResGt1 only at the non-zero
+// values (up when the magnitude exceeds 1), so its recurrence runs over the COMPACTED
+// list of those events (flags -> ranks by a scan -> events) and a predictor reads the
+// state in front of the first event at or behind it.  A recurrence is cut into chunks of
+// kRateChunk events, one thread each: a thread does not know the state at its chunk's
+// start, so it runs the recurrence from the two EXTREME reachable states (63 and
+// 2^20 - 63: the fixed points of the two steps) over a warm-up window in front of the
+// chunk -- every step is monotone in the state, the true state lies between the two
+// runs, and where they have met it is known exactly.  A warm-up that has not met is
+// quadrupled (at worst back to the first event, where the state is the initial one).
+constexpr int kRateChunk = 256;
+constexpr int kRateMin = 63, kRateMax = kRateScale - 63;
+
+// rank[i + 1] = (value of component k at predictor i is non-zero); rank[0] = 0
+__global__ __launch_bounds__(256) void
+pred_rate_flags_kernel(const int32_t* __restrict__ values, int n, int c, int k, int32_t* __restrict__ rank)
+{
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    rank[i + 1] = values[(size_t)i * c + k] != 0;
+    if (i == 0)
+      rank[0] = 0;
+  }
+}
+
+// after the inclusive scan rank[i] = non-zero values before predictor i
+__global__ __launch_bounds__(256) void
+pred_rate_events_kernel(
+  const int32_t* __restrict__ values, int n, int c, int k, const int32_t* __restrict__ rank,
+  uint8_t* __restrict__ ev)
+{
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int32_t v = values[(size_t)i * c + k];
+    if (v)
+      ev[rank[i]] = (v < 0 ? -v : v) > 1;
+  }
+}
+
+// One recurrence over `m` events (up[e] from the values for probResGt0: stride c,
+// non-zero test; from the event bytes for probResGt1); state[e] = the state in front of
+// event e, state[m] behind the last (m is read from *m_ptr when given).
+__global__ __launch_bounds__(64) void
+pred_rate_scan_kernel(
+  const int32_t* __restrict__ values, int stride, const uint8_t* __restrict__ ev, int m_max,
+  const int32_t* __restrict__ m_ptr, int32_t* __restrict__ state, int state_stride, int write_final)
+{
+  const int m = m_ptr ? *m_ptr : m_max;
+  const int chunk = blockIdx.x * blockDim.x + threadIdx.x;
+  const long long start = (long long)chunk * kRateChunk;
+  if (start > m || (start == m && m > 0))
+    return;
+  const int end = start + kRateChunk < m ? (int)(start + kRateChunk) : m;
+  auto up = [&](int e) -> bool { return values ? values[(size_t)e * stride] != 0 : ev[e] != 0; };
+  int x = kRateScale >> 1;
+  if (start > 0) {
+    for (long long w = 1024;; w *= 4) {
+      const int b = start - w > 0 ? (int)(start - w) : 0;
+      int lo = b == 0 ? kRateScale >> 1 : kRateMin, hi = b == 0 ? kRateScale >> 1 : kRateMax;
+      // (the loads of a batch do not depend on the state: issued together)
+      for (int e0 = b; e0 < (int)start; e0 += 16) {
+        bool u[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+          u[j] = e0 + j < (int)start ? up(e0 + j) : false;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+          if (e0 + j < (int)start) {
+            lo = pred_rate_step(lo, u[j]);
+            hi = pred_rate_step(hi, u[j]);
+          }
+        }
+      }
+      x = lo;
+      if (lo == hi)
+        break;
+    }
+  }
+  for (int e0 = (int)start; e0 < end; e0 += 16) {
+    bool u[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++)
+      u[j] = e0 + j < end ? up(e0 + j) : false;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      if (e0 + j < end) {
+        state[(size_t)(e0 + j) * state_stride] = x;
+        x = pred_rate_step(x, u[j]);
+      }
+    }
+  }
+  if (write_final && end == m)
+    state[(size_t)m * state_stride] = x;
+}
+
+// probResGt1 of every predictor: the state in front of the first event at or behind it
+__global__ __launch_bounds__(256) void
+pred_rate_gather_kernel(
+  const int32_t* __restrict__ rank, const int32_t* __restrict__ evstate, int n, int k, int32_t* __restrict__ rm)
+{
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    rm[(size_t)i * 6 + 3 + k] = evstate[rank[i]];
+}
+
+// did this pass change a value?  (and keep the values for the next comparison)
+__global__ __launch_bounds__(256) void
+pred_values_diff_kernel(const int32_t* __restrict__ values, int32_t* __restrict__ prev, size_t count, int32_t* flag)
+{
+  bool diff = false;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+    const int32_t v = values[i];
+    diff |= v != prev[i];
+    prev[i] = v;
+  }
+  if (__any(diff) && (threadIdx.x & 63) == 0)
+    atomicOr(flag, 1);
+}
+
 // ---- reconstruction: the DAG walked forward --------------------------------
 template<int C, bool ENC>
 __global__ __launch_bounds__(256) void
@@ -338,7 +594,7 @@ pred_dag_kernel(PredCtx cx)
       }
       for (int k = 0; k < C; k++) {
         if (ENC)
-          col[k] = cx.attrs[(size_t)pt * C + k];
+          col[k] = (cx.src ? cx.src : cx.attrs)[(size_t)pt * C + k];
         else
           val[k] = cx.values[(size_t)i * C + k];
       }
@@ -381,7 +637,7 @@ pred_dag_kernel(PredCtx cx)
             g[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, nidx[j] * 16, 0, /*sc1*/ 16);
         }
         for (int j = 0; j < 3; j++)
-          if (((todo >> j) & 1) && nidx[j] < base && g[j].w) {
+          if (((todo >> j) & 1) && nidx[j] < base && g[j].w == cx.tag) {
             nbv[j][0] = (int32_t)g[j].x;
             nbv[j][1 % C] = C > 1 ? (int32_t)g[j].y : nbv[j][1 % C];
             nbv[j][2 % C] = C > 2 ? (int32_t)g[j].z : nbv[j][2 % C];
@@ -448,6 +704,61 @@ pred_dag_kernel(PredCtx cx)
           }
           mode += cx.avg_disabled;
         }
+        if (ENC && elig) {
+          // decidePredModeRefl / decidePredModeColor with the rate model as it is
+          // before this predictor
+#pragma clang fp contract(off)
+          const int32_t* rm = cx.rm + (size_t)i * 6;
+          const int dis = cx.avg_disabled;
+          mode = dis;
+          int64_t p0[3] = {0, 0, 0};
+          if (dis) {
+            for (int k = 0; k < C; k++)
+              p0[k] = nbv[0][k];
+          } else {
+            for (int k = 0; k < C; k++) {
+              int64_t s = 0;
+              for (int j = 0; j < 3; j++)
+                if (j < cnt)
+                  s += (int64_t)(uint32_t)nwt[j] * nbv[j][k];
+              p0[k] = (uint16_t)div_exp2_round_half_inf(s, 8);
+            }
+          }
+          if (C == 1) {
+            int64_t rq = quantize(q[0], ((int64_t)col[0] - p0[0]) << 8);
+            int64_t best = (int64_t)pred_rate_refl(cx, rm, maxcand, (int32_t)rq, mode - dis);
+            for (int j = 0; j < 3; j++) {
+              if (j < dis || j >= cnt || j >= cx.max_direct)
+                continue;
+              rq = quantize(q[0], ((int64_t)col[0] - (int64_t)nbv[j][0]) << 8);
+              const int64_t score = (int64_t)pred_rate_refl(cx, rm, maxcand, (int32_t)rq, j + !dis);
+              if (score < best) {
+                best = score;
+                mode = j + 1;
+              }
+            }
+          } else {
+            int32_t c3[3] = {col[0], col[1 % C], col[2 % C]};
+            int64_t r[3];
+            pred_colour_residuals(cx.icp_enabled != 0, c3, p0, icpc, q, r);
+            int dist = pred_colour_distortion(clip_max, c3, p0, q);
+            double rate = pred_rate_colour(cx, rm, maxcand, r, 0);
+            double best = dist + rate * 0.14 * (q[0].step >> 8);
+            for (int j = 0; j < 3; j++) {
+              if (j < dis || j >= cnt || j >= cx.max_direct)
+                continue;
+              const int64_t np[3] = {nbv[j][0], nbv[j][1 % C], nbv[j][2 % C]};
+              pred_colour_residuals(cx.icp_enabled != 0, c3, np, icpc, q, r);
+              dist = pred_colour_distortion(clip_max, c3, np, q);
+              rate = pred_rate_colour(cx, rm, maxcand, r, j + !dis);
+              const double score = dist + rate * 0.14 * (q[0].step >> 8);
+              if (score < best) {
+                best = score;
+                mode = j + 1;
+              }
+            }
+          }
+        }
         // PCCPredictor::predictColor / predictReflectance
         int64_t pr[C];
         for (int k = 0; k < C; k++)
@@ -495,8 +806,42 @@ pred_dag_kernel(PredCtx cx)
           v = v < 0 ? 0 : (v > clip_max ? clip_max : v);
           myrec[k] = (int32_t)(uint16_t)v;
         }
+        if (ENC && elig) {
+          // encodePredModeRefl (:749-772) / encodePredModeColor (:988-1016): the mode
+          // travels in the low bits of the coded magnitudes
+          const int m = mode - cx.avg_disabled;
+          if (C == 1) {
+            const int sg = val[0] < 0 ? -1 : 1;
+            int a = val[0] < 0 ? -val[0] : val[0];
+            if (maxcand == 4) {
+              a = (a << 2) + m;
+            } else if (maxcand == 3) {
+              if (m > 0)
+                a = (a << 1) + (m - 1);
+              a = (a << 1) + (m > 0);
+            } else if (maxcand == 2) {
+              a = (a << 1) + m;
+            }
+            val[0] = sg * a;
+          } else {
+            const int s1 = val[1 % C] < 0 ? -1 : 1, s2 = val[2 % C] < 0 ? -1 : 1;
+            const int a1 = val[1 % C] < 0 ? -val[1 % C] : val[1 % C];
+            const int a2 = val[2 % C] < 0 ? -val[2 % C] : val[2 % C];
+            if (maxcand == 4) {
+              val[1 % C] = s1 * ((a1 << 1) + (m >> 1));
+              val[2 % C] = s2 * ((a2 << 1) + (m & 1));
+            } else if (maxcand == 3) {
+              const int p1 = m ? 1 : 0;
+              val[1 % C] = s1 * ((a1 << 1) + p1);
+              if (p1)
+                val[2 % C] = s2 * ((a2 << 1) + (m - p1));
+            } else if (maxcand == 2) {
+              val[1 % C] = s1 * ((a1 << 1) + m);
+            }
+          }
+        }
         {
-          const u32x4 st = {(uint32_t)myrec[0], (uint32_t)myrec[1 % C], (uint32_t)myrec[2 % C], 1u};
+          const u32x4 st = {(uint32_t)myrec[0], (uint32_t)myrec[1 % C], (uint32_t)myrec[2 % C], cx.tag};
           __builtin_amdgcn_raw_buffer_store_b128(st, rsrc, i * 16, 0, /*sc1*/ 16);
         }
         for (int k = 0; k < C; k++) {

@@ -2,8 +2,9 @@
 (oracle/pred_oracle.c, pinned to the compiled reference at symbol level by
 tests/test_oracle_pred.py) and, where oracle/_ref is present, against the
 reference operator itself.  The decoder covers every tool (prediction modes,
-inter-component prediction, QP layers, region offsets); the encoder the
-configurations without direct predictors."""
+inter-component prediction, QP layers, region offsets), and so does the encoder:
+its choice among direct predictors (a running rate model in the reference) is
+iterated to the sequential coder's fixed point."""
 import numpy as np
 import pytest
 
@@ -85,40 +86,49 @@ def test_encoder_without_direct_predictors_matches_oracle(name, ctx):
     np.testing.assert_array_equal(ctx.pred_decode_attr(lp, pp2, xyz, v2, icp=icp2), want_rec)
 
 
-def test_encoder_with_direct_predictors_is_declined(ctx):
-    from mpeg_pcc_tmc13_amd import _lib
-    xyz, attrs, lp, lod, pp, _ = oracle_case("dense_direct1")
-    before = ctx.stats()["calls_unsupported"]
-    with pytest.raises(_lib.GpccError) as e:
-        ctx.pred_forward(pp, lod["nc"], lod["ni"], lod["w"].astype(np.int32), lod["indexes"], attrs)
-    assert e.value.code == -2  # GPCC_ERR_UNSUPPORTED: the caller keeps the reference's loop
-    assert ctx.stats()["calls_unsupported"] == before + 1
-
-
-def test_one_call_encoders_decline_direct_predictors_with_the_documented_code(ctx):
-    """gpcc_pred_encode_attr / gpcc_dev_pred_encode_attr with the reference's default
-    (three direct predictors): GPCC_ERR_UNSUPPORTED, counted as such -- num_lods is an
-    OUTPUT of these entries and must not be validated first."""
-    import torch
-    from mpeg_pcc_tmc13_amd import _lib, lod_params, pred_params, synth
-    xyz, attrs = synth.dense_cloud(5000, seed=3, bits=7)
-    lp = lod_params()
-    pp = pred_params([len(xyz)], qp=34, direct=3)
-    pp.num_lods = 0  # what a caller that only fills the coding tools hands in
+@pytest.mark.parametrize("name", list(top.CASES))
+def test_encoder_with_direct_predictors_matches_oracle(name, ctx):
+    """the CTC encoder (three direct predictors, AttributeEncoder.cpp:663-745, 896-985): the
+    choice among them reads the running rate model; the device iterates the DAG pass and the
+    model's trajectory to their fixed point, which IS the sequential coder's result -- values
+    (mode bits included), reconstruction and inter-component coefficients equal the oracle's
+    (pinned to the reference's own bitstream symbols by tests/test_oracle_pred.py)"""
+    xyz, attrs, lp, lod, pp, (want_v, want_rec, want_icp, modes) = oracle_case(name)
     before = ctx.stats()
-    with pytest.raises(_lib.GpccError) as e:
-        ctx.pred_encode_attr(lp, pp, xyz, attrs)
-    assert e.value.code == -2
+    v, rec, icp = ctx.pred_forward(pp, lod["nc"], lod["ni"], lod["w"].astype(np.int32), lod["indexes"], attrs)
+    if attrs.shape[1] == 3 and pp.inter_component_prediction_enabled_flag:
+        np.testing.assert_array_equal(icp, want_icp)
+    np.testing.assert_array_equal(v, want_v)
+    np.testing.assert_array_equal(rec, want_rec)
+    assert ctx.stats()["calls_unsupported"] == before["calls_unsupported"]
+    # and the decoder gives the encoder's reconstruction back
+    np.testing.assert_array_equal(
+        ctx.pred_inverse(pp, lod["nc"], lod["ni"], lod["w"].astype(np.int32), lod["indexes"], v, icp=icp), rec)
+
+
+def test_one_call_encoders_take_the_ctc_configuration(ctx):
+    """gpcc_pred_encode_attr / gpcc_dev_pred_encode_attr with three direct predictors (the
+    reference's default; declined until round 3): same values as the oracle's encoder on the
+    oracle's LoD structure"""
+    import torch
+    from mpeg_pcc_tmc13_amd import lod_params, pred_params, synth
+    xyz, attrs = synth.dense_cloud(20000, seed=3, bits=8)
+    lp = lod_params()
+    lod = lh.oracle_lod_generate(xyz, lp)
+    ppo = pred_params(lod["npl"], qp=34, direct=3, max_levels=lp.num_detail_levels_minus1 + 1)
+    want_v, want_rec, want_icp, _ = lh.oracle_pred(True, ppo, lod, attrs=attrs)
+    pp = pred_params([len(xyz)], qp=34, direct=3, max_levels=lp.num_detail_levels_minus1 + 1)
+    v, rec, icp, idx = ctx.pred_encode_attr(lp, pp, xyz, attrs)
+    np.testing.assert_array_equal(v, want_v)
+    np.testing.assert_array_equal(rec, want_rec)
     dev = torch.device("cuda:0")
     d_xyz = torch.from_numpy(np.ascontiguousarray(xyz)).to(dev)
     d_a = torch.from_numpy(np.ascontiguousarray(attrs).reshape(-1)).to(dev)
     d_v = torch.zeros_like(d_a)
-    with pytest.raises(_lib.GpccError) as e:
-        ctx.dev_pred_attr(True, lp, [pp], [0, len(xyz)], d_xyz.data_ptr(), d_a.data_ptr(), d_v.data_ptr(), 3)
-    assert e.value.code == -2
-    after = ctx.stats()
-    assert after["calls_unsupported"] == before["calls_unsupported"] + 2
-    assert after["calls_failed"] == before["calls_failed"]
+    pp3 = pred_params([len(xyz)], qp=34, direct=3, max_levels=lp.num_detail_levels_minus1 + 1)
+    ctx.dev_pred_attr(True, lp, [pp3], [0, len(xyz)], d_xyz.data_ptr(), d_a.data_ptr(), d_v.data_ptr(), 3)
+    ctx.synchronize()
+    np.testing.assert_array_equal(d_v.cpu().numpy().reshape(-1, 3), want_v)
 
 
 def test_qp_layers_and_region_offsets(ctx):
