@@ -127,3 +127,43 @@ def test_raht_10M_as_slices_vs_checker(ctx):
             want_co, want_rec = chk.raht_forward(p, f[0], f[1])
             np.testing.assert_array_equal(co[c * a:c * b], want_co, err_msg=f"slice {i}, C={c}")
             np.testing.assert_array_equal(rec[a:b], want_rec, err_msg=f"slice {i}, C={c}")
+
+
+def test_predicting_device_tier_5x1M_vs_oracle(ctx):
+    """configs[2]'s other half at full size: the predicting coder's device tier on five
+    1 M-point slices resident in HBM (LoD build + transform per slice, CTC tools: three direct
+    predictors, inter-component prediction) -- every slice's values and reconstruction against
+    the oracle's encoder on the device-built structure (itself pinned to the reference, above),
+    and the device decoder gives the reconstruction back."""
+    import torch
+    from mpeg_pcc_tmc13_amd import lod_params, pred_params, synth
+    slices, n = 5, 1_000_000
+    clouds = [synth.dense_cloud(n, seed=81 + i, bits=10) for i in range(slices)]
+    sizes = [len(c[0]) for c in clouds]
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    lp = lod_params(levels=12, lifting=False, intra_range=1100000, blend=True)
+    lp.intra_lod_prediction_skip_layers = 0
+    dev = torch.device("cuda:0")
+    d_xyz = torch.from_numpy(np.concatenate([c[0] for c in clouds])).to(dev)
+    d_attrs = torch.from_numpy(np.concatenate([c[1] for c in clouds]).reshape(-1)).to(dev)
+    d_vals = torch.zeros_like(d_attrs)
+    d_dec = torch.zeros_like(d_attrs)
+    ctx.set_morton_bits(30)
+    mk = lambda: [pred_params([sz], qp=34, bitdepth=8, max_levels=12, quant_neigh_weight=(16, 8, 4)) for sz in sizes]
+    pps = mk()
+    icp = ctx.dev_pred_attr(True, lp, pps, offs, d_xyz.data_ptr(), d_attrs.data_ptr(), d_vals.data_ptr(), 3)
+    ctx.dev_pred_attr(False, lp, mk(), offs, d_xyz.data_ptr(), d_dec.data_ptr(), d_vals.data_ptr(), 3, icp=icp)
+    ctx.synchronize()
+    ctx.set_morton_bits(0)
+    assert torch.equal(d_attrs, d_dec)
+    vals = d_vals.cpu().numpy().reshape(-1, 3)
+    recs = d_attrs.cpu().numpy().reshape(-1, 3)
+    for s in (0, slices - 1):  # (the oracle's encoder takes ~0.1 s per slice, its LoD input comes from the device)
+        xyz, col = clouds[s]
+        lod = ctx.lod_build(lp, xyz)
+        pp = pred_params(lod["npl"], qp=34, bitdepth=8, max_levels=12, quant_neigh_weight=(16, 8, 4))
+        want_v, want_rec, want_icp, _ = lh.oracle_pred(True, pp, lod, attrs=col)
+        a, b = int(offs[s]), int(offs[s + 1])
+        np.testing.assert_array_equal(vals[a:b], want_v, err_msg=f"slice {s}")
+        np.testing.assert_array_equal(recs[a:b], want_rec, err_msg=f"slice {s}")
+        np.testing.assert_array_equal(icp[s], want_icp, err_msg=f"slice {s}")
