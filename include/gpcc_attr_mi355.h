@@ -549,7 +549,10 @@ int gpcc_dev_pred_decode_attr(
  * listed device; a call gives every device a contiguous, size-balanced run of
  * the slices, runs the transforms concurrently and gathers reconstructions and
  * coefficients on devices[0] -- RCCL send / receive over xGMI (librccl is
- * loaded on first use) -- from where one download fills the host buffers.
+ * loaded on first use) -- the COEFFICIENTS, which feed one arithmetic coder; the
+ * reconstruction is downloaded from the device that made it.  The caller's
+ * buffers are pinned for the duration of the call (hipHostRegister) so that the
+ * uploads of all devices overlap.
  * Listing one physical device several times is allowed (the gather is then a
  * device copy): it exercises the sharding on a one-GPU box.
  *   offsets [num_slices + 1], morton [N] (ascending per slice), attrs [N][c]
@@ -560,6 +563,10 @@ int gpcc_multi_create(const int32_t* devices, int32_t num_devices, gpcc_multi** 
 void gpcc_multi_destroy(gpcc_multi* m);
 int gpcc_multi_num_devices(const gpcc_multi* m);
 int gpcc_multi_uses_rccl(const gpcc_multi* m); /* 1: the gather goes through RCCL */
+/* librccl loads, its symbols resolve and a one-rank communicator moves a buffer
+ * through ncclSend / ncclRecv on `device` (what a single-GPU box can check of
+ * the gather's transport); 0 = fine. */
+int gpcc_multi_rccl_selftest(int32_t device);
 int gpcc_multi_raht_forward(
   gpcc_multi* m, const gpcc_raht_params* params, int32_t num_slices,
   const int64_t* offsets, const int64_t* morton, int32_t* attrs,

@@ -20,7 +20,7 @@ ABI_SYMBOLS = [
     "gpcc_lift_forward", "gpcc_lift_inverse", "gpcc_lod_compute_weights", "gpcc_lod_build", "gpcc_estimate_dist2", "gpcc_recolour", "gpcc_raht_encode_attr", "gpcc_raht_decode_attr",
     "gpcc_lift_encode_attr", "gpcc_lift_decode_attr", "gpcc_zero_run_pack", "gpcc_raht_encode_attr_packed",
     "gpcc_dev_lod_build", "gpcc_dev_lift_encode_attr", "gpcc_dev_lift_decode_attr",
-    "gpcc_multi_create", "gpcc_multi_destroy", "gpcc_multi_num_devices", "gpcc_multi_uses_rccl",
+    "gpcc_multi_create", "gpcc_multi_destroy", "gpcc_multi_num_devices", "gpcc_multi_uses_rccl", "gpcc_multi_rccl_selftest",
     "gpcc_multi_raht_forward", "gpcc_multi_raht_inverse", "gpcc_binarise_symbols",
     "gpcc_pred_forward", "gpcc_pred_inverse", "gpcc_pred_encode_attr", "gpcc_pred_decode_attr",
     "gpcc_dev_pred_encode_attr", "gpcc_dev_pred_decode_attr",

@@ -3624,7 +3624,23 @@ multi_transform(
   int bits = 1;
   for (int s = 0; s < num_slices; s++)
     bits = std::max(bits, bitlen64((uint64_t)(morton[offsets[s]] ^ morton[offsets[s + 1] - 1])));
+  // The caller's buffers are pageable: an "asynchronous" copy from pageable memory is
+  // staged synchronously, so the uploads of eight devices would run one after the other
+  // in front of transforms that take less time than they do.  Pinned for the duration of
+  // the call (when the runtime allows it), the copies of all devices overlap.
+  std::vector<void*> pinned;
+  auto pin = [&](const void* ptr, size_t bytes) {
+    if (nd > 1 && bytes && hipHostRegister((void*)ptr, bytes, hipHostRegisterDefault) == hipSuccess)
+      pinned.push_back((void*)ptr);
+    else
+      (void)hipGetLastError();  // (already registered, or not permitted: the copies still work)
+  };
+  pin(morton, sizeof(int64_t) * (size_t)n_total);
+  pin(attrs, sizeof(int32_t) * (size_t)n_total * c);
+  pin(coeffs, sizeof(int32_t) * (size_t)n_total * c);
   auto release = [&]() {
+    for (void* q : pinned)
+      hipHostUnregister(q);
     for (int d = 0; d < nd; d++) {
       auto& p = m->part[d];
       pool_free(m->ctx[d], p.d_m);
@@ -3640,13 +3656,14 @@ multi_transform(
       auto& p = m->part[d];
       gpcc_ctx* ctx = m->ctx[d];
       HIP_TRY(hipSetDevice(ctx->device));
-      // device 0 holds the gathered batch, the others their own part
+      // device 0 holds the gathered coefficients (the encoder's output for the
+      // arithmetic coder), every device its own part of everything else
       const int64_t b = offsets[p.s0];
       const int64_t np = offsets[p.s1] - b;
-      const int64_t nbuf = d == 0 ? n_total : np;
+      const int64_t nbuf = (d == 0 && encoder) ? n_total : np;
       if (nbuf == 0)
         continue;
-      HIP_TRY(pool_malloc(ctx, (void**)&p.d_a, sizeof(int32_t) * nbuf * c));
+      HIP_TRY(pool_malloc(ctx, (void**)&p.d_a, sizeof(int32_t) * std::max<int64_t>(np, 1) * c));
       HIP_TRY(pool_malloc(ctx, (void**)&p.d_c, sizeof(int32_t) * nbuf * c));
       if (np == 0)
         continue;
@@ -3685,19 +3702,17 @@ multi_transform(
       if (np == 0)
         continue;
       hipStream_t st = m->ctx[d]->stream;
-      if (!m->comm.empty()) {
-        nccl(m->rccl.Send(p.d_a, (size_t)np * c, kNcclInt32, 0, m->comm[d], st));
-        nccl(m->rccl.Recv(root.d_a + b * c, (size_t)np * c, kNcclInt32, d, m->comm[0], st0));
-        if (encoder) {
+      // The COEFFICIENTS are gathered on device 0 over xGMI (they feed one arithmetic
+      // coder); the reconstruction goes home from the device that made it.
+      if (encoder) {
+        if (!m->comm.empty()) {
           nccl(m->rccl.Send(p.d_c, (size_t)np * c, kNcclInt32, 0, m->comm[d], st));
           nccl(m->rccl.Recv(root.d_c + b * c, (size_t)np * c, kNcclInt32, d, m->comm[0], st0));
-        }
-      } else {
-        // one physical device behind several entries: a copy on the producer's stream
-        HIP_TRY(hipSetDevice(m->ctx[d]->device));
-        HIP_TRY(hipMemcpyAsync(root.d_a + b * c, p.d_a, sizeof(int32_t) * np * c, hipMemcpyDeviceToDevice, st));
-        if (encoder)
+        } else {
+          // one physical device behind several entries: a copy on the producer's stream
+          HIP_TRY(hipSetDevice(m->ctx[d]->device));
           HIP_TRY(hipMemcpyAsync(root.d_c + b * c, p.d_c, sizeof(int32_t) * np * c, hipMemcpyDeviceToDevice, st));
+        }
       }
     }
     if (!m->comm.empty()) {
@@ -3713,10 +3728,22 @@ multi_transform(
       if (r)
         return r;
     }
-    HIP_TRY(hipMemcpyAsync(attrs, root.d_a, sizeof(int32_t) * n_total * c, hipMemcpyDeviceToHost, st0));
+    // (outputs only now: a failed device leaves the caller's buffers as they were)
+    for (int d = 0; d < nd; d++) {
+      auto& p = m->part[d];
+      const int64_t b = offsets[p.s0], np = offsets[p.s1] - b;
+      if (np == 0)
+        continue;
+      HIP_TRY(hipSetDevice(m->ctx[d]->device));
+      HIP_TRY(hipMemcpyAsync(attrs + b * c, p.d_a, sizeof(int32_t) * np * c, hipMemcpyDeviceToHost, m->ctx[d]->stream));
+    }
+    HIP_TRY(hipSetDevice(m->ctx[0]->device));
     if (encoder)
       HIP_TRY(hipMemcpyAsync(coeffs, root.d_c, sizeof(int32_t) * n_total * c, hipMemcpyDeviceToHost, st0));
-    HIP_TRY(hipStreamSynchronize(st0));
+    for (int d = 0; d < nd; d++) {
+      HIP_TRY(hipSetDevice(m->ctx[d]->device));
+      HIP_TRY(hipStreamSynchronize(m->ctx[d]->stream));
+    }
     return GPCC_OK;
   };
   r = run();
@@ -3790,6 +3817,58 @@ int
 gpcc_multi_uses_rccl(const gpcc_multi* m)
 {
   return m && !m->comm.empty();
+}
+
+// librccl loads, the seven symbols resolve, and a one-rank communicator moves a buffer
+// through ncclSend / ncclRecv on `device`: what can be checked of the gather's transport
+// on a box with a single GPU.  0 = fine.
+int
+gpcc_multi_rccl_selftest(int32_t device)
+{
+  static RcclApi api;
+  if (!api.load())
+    return fail(GPCC_ERR_NO_DEVICE, "librccl could not be loaded or lacks a symbol");
+  HIP_TRY(hipSetDevice(device));
+  ncclComm_t comm = nullptr;
+  int dev = device;
+  int e = api.CommInitAll(&comm, 1, &dev);
+  if (e)
+    return fail(GPCC_ERR_HIP, std::string("ncclCommInitAll: ") + api.GetErrorString(e));
+  const int n = 1 << 16;
+  int32_t *a = nullptr, *b = nullptr;
+  hipStream_t st = nullptr;
+  int rc = GPCC_OK;
+  auto run = [&]() -> int {
+    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    HIP_TRY(hipMalloc((void**)&a, sizeof(int32_t) * n));
+    HIP_TRY(hipMalloc((void**)&b, sizeof(int32_t) * n));
+    std::vector<int32_t> h(n), g(n, 0);
+    for (int i = 0; i < n; i++)
+      h[i] = i * 2654435761u;
+    HIP_TRY(hipMemcpyAsync(a, h.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(b, 0, sizeof(int32_t) * n, st));
+    int err = api.GroupStart();
+    err = err ? err : api.Send(a, n, kNcclInt32, 0, comm, st);
+    err = err ? err : api.Recv(b, n, kNcclInt32, 0, comm, st);
+    const int end = api.GroupEnd();
+    err = err ? err : end;
+    if (err)
+      return fail(GPCC_ERR_HIP, std::string("RCCL send / receive: ") + api.GetErrorString(err));
+    HIP_TRY(hipMemcpyAsync(g.data(), b, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (g != h)
+      return fail(GPCC_ERR_HIP, "RCCL send / receive returned different data");
+    return GPCC_OK;
+  };
+  rc = run();
+  if (a)
+    hipFree(a);
+  if (b)
+    hipFree(b);
+  if (st)
+    hipStreamDestroy(st);
+  api.CommDestroy(comm);
+  return rc;
 }
 
 int

@@ -67,3 +67,30 @@ def test_distinct_devices_gather_through_rccl():
         o_co, o_rec = o.raht_forward(p, ms[i], as_[i])
         np.testing.assert_array_equal(co[a:b], o_co)
         np.testing.assert_array_equal(rec[a:b], o_rec)
+
+
+def test_rccl_transport_selftest():
+    """What a one-GPU box can check of the gather's transport: librccl loads, the seven
+    symbols the library uses resolve, and a one-rank communicator moves a buffer through
+    ncclSend / ncclRecv (the calls multi_transform issues) bit for bit."""
+    from mpeg_pcc_tmc13_amd import _lib
+    lib = _lib.load()
+    lib.gpcc_multi_rccl_selftest.argtypes = [__import__("ctypes").c_int32]
+    rc = lib.gpcc_multi_rccl_selftest(0)
+    assert rc == 0, lib.gpcc_last_error()
+
+
+def test_failed_call_leaves_the_callers_buffers(tmp_path):
+    """outputs are written only once every device has finished without an error: an
+    invalid batch (unsorted slice) returns an error and attrs / coeffs are untouched"""
+    from mpeg_pcc_tmc13_amd import _lib, raht_params
+    from mpeg_pcc_tmc13_amd.raht import MultiContext
+    ms, as_, offsets = make_batch([5000, 4000], 1)
+    morton = np.concatenate(ms)
+    attrs = np.concatenate(as_)
+    bad_offsets = offsets.copy()
+    bad_offsets[1] = bad_offsets[2]  # an empty slice
+    mc = MultiContext([0, 0])
+    with pytest.raises(_lib.GpccError):
+        mc.raht_forward(raht_params(qp=30), bad_offsets, morton, attrs)
+    mc.close()
