@@ -3,8 +3,9 @@
 // recolourReflectance :618-916) on the device.
 //
 // The reference searches two nanoflann k-d trees point by point.  Here both clouds
-// get a DENSE CELL TABLE over their bounding box (cell side 2^shift chosen so that
-// the table has at most ~4 cells per point: count / scan / fill, three launches),
+// get a DENSE CELL TABLE over their bounding box (cell side 2^shift: at most 32 cells per
+// point, refined for sparse clouds while an occupied cell holds more than 24 points;
+// count / scan / fill, three launches),
 // and a thread finds the exact K nearest points of its query by visiting the cells
 // ring after ring around the query's cell until the K-th distance is not larger
 // than anything an unvisited cell can hold.  Distances, weights, centroids and the
@@ -30,6 +31,8 @@
 namespace gpcc {
 
 constexpr int kRcMaxK = 8;
+// refine the cell side while the cell an average point sits in holds more than this
+constexpr double kRcMaxCellLoad = 12.0;
 constexpr int kRcScanBlock = 2048;  // elements per workgroup of the scan
 
 struct RcGrid {
@@ -99,6 +102,24 @@ rc_cell_count_kernel(RcGrid g)
 {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < g.n; i += gridDim.x * blockDim.x)
     atomicAdd(&g.start[rc_cell(g, g.xyz[3 * i], g.xyz[3 * i + 1], g.xyz[3 * i + 2]) + 1], 1);
+}
+
+// sum over cells of count^2 (start[c + 1] still holds the cell's count here): divided by
+// the number of points it is the load of the cell an average POINT sits in, which is what
+// a query pays per cell it opens -- the mean over cells hides the crowded ones
+__global__ __launch_bounds__(256) void
+rc_cell_load_kernel(const int32_t* __restrict__ start, size_t cells, unsigned long long* load)
+{
+  unsigned long long acc = 0;
+  for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < cells; c += (size_t)gridDim.x * blockDim.x) {
+    const unsigned long long k = (unsigned)start[c + 1];
+    acc += k * k;
+  }
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1)
+    acc += __shfl_xor(acc, d);
+  if ((threadIdx.x & 63) == 0 && acc)
+    atomicAdd(load, acc);
 }
 
 __global__ __launch_bounds__(256) void
