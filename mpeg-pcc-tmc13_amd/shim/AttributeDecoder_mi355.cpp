@@ -1,0 +1,161 @@
+// AttributeDecoder_mi355.cpp -- seam 3, decoder side: the operator behind
+//   pcc::makeAttributeDecoder()                       (tmc3/Attribute.h:80,
+//                                                      AttributeDecoder.cpp:183-187)
+// for the LIFTING and PREDICTING transforms (decodeColorsLift /
+// decodeReflectancesLift AttributeDecoder.cpp:678-857, decodeColorsPred /
+// decodeReflectancesPred :328-523).  As on the encoder side
+// (AttributeEncoder_mi355.cpp) the seam is the factory: the integrator compiles
+// tmc3/AttributeDecoder.cpp with -DmakeAttributeDecoder=makeAttributeDecoderCpu
+// and adds this translation unit.  The symbols of a slice do not depend on its
+// reconstruction, so the whole slice is parsed first -- the reference's own
+// arithmetic decoder and context models, the residual syntax of shim_common.hpp --
+// and ONE device call (gpcc_lift_decode_attr / gpcc_pred_decode_attr: LoD build +
+// inverse transform) turns the values into the attributes.  Every other slice
+// (RAHT -- seam 1 --, raw, inter prediction, a partial geometry octree) goes to
+// the reference's decoder unchanged.
+//
+// Built against the reference's headers; contains no reference code.
+#include <memory>
+#include <vector>
+
+#include "Attribute.h"
+
+#include "shim_common.hpp"
+
+namespace pcc {
+// the reference's factory, renamed at compile time (see above)
+std::unique_ptr<AttributeDecoderIntf> makeAttributeDecoderCpu();
+}  // namespace pcc
+
+namespace gpcc_shim {
+long long g_dec_device = 0, g_dec_cpu = 0;
+
+namespace {
+
+using namespace pcc;
+
+class DeviceAttributeDecoder : public AttributeDecoderIntf {
+public:
+  DeviceAttributeDecoder() : _cpu(makeAttributeDecoderCpu()) {}
+
+  void decode(
+    const SequenceParameterSet& sps, const AttributeDescription& desc,
+    const AttributeParameterSet& aps, const AttributeBrickHeader& abh,
+    int geom_num_points_minus1, int minGeomNodeSizeLog2, const char* payload,
+    size_t payloadLen, AttributeContexts& ctxtMem, PCCPointSet3& cloud,
+    AttributeInterPredParams& inter) override
+  {
+    const bool ours = aps.attr_encoding == AttributeEncoding::kLiftingTransform
+      || aps.attr_encoding == AttributeEncoding::kPredictingTransform;
+    if (ours) {
+      if (on_device(sps, desc, aps, abh, minGeomNodeSizeLog2, payload, payloadLen, ctxtMem, cloud, inter)) {
+        g_dec_device++;
+        return;
+      }
+      g_dec_cpu++;
+      strict_check("the lifting / predicting attribute decoder");
+    }
+    _cpu->decode(
+      sps, desc, aps, abh, geom_num_points_minus1, minGeomNodeSizeLog2, payload, payloadLen,
+      ctxtMem, cloud, inter);
+  }
+
+  bool isReusable(const AttributeParameterSet& aps, const AttributeBrickHeader& abh) const override
+  {
+    return _cpu->isReusable(aps, abh);
+  }
+
+private:
+  bool on_device(
+    const SequenceParameterSet& sps, const AttributeDescription& desc,
+    const AttributeParameterSet& aps, const AttributeBrickHeader& abh,
+    int minGeomNodeSizeLog2, const char* payload, size_t payloadLen,
+    AttributeContexts& ctxtMem, PCCPointSet3& cloud, AttributeInterPredParams& inter)
+  {
+    const int c = desc.attr_num_dimensions_minus1 + 1;
+    const int n = int(cloud.getPointCount());
+    if ((c != 1 && c != 3) || n <= 0 || inter.enableAttrInterPred)
+      return false;
+    gpcc_ctx* ctx = process_context("the attribute decoder");
+    gpcc_lod_params lod;
+    if (!ctx || !flatten_lod(aps, abh, minGeomNodeSizeLog2, inter, &lod))
+      return false;
+    const QpSet qpSet = deriveQpSet(desc, aps, abh);
+    const bool lifting = aps.attr_encoding == AttributeEncoding::kLiftingTransform;
+    gpcc_lift_params lp{};
+    gpcc_pred_params pp{};
+    if (lifting ? !flatten_qp(qpSet, &lp) : !flatten_qp(qpSet, &pp))
+      return false;
+
+    // ---- the slice's symbols: the reference's arithmetic decoder, set up as
+    //      PCCResidualsDecoder::start (:80-88) does.  A copy of the models is
+    //      advanced; the caller's are replaced only when the slice is done ----------
+    SliceContexts models(ctxtMem);
+    EntropyDecoder ac;
+    ac.setBuffer(payloadLen, payload);
+    ac.enableBypassStream(sps.cabac_bypass_stream_enabled_flag);
+    ac.setBypassBinCodingWithoutProbUpdate(sps.bypass_bin_coding_without_prob_update);
+    ac.start();
+    std::vector<int32_t> values(size_t(c) * n);
+    models.parse_slice(ac, n, c, values.data());
+    ac.stop();
+
+    // ---- LoD build + inverse transform -----------------------------------------------
+    std::vector<int32_t> xyz, attrs(size_t(c) * n);
+    positions_of(cloud, &xyz);
+    int rc;
+    if (lifting) {
+      lp.bitdepth = desc.bitdepth;
+      lp.fixed_point_qp_offset = qpSet.fixedPointQpOffset;
+      lp.last_component_prediction_enabled_flag = abh.lcpPresent(desc, aps);
+      int8_t lcp[GPCC_MAX_LODS] = {};
+      if (lp.last_component_prediction_enabled_flag)
+        for (size_t l = 0; l < abh.attrLcpCoeffs.size() && l < GPCC_MAX_LODS; l++)
+          lcp[l] = abh.attrLcpCoeffs[l];
+      rc = gpcc_lift_decode_attr(ctx, &lod, &lp, xyz.data(), attrs.data(), values.data(), lcp, nullptr, n, c);
+    } else {
+      pp.bitdepth = desc.bitdepth;
+      pp.max_num_direct_predictors = aps.max_num_direct_predictors;
+      pp.direct_avg_predictor_disabled_flag = aps.direct_avg_predictor_disabled_flag;
+      pp.adaptive_prediction_threshold = aps.adaptivePredictionThreshold(desc);
+      pp.inter_component_prediction_enabled_flag = abh.icpPresent(desc, aps);
+      for (int k = 0; k < 3; k++)
+        pp.quant_neigh_weight[k] = aps.quant_neigh_weight[k];
+      pp.max_num_detail_levels = aps.maxNumDetailLevels();
+      int8_t icp[GPCC_MAX_LODS][3] = {};
+      if (pp.inter_component_prediction_enabled_flag)
+        for (size_t l = 0; l < abh.icpCoeffs.size() && l < GPCC_MAX_LODS; l++)
+          for (int k = 0; k < 3; k++)
+            icp[l][k] = abh.icpCoeffs[l][k];
+      rc = gpcc_pred_decode_attr(ctx, &lod, &pp, xyz.data(), attrs.data(), values.data(), &icp[0][0], nullptr, n, c);
+    }
+    if (rc) {
+      if (rc != GPCC_ERR_UNSUPPORTED)
+        std::fprintf(stderr, "gpcc: %s; the attribute decoder falls back to the CPU\n", gpcc_last_error());
+      return false;
+    }
+    store_attributes(attrs, c, &cloud);
+    ctxtMem = models.saved();
+    return true;
+  }
+
+  std::unique_ptr<AttributeDecoderIntf> _cpu;
+};
+
+}  // namespace
+}  // namespace gpcc_shim
+
+namespace pcc {
+std::unique_ptr<AttributeDecoderIntf>
+makeAttributeDecoder()
+{
+  return std::unique_ptr<AttributeDecoderIntf>(new gpcc_shim::DeviceAttributeDecoder());
+}
+}  // namespace pcc
+
+extern "C" void
+gpcc_shim_decoder_counters(long long out[2])
+{
+  out[0] = gpcc_shim::g_dec_device;
+  out[1] = gpcc_shim::g_dec_cpu;
+}

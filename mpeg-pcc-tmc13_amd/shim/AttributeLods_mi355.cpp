@@ -16,14 +16,9 @@
 // device path declines (no GPU, inter prediction, scalable lifting, ...) the renamed reference body runs instead.
 //
 // Built against the reference's headers; contains no reference code.
-#include <cstdio>
-#include <cstdlib>
 #include <vector>
 
-#include "AttributeCommon.h"
-#include "PCCTMC3Common.h"
-
-#include "gpcc_attr_mi355.h"
+#include "shim_common.hpp"
 
 namespace gpcc_shim {
 // AttributeLods_cpu_adapter.cpp: calls the renamed reference member
@@ -35,67 +30,9 @@ void lods_generate_cpu(
 
 // what this TU did (gpcc_shim_lod_counters)
 long long g_lod_device_calls = 0, g_lod_cpu_calls = 0;
-
-gpcc_ctx*
-lod_device_context()
-{
-  static gpcc_ctx* ctx = nullptr;
-  static bool tried = false;
-  if (!tried) {
-    tried = true;
-    const char* dev = std::getenv("GPCC_DEVICE");
-    if (gpcc_ctx_create(dev ? std::atoi(dev) : 0, nullptr, &ctx) != GPCC_OK) {
-      std::fprintf(
-        stderr, "gpcc: no MI355X context (%s); LoD build stays on the CPU\n",
-        gpcc_last_error());
-      ctx = nullptr;
-    }
-  }
-  return ctx;
-}
 }  // namespace gpcc_shim
 
 namespace pcc {
-
-namespace {
-
-// false: the block cannot express these parameters -> CPU path
-bool
-flatten(
-  const AttributeParameterSet& aps, const AttributeBrickHeader& abh,
-  int minGeomNodeSizeLog2, const AttributeInterPredParams& inter,
-  gpcc_lod_params* lp)
-{
-  if (inter.enableAttrInterPred || minGeomNodeSizeLog2 > 0)
-    return false;
-  if (aps.num_detail_levels_minus1 + 1 >= GPCC_MAX_LODS)
-    return false;
-  *lp = gpcc_lod_params{};
-  lp->attr_encoding = int(aps.attr_encoding);
-  lp->lod_decimation_type = int(aps.lod_decimation_type);
-  lp->num_detail_levels_minus1 = aps.num_detail_levels_minus1;
-  lp->num_pred_nearest_neighbours_minus1 = aps.num_pred_nearest_neighbours_minus1;
-  lp->intra_lod_search_range = aps.intra_lod_search_range;
-  lp->inter_lod_search_range = aps.inter_lod_search_range;
-  lp->prediction_with_distribution_enabled = aps.predictionWithDistributionEnabled;
-  for (int k = 0; k < 3; k++)
-    lp->lod_neigh_bias[k] = aps.lodNeighBias[k];
-  lp->intra_lod_prediction_skip_layers = aps.intra_lod_prediction_skip_layers;
-  lp->dist2 = aps.dist2;
-  lp->attr_dist2_delta = abh.attr_dist2_delta;
-  lp->canonical_point_order_flag = aps.canonical_point_order_flag;
-  lp->max_points_per_sort_log2_plus1 = aps.max_points_per_sort_log2_plus1;
-  lp->scalable_lifting_enabled_flag = aps.scalable_lifting_enabled_flag;
-  lp->max_neigh_range_minus1 = aps.max_neigh_range_minus1;
-  lp->pred_weight_blending_enabled_flag =
-    aps.attr_encoding == AttributeEncoding::kPredictingTransform
-    && aps.pred_weight_blending_enabled_flag;
-  for (size_t i = 0; i < aps.lodSamplingPeriod.size() && i < GPCC_MAX_LODS; i++)
-    lp->lod_sampling_period[i] = aps.lodSamplingPeriod[i];
-  return true;
-}
-
-}  // namespace
 
 void
 AttributeLods::generate(
@@ -104,14 +41,11 @@ AttributeLods::generate(
   const PCCPointSet3& cloud, const AttributeInterPredParams& attrInterPredParams)
 {
   gpcc_lod_params lp;
-  gpcc_ctx* ctx = gpcc_shim::lod_device_context();
+  gpcc_ctx* ctx = gpcc_shim::process_context("the LoD build");
   const int n = int(cloud.getPointCount());
-  if (ctx && n > 0 && flatten(aps, abh, minGeomNodeSizeLog2, attrInterPredParams, &lp)) {
-    static_assert(sizeof(point_t) == 3 * sizeof(int32_t), "Vec3<int32_t> is three ints");
-    std::vector<int32_t> xyz(size_t(n) * 3);
-    for (int i = 0; i < n; i++)
-      for (int k = 0; k < 3; k++)
-        xyz[3 * size_t(i) + k] = cloud[i][k];
+  if (ctx && n > 0 && gpcc_shim::flatten_lod(aps, abh, minGeomNodeSizeLog2, attrInterPredParams, &lp)) {
+    std::vector<int32_t> xyz;
+    gpcc_shim::positions_of(cloud, &xyz);
     std::vector<int32_t> nc(n), ni(size_t(n) * 3), nw(size_t(n) * 3), idx(n);
     int32_t npl[GPCC_MAX_LODS], nl = 0;
     int rc = gpcc_lod_build(
@@ -141,13 +75,7 @@ AttributeLods::generate(
       std::fprintf(stderr, "gpcc: %s; LoD build falls back to the CPU\n", gpcc_last_error());
   }
   gpcc_shim::g_lod_cpu_calls++;
-  {
-    const char* strict = std::getenv("GPCC_STRICT");
-    if (strict && strict[0] == '1') {
-      std::fprintf(stderr, "gpcc: GPCC_STRICT=1 and AttributeLods::generate did not run on the device (%s)\n", gpcc_last_error());
-      std::abort();
-    }
-  }
+  gpcc_shim::strict_check("AttributeLods::generate");
   gpcc_shim::lods_generate_cpu(
     *this, aps, abh, geom_num_points_minus1, minGeomNodeSizeLog2, cloud,
     attrInterPredParams);

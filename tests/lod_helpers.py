@@ -199,10 +199,11 @@ def oracle_pred(forward, pp, lod, attrs=None, values=None, icp=None, qp_off=None
     return v, a, l, modes
 
 
-def ref_pred_roundtrip(lp, pp, aps_threshold, qp, chroma, xyz, attrs):
+def ref_pred_roundtrip(lp, pp, aps_threshold, qp, chroma, xyz, attrs, lib=None):
     """reference AttributeEncoder::encode + AttributeDecoder::decode for the
-    predicting transform -> (payload, recon_enc, recon_dec, icp int8 [32,3])"""
-    lib = ol.ref().lib
+    predicting transform -> (payload, recon_enc, recon_dec, icp int8 [32,3]).
+    `lib`: another build of the same harness (libtmc3_shim3.so)."""
+    lib = lib or ol.ref().lib
     lib.ref_pred_roundtrip.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, i32p, i32p, C.c_int32,
                                        C.c_int32, i32p, i32p, u8p, C.c_int32, C.c_void_p]
     xyz = np.ascontiguousarray(xyz, dtype=np.int32)

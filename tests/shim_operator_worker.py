@@ -34,6 +34,16 @@ def make_case(case):
     return xyz, attrs, rp, lp
 
 
+def pred_case(case):
+    """a case of tests/test_oracle_pred.py (transform == 1): cloud, LoD and tool parameters"""
+    from mpeg_pcc_tmc13_amd import pred_params
+    import test_oracle_pred as top
+    xyz, attrs, lp, qp, bitdepth, thr, po = top.make(case["pred_case"])
+    pp = pred_params([attrs.shape[0]], qp=qp, chroma_offset=0, bitdepth=bitdepth, threshold=thr,
+                     max_levels=lp.num_detail_levels_minus1 + 1, **po)
+    return xyz, attrs, lp, pp, thr, qp
+
+
 def digest(a):
     return hashlib.md5(np.ascontiguousarray(a).tobytes()).hexdigest()
 
@@ -42,17 +52,26 @@ def main():
     import conftest  # noqa: F401  (loads the package under its alias)
     import lod_helpers as lh
     case = json.loads(sys.argv[1])
-    xyz, attrs, rp, lp = make_case(case)
     import torch  # noqa: F401  (one HIP runtime per process: torch's, see _lib.load)
-    lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libtmc3_shim.so"))
-    payload, rec_enc, rec_dec = lh.ref_operator_roundtrip(
-        lp, case["transform"], rp, case["qp"], case["chroma"], 8, 1, xyz, attrs, lib=lib)
-    raht, lod = (C.c_longlong * 2)(), (C.c_longlong * 2)()
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", case.get("lib", "libtmc3_shim.so")))
+    if case["transform"] == 1:
+        xyz, attrs, lp, pp, thr, qp = pred_case(case)
+        payload, rec_enc, rec_dec, _ = lh.ref_pred_roundtrip(lp, pp, thr, qp, 0, xyz, attrs, lib=lib)
+    else:
+        xyz, attrs, rp, lp = make_case(case)
+        payload, rec_enc, rec_dec = lh.ref_operator_roundtrip(
+            lp, case["transform"], rp, case["qp"], case["chroma"], 8 if attrs.shape[1] == 3 else case.get("bitdepth", 8),
+            1, xyz, attrs, lib=lib)
+    raht, lod, enc, dec = ((C.c_longlong * 2)() for _ in range(4))
     lib.gpcc_shim_raht_counters(raht)
     lib.gpcc_shim_lod_counters(lod)
+    if hasattr(lib, "gpcc_shim_encoder_counters"):  # seam 3 (libtmc3_shim3.so)
+        lib.gpcc_shim_encoder_counters(enc)
+        lib.gpcc_shim_decoder_counters(dec)
     print(json.dumps({"payload_md5": hashlib.md5(payload).hexdigest(), "payload_len": len(payload),
                       "rec_enc_md5": digest(rec_enc), "rec_dec_md5": digest(rec_dec),
-                      "raht_device": raht[0], "raht_cpu": raht[1], "lod_device": lod[0], "lod_cpu": lod[1]}))
+                      "raht_device": raht[0], "raht_cpu": raht[1], "lod_device": lod[0], "lod_cpu": lod[1],
+                      "enc_device": enc[0], "enc_cpu": enc[1], "dec_device": dec[0], "dec_cpu": dec[1]}))
 
 
 if __name__ == "__main__":

@@ -50,8 +50,14 @@ def unmodified(case):
     import lod_helpers as lh
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import shim_operator_worker as w
-    xyz, attrs, rp, lp = w.make_case(case)
-    payload, rec_enc, rec_dec = lh.ref_operator_roundtrip(lp, case["transform"], rp, case["qp"], case["chroma"], 8, 1, xyz, attrs)
+    if case["transform"] == 1:
+        xyz, attrs, lp, pp, thr, qp = w.pred_case(case)
+        payload, rec_enc, rec_dec, _ = lh.ref_pred_roundtrip(lp, pp, thr, qp, 0, xyz, attrs)
+    else:
+        xyz, attrs, rp, lp = w.make_case(case)
+        payload, rec_enc, rec_dec = lh.ref_operator_roundtrip(
+            lp, case["transform"], rp, case["qp"], case["chroma"], 8 if attrs.shape[1] == 3 else case.get("bitdepth", 8),
+            1, xyz, attrs)
     np.testing.assert_array_equal(rec_enc, rec_dec)  # the reference's own conformance criterion
     return hashlib.md5(payload).hexdigest(), len(payload), w.digest(rec_enc)
 
@@ -86,3 +92,57 @@ def test_operator_bitstream_identical_with_device_inside(name):
     else:
         # AttributeLods::generate once in the encoder, once in the decoder
         assert (got["lod_device"], got["lod_cpu"]) == (2, 0)
+
+
+# ---- seam 3: the operator factories (libtmc3_shim3.so) --------------------------------------
+SHIM3 = os.path.join(ROOT, "oracle", "_ref", "libtmc3_shim3.so")
+needs3 = pytest.mark.skipif(not (os.path.exists(SHIM3) and ol.ref_available()), reason="libtmc3_shim3.so / libtmc3_ref.so not built")
+
+# lifting (cfg/octree-liftt-ctc-*: colour with last-component prediction, reflectance) and the
+# predicting transform (cfg/octree-predt-ctc-*: three direct predictors, inter-component
+# prediction; a LiDAR reflectance slice; no direct predictors with neighbour-weighted quantisation)
+CASES3 = {
+    "lifting_colour_100k": dict(cloud="dense", n=100_000, seed=8, transform=2, qp=34, chroma=-1, subnode=1, search_range=50000),
+    "lifting_refl_lidar_60k": dict(cloud="lidar", n=60_000, seed=9, transform=2, qp=28, chroma=0, subnode=1, search_range=2500),
+    "pred_dense_ctc": dict(transform=1, pred_case="dense_ctc"),
+    "pred_lidar_refl_ctc": dict(transform=1, pred_case="lidar_refl_ctc"),
+    "pred_dense_nodirect_qnw": dict(transform=1, pred_case="dense_nodirect_qnw"),
+    "raht_colour_sub0": dict(cloud="dense", n=60_000, seed=6, transform=0, qp=40, chroma=-1, subnode=0, search_range=50000),
+}
+
+
+@needs3
+def test_operator_factories_fall_back_without_gpu():
+    """CPU box: the factories' encoder / decoder hand the slice to the reference's own."""
+    from mpeg_pcc_tmc13_amd import _lib
+    if _lib.load().gpcc_device_count() > 0:
+        pytest.skip("a GPU is present")
+    case = dict(CASES3["lifting_colour_100k"], n=6000, lib="libtmc3_shim3.so")
+    got, err = run_worker(case, strict=False)
+    md5, ln, rec = unmodified(case)
+    assert (got["payload_md5"], got["payload_len"], got["rec_enc_md5"], got["rec_dec_md5"]) == (md5, ln, rec, rec)
+    assert (got["enc_device"], got["enc_cpu"], got["dec_device"], got["dec_cpu"]) == (0, 1, 0, 1)
+
+
+@needs3
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(CASES3))
+def test_operator_bitstream_identical_with_device_coders_inside(name):
+    """makeAttributeEncoder() / makeAttributeDecoder() of the drop-in build: transform, zero
+    runs and binarisation of a lifting / predicting slice on the MI355X, the decisions on the
+    reference's arithmetic coder -- payload and reconstructions byte-identical to the unmodified
+    build, the device counted once per direction, no fallback (GPCC_STRICT=1)."""
+    case = dict(CASES3[name], lib="libtmc3_shim3.so")
+    got, err = run_worker(case, strict=True)
+    md5, ln, rec = unmodified(case)
+    assert got["payload_len"] == ln and got["payload_md5"] == md5, "attribute payload differs from the unmodified build"
+    assert got["rec_enc_md5"] == rec and got["rec_dec_md5"] == rec
+    assert "falls back" not in err
+    if case["transform"] == 0:
+        # RAHT slices pass through the factories' objects to the reference coder and seam 1
+        assert (got["raht_device"], got["raht_cpu"]) == (2, 0)
+        assert (got["enc_device"], got["enc_cpu"], got["dec_device"], got["dec_cpu"]) == (0, 0, 0, 0)
+    else:
+        assert (got["enc_device"], got["enc_cpu"], got["dec_device"], got["dec_cpu"]) == (1, 0, 1, 0)
+        # the LoD structure is built inside the one-call entries: AttributeLods::generate is not reached
+        assert (got["lod_device"], got["lod_cpu"]) == (0, 0)
