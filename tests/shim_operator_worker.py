@@ -54,22 +54,31 @@ def main():
     case = json.loads(sys.argv[1])
     import torch  # noqa: F401  (one HIP runtime per process: torch's, see _lib.load)
     lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", case.get("lib", "libtmc3_shim.so")))
+    import time
+    t0 = time.time()
     if case["transform"] == 1:
         xyz, attrs, lp, pp, thr, qp = pred_case(case)
+        t0 = time.time()
         payload, rec_enc, rec_dec, _ = lh.ref_pred_roundtrip(lp, pp, thr, qp, 0, xyz, attrs, lib=lib)
     else:
         xyz, attrs, rp, lp = make_case(case)
         payload, rec_enc, rec_dec = lh.ref_operator_roundtrip(
             lp, case["transform"], rp, case["qp"], case["chroma"], 8 if attrs.shape[1] == 3 else case.get("bitdepth", 8),
             1, xyz, attrs, lib=lib)
+    seconds = time.time() - t0
+    if case.get("repeat"):  # a second round trip in the same process: contexts and arenas warm
+        t0 = time.time()
+        lh.ref_operator_roundtrip(lp, case["transform"], rp, case["qp"], case["chroma"], 8, 1, xyz, attrs, lib=lib)
+        seconds = time.time() - t0
     raht, lod, enc, dec = ((C.c_longlong * 2)() for _ in range(4))
-    lib.gpcc_shim_raht_counters(raht)
-    lib.gpcc_shim_lod_counters(lod)
+    if hasattr(lib, "gpcc_shim_raht_counters"):  # (not in the unmodified build, libtmc3_ref.so)
+        lib.gpcc_shim_raht_counters(raht)
+        lib.gpcc_shim_lod_counters(lod)
     if hasattr(lib, "gpcc_shim_encoder_counters"):  # seam 3 (libtmc3_shim3.so)
         lib.gpcc_shim_encoder_counters(enc)
         lib.gpcc_shim_decoder_counters(dec)
     print(json.dumps({"payload_md5": hashlib.md5(payload).hexdigest(), "payload_len": len(payload),
-                      "rec_enc_md5": digest(rec_enc), "rec_dec_md5": digest(rec_dec),
+                      "rec_enc_md5": digest(rec_enc), "rec_dec_md5": digest(rec_dec), "seconds": round(seconds, 4),
                       "raht_device": raht[0], "raht_cpu": raht[1], "lod_device": lod[0], "lod_cpu": lod[1],
                       "enc_device": enc[0], "enc_cpu": enc[1], "dec_device": dec[0], "dec_cpu": dec[1]}))
 
