@@ -576,6 +576,33 @@ int gpcc_multi_raht_inverse(
   const int64_t* offsets, const int64_t* morton, int32_t* attrs,
   const int32_t* coeffs, int32_t c);
 
+/* The LoD-based coders on several GPUs: gpcc_lift_encode_attr /
+ * gpcc_lift_decode_attr / gpcc_pred_encode_attr / gpcc_pred_decode_attr for every
+ * slice of a batch (BASELINE configs[2]: five slices), the slices sharded over
+ * the devices as above, each device driven by its own host thread for the
+ * duration of the call.  Host buffers: xyz [N][3], attrs [N][c] point order per
+ * slice, coeffs / values [N][c] coding order per slice (they feed the host's
+ * arithmetic coder, so nothing is gathered between devices), lift / pred
+ * [num_slices] parameter blocks (in: QP, tools; out: each slice's LoD structure),
+ * lcp_coeffs [num_slices][GPCC_MAX_LODS], icp_coeffs [num_slices][GPCC_MAX_LODS][3],
+ * indexes [N] out, may be NULL.  The first failing slice fails the call. */
+int gpcc_multi_lift_encode_attr(
+  gpcc_multi* m, const gpcc_lod_params* lod, gpcc_lift_params* lift,
+  int32_t num_slices, const int64_t* offsets, const int32_t* xyz, int32_t* attrs,
+  int32_t* coeffs, int8_t* lcp_coeffs, int32_t* indexes, int32_t c);
+int gpcc_multi_lift_decode_attr(
+  gpcc_multi* m, const gpcc_lod_params* lod, gpcc_lift_params* lift,
+  int32_t num_slices, const int64_t* offsets, const int32_t* xyz, int32_t* attrs,
+  const int32_t* coeffs, const int8_t* lcp_coeffs, int32_t* indexes, int32_t c);
+int gpcc_multi_pred_encode_attr(
+  gpcc_multi* m, const gpcc_lod_params* lod, gpcc_pred_params* pred,
+  int32_t num_slices, const int64_t* offsets, const int32_t* xyz, int32_t* attrs,
+  int32_t* values, int8_t* icp_coeffs, int32_t* indexes, int32_t c);
+int gpcc_multi_pred_decode_attr(
+  gpcc_multi* m, const gpcc_lod_params* lod, gpcc_pred_params* pred,
+  int32_t num_slices, const int64_t* offsets, const int32_t* xyz, int32_t* attrs,
+  const int32_t* values, const int8_t* icp_coeffs, int32_t* indexes, int32_t c);
+
 /* ------------------------------------------------------------------ */
 /* attribute transfer ("recolouring") onto a re-quantised geometry       */
 

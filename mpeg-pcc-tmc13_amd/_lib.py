@@ -22,6 +22,7 @@ ABI_SYMBOLS = [
     "gpcc_dev_lod_build", "gpcc_dev_lift_encode_attr", "gpcc_dev_lift_decode_attr",
     "gpcc_multi_create", "gpcc_multi_destroy", "gpcc_multi_num_devices", "gpcc_multi_uses_rccl", "gpcc_multi_rccl_selftest",
     "gpcc_multi_raht_forward", "gpcc_multi_raht_inverse", "gpcc_binarise_symbols",
+    "gpcc_multi_lift_encode_attr", "gpcc_multi_lift_decode_attr", "gpcc_multi_pred_encode_attr", "gpcc_multi_pred_decode_attr",
     "gpcc_pred_forward", "gpcc_pred_inverse", "gpcc_pred_encode_attr", "gpcc_pred_decode_attr",
     "gpcc_dev_pred_encode_attr", "gpcc_dev_pred_decode_attr",
 ]
@@ -113,6 +114,9 @@ def load():
     lib.gpcc_multi_uses_rccl.argtypes = [vp]
     for name in ("gpcc_multi_raht_forward", "gpcc_multi_raht_inverse"):
         getattr(lib, name).argtypes = [vp, pp, i32, i64p, vp, vp, vp, i32]
+    for name in ("gpcc_multi_lift_encode_attr", "gpcc_multi_lift_decode_attr", "gpcc_multi_pred_encode_attr",
+                 "gpcc_multi_pred_decode_attr"):
+        getattr(lib, name).argtypes = [vp, C.POINTER(LodParams), vp, i32, i64p, vp, vp, vp, vp, vp, i32]
     lib.gpcc_binarise_symbols.argtypes = [vp, vp, vp, i32, i32, i32, vp, C.c_int64, C.POINTER(C.c_int64)]
     _lib = lib
     return lib

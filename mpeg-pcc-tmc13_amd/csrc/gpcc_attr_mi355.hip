@@ -3753,6 +3753,50 @@ multi_transform(
 
 }  // namespace
 
+namespace {
+
+// The LoD-based coders of a batch: every device codes its run of slices with the
+// host-tier one-call entry (upload, LoD build, transform, download -- the values go
+// straight back into the caller's buffers, which is where the host's arithmetic coder
+// reads them), one host thread per device so that the devices work concurrently.
+// A failed slice fails the call; the first failure's message is the caller's.
+template<class Slice>
+int
+multi_slices(gpcc_multi* m, int32_t num_slices, const int64_t* offsets, int32_t c, Slice&& slice)
+{
+  if (!m)
+    return fail(GPCC_ERR_INVALID_ARG, "multi context is null");
+  int r = check_slices(m->ctx[0], num_slices, offsets);
+  if (r)
+    return r;
+  if (c != 1 && c != 3)
+    return fail(GPCC_ERR_INVALID_ARG, "attribute count not 1 / 3");
+  for (int s = 0; s < num_slices; s++)
+    if (offsets[s + 1] - offsets[s] > INT32_MAX)
+      return fail(GPCC_ERR_INVALID_ARG, "slice larger than 2^31 points");
+  const int nd = (int)m->devices.size();
+  shard_slices(num_slices, offsets, nd, &m->part);
+  std::vector<int> rc(nd, GPCC_OK);
+  std::vector<std::string> msg(nd);
+  std::vector<std::thread> th;
+  for (int d = 0; d < nd; d++)
+    th.emplace_back([&, d]() {
+      for (int s = m->part[d].s0; s < m->part[d].s1 && rc[d] == GPCC_OK; s++) {
+        rc[d] = slice(m->ctx[d], s, offsets[s], (int32_t)(offsets[s + 1] - offsets[s]));
+        if (rc[d])
+          msg[d] = g_last_error;  // (thread local: carried over to the caller's thread)
+      }
+    });
+  for (auto& t : th)
+    t.join();
+  for (int d = 0; d < nd; d++)
+    if (rc[d])
+      return fail(rc[d], msg[d]);
+  return GPCC_OK;
+}
+
+}  // namespace
+
 extern "C" {
 
 int
@@ -3869,6 +3913,66 @@ gpcc_multi_rccl_selftest(int32_t device)
     hipStreamDestroy(st);
   api.CommDestroy(comm);
   return rc;
+}
+
+int
+gpcc_multi_lift_encode_attr(
+  gpcc_multi* m, const gpcc_lod_params* lod, gpcc_lift_params* lift, int32_t num_slices,
+  const int64_t* offsets, const int32_t* xyz, int32_t* attrs, int32_t* coeffs,
+  int8_t* lcp_coeffs, int32_t* indexes, int32_t c)
+{
+  if (!lod || !lift || !xyz || !attrs || !coeffs || !lcp_coeffs)
+    return fail(GPCC_ERR_INVALID_ARG, "null argument");
+  return multi_slices(m, num_slices, offsets, c, [&](gpcc_ctx* ctx, int s, int64_t o, int32_t n) {
+    return gpcc_lift_encode_attr(
+      ctx, lod, &lift[s], xyz + 3 * o, attrs + c * o, coeffs + c * o, lcp_coeffs + (size_t)s * GPCC_MAX_LODS,
+      indexes ? indexes + o : nullptr, n, c);
+  });
+}
+
+int
+gpcc_multi_lift_decode_attr(
+  gpcc_multi* m, const gpcc_lod_params* lod, gpcc_lift_params* lift, int32_t num_slices,
+  const int64_t* offsets, const int32_t* xyz, int32_t* attrs, const int32_t* coeffs,
+  const int8_t* lcp_coeffs, int32_t* indexes, int32_t c)
+{
+  if (!lod || !lift || !xyz || !attrs || !coeffs || !lcp_coeffs)
+    return fail(GPCC_ERR_INVALID_ARG, "null argument");
+  return multi_slices(m, num_slices, offsets, c, [&](gpcc_ctx* ctx, int s, int64_t o, int32_t n) {
+    return gpcc_lift_decode_attr(
+      ctx, lod, &lift[s], xyz + 3 * o, attrs + c * o, coeffs + c * o, lcp_coeffs + (size_t)s * GPCC_MAX_LODS,
+      indexes ? indexes + o : nullptr, n, c);
+  });
+}
+
+int
+gpcc_multi_pred_encode_attr(
+  gpcc_multi* m, const gpcc_lod_params* lod, gpcc_pred_params* pred, int32_t num_slices,
+  const int64_t* offsets, const int32_t* xyz, int32_t* attrs, int32_t* values,
+  int8_t* icp_coeffs, int32_t* indexes, int32_t c)
+{
+  if (!lod || !pred || !xyz || !attrs || !values || !icp_coeffs)
+    return fail(GPCC_ERR_INVALID_ARG, "null argument");
+  return multi_slices(m, num_slices, offsets, c, [&](gpcc_ctx* ctx, int s, int64_t o, int32_t n) {
+    return gpcc_pred_encode_attr(
+      ctx, lod, &pred[s], xyz + 3 * o, attrs + c * o, values + c * o, icp_coeffs + (size_t)s * GPCC_MAX_LODS * 3,
+      indexes ? indexes + o : nullptr, n, c);
+  });
+}
+
+int
+gpcc_multi_pred_decode_attr(
+  gpcc_multi* m, const gpcc_lod_params* lod, gpcc_pred_params* pred, int32_t num_slices,
+  const int64_t* offsets, const int32_t* xyz, int32_t* attrs, const int32_t* values,
+  const int8_t* icp_coeffs, int32_t* indexes, int32_t c)
+{
+  if (!lod || !pred || !xyz || !attrs || !values || !icp_coeffs)
+    return fail(GPCC_ERR_INVALID_ARG, "null argument");
+  return multi_slices(m, num_slices, offsets, c, [&](gpcc_ctx* ctx, int s, int64_t o, int32_t n) {
+    return gpcc_pred_decode_attr(
+      ctx, lod, &pred[s], xyz + 3 * o, attrs + c * o, values + c * o, icp_coeffs + (size_t)s * GPCC_MAX_LODS * 3,
+      indexes ? indexes + o : nullptr, n, c);
+  });
 }
 
 int

@@ -429,3 +429,38 @@ class MultiContext:
             self._h, C.byref(params), len(offs) - 1, offs.ctypes.data_as(C.POINTER(C.c_int64)),
             morton.ctypes.data, rec.ctypes.data, co.ctypes.data, c))
         return rec
+
+    def _lod_coder(self, name, lod_params, params_list, offsets, xyz, attrs, values, side, c):
+        offs = np.ascontiguousarray(offsets, dtype=np.int64)
+        s = len(offs) - 1
+        blocks = (type(params_list[0]) * s)(*params_list)
+        xyz = np.ascontiguousarray(xyz, dtype=np.int32)
+        idx = np.zeros(len(xyz), dtype=np.int32)
+        _lib.check(getattr(self._lib, name)(
+            self._h, C.byref(lod_params), C.cast(blocks, C.c_void_p), s, offs.ctypes.data_as(C.POINTER(C.c_int64)),
+            xyz.ctypes.data, attrs.ctypes.data, values.ctypes.data, side.ctypes.data, idx.ctypes.data, c))
+        for i in range(s):  # the LoD structure of every slice comes back in its block
+            C.memmove(C.addressof(params_list[i]), C.addressof(blocks[i]), C.sizeof(blocks[i]))
+        return idx
+
+    def lod_encode_attr(self, predicting, lod_params, params_list, offsets, xyz, attrs):
+        """gpcc_multi_lift_encode_attr / gpcc_multi_pred_encode_attr: every slice's LoD build +
+        transform on the device its run belongs to -> (values [N,c] coding order per slice,
+        recon [N,c], side int8 [slices,32] (lcp) or [slices,32,3] (icp), indexes [N])"""
+        a = np.ascontiguousarray(attrs, dtype=np.int32).copy()
+        n, c = a.shape
+        v = np.zeros((n, c), dtype=np.int32)
+        side = np.zeros((len(offsets) - 1, 32, 3) if predicting else (len(offsets) - 1, 32), dtype=np.int8)
+        name = "gpcc_multi_pred_encode_attr" if predicting else "gpcc_multi_lift_encode_attr"
+        idx = self._lod_coder(name, lod_params, params_list, offsets, xyz, a, v, side, c)
+        return v, a, side, idx
+
+    def lod_decode_attr(self, predicting, lod_params, params_list, offsets, xyz, values, side):
+        """gpcc_multi_lift_decode_attr / gpcc_multi_pred_decode_attr -> recon [N,c]"""
+        v = np.ascontiguousarray(values, dtype=np.int32)
+        n, c = v.shape
+        a = np.zeros((n, c), dtype=np.int32)
+        side = np.ascontiguousarray(side, dtype=np.int8)
+        name = "gpcc_multi_pred_decode_attr" if predicting else "gpcc_multi_lift_decode_attr"
+        self._lod_coder(name, lod_params, params_list, offsets, xyz, a, v, side, c)
+        return a
