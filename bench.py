@@ -634,6 +634,17 @@ def predicting_leg(ctx, args):
         t_dec = time.perf_counter() - t0
         res["cpu_port"] = {"encode_ms": round(t_enc * 1e3, 1), "decode_ms": round(t_dec * 1e3, 1), "cores": 1,
                            "kind": "port", "direct_modes_chosen": int((modes > 0).sum())}
+        import oracle_loader as ol
+        if ol.ref_available():
+            # the compiled reference's whole operator for the same slice: AttributeLods::generate (twice),
+            # encodeColorsPred + decodeColorsPred and its arithmetic coder
+            t0 = time.perf_counter()
+            payload, rec_enc, rec_dec, _ = lh.ref_pred_roundtrip(lp, pp, 64, 28, 0, xyz, attrs)
+            t_op = time.perf_counter() - t0
+            res["cpu_reference_operator"] = {
+                "seconds": round(t_op, 3), "cores": 1, "kind": "reference", "payload_bytes": len(payload),
+                "what": "AttributeEncoder::encode + AttributeDecoder::decode (LoD generation x2, transform, entropy coder)",
+                "reconstruction_equals_port": bool(np.array_equal(rec_enc, want) and np.array_equal(rec_dec, want))}
     # encoder without direct predictors, then the decoder on its symbols
     ctx.pred_forward(pp0, lod["nc"], lod["ni"], lod["w"], lod["indexes"], attrs)  # warm-up
     ctx.set_profiling(True)
