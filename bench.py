@@ -480,6 +480,24 @@ def recolour_leg(ctx, args):
         res["cpu_baseline"] = {"value": round(len(tgt) / (time.perf_counter() - t0) / 1e6, 3), "unit": "M target points/s",
                                "cores": 1, "kind": "reference" if ol.ref_available() else "port"}
         res["identical_to_cpu_fraction"] = round(float(np.all(got == ref, axis=1).mean()), 4)
+        # Where the reference and the device differ: target points at which candidates at EQUAL distance decide
+        # (the reference takes them in its k-d tree's / std::sort's order, the device by point index).  A dyadic scale
+        # on a voxelised cloud puts a tie at nearly every point; the oracle restatement flags them, the device equals
+        # the restatement everywhere and the reference wherever no tie decides.
+        import ctypes as C
+        ora = ol.oracle().recolour(p, xyz, a, tgt, scale=scale)
+        fl = np.zeros(len(tgt), dtype=np.uint8)
+        f = ol.oracle().fn("recolour_ties", C.c_int, [C.c_void_p, np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS"), C.c_int32,
+                                                    np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS"), C.c_int32, C.c_float,
+                                                    np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS"),
+                                                    np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")])
+        rc = f(C.addressof(p), np.ascontiguousarray(xyz, dtype=np.int32).reshape(-1), len(xyz),
+               np.ascontiguousarray(tgt, dtype=np.int32).reshape(-1), len(tgt), scale, np.zeros(3, dtype=np.int32), fl)
+        bad = np.any(got != ref, axis=1)
+        res["identical_to_oracle_restatement"] = bool(np.array_equal(got, ora))
+        res["target_points_with_an_equidistant_tie"] = round(float((fl != 0).mean()), 4) if rc == 0 else None
+        res["identical_to_reference_where_no_tie_decides"] = bool(rc == 0 and not np.any(bad & (fl == 0)))
+        res["max_abs_difference_at_ties"] = int(np.abs(got - ref).max())
     return res
 
 
