@@ -93,12 +93,15 @@ cx_carve(Take&& take, CxWork& w)
 }
 
 // Everything after the uploads of params / pt_off.  `prof(name, level)` returns a scoped
-// timer object; `fetch()` makes *stats and *tab (host copies) valid.
-template<int C, class Prof, class Fetch>
+// timer object; `mark()` records an event on the stream and `wait()` blocks the host on it:
+// the level table is copied to the host right behind the scan, the wait comes after the
+// emit and schedule kernels have been enqueued, so the host sizes and enqueues the level
+// kernels while the device is still emitting the tree.
+template<int C, class Prof, class Mark, class Wait>
 hipError_t
 cx_run(
   hipStream_t st, CxWork& w, const SharedLut* d_lut, int num_qp_layers, int32_t* d_attrs,
-  int32_t* d_coeffs, TreeStats* stats, CxLevelTab* tab, Prof&& prof, Fetch&& fetch)
+  int32_t* d_coeffs, TreeStats* stats, CxLevelTab* tab, Prof&& prof, Mark&& mark, Wait&& wait)
 {
   const TreeView tv = w.tv;
   const CxLists cl = w.cl;
@@ -116,6 +119,13 @@ cx_run(
       HIP_KERNEL_NAME(cx_scan_fin_kernel<C>), dim3(1), dim3(64), 0, st, tv, cl, w.attr_prefix,
       sum_attrs != nullptr);
   }
+  // (the level table: final behind cx_scan_fin)
+  hipError_t e = hipMemcpyAsync(tab, cl.tab, sizeof(CxLevelTab), hipMemcpyDeviceToHost, st);
+  if (e != hipSuccess)
+    return e;
+  e = mark();
+  if (e != hipSuccess)
+    return e;
   {
     auto t = prof("cx_emit", -1);
     hipLaunchKernelGGL(
@@ -125,16 +135,13 @@ cx_run(
     auto t = prof("schedule", -1);
     hipLaunchKernelGGL(schedule_kernel, dim3(1), dim3(256), 0, st, tv, w.sched, num_qp_layers, 0, stats);
   }
-  hipError_t e = hipMemcpyAsync(tab, cl.tab, sizeof(CxLevelTab), hipMemcpyDeviceToHost, st);
-  if (e != hipSuccess)
-    return e;
   e = hipMemsetAsync(w.tstate, 0, ((size_t)w.max_tiles + 1) * sizeof(unsigned long long), st);
   if (e != hipSuccess)
     return e;
   e = hipMemsetAsync(w.slice_l, 0xff, 2 * (size_t)w.s * sizeof(int32_t), st);
   if (e != hipSuccess)
     return e;
-  e = fetch();
+  e = wait();
   if (e != hipSuccess)
     return e;
 
@@ -151,8 +158,25 @@ cx_run(
   cx.lut = d_lut;
   cx.tstate = w.tstate;
   cx.slice_l = w.slice_l;
-  const int first_level = std::min(w.nlev - 1, (int)stats->max_top);
-  for (int li = first_level - 1; li >= 0; li--) {
+  // (levels above the tallest slice's root hold no block: nr = 0)
+  int li_start = w.nlev - 2;
+  while (li_start >= 0 && tab->nr[li_start] <= 0)
+    li_start--;
+  // the top levels, as long as a level is a few tiles: one launch (cx_top_kernel)
+  {
+    int li_lo = li_start + 1;
+    while (li_lo - 1 >= 0 && tab->nr[li_lo - 1] <= kCxTopTiles * kCxG)
+      li_lo--;
+    if (li_start - li_lo + 1 >= 2) {
+      auto t = prof(w.encoder ? "cx_top_enc" : "cx_top_dec", -1);
+      if (w.encoder)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(cx_top_kernel<C, true>), dim3(1), dim3(256), 0, st, cx, li_start, li_lo);
+      else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(cx_top_kernel<C, false>), dim3(1), dim3(256), 0, st, cx, li_start, li_lo);
+      li_start = li_lo - 1;
+    }
+  }
+  for (int li = li_start; li >= 0; li--) {
     const int nr = tab->nr[li];
     if (nr <= 0)
       continue;

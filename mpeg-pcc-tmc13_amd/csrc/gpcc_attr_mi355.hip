@@ -132,6 +132,12 @@ struct gpcc_ctx {
   // host staging for the host tier
   void* h_pinned = nullptr;
   size_t h_pinned_cap = 0;
+  // compact level pass: its own staging, two slots taken in turn (a call returns only after
+  // the event behind its uploads, so the slot of the call before last is free: no wait for
+  // the stream when a call starts)
+  void* h_cx_stage = nullptr;
+  size_t h_cx_stage_cap = 0;
+  int cx_stage_flip = 0;
   // profiling
   bool profiling = false;
   struct Span {
@@ -724,17 +730,18 @@ launch_cx(
   std::vector<int32_t> h_off(s + 1);
   for (int i = 0; i <= s; i++)
     h_off[i] = (int32_t)offsets[i];
-  const size_t stage_bytes = sizeof(gpcc_raht_params) + (s + 1) * sizeof(int32_t) + 64;
-  if (ctx->h_pinned_cap < stage_bytes) {
+  const size_t stage_bytes = (sizeof(gpcc_raht_params) + (s + 1) * sizeof(int32_t) + 64 + 255) & ~size_t(255);
+  if (ctx->h_cx_stage_cap < stage_bytes) {
     HIP_TRY(hipStreamSynchronize(st));
-    if (ctx->h_pinned)
-      HIP_TRY(hipHostFree(ctx->h_pinned));
-    HIP_TRY(hipHostMalloc(&ctx->h_pinned, stage_bytes * 2));
-    ctx->h_pinned_cap = stage_bytes * 2;
-  } else {
-    HIP_TRY(hipStreamSynchronize(st));  // the previous call's async copies read this buffer
+    if (ctx->h_cx_stage)
+      HIP_TRY(hipHostFree(ctx->h_cx_stage));
+    ctx->h_cx_stage = nullptr;
+    ctx->h_cx_stage_cap = 0;
+    HIP_TRY(hipHostMalloc(&ctx->h_cx_stage, stage_bytes * 4));
+    ctx->h_cx_stage_cap = stage_bytes * 2;
   }
-  char* hp_base = (char*)ctx->h_pinned;
+  ctx->cx_stage_flip ^= 1;
+  char* hp_base = (char*)ctx->h_cx_stage + (ctx->cx_stage_flip ? ctx->h_cx_stage_cap : 0);
   memcpy(hp_base, hp, sizeof(*hp));
   HIP_TRY(hipMemcpyAsync(w.params, hp_base, sizeof(*hp), hipMemcpyHostToDevice, st));
   const size_t o = (sizeof(*hp) + 15) & ~size_t(15);
@@ -745,10 +752,8 @@ launch_cx(
   hipError_t e = cx_run<C>(
     st, w, ctx->d_lut, hp->num_qp_layers, d_attrs, d_coeffs, ctx->h_stats, ctx->h_cxtab,
     [&](const char* name, int li) { return Timer(ctx, li < 0 ? name : level_name(name, li)); },
-    [&]() -> hipError_t {
-      hipError_t r = hipEventRecord(ctx->ev_stats, st);
-      return r != hipSuccess ? r : hipEventSynchronize(ctx->ev_stats);
-    });
+    [&]() -> hipError_t { return hipEventRecord(ctx->ev_stats, st); },
+    [&]() -> hipError_t { return hipEventSynchronize(ctx->ev_stats); });
   if (e != hipSuccess)
     return fail(GPCC_ERR_HIP, std::string("compact level pass: ") + hipGetErrorString(e));
   if (ctx->h_error)
@@ -1693,6 +1698,8 @@ gpcc_ctx_destroy(gpcc_ctx* ctx)
     hipEventDestroy(ctx->ev_stats);
   if (ctx->h_pinned)
     hipHostFree(ctx->h_pinned);
+  if (ctx->h_cx_stage)
+    hipHostFree(ctx->h_cx_stage);
   if (ctx->own_stream)
     hipStreamDestroy(ctx->stream);
   delete ctx;

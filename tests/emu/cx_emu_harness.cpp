@@ -61,9 +61,9 @@ cx_emu_transform(
   hipError_t e;
   auto fetch = [&]() { return hipSuccess; };
   switch (c) {
-  case 1: e = cx_run<1>(nullptr, w, lut, params->num_qp_layers, attrs, coeffs, &stats, &tab, NoProf(), fetch); break;
-  case 2: e = cx_run<2>(nullptr, w, lut, params->num_qp_layers, attrs, coeffs, &stats, &tab, NoProf(), fetch); break;
-  default: e = cx_run<3>(nullptr, w, lut, params->num_qp_layers, attrs, coeffs, &stats, &tab, NoProf(), fetch); break;
+  case 1: e = cx_run<1>(nullptr, w, lut, params->num_qp_layers, attrs, coeffs, &stats, &tab, NoProf(), fetch, fetch); break;
+  case 2: e = cx_run<2>(nullptr, w, lut, params->num_qp_layers, attrs, coeffs, &stats, &tab, NoProf(), fetch, fetch); break;
+  default: e = cx_run<3>(nullptr, w, lut, params->num_qp_layers, attrs, coeffs, &stats, &tab, NoProf(), fetch, fetch); break;
   }
   if (debug_tab)
     for (int l = 0; l < kMaxLevels; l++) {
