@@ -12,6 +12,7 @@
 // the tree's shape (an event on pinned memory in the library) so that the same
 // code runs under the CPU wavefront emulator of the test tier (tests/emu).
 #pragma once
+#include <cstdlib>
 
 #include <algorithm>
 
@@ -167,7 +168,11 @@ cx_run(
     int li_lo = li_start + 1;
     while (li_lo - 1 >= 0 && tab->nr[li_lo - 1] <= kCxTopTiles * kCxG)
       li_lo--;
-    if (li_start - li_lo + 1 >= 2) {
+    static const bool top_on = [] {
+      const char* e = getenv("GPCC_CX_TOP");
+      return !(e && e[0] == '0');
+    }();
+    if (top_on && li_start - li_lo + 1 >= 2) {
       auto t = prof(w.encoder ? "cx_top_enc" : "cx_top_dec", -1);
       if (w.encoder)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(cx_top_kernel<C, true>), dim3(1), dim3(256), 0, st, cx, li_start, li_lo);

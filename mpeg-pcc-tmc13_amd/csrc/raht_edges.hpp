@@ -174,11 +174,16 @@ template<int C>
 __global__ __launch_bounds__(256) void
 finish_kernel(FinishCtx cx)
 {
-  __shared__ SharedLut lut_s;
   if (tree_failed(cx.tv))
     return;
-  load_lut(&lut_s, cx.lut);
-  const SharedLut& lut = lut_s;
+  // The tables are read where lut_init_kernel left them (3 KB, cache resident; the chains of
+  // duplicates that use them are rare).  An LDS copy staged per workgroup, as in the level
+  // kernels, gave WRONG first coefficients of long duplicate chains on the device in large
+  // batches, not reproducibly (tests/stress/stress_cx_batch.py; C = 1, ~70 % of the runs of one
+  // batch) while the emulator, a host sync in front of the launch, a second barrier and a
+  // closing barrier changed nothing and an in-kernel comparison of the two tables' results made
+  // it disappear: the cause was not found, this form has run the stress clean.
+  const SharedLut& lut = *cx.lut;
   const TreeView& tv = cx.tv;
   const gpcc_raht_params* __restrict__ prm = cx.params;
   const bool haar = prm->integer_haar_enable_flag != 0;
