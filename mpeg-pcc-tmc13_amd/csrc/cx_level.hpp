@@ -970,9 +970,13 @@ cx_level_tile(const CxCtx& cx, CxSmem& sm, int li, int tile)
   prof.count(12, 1);
 }
 
-// One launch per level: a wavefront per tile.
+// One launch per level: a wavefront per tile.  Wavefronts per SIMD, measured on ten 1 M-point
+// slices (forward / inverse, ms): left to the compiler (5 / 7: it squeezes the decoder into 66
+// registers) 3.38 / 3.24; at most 4: 3.50 / 3.17; at most 5: 3.36 / 2.93; 5-6: 3.30 / 2.91; exactly
+// 6: 3.37 / 2.80 -- so the encoder is asked for 5-6 and the one-component decoder for 6 (with more components six
+// wavefronts spill).
 template<int C, bool ENC>
-__global__ __launch_bounds__(256) void
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ENC || C > 1) ? 5 : 6, 6))) void
 cx_level_kernel(CxCtx cx)
 {
   __shared__ CxSmem sm;

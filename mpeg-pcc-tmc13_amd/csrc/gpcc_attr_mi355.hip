@@ -138,6 +138,8 @@ struct gpcc_ctx {
   void* h_cx_stage = nullptr;
   size_t h_cx_stage_cap = 0;
   int cx_stage_flip = 0;
+  // downloads into the caller's pageable memory go through this pinned buffer (d2h_user)
+  void* h_bounce = nullptr;
   // profiling
   bool profiling = false;
   struct Span {
@@ -367,6 +369,86 @@ pool_free(gpcc_ctx* ctx, void* p)
   for (auto& b : ctx->pool)
     if (b.ptr == p)
       b.used = false;
+}
+
+// A result for the caller's (pageable) memory.  An asynchronous copy straight into pageable
+// memory makes the runtime pin the caller's pages on the fly, and it keeps such pins: a range it
+// has pinned READ-ONLY once, as the source of an upload, is not pinned again when the same
+// addresses later receive a download -- "Memory access fault ... Write access to a read-only
+// page" in the middle of a long-running host process (the GPU test tier in one pytest process:
+// numpy arrays of earlier tests freed, their heap addresses reused).  So large results are
+// copied into a pinned buffer of the context and from there by the CPU; small ones take the
+// runtime's own staging path.
+constexpr size_t kBounceBytes = (size_t)8 << 20;
+constexpr size_t kBounceMin = (size_t)64 << 10;
+
+// ... and an input from the caller's memory: through the same buffer, so that the runtime never
+// pins a page of the caller (it is those pins, read-only, that a later download trips over --
+// this library's or anybody else's in the process).  The buffer is free again when the call
+// returns.
+hipError_t
+h2d_user(gpcc_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t st)
+{
+  if (bytes < kBounceMin)
+    return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
+  if (!ctx->h_bounce) {
+    hipError_t e = hipHostMalloc(&ctx->h_bounce, 2 * kBounceBytes);
+    if (e != hipSuccess)
+      return e;
+  }
+  size_t off = 0;
+  for (int turn = 0; off < bytes; turn++) {
+    if (turn >= 2) {  // the copy out of this half, two turns ago, has to be over
+      hipError_t e = hipStreamSynchronize(st);
+      if (e != hipSuccess)
+        return e;
+    }
+    const size_t chunk = std::min(kBounceBytes, bytes - off);
+    char* buf = (char*)ctx->h_bounce + (size_t)(turn & 1) * kBounceBytes;
+    memcpy(buf, (const char*)src + off, chunk);
+    hipError_t e = hipMemcpyAsync((char*)dst + off, buf, chunk, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess)
+      return e;
+    off += chunk;
+  }
+  return hipStreamSynchronize(st);
+}
+
+hipError_t
+d2h_user(gpcc_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t st)
+{
+  if (bytes < kBounceMin)
+    return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st);
+  if (!ctx->h_bounce) {
+    hipError_t e = hipHostMalloc(&ctx->h_bounce, 2 * kBounceBytes);
+    if (e != hipSuccess)
+      return e;
+  }
+  // two halves in turn: the CPU empties one while the next chunk arrives in the other
+  size_t off = 0, prev_off = 0, prev_bytes = 0;
+  int half = 0;
+  while (off < bytes || prev_bytes) {
+    size_t chunk = 0;
+    char* buf = (char*)ctx->h_bounce + (size_t)half * kBounceBytes;
+    if (off < bytes) {
+      chunk = std::min(kBounceBytes, bytes - off);
+      hipError_t e = hipMemcpyAsync(buf, (const char*)src + off, chunk, hipMemcpyDeviceToHost, st);
+      if (e != hipSuccess)
+        return e;
+    }
+    if (prev_bytes)  // (its copy was waited for at the end of the previous turn)
+      memcpy((char*)dst + prev_off, (char*)ctx->h_bounce + (size_t)(half ^ 1) * kBounceBytes, prev_bytes);
+    if (chunk) {
+      hipError_t e = hipStreamSynchronize(st);
+      if (e != hipSuccess)
+        return e;
+    }
+    prev_off = off;
+    prev_bytes = chunk;
+    off += chunk;
+    half ^= 1;
+  }
+  return hipSuccess;
 }
 
 int
@@ -924,18 +1006,18 @@ host_transform(
     HIP_TRY(pool_malloc(ctx, (void**)&d_m, sizeof(int64_t) * n));
     HIP_TRY(pool_malloc(ctx, (void**)&d_a, sizeof(int32_t) * n * c));
     HIP_TRY(pool_malloc(ctx, (void**)&d_c, sizeof(int32_t) * n * c));
-    HIP_TRY(hipMemcpyAsync(d_m, morton, sizeof(int64_t) * n, hipMemcpyHostToDevice, st));
+    HIP_TRY(h2d_user(ctx, d_m, morton, sizeof(int64_t) * n, st));
     if (qp_off) {
       HIP_TRY(pool_malloc(ctx, (void**)&d_q, sizeof(int32_t) * n * 2));
-      HIP_TRY(hipMemcpyAsync(d_q, qp_off, sizeof(int32_t) * n * 2, hipMemcpyHostToDevice, st));
+      HIP_TRY(h2d_user(ctx, d_q, qp_off, sizeof(int32_t) * n * 2, st));
     }
     if (encoder) {
-      HIP_TRY(hipMemcpyAsync(d_a, attrs, sizeof(int32_t) * n * c, hipMemcpyHostToDevice, st));
+      HIP_TRY(h2d_user(ctx, d_a, attrs, sizeof(int32_t) * n * c, st));
       // the reference's callers hand in a zero-initialised coefficient
       // vector; the one slot an all-duplicates slice leaves unwritten stays 0
       HIP_TRY(hipMemsetAsync(d_c, 0, sizeof(int32_t) * n * c, st));
     } else
-      HIP_TRY(hipMemcpyAsync(d_c, coeffs, sizeof(int32_t) * n * c, hipMemcpyHostToDevice, st));
+      HIP_TRY(h2d_user(ctx, d_c, coeffs, sizeof(int32_t) * n * c, st));
     const int64_t offs[2] = {0, n};
     int r = dev_transform(
       ctx, params, encoder, 1, offs, d_m, d_q, d_a, d_c, c, std::max(bits, 1));
@@ -948,9 +1030,9 @@ host_transform(
     r = check_device_error(ctx);
     if (r)
       return r;
-    HIP_TRY(hipMemcpyAsync(attrs, d_a, sizeof(int32_t) * n * c, hipMemcpyDeviceToHost, st));
+    HIP_TRY(d2h_user(ctx, attrs, d_a, sizeof(int32_t) * n * c, st));
     if (encoder)
-      HIP_TRY(hipMemcpyAsync(coeffs, d_c, sizeof(int32_t) * n * c, hipMemcpyDeviceToHost, st));
+      HIP_TRY(d2h_user(ctx, coeffs, d_c, sizeof(int32_t) * n * c, st));
     HIP_TRY(hipStreamSynchronize(st));
     return GPCC_OK;
   };
@@ -1181,16 +1263,16 @@ host_lift(
   d.nw = d_nw;
   d.indexes = d_ix;
   d.qp_off = d_qp;
-  HIP_TRY(hipMemcpyAsync(d_nc, nc, sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(d_ni, ni, sizeof(int32_t) * n * 3, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(d_nw, nw, sizeof(int32_t) * n * 3, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(d_ix, indexes, sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
+  HIP_TRY(h2d_user(ctx, d_nc, nc, sizeof(int32_t) * n, st));
+  HIP_TRY(h2d_user(ctx, d_ni, ni, sizeof(int32_t) * n * 3, st));
+  HIP_TRY(h2d_user(ctx, d_nw, nw, sizeof(int32_t) * n * 3, st));
+  HIP_TRY(h2d_user(ctx, d_ix, indexes, sizeof(int32_t) * n, st));
   if (qp_off)
-    HIP_TRY(hipMemcpyAsync(d_qp, qp_off, sizeof(int32_t) * n * 2, hipMemcpyHostToDevice, st));
+    HIP_TRY(h2d_user(ctx, d_qp, qp_off, sizeof(int32_t) * n * 2, st));
   if (encoder) {
-    HIP_TRY(hipMemcpyAsync(d.attrs, attrs, sizeof(int32_t) * n * c, hipMemcpyHostToDevice, st));
+    HIP_TRY(h2d_user(ctx, d.attrs, attrs, sizeof(int32_t) * n * c, st));
   } else {
-    HIP_TRY(hipMemcpyAsync(d.coeffs, coeffs, sizeof(int32_t) * n * c, hipMemcpyHostToDevice, st));
+    HIP_TRY(h2d_user(ctx, d.coeffs, coeffs, sizeof(int32_t) * n * c, st));
     if (lcp_on)
       HIP_TRY(hipMemcpyAsync(d_lcp, lcp, GPCC_MAX_LODS, hipMemcpyHostToDevice, st));
   }
@@ -1201,9 +1283,9 @@ host_lift(
   }
   if (rcode)
     return rcode;
-  HIP_TRY(hipMemcpyAsync(attrs, d.attrs, sizeof(int32_t) * n * c, hipMemcpyDeviceToHost, st));
+  HIP_TRY(d2h_user(ctx, attrs, d.attrs, sizeof(int32_t) * n * c, st));
   if (encoder) {
-    HIP_TRY(hipMemcpyAsync(coeffs, d.coeffs, sizeof(int32_t) * n * c, hipMemcpyDeviceToHost, st));
+    HIP_TRY(d2h_user(ctx, coeffs, d.coeffs, sizeof(int32_t) * n * c, st));
     if (lcp_on)
       HIP_TRY(hipMemcpyAsync(lcp, d_lcp, GPCC_MAX_LODS, hipMemcpyDeviceToHost, st));
   }
@@ -1543,16 +1625,16 @@ host_pred(
   d.nw = d_nw;
   d.indexes = d_ix;
   d.qp_off = d_qp;
-  HIP_TRY(hipMemcpyAsync(d_nc, nc, sizeof(int32_t) * N, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(d_ni, ni, sizeof(int32_t) * N * 3, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(d_nw, nw, sizeof(int32_t) * N * 3, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(d_ix, indexes, sizeof(int32_t) * N, hipMemcpyHostToDevice, st));
+  HIP_TRY(h2d_user(ctx, d_nc, nc, sizeof(int32_t) * N, st));
+  HIP_TRY(h2d_user(ctx, d_ni, ni, sizeof(int32_t) * N * 3, st));
+  HIP_TRY(h2d_user(ctx, d_nw, nw, sizeof(int32_t) * N * 3, st));
+  HIP_TRY(h2d_user(ctx, d_ix, indexes, sizeof(int32_t) * N, st));
   if (qp_off)
-    HIP_TRY(hipMemcpyAsync(d_qp, qp_off, sizeof(int32_t) * N * 2, hipMemcpyHostToDevice, st));
+    HIP_TRY(h2d_user(ctx, d_qp, qp_off, sizeof(int32_t) * N * 2, st));
   if (encoder) {
-    HIP_TRY(hipMemcpyAsync(d.attrs, attrs, sizeof(int32_t) * N * c, hipMemcpyHostToDevice, st));
+    HIP_TRY(h2d_user(ctx, d.attrs, attrs, sizeof(int32_t) * N * c, st));
   } else {
-    HIP_TRY(hipMemcpyAsync(d.values, values, sizeof(int32_t) * N * c, hipMemcpyHostToDevice, st));
+    HIP_TRY(h2d_user(ctx, d.values, values, sizeof(int32_t) * N * c, st));
     if (icp_on)
       HIP_TRY(hipMemcpyAsync(d_icp, icp, GPCC_MAX_LODS * 3, hipMemcpyHostToDevice, st));
   }
@@ -1560,9 +1642,9 @@ host_pred(
                  : launch_pred<3>(ctx, encoder, p, n, d, d_icp, scratch);
   if (rcode)
     return rcode;
-  HIP_TRY(hipMemcpyAsync(attrs, d.attrs, sizeof(int32_t) * N * c, hipMemcpyDeviceToHost, st));
+  HIP_TRY(d2h_user(ctx, attrs, d.attrs, sizeof(int32_t) * N * c, st));
   if (encoder) {
-    HIP_TRY(hipMemcpyAsync(values, d.values, sizeof(int32_t) * N * c, hipMemcpyDeviceToHost, st));
+    HIP_TRY(d2h_user(ctx, values, d.values, sizeof(int32_t) * N * c, st));
     if (icp_on)
       HIP_TRY(hipMemcpyAsync(icp, d_icp, GPCC_MAX_LODS * 3, hipMemcpyDeviceToHost, st));
   }
@@ -1700,6 +1782,8 @@ gpcc_ctx_destroy(gpcc_ctx* ctx)
     hipHostFree(ctx->h_pinned);
   if (ctx->h_cx_stage)
     hipHostFree(ctx->h_cx_stage);
+  if (ctx->h_bounce)
+    hipHostFree(ctx->h_bounce);
   if (ctx->own_stream)
     hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -1968,7 +2052,7 @@ gpcc_attr_morton_sort_impl(
     HIP_TRY(pool_malloc(ctx, (void**)&d_x, sizeof(int32_t) * 3 * n));
     HIP_TRY(pool_malloc(ctx, (void**)&d_m, sizeof(int64_t) * n));
     HIP_TRY(pool_malloc(ctx, (void**)&d_o, sizeof(int32_t) * n));
-    HIP_TRY(hipMemcpyAsync(d_x, xyz, sizeof(int32_t) * 3 * n, hipMemcpyHostToDevice, st));
+    HIP_TRY(h2d_user(ctx, d_x, xyz, sizeof(int32_t) * 3 * n, st));
     const int saved = ctx->morton_bits;
     ctx->morton_bits = std::max(1, 3 * bitlen64((uint64_t)mx));
     const int64_t offs[2] = {0, n};
@@ -1976,8 +2060,8 @@ gpcc_attr_morton_sort_impl(
     ctx->morton_bits = saved;
     if (r)
       return r;
-    HIP_TRY(hipMemcpyAsync(morton, d_m, sizeof(int64_t) * n, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(order, d_o, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(d2h_user(ctx, morton, d_m, sizeof(int64_t) * n, st));
+    HIP_TRY(d2h_user(ctx, order, d_o, sizeof(int32_t) * n, st));
     HIP_TRY(hipStreamSynchronize(st));
     return GPCC_OK;
   };
@@ -2035,12 +2119,12 @@ gpcc_lod_compute_weights_impl(
   int32_t* d_nc = ar.take<int32_t>(n);
   uint64_t* d_d = ar.take<uint64_t>((size_t)n * 3);
   int32_t* d_w = ar.take<int32_t>((size_t)n * 3);
-  HIP_TRY(hipMemcpyAsync(d_nc, neigh_count, sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(d_d, dist2, sizeof(uint64_t) * n * 3, hipMemcpyHostToDevice, st));
+  HIP_TRY(h2d_user(ctx, d_nc, neigh_count, sizeof(int32_t) * n, st));
+  HIP_TRY(h2d_user(ctx, d_d, dist2, sizeof(uint64_t) * n * 3, st));
   lod_compute_weights_kernel<<<grid_for(n, 256), 256, 0, st>>>(n, d_nc, d_d, d_w);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(neigh_count, d_nc, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(neigh_weight, d_w, sizeof(int32_t) * n * 3, hipMemcpyDeviceToHost, st));
+  HIP_TRY(d2h_user(ctx, neigh_count, d_nc, sizeof(int32_t) * n, st));
+  HIP_TRY(d2h_user(ctx, neigh_weight, d_w, sizeof(int32_t) * n * 3, st));
   HIP_TRY(hipStreamSynchronize(st));
   return GPCC_OK;
 }
@@ -2157,7 +2241,7 @@ lod_build_core(
     int32_t* d_error = d_small + 8;
     int32_t* d_counts = d_small + 16;
     if (!xyz_on_device)
-      HIP_TRY(hipMemcpyAsync(d_xyz_own, xyz, sizeof(int32_t) * 3 * N, hipMemcpyHostToDevice, st));
+      HIP_TRY(h2d_user(ctx, d_xyz_own, xyz, sizeof(int32_t) * 3 * N, st));
     HIP_TRY(hipMemsetAsync(d_cell_state, 0, sizeof(uint32_t) * 4 * (N + 1), st));
     HIP_TRY(hipMemsetAsync(d_small, 0, sizeof(int32_t) * 64, st));
     HIP_TRY(hipMemsetAsync(d_scan, 0, sizeof(unsigned long long) * 1024, st));
@@ -2418,10 +2502,10 @@ gpcc_lod_build_impl(
   hipStream_t st = ctx->stream;
   const size_t N = (size_t)n;
   int32_t h_err = 0;
-  HIP_TRY(hipMemcpyAsync(neigh_count, o.count, sizeof(int32_t) * N, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(neigh_index, o.neigh_index, sizeof(int32_t) * 3 * N, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(neigh_weight, o.weight, sizeof(int32_t) * 3 * N, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(indexes, o.indexes, sizeof(int32_t) * N, hipMemcpyDeviceToHost, st));
+  HIP_TRY(d2h_user(ctx, neigh_count, o.count, sizeof(int32_t) * N, st));
+  HIP_TRY(d2h_user(ctx, neigh_index, o.neigh_index, sizeof(int32_t) * 3 * N, st));
+  HIP_TRY(d2h_user(ctx, neigh_weight, o.weight, sizeof(int32_t) * 3 * N, st));
+  HIP_TRY(d2h_user(ctx, indexes, o.indexes, sizeof(int32_t) * N, st));
   HIP_TRY(hipMemcpyAsync(&h_err, o.error, sizeof(int32_t), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   if (h_err)
@@ -2479,9 +2563,9 @@ pred_attr_driver(
   if (ar.used + pred_scratch_bytes(n) > ctx->arena.cap)
     return fail(GPCC_ERR_OUT_OF_MEMORY, "arena reservation too small");
   if (encoder) {
-    HIP_TRY(hipMemcpyAsync(d.attrs, attrs, sizeof(int32_t) * N * c, hipMemcpyHostToDevice, st));
+    HIP_TRY(h2d_user(ctx, d.attrs, attrs, sizeof(int32_t) * N * c, st));
   } else {
-    HIP_TRY(hipMemcpyAsync(d.values, values, sizeof(int32_t) * N * c, hipMemcpyHostToDevice, st));
+    HIP_TRY(h2d_user(ctx, d.values, values, sizeof(int32_t) * N * c, st));
     if (icp_on)
       HIP_TRY(hipMemcpyAsync(d_icp, icp, GPCC_MAX_LODS * 3, hipMemcpyHostToDevice, st));
   }
@@ -2490,14 +2574,14 @@ pred_attr_driver(
   if (r)
     return r;
   int32_t h_err = 0;
-  HIP_TRY(hipMemcpyAsync(attrs, d.attrs, sizeof(int32_t) * N * c, hipMemcpyDeviceToHost, st));
+  HIP_TRY(d2h_user(ctx, attrs, d.attrs, sizeof(int32_t) * N * c, st));
   if (encoder) {
-    HIP_TRY(hipMemcpyAsync(values, d.values, sizeof(int32_t) * N * c, hipMemcpyDeviceToHost, st));
+    HIP_TRY(d2h_user(ctx, values, d.values, sizeof(int32_t) * N * c, st));
     if (icp_on)
       HIP_TRY(hipMemcpyAsync(icp, d_icp, GPCC_MAX_LODS * 3, hipMemcpyDeviceToHost, st));
   }
   if (indexes)
-    HIP_TRY(hipMemcpyAsync(indexes, o.indexes, sizeof(int32_t) * N, hipMemcpyDeviceToHost, st));
+    HIP_TRY(d2h_user(ctx, indexes, o.indexes, sizeof(int32_t) * N, st));
   HIP_TRY(hipMemcpyAsync(&h_err, o.error, sizeof(int32_t), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   if (h_err)
@@ -2552,9 +2636,9 @@ lift_attr_driver(
   if (ar.used + lift_scratch_bytes(n, c) > ctx->arena.cap)
     return fail(GPCC_ERR_OUT_OF_MEMORY, "arena reservation too small");
   if (encoder) {
-    HIP_TRY(hipMemcpyAsync(d.attrs, attrs, sizeof(int32_t) * N * c, hipMemcpyHostToDevice, st));
+    HIP_TRY(h2d_user(ctx, d.attrs, attrs, sizeof(int32_t) * N * c, st));
   } else {
-    HIP_TRY(hipMemcpyAsync(d.coeffs, coeffs, sizeof(int32_t) * N * c, hipMemcpyHostToDevice, st));
+    HIP_TRY(h2d_user(ctx, d.coeffs, coeffs, sizeof(int32_t) * N * c, st));
     if (lcp_on)
       HIP_TRY(hipMemcpyAsync(d_lcp, lcp, GPCC_MAX_LODS, hipMemcpyHostToDevice, st));
   }
@@ -2566,14 +2650,14 @@ lift_attr_driver(
   if (r)
     return r;
   int32_t h_err = 0;
-  HIP_TRY(hipMemcpyAsync(attrs, d.attrs, sizeof(int32_t) * N * c, hipMemcpyDeviceToHost, st));
+  HIP_TRY(d2h_user(ctx, attrs, d.attrs, sizeof(int32_t) * N * c, st));
   if (encoder) {
-    HIP_TRY(hipMemcpyAsync(coeffs, d.coeffs, sizeof(int32_t) * N * c, hipMemcpyDeviceToHost, st));
+    HIP_TRY(d2h_user(ctx, coeffs, d.coeffs, sizeof(int32_t) * N * c, st));
     if (lcp_on)
       HIP_TRY(hipMemcpyAsync(lcp, d_lcp, GPCC_MAX_LODS, hipMemcpyDeviceToHost, st));
   }
   if (indexes)
-    HIP_TRY(hipMemcpyAsync(indexes, o.indexes, sizeof(int32_t) * N, hipMemcpyDeviceToHost, st));
+    HIP_TRY(d2h_user(ctx, indexes, o.indexes, sizeof(int32_t) * N, st));
   HIP_TRY(hipMemcpyAsync(&h_err, o.error, sizeof(int32_t), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   if (h_err)
@@ -2649,7 +2733,7 @@ slice_driver(
     HIP_TRY(pool_malloc(ctx, (void**)&d_pt, sizeof(int32_t) * N * c));
     HIP_TRY(pool_malloc(ctx, (void**)&d_a, sizeof(int32_t) * N * c));
     HIP_TRY(pool_malloc(ctx, (void**)&d_c, sizeof(int32_t) * N * c));
-    HIP_TRY(hipMemcpyAsync(d_xyz, xyz, sizeof(int32_t) * 3 * N, hipMemcpyHostToDevice, st));
+    HIP_TRY(h2d_user(ctx, d_xyz, xyz, sizeof(int32_t) * 3 * N, st));
     const int bits = std::max(1, 3 * bitlen64((uint64_t)mx));
     const int64_t offs[2] = {0, n};
     {
@@ -2661,14 +2745,14 @@ slice_driver(
         return r;
     }
     if (encoder) {
-      HIP_TRY(hipMemcpyAsync(d_pt, attrs, sizeof(int32_t) * N * c, hipMemcpyHostToDevice, st));
+      HIP_TRY(h2d_user(ctx, d_pt, attrs, sizeof(int32_t) * N * c, st));
       {
         Timer tm(ctx, "attr_gather");
         attr_gather_kernel<<<grid_for(n, 256), 256, 0, st>>>(n, c, d_order, d_pt, d_a);
       }
       HIP_TRY(hipMemsetAsync(d_c, 0, sizeof(int32_t) * N * c, st));
     } else {
-      HIP_TRY(hipMemcpyAsync(d_c, coeffs, sizeof(int32_t) * N * c, hipMemcpyHostToDevice, st));
+      HIP_TRY(h2d_user(ctx, d_c, coeffs, sizeof(int32_t) * N * c, st));
     }
     int r = dev_transform(ctx, params, encoder, 1, offs, d_m, nullptr, d_a, d_c, c, bits);
     if (r)
@@ -2713,8 +2797,8 @@ slice_driver(
       HIP_TRY(hipMemcpyAsync(h, d_small, sizeof(h), hipMemcpyDeviceToHost, st));
       HIP_TRY(hipStreamSynchronize(st));
       if (h[0] > 0) {
-        HIP_TRY(hipMemcpyAsync(runs, d_runs, sizeof(int32_t) * (size_t)h[0], hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(values, d_vals, sizeof(int32_t) * (size_t)h[0] * c, hipMemcpyDeviceToHost, st));
+        HIP_TRY(d2h_user(ctx, runs, d_runs, sizeof(int32_t) * (size_t)h[0], st));
+        HIP_TRY(d2h_user(ctx, values, d_vals, sizeof(int32_t) * (size_t)h[0] * c, st));
       }
       *num_symbols = h[0];
       *trailing_run = h[1];
@@ -2725,9 +2809,9 @@ slice_driver(
     r = check_device_error(ctx);
     if (r)
       return r;
-    HIP_TRY(hipMemcpyAsync(attrs, d_pt, sizeof(int32_t) * N * c, hipMemcpyDeviceToHost, st));
+    HIP_TRY(d2h_user(ctx, attrs, d_pt, sizeof(int32_t) * N * c, st));
     if (encoder && !packed)
-      HIP_TRY(hipMemcpyAsync(coeffs, d_c, sizeof(int32_t) * N * c, hipMemcpyDeviceToHost, st));
+      HIP_TRY(d2h_user(ctx, coeffs, d_c, sizeof(int32_t) * N * c, st));
     HIP_TRY(hipStreamSynchronize(st));
     return GPCC_OK;
   };
@@ -2800,7 +2884,7 @@ gpcc_zero_run_pack_impl(
   if (rcode)
     return rcode;
   carve(ctx->arena);
-  HIP_TRY(hipMemcpyAsync(d_co, coeffs, sizeof(int32_t) * N * c, hipMemcpyHostToDevice, st));
+  HIP_TRY(h2d_user(ctx, d_co, coeffs, sizeof(int32_t) * N * c, st));
   HIP_TRY(hipMemsetAsync(d_small, 0, sizeof(int32_t) * 64, st));
   HIP_TRY(hipMemsetAsync(d_scan, 0, sizeof(unsigned long long) * 1024, st));
   {
@@ -2817,8 +2901,8 @@ gpcc_zero_run_pack_impl(
   HIP_TRY(hipStreamSynchronize(st));
   // only the symbols cross PCIe
   if (h[0] > 0) {
-    HIP_TRY(hipMemcpyAsync(runs, d_runs, sizeof(int32_t) * (size_t)h[0], hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(values, d_vals, sizeof(int32_t) * (size_t)h[0] * c, hipMemcpyDeviceToHost, st));
+    HIP_TRY(d2h_user(ctx, runs, d_runs, sizeof(int32_t) * (size_t)h[0], st));
+    HIP_TRY(d2h_user(ctx, values, d_vals, sizeof(int32_t) * (size_t)h[0] * c, st));
     HIP_TRY(hipStreamSynchronize(st));
   }
   *num_symbols = h[0];
@@ -2854,7 +2938,7 @@ gpcc_estimate_dist2_impl(
       rc = fail(GPCC_ERR_OUT_OF_MEMORY, "hipMalloc(estimate_dist2)");
       break;
     }
-    hipError_t e = hipMemcpyAsync(d_xyz, xyz, sizeof(int32_t) * 3 * (size_t)n, hipMemcpyHostToDevice, st);
+    hipError_t e = h2d_user(ctx, d_xyz, xyz, sizeof(int32_t) * 3 * (size_t)n, st);
     if (e == hipSuccess) {
       Timer tm(ctx, "estimate_dist2");
       estimate_dist2_kernel<<<grid_for(ns * 64, 256), 256, 0, st>>>(
@@ -4039,8 +4123,8 @@ binarise_symbols(
     HIP_TRY(pool_malloc(ctx, (void**)&d_blk, sizeof(int32_t) * ((size_t)nblk + 1)));
     HIP_TRY(pool_malloc(ctx, (void**)&d_base, sizeof(long long) * ((size_t)nblk + 1)));
     if (m) {
-      HIP_TRY(hipMemcpyAsync(d_runs, runs, sizeof(int32_t) * m, hipMemcpyHostToDevice, st));
-      HIP_TRY(hipMemcpyAsync(d_vals, values, sizeof(int32_t) * m * c, hipMemcpyHostToDevice, st));
+      HIP_TRY(h2d_user(ctx, d_runs, runs, sizeof(int32_t) * m, st));
+      HIP_TRY(h2d_user(ctx, d_vals, values, sizeof(int32_t) * m * c, st));
     }
     {
       Timer t(ctx, "bins_count");
@@ -4062,7 +4146,7 @@ binarise_symbols(
       Timer t(ctx, "bins_emit");
       bins_emit_kernel<<<nblk, kBinBlock, 0, st>>>(num_symbols, d_runs, d_vals, trailing_run, c, d_cnt, d_base, d_bins);
     }
-    HIP_TRY(hipMemcpyAsync(bins, d_bins, (size_t)total, hipMemcpyDeviceToHost, st));
+    HIP_TRY(d2h_user(ctx, bins, d_bins, (size_t)total, st));
     HIP_TRY(hipStreamSynchronize(st));
     return GPCC_OK;
   };
@@ -4183,9 +4267,9 @@ recolour_impl(
     HIP_TRY(pool_malloc(ctx, (void**)&d_tx, sizeof(int32_t) * 3 * (size_t)nt));
     HIP_TRY(pool_malloc(ctx, (void**)&d_out, sizeof(int32_t) * (size_t)c * nt));
     HIP_TRY(pool_malloc(ctx, (void**)&d_box, sizeof(int32_t) * 12));
-    HIP_TRY(hipMemcpyAsync(d_sx, src_xyz, sizeof(int32_t) * 3 * (size_t)ns, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_sa, src_attrs, sizeof(int32_t) * (size_t)c * ns, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_tx, tgt_xyz, sizeof(int32_t) * 3 * (size_t)nt, hipMemcpyHostToDevice, st));
+    HIP_TRY(h2d_user(ctx, d_sx, src_xyz, sizeof(int32_t) * 3 * (size_t)ns, st));
+    HIP_TRY(h2d_user(ctx, d_sa, src_attrs, sizeof(int32_t) * (size_t)c * ns, st));
+    HIP_TRY(h2d_user(ctx, d_tx, tgt_xyz, sizeof(int32_t) * 3 * (size_t)nt, st));
     int32_t h_box[12];
     for (int k = 0; k < 3; k++) {
       h_box[k] = h_box[6 + k] = 0x7fffffff;
@@ -4304,7 +4388,7 @@ recolour_impl(
         rc_blend_kernel<1><<<(nt + 255) / 256, 256, 0, st>>>(cx);
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(tgt_attrs, d_out, sizeof(int32_t) * (size_t)c * nt, hipMemcpyDeviceToHost, st));
+    HIP_TRY(d2h_user(ctx, tgt_attrs, d_out, sizeof(int32_t) * (size_t)c * nt, st));
     HIP_TRY(hipStreamSynchronize(st));
     return GPCC_OK;
   };
