@@ -4362,16 +4362,44 @@ recolour_impl(
     // ---- forward, backward, lists, blend ------------------------------------------------
     {
       Timer t(ctx, "rc_forward");
+      // list capacity 1 / 2 / 4 / 8 and with / without the attribute limit: 16 variants
+      const bool alimit = p->max_attribute_dist2_fwd < 512;
+      const int kcap = kf <= 1 ? 1 : kf <= 2 ? 2 : kf <= 4 ? 4 : 8;
+      const int fgrid = (nt + 255) / 256;
+#define GPCC_RC_FWD(CC, KK)                                                \
+  do {                                                                     \
+    if (alimit)                                                            \
+      rc_forward_kernel<CC, KK, true><<<fgrid, 256, 0, st>>>(cx);          \
+    else                                                                   \
+      rc_forward_kernel<CC, KK, false><<<fgrid, 256, 0, st>>>(cx);         \
+  } while (0)
+#define GPCC_RC_FWD_K(CC)                                                  \
+  do {                                                                     \
+    switch (kcap) {                                                        \
+    case 1: GPCC_RC_FWD(CC, 1); break;                                     \
+    case 2: GPCC_RC_FWD(CC, 2); break;                                     \
+    case 4: GPCC_RC_FWD(CC, 4); break;                                     \
+    default: GPCC_RC_FWD(CC, 8); break;                                    \
+    }                                                                      \
+  } while (0)
       if (c == 3)
-        rc_forward_kernel<3><<<(nt + 255) / 256, 256, 0, st>>>(cx);
+        GPCC_RC_FWD_K(3);
       else
-        rc_forward_kernel<1><<<(nt + 255) / 256, 256, 0, st>>>(cx);
+        GPCC_RC_FWD_K(1);
+#undef GPCC_RC_FWD_K
+#undef GPCC_RC_FWD
     }
     HIP_TRY(hipMemsetAsync(d_lstart, 0, sizeof(int32_t) * ((size_t)nt + 1), st));
     HIP_TRY(hipMemsetAsync(d_lcur, 0, sizeof(int32_t) * (size_t)nt, st));
     {
       Timer t(ctx, "rc_backward");
-      rc_backward_kernel<<<(ns + 255) / 256, 256, 0, st>>>(cx);
+      const int bgrid = (ns + 255) / 256;
+      switch (kb <= 1 ? 1 : kb <= 2 ? 2 : kb <= 4 ? 4 : 8) {
+      case 1: rc_backward_kernel<1><<<bgrid, 256, 0, st>>>(cx); break;
+      case 2: rc_backward_kernel<2><<<bgrid, 256, 0, st>>>(cx); break;
+      case 4: rc_backward_kernel<4><<<bgrid, 256, 0, st>>>(cx); break;
+      default: rc_backward_kernel<8><<<bgrid, 256, 0, st>>>(cx); break;
+      }
     }
     {
       Timer t(ctx, "rc_lists");

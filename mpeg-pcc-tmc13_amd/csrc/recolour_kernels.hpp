@@ -212,33 +212,38 @@ rc_scan_apply_kernel(int32_t* a, size_t n, const long long* __restrict__ sums)
 }
 
 // ---- exact K nearest neighbours -----------------------------------------------------
+// (K = the list's capacity, a template parameter: the kernels are built for 1, 2, 4 and 8 -- with
+// the one list of 8 the forward kernel took 256 registers and 1.9 KB of scratch per lane, one
+// wavefront per SIMD, and the backward kernel, which keeps ONE neighbour, carried seven idle ones)
+template<int K>
 struct RcKnn {
-  double d[kRcMaxK];
-  int32_t i[kRcMaxK];
+  double d[K];
+  int32_t i[K];
   int count;
 };
 
 // (d2, idx) into the ascending list; equal distances by index; entries beyond the
 // k-th fall off.  Static register indices only.
+template<int K>
 __device__ __forceinline__ void
-rc_insert(RcKnn& r, int k, double d, int32_t idx)
+rc_insert(RcKnn<K>& r, int k, double d, int32_t idx)
 {
   // where it goes: the number of entries that come before it
   int pos = 0;
 #pragma unroll
-  for (int p = 0; p < kRcMaxK; p++)
+  for (int p = 0; p < K; p++)
     pos += (p < r.count && (r.d[p] < d || (r.d[p] == d && r.i[p] < idx))) ? 1 : 0;
   if (pos >= k)
     return;
 #pragma unroll
-  for (int p = kRcMaxK - 1; p > 0; p--) {
+  for (int p = K - 1; p > 0; p--) {
     if (p > pos) {
       r.d[p] = r.d[p - 1];
       r.i[p] = r.i[p - 1];
     }
   }
 #pragma unroll
-  for (int p = 0; p < kRcMaxK; p++) {
+  for (int p = 0; p < K; p++) {
     if (p == pos) {
       r.d[p] = d;
       r.i[p] = idx;
@@ -247,18 +252,20 @@ rc_insert(RcKnn& r, int k, double d, int32_t idx)
   r.count = r.count < k ? r.count + 1 : k;
 }
 
+template<int K>
 __device__ __forceinline__ double
-rc_kth(const RcKnn& r, int k)
+rc_kth(const RcKnn<K>& r, int k)
 {
   double v = r.d[0];
 #pragma unroll
-  for (int p = 1; p < kRcMaxK; p++)
+  for (int p = 1; p < K; p++)
     v = p == k - 1 ? r.d[p] : v;
   return v;
 }
 
+template<int K>
 __device__ __forceinline__ void
-rc_knn(const RcGrid& g, const double q[3], int k, RcKnn& r)
+rc_knn(const RcGrid& g, const double q[3], int k, RcKnn<K>& r)
 {
 #pragma clang fp contract(off)
   const int cs = 1 << g.shift;
@@ -268,7 +275,7 @@ rc_knn(const RcGrid& g, const double q[3], int k, RcKnn& r)
     cq[a] = (int)floor(q[a] / cs) - g.lo[a];
   r.count = 0;
 #pragma unroll
-  for (int p = 0; p < kRcMaxK; p++) {
+  for (int p = 0; p < K; p++) {
     r.d[p] = 0.0;
     r.i[p] = 0;
   }
@@ -330,7 +337,9 @@ rc_limit(double v)
 }
 
 // ---- forward (pointset_processing.cpp:296-384 / 659-728) ---------------------------
-template<int C>
+// (ALIMIT: a finite max_attribute_dist2_fwd; without one the k x k comparison of the neighbours'
+// attributes decides nothing and is left out)
+template<int C, int K, bool ALIMIT>
 __global__ __launch_bounds__(256) void
 rc_forward_kernel(RcCtx cx)
 {
@@ -346,12 +355,12 @@ rc_forward_kernel(RcCtx cx)
 #pragma unroll
   for (int a = 0; a < 3; a++)
     q[a] = (double)(cx.tgt.xyz[3 * t + a] + cx.off[a]) * cx.t2s;
-  RcKnn r;
-  rc_knn(cx.src, q, kf, r);
+  RcKnn<K> r;
+  rc_knn<K>(cx.src, q, kf, r);
   // the neighbours' attributes, nearest first
-  int32_t col[kRcMaxK][C];
+  int32_t col[K][C];
 #pragma unroll
-  for (int i = 0; i < kRcMaxK; i++)
+  for (int i = 0; i < K; i++)
 #pragma unroll
     for (int k = 0; k < C; k++)
       col[i][k] = i < r.count ? cx.src_attrs[(size_t)r.i[i] * C + k] : 0;
@@ -372,10 +381,11 @@ rc_forward_kernel(RcCtx cx)
     // (colour differences wrap in 16 bits there: Vec3<attr_t> - Vec3<attr_t>,
     // tmc3/PCCMath.h:280; reflectances are subtracted as int)
     double maxa = 2.2250738585072014e-308;
+    if (ALIMIT)
 #pragma unroll
-    for (int i = 0; i < kRcMaxK; i++)
+    for (int i = 0; i < K; i++)
 #pragma unroll
-      for (int j = 0; j < kRcMaxK; j++) {
+      for (int j = 0; j < K; j++) {
         if (i < nn && j < nn) {
           double s = 0.0;
 #pragma unroll
@@ -396,7 +406,7 @@ rc_forward_kernel(RcCtx cx)
     if (p.use_dist_weighted_avg_fwd) {
       double sumw = 0.0;
 #pragma unroll
-      for (int i = 0; i < kRcMaxK; i++) {
+      for (int i = 0; i < K; i++) {
         if (i < nn) {
           const double w = 1 / (r.d[i] + p.dist_offset_fwd);
 #pragma unroll
@@ -410,7 +420,7 @@ rc_forward_kernel(RcCtx cx)
         acc[k] /= sumw;
     } else {
 #pragma unroll
-      for (int i = 0; i < kRcMaxK; i++) {
+      for (int i = 0; i < K; i++) {
         if (i < nn) {
 #pragma unroll
           for (int k = 0; k < C; k++)
@@ -429,6 +439,7 @@ rc_forward_kernel(RcCtx cx)
 }
 
 // ---- backward (:386-424 / 730-766): nearest targets of every source point ------------
+template<int K>
 __global__ __launch_bounds__(256) void
 rc_backward_kernel(RcCtx cx)
 {
@@ -442,10 +453,10 @@ rc_backward_kernel(RcCtx cx)
 #pragma unroll
   for (int a = 0; a < 3; a++)
     q[a] = (double)cx.src.xyz[3 * s + a] * cx.s2t - (double)cx.off[a];
-  RcKnn r;
-  rc_knn(cx.tgt, q, kb, r);
+  RcKnn<K> r;
+  rc_knn<K>(cx.tgt, q, kb, r);
 #pragma unroll
-  for (int i = 0; i < kRcMaxK; i++) {
+  for (int i = 0; i < K; i++) {
     if (i < kb) {
       const bool ok = i < r.count && r.d[i] <= max_g;
       cx.bt[(size_t)s * kb + i] = ok ? r.i[i] : -1;
