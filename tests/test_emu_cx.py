@@ -87,6 +87,33 @@ def test_ragged_batches(sizes, c):
     assert np.array_equal(emu.inverse(p, morton, dec_in, c, offsets=offs), rec)
 
 
+@pytest.mark.parametrize("c", [1, 3])
+def test_long_duplicate_chains_late_in_a_batch(c):
+    """slices of a handful of voxels with a hundred points each (finish_kernel's chains of
+    (w, 1) transforms, weights beyond the small-weight tables) behind larger slices: the
+    shape whose first chain coefficients came out wrong on the device in round 3
+    (tests/test_gpu_batches.py) -- the logic, under the emulator"""
+    sizes = [4000, 900, 3, 1072, 61, 658, 2]
+    bits = [8, 6, 2, 1, 3, 1, 1]
+    p = raht_params(qp=11, prediction=False, subnode=False)
+    ms, as_ = [], []
+    for i, (n, b) in enumerate(zip(sizes, bits)):
+        xyz, a = synth.random_cloud(n, seed=510 + i, bits=b, c=c, dup_fraction=0.0)
+        m, a, _ = synth.sort_by_morton(xyz, a)
+        ms.append(m)
+        as_.append(a)
+    offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    co, rec = emu.forward(p, np.concatenate(ms), np.concatenate(as_), offsets)
+    inv = emu.inverse(p, np.concatenate(ms), co, c, offsets)
+    o = ol.oracle()
+    for i, n in enumerate(sizes):
+        o_co, o_rec = o.raht_forward(p, ms[i], as_[i])
+        b = int(offsets[i])
+        assert np.array_equal(co[c * b:c * (b + n)], o_co), f"slice {i}"
+        assert np.array_equal(rec[b:b + n], o_rec), f"slice {i}"
+        assert np.array_equal(inv[b:b + n], o_rec), f"slice {i}"
+
+
 @pytest.mark.parametrize("n,bits,slices", [(1000, 12, 1), (5000, 30, 1), (3000, 9, 3), (70000, 36, 2),
                                            (2500, 54, 1), (5000, 20, 40), (4000, 10, 300)])
 def test_tree_and_block_lists(n, bits, slices):
