@@ -272,8 +272,12 @@ typedef struct gpcc_lod_params {
  *   num_points_in_lod [GPCC_MAX_LODS] cumulative, *num_lods.
  * All three decimators (lod_decimation_type 0 distance, 1 periodic, 2
  * centroid) and, for the predicting transform, blendWeights run on the
- * device; scalable lifting, canonical point order and inter prediction
- * return GPCC_ERR_UNSUPPORTED (the shim keeps them on the reference path). */
+ * device.  canonical_point_order_flag / max_points_per_sort_log2_plus1
+ * (PCCTMC3Common.h:2322-2331: the points taken as they come, or sorted in
+ * chunks) are accepted when the points ARE in Morton order -- what the octree
+ * geometry coder hands over; then neither changes the result.  Points in any
+ * other order with those flags, scalable lifting and inter prediction return
+ * GPCC_ERR_UNSUPPORTED (the shim keeps them on the reference path). */
 int gpcc_lod_build(
   gpcc_ctx* ctx, const gpcc_lod_params* params, const int32_t* xyz, int32_t n,
   int32_t* neigh_count, int32_t* neigh_index, int32_t* neigh_weight,

@@ -2157,12 +2157,8 @@ lod_build_core(
     return fail(GPCC_ERR_INVALID_ARG, "null buffer or n <= 0");
   if (n > kMaxPoints)
     return fail(GPCC_ERR_INVALID_ARG, "more than 2^29 points per call");
-  if (lp->scalable_lifting_enabled_flag || lp->canonical_point_order_flag
-      || lp->max_points_per_sort_log2_plus1 || lp->lod_decimation_type < 0
-      || lp->lod_decimation_type > 2)
-    return fail(
-      GPCC_ERR_UNSUPPORTED,
-      "scalable lifting / canonical point order stay on the reference CPU path");
+  if (lp->scalable_lifting_enabled_flag || lp->lod_decimation_type < 0 || lp->lod_decimation_type > 2)
+    return fail(GPCC_ERR_UNSUPPORTED, "scalable lifting stays on the reference CPU path");
   const int max_levels = lp->num_detail_levels_minus1 + 1;
   if (max_levels < 1 || max_levels > GPCC_MAX_LODS - 1)
     return fail(GPCC_ERR_INVALID_ARG, "num_detail_levels out of range");
@@ -2254,6 +2250,20 @@ lod_build_core(
       ctx->morton_bits = saved;
       if (r)
         return r;
+    }
+    // canonical_point_order_flag / max_points_per_sort_log2_plus1 (PCCTMC3Common.h:2322-2331): the
+    // reference takes the points as they come (or sorts them in chunks).  What the octree geometry
+    // coder hands over IS in (Morton code, index) order -- then neither changes anything and the
+    // build is the one below; any other order stays on the reference CPU path.
+    if (lp->canonical_point_order_flag || lp->max_points_per_sort_log2_plus1) {
+      int32_t moved = 0;
+      lod_count_moved_kernel<<<grid_for(n, 256), 256, 0, st>>>(n, d_order, d_small + 24);
+      HIP_TRY(hipMemcpyAsync(&moved, d_small + 24, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      if (moved)
+        return fail(
+          GPCC_ERR_UNSUPPORTED,
+          "canonical point order / chunked sort with points that are not in Morton order stay on the reference CPU path");
     }
     {
       Timer tm(ctx, "lod_gather");

@@ -65,6 +65,17 @@ norm1_i3(const int32_t* a, const int32_t* b)
   return abs(a[0] - b[0]) + abs(a[1] - b[1]) + abs(a[2] - b[2]);
 }
 
+// positions the sort moved (canonical point order: none may have)
+__global__ __launch_bounds__(256) void
+lod_count_moved_kernel(int n, const int32_t* __restrict__ order, int32_t* moved)
+{
+  int cnt = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    cnt += order[i] != i;
+  if (cnt)
+    atomicAdd(moved, cnt);
+}
+
 // ---- gather sorted positions ---------------------------------------------
 __global__ __launch_bounds__(256) void
 lod_gather_pos_kernel(

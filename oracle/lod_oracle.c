@@ -704,14 +704,24 @@ oracle_lod_generate(
   int32_t* neigh_count, int32_t* neigh_index, uint64_t* weight64,
   int32_t* indexes_out, int32_t* num_points_in_lod, int32_t* num_lods)
 {
-  if (lp->scalable_lifting_enabled_flag || lp->canonical_point_order_flag
-      || lp->max_points_per_sort_log2_plus1)
+  if (lp->scalable_lifting_enabled_flag)
     return -2; /* not restated */
   voxel_t* pv = (voxel_t*)malloc(sizeof(voxel_t) * (size_t)n);
   for (int i = 0; i < n; i++) {
     pv[i].code = morton_addr(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
     memcpy(pv[i].pos, &xyz[3 * i], 12);
     pv[i].index = i;
+  }
+  /* canonical_point_order_flag / max_points_per_sort_log2_plus1 (:2322-2331): the points are
+   * taken in the order they come (or sorted in chunks).  Restated for the case the octree
+   * geometry coder produces -- the points ARE in (Morton code, index) order, so neither the
+   * full sort nor the chunked one moves anything; any other order is not restated. */
+  if (lp->canonical_point_order_flag || lp->max_points_per_sort_log2_plus1) {
+    for (int i = 1; i < n; i++)
+      if (pv[i - 1].code > pv[i].code) {
+        free(pv);
+        return -2;
+      }
   }
   qsort(pv, (size_t)n, sizeof(voxel_t), cmp_voxel);
   int32_t* bias_pos = (int32_t*)malloc(sizeof(int32_t) * 3 * (size_t)n);

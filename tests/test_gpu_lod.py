@@ -209,3 +209,29 @@ def test_device_tier_concurrent_lanes_many_ragged_slices():
         ctx.dev_lod_build(bad, offsets, d_xyz.data_ptr(), *[t.data_ptr() for t in outs])
     assert e.value.code == -2
     ctx.close()
+
+
+@pytest.mark.parametrize("flags", [dict(canonical=1), dict(chunk=1), dict(chunk=6)])
+def test_canonical_point_order_on_morton_sorted_points(flags, ctx):
+    """canonical_point_order_flag / max_points_per_sort_log2_plus1 with the points in Morton order
+    (what the octree geometry coder hands over): the build is the ordinary one and equals the
+    oracle (pinned to the reference with the same flags, tests/test_oracle_lod.py); points in
+    any other order are declined."""
+    from mpeg_pcc_tmc13_amd import lod_params, synth
+    from mpeg_pcc_tmc13_amd._lib import GpccError
+    for name, xyz in clouds():
+        _, _, order = synth.sort_by_morton(xyz, np.zeros((len(xyz), 1), np.int32))
+        xs = np.ascontiguousarray(xyz[order])
+        lp = lod_params()
+        lp.canonical_point_order_flag = flags.get("canonical", 0)
+        lp.max_points_per_sort_log2_plus1 = flags.get("chunk", 0)
+        o = lh.oracle_lod_generate(xs, lp)
+        g = ctx.lod_build(lp, xs)
+        for k in ("npl", "indexes", "nc", "ni"):
+            np.testing.assert_array_equal(g[k], o[k], err_msg=f"{name} {flags} {k}")
+        np.testing.assert_array_equal(g["w"].astype(np.uint64), o["w"], err_msg=f"{name} {flags}")
+    lp = lod_params()
+    lp.canonical_point_order_flag = 1
+    with pytest.raises(GpccError) as e:
+        ctx.lod_build(lp, synth.random_cloud(3000, seed=2, bits=5)[0])
+    assert "Morton order" in str(e.value)

@@ -56,3 +56,26 @@ def test_lod_structure_invariants():
         m = o["nc"] > k
         assert np.all(lod_of[o["ni"][m, k]] < lod_of[np.nonzero(m)[0]])
     assert np.all(o["w"][o["nc"] == 3].sum(axis=1) == 256)
+
+
+@pytest.mark.parametrize("flags", [dict(canonical=1), dict(chunk=1), dict(chunk=6), dict(canonical=1, chunk=9)])
+def test_canonical_point_order_on_morton_sorted_points(flags):
+    """canonical_point_order_flag / max_points_per_sort_log2_plus1 (PCCTMC3Common.h:2322-2331) with the
+    points in Morton order, as the octree geometry coder leaves them: the oracle equals the
+    reference run with the same flags; any other order is declined (not restated)."""
+    from mpeg_pcc_tmc13_amd import lod_params, synth
+    for name, xyz in clouds():
+        _, _, order = synth.sort_by_morton(xyz, np.zeros((len(xyz), 1), np.int32))
+        xs = np.ascontiguousarray(xyz[order])
+        lp = lod_params()
+        lp.canonical_point_order_flag = flags.get("canonical", 0)
+        lp.max_points_per_sort_log2_plus1 = flags.get("chunk", 0)
+        r = lh.ref_lod_generate(xs, lp)
+        o = lh.oracle_lod_generate(xs, lp)
+        for k in r:
+            np.testing.assert_array_equal(o[k], r[k], err_msg=f"{name} {flags} {k}")
+    xyz = synth.random_cloud(3000, seed=2, bits=5)[0]
+    lp = lod_params()
+    lp.canonical_point_order_flag = 1
+    with pytest.raises(AssertionError):
+        lh.oracle_lod_generate(xyz, lp)   # (the loader asserts on the "not restated" code)
