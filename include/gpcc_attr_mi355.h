@@ -205,6 +205,11 @@ typedef struct gpcc_lift_params {
   int32_t layer_qp[GPCC_MAX_QP_LAYERS][2];
   int32_t max_qp;
   int32_t fixed_point_qp_offset;
+  /* AttributeParameterSet::scalable_lifting_enabled_flag: the quantisation
+   * weight of a predictor is then a function of its level of detail alone
+   * (computeQuantizationWeightsScalable, PCCTMC3Common.h:858-891, whole
+   * slices: minGeomNodeSizeLog2 = 0) */
+  int32_t scalable_lifting_enabled_flag;
 } gpcc_lift_params;
 
 /* The predictors of AttributeLods (AttributeCommon.h:89-94) as flat arrays in

@@ -100,10 +100,11 @@ class LiftParams(C.Structure):
         ("layer_qp", (C.c_int32 * 2) * GPCC_MAX_QP_LAYERS),
         ("max_qp", C.c_int32),
         ("fixed_point_qp_offset", C.c_int32),
+        ("scalable_lifting_enabled_flag", C.c_int32),
     ]
 
 
-def lift_params(num_points_in_lod, qp=34, chroma_offset=-1, bitdepth=8, lcp=True, layers=None):
+def lift_params(num_points_in_lod, qp=34, chroma_offset=-1, bitdepth=8, lcp=True, layers=None, scalable=False):
     """Effective values of cfg/octree-liftt-ctc-lossless-geom-lossy-attrs.yaml
     (transformType 2): fixedPointQpOffset = (kFixedPointWeightShift / 2) * 6
     = 24 (quantization.cpp:155-158), last component prediction on."""
@@ -122,6 +123,7 @@ def lift_params(num_points_in_lod, qp=34, chroma_offset=-1, bitdepth=8, lcp=True
         p.layer_qp[i][1] = b
     p.max_qp = 51 + 6 * (bitdepth - 8)
     p.fixed_point_qp_offset = 24
+    p.scalable_lifting_enabled_flag = int(scalable)
     return p
 
 

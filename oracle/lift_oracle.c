@@ -77,6 +77,22 @@ quant_weights(
       qw[ni[3 * i + j]] += round_shift8_u64((uint64_t)(uint32_t)nw[3 * i + j] * qw[i]);
 }
 
+/* computeQuantizationWeightsScalable (PCCTMC3Common.h:858-891) for a whole
+ * slice (minGeomNodeSizeLog2 = 0): every predictor of a level of detail gets
+ * numPoints / (points up to and including that level), the finest level 1 */
+static void
+quant_weights_scalable(int n, int lods, const int32_t* npl, uint64_t* qw)
+{
+  for (int i = 0; i < n; i++)
+    qw[i] = 1u << 8;
+  for (int l = 0; l < lods; l++) {
+    const int start = l ? npl[l - 1] : 0;
+    const uint64_t w = (uint64_t)(n / npl[l]) << 8;
+    for (int i = start; i < npl[l]; i++)
+      qw[i] = l == lods - 1 ? 1u << 8 : w;
+  }
+}
+
 /* PCCLiftPredict over [start, end) */
 static void
 lift_predict(
@@ -153,7 +169,10 @@ lift_process(
   uint64_t* uw = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)n);
   int64_t* up = (int64_t*)malloc(sizeof(int64_t) * (size_t)n * c);
   int64_t* a = (int64_t*)calloc((size_t)n * c, sizeof(int64_t));
-  quant_weights(n, nc, ni, nw, qw);
+  if (p->scalable_lifting_enabled_flag)
+    quant_weights_scalable(n, lods, npl, qw);
+  else
+    quant_weights(n, nc, ni, nw, qw);
 
   int8_t signs[GPCC_MAX_LODS];
   memset(signs, 0, sizeof(signs));

@@ -1,7 +1,9 @@
 /* lod_oracle.c -- TEST INFRASTRUCTURE (CPU oracle), not product code.
  *
- * Plain-C restatement of the level-of-detail generation of TMC13 for intra,
- * non-scalable attribute coding:
+ * Plain-C restatement of the level-of-detail generation of TMC13 for intra
+ * attribute coding of whole slices (scalable lifting included: octree
+ * sub-sampling by LoD index, node-corner positions, pruning by range, the
+ * repeated search of the finer layers :2377-2448):
  *   buildPredictorsFast          tmc3/PCCTMC3Common.h:2300-2469
  *   subsampleByDistance          :1984-2085   (MortonIndexMap3d :111-172)
  *   subsampleByDecimation        :2198-2214
@@ -191,7 +193,7 @@ subsample_by_decimation(
 static void
 subsample_by_octree(
   const voxel_t* pv, const int32_t* input, int n_in, int node_log2, int period,
-  int32_t* retained, int* n_ret, int32_t* refine, int* n_ref)
+  int backward, int32_t* retained, int* n_ret, int32_t* refine, int* n_ref)
 {
   *n_ret = 0;
   if (n_in == 1) {
@@ -215,9 +217,11 @@ subsample_by_octree(
       for (int v = 0; v < nv; v++)
         for (int d = 0; d < 3; d++)
           cen[d] += (int32_t)((uint32_t)pv[vox[v]].pos[d] & mask);
-      int best = nv - 1;
+      /* the first minimum met walking from the back (direction) or the front */
+      int best = backward ? nv - 1 : 0;
       int64_t best_m = INT64_MAX;
-      for (int v = nv - 1; v >= 0; v--) {
+      for (int w = 0; w < nv; w++) {
+        const int v = backward ? nv - 1 - w : w;
         int64_t m = 0;
         for (int d = 0; d < 3; d++) {
           int32_t p = (int32_t)((uint32_t)pv[vox[v]].pos[d] & mask) * nv;
@@ -451,12 +455,27 @@ typedef struct {
 
 static void
 compute_nearest_neighbours(
-  const gpcc_lod_params* lp, const voxel_t* pv, const int32_t* bias_pos /*[n][3]*/,
+  const gpcc_lod_params* lp, const voxel_t* pv, int32_t n, const int32_t* bias_pos_in /*[n][3]*/,
   const int32_t* retained, int n_ret, int32_t* indexes /* in: packed idx, out: point idx */,
   int start, int end, int lod_index, raw_pred_t* preds, int32_t* pt2pred,
   int* pred_index)
 {
-  const int shift_bits = 1 + lp->dist2 + lp->attr_dist2_delta + lod_index;
+  /* scalable lifting (:1174-1176, :1232-1236, clacIntermediatePosition :925-940): the
+   * search cells are those of the octree level, and every position is replaced by the
+   * corner of its node at that level before the bias is applied */
+  const int scalable = lp->scalable_lifting_enabled_flag != 0;
+  const int shift_bits =
+    scalable ? 1 + lod_index : 1 + lp->dist2 + lp->attr_dist2_delta + lod_index;
+  const uint32_t node_mask = scalable && lod_index ? (uint32_t)(-1) << lod_index : (uint32_t)(-1);
+  int32_t* bias_pos_lod = NULL;
+  if (scalable && lod_index) {
+    bias_pos_lod = (int32_t*)malloc(sizeof(int32_t) * 3 * (size_t)n);
+    for (int i = 0; i < n; i++)
+      for (int d = 0; d < 3; d++)
+        bias_pos_lod[3 * i + d] =
+          (int32_t)((uint32_t)pv[i].pos[d] & node_mask) * lp->lod_neigh_bias[d];
+  }
+  const int32_t* bias_pos = bias_pos_lod ? bias_pos_lod : bias_pos_in;
   const int shift3 = 3 * shift_bits;
   const int boundary = min_i(63, shift3 + kAtlasBits);
   const int distribution = lp->prediction_with_distribution_enabled != 0;
@@ -664,6 +683,30 @@ compute_nearest_neighbours(
       pr->pidx[h] = pv[s.idx[h]].index;
       pr->w[h] = (uint64_t)norm2(&bias_pos[3 * s.idx[h]], bp);
     }
+    /* scalable lifting: neighbours further than the range are dropped, and all
+     * that follow them (:1918-1939, pruneDistanceGt :695-703) */
+    if (scalable) {
+      const int64_t max_dist = (3ll * (lp->max_neigh_range_minus1 + 1)) << (2 * lod_index);
+      const int unit_bias =
+        lp->lod_neigh_bias[0] == 1 && lp->lod_neigh_bias[1] == 1 && lp->lod_neigh_bias[2] == 1;
+      for (int h = 1; h < count; h++) {
+        int64_t d2;
+        if (unit_bias)
+          d2 = (int64_t)pr->w[h];
+        else {
+          d2 = 0;
+          for (int d = 0; d < 3; d++) {
+            const int64_t a = (int64_t)(int32_t)((uint32_t)pv[index].pos[d] & node_mask)
+              - (int64_t)(int32_t)((uint32_t)pv[s.idx[h]].pos[d] & node_mask);
+            d2 += a * a;
+          }
+        }
+        if (d2 > max_dist) {
+          pr->count = count = h;
+          break;
+        }
+      }
+    }
     /* order by weight (:1941-1951) */
     if (count > 1) {
 #define SWAP_PRED(a, b)                                                      \
@@ -686,6 +729,7 @@ compute_nearest_neighbours(
     }
   }
   free(packed);
+  free(bias_pos_lod);
   free(bret);
   bbox_free(&hb);
   if (intra) {
@@ -704,8 +748,6 @@ oracle_lod_generate(
   int32_t* neigh_count, int32_t* neigh_index, uint64_t* weight64,
   int32_t* indexes_out, int32_t* num_points_in_lod, int32_t* num_lods)
 {
-  if (lp->scalable_lifting_enabled_flag)
-    return -2; /* not restated */
   voxel_t* pv = (voxel_t*)malloc(sizeof(voxel_t) * (size_t)n);
   for (int i = 0; i < n; i++) {
     pv[i].code = morton_addr(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
@@ -740,27 +782,49 @@ oracle_lod_generate(
   int32_t npl[GPCC_MAX_LODS + 2];
   int nl = 0;
   npl[nl++] = n;
-  const int max_levels = lp->num_detail_levels_minus1 + 1;
+  /* AttributeParameterSet::maxNumDetailLevels hls.h:835-839 */
+  const int max_levels = lp->scalable_lifting_enabled_flag ? 21 : lp->num_detail_levels_minus1 + 1;
+  /* scalable lifting (:2377-2380, :2416-2448; whole slices only: minGeomNodeSizeLog2 = 0 and
+   * no skipped points): while a new refinement layer is larger than all the finer ones
+   * together, the finer layers are searched AGAIN, against the new (coarser) retained set */
+  int concatenate = lp->scalable_lifting_enabled_flag != 0;
+  int32_t* packed_of_layers = concatenate ? (int32_t*)malloc(sizeof(int32_t) * (size_t)n) : NULL;
   for (int lod = 0; n_in > 0 && lod < max_levels; lod++) {
     const int start = n_idx;
     int n_ret = 0;
     if (lod == max_levels - 1) {
       for (int i = 0; i < n_in; i++)
         indexes[n_idx++] = input[i];
+    } else if (lp->scalable_lifting_enabled_flag) {
+      /* subsample :2230-2235: octree level = LoD index, the direction alternates */
+      subsample_by_octree(pv, input, n_in, lod, 0, lod & 1, retained, &n_ret, indexes, &n_idx);
     } else if (lp->lod_decimation_type == 1) {
       subsample_by_decimation(
         input, n_in, lp->lod_sampling_period[lod], retained, &n_ret, indexes, &n_idx);
     } else if (lp->lod_decimation_type == 2) {
       subsample_by_octree(
         pv, input, n_in, lp->dist2 + lp->attr_dist2_delta + lod,
-        lp->lod_sampling_period[lod], retained, &n_ret, indexes, &n_idx);
+        lp->lod_sampling_period[lod], 1, retained, &n_ret, indexes, &n_idx);
     } else {
       subsample_by_distance(
         pv, input, n_in, lp->dist2 + lp->attr_dist2_delta + lod, retained, &n_ret,
         indexes, &n_idx);
     }
+    if (concatenate && start != n_idx) {
+      memcpy(&packed_of_layers[start], &indexes[start], sizeof(int32_t) * (size_t)(n_idx - start));
+      if (n_idx - start <= start)
+        concatenate = 0;
+      else {
+        memcpy(indexes, packed_of_layers, sizeof(int32_t) * (size_t)start);
+        pred_index = n;
+        for (int l = 0; l < lod; l++)
+          compute_nearest_neighbours(
+            lp, pv, n, bias_pos, retained, n_ret, indexes, n - npl[l], n - npl[l + 1], l, preds,
+            pt2pred, &pred_index);
+      }
+    }
     compute_nearest_neighbours(
-      lp, pv, bias_pos, retained, n_ret, indexes, start, n_idx, lod, preds, pt2pred,
+      lp, pv, n, bias_pos, retained, n_ret, indexes, start, n_idx, lod, preds, pt2pred,
       &pred_index);
     if (n_ret && nl < GPCC_MAX_LODS + 1)
       npl[nl++] = n_ret;
@@ -824,6 +888,7 @@ oracle_lod_generate(
     }
   }
   free(pv);
+  free(packed_of_layers);
   free(bias_pos);
   free(input);
   free(retained);

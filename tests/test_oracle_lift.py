@@ -117,3 +117,33 @@ def test_lift_oracle_vs_committed_golden():
         nc2, w2 = lh.compute_weights(ol.oracle(), g[name + "/nc_raw"], g[name + "/dist2"])
         np.testing.assert_array_equal(nc2, g[name + "/nc"])
         np.testing.assert_array_equal(w2.astype(np.int32), g[name + "/w"])
+
+
+@_mark
+@pytest.mark.parametrize("rng", [0, 5])
+def test_scalable_lifting_oracle_gives_the_reference_operator_bitstream(rng):
+    """aps.scalable_lifting_enabled_flag: the oracle's LoD structure and lifting (quantisation weights by
+    level of detail, computeQuantizationWeightsScalable) -> zero runs -> the reference's arithmetic coder
+    = the payload the reference operator writes; reconstruction equal, and the inverse returns it."""
+    from mpeg_pcc_tmc13_amd import lift_params, lod_params, raht_params, synth
+    if not lh.entropy_available():
+        pytest.skip("entropy harness absent")
+    o = ol.oracle()
+    cases = [synth.dense_cloud(8000, seed=61, bits=7), synth.lidar_cloud(9000, seed=61),
+             synth.random_cloud(3000, seed=2, bits=5), synth.random_cloud(2, seed=1, bits=3)]
+    for xyz, attrs in cases:
+        c = attrs.shape[1]
+        bitdepth = 8 if c == 3 else 16
+        lp = lod_params()
+        lp.scalable_lifting_enabled_flag = 1
+        lp.max_neigh_range_minus1 = rng
+        payload, rec_enc, rec_dec = lh.ref_operator_roundtrip(lp, 2, raht_params(), 34, 0, bitdepth, c == 3, xyz, attrs)
+        np.testing.assert_array_equal(rec_enc, rec_dec)
+        lod = lh.oracle_lod_generate(xyz, lp)
+        lf = lift_params(lod["npl"], qp=34, chroma_offset=0, lcp=(c == 3), bitdepth=bitdepth, scalable=True)
+        co, rec, lcp = lh.lift(o, True, lf, lod, attrs)
+        np.testing.assert_array_equal(rec, rec_enc)
+        runs, vals, trailing = lh.oracle_zero_run_pack(co, len(xyz), c, planar=False)
+        assert lh.ref_entropy_encode_symbols(c, len(xyz), runs, vals, trailing) == bytes(payload[lh.ref_last_abh_size():])
+        _, inv, _ = lh.lift(o, False, lf, lod, attrs, coeffs=co, lcp=lcp)
+        np.testing.assert_array_equal(inv, rec)
