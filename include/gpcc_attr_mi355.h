@@ -281,8 +281,17 @@ typedef struct gpcc_lod_params {
  * (PCCTMC3Common.h:2322-2331: the points taken as they come, or sorted in
  * chunks) are accepted when the points ARE in Morton order -- what the octree
  * geometry coder hands over; then neither changes the result.  Points in any
- * other order with those flags, scalable lifting and inter prediction return
- * GPCC_ERR_UNSUPPORTED (the shim keeps them on the reference path). */
+ * other order with those flags and inter prediction return
+ * GPCC_ERR_UNSUPPORTED (the shim keeps them on the reference path).
+ * scalable_lifting_enabled_flag (whole slices: minGeomNodeSizeLog2 = 0, no
+ * points skipped by a partial decode) builds the structure of
+ * PCCTMC3Common.h:2377-2448: always 21 levels, octree sub-sampling by LoD
+ * index, node-corner positions in the search, neighbours beyond
+ * max_neigh_range_minus1 dropped, the finer layers searched again while a new
+ * layer outweighs them; num_detail_levels_minus1, lod_decimation_type, dist2
+ * and the sampling periods are then not read.  neigh_weight entries at and
+ * beyond neigh_count are unspecified then (the reference keeps the raw squared
+ * distance of a dropped neighbour in its slot; nothing reads it). */
 int gpcc_lod_build(
   gpcc_ctx* ctx, const gpcc_lod_params* params, const int32_t* xyz, int32_t n,
   int32_t* neigh_count, int32_t* neigh_index, int32_t* neigh_weight,

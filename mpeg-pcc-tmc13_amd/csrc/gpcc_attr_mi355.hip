@@ -43,6 +43,7 @@
 #include "cx_driver.hpp"
 #include "lift_kernels.hpp"
 #include "lod_kernels.hpp"
+#include "lod_scalable.hpp"
 #include "pred_kernels.hpp"
 #include "morton_sort.hpp"
 #include "residual_bins.hpp"
@@ -1154,9 +1155,12 @@ launch_lift(
   }
   {
     Timer t(ctx, "lift_quant_weights");
-    for (int l = p->num_lods - 1; l >= 1; l--)
-      if (npl[l] > npl[l - 1])
-        lift_quant_weights_kernel<<<grid(npl[l] - npl[l - 1]), 256, 0, st>>>(cx, npl[l - 1], npl[l]);
+    if (p->scalable_lifting_enabled_flag)
+      lift_quant_weights_scalable_kernel<<<grid(n), 256, 0, st>>>(cx);
+    else
+      for (int l = p->num_lods - 1; l >= 1; l--)
+        if (npl[l] > npl[l - 1])
+          lift_quant_weights_kernel<<<grid(npl[l] - npl[l - 1]), 256, 0, st>>>(cx, npl[l - 1], npl[l]);
   }
   if (encoder) {
     Timer t(ctx, "lift_forward");
@@ -2157,9 +2161,13 @@ lod_build_core(
     return fail(GPCC_ERR_INVALID_ARG, "null buffer or n <= 0");
   if (n > kMaxPoints)
     return fail(GPCC_ERR_INVALID_ARG, "more than 2^29 points per call");
-  if (lp->scalable_lifting_enabled_flag || lp->lod_decimation_type < 0 || lp->lod_decimation_type > 2)
-    return fail(GPCC_ERR_UNSUPPORTED, "scalable lifting stays on the reference CPU path");
-  const int max_levels = lp->num_detail_levels_minus1 + 1;
+  const bool scalable = lp->scalable_lifting_enabled_flag != 0;
+  if (!scalable && (lp->lod_decimation_type < 0 || lp->lod_decimation_type > 2))
+    return fail(GPCC_ERR_INVALID_ARG, "lod_decimation_type out of range");
+  if (scalable && (lp->max_neigh_range_minus1 < 0 || lp->max_neigh_range_minus1 > (1 << 20)))
+    return fail(GPCC_ERR_INVALID_ARG, "max_neigh_range_minus1 out of range");
+  // (scalable lifting: always 21 levels, hls.h:835-839 -- lod_scalable.hpp)
+  const int max_levels = scalable ? 21 : lp->num_detail_levels_minus1 + 1;
   if (max_levels < 1 || max_levels > GPCC_MAX_LODS - 1)
     return fail(GPCC_ERR_INVALID_ARG, "num_detail_levels out of range");
   int32_t mx = 0;
@@ -2183,7 +2191,7 @@ lod_build_core(
   const size_t sort_region = 32 * (size_t)n + ((size_t)1 << 20);
   {
     // 26 arrays, the largest 24 B per point (see the DM list below)
-    const size_t mine = (size_t)n * 232 + 64 * 1024;
+    const size_t mine = (size_t)n * (scalable ? 244 : 232) + 64 * 1024;
     int rc0 = ensure_arena(ctx, sort_region + mine + extra_bytes);
     if (rc0)
       return rc0;
@@ -2232,6 +2240,7 @@ lod_build_core(
     DM(int32_t, d_indexes, N)
     DM(int32_t, d_neigh_index, 3 * N)
     DM(int32_t, d_weight, 3 * N)
+    DM(int32_t, d_bpos_lod, scalable ? 3 * N : 1)
 #undef DM
     int32_t* d_ticket = d_small;
     int32_t* d_error = d_small + 8;
@@ -2325,6 +2334,40 @@ lod_build_core(
     int32_t* d_input = d_list_a;
     int32_t* d_ret = d_list_b;
     int n_in = n, n_idx = 0;
+    if (scalable) {
+      // its own level loop (lod_scalable.hpp), same kernels
+      LodWork w{};
+      w.n = n;
+      w.code = d_code;
+      w.order = d_order;
+      w.pos = d_pos;
+      w.bpos = d_bpos;
+      w.bpos_lod = d_bpos_lod;
+      w.list_a = d_list_a;
+      w.list_b = d_list_b;
+      w.refine = d_refine;
+      w.flags = d_flags;
+      w.heads = d_heads;
+      w.nxt0 = d_cell_first;
+      w.nj0 = d_positions;
+      w.nj1 = d_cent_tmp;
+      w.ret_key = d_ret_key;
+      w.counts = d_counts;
+      w.scan = d_scan;
+      w.atlas_limit = d_atlas_limit;
+      for (int l = 0; l < 2; l++)
+        for (int lev = 0; lev < 3; lev++)
+          for (int m = 0; m < 2; m++)
+            w.box[l][lev][m] = box[l][lev][m];
+      w.pred_count = d_pred_count;
+      w.pred_point = d_pred_point;
+      w.pred_dist2 = d_pred_dist2;
+      w.pt2pred = d_pt2pred;
+      w.indexes = d_indexes;
+      Timer tm(ctx, "lod_scalable_levels");
+      HIP_TRY(lod_scalable_levels(lp, w, st, &npl, &scan_epoch));
+      n_in = 0;  // the loop below has nothing left to do
+    }
     for (int lod = 0; n_in > 0 && lod < max_levels; lod++) {
       const int start = n_idx;
       int n_ret = 0, n_ref = 0;
@@ -2364,7 +2407,7 @@ lod_build_core(
             cur = nj[r & 1];
           }
           lod_centroid_pick_kernel<<<grid_for(n_in, 256), 256, 0, st>>>(
-            lc, shift_bits0, nxt0, d_heads);
+            lc, shift_bits0, nxt0, d_heads, 1);
         } else {
           LodCtx lc{};
           lc.n = n;
@@ -2462,7 +2505,7 @@ lod_build_core(
           }
         {
           Timer tm(ctx, level_name("lod_nn_search", lod));
-          lod_nn_search_kernel<<<grid_for(n_ref, 256), 256, 0, st>>>(nc);
+          lod_nn_search_kernel<false><<<grid_for(n_ref, 256), 256, 0, st>>>(nc);
         }
       }
       if (n_ret > 0)
@@ -2547,6 +2590,8 @@ pred_attr_driver(
   const size_t N = (size_t)(n > 0 ? n : 0);
   const size_t extra = ((N * c * sizeof(int32_t) + 255) & ~size_t(255)) * 2 + 512
     + pred_scratch_bytes(n > 0 ? n : 1) + 1024;
+  if (lod && lod->scalable_lifting_enabled_flag)
+    return fail(GPCC_ERR_UNSUPPORTED, "the predicting transform over a scalable LoD structure stays on the reference CPU path");
   LodDeviceOut o;
   int r = lod_build_core(ctx, lod, xyz, n, extra, &o);
   if (r)
@@ -2624,6 +2669,7 @@ lift_attr_driver(
   int r = lod_build_core(ctx, lod, xyz, n, extra, &o);
   if (r)
     return r;
+  lift->scalable_lifting_enabled_flag = lod->scalable_lifting_enabled_flag != 0;
   lift->num_lods = (int)o.npl.size();
   for (size_t i = 0; i < o.npl.size(); i++)
     lift->num_points_in_lod[i] = o.npl[i];
@@ -3432,6 +3478,7 @@ dev_lift_attr(
     r = lod_build_core(lane, lod, d_xyz + 3 * b, n, extra, &o, true);
     if (r)
       return r;
+    lf->scalable_lifting_enabled_flag = lod->scalable_lifting_enabled_flag != 0;
     lf->num_lods = (int)o.npl.size();
     for (size_t i = 0; i < o.npl.size(); i++)
       lf->num_points_in_lod[i] = o.npl[i];
@@ -3495,6 +3542,8 @@ dev_pred_attr(
     const size_t b = (size_t)offsets[s], N = (size_t)(offsets[s + 1] - offsets[s]);
     const int32_t n = (int32_t)N;
     const size_t extra = 1024 + pred_scratch_bytes(n) + 1024;
+    if (lod && lod->scalable_lifting_enabled_flag)
+      return fail(GPCC_ERR_UNSUPPORTED, "the predicting transform over a scalable LoD structure stays on the reference CPU path");
     LodDeviceOut o;
     int r = lod_build_core(lane, lod, d_xyz + 3 * b, n, extra, &o, true);
     if (r)

@@ -183,6 +183,21 @@ lift_quant_weights_kernel(LiftCtx cx, int start, int end)
   }
 }
 
+// computeQuantizationWeightsScalable (PCCTMC3Common.h:858-891), whole slices:
+// numPoints / (points up to and including the predictor's level), the finest
+// level 1
+__global__ __launch_bounds__(256) void
+lift_quant_weights_scalable_kernel(LiftCtx cx)
+{
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cx.n;
+       i += gridDim.x * blockDim.x) {
+    int l = 0;
+    while (l < cx.num_lods - 1 && cx.npl[l] <= i)
+      l++;
+    cx.qw[i] = l == cx.num_lods - 1 ? 256ull : (unsigned long long)(cx.n / cx.npl[l]) << 8;
+  }
+}
+
 template<int C>
 __global__ __launch_bounds__(256) void
 lift_predict_kernel(LiftCtx cx, int start, int end, int direct)

@@ -23,7 +23,9 @@
 #pragma once
 
 #include "raht_common.hpp"
+#ifndef GPCC_EMU  // (tests/emu: the buffer-resource builtins have no CPU counterpart)
 #include "raht_subnode.hpp"
+#endif
 #include "lift_kernels.hpp"
 
 namespace gpcc {
@@ -93,6 +95,19 @@ lod_gather_pos_kernel(
     bpos[3 * (size_t)i + 1] = y * b1;
     bpos[3 * (size_t)i + 2] = z * b2;
     list[i] = i;
+  }
+}
+
+// scalable lifting: the search of LoD `l` sees every point at the corner of its
+// octree node of size 2^l (clacIntermediatePosition :925-940), then biased
+__global__ __launch_bounds__(256) void
+lod_node_corner_bpos_kernel(
+  int n, const int32_t* __restrict__ pos, uint32_t mask, int b0, int b1, int b2, int32_t* bpos)
+{
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    bpos[3 * (size_t)i] = (int32_t)((uint32_t)pos[3 * (size_t)i] & mask) * b0;
+    bpos[3 * (size_t)i + 1] = (int32_t)((uint32_t)pos[3 * (size_t)i + 1] & mask) * b1;
+    bpos[3 * (size_t)i + 2] = (int32_t)((uint32_t)pos[3 * (size_t)i + 2] & mask) * b2;
   }
 }
 
@@ -230,11 +245,13 @@ lod_centroid_jump_kernel(
   }
 }
 
-// one thread per group: centroid, nearest member (ties: the last one), flags
+// one thread per group: centroid, nearest member (ties: the first one met walking
+// from the back -- lodDecimator 2 and the odd levels of scalable lifting -- or
+// from the front -- its even levels, subsample :2230-2235), flags
 __global__ __launch_bounds__(256) void
 lod_centroid_pick_kernel(
   LodCtx cx, int node_log2, const int32_t* __restrict__ nxt0,
-  const uint8_t* __restrict__ mark)
+  const uint8_t* __restrict__ mark, int backward)
 {
   const uint32_t mask = node_log2 ? 0xffffffffu << node_log2 : 0xffffffffu;
   for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < cx.n_in;
@@ -250,9 +267,10 @@ lod_centroid_pick_kernel(
       for (int d = 0; d < 3; d++)
         cen[d] += (uint32_t)cx.pos[3 * (size_t)idx + d] & mask;
     }
-    int best = e - 1;
+    int best = backward ? e - 1 : g;
     int64_t best_m = INT64_MAX;
-    for (int v = e - 1; v >= g; v--) {
+    for (int w = 0; w < nv; w++) {
+      const int v = backward ? e - 1 - w : g + w;
       const int idx = cx.input[v];
       int64_t m = 0;
 #pragma unroll
@@ -307,6 +325,7 @@ lod_cell_keys_kernel(LodCtx cx)
 // neighbour is folded into a bit mask of eliminated points at once and nothing
 // else is kept of it (no per-lane neighbour lists in LDS; 168 registers, three
 // waves per SIMD -- at four the prologue's 19 lock-step bisections spill).
+#ifndef GPCC_EMU
 #ifndef GPCC_LOD_SUB_WAVES
 #define GPCC_LOD_SUB_WAVES 3
 #endif
@@ -623,6 +642,7 @@ lod_subsample_distance_kernel(LodCtx cx)
     }
   }
 }
+#endif  // GPCC_EMU
 
 // ---- nearest-neighbour search ----------------------------------------------
 struct NnCtx {
@@ -647,6 +667,12 @@ struct NnCtx {
   uint64_t* pred_dist2;      // [n][3]
   int32_t* pt2pred;          // [n]
   int32_t* indexes;          // [n] predictor order -> point index
+  // scalable lifting only (lod_nn_search_kernel<true>): neighbours beyond the
+  // range are dropped with all that follow (:1918-1939)
+  const int32_t* pos;        // [n][3] positions, sorted order
+  uint32_t node_mask;        // clears the bits below the octree level of this LoD
+  int32_t unit_bias;         // lodNeighBias == 1: the squared distances ARE the test values
+  int64_t prune_dist;        // 3 * (max_neigh_range_minus1 + 1) << 2 * lod
 };
 
 struct NnState {
@@ -917,6 +943,7 @@ lod_atlas_limit_kernel(NnCtx cx, long long* atlas_limit)
 #ifndef GPCC_NN_WAVES
 #define GPCC_NN_WAVES 4
 #endif
+template<bool SCALABLE>
 __global__ __launch_bounds__(256, GPCC_NN_WAVES) void
 lod_nn_search_kernel(NnCtx cx)
 {
@@ -1117,6 +1144,28 @@ lod_nn_search_kernel(NnCtx cx)
     for (int h = 0; h < count; h++) {
       pp[h] = cx.order[s.idx[h]];
       pw[h] = (uint64_t)norm2_i3(&cx.bpos[3 * (size_t)s.idx[h]], bp);
+    }
+    if (SCALABLE) {
+      bool cut = false;
+#pragma unroll
+      for (int h = 1; h < 3; h++) {
+        if (h >= count || cut)
+          continue;
+        int64_t d2 = (int64_t)pw[h];
+        if (!cx.unit_bias) {
+          d2 = 0;
+#pragma unroll
+          for (int d = 0; d < 3; d++) {
+            const int64_t a = (int64_t)(int32_t)((uint32_t)cx.pos[3 * (size_t)index + d] & cx.node_mask)
+              - (int64_t)(int32_t)((uint32_t)cx.pos[3 * (size_t)s.idx[h] + d] & cx.node_mask);
+            d2 += a * a;
+          }
+        }
+        if (d2 > cx.prune_dist) {
+          count = h;
+          cut = true;
+        }
+      }
     }
     if (count > 1) {
       if (pw[0] > pw[1]) {

@@ -48,7 +48,10 @@ public:
     const bool ours = aps.attr_encoding == AttributeEncoding::kLiftingTransform
       || aps.attr_encoding == AttributeEncoding::kPredictingTransform;
     if (ours) {
-      if (on_device(sps, desc, aps, abh, minGeomNodeSizeLog2, payload, payloadLen, ctxtMem, cloud, inter)) {
+      // (scalable lifting: whole slices only -- no points skipped by a partial decode)
+      const bool whole =
+        !aps.scalable_lifting_enabled_flag || geom_num_points_minus1 + 1 == int(cloud.getPointCount());
+      if (whole && on_device(sps, desc, aps, abh, minGeomNodeSizeLog2, payload, payloadLen, ctxtMem, cloud, inter)) {
         g_dec_device++;
         return;
       }

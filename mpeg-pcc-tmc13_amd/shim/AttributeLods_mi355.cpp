@@ -13,7 +13,7 @@
 // AttributeLods::generate with the original signature.  The LoD fields of
 // the APS / ABH are flattened into gpcc_lod_params, the build runs on the
 // MI355X through the C ABI and the public vectors are filled; whenever the
-// device path declines (no GPU, inter prediction, scalable lifting, ...) the renamed reference body runs instead.
+// device path declines (no GPU, inter prediction, a partially decoded scalable slice, ...) the renamed reference body runs instead.
 //
 // Built against the reference's headers; contains no reference code.
 #include <vector>
@@ -43,7 +43,9 @@ AttributeLods::generate(
   gpcc_lod_params lp;
   gpcc_ctx* ctx = gpcc_shim::process_context("the LoD build");
   const int n = int(cloud.getPointCount());
-  if (ctx && n > 0 && gpcc_shim::flatten_lod(aps, abh, minGeomNodeSizeLog2, attrInterPredParams, &lp)) {
+  // (scalable lifting: whole slices only -- no points skipped by a partial decode)
+  const bool whole = !aps.scalable_lifting_enabled_flag || geom_num_points_minus1 + 1 == n;
+  if (ctx && n > 0 && whole && gpcc_shim::flatten_lod(aps, abh, minGeomNodeSizeLog2, attrInterPredParams, &lp)) {
     std::vector<int32_t> xyz;
     gpcc_shim::positions_of(cloud, &xyz);
     std::vector<int32_t> nc(n), ni(size_t(n) * 3), nw(size_t(n) * 3), idx(n);

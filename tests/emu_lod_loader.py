@@ -1,0 +1,50 @@
+"""ctypes loader of tests/emu/liblod_emu.so (TEST INFRASTRUCTURE): the scalable-lifting LoD build
+of the library (lod_scalable.hpp + lod_kernels.hpp) compiled for the CPU wavefront emulator."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU_DIR = os.path.join(ROOT, "tests", "emu")
+
+_i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        subprocess.run(["make", "-s", "-C", EMU_DIR, "liblod_emu.so"], check=True, stdout=subprocess.DEVNULL)
+        _lib = C.CDLL(os.path.join(EMU_DIR, "liblod_emu.so"))
+        _lib.lod_emu_scalable_build.argtypes = [C.c_void_p, _i32p, C.c_int32, _i32p, _i32p, _i32p, _i32p, _i32p,
+                                                C.POINTER(C.c_int32)]
+        _lib.lod_emu_scalable_build.restype = C.c_int
+    return _lib
+
+
+def scalable_build(lp, xyz):
+    """-> dict as lod_helpers.oracle_lod_generate (weights int32)"""
+    xyz = np.ascontiguousarray(xyz, dtype=np.int32)
+    n = len(xyz)
+    nc = np.zeros(n, np.int32)
+    ni = np.zeros((n, 3), np.int32)
+    w = np.zeros((n, 3), np.int32)
+    idx = np.zeros(n, np.int32)
+    npl = np.zeros(32, np.int32)
+    nl = C.c_int32()
+    rc = lib().lod_emu_scalable_build(C.addressof(lp), xyz.reshape(-1), n, nc, ni.reshape(-1), w.reshape(-1), idx, npl,
+                                      C.byref(nl))
+    assert rc == 0, rc
+    return dict(nc=nc, ni=ni, w=w, indexes=idx, npl=npl[:nl.value].copy())
+
+
+def assert_same_lod(got, want, msg=""):
+    """LoD structures equal; weights compared for the neighbours that exist (under scalable lifting the
+    reference leaves the raw squared distance of a pruned neighbour in its slot, nobody reads it)"""
+    for k in ("npl", "indexes", "nc", "ni"):
+        np.testing.assert_array_equal(got[k], want[k], err_msg=f"{msg} {k}")
+    live = np.arange(3)[None, :] < np.asarray(want["nc"])[:, None]
+    np.testing.assert_array_equal(np.asarray(got["w"]).astype(np.uint64)[live], np.asarray(want["w"]).astype(np.uint64)[live],
+                                  err_msg=f"{msg} w")

@@ -31,6 +31,9 @@ def make_case(case):
     rp = raht_params(qp=case["qp"], chroma_offset=case["chroma"], subnode=bool(case["subnode"]),
                      haar=bool(case.get("haar", 0)), search_range=case["search_range"])
     lp = lod_params(lifting=case["transform"] == 2) if case["transform"] else lod_params()
+    if case.get("scalable"):
+        lp.scalable_lifting_enabled_flag = 1
+        lp.max_neigh_range_minus1 = case.get("neigh_range", 5)
     return xyz, attrs, rp, lp
 
 

@@ -110,3 +110,42 @@ def test_lift_attr_driver_matches_composition(kind, n, kw, ctx):
     o_co, o_rec, _ = lh.lift(ol.oracle(), True, lf, o, attrs)
     np.testing.assert_array_equal(co, o_co)
     np.testing.assert_array_equal(rec, o_rec)
+
+
+@pytest.mark.parametrize("kind,n", [("dense", 60000), ("lidar", 40000), ("random", 5), ("random", 1)])
+def test_scalable_lifting_attr_driver_vs_oracle(kind, n, ctx):
+    """aps.scalable_lifting_enabled_flag through the one-call entries: the LoD structure of
+    lod_scalable.hpp and the quantisation weights by level of detail
+    (computeQuantizationWeightsScalable) == the oracle, which gives the reference operator's
+    payload byte for byte (tests/test_oracle_lift.py); the decoder returns the reconstruction."""
+    from mpeg_pcc_tmc13_amd import lift_params, lod_params, synth
+    if kind == "dense":
+        xyz, attrs = synth.dense_cloud(n, seed=52, bits=9)
+    elif kind == "lidar":
+        xyz, attrs = synth.lidar_cloud(n, seed=52)
+    else:
+        xyz, attrs = synth.random_cloud(n, seed=52, bits=3)
+    c = attrs.shape[1]
+    lp = lod_params()
+    lp.scalable_lifting_enabled_flag = 1
+    lp.max_neigh_range_minus1 = 5
+    o = lh.oracle_lod_generate(xyz, lp)
+    lf = lift_params(o["npl"], qp=34, lcp=(c == 3), scalable=True)
+    o_co, o_rec, o_lcp = lh.lift(ol.oracle(), True, lf, o, attrs)
+    lf2 = lift_params([len(xyz)], qp=34, lcp=(c == 3))   # LoD sizes and the scalable flag come from the call
+    co, rec, lcp, idx = ctx.lift_encode_attr(lp, lf2, xyz, attrs)
+    assert lf2.scalable_lifting_enabled_flag == 1
+    assert list(lf2.num_points_in_lod[:lf2.num_lods]) == list(o["npl"])
+    np.testing.assert_array_equal(idx, o["indexes"])
+    np.testing.assert_array_equal(co, o_co)
+    np.testing.assert_array_equal(rec, o_rec)
+    if c == 3:
+        np.testing.assert_array_equal(np.asarray(lcp)[:len(o["npl"])], o_lcp[:len(o["npl"])])
+    lf3 = lift_params([len(xyz)], qp=34, lcp=(c == 3))
+    dec = ctx.lift_decode_attr(lp, lf3, xyz, co, lcp)
+    np.testing.assert_array_equal(dec, rec)
+    # the two-call form: structure out, lifting with the flag set by the caller
+    g = ctx.lod_build(lp, xyz)
+    co2, rec2, _ = ctx.lift_forward(lf, g["nc"], g["ni"], g["w"], g["indexes"], attrs)
+    np.testing.assert_array_equal(co2, o_co)
+    np.testing.assert_array_equal(rec2, o_rec)

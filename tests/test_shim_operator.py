@@ -33,6 +33,8 @@ CASES = {
     "raht_colour_sub0": dict(cloud="dense", n=60_000, seed=6, transform=0, qp=40, chroma=-1, subnode=0, search_range=50000),
     "raht_haar_lossless": dict(cloud="dense", n=50_000, seed=7, transform=0, qp=4, chroma=0, subnode=1, haar=1, search_range=50000),
     "lifting_colour_100k": dict(cloud="dense", n=100_000, seed=8, transform=2, qp=34, chroma=-1, subnode=1, search_range=50000),
+    "lifting_scalable_colour_60k": dict(cloud="dense", n=60_000, seed=10, transform=2, qp=34, chroma=-1, subnode=1, search_range=50000,
+                                        scalable=1),
 }
 
 
@@ -104,6 +106,10 @@ needs3 = pytest.mark.skipif(not (os.path.exists(SHIM3) and ol.ref_available()), 
 CASES3 = {
     "lifting_colour_100k": dict(cloud="dense", n=100_000, seed=8, transform=2, qp=34, chroma=-1, subnode=1, search_range=50000),
     "lifting_refl_lidar_60k": dict(cloud="lidar", n=60_000, seed=9, transform=2, qp=28, chroma=0, subnode=1, search_range=2500),
+    "lifting_scalable_colour_60k": dict(cloud="dense", n=60_000, seed=10, transform=2, qp=34, chroma=-1, subnode=1, search_range=50000,
+                                        scalable=1),
+    "lifting_scalable_refl_lidar_40k": dict(cloud="lidar", n=40_000, seed=11, transform=2, qp=28, chroma=0, subnode=1, search_range=2500,
+                                            scalable=1, neigh_range=20),
     "pred_dense_ctc": dict(transform=1, pred_case="dense_ctc"),
     "pred_lidar_refl_ctc": dict(transform=1, pred_case="lidar_refl_ctc"),
     "pred_dense_nodirect_qnw": dict(transform=1, pred_case="dense_nodirect_qnw"),
