@@ -109,12 +109,18 @@ def test_lod_then_lift_end_to_end(ctx):
 def test_lod_unsupported_modes(ctx):
     from mpeg_pcc_tmc13_amd import lod_params
     from mpeg_pcc_tmc13_amd._lib import GpccError
-    xyz = np.zeros((4, 3), np.int32)
-    lp = lod_params()
-    lp.scalable_lifting_enabled_flag = 1
+    from mpeg_pcc_tmc13_amd import pred_params, synth
+    xyz, attrs = synth.random_cloud(50, seed=3, bits=4)
+    lp = lod_params(lifting=False)
+    lp.scalable_lifting_enabled_flag = 1   # the LoD structure is built, the predicting transform over it is not
+    ctx.lod_build(lp, xyz)
+    with pytest.raises(GpccError) as ei:
+        ctx.pred_encode_attr(lp, pred_params([len(xyz)], qp=34, chroma_offset=0, bitdepth=8), xyz, attrs)
+    assert ei.value.code == -2  # GPCC_ERR_UNSUPPORTED: the shim keeps the reference CPU path
+    lp.max_neigh_range_minus1 = -1
     with pytest.raises(GpccError) as ei:
         ctx.lod_build(lp, xyz)
-    assert ei.value.code == -2  # GPCC_ERR_UNSUPPORTED: the shim keeps the reference CPU path
+    assert ei.value.code == -1  # GPCC_ERR_INVALID_ARG
 
 
 def test_device_tier_lod_and_lifting_equal_host_tier():
@@ -204,7 +210,7 @@ def test_device_tier_concurrent_lanes_many_ragged_slices():
             np.testing.assert_array_equal(w3[3 * a:3 * b].reshape(-1, 3), g["w"])
             np.testing.assert_array_equal(indexes[a:b], g["indexes"])
     bad = lod_params()
-    bad.scalable_lifting_enabled_flag = 1
+    bad.canonical_point_order_flag = 1   # the points are not in Morton order
     with pytest.raises(_lib.GpccError) as e:
         ctx.dev_lod_build(bad, offsets, d_xyz.data_ptr(), *[t.data_ptr() for t in outs])
     assert e.value.code == -2

@@ -149,9 +149,9 @@ def test_lod_coders_failed_slice_fails_the_call():
     xyz, attrs = synth.dense_cloud(4000, seed=3, bits=6)
     offsets = np.array([0, 1500, 4000], dtype=np.int64)
     lp = lod_params(levels=8)
-    lp.scalable_lifting_enabled_flag = 1  # declined by the device path
+    lp.canonical_point_order_flag = 1  # the points are not in Morton order: declined by the device path
     mc = MultiContext([0, 0])
     with pytest.raises(GpccError) as e:
         mc.lod_encode_attr(False, lp, [lift_params([0]), lift_params([0])], offsets, xyz, attrs)
-    assert "scalable" in str(e.value)
+    assert "Morton order" in str(e.value)
     mc.close()
