@@ -389,6 +389,10 @@ typedef struct gpcc_pred_params {
   int32_t quant_neigh_weight[3];
   int32_t max_num_detail_levels;         /* aps.maxNumDetailLevels(): icp_coeffs
                                           * beyond it are zero */
+  int32_t scalable_lifting_enabled_flag; /* quantisation weights by level of detail
+                                          * (computeQuantizationWeightsScalable,
+                                          * PCCTMC3Common.h:858-891; whole slices) instead
+                                          * of quant_neigh_weight */
 } gpcc_pred_params;
 
 /* Replaces decodeColorsPred / decodeReflectancesPred after the entropy decode

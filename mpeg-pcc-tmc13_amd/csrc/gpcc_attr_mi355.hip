@@ -1155,9 +1155,13 @@ launch_lift(
   }
   {
     Timer t(ctx, "lift_quant_weights");
-    if (p->scalable_lifting_enabled_flag)
-      lift_quant_weights_scalable_kernel<<<grid(n), 256, 0, st>>>(cx);
-    else
+    if (p->scalable_lifting_enabled_flag) {
+      LodSizes t{};
+      t.num_lods = p->num_lods;
+      for (int l = 0; l < p->num_lods; l++)
+        t.npl[l] = p->num_points_in_lod[l];
+      quant_weights_scalable_kernel<<<grid(n), 256, 0, st>>>(n, t, cx.qw);
+    } else
       for (int l = p->num_lods - 1; l >= 1; l--)
         if (npl[l] > npl[l - 1])
           lift_quant_weights_kernel<<<grid(npl[l] - npl[l - 1]), 256, 0, st>>>(cx, npl[l - 1], npl[l]);
@@ -1487,7 +1491,15 @@ launch_pred(
     Timer t(ctx, "pred_indegree");
     pred_indegree_kernel<<<grid(n), 256, 0, st>>>(cx);
   }
-  if (cx.qnw[0] || cx.qnw[1] || cx.qnw[2]) {
+  if (p->scalable_lifting_enabled_flag) {
+    // computeQuantizationWeightsScalable: by level of detail, quant_neigh_weight is not read
+    Timer tm(ctx, "pred_quant_weights");
+    LodSizes t{};
+    t.num_lods = p->num_lods;
+    for (int l = 0; l < p->num_lods; l++)
+      t.npl[l] = p->num_points_in_lod[l];
+    quant_weights_scalable_kernel<<<grid(n), 256, 0, st>>>(n, t, cx.qw);
+  } else if (cx.qnw[0] || cx.qnw[1] || cx.qnw[2]) {
     Timer t(ctx, "pred_quant_weights");
     pred_quant_weights_kernel<<<std::max(pgrid, 1), 256, 0, st>>>(cx);
   } else {
@@ -2590,12 +2602,11 @@ pred_attr_driver(
   const size_t N = (size_t)(n > 0 ? n : 0);
   const size_t extra = ((N * c * sizeof(int32_t) + 255) & ~size_t(255)) * 2 + 512
     + pred_scratch_bytes(n > 0 ? n : 1) + 1024;
-  if (lod && lod->scalable_lifting_enabled_flag)
-    return fail(GPCC_ERR_UNSUPPORTED, "the predicting transform over a scalable LoD structure stays on the reference CPU path");
   LodDeviceOut o;
   int r = lod_build_core(ctx, lod, xyz, n, extra, &o);
   if (r)
     return r;
+  pred->scalable_lifting_enabled_flag = lod->scalable_lifting_enabled_flag != 0;
   pred->num_lods = (int)o.npl.size();
   for (size_t i = 0; i < o.npl.size(); i++)
     pred->num_points_in_lod[i] = o.npl[i];
@@ -3542,12 +3553,11 @@ dev_pred_attr(
     const size_t b = (size_t)offsets[s], N = (size_t)(offsets[s + 1] - offsets[s]);
     const int32_t n = (int32_t)N;
     const size_t extra = 1024 + pred_scratch_bytes(n) + 1024;
-    if (lod && lod->scalable_lifting_enabled_flag)
-      return fail(GPCC_ERR_UNSUPPORTED, "the predicting transform over a scalable LoD structure stays on the reference CPU path");
     LodDeviceOut o;
     int r = lod_build_core(lane, lod, d_xyz + 3 * b, n, extra, &o, true);
     if (r)
       return r;
+    pp->scalable_lifting_enabled_flag = lod->scalable_lifting_enabled_flag != 0;
     pp->num_lods = (int)o.npl.size();
     for (size_t i = 0; i < o.npl.size(); i++)
       pp->num_points_in_lod[i] = o.npl[i];

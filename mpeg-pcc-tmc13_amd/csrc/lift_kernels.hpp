@@ -185,16 +185,20 @@ lift_quant_weights_kernel(LiftCtx cx, int start, int end)
 
 // computeQuantizationWeightsScalable (PCCTMC3Common.h:858-891), whole slices:
 // numPoints / (points up to and including the predictor's level), the finest
-// level 1
+// level 1.  Shared by the lifting and the predicting transform.
+struct LodSizes {
+  int32_t num_lods;
+  int32_t npl[GPCC_MAX_LODS];  // cumulative, coarse to fine
+};
+
 __global__ __launch_bounds__(256) void
-lift_quant_weights_scalable_kernel(LiftCtx cx)
+quant_weights_scalable_kernel(int n, LodSizes t, unsigned long long* qw)
 {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cx.n;
-       i += gridDim.x * blockDim.x) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     int l = 0;
-    while (l < cx.num_lods - 1 && cx.npl[l] <= i)
+    while (l < t.num_lods - 1 && t.npl[l] <= i)
       l++;
-    cx.qw[i] = l == cx.num_lods - 1 ? 256ull : (unsigned long long)(cx.n / cx.npl[l]) << 8;
+    qw[i] = l == t.num_lods - 1 ? 256ull : (unsigned long long)(n / t.npl[l]) << 8;
   }
 }
 

@@ -142,11 +142,12 @@ class PredParams(C.Structure):
         ("inter_component_prediction_enabled_flag", C.c_int32),
         ("quant_neigh_weight", C.c_int32 * 3),
         ("max_num_detail_levels", C.c_int32),
+        ("scalable_lifting_enabled_flag", C.c_int32),
     ]
 
 
 def pred_params(num_points_in_lod, qp=34, chroma_offset=0, bitdepth=8, direct=3, avg_disabled=False,
-                threshold=64, icp=True, quant_neigh_weight=(0, 0, 0), max_levels=None, layers=None):
+                threshold=64, icp=True, quant_neigh_weight=(0, 0, 0), max_levels=None, layers=None, scalable=False):
     """Effective values of cfg/octree-predt-ctc-lossless-geom-nearlossless-attrs.yaml
     (transformType 1): three direct predictors, adaptivePredictionThreshold 64
     (scaled by the bit depth, hls.h:808-811), inter-component prediction on."""
@@ -170,6 +171,7 @@ def pred_params(num_points_in_lod, qp=34, chroma_offset=0, bitdepth=8, direct=3,
     for k in range(3):
         p.quant_neigh_weight[k] = quant_neigh_weight[k]
     p.max_num_detail_levels = max_levels if max_levels is not None else max(len(npl), 1)
+    p.scalable_lifting_enabled_flag = int(scalable)
     return p
 
 

@@ -272,7 +272,18 @@ pred_process(
   uint64_t* qw = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)n);
   int32_t* rec = (int32_t*)calloc((size_t)n * c, sizeof(int32_t));  /* coding order */
   int32_t* src = (int32_t*)calloc((size_t)n * c, sizeof(int32_t));
-  oracle_pred_quant_weights(n, nc, ni, p->quant_neigh_weight, qw);
+  if (p->scalable_lifting_enabled_flag) {
+    /* computeQuantizationWeightsScalable (PCCTMC3Common.h:858-891), whole slices */
+    for (int i = 0; i < n; i++)
+      qw[i] = 1u << 8;
+    for (int l = 0; l < p->num_lods; l++) {
+      const int start = l ? p->num_points_in_lod[l - 1] : 0;
+      const uint64_t w = (uint64_t)(n / p->num_points_in_lod[l]) << 8;
+      for (int i = start; i < p->num_points_in_lod[l]; i++)
+        qw[i] = l == p->num_lods - 1 ? 1u << 8 : w;
+    }
+  } else
+    oracle_pred_quant_weights(n, nc, ni, p->quant_neigh_weight, qw);
   if (encoder)
     for (int i = 0; i < n; i++)
       for (int k = 0; k < c; k++)

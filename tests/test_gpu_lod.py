@@ -107,16 +107,16 @@ def test_lod_then_lift_end_to_end(ctx):
 
 
 def test_lod_unsupported_modes(ctx):
-    from mpeg_pcc_tmc13_amd import lod_params
+    from mpeg_pcc_tmc13_amd import lod_params, synth
     from mpeg_pcc_tmc13_amd._lib import GpccError
-    from mpeg_pcc_tmc13_amd import pred_params, synth
-    xyz, attrs = synth.random_cloud(50, seed=3, bits=4)
-    lp = lod_params(lifting=False)
-    lp.scalable_lifting_enabled_flag = 1   # the LoD structure is built, the predicting transform over it is not
-    ctx.lod_build(lp, xyz)
+    xyz, _ = synth.random_cloud(50, seed=3, bits=4)
+    lp = lod_params()
+    lp.canonical_point_order_flag = 1   # the points are not in Morton order
     with pytest.raises(GpccError) as ei:
-        ctx.pred_encode_attr(lp, pred_params([len(xyz)], qp=34, chroma_offset=0, bitdepth=8), xyz, attrs)
+        ctx.lod_build(lp, xyz)
     assert ei.value.code == -2  # GPCC_ERR_UNSUPPORTED: the shim keeps the reference CPU path
+    lp = lod_params()
+    lp.scalable_lifting_enabled_flag = 1
     lp.max_neigh_range_minus1 = -1
     with pytest.raises(GpccError) as ei:
         ctx.lod_build(lp, xyz)

@@ -40,6 +40,11 @@ CASES = {
     "lidar_refl_lods": ("lidar", 9000, 0, 34, {}, {}),
     "lidar_refl_direct2": ("lidar", 7000, 0, 16, {}, dict(direct=2)),
     "lidar_refl_direct1_dis": ("lidar", 7000, 0, 22, dict(levels=1), dict(direct=1, avg_disabled=True)),
+    # aps.scalable_lifting_enabled_flag: the LoD structure of PCCTMC3Common.h:2377-2448 and the
+    # quantisation weights by level of detail (computeQuantizationWeightsScalable)
+    "dense_scalable": ("dense", 9000, 7, 28, dict(scalable=5), {}),
+    "dense_scalable_nodirect": ("dense", 6000, 7, 40, dict(scalable=0), dict(direct=0)),
+    "lidar_refl_scalable": ("lidar", 8000, 0, 28, dict(scalable=20), dict(avg_disabled=True)),
     "random_sparse": ("random", 1500, 9, 34, {}, {}),
     "tiny": ("random", 3, 4, 34, {}, {}),
     "single": ("random", 1, 4, 34, {}, {}),
@@ -67,6 +72,11 @@ def make(name):
     lp.intra_lod_prediction_skip_layers = lo.get("skip", 0)
     thr = po.get("threshold", 64)
     po = {k: v for k, v in po.items() if k != "threshold"}
+    if "scalable" in lo:
+        lp.scalable_lifting_enabled_flag = 1
+        lp.max_neigh_range_minus1 = lo["scalable"]
+        lp.num_detail_levels_minus1 = 20   # not read by the build; aps.maxNumDetailLevels() is 21 then (hls.h:835-839)
+        po = dict(po, scalable=True)
     return xyz, attrs.astype(np.int32), lp, qp, bitdepth, thr, po
 
 

@@ -113,6 +113,7 @@ CASES3 = {
     "pred_dense_ctc": dict(transform=1, pred_case="dense_ctc"),
     "pred_lidar_refl_ctc": dict(transform=1, pred_case="lidar_refl_ctc"),
     "pred_dense_nodirect_qnw": dict(transform=1, pred_case="dense_nodirect_qnw"),
+    "pred_dense_scalable": dict(transform=1, pred_case="dense_scalable"),
     "raht_colour_sub0": dict(cloud="dense", n=60_000, seed=6, transform=0, qp=40, chroma=-1, subnode=0, search_range=50000),
 }
 
