@@ -66,15 +66,20 @@ round_shift8_u64(uint64_t x)
 }
 
 /* PCCComputeQuantizationWeights */
+/* inter prediction (xr != NULL): xr[3 i + j] marks a neighbour in the reference frame
+ * (PCCNeighborInfo::interFrameRef); it takes no share (:845-846) */
 static void
 quant_weights(
-  int n, const int32_t* nc, const int32_t* ni, const int32_t* nw, uint64_t* qw)
+  int n, const int32_t* nc, const int32_t* ni, const int32_t* nw, const int32_t* xr, uint64_t* qw)
 {
   for (int i = 0; i < n; i++)
     qw[i] = 1u << 8;
   for (int i = n - 1; i >= 0; i--)
-    for (int j = 0; j < nc[i]; j++)
+    for (int j = 0; j < nc[i]; j++) {
+      if (xr && xr[3 * i + j])
+        continue;
       qw[ni[3 * i + j]] += round_shift8_u64((uint64_t)(uint32_t)nw[3 * i + j] * qw[i]);
+    }
 }
 
 /* computeQuantizationWeightsScalable (PCCTMC3Common.h:858-891) for a whole
@@ -97,13 +102,19 @@ quant_weights_scalable(int n, int lods, const int32_t* npl, uint64_t* qw)
 static void
 lift_predict(
   int c, int start, int end, int direct, const int32_t* nc, const int32_t* ni,
-  const int32_t* nw, int64_t* a)
+  const int32_t* nw, int64_t* a, const int32_t* xr, const int64_t* aref)
 {
   for (int i = start; i < end; i++) {
     int64_t pred[3] = {0, 0, 0};
     for (int j = 0; j < nc[i]; j++)
-      for (int k = 0; k < c; k++)
-        pred[k] += (int64_t)(uint32_t)nw[3 * i + j] * a[(size_t)ni[3 * i + j] * c + k];
+      for (int k = 0; k < c; k++) {
+        /* a neighbour of the reference frame contributes that frame's attribute, looked
+         * up by its point index there (:735-740) */
+        if (xr && xr[3 * i + j])
+          pred[k] += (int64_t)(uint32_t)nw[3 * i + j] * aref[(size_t)ni[3 * i + j] * c + k];
+        else
+          pred[k] += (int64_t)(uint32_t)nw[3 * i + j] * a[(size_t)ni[3 * i + j] * c + k];
+      }
     for (int k = 0; k < c; k++) {
       const int64_t p = div_exp2_round_half_inf(pred[k], 8);
       if (direct)
@@ -118,12 +129,14 @@ lift_predict(
 static void
 lift_update(
   int c, int start, int end, int direct, const int32_t* nc, const int32_t* ni,
-  const int32_t* nw, const uint64_t* qw, int64_t* a, uint64_t* uw, int64_t* up)
+  const int32_t* nw, const uint64_t* qw, int64_t* a, uint64_t* uw, int64_t* up, const int32_t* xr)
 {
   memset(uw, 0, sizeof(uint64_t) * (size_t)start);
   memset(up, 0, sizeof(int64_t) * (size_t)start * c);
   for (int i = start; i < end; i++)
     for (int j = 0; j < nc[i]; j++) {
+      if (xr && xr[3 * i + j])
+        continue; /* nothing flows back into the reference frame (:799-800) */
       const uint64_t wgt = round_shift8_u64((uint64_t)(uint32_t)nw[3 * i + j] * qw[i]);
       const int nb = ni[3 * i + j];
       uw[nb] += wgt;
@@ -161,9 +174,18 @@ static int
 lift_process(
   int encoder, const gpcc_lift_params* p, int n, int c, const int32_t* nc,
   const int32_t* ni, const int32_t* nw, const int32_t* indexes,
-  const int32_t* qp_off, int32_t* attrs, int32_t* coeffs, int8_t* lcp)
+  const int32_t* qp_off, int32_t* attrs, int32_t* coeffs, int8_t* lcp,
+  const int32_t* xr, const int32_t* attrs_ref, int n_ref)
 {
   const int lods = p->num_lods;
+  int64_t* aref = NULL;
+  if (xr) {
+    if (c != 1 || p->scalable_lifting_enabled_flag)
+      return -2; /* the reference has inter prediction in the reflectance driver only */
+    aref = (int64_t*)malloc(sizeof(int64_t) * (size_t)(n_ref > 0 ? n_ref : 1));
+    for (int i = 0; i < n_ref; i++)
+      aref[i] = (int64_t)attrs_ref[i] * 256;
+  }
   const int32_t* npl = p->num_points_in_lod;
   uint64_t* qw = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)n);
   uint64_t* uw = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)n);
@@ -172,7 +194,7 @@ lift_process(
   if (p->scalable_lifting_enabled_flag)
     quant_weights_scalable(n, lods, npl, qw);
   else
-    quant_weights(n, nc, ni, nw, qw);
+    quant_weights(n, nc, ni, nw, xr, qw);
 
   int8_t signs[GPCC_MAX_LODS];
   memset(signs, 0, sizeof(signs));
@@ -181,8 +203,8 @@ lift_process(
       for (int k = 0; k < c; k++)
         a[(size_t)i * c + k] = (int64_t)attrs[(size_t)indexes[i] * c + k] * 256;
     for (int l = lods - 1; l >= 1; l--) {
-      lift_predict(c, npl[l - 1], npl[l], 1, nc, ni, nw, a);
-      lift_update(c, npl[l - 1], npl[l], 1, nc, ni, nw, qw, a, uw, up);
+      lift_predict(c, npl[l - 1], npl[l], 1, nc, ni, nw, a, xr, aref);
+      lift_update(c, npl[l - 1], npl[l], 1, nc, ni, nw, qw, a, uw, up, xr);
     }
     if (c == 3 && p->last_component_prediction_enabled_flag) {
       int64_t s12 = 0, s11 = 0;
@@ -254,8 +276,8 @@ lift_process(
 
   /* inverse lifting */
   for (int l = 1; l < lods; l++) {
-    lift_update(c, npl[l - 1], npl[l], 0, nc, ni, nw, qw, a, uw, up);
-    lift_predict(c, npl[l - 1], npl[l], 0, nc, ni, nw, a);
+    lift_update(c, npl[l - 1], npl[l], 0, nc, ni, nw, qw, a, uw, up, xr);
+    lift_predict(c, npl[l - 1], npl[l], 0, nc, ni, nw, a, xr, aref);
   }
   const int64_t clip_max = ((int64_t)1 << p->bitdepth) - 1;
   for (int i = 0; i < n; i++)
@@ -268,6 +290,7 @@ lift_process(
   free(uw);
   free(up);
   free(a);
+  free(aref);
   return 0;
 }
 
@@ -277,7 +300,7 @@ oracle_lift_forward(
   const int32_t* ni, const int32_t* nw, const int32_t* indexes,
   const int32_t* qp_off, int32_t* attrs, int32_t* coeffs, int8_t* lcp)
 {
-  return lift_process(1, p, n, c, nc, ni, nw, indexes, qp_off, attrs, coeffs, lcp);
+  return lift_process(1, p, n, c, nc, ni, nw, indexes, qp_off, attrs, coeffs, lcp, NULL, NULL, 0);
 }
 
 int
@@ -286,5 +309,28 @@ oracle_lift_inverse(
   const int32_t* ni, const int32_t* nw, const int32_t* indexes,
   const int32_t* qp_off, int32_t* attrs, int32_t* coeffs, int8_t* lcp)
 {
-  return lift_process(0, p, n, c, nc, ni, nw, indexes, qp_off, attrs, coeffs, lcp);
+  return lift_process(0, p, n, c, nc, ni, nw, indexes, qp_off, attrs, coeffs, lcp, NULL, NULL, 0);
+}
+
+/* Reflectance lifting with attribute inter prediction (encodeReflectancesLift /
+ * decodeReflectancesLift with AttributeInterPredParams::enableAttrInterPred,
+ * AttributeEncoder.cpp:1543-1648, AttributeDecoder.cpp:780-857): inter_ref [n][3] marks the
+ * neighbours that live in the reference frame (neigh_index is then a point index there),
+ * attrs_ref [n_ref] that frame's reflectances. */
+int
+oracle_lift_forward_inter(
+  const gpcc_lift_params* p, int32_t n, const int32_t* nc, const int32_t* ni, const int32_t* nw,
+  const int32_t* inter_ref, const int32_t* indexes, int32_t* attrs, const int32_t* attrs_ref,
+  int32_t n_ref, int32_t* coeffs)
+{
+  return lift_process(1, p, n, 1, nc, ni, nw, indexes, NULL, attrs, coeffs, NULL, inter_ref, attrs_ref, n_ref);
+}
+
+int
+oracle_lift_inverse_inter(
+  const gpcc_lift_params* p, int32_t n, const int32_t* nc, const int32_t* ni, const int32_t* nw,
+  const int32_t* inter_ref, const int32_t* indexes, int32_t* attrs, const int32_t* attrs_ref,
+  int32_t n_ref, int32_t* coeffs)
+{
+  return lift_process(0, p, n, 1, nc, ni, nw, indexes, NULL, attrs, coeffs, NULL, inter_ref, attrs_ref, n_ref);
 }

@@ -252,6 +252,10 @@ typedef struct {
   int32_t idx[6];
   int64_t dist[6];
   int idx2;
+  /* inter-frame prediction: candidates of the reference frame travel with a flag
+   * (localRef, :1316) -- `cur` is the flag of the candidate being visited */
+  uint8_t ref[6];
+  uint8_t cur;
 } nn_state_t;
 
 /* updateNearestNeigh :1030-1076 */
@@ -267,14 +271,20 @@ nn_update(nn_state_t* s, int32_t d, int32_t index)
     s->idx[2] = s->idx[1];
     s->idx[1] = s->idx[0];
     s->idx[0] = index;
+    s->ref[2] = s->ref[1];
+    s->ref[1] = s->ref[0];
+    s->ref[0] = s->cur;
   } else if (d < s->dist[1]) {
     s->dist[2] = s->dist[1];
     s->dist[1] = d;
     s->idx[2] = s->idx[1];
     s->idx[1] = index;
+    s->ref[2] = s->ref[1];
+    s->ref[1] = s->cur;
   } else {
     s->dist[2] = d;
     s->idx[2] = index;
+    s->ref[2] = s->cur;
   }
 }
 
@@ -282,32 +292,42 @@ nn_update(nn_state_t* s, int32_t d, int32_t index)
 static void
 nn_update_dist(nn_state_t* s, int32_t d, int32_t index)
 {
+#define NN_SPILL()                    \
+  if (s->idx[2] != -1) {              \
+    s->ref[s->idx2] = s->ref[2];      \
+    s->idx[s->idx2++] = s->idx[2];    \
+  }
   if (d > s->dist[2]) {
     /* nothing */
   } else if (d < s->dist[0]) {
-    if (s->idx[2] != -1)
-      s->idx[s->idx2++] = s->idx[2];
+    NN_SPILL();
     s->dist[2] = s->dist[1];
     s->dist[1] = s->dist[0];
     s->dist[0] = d;
     s->idx[2] = s->idx[1];
     s->idx[1] = s->idx[0];
     s->idx[0] = index;
+    s->ref[2] = s->ref[1];
+    s->ref[1] = s->ref[0];
+    s->ref[0] = s->cur;
   } else if (d < s->dist[1]) {
-    if (s->idx[2] != -1)
-      s->idx[s->idx2++] = s->idx[2];
+    NN_SPILL();
     s->dist[2] = s->dist[1];
     s->dist[1] = d;
     s->idx[2] = s->idx[1];
     s->idx[1] = index;
+    s->ref[2] = s->ref[1];
+    s->ref[1] = s->cur;
   } else if (d < s->dist[2]) {
-    if (s->idx[2] != -1)
-      s->idx[s->idx2++] = s->idx[2];
+    NN_SPILL();
     s->dist[2] = d;
     s->idx[2] = index;
+    s->ref[2] = s->cur;
   } else if (s->idx[5] == -1) {
+    s->ref[s->idx2] = s->cur;
     s->idx[s->idx2++] = index;
   }
+#undef NN_SPILL
   if (s->idx2 == 6)
     s->idx2 = 3;
 }
@@ -318,7 +338,7 @@ nn_visit(nn_state_t* s, int distribution, int check, int32_t d, int32_t index)
   if (check) {
     const int lim = distribution ? 6 : 3;
     for (int h = 0; h < lim; h++)
-      if (s->idx[h] == index)
+      if (s->idx[h] == index && s->ref[h] == s->cur)
         return;
   }
   if (distribution)
@@ -449,16 +469,30 @@ window_scan(
 
 typedef struct {
   int32_t count;
-  int32_t pidx[3];   /* neighbour POINT index */
+  int32_t pidx[3];   /* neighbour POINT index (of the reference frame when ref[] is set) */
   uint64_t w[3];     /* squared distance */
+  uint8_t ref[3];    /* PCCNeighborInfo::interFrameRef */
 } raw_pred_t;
+
+/* the reference frame of attribute inter prediction as computeNearestNeighbors sees it
+ * (:1270-1292): the whole frame in Morton order, its biased positions and one box
+ * hierarchy over the list; indexesRef is the identity, [startIndexRef, endIndexRef) the
+ * whole list at every level of detail (buildPredictorsFast :2348-2376, :2396-2400) */
+typedef struct {
+  const voxel_t* pv;
+  int32_t n;
+  const int32_t* bias_pos; /* [n][3], sorted order */
+  const int32_t* identity; /* 0 .. n-1 */
+  bbox_t boxes;
+  int32_t range;           /* abh.attrInterPredSearchRange: replaces BOTH LoD search ranges */
+} inter_frame_t;
 
 static void
 compute_nearest_neighbours(
   const gpcc_lod_params* lp, const voxel_t* pv, int32_t n, const int32_t* bias_pos_in /*[n][3]*/,
   const int32_t* retained, int n_ret, int32_t* indexes /* in: packed idx, out: point idx */,
   int start, int end, int lod_index, raw_pred_t* preds, int32_t* pt2pred,
-  int* pred_index)
+  int* pred_index, const inter_frame_t* ir)
 {
   /* scalable lifting (:1174-1176, :1232-1236, clacIntermediatePosition :925-940): the
    * search cells are those of the octree level, and every position is replaced by the
@@ -479,8 +513,10 @@ compute_nearest_neighbours(
   const int shift3 = 3 * shift_bits;
   const int boundary = min_i(63, shift3 + kAtlasBits);
   const int distribution = lp->prediction_with_distribution_enabled != 0;
-  const int range_inter = lp->inter_lod_search_range;
-  const int range_intra = lp->intra_lod_search_range;
+  const int range_inter = ir ? ir->range : lp->inter_lod_search_range;
+  const int range_intra = ir ? ir->range : lp->intra_lod_search_range;
+  /* the inter-frame atlas holds 8^3 cells (:2391-2395) */
+  const int inter_boundary = min_i(63, shift3 + 9);
   const int intra = lod_index >= lp->intra_lod_prediction_skip_layers;
   const int n_ref = end - start;
 
@@ -531,8 +567,10 @@ compute_nearest_neighbours(
     for (int h = 0; h < 6; h++) {
       s.idx[h] = -1;
       s.dist[h] = INT64_MAX;
+      s.ref[h] = 0;
     }
     s.idx2 = 3;
+    s.cur = 0;
     const int index = packed[i - start];
     const int64_t code = pv[index].code;
     const int64_t atlas_id = code >> boundary;
@@ -608,13 +646,55 @@ compute_nearest_neighbours(
       window_scan(&s, &hi, bref, bp, w0, w1, +1, distribution, 0, packed, 0);
     }
 
+    if (ir) {
+      /* candidates of the reference frame, no duplicate checks (:1606-1796) */
+      s.cur = 1;
+      /* (a) through the inter-frame atlas.  The test of a neighbour cell against the
+       * atlas block shifts by the INTRA atlas' 21 bits (:1627) while the block id was
+       * formed with 9: the two only agree in block 0, so the atlas contributes for the
+       * cells of the first 8^3 block alone, and a neighbour cell outside that block
+       * aliases into it (MortonIndexMap3d::get masks the address, :155-158) */
+      if ((code >> inter_boundary) == 0) {
+        const uint64_t base = morton3d_add((uint64_t)cell, ~(uint64_t)0);
+        for (int nn = 0; nn < 27; nn++) {
+          const int64_t nb = (int64_t)morton3d_add(base, kNnNeigh[nn]);
+          if ((nb >> kAtlasBits) != 0)
+            continue;
+          int r0, r1;
+          cell_range(ir->pv, ir->identity, ir->n, shift3, nb & 0x1ff, &r0, &r1);
+          for (int k = r0; k < r1; k++)
+            nn_visit(&s, distribution, 0, norm1(bp, &ir->bias_pos[3 * k]), k);
+        }
+      }
+      /* (b) the window around the first entry that does not precede the point */
+      if (ir->n > 0) {
+        int lo = 0, hi2 = ir->n;
+        while (lo < hi2) {
+          int mid = (lo + hi2) >> 1;
+          if (ir->pv[mid].code < code)
+            lo = mid + 1;
+          else
+            hi2 = mid;
+        }
+        const int jr = min_i(lo, ir->n - 1);
+        const int k1 = min_i(ir->n - 1, max_i(0, jr + ir->range));
+        window_scan(&s, &ir->boxes, ir->bias_pos, bp, jr, k1, +1, distribution, 0, NULL, 0);
+        const int l0 = min_i(ir->n - 1, max_i(0, jr - 1));
+        const int l1 = min_i(ir->n - 1, max_i(0, l0 - ir->range));
+        /* the left part is walked upwards too */
+        window_scan(&s, &ir->boxes, ir->bias_pos, bp, l1, l0, +1, distribution, 0, NULL, 0);
+      }
+      s.cur = 0;
+    }
+
     int count = (s.idx[0] != -1) + (s.idx[1] != -1) + (s.idx[2] != -1);
     count = min_i(lp->num_pred_nearest_neighbours_minus1 + 1, count);
+#define NN_POS(h) (s.ref[h] ? &ir->bias_pos[3 * s.idx[h]] : &bias_pos[3 * s.idx[h]])
     if (distribution) {
       const int c1 = 3 + (s.idx[3] != -1) + (s.idx[4] != -1) + (s.idx[5] != -1);
       for (int m = 3; m < c1; m++)
         if (s.dist[m] == INT64_MAX)
-          s.dist[m] = norm1(bp, &bias_pos[3 * s.idx[m]]);
+          s.dist[m] = norm1(bp, NN_POS(m));
       for (int m = 3; m < c1; m++)
         for (int l = m + 1; l < c1; l++)
           if (s.dist[l] < s.dist[m]) {
@@ -624,6 +704,9 @@ compute_nearest_neighbours(
             int64_t td = s.dist[l];
             s.dist[l] = s.dist[m];
             s.dist[m] = td;
+            uint8_t tr = s.ref[l];
+            s.ref[l] = s.ref[m];
+            s.ref[m] = tr;
           }
       if (count >= 3) {
         /* third neighbour replaced by one on the far side (:1836-1902) */
@@ -636,7 +719,7 @@ compute_nearest_neighbours(
           if ((s.dist[numend] << 5) >= s.dist[2] * 54)
             break;
         for (int h = 0; h < numend; h++)
-          dir[h] = dir_of(&bias_pos[3 * s.idx[h]], bp);
+          dir[h] = dir_of(NN_POS(h), bp);
         int replace = 1, ridx = -1;
         if (dir[1] == 7 - dir[0] || dir[2] == 7 - dir[0] || dir[2] == 7 - dir[1])
           replace = 0;
@@ -670,19 +753,24 @@ compute_nearest_neighbours(
                 }
           }
         }
-        if (ridx >= 0)
+        if (ridx >= 0) {
           s.idx[2] = s.idx[ridx];
+          s.ref[2] = s.ref[ridx];
+        }
       }
     }
     pr->count = count;
     for (int h = 0; h < 3; h++) {
       pr->pidx[h] = 0;
       pr->w[h] = 0;
+      pr->ref[h] = 0;
     }
     for (int h = 0; h < count; h++) {
-      pr->pidx[h] = pv[s.idx[h]].index;
-      pr->w[h] = (uint64_t)norm2(&bias_pos[3 * s.idx[h]], bp);
+      pr->ref[h] = s.ref[h];
+      pr->pidx[h] = s.ref[h] ? ir->pv[s.idx[h]].index : pv[s.idx[h]].index;
+      pr->w[h] = (uint64_t)norm2(NN_POS(h), bp);
     }
+#undef NN_POS
     /* scalable lifting: neighbours further than the range are dropped, and all
      * that follow them (:1918-1939, pruneDistanceGt :695-703) */
     if (scalable) {
@@ -717,6 +805,9 @@ compute_nearest_neighbours(
     uint64_t tw_ = pr->w[a];                                                 \
     pr->w[a] = pr->w[b];                                                     \
     pr->w[b] = tw_;                                                          \
+    uint8_t tr_ = pr->ref[a];                                                \
+    pr->ref[a] = pr->ref[b];                                                 \
+    pr->ref[b] = tr_;                                                        \
   } while (0)
       if (pr->w[0] > pr->w[1])
         SWAP_PRED(0, 1);
@@ -742,12 +833,18 @@ compute_nearest_neighbours(
  * squared distances).  Outputs as ref_lod_generate in ref_lod_harness.inc. */
 void oracle_compute_weights(int32_t n, int32_t* neigh_count, uint64_t* w);
 
-int
-oracle_lod_generate(
+static int
+lod_generate(
   const gpcc_lod_params* lp, const int32_t* xyz, int32_t n, int32_t raw,
   int32_t* neigh_count, int32_t* neigh_index, uint64_t* weight64,
-  int32_t* indexes_out, int32_t* num_points_in_lod, int32_t* num_lods)
+  int32_t* indexes_out, int32_t* num_points_in_lod, int32_t* num_lods,
+  /* attribute inter prediction (NULL / 0: none) */
+  const int32_t* xyz_ref, int32_t n_ref, int32_t search_range, int32_t frame_distance,
+  int32_t* inter_ref)
 {
+  if (xyz_ref && (lp->scalable_lifting_enabled_flag || lp->canonical_point_order_flag
+                  || lp->max_points_per_sort_log2_plus1 || n_ref <= 0))
+    return -2; /* not restated together */
   voxel_t* pv = (voxel_t*)malloc(sizeof(voxel_t) * (size_t)n);
   for (int i = 0; i < n; i++) {
     pv[i].code = morton_addr(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
@@ -770,6 +867,35 @@ oracle_lod_generate(
   for (int i = 0; i < n; i++)
     for (int d = 0; d < 3; d++)
       bias_pos[3 * i + d] = pv[i].pos[d] * lp->lod_neigh_bias[d];
+
+  /* the reference frame: Morton order, biased, boxes over the whole list (:2352-2376, :1270-1292) */
+  inter_frame_t irs;
+  const inter_frame_t* ir = NULL;
+  voxel_t* pvr = NULL;
+  int32_t *bias_ref = NULL, *ident = NULL;
+  if (xyz_ref) {
+    pvr = (voxel_t*)malloc(sizeof(voxel_t) * (size_t)n_ref);
+    for (int i = 0; i < n_ref; i++) {
+      pvr[i].code = morton_addr(xyz_ref[3 * i], xyz_ref[3 * i + 1], xyz_ref[3 * i + 2]);
+      memcpy(pvr[i].pos, &xyz_ref[3 * i], 12);
+      pvr[i].index = i;
+    }
+    qsort(pvr, (size_t)n_ref, sizeof(voxel_t), cmp_voxel);
+    bias_ref = (int32_t*)malloc(sizeof(int32_t) * 3 * (size_t)n_ref);
+    ident = (int32_t*)malloc(sizeof(int32_t) * (size_t)n_ref);
+    for (int i = 0; i < n_ref; i++) {
+      ident[i] = i;
+      for (int d = 0; d < 3; d++)
+        bias_ref[3 * i + d] = pvr[i].pos[d] * lp->lod_neigh_bias[d];
+    }
+    irs.pv = pvr;
+    irs.n = n_ref;
+    irs.bias_pos = bias_ref;
+    irs.identity = ident;
+    irs.range = search_range;
+    bbox_build(&irs.boxes, bias_ref, n_ref);
+    ir = &irs;
+  }
 
   int32_t* input = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
   int32_t* retained = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
@@ -820,12 +946,12 @@ oracle_lod_generate(
         for (int l = 0; l < lod; l++)
           compute_nearest_neighbours(
             lp, pv, n, bias_pos, retained, n_ret, indexes, n - npl[l], n - npl[l + 1], l, preds,
-            pt2pred, &pred_index);
+            pt2pred, &pred_index, ir);
       }
     }
     compute_nearest_neighbours(
       lp, pv, n, bias_pos, retained, n_ret, indexes, start, n_idx, lod, preds, pt2pred,
-      &pred_index);
+      &pred_index, ir);
     if (n_ret && nl < GPCC_MAX_LODS + 1)
       npl[nl++] = n_ret;
     int32_t* t = input;
@@ -847,9 +973,13 @@ oracle_lod_generate(
     neigh_count[i] = p->count;
     for (int k = 0; k < 3; k++) {
       /* entries beyond the count keep their point index un-mapped, as the
-       * reference leaves them */
-      neigh_index[3 * i + k] = k < p->count ? pt2pred[p->pidx[k]] : p->pidx[k];
-      weight64[3 * i + k] = p->w[k];
+       * reference leaves them; a neighbour in the reference frame keeps ITS point
+       * index and is moved away by the frame distance (:2286-2293) */
+      const int live = k < p->count;
+      neigh_index[3 * i + k] = live && !p->ref[k] ? pt2pred[p->pidx[k]] : p->pidx[k];
+      weight64[3 * i + k] = p->w[k] + (live && p->ref[k] ? (uint64_t)(int64_t)frame_distance : 0);
+      if (inter_ref)
+        inter_ref[3 * i + k] = p->ref[k];
     }
   }
   *num_lods = nl;
@@ -865,7 +995,8 @@ oracle_lod_generate(
           continue;
         const int32_t* q[3];
         for (int k = 0; k < 3; k++)
-          q[k] = &xyz[3 * indexes_out[neigh_index[3 * i + k]]];
+          q[k] = preds[i].ref[k] ? &xyz_ref[3 * neigh_index[3 * i + k]]
+                                 : &xyz[3 * indexes_out[neigh_index[3 * i + k]]];
         int64_t d01 = 0, d02 = 0, d12 = 0;
         for (int c = 0; c < 3; c++) {
           const int64_t a = (int64_t)q[0][c] - q[1][c], b = (int64_t)q[0][c] - q[2][c],
@@ -887,6 +1018,12 @@ oracle_lod_generate(
       }
     }
   }
+  if (ir) {
+    bbox_free(&irs.boxes);
+    free(pvr);
+    free(bias_ref);
+    free(ident);
+  }
   free(pv);
   free(packed_of_layers);
   free(bias_pos);
@@ -896,6 +1033,36 @@ oracle_lod_generate(
   free(pt2pred);
   free(preds);
   return 0;
+}
+
+int
+oracle_lod_generate(
+  const gpcc_lod_params* lp, const int32_t* xyz, int32_t n, int32_t raw,
+  int32_t* neigh_count, int32_t* neigh_index, uint64_t* weight64,
+  int32_t* indexes_out, int32_t* num_points_in_lod, int32_t* num_lods)
+{
+  return lod_generate(
+    lp, xyz, n, raw, neigh_count, neigh_index, weight64, indexes_out, num_points_in_lod, num_lods,
+    NULL, 0, 0, 0, NULL);
+}
+
+/* ... with attribute inter prediction (AttributeInterPredParams::enableAttrInterPred): the
+ * neighbour search also looks into the reference frame xyz_ref [n_ref][3]
+ * (computeNearestNeighbors :1606-1796), search_range = abh.attrInterPredSearchRange.
+ * inter_ref [n][3] out: PCCNeighborInfo::interFrameRef; for such a neighbour neigh_index is
+ * the point index IN THE REFERENCE FRAME and the distance carries frame_distance. */
+int
+oracle_lod_generate_inter(
+  const gpcc_lod_params* lp, const int32_t* xyz, int32_t n, const int32_t* xyz_ref, int32_t n_ref,
+  int32_t search_range, int32_t frame_distance, int32_t raw, int32_t* neigh_count,
+  int32_t* neigh_index, uint64_t* weight64, int32_t* indexes_out, int32_t* num_points_in_lod,
+  int32_t* num_lods, int32_t* inter_ref)
+{
+  if (!xyz_ref)
+    return -1;
+  return lod_generate(
+    lp, xyz, n, raw, neigh_count, neigh_index, weight64, indexes_out, num_points_in_lod, num_lods,
+    xyz_ref, n_ref, search_range, frame_distance, inter_ref);
 }
 
 /* estimateDist2, tmc3/AttributeEncoder.cpp:1684-1720: every samplingPeriod-th

@@ -40,6 +40,39 @@ def _lod_generate(lib, fname, xyz, lp, raw):
     return dict(nc=nc, ni=ni, w=w, indexes=idx, npl=npl[:nl.value].copy())
 
 
+def oracle_lod_generate_inter(xyz, xyz_ref, lp, search_range, frame_distance=1, raw=False):
+    return _lod_generate_inter(ol.oracle().lib, "oracle_lod_generate_inter", xyz, xyz_ref, lp, search_range,
+                               frame_distance, raw)
+
+
+def ref_lod_generate_inter(xyz, xyz_ref, lp, search_range, frame_distance=1, raw=False):
+    """reference AttributeLods::generate with attribute inter prediction: dict as ref_lod_generate
+    plus ref [n,3] (PCCNeighborInfo::interFrameRef; ni is then a point index of the reference frame)"""
+    return _lod_generate_inter(ol.ref().lib, "ref_lod_generate_inter", xyz, xyz_ref, lp, search_range,
+                               frame_distance, raw)
+
+
+def _lod_generate_inter(lib, fname, xyz, xyz_ref, lp, search_range, frame_distance, raw):
+    fn = getattr(lib, fname)
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, i32p, C.c_int32, i32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, i32p, i32p, u64p,
+                   i32p, i32p, C.POINTER(C.c_int32), i32p]
+    xyz = np.ascontiguousarray(xyz, dtype=np.int32)
+    xyz_ref = np.ascontiguousarray(xyz_ref, dtype=np.int32)
+    n = len(xyz)
+    nc = np.zeros(n, np.int32)
+    ni = np.zeros((n, 3), np.int32)
+    w = np.zeros((n, 3), np.uint64)
+    idx = np.zeros(n, np.int32)
+    npl = np.zeros(32, np.int32)
+    ref = np.zeros((n, 3), np.int32)
+    nl = C.c_int32()
+    rc = fn(C.addressof(lp), xyz.reshape(-1), n, xyz_ref.reshape(-1), len(xyz_ref), search_range, frame_distance,
+            int(raw), nc, ni.reshape(-1), w.reshape(-1), idx, npl, C.byref(nl), ref.reshape(-1))
+    assert rc == 0, rc
+    return dict(nc=nc, ni=ni, w=w, indexes=idx, npl=npl[:nl.value].copy(), ref=ref)
+
+
 def compute_weights(checker, nc, dist2):
     f = checker.fn("compute_weights", None, [C.c_int32, i32p, u64p])
     nc2 = np.ascontiguousarray(nc, dtype=np.int32).copy()
@@ -67,6 +100,43 @@ def lift(checker, forward, lf, lod, attrs, coeffs=None, lcp=None, qp_off=None):
            q.ctypes.data_as(C.c_void_p) if q is not None else None, a.reshape(-1), co.reshape(-1), l)
     assert rc == 0
     return co, a, np.array(list(l), dtype=np.int8)
+
+
+def lift_inter(checker, forward, lf, lod, attrs, attrs_ref, coeffs=None):
+    """reflectance lifting with neighbours in a reference frame (lod["ref"], lod["ni"] as
+    *_lod_generate_inter give them) -> (coeffs [n,1] coding order, recon [n,1] point order)"""
+    f = checker.fn("lift_forward_inter" if forward else "lift_inverse_inter", C.c_int,
+                   [C.c_void_p, C.c_int32, i32p, i32p, i32p, i32p, i32p, i32p, i32p, C.c_int32, i32p])
+    n = len(lod["nc"])
+    a = np.ascontiguousarray(attrs, dtype=np.int32).copy() if forward else np.zeros((n, 1), np.int32)
+    co = np.zeros((n, 1), np.int32) if forward else np.ascontiguousarray(coeffs, dtype=np.int32).copy()
+    ar = np.ascontiguousarray(attrs_ref, dtype=np.int32).reshape(-1)
+    rc = f(C.addressof(lf), n, lod["nc"], np.ascontiguousarray(lod["ni"]).reshape(-1),
+           np.ascontiguousarray(lod["w"].astype(np.int32)).reshape(-1),
+           np.ascontiguousarray(lod["ref"], dtype=np.int32).reshape(-1), lod["indexes"], a.reshape(-1), ar, len(ar),
+           co.reshape(-1))
+    assert rc == 0, rc
+    return co, a
+
+
+def ref_inter_roundtrip(lp, transform, qp, bitdepth, direct, xyz, attrs, xyz_ref, attrs_ref, search_range,
+                        frame_distance=1):
+    """the reference operator (encode + decode) with attribute inter prediction, one component
+    -> (payload, recon_enc, recon_dec)"""
+    lib = ol.ref().lib
+    lib.ref_inter_roundtrip.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, i32p, i32p, C.c_int32,
+                                        i32p, i32p, C.c_int32, C.c_int32, C.c_int32, i32p, i32p, u8p, C.c_int32]
+    xyz = np.ascontiguousarray(xyz, dtype=np.int32)
+    xyz_ref = np.ascontiguousarray(xyz_ref, dtype=np.int32)
+    a = np.ascontiguousarray(attrs, dtype=np.int32).reshape(-1)
+    ar = np.ascontiguousarray(attrs_ref, dtype=np.int32).reshape(-1)
+    n = len(xyz)
+    re = np.zeros(n, np.int32)
+    rd = np.zeros(n, np.int32)
+    pay = np.zeros(n * 8 + 4096, np.uint8)
+    ln = lib.ref_inter_roundtrip(C.addressof(lp), transform, qp, bitdepth, direct, xyz.reshape(-1), a, n,
+                                 xyz_ref.reshape(-1), ar, len(xyz_ref), search_range, frame_distance, re, rd, pay, pay.size)
+    return pay[:ln].tobytes(), re.reshape(n, 1), rd.reshape(n, 1)
 
 
 def ref_operator_roundtrip(lp, transform, rp, qp, chroma, bitdepth, lcp, xyz, attrs, lib=None):

@@ -147,3 +147,38 @@ def test_scalable_lifting_oracle_gives_the_reference_operator_bitstream(rng):
         assert lh.ref_entropy_encode_symbols(c, len(xyz), runs, vals, trailing) == bytes(payload[lh.ref_last_abh_size():])
         _, inv, _ = lh.lift(o, False, lf, lod, attrs, coeffs=co, lcp=lcp)
         np.testing.assert_array_equal(inv, rec)
+
+
+@_mark
+@pytest.mark.parametrize("qp", [10, 34])
+def test_inter_frame_lifting_oracle_gives_the_reference_operator_bitstream(qp):
+    """attribute inter prediction, reflectance lifting: the oracle's LoD structure with
+    neighbours in the reference frame (oracle_lod_generate_inter) and its lifting with them
+    (PCCLiftPredict takes the reference frame's reflectance, PCCLiftUpdate and the quantisation weights
+    leave such neighbours out) -> zero runs -> the reference's arithmetic coder = the payload of the
+    reference operator run with the same reference frame; reconstruction and inverse agree."""
+    from mpeg_pcc_tmc13_amd import lift_params, lod_params, synth
+    if not lh.entropy_available():
+        pytest.skip("entropy harness absent")
+    o = ol.oracle()
+    rng = np.random.default_rng(7)
+    for xyz, attrs in (synth.lidar_cloud(9000, seed=61), synth.dense_cloud(6000, seed=3, bits=7)):
+        attrs = attrs[:, :1].copy()
+        if attrs.max() > 255:
+            attrs = attrs >> 8
+        keep = rng.random(len(xyz)) > 0.1    # the previous frame: jittered, a tenth of the points gone
+        xr = np.clip(xyz + rng.integers(-2, 3, size=xyz.shape), 0, None)[keep].astype(np.int32)
+        ar = np.clip(attrs + rng.integers(-6, 7, size=attrs.shape), 0, 255)[keep].astype(np.int32)
+        for search_range in (5, 128):
+            lp = lod_params()
+            payload, rec_enc, rec_dec = lh.ref_inter_roundtrip(lp, 2, qp, 8, 0, xyz, attrs, xr, ar, search_range, 1)
+            np.testing.assert_array_equal(rec_enc, rec_dec)
+            lod = lh.oracle_lod_generate_inter(xyz, xr, lp, search_range, 1)
+            assert lod["ref"].sum() > len(xyz) // 2
+            lf = lift_params(lod["npl"], qp=qp, chroma_offset=0, lcp=False, bitdepth=8)
+            co, rec = lh.lift_inter(o, True, lf, lod, attrs, ar)
+            np.testing.assert_array_equal(rec, rec_enc)
+            runs, vals, trailing = lh.oracle_zero_run_pack(co, len(xyz), 1, planar=False)
+            assert lh.ref_entropy_encode_symbols(1, len(xyz), runs, vals, trailing) == payload[lh.ref_last_abh_size():]
+            _, inv = lh.lift_inter(o, False, lf, lod, attrs, ar, coeffs=co)
+            np.testing.assert_array_equal(inv, rec)

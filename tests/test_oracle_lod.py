@@ -101,3 +101,41 @@ def test_scalable_lifting_lod_matches_reference(vi):
                 o = lh.oracle_lod_generate(xyz, lp, raw=raw)
                 for k in r:
                     np.testing.assert_array_equal(o[k], r[k], err_msg=f"{name} {kw} range={rng} raw={raw} {k}")
+
+
+def _moved(xyz, seed, amp=2):
+    """a 'previous frame': the cloud jittered, a tenth of the points dropped"""
+    rng = np.random.default_rng(seed)
+    y = xyz + rng.integers(-amp, amp + 1, size=xyz.shape)
+    keep = rng.random(len(xyz)) > 0.1
+    return np.clip(y[keep], 0, None).astype(np.int32)
+
+
+INTER = [dict(), dict(decimation=1), dict(decimation=2), dict(distribution=False), dict(bias=(1, 2, 1)), dict(neighbours=2),
+         dict(lifting=False, intra_range=64, blend=True), dict(levels=1)]
+
+
+@pytest.mark.parametrize("vi", range(len(INTER)))
+def test_inter_frame_lod_search_matches_reference(vi):
+    """attribute inter prediction (the LoD half): the neighbour search also takes
+    candidates from the reference frame -- the inter-frame atlas (which, by the shift it is tested
+    with, only ever answers in the first 8^3 block of cells) and a window around the point's place in
+    the reference frame's Morton order, without duplicate checks (PCCTMC3Common.h:1606-1796) -- flags
+    them (interFrameRef), keeps their reference-frame point index and adds the frame distance to their
+    squared distance (updatePredictors :2286-2293).  Oracle == compiled reference, bit for bit."""
+    from mpeg_pcc_tmc13_amd import lod_params
+    kw = INTER[vi]
+    seen_refs = 0
+    for name, xyz in clouds():
+        ref = _moved(xyz, 5) if len(xyz) > 3 else xyz.copy()
+        for search_range in (0, 5, 128):
+            lp = lod_params(**kw)
+            if kw.get("lifting") is False:
+                lp.intra_lod_prediction_skip_layers = 0
+            for raw in (True, False):
+                r = lh.ref_lod_generate_inter(xyz, ref, lp, search_range, 2, raw=raw)
+                o = lh.oracle_lod_generate_inter(xyz, ref, lp, search_range, 2, raw=raw)
+                for k in r:
+                    np.testing.assert_array_equal(o[k], r[k], err_msg=f"{name} {kw} range={search_range} raw={raw} {k}")
+                seen_refs += int(r["ref"].sum())
+    assert seen_refs > 1000   # the reference frame was actually used
