@@ -38,12 +38,17 @@ oracle_pred_quant_weights(
   for (int i = 0; i < n; i++)
     qw[i] = 1u << 8;
   for (int i = n - 1; i >= 0; i--)
-    for (int j = 0; j < nc[i]; j++)
+    for (int j = 0; j < nc[i]; j++) {
+      /* inter prediction: a neighbour in the reference frame (addressed behind the n
+       * predictors, see pred_process) takes no share (PCCTMC3Common.h:913-914) */
+      if (ni[3 * (size_t)i + j] >= n)
+        continue;
       /* int32 * uint64 -> uint64: the reference lands in the UNSIGNED
        * overload of divExp2RoundHalfInf (PCCMath.h:678-685): modular product,
        * logical shift -- it matters once the weights wrap (shares that add up
        * to more than the weight itself on a deep structure) */
       qw[ni[3 * (size_t)i + j]] += ((uint64_t)(int64_t)qnw[j] * qw[i] + 128u) >> 8;
+    }
 }
 
 static void
@@ -262,15 +267,35 @@ static int
 pred_process(
   int encoder, const gpcc_pred_params* p, int n, int c, const int32_t* nc, const int32_t* ni,
   const int32_t* nw, const int32_t* indexes, const int32_t* qp_off, int32_t* attrs,
-  int32_t* values, int8_t* icp_io, int32_t* modes)
+  int32_t* values, int8_t* icp_io, int32_t* modes,
+  /* attribute inter prediction (NULL: none): inter_ref [n][3] marks neighbours that live in
+   * the reference frame (ni is then a point index there), attrs_ref [n_ref] its reflectances */
+  const int32_t* inter_ref, const int32_t* attrs_ref, int n_ref)
 {
   if (c != 1 && c != 3)
     return -1;
+  /* Every place the reference reads a neighbour's value (predictReflectance
+   * PCCTMC3Common.h:555-585, predModeEligibleRefl AttributeCommon.cpp:176-210,
+   * decidePredModeRefl AttributeEncoder.cpp:663-717) takes the reference frame's reflectance
+   * for such a neighbour: here the frame's values are appended to the reconstruction array
+   * and the neighbour index points there. */
+  int32_t* ni_ext = NULL;
+  if (inter_ref) {
+    if (c != 1 || p->scalable_lifting_enabled_flag)
+      return -2; /* the reference has inter prediction in the reflectance driver only */
+    ni_ext = (int32_t*)malloc(sizeof(int32_t) * 3 * (size_t)n);
+    for (size_t t = 0; t < 3 * (size_t)n; t++)
+      ni_ext[t] = inter_ref[t] && (int)(t % 3) < nc[t / 3] ? n + ni[t] : ni[t];
+    ni = ni_ext;
+  } else
+    n_ref = 0;
   const int maxcand = p->max_num_direct_predictors + !p->direct_avg_predictor_disabled_flag;
   const int dis = p->direct_avg_predictor_disabled_flag != 0;
   const int64_t clip_max = ((int64_t)1 << p->bitdepth) - 1;
   uint64_t* qw = (uint64_t*)malloc(sizeof(uint64_t) * (size_t)n);
-  int32_t* rec = (int32_t*)calloc((size_t)n * c, sizeof(int32_t));  /* coding order */
+  int32_t* rec = (int32_t*)calloc(((size_t)n + n_ref) * c, sizeof(int32_t));  /* coding order */
+  for (int r = 0; r < n_ref; r++)
+    rec[(size_t)n + r] = attrs_ref[r];
   int32_t* src = (int32_t*)calloc((size_t)n * c, sizeof(int32_t));
   if (p->scalable_lifting_enabled_flag) {
     /* computeQuantizationWeightsScalable (PCCTMC3Common.h:858-891), whole slices */
@@ -509,6 +534,7 @@ pred_process(
       attrs[(size_t)indexes[i] * c + k] = rec[(size_t)i * c + k];
   free(qw);
   free(rec);
+  free(ni_ext);
   free(src);
   return 0;
 }
@@ -519,7 +545,7 @@ oracle_pred_forward(
   const int32_t* nw, const int32_t* indexes, const int32_t* qp_off, int32_t* attrs,
   int32_t* values, int8_t* icp, int32_t* modes)
 {
-  return pred_process(1, p, n, c, nc, ni, nw, indexes, qp_off, attrs, values, icp, modes);
+  return pred_process(1, p, n, c, nc, ni, nw, indexes, qp_off, attrs, values, icp, modes, NULL, NULL, 0);
 }
 
 int
@@ -528,5 +554,25 @@ oracle_pred_inverse(
   const int32_t* nw, const int32_t* indexes, const int32_t* qp_off, int32_t* attrs,
   int32_t* values, int8_t* icp, int32_t* modes)
 {
-  return pred_process(0, p, n, c, nc, ni, nw, indexes, qp_off, attrs, values, icp, modes);
+  return pred_process(0, p, n, c, nc, ni, nw, indexes, qp_off, attrs, values, icp, modes, NULL, NULL, 0);
+}
+
+/* The reflectance predicting transform with attribute inter prediction
+ * (encodeReflectancesPred / decodeReflectancesPred with enableAttrInterPred). */
+int
+oracle_pred_forward_inter(
+  const gpcc_pred_params* p, int32_t n, const int32_t* nc, const int32_t* ni, const int32_t* nw,
+  const int32_t* inter_ref, const int32_t* indexes, int32_t* attrs, const int32_t* attrs_ref,
+  int32_t n_ref, int32_t* values, int32_t* modes)
+{
+  return pred_process(1, p, n, 1, nc, ni, nw, indexes, NULL, attrs, values, NULL, modes, inter_ref, attrs_ref, n_ref);
+}
+
+int
+oracle_pred_inverse_inter(
+  const gpcc_pred_params* p, int32_t n, const int32_t* nc, const int32_t* ni, const int32_t* nw,
+  const int32_t* inter_ref, const int32_t* indexes, int32_t* attrs, const int32_t* attrs_ref,
+  int32_t n_ref, int32_t* values, int32_t* modes)
+{
+  return pred_process(0, p, n, 1, nc, ni, nw, indexes, NULL, attrs, values, NULL, modes, inter_ref, attrs_ref, n_ref);
 }

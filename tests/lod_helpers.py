@@ -119,13 +119,32 @@ def lift_inter(checker, forward, lf, lod, attrs, attrs_ref, coeffs=None):
     return co, a
 
 
+def pred_inter(forward, pp, lod, attrs_ref, attrs=None, values=None):
+    """the reflectance predicting transform with neighbours in a reference frame
+    -> (values [n,1] coding order, recon [n,1] point order, modes [n])"""
+    o = ol.oracle()
+    f = o.fn("pred_forward_inter" if forward else "pred_inverse_inter", C.c_int,
+             [C.c_void_p, C.c_int32, i32p, i32p, i32p, i32p, i32p, i32p, i32p, C.c_int32, i32p, i32p])
+    n = len(lod["nc"])
+    a = np.ascontiguousarray(attrs, dtype=np.int32).copy() if forward else np.zeros((n, 1), np.int32)
+    v = np.zeros((n, 1), np.int32) if forward else np.ascontiguousarray(values, dtype=np.int32).copy()
+    ar = np.ascontiguousarray(attrs_ref, dtype=np.int32).reshape(-1)
+    modes = np.zeros(n, np.int32)
+    rc = f(C.addressof(pp), n, lod["nc"], np.ascontiguousarray(lod["ni"]).reshape(-1),
+           np.ascontiguousarray(lod["w"].astype(np.int32)).reshape(-1),
+           np.ascontiguousarray(lod["ref"], dtype=np.int32).reshape(-1), lod["indexes"], a.reshape(-1), ar, len(ar),
+           v.reshape(-1), modes)
+    assert rc == 0, rc
+    return v, a, modes
+
+
 def ref_inter_roundtrip(lp, transform, qp, bitdepth, direct, xyz, attrs, xyz_ref, attrs_ref, search_range,
-                        frame_distance=1):
+                        frame_distance=1, threshold=64):
     """the reference operator (encode + decode) with attribute inter prediction, one component
     -> (payload, recon_enc, recon_dec)"""
     lib = ol.ref().lib
-    lib.ref_inter_roundtrip.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, i32p, i32p, C.c_int32,
-                                        i32p, i32p, C.c_int32, C.c_int32, C.c_int32, i32p, i32p, u8p, C.c_int32]
+    lib.ref_inter_roundtrip.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, i32p, i32p,
+                                        C.c_int32, i32p, i32p, C.c_int32, C.c_int32, C.c_int32, i32p, i32p, u8p, C.c_int32]
     xyz = np.ascontiguousarray(xyz, dtype=np.int32)
     xyz_ref = np.ascontiguousarray(xyz_ref, dtype=np.int32)
     a = np.ascontiguousarray(attrs, dtype=np.int32).reshape(-1)
@@ -134,7 +153,7 @@ def ref_inter_roundtrip(lp, transform, qp, bitdepth, direct, xyz, attrs, xyz_ref
     re = np.zeros(n, np.int32)
     rd = np.zeros(n, np.int32)
     pay = np.zeros(n * 8 + 4096, np.uint8)
-    ln = lib.ref_inter_roundtrip(C.addressof(lp), transform, qp, bitdepth, direct, xyz.reshape(-1), a, n,
+    ln = lib.ref_inter_roundtrip(C.addressof(lp), transform, qp, bitdepth, direct, threshold, xyz.reshape(-1), a, n,
                                  xyz_ref.reshape(-1), ar, len(xyz_ref), search_range, frame_distance, re, rd, pay, pay.size)
     return pay[:ln].tobytes(), re.reshape(n, 1), rd.reshape(n, 1)
 

@@ -112,3 +112,38 @@ def test_oracle_decoder_from_reference_symbols(name):
     xyz, attrs, lod, pp, values, want_rec, icp = run_reference(name)
     _, rec, _, _ = lh.oracle_pred(False, pp, lod, values=values, icp=icp)
     np.testing.assert_array_equal(rec, want_rec)
+
+
+@needs_ref
+@pytest.mark.parametrize("direct,qp", [(3, 4), (3, 28), (0, 28), (1, 10)])
+def test_inter_frame_predicting_transform_oracle_vs_reference_operator(direct, qp):
+    """attribute inter prediction, reflectance predicting transform: every neighbour
+    value the coder reads (the prediction, the eligibility test of the direct predictors, their
+    evaluation) is the reference frame's reflectance for a neighbour found there, and such a
+    neighbour takes no quantisation-weight share.  Oracle over its own inter LoD structure ==
+    the reference operator given the same reference frame: the symbols of its bitstream, the
+    reconstruction; the inverse returns it."""
+    from mpeg_pcc_tmc13_amd import lod_params, pred_params, synth
+    rng = np.random.default_rng(7)
+    for xyz, attrs in (synth.lidar_cloud(9000, seed=61), synth.dense_cloud(6000, seed=3, bits=7)):
+        attrs = attrs[:, :1].copy()
+        if attrs.max() > 255:
+            attrs = attrs >> 8
+        keep = rng.random(len(xyz)) > 0.1
+        xr = np.clip(xyz + rng.integers(-2, 3, size=xyz.shape), 0, None)[keep].astype(np.int32)
+        ar = np.clip(attrs + rng.integers(-6, 7, size=attrs.shape), 0, 255)[keep].astype(np.int32)
+        lp = lod_params(lifting=False, intra_range=64)
+        lp.intra_lod_prediction_skip_layers = 0
+        payload, rec_enc, rec_dec = lh.ref_inter_roundtrip(lp, 1, qp, 8, direct, xyz, attrs, xr, ar, 64, 1, threshold=4)
+        np.testing.assert_array_equal(rec_enc, rec_dec)
+        want = lh.ref_entropy_decode_symbols(payload[lh.ref_last_abh_size():], len(xyz), 1)
+        lod = lh.oracle_lod_generate_inter(xyz, xr, lp, 64, 1)
+        pp = pred_params(lod["npl"], qp=qp, chroma_offset=0, bitdepth=8, threshold=4, direct=direct, icp=False,
+                         max_levels=lp.num_detail_levels_minus1 + 1)
+        v, rec, modes = lh.pred_inter(True, pp, lod, ar, attrs=attrs)
+        np.testing.assert_array_equal(v, want)
+        np.testing.assert_array_equal(rec, rec_enc)
+        if direct and qp < 20:
+            assert (modes > 0).sum() > 100   # direct predictors (possibly in the reference frame) were chosen
+        _, inv, _ = lh.pred_inter(False, pp, lod, ar, values=v)
+        np.testing.assert_array_equal(inv, rec)
