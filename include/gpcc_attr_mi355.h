@@ -297,6 +297,33 @@ int gpcc_lod_build(
   int32_t* neigh_count, int32_t* neigh_index, int32_t* neigh_weight,
   int32_t* indexes, int32_t* num_points_in_lod, int32_t* num_lods);
 
+/* AttributeLods::generate with attribute INTER prediction
+ * (AttributeInterPredParams::enableAttrInterPred; buildPredictorsFast with
+ * interRef, PCCTMC3Common.h:2348-2376, 2396-2400; the reference-frame part of
+ * computeNearestNeighbors :1270-1292, :1606-1796; updatePredictors :2286-2293;
+ * blendWeights :654-656): the neighbour search also takes candidates from the
+ * reference frame xyz_ref [n_ref][3] (AttributeInterPredParams::
+ * referencePointCloud, point order), search_range =
+ * AttributeBrickHeader::attrInterPredSearchRange (it replaces both LoD search
+ * ranges of the block), frame_distance = AttributeInterPredParams::
+ * frameDistance.  Outputs as gpcc_lod_build, plus inter_ref [n][3]
+ * (PCCNeighborInfo::interFrameRef): for a neighbour with the flag set
+ * neigh_index is a POINT index of the reference frame (PCCNeighborInfo::
+ * pointIndex) and its distance carried the frame distance into the weights.
+ * Not combined with scalable lifting / canonical point order
+ * (GPCC_ERR_UNSUPPORTED).
+ * STATUS (round 3): bit-exact against the oracle on the MI355X
+ * (tests/test_zz_gpu_inter_lod.py) and under the CPU wavefront emulator
+ * (tests/test_emu_lod.py).  No transform entry consumes inter_ref yet: the
+ * lifting / predicting transforms over such a structure exist in the oracle
+ * only, and the shims keep inter slices on the reference path. */
+int gpcc_lod_build_inter(
+  gpcc_ctx* ctx, const gpcc_lod_params* params, const int32_t* xyz, int32_t n,
+  const int32_t* xyz_ref, int32_t n_ref, int32_t search_range,
+  int32_t frame_distance, int32_t* neigh_count, int32_t* neigh_index,
+  int32_t* neigh_weight, int32_t* indexes, int32_t* num_points_in_lod,
+  int32_t* num_lods, int32_t* inter_ref);
+
 /* PCCPredictor::computeWeights (PCCTMC3Common.h:589-633) for n predictors:
  * squared distances in neigh_weight (uint64 [n][3]) -> 8-bit weights
  * (int32 [n][3]); neigh_count is updated in place (far neighbours are

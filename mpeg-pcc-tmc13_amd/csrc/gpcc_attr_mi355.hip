@@ -2156,8 +2156,17 @@ struct LodDeviceOut {
   int32_t* weight = nullptr;       // [n][3]
   int32_t* indexes = nullptr;      // [n] predictor -> point
   int32_t* error = nullptr;        // device error word of the sub-sampling kernel
+  int32_t* inter_ref = nullptr;    // [n][3] neighbour lives in the reference frame (inter builds only)
   std::vector<int32_t> npl;        // cumulative LoD sizes, coarse to fine
   size_t arena_end = 0;            // first free byte behind the build's workspace
+};
+
+// the reference frame of attribute inter prediction (host memory, point order)
+struct LodInterFrame {
+  const int32_t* xyz;
+  int32_t n;
+  int32_t search_range;    // abh.attrInterPredSearchRange: replaces both LoD search ranges
+  int32_t frame_distance;  // AttributeInterPredParams::frameDistance
 };
 
 // AttributeLods::generate on the device; results stay there.  `extra_bytes`
@@ -2165,7 +2174,8 @@ struct LodDeviceOut {
 int
 lod_build_core(
   gpcc_ctx* ctx, const gpcc_lod_params* lp, const int32_t* xyz, int32_t n,
-  size_t extra_bytes, LodDeviceOut* out, bool xyz_on_device = false)
+  size_t extra_bytes, LodDeviceOut* out, bool xyz_on_device = false,
+  const LodInterFrame* frame = nullptr)
 {
   if (!ctx)
     return fail(GPCC_ERR_INVALID_ARG, "ctx is null");
@@ -2173,6 +2183,17 @@ lod_build_core(
     return fail(GPCC_ERR_INVALID_ARG, "null buffer or n <= 0");
   if (n > kMaxPoints)
     return fail(GPCC_ERR_INVALID_ARG, "more than 2^29 points per call");
+  if (frame) {
+    if (!frame->xyz || frame->n <= 0 || frame->n > kMaxPoints || frame->search_range < 0 || xyz_on_device)
+      return fail(GPCC_ERR_INVALID_ARG, "reference frame: null, empty, too large or a negative search range");
+    if (lp->scalable_lifting_enabled_flag || lp->canonical_point_order_flag || lp->max_points_per_sort_log2_plus1)
+      return fail(
+        GPCC_ERR_UNSUPPORTED,
+        "inter prediction together with scalable lifting / canonical point order stays on the reference CPU path");
+    for (int64_t i = 0; i < (int64_t)frame->n * 3; i++)
+      if (frame->xyz[i] < 0 || frame->xyz[i] >= (1 << 21))
+        return fail(GPCC_ERR_INVALID_ARG, "reference frame coordinate outside [0, 2^21)");
+  }
   const bool scalable = lp->scalable_lifting_enabled_flag != 0;
   if (!scalable && (lp->lod_decimation_type < 0 || lp->lod_decimation_type > 2))
     return fail(GPCC_ERR_INVALID_ARG, "lod_decimation_type out of range");
@@ -2200,10 +2221,13 @@ lod_build_core(
   // Workspace from the context's arena (no allocation per call once it has
   // grown).  The Morton sort below carves its own scratch from the arena's
   // start; everything that has to outlive it is placed behind that region.
-  const size_t sort_region = 32 * (size_t)n + ((size_t)1 << 20);
+  const size_t NF = frame ? (size_t)frame->n : 0;
+  const size_t sort_region = 32 * std::max((size_t)n, NF) + ((size_t)1 << 20);
   {
-    // 26 arrays, the largest 24 B per point (see the DM list below)
-    const size_t mine = (size_t)n * (scalable ? 244 : 232) + 64 * 1024;
+    // 26 arrays, the largest 24 B per point (see the DM list below); an inter build adds
+    // the reference frame (positions twice, biased positions, codes, order, list, boxes)
+    // and the flags of the result
+    const size_t mine = (size_t)n * (scalable ? 244 : 232) + 64 * 1024 + (frame ? NF * 56 + (size_t)n * 12 + 64 * 1024 : 0);
     int rc0 = ensure_arena(ctx, sort_region + mine + extra_bytes);
     if (rc0)
       return rc0;
@@ -2253,6 +2277,16 @@ lod_build_core(
     DM(int32_t, d_neigh_index, 3 * N)
     DM(int32_t, d_weight, 3 * N)
     DM(int32_t, d_bpos_lod, scalable ? 3 * N : 1)
+    // attribute inter prediction: the reference frame, sorted
+    const int nfb0 = ((int)NF + 31) >> 5, nfb1 = (nfb0 + 31) >> 5, nfb2 = (nfb1 + 31) >> 5;
+    DM(int32_t, d_fxyz, 3 * NF + 1)
+    DM(int64_t, d_fcode, NF + 1)
+    DM(int32_t, d_forder, NF + 1)
+    DM(int32_t, d_fpos, 3 * NF + 1)
+    DM(int32_t, d_fbpos, 3 * NF + 1)
+    DM(int32_t, d_flist, NF + 1)
+    DM(int32_t, d_fbox, (size_t)2 * 3 * (nfb0 + nfb1 + nfb2 + 3) + 1)
+    DM(int32_t, d_inter_ref, frame ? 3 * N : 1)
 #undef DM
     int32_t* d_ticket = d_small;
     int32_t* d_error = d_small + 8;
@@ -2291,6 +2325,41 @@ lod_build_core(
       lod_gather_pos_kernel<<<grid_for(n, 256), 256, 0, st>>>(
         n, d_xyz, d_order, lp->lod_neigh_bias[0], lp->lod_neigh_bias[1],
         lp->lod_neigh_bias[2], d_pos, d_bpos, d_list_a);
+    }
+    // the reference frame of inter prediction: Morton order, biased positions, the list
+    // 0, 1, 2, ... and one box hierarchy over it (buildPredictorsFast :2352-2376,
+    // computeNearestNeighbors :1270-1292) -- the same at every level of detail
+    int32_t* fbox[3][2] = {};
+    if (frame) {
+      HIP_TRY(h2d_user(ctx, d_fxyz, frame->xyz, sizeof(int32_t) * 3 * NF, st));
+      int32_t fmx = 0;
+      for (size_t i = 0; i < 3 * NF; i++)
+        fmx = std::max(fmx, frame->xyz[i]);
+      const int saved = ctx->morton_bits;
+      ctx->morton_bits = std::max(1, 3 * bitlen64((uint64_t)fmx));
+      const int64_t offs[2] = {0, (int64_t)NF};
+      int r = gpcc_dev_attr_morton_sort_impl(ctx, 1, offs, d_fxyz, d_fcode, d_forder);
+      ctx->morton_bits = saved;
+      if (r)
+        return r;
+      lod_gather_pos_kernel<<<grid_for((int64_t)NF, 256), 256, 0, st>>>(
+        (int)NF, d_fxyz, d_forder, lp->lod_neigh_bias[0], lp->lod_neigh_bias[1],
+        lp->lod_neigh_bias[2], d_fpos, d_fbpos, d_flist);
+      {
+        int32_t* p = d_fbox;
+        const int cnt[3] = {nfb0 + 1, nfb1 + 1, nfb2 + 1};
+        for (int lev = 0; lev < 3; lev++)
+          for (int m = 0; m < 2; m++) {
+            fbox[lev][m] = p;
+            p += 3 * cnt[lev];
+          }
+      }
+      lod_box0_kernel<<<grid_for(std::max(nfb0, 1), 256), 256, 0, st>>>(
+        (int)NF, d_flist, d_fbpos, fbox[0][0], fbox[0][1]);
+      lod_box_up_kernel<<<grid_for(std::max(nfb1, 1), 256), 256, 0, st>>>(
+        nfb0, fbox[0][0], fbox[0][1], fbox[1][0], fbox[1][1]);
+      lod_box_up_kernel<<<1, 256, 0, st>>>(nfb1, fbox[1][0], fbox[1][1], fbox[2][0], fbox[2][1]);
+      HIP_TRY(hipGetLastError());
     }
 
     // box storage: [list 0 = retained, 1 = refine][level][min/max]
@@ -2486,9 +2555,21 @@ lod_build_core(
         nc.shift3 = 3 * (1 + shift_bits0);
         nc.boundary = std::min(63, nc.shift3 + 21);
         nc.distribution = lp->prediction_with_distribution_enabled;
-        nc.range_inter = lp->inter_lod_search_range;
-        nc.range_intra = lp->intra_lod_search_range;
+        nc.range_inter = frame ? frame->search_range : lp->inter_lod_search_range;
+        nc.range_intra = frame ? frame->search_range : lp->intra_lod_search_range;
         nc.intra = lod >= lp->intra_lod_prediction_skip_layers;
+        if (frame) {
+          nc.frame_code = d_fcode;
+          nc.frame_order = d_forder;
+          nc.frame_bpos = d_fbpos;
+          nc.frame_identity = d_flist;
+          nc.n_frame = (int)NF;
+          nc.frame_range = frame->search_range;
+          nc.frame_boundary = std::min(63, nc.shift3 + 9);
+          for (int lev = 0; lev < 3; lev++)
+            for (int m = 0; m < 2; m++)
+              nc.box_frame[lev][m] = fbox[lev][m];
+        }
         nc.max_neigh = lp->num_pred_nearest_neighbours_minus1 + 1;
         for (int lev = 0; lev < 3; lev++)
           for (int m = 0; m < 2; m++) {
@@ -2517,7 +2598,10 @@ lod_build_core(
           }
         {
           Timer tm(ctx, level_name("lod_nn_search", lod));
-          lod_nn_search_kernel<false><<<grid_for(n_ref, 256), 256, 0, st>>>(nc);
+          if (frame)
+            lod_nn_search_kernel<false, true><<<grid_for(n_ref, 256), 256, 0, st>>>(nc);
+          else
+            lod_nn_search_kernel<false><<<grid_for(n_ref, 256), 256, 0, st>>>(nc);
         }
       }
       if (n_ret > 0)
@@ -2527,20 +2611,31 @@ lod_build_core(
     }
     {
       Timer tm(ctx, "lod_finalise");
-      lod_finalise_kernel<<<grid_for(n, 256), 256, 0, st>>>(
-        n, 0, d_pred_count, d_pred_point, d_pt2pred, d_pred_dist2, d_neigh_index);
+      if (frame)
+        lod_finalise_inter_kernel<<<grid_for(n, 256), 256, 0, st>>>(
+          n, d_pred_count, d_pred_point, d_pt2pred, d_pred_dist2, d_neigh_index, d_inter_ref,
+          frame->frame_distance);
+      else
+        lod_finalise_kernel<<<grid_for(n, 256), 256, 0, st>>>(
+          n, 0, d_pred_count, d_pred_point, d_pt2pred, d_pred_dist2, d_neigh_index);
     }
     lod_compute_weights_kernel<<<grid_for(n, 256), 256, 0, st>>>(
       n, d_pred_count, d_pred_dist2, d_weight);
-    if (lp->attr_encoding == 1 && lp->pred_weight_blending_enabled_flag)
-      lod_blend_weights_kernel<<<grid_for(n, 256), 256, 0, st>>>(
-        n, d_pred_count, d_pred_point, d_xyz, d_weight);
+    if (lp->attr_encoding == 1 && lp->pred_weight_blending_enabled_flag) {
+      if (frame)
+        lod_blend_weights_inter_kernel<<<grid_for(n, 256), 256, 0, st>>>(
+          n, d_pred_count, d_pred_point, d_xyz, d_fxyz, d_weight);
+      else
+        lod_blend_weights_kernel<<<grid_for(n, 256), 256, 0, st>>>(
+          n, d_pred_count, d_pred_point, d_xyz, d_weight);
+    }
     HIP_TRY(hipGetLastError());
     out->count = d_pred_count;
     out->neigh_index = d_neigh_index;
     out->weight = d_weight;
     out->indexes = d_indexes;
     out->error = d_error;
+    out->inter_ref = frame ? d_inter_ref : nullptr;
     out->npl.assign(npl.rbegin(), npl.rend());
     out->arena_end = ar_used;
     return GPCC_OK;
@@ -2571,6 +2666,38 @@ gpcc_lod_build_impl(
   HIP_TRY(d2h_user(ctx, neigh_index, o.neigh_index, sizeof(int32_t) * 3 * N, st));
   HIP_TRY(d2h_user(ctx, neigh_weight, o.weight, sizeof(int32_t) * 3 * N, st));
   HIP_TRY(d2h_user(ctx, indexes, o.indexes, sizeof(int32_t) * N, st));
+  HIP_TRY(hipMemcpyAsync(&h_err, o.error, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (h_err)
+    return fail(GPCC_ERR_HIP, "a dependency wait in the LoD sub-sampling kernel expired");
+  *num_lods = (int)o.npl.size();
+  for (size_t i = 0; i < o.npl.size(); i++)
+    num_points_in_lod[i] = o.npl[i];
+  return GPCC_OK;
+}
+
+static int
+gpcc_lod_build_inter_impl(
+  gpcc_ctx* ctx, const gpcc_lod_params* lp, const int32_t* xyz, int32_t n, const int32_t* xyz_ref,
+  int32_t n_ref, int32_t search_range, int32_t frame_distance, int32_t* neigh_count,
+  int32_t* neigh_index, int32_t* neigh_weight, int32_t* indexes, int32_t* num_points_in_lod,
+  int32_t* num_lods, int32_t* inter_ref)
+{
+  if (!neigh_count || !neigh_index || !neigh_weight || !indexes || !num_points_in_lod || !num_lods || !inter_ref)
+    return fail(GPCC_ERR_INVALID_ARG, "null output buffer");
+  LodInterFrame frame{xyz_ref, n_ref, search_range, frame_distance};
+  LodDeviceOut o;
+  int r = lod_build_core(ctx, lp, xyz, n, 0, &o, false, &frame);
+  if (r)
+    return r;
+  hipStream_t st = ctx->stream;
+  const size_t N = (size_t)n;
+  int32_t h_err = 0;
+  HIP_TRY(d2h_user(ctx, neigh_count, o.count, sizeof(int32_t) * N, st));
+  HIP_TRY(d2h_user(ctx, neigh_index, o.neigh_index, sizeof(int32_t) * 3 * N, st));
+  HIP_TRY(d2h_user(ctx, neigh_weight, o.weight, sizeof(int32_t) * 3 * N, st));
+  HIP_TRY(d2h_user(ctx, indexes, o.indexes, sizeof(int32_t) * N, st));
+  HIP_TRY(d2h_user(ctx, inter_ref, o.inter_ref, sizeof(int32_t) * 3 * N, st));
   HIP_TRY(hipMemcpyAsync(&h_err, o.error, sizeof(int32_t), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   if (h_err)
@@ -3202,6 +3329,21 @@ gpcc_lod_build(
   int32_t* indexes, int32_t* num_points_in_lod, int32_t* num_lods)
 {
   return counted(ctx, gpcc_lod_build_impl(ctx, lp, xyz, n, neigh_count, neigh_index, neigh_weight, indexes, num_points_in_lod, num_lods), n);
+}
+
+int
+gpcc_lod_build_inter(
+  gpcc_ctx* ctx, const gpcc_lod_params* lp, const int32_t* xyz, int32_t n, const int32_t* xyz_ref,
+  int32_t n_ref, int32_t search_range, int32_t frame_distance, int32_t* neigh_count,
+  int32_t* neigh_index, int32_t* neigh_weight, int32_t* indexes, int32_t* num_points_in_lod,
+  int32_t* num_lods, int32_t* inter_ref)
+{
+  return counted(
+    ctx,
+    gpcc_lod_build_inter_impl(
+      ctx, lp, xyz, n, xyz_ref, n_ref, search_range, frame_distance, neigh_count, neigh_index,
+      neigh_weight, indexes, num_points_in_lod, num_lods, inter_ref),
+    n);
 }
 
 int

@@ -673,7 +673,23 @@ struct NnCtx {
   uint32_t node_mask;        // clears the bits below the octree level of this LoD
   int32_t unit_bias;         // lodNeighBias == 1: the squared distances ARE the test values
   int64_t prune_dist;        // 3 * (max_neigh_range_minus1 + 1) << 2 * lod
+  // attribute inter prediction only (lod_nn_search_kernel<.., true>): the reference
+  // frame in Morton order (computeNearestNeighbors :1270-1292, :1606-1796)
+  const int64_t* frame_code;     // [n_frame] sorted Morton codes
+  const int32_t* frame_order;    // [n_frame] point index (in the reference frame) of each entry
+  const int32_t* frame_bpos;     // [n_frame][3] biased positions, sorted order
+  const int32_t* frame_identity; // [n_frame] 0, 1, 2, ... (the list the window scan walks)
+  int32_t n_frame;
+  int32_t frame_range;           // abh.attrInterPredSearchRange
+  int32_t frame_boundary;        // min(63, shift3 + 9): the 8^3-cell inter atlas
+  const int32_t* box_frame[3][2];
 };
+
+// A candidate of the reference frame carries this bit in its index from the moment it is
+// met: the pair (index, localRef) of the reference in one word, so the duplicate tests,
+// the sorting and the replacement rules need no second array (indices are < 2^29).  In
+// pred_point it marks a neighbour whose value is a point index of the reference frame.
+constexpr int32_t kFrameTag = 1 << 30;
 
 struct NnState {
   int32_t idx[6];
@@ -782,6 +798,7 @@ box_dist1(const int32_t* const box[2], int b, const int32_t* p)
 // the bucketed window scans of :1436-1522 / :1551-1604 over a list whose
 // biased positions are bpos[list[k]]; candidates are reported as `k` (list
 // position) or list[k] (packed index)
+template<int TAG = 0>
 __device__ __forceinline__ void
 window_scan(
   NnState& s, const int32_t* const box[3][2], const int32_t* __restrict__ bpos,
@@ -818,7 +835,7 @@ window_scan(
 #pragma unroll
             for (int u = 0; u < 8; u++)
               if (kb + u <= h1)
-                nn_visit(s, distribution, check, d8[u], report_packed ? pk8[u] : kb + u);
+                nn_visit(s, distribution, check, d8[u], (report_packed ? pk8[u] : kb + u) | TAG);
           }
         }
       }
@@ -848,7 +865,7 @@ window_scan(
 #pragma unroll
             for (int u = 0; u < 8; u++)
               if (kb - u >= h0)
-                nn_visit(s, distribution, check, d8[u], report_packed ? pk8[u] : kb - u);
+                nn_visit(s, distribution, check, d8[u], (report_packed ? pk8[u] : kb - u) | TAG);
           }
         }
       }
@@ -943,7 +960,7 @@ lod_atlas_limit_kernel(NnCtx cx, long long* atlas_limit)
 #ifndef GPCC_NN_WAVES
 #define GPCC_NN_WAVES 4
 #endif
-template<bool SCALABLE>
+template<bool SCALABLE, bool INTER = false>
 __global__ __launch_bounds__(256, GPCC_NN_WAVES) void
 lod_nn_search_kernel(NnCtx cx)
 {
@@ -1058,6 +1075,58 @@ lod_nn_search_kernel(NnCtx cx)
       window_scan(s, cx.box_ref, cx.bpos, cx.refine, bp, w0, w1, +1, distribution, false, true);
     }
 
+    if (INTER) {
+      // candidates of the reference frame, no duplicate tests (:1606-1796).
+      // (a) The inter-frame atlas.  Its block test shifts a neighbour CELL by the intra
+      // atlas' 21 bits (:1627) although the block id was formed with 9: the two agree
+      // in block 0 only, so the atlas answers for cells of the first 8^3 block alone,
+      // and a neighbour cell outside that block aliases into it (the address is
+      // masked, :155-158).
+      if ((code >> cx.frame_boundary) == 0) {
+        const uint64_t base = morton3d_add((uint64_t)cell, ~0ull);
+        for (int nb0 = 0; nb0 < 27; nb0++) {
+          const int64_t nb = (int64_t)morton3d_add(base, kNeigh[nb0]);
+          if ((nb >> kAtlasBits) != 0)
+            continue;
+          const int64_t want = nb & 0x1ff;
+          int lo = 0, hi = cx.n_frame;
+          while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if ((cx.frame_code[mid] >> cx.shift3) < want)
+              lo = mid + 1;
+            else
+              hi = mid;
+          }
+          for (int k = lo; k < cx.n_frame && (cx.frame_code[k] >> cx.shift3) == want; k++)
+            nn_visit(s, distribution, false, norm1_i3(bp, &cx.frame_bpos[3 * (size_t)k]), k | kFrameTag);
+        }
+      }
+      // (b) the window around the first entry that does not precede the point; the
+      // left part is walked upwards too
+      if (cx.n_frame > 0) {
+        int lo = 0, hi = cx.n_frame;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (cx.frame_code[mid] < code)
+            lo = mid + 1;
+          else
+            hi = mid;
+        }
+        const int jr = min(lo, cx.n_frame - 1);
+        const int k1 = min(cx.n_frame - 1, max(0, jr + cx.frame_range));
+        window_scan<kFrameTag>(
+          s, cx.box_frame, cx.frame_bpos, cx.frame_identity, bp, jr, k1, +1, distribution, false, false);
+        const int l0 = min(cx.n_frame - 1, max(0, jr - 1));
+        const int l1 = min(cx.n_frame - 1, max(0, l0 - cx.frame_range));
+        window_scan<kFrameTag>(
+          s, cx.box_frame, cx.frame_bpos, cx.frame_identity, bp, l1, l0, +1, distribution, false, false);
+      }
+    }
+    // biased position of a candidate: the reference frame's for a tagged one
+    auto pos_of = [&](int32_t v) -> const int32_t* {
+      return INTER && (v & kFrameTag) ? &cx.frame_bpos[3 * (size_t)(v & ~kFrameTag)] : &cx.bpos[3 * (size_t)v];
+    };
+
     int count = (s.idx[0] != -1) + (s.idx[1] != -1) + (s.idx[2] != -1);
     count = min(cx.max_neigh, count);
     if (distribution) {
@@ -1065,7 +1134,7 @@ lod_nn_search_kernel(NnCtx cx)
 #pragma unroll
       for (int m = 3; m < 6; m++)
         if (m < c1 && s.dist[m] == INT64_MAX)
-          s.dist[m] = norm1_i3(bp, &cx.bpos[3 * (size_t)s.idx[m]]);
+          s.dist[m] = norm1_i3(bp, pos_of(s.idx[m]));
 #pragma unroll
       for (int m = 3; m < 6; m++)
 #pragma unroll
@@ -1095,7 +1164,7 @@ lod_nn_search_kernel(NnCtx cx)
         for (int h = 0; h < 6; h++) {
           dir[h] = -1;
           if (h < numend) {
-            const int32_t* o = &cx.bpos[3 * (size_t)s.idx[h]];
+            const int32_t* o = pos_of(s.idx[h]);
             dir[h] = ((o[0] - bp[0] >= 0) << 2) + ((o[1] - bp[1] >= 0) << 1) + (o[2] - bp[2] >= 0);
           }
         }
@@ -1142,8 +1211,8 @@ lod_nn_search_kernel(NnCtx cx)
     int32_t pp[3] = {0, 0, 0};
     uint64_t pw[3] = {0, 0, 0};
     for (int h = 0; h < count; h++) {
-      pp[h] = cx.order[s.idx[h]];
-      pw[h] = (uint64_t)norm2_i3(&cx.bpos[3 * (size_t)s.idx[h]], bp);
+      pp[h] = INTER && (s.idx[h] & kFrameTag) ? (cx.frame_order[s.idx[h] & ~kFrameTag] | kFrameTag) : cx.order[s.idx[h]];
+      pw[h] = (uint64_t)norm2_i3(pos_of(s.idx[h]), bp);
     }
     if (SCALABLE) {
       bool cut = false;
@@ -1215,6 +1284,75 @@ lod_finalise_kernel(
       const int p = pred_point[3 * (size_t)i + k];
       neigh_index[3 * (size_t)i + k] = k < c ? pt2pred[p] : p;
     }
+  }
+}
+
+// ... with attribute inter prediction: a neighbour in the reference frame (tagged in
+// pred_point) keeps its point index there, is flagged in inter_ref [n][3] and moves away
+// by the frame distance (updatePredictors :2286-2293)
+__global__ __launch_bounds__(256) void
+lod_finalise_inter_kernel(
+  int n, int32_t* count, const int32_t* __restrict__ pred_point,
+  const int32_t* __restrict__ pt2pred, uint64_t* dist2, int32_t* neigh_index, int32_t* inter_ref,
+  int frame_distance)
+{
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += gridDim.x * blockDim.x) {
+    int c = count[i];
+    uint64_t w0 = dist2[3 * (size_t)i];
+    if (c < 2) {
+      w0 = 1;
+    } else if (w0 == 0) {
+      c = 1;
+      w0 = 1;
+    }
+    dist2[3 * (size_t)i] = w0;
+    count[i] = c;
+    for (int k = 0; k < 3; k++) {
+      const int p = pred_point[3 * (size_t)i + k];
+      const bool frame = (p & kFrameTag) != 0;
+      const int pi = p & ~kFrameTag;
+      neigh_index[3 * (size_t)i + k] = k < c && !frame ? pt2pred[pi] : pi;
+      inter_ref[3 * (size_t)i + k] = frame;
+      if (k < c && frame)
+        dist2[3 * (size_t)i + k] += (uint64_t)(int64_t)frame_distance;
+    }
+  }
+}
+
+// blendWeights with neighbours in the reference frame: their positions are that
+// frame's (:654-656)
+__global__ __launch_bounds__(256) void
+lod_blend_weights_inter_kernel(
+  int n, const int32_t* __restrict__ neigh_count, const int32_t* __restrict__ neigh_point,
+  const int32_t* __restrict__ xyz, const int32_t* __restrict__ xyz_frame, int32_t* weight)
+{
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += gridDim.x * blockDim.x) {
+    if (neigh_count[i] != 3)
+      continue;
+    const int32_t* q[3];
+    for (int k = 0; k < 3; k++) {
+      const int p = neigh_point[3 * (size_t)i + k];
+      q[k] = p & kFrameTag ? &xyz_frame[3 * (size_t)(p & ~kFrameTag)] : &xyz[3 * (size_t)p];
+    }
+    int64_t d01 = 0, d02 = 0, d12 = 0;
+    for (int c = 0; c < 3; c++) {
+      const int64_t a = (int64_t)q[0][c] - q[1][c], b = (int64_t)q[0][c] - q[2][c], e = (int64_t)q[1][c] - q[2][c];
+      d01 += a * a;
+      d02 += b * b;
+      d12 += e * e;
+    }
+    constexpr int dd = 10, bb = 1, cc = 5;
+    const int b1 = d01 <= d02 ? bb : cc;
+    const int b2 = d01 <= d12 ? cc : bb;
+    const int b3 = d02 <= d12 ? bb : cc;
+    const int w0 = weight[3 * (size_t)i], w1 = weight[3 * (size_t)i + 1], w2 = weight[3 * (size_t)i + 2];
+    const int v0 = (w0 * dd + w1 * (16 - dd - b2) + w2 * b3) >> 4;
+    const int v1 = (w0 * b1 + w1 * dd + w2 * (16 - dd - b3)) >> 4;
+    weight[3 * (size_t)i] = v0;
+    weight[3 * (size_t)i + 1] = v1;
+    weight[3 * (size_t)i + 2] = 256 - v0 - v1;
   }
 }
 

@@ -170,6 +170,25 @@ class Context:
                                             C.byref(nl)))
         return dict(nc=nc, ni=ni, w=w, indexes=idx, npl=npl[:nl.value].copy())
 
+    def lod_build_inter(self, params, xyz, xyz_ref, search_range, frame_distance=1):
+        """AttributeLods::generate with attribute inter prediction -> dict as lod_build plus
+        ref [n,3] (neighbour lives in the reference frame; ni is then a point index there)"""
+        xyz = np.ascontiguousarray(xyz, dtype=np.int32)
+        xyz_ref = np.ascontiguousarray(xyz_ref, dtype=np.int32)
+        n = xyz.shape[0]
+        nc = np.zeros(n, np.int32)
+        ni = np.zeros((n, 3), np.int32)
+        w = np.zeros((n, 3), np.int32)
+        idx = np.zeros(n, np.int32)
+        npl = np.zeros(32, np.int32)
+        ref = np.zeros((n, 3), np.int32)
+        nl = C.c_int32()
+        _lib.check(self._lib.gpcc_lod_build_inter(self._h, C.byref(params), xyz.ctypes.data, n, xyz_ref.ctypes.data,
+                                                  xyz_ref.shape[0], search_range, frame_distance, nc.ctypes.data,
+                                                  ni.ctypes.data, w.ctypes.data, idx.ctypes.data, npl.ctypes.data,
+                                                  C.byref(nl), ref.ctypes.data))
+        return dict(nc=nc, ni=ni, w=w, indexes=idx, npl=npl[:nl.value].copy(), ref=ref)
+
     def estimate_dist2(self, xyz, sampling_period=100, search_range=128, percentile=0.85):
         """pcc::estimateDist2 (encoder.cpp:1203 uses period 100, range 128) -> shift bits"""
         xyz = np.ascontiguousarray(xyz, dtype=np.int32)

@@ -130,3 +130,220 @@ lod_emu_scalable_build(
     free(p);
   return e == hipSuccess ? 0 : -5;
 }
+
+// ---- attribute inter prediction ---------------------------------------------------------
+// lod_nn_search_kernel<false, true> + lod_finalise_inter_kernel + the frame preparation, as
+// lod_build_core launches them.  The level loop below is this harness' own (the library's is
+// HIP host code inside gpcc_attr_mi355.hip) and covers the periodic and the centroid
+// sub-samplers; the distance sub-sampler uses buffer instructions the emulator does not model --
+// the search, which is what inter prediction changes, does not depend on who made the lists.
+extern "C" int
+lod_emu_inter_build(
+  const gpcc_lod_params* lp, const int32_t* xyz, int32_t n, const int32_t* xyz_ref, int32_t n_ref,
+  int32_t search_range, int32_t frame_distance, int32_t* neigh_count, int32_t* neigh_index,
+  int32_t* neigh_weight, int32_t* indexes, int32_t* num_points_in_lod, int32_t* num_lods,
+  int32_t* inter_ref)
+{
+  if (lp->scalable_lifting_enabled_flag || (lp->lod_decimation_type != 1 && lp->lod_decimation_type != 2) || n <= 0
+      || n_ref <= 0)
+    return -1;
+  std::vector<void*> blocks;
+  const size_t N = (size_t)n, NF = (size_t)n_ref;
+  auto sorted = [&](const int32_t* p, size_t cnt, int64_t* code, int32_t* order) {
+    std::vector<std::pair<int64_t, int32_t>> v(cnt);
+    for (size_t i = 0; i < cnt; i++)
+      v[i] = {morton_of(p + 3 * i), (int32_t)i};
+    std::sort(v.begin(), v.end());
+    for (size_t i = 0; i < cnt; i++) {
+      code[i] = v[i].first;
+      order[i] = v[i].second;
+    }
+  };
+  auto boxes_of = [&](int cnt, int32_t* box[3][2]) {
+    const int b0 = (cnt + 31) >> 5, b1 = (b0 + 31) >> 5, b2 = (b1 + 31) >> 5;
+    int32_t* p = carve<int32_t>(&blocks, (size_t)2 * 3 * (b0 + b1 + b2 + 3));
+    const int c3[3] = {b0 + 1, b1 + 1, b2 + 1};
+    for (int lev = 0; lev < 3; lev++)
+      for (int m = 0; m < 2; m++) {
+        box[lev][m] = p;
+        p += 3 * c3[lev];
+      }
+  };
+  auto build_boxes = [&](int32_t* box[3][2], const int32_t* list, int cnt, const int32_t* bpos) {
+    const int c0 = (cnt + 31) >> 5, c1 = (c0 + 31) >> 5;
+    hipLaunchKernelGGL(lod_box0_kernel, dim3(lod_grid(std::max(c0, 1), 256)), dim3(256), 0, nullptr, cnt, list, bpos,
+                       box[0][0], box[0][1]);
+    hipLaunchKernelGGL(lod_box_up_kernel, dim3(lod_grid(std::max(c1, 1), 256)), dim3(256), 0, nullptr, c0,
+                       (const int32_t*)box[0][0], (const int32_t*)box[0][1], box[1][0], box[1][1]);
+    hipLaunchKernelGGL(lod_box_up_kernel, dim3(1), dim3(256), 0, nullptr, c1, (const int32_t*)box[1][0],
+                       (const int32_t*)box[1][1], box[2][0], box[2][1]);
+  };
+
+  int64_t* d_code = carve<int64_t>(&blocks, N);
+  int32_t* d_order = carve<int32_t>(&blocks, N);
+  sorted(xyz, N, d_code, d_order);
+  int32_t* d_pos = carve<int32_t>(&blocks, 3 * N);
+  int32_t* d_bpos = carve<int32_t>(&blocks, 3 * N);
+  int32_t* d_list_a = carve<int32_t>(&blocks, N + 1);
+  int32_t* d_list_b = carve<int32_t>(&blocks, N + 1);
+  int32_t* d_refine = carve<int32_t>(&blocks, N + 1);
+  uint8_t* d_flags = carve<uint8_t>(&blocks, N + 1);
+  uint8_t* d_heads = carve<uint8_t>(&blocks, N + 1);
+  int32_t* d_nxt0 = carve<int32_t>(&blocks, N + 2);
+  int32_t* d_nj[2] = {carve<int32_t>(&blocks, N + 2), carve<int32_t>(&blocks, N + 2)};
+  int64_t* d_ret_key = carve<int64_t>(&blocks, N + 1);
+  int32_t* d_counts = carve<int32_t>(&blocks, 64);
+  unsigned long long* d_scan = carve<unsigned long long>(&blocks, 1024);
+  memset(d_counts, 0, sizeof(int32_t) * 64);
+  memset(d_scan, 0, sizeof(unsigned long long) * 1024);
+  long long* d_atlas_limit = carve<long long>(&blocks, 1);
+  int32_t* box_ret[3][2];
+  int32_t* box_ref[3][2];
+  int32_t* box_frame[3][2];
+  boxes_of(n, box_ret);
+  boxes_of(n, box_ref);
+  boxes_of(n_ref, box_frame);
+  int32_t* d_pred_count = carve<int32_t>(&blocks, N);
+  int32_t* d_pred_point = carve<int32_t>(&blocks, 3 * N);
+  uint64_t* d_pred_dist2 = carve<uint64_t>(&blocks, 3 * N);
+  int32_t* d_pt2pred = carve<int32_t>(&blocks, N);
+  int32_t* d_indexes = carve<int32_t>(&blocks, N);
+  int32_t* d_neigh_index = carve<int32_t>(&blocks, 3 * N);
+  int32_t* d_weight = carve<int32_t>(&blocks, 3 * N);
+  int32_t* d_inter_ref = carve<int32_t>(&blocks, 3 * N);
+  // the reference frame
+  int64_t* d_fcode = carve<int64_t>(&blocks, NF);
+  int32_t* d_forder = carve<int32_t>(&blocks, NF);
+  sorted(xyz_ref, NF, d_fcode, d_forder);
+  int32_t* d_fpos = carve<int32_t>(&blocks, 3 * NF);
+  int32_t* d_fbpos = carve<int32_t>(&blocks, 3 * NF);
+  int32_t* d_flist = carve<int32_t>(&blocks, NF + 1);
+
+  const int b0 = lp->lod_neigh_bias[0], b1 = lp->lod_neigh_bias[1], b2 = lp->lod_neigh_bias[2];
+  hipLaunchKernelGGL(lod_gather_pos_kernel, dim3(lod_grid(n, 256)), dim3(256), 0, nullptr, n, xyz,
+                     (const int32_t*)d_order, b0, b1, b2, d_pos, d_bpos, d_list_a);
+  hipLaunchKernelGGL(lod_gather_pos_kernel, dim3(lod_grid(n_ref, 256)), dim3(256), 0, nullptr, n_ref, xyz_ref,
+                     (const int32_t*)d_forder, b0, b1, b2, d_fpos, d_fbpos, d_flist);
+  build_boxes(box_frame, d_flist, n_ref, d_fbpos);
+
+  std::vector<int32_t> npl;
+  npl.push_back(n);
+  int32_t* d_input = d_list_a;
+  int32_t* d_ret = d_list_b;
+  int n_in = n, n_idx = 0, scan_epoch = 0;
+  const int max_levels = lp->num_detail_levels_minus1 + 1;
+  for (int lod = 0; n_in > 0 && lod < max_levels; lod++) {
+    const int start = n_idx;
+    int n_ret = 0, n_ref_l = 0;
+    const int shift_bits0 = lp->dist2 + lp->attr_dist2_delta + lod;
+    if (lod == max_levels - 1 || (lp->lod_decimation_type != 1 && n_in == 1)) {
+      memcpy(d_refine + start, d_input, sizeof(int32_t) * n_in);
+      n_ref_l = n_in;
+    } else {
+      const int period = lp->lod_sampling_period[lod];
+      if (lp->lod_decimation_type == 1) {
+        hipLaunchKernelGGL(lod_flag_periodic_kernel, dim3(lod_grid(n_in, 256)), dim3(256), 0, nullptr, n_in, period, d_flags);
+      } else {
+        LodCtx lc{};
+        lc.code = d_code;
+        lc.pos = d_pos;
+        lc.input = d_input;
+        lc.n_in = n_in;
+        lc.shift3 = 3 * (shift_bits0 + 1);
+        lc.flags = d_flags;
+        hipLaunchKernelGGL(lod_centroid_next_kernel, dim3(lod_grid(n_in + 1, 256)), dim3(256), 0, nullptr, lc, period, d_nxt0);
+        memset(d_heads, 0, (size_t)n_in + 1);
+        d_heads[0] = 1;
+        const int32_t* cur = d_nxt0;
+        for (int r = 0, reach = 1; reach < n_in; r++, reach *= 2) {
+          hipLaunchKernelGGL(lod_centroid_jump_kernel, dim3(lod_grid(n_in + 1, 256)), dim3(256), 0, nullptr, n_in, cur,
+                             d_nj[r & 1], d_heads);
+          cur = d_nj[r & 1];
+        }
+        hipLaunchKernelGGL(lod_centroid_pick_kernel, dim3(lod_grid(n_in, 256)), dim3(256), 0, nullptr, lc, shift_bits0,
+                           (const int32_t*)d_nxt0, (const uint8_t*)d_heads, 1);
+      }
+      scan_epoch++;
+      const int grid = (int)std::min<int64_t>(1024, ((int64_t)n_in + 1023) / 1024);
+      hipLaunchKernelGGL(lod_partition_kernel, dim3(std::max(grid, 1)), dim3(256), 0, nullptr, n_in,
+                         (const uint8_t*)d_flags, (const int32_t*)d_input, d_ret, d_refine + start, d_counts, d_scan,
+                         scan_epoch);
+      n_ret = d_counts[0];
+      n_ref_l = n_in - n_ret;
+    }
+    n_idx += n_ref_l;
+    if (n_ref_l > 0) {
+      NnCtx nc{};
+      nc.n = n;
+      nc.code = d_code;
+      nc.order = d_order;
+      nc.bpos = d_bpos;
+      nc.retained = d_ret;
+      nc.ret_key = d_ret_key;
+      nc.n_ret = n_ret;
+      nc.refine = d_refine + start;
+      nc.n_ref = n_ref_l;
+      nc.start = start;
+      nc.shift3 = 3 * (1 + shift_bits0);
+      nc.boundary = std::min(63, nc.shift3 + 21);
+      nc.distribution = lp->prediction_with_distribution_enabled;
+      nc.range_inter = search_range;
+      nc.range_intra = search_range;
+      nc.intra = lod >= lp->intra_lod_prediction_skip_layers;
+      nc.max_neigh = lp->num_pred_nearest_neighbours_minus1 + 1;
+      for (int lev = 0; lev < 3; lev++)
+        for (int m = 0; m < 2; m++) {
+          nc.box_ret[lev][m] = box_ret[lev][m];
+          nc.box_ref[lev][m] = box_ref[lev][m];
+          nc.box_frame[lev][m] = box_frame[lev][m];
+        }
+      nc.atlas_limit = d_atlas_limit;
+      nc.pred_count = d_pred_count;
+      nc.pred_point = d_pred_point;
+      nc.pred_dist2 = d_pred_dist2;
+      nc.pt2pred = d_pt2pred;
+      nc.indexes = d_indexes;
+      nc.frame_code = d_fcode;
+      nc.frame_order = d_forder;
+      nc.frame_bpos = d_fbpos;
+      nc.frame_identity = d_flist;
+      nc.n_frame = n_ref;
+      nc.frame_range = search_range;
+      nc.frame_boundary = std::min(63, nc.shift3 + 9);
+      if (n_ret > 0) {
+        hipLaunchKernelGGL(lod_ret_keys_kernel, dim3(lod_grid(n_ret, 256)), dim3(256), 0, nullptr, n_ret,
+                           (const int32_t*)d_ret, (const int64_t*)d_code, nc.shift3, d_ret_key);
+        build_boxes(box_ret, d_ret, n_ret, d_bpos);
+      }
+      if (nc.intra)
+        build_boxes(box_ref, d_refine + start, n_ref_l, d_bpos);
+      *d_atlas_limit = INT64_MAX;
+      if (n_ret > 0)
+        hipLaunchKernelGGL(lod_atlas_limit_kernel, dim3(lod_grid(n_ret, 256)), dim3(256), 0, nullptr, nc, d_atlas_limit);
+      hipLaunchKernelGGL((lod_nn_search_kernel<false, true>), dim3(lod_grid(n_ref_l, 256)), dim3(256), 0, nullptr, nc);
+    }
+    if (n_ret > 0)
+      npl.push_back(n_ret);
+    std::swap(d_input, d_ret);
+    n_in = n_ret;
+  }
+  hipLaunchKernelGGL(lod_finalise_inter_kernel, dim3(lod_grid(n, 256)), dim3(256), 0, nullptr, n, d_pred_count,
+                     (const int32_t*)d_pred_point, (const int32_t*)d_pt2pred, d_pred_dist2, d_neigh_index, d_inter_ref,
+                     frame_distance);
+  hipLaunchKernelGGL(lod_compute_weights_kernel, dim3(lod_grid(n, 256)), dim3(256), 0, nullptr, n, d_pred_count,
+                     (const uint64_t*)d_pred_dist2, d_weight);
+  if (lp->attr_encoding == 1 && lp->pred_weight_blending_enabled_flag)
+    hipLaunchKernelGGL(lod_blend_weights_inter_kernel, dim3(lod_grid(n, 256)), dim3(256), 0, nullptr, n,
+                       (const int32_t*)d_pred_count, (const int32_t*)d_pred_point, xyz, xyz_ref, d_weight);
+  memcpy(neigh_count, d_pred_count, sizeof(int32_t) * N);
+  memcpy(neigh_index, d_neigh_index, sizeof(int32_t) * 3 * N);
+  memcpy(neigh_weight, d_weight, sizeof(int32_t) * 3 * N);
+  memcpy(indexes, d_indexes, sizeof(int32_t) * N);
+  memcpy(inter_ref, d_inter_ref, sizeof(int32_t) * 3 * N);
+  *num_lods = (int)npl.size();
+  for (size_t i = 0; i < npl.size(); i++)
+    num_points_in_lod[i] = npl[npl.size() - 1 - i];
+  for (void* p : blocks)
+    free(p);
+  return 0;
+}

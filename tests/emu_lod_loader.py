@@ -21,7 +21,29 @@ def lib():
         _lib.lod_emu_scalable_build.argtypes = [C.c_void_p, _i32p, C.c_int32, _i32p, _i32p, _i32p, _i32p, _i32p,
                                                 C.POINTER(C.c_int32)]
         _lib.lod_emu_scalable_build.restype = C.c_int
+        _lib.lod_emu_inter_build.argtypes = [C.c_void_p, _i32p, C.c_int32, _i32p, C.c_int32, C.c_int32, C.c_int32, _i32p,
+                                             _i32p, _i32p, _i32p, _i32p, C.POINTER(C.c_int32), _i32p]
+        _lib.lod_emu_inter_build.restype = C.c_int
     return _lib
+
+
+def inter_build(lp, xyz, xyz_ref, search_range, frame_distance=1):
+    """the inter-prediction LoD build (periodic / centroid sub-sampling) under the emulator
+    -> dict as lod_helpers.oracle_lod_generate_inter (weights int32)"""
+    xyz = np.ascontiguousarray(xyz, dtype=np.int32)
+    xyz_ref = np.ascontiguousarray(xyz_ref, dtype=np.int32)
+    n = len(xyz)
+    nc = np.zeros(n, np.int32)
+    ni = np.zeros((n, 3), np.int32)
+    w = np.zeros((n, 3), np.int32)
+    idx = np.zeros(n, np.int32)
+    npl = np.zeros(32, np.int32)
+    ref = np.zeros((n, 3), np.int32)
+    nl = C.c_int32()
+    rc = lib().lod_emu_inter_build(C.addressof(lp), xyz.reshape(-1), n, xyz_ref.reshape(-1), len(xyz_ref), search_range,
+                                   frame_distance, nc, ni.reshape(-1), w.reshape(-1), idx, npl, C.byref(nl), ref.reshape(-1))
+    assert rc == 0, rc
+    return dict(nc=nc, ni=ni, w=w, indexes=idx, npl=npl[:nl.value].copy(), ref=ref)
 
 
 def scalable_build(lp, xyz):

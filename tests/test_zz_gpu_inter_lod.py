@@ -1,0 +1,62 @@
+"""GPU parity of gpcc_lod_build_inter (AttributeLods::generate with attribute inter prediction,
+SURVEY §8 f3, the LoD half) against the oracle (pinned to the compiled reference by
+tests/test_oracle_lod.py; the kernels also run under the CPU emulator, tests/test_emu_lod.py).
+The comparison runs in a child process: a fault in the newest device path must not take the
+rest of the GPU tier with it (the file also sorts last)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import json, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import conftest
+import numpy as np
+import lod_helpers as lh
+from mpeg_pcc_tmc13_amd import context, lod_params, synth
+ctx = context(0)
+rng = np.random.default_rng(5)
+clouds = [synth.random_cloud(5, seed=24, bits=2)[0], synth.random_cloud(1, seed=1, bits=3)[0],
+          synth.random_cloud(3000, seed=2, bits=5)[0], synth.random_cloud(400, seed=9, bits=2, dup_fraction=0.3)[0],
+          synth.dense_cloud(20000, seed=4, bits=8)[0], synth.lidar_cloud(15000, seed=3)[0],
+          synth.random_cloud(3000, seed=8, bits=20)[0], synth.dense_cloud(200000, seed=14, bits=10)[0]]
+variants = [dict(), dict(decimation=1), dict(decimation=2), dict(distribution=False), dict(bias=(1, 2, 1)),
+            dict(neighbours=2), dict(lifting=False, intra_range=64, blend=True), dict(levels=1)]
+cases = refs = 0
+for xyz in clouds:
+    keep = rng.random(len(xyz)) > 0.1
+    frame = np.clip(xyz + rng.integers(-2, 3, size=xyz.shape), 0, None)[keep].astype(np.int32) if len(xyz) > 3 else xyz.copy()
+    for kw in (variants if len(xyz) < 100000 else variants[:1]):
+        for search_range in ((0, 5, 128) if len(xyz) < 100000 else (128,)):
+            lp = lod_params(**kw)
+            if kw.get("lifting") is False:
+                lp.intra_lod_prediction_skip_layers = 0
+            o = lh.oracle_lod_generate_inter(xyz, frame, lp, search_range, 2)
+            g = ctx.lod_build_inter(lp, xyz, frame, search_range, 2)
+            for k in ("npl", "indexes", "nc", "ni", "ref"):
+                assert np.array_equal(g[k], o[k]), (k, kw, search_range, len(xyz))
+            assert np.array_equal(g["w"].astype(np.uint32), (o["w"] & 0xffffffff).astype(np.uint32)), ("w", kw, search_range, len(xyz))
+            cases += 1
+            refs += int(o["ref"].sum())
+# the intra build on the same context afterwards is untouched
+lp = lod_params()
+xyz = clouds[4]
+o = lh.oracle_lod_generate(xyz, lp)
+g = ctx.lod_build(lp, xyz)
+for k in ("npl", "indexes", "nc", "ni"):
+    assert np.array_equal(g[k], o[k]), ("intra after inter", k)
+print(json.dumps(dict(cases=cases, refs=refs)))
+'''
+
+
+def test_inter_frame_lod_build_vs_oracle():
+    r = subprocess.run([sys.executable, "-c", WORKER, ROOT], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["cases"] > 100 and out["refs"] > 100000
