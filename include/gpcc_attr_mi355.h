@@ -324,6 +324,32 @@ int gpcc_lod_build_inter(
   int32_t* neigh_weight, int32_t* indexes, int32_t* num_points_in_lod,
   int32_t* num_lods, int32_t* inter_ref);
 
+/* Reflectance lifting over such a structure (encodeReflectancesLift /
+ * decodeReflectancesLift with enableAttrInterPred, AttributeEncoder.cpp:
+ * 1543-1648, AttributeDecoder.cpp:780-857; one component -- the reference's
+ * colour driver takes no reference frame): predictors and inter_ref as
+ * gpcc_lod_build_inter returns them, attrs_ref [n_ref] the reference frame's
+ * reflectances in ITS point order.  PCCLiftPredict takes the frame's value
+ * for a flagged neighbour; PCCLiftUpdate and the quantisation weights leave
+ * it out (PCCTMC3Common.h:735-740, :799-800, :845-846).  Buffers otherwise
+ * as gpcc_lift_forward / gpcc_lift_inverse with c = 1.
+ * STATUS (round 3): the kernels are the intra ones (the frame's values sit
+ * behind the n working values and flagged neighbours point there); that
+ * arrangement runs under the CPU emulator against the oracle
+ * (tests/test_emu_lod.py) and the entry's first hardware run is
+ * tests/test_zz_gpu_inter_lod.py in the round-end tier. */
+int gpcc_lift_forward_inter(
+  gpcc_ctx* ctx, const gpcc_lift_params* params, int32_t n,
+  const int32_t* neigh_count, const int32_t* neigh_index,
+  const int32_t* neigh_weight, const int32_t* inter_ref, const int32_t* indexes,
+  int32_t* attrs, const int32_t* attrs_ref, int32_t n_ref, int32_t* coeffs);
+int gpcc_lift_inverse_inter(
+  gpcc_ctx* ctx, const gpcc_lift_params* params, int32_t n,
+  const int32_t* neigh_count, const int32_t* neigh_index,
+  const int32_t* neigh_weight, const int32_t* inter_ref, const int32_t* indexes,
+  int32_t* attrs, const int32_t* attrs_ref, int32_t n_ref,
+  const int32_t* coeffs);
+
 /* PCCPredictor::computeWeights (PCCTMC3Common.h:589-633) for n predictors:
  * squared distances in neigh_weight (uint64 [n][3]) -> 8-bit weights
  * (int32 [n][3]); neigh_count is updated in place (far neighbours are

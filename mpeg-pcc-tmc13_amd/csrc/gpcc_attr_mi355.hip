@@ -1071,11 +1071,19 @@ check_lift_params(const gpcc_lift_params* p, int n, int c)
   return GPCC_OK;
 }
 
+// Attribute inter prediction (n_frame > 0): the working arrays get n_frame entries
+// BEHIND the n predictors.  a[n + r] holds the reference frame's attribute r in fixed
+// point (h_frame, host memory, [n_frame][C]) and the caller has pointed every neighbour
+// that lives in that frame at n + r: PCCLiftPredict then reads the frame's value
+// (PCCTMC3Common.h:735-740) and what PCCLiftUpdate / PCCComputeQuantizationWeights skip for
+// such a neighbour (:799-800, :845-846) lands in entries nobody reads -- the kernels are
+// the intra ones, untouched.
 template<int C>
 int
 launch_lift(
   gpcc_ctx* ctx, bool encoder, const gpcc_lift_params* p, int n,
-  const LiftDev& d, int8_t* d_lcp_io, char* scratch)
+  const LiftDev& d, int8_t* d_lcp_io, char* scratch, int n_frame = 0,
+  const int64_t* h_frame = nullptr)
 {
   hipStream_t st = ctx->stream;
   LiftCtx cx{};
@@ -1140,12 +1148,15 @@ launch_lift(
   Arena ar;
   ar.base = scratch;
   ar.cap = ~size_t(0);
-  cx.a = ar.take<int64_t>((size_t)n * C);
-  cx.qw = ar.take<unsigned long long>(n);
-  cx.uw = ar.take<unsigned long long>(n);
-  cx.up = ar.take<unsigned long long>((size_t)n * C);
+  const size_t n_ext = (size_t)n + (size_t)n_frame;
+  cx.a = ar.take<int64_t>(n_ext * C);
+  cx.qw = ar.take<unsigned long long>(n_ext);
+  cx.uw = ar.take<unsigned long long>(n_ext);
+  cx.up = ar.take<unsigned long long>(n_ext * C);
   cx.lcp_sums = ar.take<long long>(2 * GPCC_MAX_LODS);
   cx.rsqrt = &ctx->d_lut->rsqrt;
+  if (n_frame > 0)
+    HIP_TRY(h2d_user(ctx, cx.a + (size_t)n * C, h_frame, sizeof(int64_t) * (size_t)n_frame * C, st));
 
   const int* npl = cx.npl;
   auto grid = [&](int items) { return grid_for(std::max(items, 1), 256); };
@@ -1218,7 +1229,10 @@ host_lift(
   gpcc_ctx* ctx, bool encoder, const gpcc_lift_params* p, int n, int c,
   const int32_t* nc, const int32_t* ni, const int32_t* nw,
   const int32_t* indexes, const int32_t* qp_off, int32_t* attrs,
-  int32_t* coeffs, int8_t* lcp)
+  int32_t* coeffs, int8_t* lcp,
+  // attribute inter prediction (null: none): inter_ref [n][3] marks the neighbours that live in
+  // the reference frame (ni is then a point index there), attrs_ref [n_frame][c] its attributes
+  const int32_t* inter_ref = nullptr, const int32_t* attrs_ref = nullptr, int n_frame = 0)
 {
   if (!ctx)
     return fail(GPCC_ERR_INVALID_ARG, "ctx is null");
@@ -1230,12 +1244,40 @@ host_lift(
   const bool lcp_on = c == 3 && p->last_component_prediction_enabled_flag;
   if (lcp_on && !lcp)
     return fail(GPCC_ERR_INVALID_ARG, "lcp_coeffs is null");
+  if (inter_ref) {
+    if (!attrs_ref || n_frame <= 0 || n_frame > kMaxPoints)
+      return fail(GPCC_ERR_INVALID_ARG, "reference frame: null, empty or too large");
+    if (c != 1 || p->scalable_lifting_enabled_flag)
+      return fail(
+        GPCC_ERR_UNSUPPORTED,
+        "inter prediction exists in the reference's reflectance lifting driver only, and not with scalable lifting");
+  } else
+    n_frame = 0;
   for (int i = 0; i < n; i++) {
     if (nc[i] < 0 || nc[i] > 3 || indexes[i] < 0 || indexes[i] >= n)
       return fail(GPCC_ERR_INVALID_ARG, "bad neighbour count / index table");
-    for (int j = 0; j < nc[i]; j++)
-      if (ni[3 * (size_t)i + j] < 0 || ni[3 * (size_t)i + j] >= i)
+    for (int j = 0; j < nc[i]; j++) {
+      const int32_t v = ni[3 * (size_t)i + j];
+      if (inter_ref && inter_ref[3 * (size_t)i + j]) {
+        if (v < 0 || v >= n_frame)
+          return fail(GPCC_ERR_INVALID_ARG, "a neighbour outside the reference frame");
+      } else if (v < 0 || v >= i)
         return fail(GPCC_ERR_INVALID_ARG, "a neighbour does not precede its predictor");
+    }
+  }
+  // neighbours in the reference frame are addressed behind the n predictors (launch_lift)
+  std::vector<int32_t> ni_frame;
+  std::vector<int64_t> a_frame;
+  if (inter_ref) {
+    ni_frame.assign(ni, ni + (size_t)n * 3);
+    for (int i = 0; i < n; i++)
+      for (int j = 0; j < nc[i]; j++)
+        if (inter_ref[3 * (size_t)i + j])
+          ni_frame[3 * (size_t)i + j] += n;
+    ni = ni_frame.data();
+    a_frame.resize((size_t)n_frame * c);
+    for (size_t t = 0; t < a_frame.size(); t++)
+      a_frame[t] = (int64_t)attrs_ref[t] * 256;  // << kFixedPointAttributeShift
   }
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
@@ -1255,7 +1297,7 @@ host_lift(
     d.coeffs = ar.take<int32_t>((size_t)n * c);
     d_lcp = ar.take<int8_t>(GPCC_MAX_LODS);
     scratch = ar.base ? ar.base + ar.used : nullptr;
-    ar.used += lift_scratch_bytes(n, c);
+    ar.used += lift_scratch_bytes(n + n_frame, c);
   };
   LiftDev d{};
   int32_t *d_nc, *d_ni, *d_nw, *d_ix, *d_qp;
@@ -1285,12 +1327,14 @@ host_lift(
       HIP_TRY(hipMemcpyAsync(d_lcp, lcp, GPCC_MAX_LODS, hipMemcpyHostToDevice, st));
   }
   switch (c) {
-  case 1: rcode = launch_lift<1>(ctx, encoder, p, n, d, d_lcp, scratch); break;
+  case 1: rcode = launch_lift<1>(ctx, encoder, p, n, d, d_lcp, scratch, n_frame, a_frame.data()); break;
   case 2: rcode = launch_lift<2>(ctx, encoder, p, n, d, d_lcp, scratch); break;
   default: rcode = launch_lift<3>(ctx, encoder, p, n, d, d_lcp, scratch); break;
   }
   if (rcode)
     return rcode;
+  // (a_frame was staged by h2d_user: through the context's pinned buffer, or copied before the
+  // call returned -- the vector may go)
   HIP_TRY(d2h_user(ctx, attrs, d.attrs, sizeof(int32_t) * n * c, st));
   if (encoder) {
     HIP_TRY(d2h_user(ctx, coeffs, d.coeffs, sizeof(int32_t) * n * c, st));
@@ -3312,6 +3356,39 @@ gpcc_lift_inverse(
   int32_t* attrs, const int32_t* coeffs, const int8_t* lcp_coeffs)
 {
   return counted(ctx, gpcc_lift_inverse_impl(ctx, params, n, c, neigh_count, neigh_index, neigh_weight, indexes, qp_off, attrs, coeffs, lcp_coeffs), n);
+}
+
+int
+gpcc_lift_forward_inter(
+  gpcc_ctx* ctx, const gpcc_lift_params* params, int32_t n, const int32_t* neigh_count,
+  const int32_t* neigh_index, const int32_t* neigh_weight, const int32_t* inter_ref,
+  const int32_t* indexes, int32_t* attrs, const int32_t* attrs_ref, int32_t n_ref, int32_t* coeffs)
+{
+  if (!inter_ref)
+    return counted(ctx, fail(GPCC_ERR_INVALID_ARG, "inter_ref is null"), n);
+  return counted(
+    ctx,
+    host_lift(
+      ctx, true, params, n, 1, neigh_count, neigh_index, neigh_weight, indexes, nullptr, attrs, coeffs,
+      nullptr, inter_ref, attrs_ref, n_ref),
+    n);
+}
+
+int
+gpcc_lift_inverse_inter(
+  gpcc_ctx* ctx, const gpcc_lift_params* params, int32_t n, const int32_t* neigh_count,
+  const int32_t* neigh_index, const int32_t* neigh_weight, const int32_t* inter_ref,
+  const int32_t* indexes, int32_t* attrs, const int32_t* attrs_ref, int32_t n_ref,
+  const int32_t* coeffs)
+{
+  if (!inter_ref)
+    return counted(ctx, fail(GPCC_ERR_INVALID_ARG, "inter_ref is null"), n);
+  return counted(
+    ctx,
+    host_lift(
+      ctx, false, params, n, 1, neigh_count, neigh_index, neigh_weight, indexes, nullptr, attrs,
+      const_cast<int32_t*>(coeffs), nullptr, inter_ref, attrs_ref, n_ref),
+    n);
 }
 
 int

@@ -347,3 +347,87 @@ lod_emu_inter_build(
     free(p);
   return 0;
 }
+
+// ---- reflectance lifting with neighbours in a reference frame -----------------------------
+// The arrangement host_lift / launch_lift (gpcc_attr_mi355.hip) use for attribute inter
+// prediction: the frame's attributes in fixed point BEHIND the n working values, flagged
+// neighbours pointed there, the intra kernels unchanged.  One QP layer, one component.
+extern "C" int
+lift_emu_inter(
+  const gpcc_lift_params* p, int32_t encoder, int32_t n, const int32_t* nc, const int32_t* ni,
+  const int32_t* nw, const int32_t* inter_ref, const int32_t* indexes, int32_t* attrs,
+  const int32_t* attrs_ref, int32_t n_ref, int32_t* coeffs)
+{
+  if (p->num_qp_layers != 1 || p->scalable_lifting_enabled_flag || n <= 0 || n_ref <= 0)
+    return -1;
+  std::vector<void*> blocks;
+  const size_t N = (size_t)n, NE = N + (size_t)n_ref;
+  int32_t* d_ni = carve<int32_t>(&blocks, 3 * N);
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < 3; j++)
+      d_ni[3 * i + j] = ni[3 * i + j] + (j < nc[i] && inter_ref[3 * i + j] ? n : 0);
+  RsqrtLut* lut = (RsqrtLut*)carve<char>(&blocks, sizeof(RsqrtLut));
+  {
+    const uint16_t r3[96] = {GPCC_RSQRT_R3};
+    const uint32_t rc[96] = {GPCC_RSQRT_RC};
+    memcpy(lut->r3, r3, sizeof(r3));
+    memcpy(lut->rc, rc, sizeof(rc));
+  }
+  LiftCtx cx{};
+  cx.n = n;
+  cx.c = 1;
+  cx.num_lods = p->num_lods;
+  for (int l = 0; l < p->num_lods; l++)
+    cx.npl[l] = p->num_points_in_lod[l];
+  cx.num_ranges = 1;
+  cx.lcp_enabled = 0;
+  cx.bitdepth = p->bitdepth;
+  cx.num_qp_layers = 1;
+  memcpy(cx.layer_qp, p->layer_qp, sizeof(cx.layer_qp));
+  cx.max_qp = p->max_qp;
+  cx.fixed_point_qp_offset = p->fixed_point_qp_offset;
+  cx.nc = nc;
+  cx.ni = d_ni;
+  cx.nw = nw;
+  cx.indexes = indexes;
+  cx.qp_off = nullptr;
+  cx.attrs = attrs;
+  cx.coeffs = coeffs;
+  cx.lcp = carve<int8_t>(&blocks, GPCC_MAX_LODS);
+  cx.a = carve<int64_t>(&blocks, NE);
+  cx.qw = carve<unsigned long long>(&blocks, NE);
+  cx.uw = carve<unsigned long long>(&blocks, NE);
+  cx.up = carve<unsigned long long>(&blocks, NE);
+  cx.lcp_sums = carve<long long>(&blocks, 2 * GPCC_MAX_LODS);
+  cx.rsqrt = lut;
+  for (int r = 0; r < n_ref; r++)
+    cx.a[N + r] = (int64_t)attrs_ref[r] * 256;
+  const int* npl = cx.npl;
+  auto grid = [&](int items) { return dim3(lod_grid(std::max(items, 1), 256)); };
+  hipLaunchKernelGGL(lift_init_kernel, grid(n), dim3(256), 0, nullptr, cx, encoder);
+  for (int l = p->num_lods - 1; l >= 1; l--)
+    if (npl[l] > npl[l - 1])
+      hipLaunchKernelGGL(lift_quant_weights_kernel, grid(npl[l] - npl[l - 1]), dim3(256), 0, nullptr, cx, npl[l - 1], npl[l]);
+  if (encoder)
+    for (int l = p->num_lods - 1; l >= 1; l--) {
+      if (npl[l] == npl[l - 1])
+        continue;
+      const int cnt = npl[l] - npl[l - 1];
+      hipLaunchKernelGGL(lift_predict_kernel<1>, grid(cnt), dim3(256), 0, nullptr, cx, npl[l - 1], npl[l], 1);
+      hipLaunchKernelGGL(lift_update_scatter_kernel<1>, grid(cnt), dim3(256), 0, nullptr, cx, npl[l - 1], npl[l]);
+      hipLaunchKernelGGL(lift_update_apply_kernel<1>, grid(npl[l - 1]), dim3(256), 0, nullptr, cx, npl[l - 1], 1);
+    }
+  hipLaunchKernelGGL(lift_quantise_kernel<1>, grid(n), dim3(256), 0, nullptr, cx, encoder);
+  for (int l = 1; l < p->num_lods; l++) {
+    if (npl[l] == npl[l - 1])
+      continue;
+    const int cnt = npl[l] - npl[l - 1];
+    hipLaunchKernelGGL(lift_update_scatter_kernel<1>, grid(cnt), dim3(256), 0, nullptr, cx, npl[l - 1], npl[l]);
+    hipLaunchKernelGGL(lift_update_apply_kernel<1>, grid(npl[l - 1]), dim3(256), 0, nullptr, cx, npl[l - 1], 0);
+    hipLaunchKernelGGL(lift_predict_kernel<1>, grid(cnt), dim3(256), 0, nullptr, cx, npl[l - 1], npl[l], 0);
+  }
+  hipLaunchKernelGGL(lift_writeback_kernel, grid(n), dim3(256), 0, nullptr, cx);
+  for (void* b : blocks)
+    free(b);
+  return 0;
+}

@@ -24,7 +24,26 @@ def lib():
         _lib.lod_emu_inter_build.argtypes = [C.c_void_p, _i32p, C.c_int32, _i32p, C.c_int32, C.c_int32, C.c_int32, _i32p,
                                              _i32p, _i32p, _i32p, _i32p, C.POINTER(C.c_int32), _i32p]
         _lib.lod_emu_inter_build.restype = C.c_int
+        _lib.lift_emu_inter.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _i32p, _i32p, _i32p, _i32p, _i32p, _i32p, _i32p,
+                                        C.c_int32, _i32p]
+        _lib.lift_emu_inter.restype = C.c_int
     return _lib
+
+
+def lift_inter(forward, lf, lod, attrs_ref, attrs=None, coeffs=None):
+    """reflectance lifting with neighbours in a reference frame, the library's arrangement under the
+    emulator -> (coeffs [n,1], recon [n,1])"""
+    n = len(lod["nc"])
+    a = np.ascontiguousarray(attrs, dtype=np.int32).copy().reshape(-1) if forward else np.zeros(n, np.int32)
+    co = np.zeros(n, np.int32) if forward else np.ascontiguousarray(coeffs, dtype=np.int32).copy().reshape(-1)
+    ar = np.ascontiguousarray(attrs_ref, dtype=np.int32).reshape(-1)
+    rc = lib().lift_emu_inter(C.addressof(lf), int(forward), n, np.ascontiguousarray(lod["nc"], dtype=np.int32),
+                              np.ascontiguousarray(lod["ni"], dtype=np.int32).reshape(-1),
+                              np.ascontiguousarray(np.asarray(lod["w"]).astype(np.int32)).reshape(-1),
+                              np.ascontiguousarray(lod["ref"], dtype=np.int32).reshape(-1),
+                              np.ascontiguousarray(lod["indexes"], dtype=np.int32), a, ar, len(ar), co)
+    assert rc == 0, rc
+    return co.reshape(n, 1), a.reshape(n, 1)
 
 
 def inter_build(lp, xyz, xyz_ref, search_range, frame_distance=1):

@@ -80,3 +80,31 @@ def test_inter_frame_search_under_the_emulator(vi):
                                           err_msg=f"{name} {kw} range={search_range} w")
             refs += int(o["ref"].sum())
     assert refs > 1000
+
+
+@pytest.mark.parametrize("qp", [10, 34])
+def test_inter_frame_lifting_arrangement_under_the_emulator(qp):
+    """gpcc_lift_forward_inter / _inverse_inter keep the lifting kernels as they are: the reference
+    frame's reflectances sit behind the n working values and a flagged neighbour points there, so
+    the prediction reads the frame and what the update step and the quantisation weights would have
+    skipped lands in entries nobody reads.  That arrangement, with the library's kernels under the
+    emulator == the oracle (pinned to the reference operator's payload, tests/test_oracle_lift.py)."""
+    import oracle_loader as ol
+    from mpeg_pcc_tmc13_amd import lift_params, lod_params, synth
+    rng = np.random.default_rng(7)
+    for xyz, attrs in (synth.lidar_cloud(9000, seed=61), synth.dense_cloud(6000, seed=3, bits=7), synth.random_cloud(5, seed=2, bits=3)):
+        attrs = attrs[:, :1].copy()
+        if attrs.max() > 255:
+            attrs = attrs >> 8
+        keep = rng.random(len(xyz)) > 0.1 if len(xyz) > 5 else np.ones(len(xyz), bool)
+        xr = np.clip(xyz + rng.integers(-2, 3, size=xyz.shape), 0, None)[keep].astype(np.int32)
+        ar = np.clip(attrs + rng.integers(-6, 7, size=attrs.shape), 0, 255)[keep].astype(np.int32)
+        lp = lod_params()
+        lod = lh.oracle_lod_generate_inter(xyz, xr, lp, 64, 1)
+        lf = lift_params(lod["npl"], qp=qp, chroma_offset=0, lcp=False, bitdepth=8)
+        co, rec = lh.lift_inter(ol.oracle(), True, lf, lod, attrs, ar)
+        eco, erec = el.lift_inter(True, lf, lod, ar, attrs=attrs)
+        np.testing.assert_array_equal(eco, co)
+        np.testing.assert_array_equal(erec, rec)
+        _, einv = el.lift_inter(False, lf, lod, ar, coeffs=co)
+        np.testing.assert_array_equal(einv, rec)

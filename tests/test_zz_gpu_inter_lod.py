@@ -60,3 +60,54 @@ def test_inter_frame_lod_build_vs_oracle():
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["cases"] > 100 and out["refs"] > 100000
+
+
+LIFT_WORKER = r'''
+import json, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import conftest
+import numpy as np
+import lod_helpers as lh, oracle_loader as ol
+from mpeg_pcc_tmc13_amd import context, lift_params, lod_params, synth
+ctx = context(0)
+rng = np.random.default_rng(7)
+cases = 0
+for xyz, attrs in (synth.lidar_cloud(9000, seed=61), synth.dense_cloud(6000, seed=3, bits=7), synth.random_cloud(5, seed=2, bits=3),
+                   synth.lidar_cloud(300000, seed=62)):
+    attrs = attrs[:, :1].copy()
+    if attrs.max() > 255:
+        attrs = attrs >> 8
+    keep = rng.random(len(xyz)) > 0.1 if len(xyz) > 5 else np.ones(len(xyz), bool)
+    xr = np.clip(xyz + rng.integers(-2, 3, size=xyz.shape), 0, None)[keep].astype(np.int32)
+    ar = np.clip(attrs + rng.integers(-6, 7, size=attrs.shape), 0, 255)[keep].astype(np.int32)
+    for qp in (10, 34):
+        lp = lod_params()
+        lod = lh.oracle_lod_generate_inter(xyz, xr, lp, 64, 1)
+        g = ctx.lod_build_inter(lp, xyz, xr, 64, 1)
+        for k in ("npl", "indexes", "nc", "ni", "ref"):
+            assert np.array_equal(g[k], lod[k]), k
+        lf = lift_params(lod["npl"], qp=qp, chroma_offset=0, lcp=False, bitdepth=8)
+        co, rec = lh.lift_inter(ol.oracle(), True, lf, lod, attrs, ar)
+        gco, grec = ctx.lift_inter(True, lf, g, ar, attrs=attrs)
+        assert np.array_equal(gco, co) and np.array_equal(grec, rec), ("forward", len(xyz), qp)
+        _, ginv = ctx.lift_inter(False, lf, g, ar, coeffs=gco)
+        assert np.array_equal(ginv, rec), ("inverse", len(xyz), qp)
+        cases += 1
+# the intra lifting on the same context afterwards
+xyz, attrs = synth.dense_cloud(20000, seed=4, bits=8)
+lp = lod_params()
+o = lh.oracle_lod_generate(xyz, lp)
+lf = lift_params(o["npl"], qp=34)
+oco, orec, _ = lh.lift(ol.oracle(), True, lf, o, attrs)
+gco, grec, _ = ctx.lift_forward(lf, o["nc"], o["ni"], o["w"].astype(np.int32), o["indexes"], attrs)
+assert np.array_equal(gco, oco) and np.array_equal(grec, orec), "intra after inter"
+print(json.dumps(dict(cases=cases)))
+'''
+
+
+def test_inter_frame_reflectance_lifting_vs_oracle():
+    """gpcc_lift_forward_inter / gpcc_lift_inverse_inter over gpcc_lod_build_inter's structure == the
+    oracle, whose coefficients give the reference operator's payload (tests/test_oracle_lift.py)."""
+    r = subprocess.run([sys.executable, "-c", LIFT_WORKER, ROOT], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    assert json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])["cases"] == 8
