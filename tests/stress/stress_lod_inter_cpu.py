@@ -1,0 +1,47 @@
+"""Randomised differential stress of the LoD build with attribute inter prediction on the CPU (not
+collected by pytest): the oracle against the compiled reference, and (periodic / centroid sub-sampling)
+the library's search kernel under the wavefront emulator against the oracle.
+    python tests/stress/stress_lod_inter_cpu.py <seed base> [seconds]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import __graft_entry__ as g; g.load_package()
+import numpy as np
+import emu_lod_loader as el, lod_helpers as lh, oracle_loader as ol
+from mpeg_pcc_tmc13_amd import lod_params, synth
+budget = float(sys.argv[2]) if len(sys.argv) > 2 else 100.0
+t0 = time.time(); cases = emu = 0
+for seed in range(100000):
+    rng = np.random.default_rng(int(sys.argv[1]) + seed)
+    n = int(rng.integers(1, 30000)) if seed % 5 == 0 else int(rng.integers(1, 3000))
+    kind = rng.integers(3)
+    if kind == 0: xyz, _ = synth.random_cloud(n, seed=int(rng.integers(1 << 30)), bits=int(rng.integers(2, 18)), dup_fraction=float(rng.choice([0.0, 0.2])))
+    elif kind == 1: xyz, _ = synth.dense_cloud(n, seed=int(rng.integers(1 << 30)), bits=int(rng.integers(6, 11)))
+    else: xyz, _ = synth.lidar_cloud(n, seed=int(rng.integers(1 << 30)))
+    xyz = (xyz + rng.integers(0, 3, size=3) * int(rng.choice([0, 0, 1000]))).astype(np.int32)   # sometimes away from the origin block
+    amp = int(rng.choice([0, 1, 3, 40]))
+    keep = rng.random(len(xyz)) > float(rng.choice([0.0, 0.1, 0.6]))
+    frame = np.clip(xyz + rng.integers(-amp, amp + 1, size=xyz.shape), 0, (1 << 21) - 1)[keep].astype(np.int32)
+    if len(frame) == 0: frame = xyz[:1].copy()
+    if rng.integers(4) == 0: frame = frame[rng.permutation(len(frame))]
+    lifting = bool(rng.integers(3) > 0)
+    kw = dict(decimation=int(rng.integers(3)), dist2=int(rng.integers(0, 3)), neighbours=int(rng.integers(1, 4)), lifting=lifting,
+              distribution=bool(rng.integers(2)), bias=tuple(int(x) for x in rng.integers(1, 4, size=3)) if rng.integers(2) else (1, 1, 1),
+              sampling_period=int(rng.integers(1, 6)), levels=int(rng.integers(1, 14)), blend=(not lifting) and bool(rng.integers(2)))
+    lp = lod_params(**kw)
+    lp.intra_lod_prediction_skip_layers = int(rng.choice([0, 2, 0x7fffffff]))
+    search_range = int(rng.choice([0, 1, 8, 64, 128, 5000]))
+    fd = int(rng.choice([0, 1, 2, 7]))
+    o = lh.oracle_lod_generate_inter(xyz, frame, lp, search_range, fd)
+    if ol.ref_available():
+        r = lh.ref_lod_generate_inter(xyz, frame, lp, search_range, fd)
+        for k in r:
+            assert np.array_equal(o[k], r[k]), ("oracle vs reference", k, seed, kw, n, search_range)
+    if kw["decimation"] in (1, 2) and kw["sampling_period"] >= 1:
+        e = el.inter_build(lp, xyz, frame, search_range, fd)
+        for k in ("npl", "indexes", "nc", "ni", "ref"):
+            assert np.array_equal(e[k], o[k]), ("emulator vs oracle", k, seed, kw, n, search_range)
+        assert np.array_equal(e["w"].astype(np.uint32), (o["w"] & 0xffffffff).astype(np.uint32)), ("emulator vs oracle w", seed, kw)
+        emu += 1
+    cases += 1
+    if time.time() - t0 > budget: break
+print("inter lod stress ok", cases, "cases,", emu, "under the emulator,", round(time.time() - t0, 1), "s")
