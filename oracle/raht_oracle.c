@@ -414,13 +414,85 @@ scale_rsqrt(int64_t v, int32_t weight)
   return fp_mul(v >> shift, rs);
 }
 
+/* attribute inter prediction (AttributeInterPredParams / paramsForInterRAHT,
+ * PCCTMC3Common.h:236-298): the reference frame in Morton order and the tools */
+typedef struct {
+  const int64_t* pos;   /* [n] */
+  const int32_t* attrs; /* [n][c] */
+  int n;
+  int depth_limit;      /* raht_inter_prediction_depth_minus1 + 1 */
+  int layer_rdo;        /* raht_enable_inter_intra_layer_RDO */
+  int filter_est;       /* enableFilterEstimation */
+  int skip_layers;      /* skipInitLayersForFiltering */
+  int32_t* layer_modes; /* attr_layer_code_mode: encoder out, decoder in */
+  int32_t* num_modes;
+  int32_t* filter_taps; /* FilterTaps: encoder out, decoder in */
+  int32_t* num_taps;
+} raht_inter_t;
+
+/* the nodes of the reference frame's tree at bit level `lv` (unique pos >> lv): what
+ * weightsLf_ref / attrsLf_ref hold when the descent has reached that level
+ * (RAHT.cpp:1065-1120, 1185-1195); attribute sums wrap like the reference's ints */
+typedef struct {
+  int m;
+  int64_t* key;
+  int32_t* weight;
+  int32_t* attr;
+} ref_nodes_t;
+
+static void
+ref_nodes_build(ref_nodes_t* r, const raht_inter_t* ir, int lv, int c)
+{
+  r->key = (int64_t*)malloc(sizeof(int64_t) * (size_t)ir->n);
+  r->weight = (int32_t*)malloc(sizeof(int32_t) * (size_t)ir->n);
+  r->attr = (int32_t*)malloc(sizeof(int32_t) * (size_t)ir->n * c);
+  int m = 0;
+  for (int i = 0; i < ir->n; i++) {
+    const int64_t k = ir->pos[i] >> lv;
+    if (m && r->key[m - 1] == k) {
+      r->weight[m - 1]++;
+      for (int t = 0; t < c; t++)
+        r->attr[(m - 1) * c + t] = wrap_add(r->attr[(m - 1) * c + t], ir->attrs[(size_t)i * c + t]);
+    } else {
+      r->key[m] = k;
+      r->weight[m] = 1;
+      for (int t = 0; t < c; t++)
+        r->attr[m * c + t] = ir->attrs[(size_t)i * c + t];
+      m++;
+    }
+  }
+  r->m = m;
+}
+
+static void
+ref_nodes_free(ref_nodes_t* r)
+{
+  free(r->key);
+  free(r->weight);
+  free(r->attr);
+}
+
+static int
+bitlen_i64(int64_t v)
+{
+  int b = 0;
+  while (v) {
+    b++;
+    v = (int64_t)((uint64_t)v >> 1);
+  }
+  return b;
+}
+
 static int
 raht_process(
   int encoder, const gpcc_raht_params* p, const int64_t* pos,
-  const int32_t* qp_off, int32_t* attributes, int32_t* coeffs, int n, int c)
+  const int32_t* qp_off, int32_t* attributes, int32_t* coeffs, int n, int c,
+  const raht_inter_t* ir)
 {
   const int haar = p->integer_haar_enable_flag != 0;
   const int ext = p->raht_extension != 0;
+  if (ir && (haar || ir->layer_rdo || ir->filter_est))
+    return -2; /* restated so far: orthonormal kernel, no per-layer decision, fixed filter taps */
   int32_t* coef_it[3] = {coeffs, coeffs + n, coeffs + 2 * (size_t)n};
 
   /* single point: RAHT.cpp:998-1017 */
@@ -475,6 +547,15 @@ raht_process(
   int first = 1;
   int last_done = -1; /* index in lv[] of the most recent processed level */
 
+  /* inter prediction: the two trees descend in lock step from their OWN tops
+   * (RAHT.cpp:1165-1198): B / B_ref = number of bit levels below the single root */
+  int tree_depth = 0;
+  int bits_cur = 0, bits_ref = -1;
+  if (ir) {
+    bits_cur = bitlen_i64(pos[0] ^ pos[n - 1]);
+    bits_ref = ir->n <= 1 ? -1 : bitlen_i64(ir->pos[0] ^ ir->pos[ir->n - 1]);
+  }
+
   for (int li = nlv - 2; li >= 0; li--) {
     const level_t* ch = &lv[li];     /* children of the blocks           */
     const level_t* pa = &lv[li + 1]; /* parents = one block each         */
@@ -491,6 +572,20 @@ raht_process(
     qp_layer = qp_layer + 1 < p->num_qp_layers ? qp_layer + 1
                                                  : p->num_qp_layers - 1;
     ac_layer++;
+
+    /* inter prediction at this level: the reference frame's tree has nodes at bit level
+     * lr (it ran out when lr would be negative, :1180-1181), the depth limit is not
+     * reached (:1183-1184); both conditions only ever turn it off */
+    const int lr = bits_ref - bits_cur + 3 * li;
+    const int inter_on = ir && lr >= 0 && tree_depth < ir->depth_limit;
+    /* without the per-layer decision a block is matched against the reference frame
+     * only where the level has no intra prediction (:1323-1335) */
+    const int inter_blocks = inter_on && !pred_in_level;
+    static const int kFixedTaps[7] = {128, 128, 128, 127, 125, 121, 115};
+    const int64_t filter_tap = inter_on ? kFixedTaps[tree_depth < 7 ? tree_depth : 6] : 128;
+    ref_nodes_t rn = {0, NULL, NULL, NULL};
+    if (inter_blocks)
+      ref_nodes_build(&rn, ir, lr, c);
 
     /* previous reconstruction -> parent (RAHT.cpp:1275-1277) */
     {
@@ -526,6 +621,35 @@ raht_process(
         if (encoder)
           for (int k = 0; k < c; k++)
             buf[k][idx] = fp_from_int(ch->attr[i * c + k]);
+      }
+
+      /* the block of the reference frame at the same place (:1322-1347) */
+      int inter_node = 0;
+      int32_t wr[8] = {0};
+      int64_t ibuf[3][8];
+      memset(ibuf, 0, sizeof(ibuf));
+      if (inter_blocks) {
+        const int64_t want = pa->key[j];
+        int lo = 0, hi = rn.m;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if ((rn.key[mid] >> 3) < want)
+            lo = mid + 1;
+          else
+            hi = mid;
+        }
+        const int jr = lo < rn.m - 1 ? lo : rn.m - 1; /* the cursor stops at the last node */
+        if ((rn.key[jr] >> 3) == want) {
+          inter_node = 1;
+          for (int t = jr; t < rn.m && (rn.key[t] >> 3) == want; t++) {
+            const int idx = (int)(rn.key[t] & 7);
+            wr[idx] = rn.weight[t];
+            for (int k = 0; k < c; k++)
+              ibuf[k][idx] = fp_from_int(rn.attr[t * c + k]);
+          }
+        }
+        if (ext && node_cnt == 1)
+          inter_node = 0;
       }
 
       descend_block_qp(w, asc_qp, &par.dqp[2 * j], dsc_qp);
@@ -702,6 +826,15 @@ raht_process(
         }
       }
 
+      if (inter_node) {
+        for (int t = 0; t < 8; t++)
+          if (wr[t] > 1)
+            for (int k = 0; k < c; k++)
+              ibuf[k][t] = scale_rsqrt(ibuf[k][t], wr[t]);
+        if (!encoder)
+          enable_pred = 0;
+      }
+
       /* ---- forward transform (RAHT.cpp:1504-1549) ---- */
       if (encoder && enable_pred)
         block_fwd(2 * c, buf, &bw, haar);
@@ -709,6 +842,17 @@ raht_process(
         block_fwd(c, buf, &bw, haar);
       else if (enable_pred)
         block_fwd(c, pred, &bw, haar);
+      if (inter_node) {
+        /* the reference frame's block in ITS OWN weights, filtered, is the prediction
+         * of every coefficient -- the DC as well where the level codes one (:1533-1545) */
+        block_weights_t bwr;
+        block_weights(wr, &bwr);
+        block_fwd(c, ibuf, &bwr, haar);
+        for (int t = 0; t < 8; t++)
+          for (int k = 0; k < c; k++)
+            pred[k][t] = tree_depth < ir->skip_layers ? ibuf[k][t] : (ibuf[k][t] * filter_tap) >> 7;
+        enable_pred = 1;
+      }
 
       /* ---- per-coefficient scan (RAHT.cpp:1558-1724) ---- */
       static const int8_t kScan[8] = {0, 4, 2, 1, 6, 5, 3, 7};
@@ -818,6 +962,9 @@ raht_process(
       }
     }
     last_done = li;
+    if (inter_blocks)
+      ref_nodes_free(&rn);
+    tree_depth++;
   }
 
   /* ---- duplicates (RAHT.cpp:1840-1964) and write-back (:1967-1975) ---- */
@@ -939,7 +1086,7 @@ oracle_raht_forward(
 {
   if (!p || !morton || !attrs || !coeffs || n <= 0 || c < 1 || c > 3)
     return -1;
-  return raht_process(1, p, morton, qp_off, attrs, coeffs, n, c);
+  return raht_process(1, p, morton, qp_off, attrs, coeffs, n, c, NULL);
 }
 
 int
@@ -949,7 +1096,22 @@ oracle_raht_inverse(
 {
   if (!p || !morton || !attrs || !coeffs || n <= 0 || c < 1 || c > 3)
     return -1;
-  return raht_process(0, p, morton, qp_off, attrs, coeffs, n, c);
+  return raht_process(0, p, morton, qp_off, attrs, coeffs, n, c, NULL);
+}
+
+/* RAHT with attribute inter prediction; arguments as ref_raht_inter (oracle/ref_harness.cpp) */
+int
+oracle_raht_inter(
+  const gpcc_raht_params* p, int32_t fwd, const int64_t* morton, int32_t* attrs, int32_t* coeffs,
+  int32_t n, int32_t c, const int64_t* morton_ref, const int32_t* attrs_ref, int32_t n_ref,
+  int32_t depth_minus1, int32_t layer_rdo, int32_t filter_est, int32_t skip_layers,
+  int32_t* layer_modes, int32_t* num_modes, int32_t* filter_taps, int32_t* num_taps)
+{
+  if (!p || !morton || !attrs || !coeffs || n <= 0 || c < 1 || c > 3 || !morton_ref || !attrs_ref || n_ref <= 0)
+    return -1;
+  raht_inter_t ir = {morton_ref, attrs_ref, n_ref, depth_minus1 + 1, layer_rdo, filter_est, skip_layers,
+                     layer_modes, num_modes, filter_taps, num_taps};
+  return raht_process(fwd != 0, p, morton, NULL, attrs, coeffs, n, c, &ir);
 }
 
 /* primitives exported for the pinning tests */

@@ -131,6 +131,60 @@ ref_raht_inverse(
   return run(false, p, morton, qp_off, attrs, coeffs, n, c);
 }
 
+// RAHT with attribute inter prediction (AttributeInterPredParams::enableAttrInterPred,
+// RAHT.cpp:1025-1345, 1540): morton_ref / attrs_ref [n_ref][c] the reference frame in Morton
+// order.  tools: depth_minus1 (raht_inter_prediction_depth_minus1), layer_rdo
+// (raht_enable_inter_intra_layer_RDO), filter_est (enableFilterEstimation), skip_layers
+// (skipInitLayersForFiltering).  layer_modes [<= 32] / filter_taps [<= 32]: written by the
+// encoder (counts in *num_modes / *num_taps), read by the decoder.
+int
+ref_raht_inter(
+  const gpcc_raht_params* p, int32_t fwd, const int64_t* morton, int32_t* attrs, int32_t* coeffs,
+  int32_t n, int32_t c, const int64_t* morton_ref, const int32_t* attrs_ref, int32_t n_ref,
+  int32_t depth_minus1, int32_t layer_rdo, int32_t filter_est, int32_t skip_layers,
+  int32_t* layer_modes, int32_t* num_modes, int32_t* filter_taps, int32_t* num_taps)
+{
+  if (!p || !morton || !attrs || !coeffs || n <= 0 || c < 1 || c > 3 || n_ref <= 0)
+    return -1;
+  pcc::RahtPredictionParams rp;
+  pcc::QpSet qs;
+  unflatten(*p, &rp, &qs);
+  std::vector<pcc::Qps> qps(n, pcc::Qps{0, 0});
+  std::vector<int64_t> mc(morton, morton + n);
+  pcc::AttributeInterPredParams inter;
+  inter.enableAttrInterPred = true;
+  inter.attrInterIntraSliceRDO = false;
+  inter.frameDistance = 1;
+  auto& ir = inter.paramsForInterRAHT;
+  ir.voxelCount = n_ref;
+  ir.mortonCode.assign(morton_ref, morton_ref + n_ref);
+  ir.attributes.assign(attrs_ref, attrs_ref + size_t(n_ref) * c);
+  ir.raht_inter_prediction_depth_minus1 = depth_minus1;
+  ir.raht_inter_prediction_enabled = true;
+  ir.raht_enable_inter_intra_layer_RDO = layer_rdo != 0;
+  ir.enableFilterEstimation = filter_est != 0;
+  ir.skipInitLayersForFiltering = skip_layers;
+  if (!fwd) {
+    inter.attr_layer_code_mode.assign(layer_modes, layer_modes + *num_modes);
+    ir.FilterTaps.assign(filter_taps, filter_taps + *num_taps);
+  }
+  if (fwd)
+    pcc::regionAdaptiveHierarchicalTransform(
+      rp, qs, qps.data(), mc.data(), attrs, c, n, coeffs, p->raht_extension != 0, inter);
+  else
+    pcc::regionAdaptiveHierarchicalInverseTransform(
+      rp, qs, qps.data(), mc.data(), attrs, c, n, coeffs, p->raht_extension != 0, inter);
+  if (fwd) {
+    *num_modes = std::min<int>(32, inter.attr_layer_code_mode.size());
+    for (int i = 0; i < *num_modes; i++)
+      layer_modes[i] = inter.attr_layer_code_mode[i];
+    *num_taps = std::min<int>(32, ir.FilterTaps.size());
+    for (int i = 0; i < *num_taps; i++)
+      filter_taps[i] = ir.FilterTaps[i];
+  }
+  return 0;
+}
+
 // The Morton prologue of encodeColorsTransformRaht
 // (AttributeEncoder.cpp:1316-1321) on a raw xyz array.
 int
