@@ -15,6 +15,7 @@
  * (enableAttrInterPred) are not restated: intra slices only.
  */
 #include <stdint.h>
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -414,6 +415,47 @@ scale_rsqrt(int64_t v, int32_t weight)
   return fp_mul(v >> shift, rs);
 }
 
+/* PCCRAHTACCoefficientEntropyEstimate (RAHT.h:71-94, RAHT.cpp:54-91): the adaptive
+ * rate model behind the per-layer inter / intra decision; doubles, summed in coding order */
+typedef struct {
+  int p0[3], p1[3];
+  double bits;
+} ac_estimate_t;
+
+static void
+ac_estimate_init(ac_estimate_t* e)
+{
+  for (int k = 0; k < 3; k++)
+    e->p0[k] = e->p1[k] = (1 << 20) >> 1;
+  e->bits = 0.;
+}
+
+static void
+ac_estimate_cost(ac_estimate_t* e, int32_t value, int k)
+{
+  const unsigned scale = 1u << 20;
+  const int lg = 20;
+  double bits = 0;
+  bits += value ? lg - log2((double)e->p0[k]) : lg - log2((double)(scale - (unsigned)e->p0[k]));
+  const int mag = abs(value);
+  if (mag) {
+    bits += mag > 1 ? lg - log2((double)e->p1[k]) : lg - log2((double)(scale - (unsigned)e->p1[k]));
+    bits += 1;
+    if (mag > 1)
+      bits += 2.0 * log2(mag - 1.0) + 1.0;
+  }
+  e->bits += bits;
+}
+
+static void
+ac_estimate_update(ac_estimate_t* e, int32_t value, int k)
+{
+  const unsigned scale = 1u << 20;
+  e->p0[k] += value ? (int)((scale - (unsigned)e->p0[k]) >> 6) : -(e->p0[k] >> 6);
+  if (value)
+    e->p1[k] += abs(value) > 1 ? (int)((scale - (unsigned)e->p1[k]) >> 6) : -(e->p1[k] >> 6);
+}
+
 /* attribute inter prediction (AttributeInterPredParams / paramsForInterRAHT,
  * PCCTMC3Common.h:236-298): the reference frame in Morton order and the tools */
 typedef struct {
@@ -491,8 +533,8 @@ raht_process(
 {
   const int haar = p->integer_haar_enable_flag != 0;
   const int ext = p->raht_extension != 0;
-  if (ir && (haar || ir->layer_rdo || ir->filter_est))
-    return -2; /* restated so far: orthonormal kernel, no per-layer decision, fixed filter taps */
+  if (ir && (haar || ir->filter_est))
+    return -2; /* restated so far: orthonormal kernel, fixed filter taps */
   int32_t* coef_it[3] = {coeffs, coeffs + n, coeffs + 2 * (size_t)n};
 
   /* single point: RAHT.cpp:998-1017 */
@@ -550,6 +592,24 @@ raht_process(
   /* inter prediction: the two trees descend in lock step from their OWN tops
    * (RAHT.cpp:1165-1198): B / B_ref = number of bit levels below the single root */
   int tree_depth = 0;
+  int depth = 0; /* index of the next per-layer mode */
+  int intra_train_zeros = 0;
+  ac_estimate_t est_cur, est_intra;
+  ac_estimate_init(&est_cur);
+  ac_estimate_init(&est_intra);
+  /* the intra candidate of a level under the per-layer decision: its reconstruction
+   * (intraAttrRec / intraAttrRecUs) and its coefficients (intraACCoeffcients) */
+  int64_t *irec = NULL, *irec_us = NULL;
+  int32_t* icoef = NULL;
+  if (ir && ir->layer_rdo && encoder) {
+    irec = (int64_t*)calloc((size_t)(num_unique + 1) * c, sizeof(int64_t));
+    irec_us = (int64_t*)calloc((size_t)(num_unique + 1) * c, sizeof(int64_t));
+    icoef = (int32_t*)calloc((size_t)n * c + 1, sizeof(int32_t));
+  }
+  if (ir && encoder) {
+    *ir->num_modes = 0;
+    *ir->num_taps = 0;
+  }
   int bits_cur = 0, bits_ref = -1;
   if (ir) {
     bits_cur = bitlen_i64(pos[0] ^ pos[n - 1]);
@@ -578,9 +638,17 @@ raht_process(
      * reached (:1183-1184); both conditions only ever turn it off */
     const int lr = bits_ref - bits_cur + 3 * li;
     const int inter_on = ir && lr >= 0 && tree_depth < ir->depth_limit;
-    /* without the per-layer decision a block is matched against the reference frame
-     * only where the level has no intra prediction (:1323-1335) */
-    const int inter_blocks = inter_on && !pred_in_level;
+    /* the per-layer decision (:1256-1262): the encoder codes such a level twice, the
+     * decoder follows the signalled mode */
+    const int rdo_on = inter_on && ir->layer_rdo;
+    const int cur_level = pred_in_level && rdo_on && (encoder || ir->layer_modes[depth]);
+    const int dual = encoder && cur_level;
+    /* a block is matched against the reference frame in such a level, and wherever the
+     * level has no intra prediction (:1323-1335) */
+    const int inter_blocks = inter_on && (cur_level || !pred_in_level);
+    const int sum_nodes = ch->m - pa->m;
+    int32_t* coef_begin[3] = {coef_it[0], coef_it[1], coef_it[2]};
+    int32_t* icoef_it[3] = {icoef, icoef ? icoef + sum_nodes : NULL, icoef ? icoef + 2 * (size_t)sum_nodes : NULL};
     static const int kFixedTaps[7] = {128, 128, 128, 127, 125, 121, 115};
     const int64_t filter_tap = inter_on ? kFixedTaps[tree_depth < 7 ? tree_depth : 6] : 128;
     ref_nodes_t rn = {0, NULL, NULL, NULL};
@@ -603,6 +671,9 @@ raht_process(
       int64_t buf[6][8];
       memset(buf, 0, sizeof(buf));
       int64_t(*pred)[8] = &buf[c];
+      int64_t ipred[3][8], ibuf2[3][8]; /* the intra candidate: prediction, coefficients */
+      memset(ipred, 0, sizeof(ipred));
+      memset(ibuf2, 0, sizeof(ibuf2));
       int32_t w[8] = {0};
       int32_t node_qp[8][2], asc_qp[8][2], dsc_qp[8][2];
       memset(node_qp, 0, sizeof(node_qp));
@@ -760,8 +831,10 @@ raht_process(
               for (int t = 0; mask; t++, mask >>= 1)
                 if (mask & 1) {
                   wsum[t] += p->pred_weight_parent[i];
-                  for (int k = 0; k < c; k++)
+                  for (int k = 0; k < c; k++) {
                     pred[k][t] += v[k];
+                    ipred[k][t] += v[k];
+                  }
                 }
             }
             if (sub) {
@@ -783,13 +856,19 @@ raht_process(
                   if (cn[i][t] != -1) {
                     int64_t cw = p->pred_weight_child[i];
                     wsum[t] += p->pred_weight_child[i];
-                    for (int k = 0; k < c; k++)
+                    for (int k = 0; k < c; k++) {
                       pred[k][t] += cur.rec[(size_t)cn[i][t] * c + k]
                         * (ext ? cw : (cw << FP_FRAC));
+                      /* the intra candidate sees ITS reconstruction of the children (:549-561) */
+                      if (dual)
+                        ipred[k][t] += irec[(size_t)cn[i][t] * c + k] * (ext ? cw : (cw << FP_FRAC));
+                    }
                   } else {
                     wsum[t] += p->pred_weight_parent[7 + i];
-                    for (int k = 0; k < c; k++)
+                    for (int k = 0; k < c; k++) {
                       pred[k][t] += v[k];
+                      ipred[k][t] += v[k];
+                    }
                   }
                 }
               }
@@ -800,6 +879,7 @@ raht_process(
               int64_t div = pred_divisor(wsum[t]);
               for (int k = 0; k < c; k++) {
                 pred[k][t] = fp_mul(pred[k][t], div);
+                ipred[k][t] = fp_mul(ipred[k][t], div);
                 if (haar)
                   pred[k][t] = (pred[k][t] >> FP_FRAC) << FP_FRAC;
               }
@@ -810,6 +890,9 @@ raht_process(
           cur.nneigh[i] = neigh_count;
       }
 
+      /* the intra candidate has a prediction where the intra prediction succeeded (:1440-1442) */
+      const int enable_intra = dual && enable_pred;
+
       /* ---- normalise (RAHT.cpp:1445-1499) ---- */
       if (!haar) {
         for (int t = 0; t < 8; t++) {
@@ -818,10 +901,14 @@ raht_process(
           if (encoder)
             for (int k = 0; k < c; k++)
               buf[k][t] = scale_rsqrt(buf[k][t], w[t]);
-          if (enable_pred) {
+          if (enable_pred || enable_intra) {
             int64_t sq = (int64_t)isqrt_u64((uint64_t)w[t] << (2 * FP_FRAC));
-            for (int k = 0; k < c; k++)
-              pred[k][t] = fp_mul(pred[k][t], sq);
+            for (int k = 0; k < c; k++) {
+              if (enable_pred)
+                pred[k][t] = fp_mul(pred[k][t], sq);
+              if (enable_intra)
+                ipred[k][t] = fp_mul(ipred[k][t], sq);
+            }
           }
         }
       }
@@ -853,6 +940,10 @@ raht_process(
             pred[k][t] = tree_depth < ir->skip_layers ? ibuf[k][t] : (ibuf[k][t] * filter_tap) >> 7;
         enable_pred = 1;
       }
+      if (enable_intra)
+        block_fwd(c, ipred, &bw, haar);
+      if (dual)
+        memcpy(ibuf2, buf, sizeof(int64_t) * 8 * (size_t)c);
 
       /* ---- per-coefficient scan (RAHT.cpp:1558-1724) ---- */
       static const int8_t kScan[8] = {0, 4, 2, 1, 6, 5, 3, 7};
@@ -870,11 +961,16 @@ raht_process(
         if (encoder && enable_pred)
           for (int k = 0; k < c; k++)
             buf[k][idx] -= pred[k][idx];
+        if (enable_intra)
+          for (int k = 0; k < c; k++)
+            ibuf2[k][idx] -= ipred[k][idx];
 
-        int flag_rdoq = 0;
+        int flag_rdoq = 0, iflag_rdoq = 0;
         if (encoder && !haar) {
           int64_t sum_coeff = 0, dist2 = 0, lambda0 = 0;
           int rate_coeff = 0;
+          int64_t isum_coeff = 0, idist2 = 0;
+          int irate_coeff = 0;
           quantizer_t q[2];
           qpset_quantizers(
             p, qp_layer, node_qp[idx][0], node_qp[idx][1], q);
@@ -888,6 +984,14 @@ raht_process(
             rate_coeff += aq < 15 ? kLutLog[aq] : kLutLog[15];
             if (!k)
               lambda0 = quantizer_scale(qk, 1);
+            if (cur_level) {
+              const int64_t ic = fp_round(ibuf2[k][idx]);
+              idist2 += ic * ic;
+              const int64_t iq = quantizer_quantize(qk, ic * 256);
+              const int64_t iaq = iq < 0 ? -iq : iq;
+              isum_coeff += iaq;
+              irate_coeff += iaq < 15 ? kLutLog[iaq] : kLutLog[15];
+            }
           }
           const int64_t lambda = lambda0 * lambda0 * (c == 1 ? 25 : 35);
           if (sum_coeff < 3) {
@@ -903,10 +1007,29 @@ raht_process(
             rate += (rate_coeff + 128) >> 8;
             flag_rdoq = (int64_t)((uint64_t)dist2 << 26) < lambda * rate;
           }
+          if (cur_level && isum_coeff < 3) {
+            int rate = kLutBins[intra_train_zeros > 10 ? 10 : intra_train_zeros];
+            if (intra_train_zeros > 10) {
+              int temp = intra_train_zeros - 11 + 1, a = 0;
+              while (temp) {
+                a++;
+                temp >>= 1;
+              }
+              rate += 2 * a - 1 + 2;
+            }
+            rate += (irate_coeff + 128) >> 8;
+            iflag_rdoq = (int64_t)((uint64_t)idist2 << 26) < lambda * rate;
+          }
           if (flag_rdoq || sum_coeff == 0)
             train_zeros++;
           else
             train_zeros = 0;
+          if (cur_level) {
+            if (iflag_rdoq || isum_coeff == 0)
+              intra_train_zeros++;
+            else
+              intra_train_zeros = 0;
+          }
         }
 
         int ac0 = 0, ac1 = 0;
@@ -923,7 +1046,11 @@ raht_process(
           if (encoder) {
             if (flag_rdoq)
               buf[k][idx] = 0;
+            if (iflag_rdoq)
+              ibuf2[k][idx] = 0;
             coeff = quantizer_quantize(qk, fp_round(buf[k][idx]) * 256);
+            if (cur_level)
+              ac_estimate_cost(&est_cur, (int32_t)coeff, k);
             *coef_it[k]++ = (int32_t)coeff;
           } else {
             coeff = *coef_it[k]++;
@@ -932,6 +1059,14 @@ raht_process(
            * (FixedPoint.h:63), i.e. a sign-symmetric << 15 */
           pred[k][idx] += fp_from_int(
             div_exp2_round_half_up(quantizer_scale(qk, coeff), 8));
+          if (dual) {
+            ac_estimate_update(&est_cur, (int32_t)coeff, k);
+            const int64_t ic = quantizer_quantize(qk, fp_round(ibuf2[k][idx]) * 256);
+            ac_estimate_cost(&est_intra, (int32_t)ic, k);
+            *icoef_it[k]++ = (int32_t)ic;
+            ipred[k][idx] += fp_from_int(div_exp2_round_half_up(quantizer_scale(qk, ic), 8));
+            ac_estimate_update(&est_intra, (int32_t)ic, k);
+          }
         }
       }
 
@@ -945,9 +1080,12 @@ raht_process(
             pred[k][0] = val << (FP_FRAC - 2);
           else
             pred[k][0] = -((-val) << (FP_FRAC - 2));
+          ipred[k][0] = pred[k][0];
         }
       }
       block_inv(c, pred, &bw, haar);
+      if (dual)
+        block_inv(c, ipred, &bw, haar);
 
       /* ---- store reconstruction (RAHT.cpp:1754-1806) ---- */
       for (int i = cs; i < ce; i++) {
@@ -958,9 +1096,42 @@ raht_process(
           if (!haar && w[idx] > 1)
             v = scale_rsqrt(v, w[idx]);
           cur.rec[(size_t)i * c + k] = ext ? v : fp_round(v);
+          if (dual) {
+            int64_t u = ipred[k][idx];
+            irec_us[(size_t)i * c + k] = ext ? u : fp_round(u * 4);
+            if (!haar && w[idx] > 1)
+              u = scale_rsqrt(u, w[idx]);
+            irec[(size_t)i * c + k] = ext ? u : fp_round(u);
+          }
         }
       }
     }
+    /* the level's decision (:1810-1829): the cheaper candidate's coefficients,
+     * reconstruction, rate model and zero-run state go on */
+    if (dual) {
+      const int intra_wins = est_intra.bits < est_cur.bits;
+      if (intra_wins) {
+        for (int k = 0; k < c; k++)
+          memcpy(coef_begin[k], icoef + (size_t)k * sum_nodes, sizeof(int32_t) * (size_t)sum_nodes);
+        int64_t* t1 = irec;
+        irec = cur.rec;
+        cur.rec = t1;
+        t1 = irec_us;
+        irec_us = cur.rec_us;
+        cur.rec_us = t1;
+        est_cur = est_intra;
+        train_zeros = intra_train_zeros;
+      } else {
+        est_intra = est_cur;
+        intra_train_zeros = train_zeros;
+      }
+      if (*ir->num_modes < 32)
+        ir->layer_modes[(*ir->num_modes)++] = !intra_wins;
+      est_cur.bits = 0.;
+      est_intra.bits = 0.;
+    }
+    if (pred_in_level && rdo_on)
+      depth++;
     last_done = li;
     if (inter_blocks)
       ref_nodes_free(&rn);
@@ -1072,6 +1243,9 @@ raht_process(
 
   recon_free(&cur);
   recon_free(&par);
+  free(irec);
+  free(irec_us);
+  free(icoef);
   for (int i = 0; i < nlv; i++)
     level_free(&lv[i]);
   return 0;

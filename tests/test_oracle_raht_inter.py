@@ -112,3 +112,25 @@ def test_inter_prediction_is_used():
     co_intra = np.zeros(a.size, np.int32)
     assert f(C.addressof(p), morton, None, a.reshape(-1), co_intra, len(morton), 3) == 0
     assert (co_inter != 0).sum() < (co_intra != 0).sum() // 2
+
+
+@pytest.mark.parametrize("vi", range(len(VARIANTS)))
+def test_inter_raht_per_layer_decision(vi):
+    """raht_enable_inter_intra_layer_RDO (the reference's default): a level with intra prediction is coded
+    twice by the encoder -- blocks predicted from the reference frame where one lines up, and the intra
+    candidate with its own coefficients, reconstruction, zero-run state and rate model -- and the cheaper
+    one (adaptive bit estimate, doubles in coding order) goes on; attr_layer_code_mode tells the decoder."""
+    from mpeg_pcc_tmc13_amd import raht_params, synth
+    kw = VARIANTS[vi]
+    rng = np.random.default_rng(3)
+    seen = set()
+    for name, xyz, attrs in clouds():
+        morton, a_sorted, _ = synth.sort_by_morton(xyz, attrs)
+        for shift, jitter in ((0, 2), (0, 40), (40, 6)):
+            mref, aref = frame_of(xyz, attrs, rng, shift=shift, jitter=jitter)
+            for depth in (0, 2, 15):
+                p = raht_params(**kw)
+                check(p, morton, a_sorted, mref, aref, depth, 1, 0, 3, f"{name} {kw} shift{shift} jitter{jitter} depth{depth}")
+                seen.update(run(ol.ref().lib, "ref_raht_inter", p, True, morton, a_sorted, None, mref, aref, depth, 1, 0, 3)[3].tolist())
+    if kw.get("prediction", True):
+        assert seen == {0, 1}   # both outcomes of the decision were exercised
