@@ -514,6 +514,37 @@ ref_nodes_free(ref_nodes_t* r)
   free(r->attr);
 }
 
+/* getFilterTap (RAHT.cpp:805-846): 128 * crosscorr / autocorr by subtraction and bisection */
+static int
+filter_tap_of(int64_t autocorr, int64_t crosscorr)
+{
+  if (crosscorr == 0)
+    return 0;
+  const int neg = crosscorr < 0;
+  crosscorr = crosscorr < 0 ? -crosscorr : crosscorr;
+  if (crosscorr == autocorr)
+    return neg ? -128 : 128;
+  int tapint = 0;
+  while (crosscorr >= autocorr) {
+    crosscorr -= autocorr;
+    tapint += 128;
+  }
+  if (crosscorr == 0)
+    return neg ? -tapint : tapint;
+  int lo = 0, hi = 128;
+  while (lo < hi - 1) {
+    const int mid = (lo + hi) >> 1;
+    const int64_t midval = (mid * autocorr) >> 7;
+    if (crosscorr == midval)
+      return neg ? -(tapint + mid) : (tapint + mid);
+    if (crosscorr < midval)
+      hi = mid;
+    else
+      lo = mid;
+  }
+  return neg ? -(tapint + lo) : (tapint + lo);
+}
+
 static int
 bitlen_i64(int64_t v)
 {
@@ -533,8 +564,9 @@ raht_process(
 {
   const int haar = p->integer_haar_enable_flag != 0;
   const int ext = p->raht_extension != 0;
-  if (ir && (haar || ir->filter_est))
-    return -2; /* restated so far: orthonormal kernel, fixed filter taps */
+  if (ir && haar)
+    return -2; /* restated for the orthonormal kernel (the integer Haar reduction of the
+                * reference frame's tree is not a plain sum) */
   int32_t* coef_it[3] = {coeffs, coeffs + n, coeffs + 2 * (size_t)n};
 
   /* single point: RAHT.cpp:998-1017 */
@@ -650,10 +682,84 @@ raht_process(
     int32_t* coef_begin[3] = {coef_it[0], coef_it[1], coef_it[2]};
     int32_t* icoef_it[3] = {icoef, icoef ? icoef + sum_nodes : NULL, icoef ? icoef + 2 * (size_t)sum_nodes : NULL};
     static const int kFixedTaps[7] = {128, 128, 128, 127, 125, 121, 115};
-    const int64_t filter_tap = inter_on ? kFixedTaps[tree_depth < 7 ? tree_depth : 6] : 128;
+    int64_t filter_tap = 128;
+    if (inter_on && !ir->filter_est)
+      filter_tap = kFixedTaps[tree_depth < 7 ? tree_depth : 6];
+    /* a filter tap of its own for the level (:1283-1305): estimated by the encoder over
+     * EVERY block that lines up (whether or not the level then uses them), sent quantised */
+    const int est_layer = inter_on && ir->filter_est && tree_depth >= ir->skip_layers;
     ref_nodes_t rn = {0, NULL, NULL, NULL};
-    if (inter_blocks)
+    if (inter_blocks || (est_layer && encoder))
       ref_nodes_build(&rn, ir, lr, c);
+    if (est_layer) {
+      quantizer_t tq[2];
+      qpset_quantizers(p, qp_layer, 0, 0, tq);
+      int64_t qtap;
+      if (encoder) {
+        /* estimate_layer_filter (:849-972) */
+        int64_t autocorr = 0, crosscorr = 0;
+        int jr = 0; /* its cursor: a block that finds it already on the last node sees no key */
+        for (int jb = 0; jb < pa->m; jb++) {
+          const int64_t want = pa->key[jb];
+          int64_t rkey = jr < rn.m - 1 ? rn.key[jr] >> 3 : INT64_MAX;
+          while (jr < rn.m - 1 && want > rkey) {
+            jr++;
+            rkey = rn.key[jr] >> 3;
+          }
+          if (want != rkey)
+            continue;
+          const int cs2 = pa->first_child[jb], ce2 = pa->first_child[jb + 1];
+          if (ext && ce2 - cs2 == 1)
+            continue;
+          int32_t w2[8] = {0}, wr2[8] = {0};
+          int64_t b2[3][8], r2[3][8];
+          memset(b2, 0, sizeof(b2));
+          memset(r2, 0, sizeof(r2));
+          for (int t = jr; t < rn.m && (rn.key[t] >> 3) == want; t++) {
+            const int idx = (int)(rn.key[t] & 7);
+            wr2[idx] = rn.weight[t];
+            r2[0][idx] = fp_from_int(rn.attr[t * c]);
+          }
+          for (int i = cs2; i < ce2; i++) {
+            const int idx = (int)(ch->key[i] & 7);
+            w2[idx] = ch->weight[i];
+            b2[0][idx] = fp_from_int(ch->attr[i * c]);
+          }
+          for (int t = 0; t < 8; t++) {
+            if (wr2[t] > 1)
+              r2[0][t] = scale_rsqrt(r2[0][t], wr2[t]);
+            if (w2[t] > 1)
+              b2[0][t] = scale_rsqrt(b2[0][t], w2[t]);
+          }
+          block_weights_t bw2, bwr2;
+          block_weights(w2, &bw2);
+          block_weights(wr2, &bwr2);
+          block_fwd(1, b2, &bw2, 0);
+          block_fwd(1, r2, &bwr2, 0);
+          static const int8_t kScan2[8] = {0, 4, 2, 1, 6, 5, 3, 7};
+          for (int sc = 0; sc < 8; sc++) {
+            const int idx = kScan2[sc];
+            if (sc && !bw2.cw[idx])
+              continue;
+            if (inherit_dc && !idx)
+              continue;
+            const int64_t rv = r2[0][idx];
+            if (rv) {
+              autocorr += (rv * rv) >> FP_FRAC;
+              crosscorr += (rv * b2[0][idx]) >> FP_FRAC;
+            }
+          }
+        }
+        const int orig = autocorr ? filter_tap_of(autocorr, crosscorr) : 128;
+        qtap = quantizer_quantize(tq[0], (int64_t)(128 - orig) * 256);
+        if (*ir->num_taps < 32)
+          ir->filter_taps[(*ir->num_taps)++] = (int32_t)qtap;
+        filter_tap = 128 - div_exp2_round_half_up(quantizer_scale(tq[0], qtap), 8);
+      } else if (tree_depth - ir->skip_layers < *ir->num_taps) {
+        qtap = ir->filter_taps[tree_depth - ir->skip_layers];
+        filter_tap = 128 - div_exp2_round_half_up(quantizer_scale(tq[0], qtap), 8);
+      }
+    }
 
     /* previous reconstruction -> parent (RAHT.cpp:1275-1277) */
     {
@@ -1133,7 +1239,7 @@ raht_process(
     if (pred_in_level && rdo_on)
       depth++;
     last_done = li;
-    if (inter_blocks)
+    if (rn.key)
       ref_nodes_free(&rn);
     tree_depth++;
   }
