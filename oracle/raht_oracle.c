@@ -483,26 +483,46 @@ typedef struct {
 } ref_nodes_t;
 
 static void
-ref_nodes_build(ref_nodes_t* r, const raht_inter_t* ir, int lv, int c)
+ref_nodes_build(ref_nodes_t* r, const raht_inter_t* ir, int lv, int c, int haar)
 {
   r->key = (int64_t*)malloc(sizeof(int64_t) * (size_t)ir->n);
   r->weight = (int32_t*)malloc(sizeof(int32_t) * (size_t)ir->n);
   r->attr = (int32_t*)malloc(sizeof(int32_t) * (size_t)ir->n * c);
-  int m = 0;
-  for (int i = 0; i < ir->n; i++) {
-    const int64_t k = ir->pos[i] >> lv;
-    if (m && r->key[m - 1] == k) {
-      r->weight[m - 1]++;
-      for (int t = 0; t < c; t++)
-        r->attr[(m - 1) * c + t] = wrap_add(r->attr[(m - 1) * c + t], ir->attrs[(size_t)i * c + t]);
-    } else {
-      r->key[m] = k;
-      r->weight[m] = 1;
-      for (int t = 0; t < c; t++)
-        r->attr[m * c + t] = ir->attrs[(size_t)i * c + t];
-      m++;
-    }
+  int m = ir->n;
+  for (int i = 0; i < m; i++) {
+    r->key[i] = ir->pos[i];
+    r->weight[i] = 1;
+    for (int t = 0; t < c; t++)
+      r->attr[i * c + t] = ir->attrs[(size_t)i * c + t];
   }
+  /* the ascent one pass at a time: duplicates (reduceUnique :108-150), then one bit per
+   * pass (reduceLevel :155-207).  A node that joins the one on its left adds its
+   * attributes -- or, with the integer Haar kernel, half its difference -- so under Haar
+   * the order of the passes is part of the result. */
+  for (int pass = 0; pass <= lv; pass++) {
+    int out = 0;
+    for (int i = 0; i < m; i++) {
+      if (out && ((r->key[out - 1] ^ r->key[i]) >> pass) == 0) {
+        r->weight[out - 1] += r->weight[i];
+        for (int t = 0; t < c; t++) {
+          int32_t* left = &r->attr[(out - 1) * c + t];
+          if (haar)
+            *left = wrap_add(*left, wrap_sub(r->attr[i * c + t], *left) >> 1);
+          else
+            *left = wrap_add(*left, r->attr[i * c + t]);
+        }
+      } else {
+        r->key[out] = r->key[i];
+        r->weight[out] = r->weight[i];
+        for (int t = 0; t < c; t++)
+          r->attr[out * c + t] = r->attr[i * c + t];
+        out++;
+      }
+    }
+    m = out;
+  }
+  for (int i = 0; i < m; i++)
+    r->key[i] >>= lv;
   r->m = m;
 }
 
@@ -564,9 +584,7 @@ raht_process(
 {
   const int haar = p->integer_haar_enable_flag != 0;
   const int ext = p->raht_extension != 0;
-  if (ir && haar)
-    return -2; /* restated for the orthonormal kernel (the integer Haar reduction of the
-                * reference frame's tree is not a plain sum) */
+
   int32_t* coef_it[3] = {coeffs, coeffs + n, coeffs + 2 * (size_t)n};
 
   /* single point: RAHT.cpp:998-1017 */
@@ -690,7 +708,7 @@ raht_process(
     const int est_layer = inter_on && ir->filter_est && tree_depth >= ir->skip_layers;
     ref_nodes_t rn = {0, NULL, NULL, NULL};
     if (inter_blocks || (est_layer && encoder))
-      ref_nodes_build(&rn, ir, lr, c);
+      ref_nodes_build(&rn, ir, lr, c, haar);
     if (est_layer) {
       quantizer_t tq[2];
       qpset_quantizers(p, qp_layer, 0, 0, tq);
@@ -986,8 +1004,10 @@ raht_process(
               for (int k = 0; k < c; k++) {
                 pred[k][t] = fp_mul(pred[k][t], div);
                 ipred[k][t] = fp_mul(ipred[k][t], div);
-                if (haar)
+                if (haar) {
                   pred[k][t] = (pred[k][t] >> FP_FRAC) << FP_FRAC;
+                  ipred[k][t] = (ipred[k][t] >> FP_FRAC) << FP_FRAC;
+                }
               }
             }
           }
@@ -1019,7 +1039,7 @@ raht_process(
         }
       }
 
-      if (inter_node) {
+      if (inter_node && !haar) {
         for (int t = 0; t < 8; t++)
           if (wr[t] > 1)
             for (int k = 0; k < c; k++)
@@ -1043,7 +1063,8 @@ raht_process(
         block_fwd(c, ibuf, &bwr, haar);
         for (int t = 0; t < 8; t++)
           for (int k = 0; k < c; k++)
-            pred[k][t] = tree_depth < ir->skip_layers ? ibuf[k][t] : (ibuf[k][t] * filter_tap) >> 7;
+            /* (the integer Haar kernel takes the frame's coefficients as they are, :1520-1526) */
+            pred[k][t] = haar || tree_depth < ir->skip_layers ? ibuf[k][t] : (ibuf[k][t] * filter_tap) >> 7;
         enable_pred = 1;
       }
       if (enable_intra)

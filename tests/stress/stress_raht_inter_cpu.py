@@ -25,7 +25,8 @@ for seed in range(100000):
     else:
         mref, aref = t.frame_of(xyz, attrs, rng, amp=int(rng.choice([0, 1, 3])), drop=float(rng.choice([0.0, 0.1, 0.7])),
                                 jitter=int(rng.choice([0, 2, 10, 60])), shift=int(rng.choice([0, 0, 1, 40, 5000])))
-    kw = dict(qp=int(rng.integers(4, 52)), chroma_offset=int(rng.integers(-3, 2)), prediction=bool(rng.integers(4) > 0), subnode=bool(rng.integers(2)),
+    haar = bool(rng.integers(5) == 0)
+    kw = dict(haar=haar, qp=4 if haar else int(rng.integers(4, 52)), chroma_offset=int(rng.integers(-3, 2)), prediction=bool(rng.integers(4) > 0), subnode=bool(rng.integers(2)),
               extension=bool(rng.integers(4) > 0), search_range=int(rng.choice([8, 2500, 50000])), threshold0=int(rng.integers(0, 4)),
               threshold1=int(rng.integers(0, 8)))
     depth = int(rng.choice([0, 1, 3, 7, 15])); rdo = int(rng.integers(2)); fest = int(rng.integers(2)); skip = int(rng.choice([0, 1, 3]))

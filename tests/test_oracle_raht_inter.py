@@ -160,9 +160,18 @@ def test_inter_raht_estimated_filters(vi):
     assert len(taps) > 2   # taps other than "no change" were sent
 
 
-def test_inter_raht_with_integer_haar_is_declined():
+@pytest.mark.parametrize("rdo,fest", [(0, 0), (1, 0), (1, 1), (0, 1)])
+def test_inter_raht_with_the_integer_haar_kernel(rdo, fest):
+    """integer_haar_enable_flag (the lossless configuration): the reference frame's tree is reduced one
+    pass at a time with half differences, its block is transformed with the Haar kernel and predicts
+    the coefficients as they are (no filter tap is applied; the taps are still estimated and sent)."""
     from mpeg_pcc_tmc13_amd import raht_params, synth
-    xyz, attrs = synth.dense_cloud(500, seed=3, bits=5)
-    morton, a_sorted, _ = synth.sort_by_morton(xyz, attrs)
-    rc = run(ol.oracle().lib, "oracle_raht_inter", raht_params(haar=True, qp=4), True, morton, a_sorted, None, morton, a_sorted, 15, 1, 0, 3)[0]
-    assert rc == -2   # not restated: the reference frame's tree under the integer Haar reduction
+    rng = np.random.default_rng(3)
+    for name, xyz, attrs in clouds():
+        morton, a_sorted, _ = synth.sort_by_morton(xyz, attrs)
+        for shift, jitter in ((0, 2), (0, 40), (40, 6)):
+            mref, aref = frame_of(xyz, attrs, rng, shift=shift, jitter=jitter)
+            for kw in (dict(haar=True, qp=4), dict(haar=True, qp=4, prediction=False), dict(haar=True, qp=4, subnode=False)):
+                for depth in (0, 15):
+                    check(raht_params(**kw), morton, a_sorted, mref, aref, depth, rdo, fest, 3,
+                          f"{name} {kw} shift{shift} jitter{jitter} depth{depth} rdo{rdo} fest{fest}")
