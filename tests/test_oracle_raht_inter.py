@@ -175,3 +175,56 @@ def test_inter_raht_with_the_integer_haar_kernel(rdo, fest):
                 for depth in (0, 15):
                     check(raht_params(**kw), morton, a_sorted, mref, aref, depth, rdo, fest, 3,
                           f"{name} {kw} shift{shift} jitter{jitter} depth{depth} rdo{rdo} fest{fest}")
+
+
+def _operator_roundtrip(rp, qp, xyz, attrs, xyz_ref, attrs_ref, depth, rdo, fest, skip):
+    u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
+    f = ol.ref().lib.ref_raht_inter_roundtrip
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_int32, C.c_int32, i32p, i32p, C.c_int32, i32p, i32p, C.c_int32, C.c_int32, C.c_int32,
+                  C.c_int32, C.c_int32, i32p, i32p, u8p, C.c_int32, i32p, C.POINTER(C.c_int32), i32p, C.POINTER(C.c_int32)]
+    n = len(xyz)
+    re, rd = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    pay = np.zeros(n * 8 + 4096, np.uint8)
+    m, t = np.zeros(32, np.int32), np.zeros(32, np.int32)
+    nm, nt = C.c_int32(0), C.c_int32(0)
+    ln = f(C.addressof(rp), qp, 8, np.ascontiguousarray(xyz, dtype=np.int32).reshape(-1),
+           np.ascontiguousarray(attrs, dtype=np.int32).reshape(-1), n, np.ascontiguousarray(xyz_ref, dtype=np.int32).reshape(-1),
+           np.ascontiguousarray(attrs_ref, dtype=np.int32).reshape(-1), len(xyz_ref), depth, rdo, fest, skip, re, rd, pay, pay.size,
+           m, C.byref(nm), t, C.byref(nt))
+    return pay[:ln].tobytes(), re, rd, m[:nm.value].copy(), t[:nt.value].copy()
+
+
+@pytest.mark.parametrize("rdo,fest", [(1, 1), (1, 0), (0, 0)])
+def test_inter_raht_oracle_gives_the_reference_operator_bitstream(rdo, fest):
+    """The whole reference operator (AttributeEncoder::encode with encodeReflectancesTransformRaht and a
+    reference frame, then AttributeDecoder::decode) against the oracle: its coefficients -> zero runs ->
+    the reference's arithmetic coder == the operator's payload byte for byte; the layer modes and filter
+    taps equal what the brick header carries; the reconstruction equals encoder's and decoder's."""
+    import lod_helpers as lh
+    from mpeg_pcc_tmc13_amd import raht_params, synth
+    if not lh.entropy_available():
+        pytest.skip("entropy harness absent")
+    rng = np.random.default_rng(11)
+    for xyz, attrs in (synth.lidar_cloud(9000, seed=61), synth.dense_cloud(6000, seed=3, bits=7)):
+        attrs = attrs[:, :1].copy()
+        if attrs.max() > 255:
+            attrs = attrs >> 8
+        keep = rng.random(len(xyz)) > 0.1
+        xr = np.clip(xyz + rng.integers(-1, 2, size=xyz.shape), 0, None)[keep].astype(np.int32)
+        ar = np.clip(attrs + rng.integers(-6, 7, size=attrs.shape), 0, 255)[keep].astype(np.int32)
+        for qp in (22, 40):
+            rp = raht_params(qp=qp, chroma_offset=0)
+            payload, rec_enc, rec_dec, modes, taps = _operator_roundtrip(rp, qp, xyz, attrs, xr, ar, 15, rdo, fest, 3)
+            np.testing.assert_array_equal(rec_enc, rec_dec)
+            morton, a_sorted, order = synth.sort_by_morton(xyz, attrs)
+            mref, aref, _ = synth.sort_by_morton(xr, ar)
+            rc, co, rec, o_modes, o_taps = run(ol.oracle().lib, "oracle_raht_inter", rp, True, morton, a_sorted, None, mref, aref, 15, rdo, fest, 3)
+            assert rc == 0
+            np.testing.assert_array_equal(o_modes, modes)
+            np.testing.assert_array_equal(o_taps, taps)
+            runs, vals, trailing = lh.oracle_zero_run_pack(co, len(xyz), 1, planar=True)
+            assert lh.ref_entropy_encode_symbols(1, len(xyz), runs, vals, trailing) == payload[lh.ref_last_abh_size():]
+            point_order = np.zeros(len(xyz), np.int32)
+            point_order[order] = np.clip(rec[:, 0], 0, 255)
+            np.testing.assert_array_equal(point_order, rec_enc)
