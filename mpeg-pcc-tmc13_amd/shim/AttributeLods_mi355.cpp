@@ -13,7 +13,8 @@
 // AttributeLods::generate with the original signature.  The LoD fields of
 // the APS / ABH are flattened into gpcc_lod_params, the build runs on the
 // MI355X through the C ABI and the public vectors are filled; whenever the
-// device path declines (no GPU, inter prediction, a partially decoded scalable slice, ...) the renamed reference body runs instead.
+// device path declines (no GPU, a partially decoded scalable slice, ...) the renamed reference body runs instead.
+// With attribute inter prediction the build is gpcc_lod_build_inter.
 //
 // Built against the reference's headers; contains no reference code.
 #include <vector>
@@ -45,13 +46,29 @@ AttributeLods::generate(
   const int n = int(cloud.getPointCount());
   // (scalable lifting: whole slices only -- no points skipped by a partial decode)
   const bool whole = !aps.scalable_lifting_enabled_flag || geom_num_points_minus1 + 1 == n;
-  if (ctx && n > 0 && whole && gpcc_shim::flatten_lod(aps, abh, minGeomNodeSizeLog2, attrInterPredParams, &lp)) {
+  // attribute inter prediction: the search also looks into the reference frame
+  // (gpcc_lod_build_inter); the transforms over the structure stay the reference's
+  const bool inter = attrInterPredParams.enableAttrInterPred;
+  const int nFrame = inter ? int(attrInterPredParams.referencePointCloud.getPointCount()) : 0;
+  if (
+    ctx && n > 0 && whole && (!inter || nFrame > 0)
+    && gpcc_shim::flatten_lod(aps, abh, minGeomNodeSizeLog2, attrInterPredParams, &lp, true)) {
     std::vector<int32_t> xyz;
     gpcc_shim::positions_of(cloud, &xyz);
-    std::vector<int32_t> nc(n), ni(size_t(n) * 3), nw(size_t(n) * 3), idx(n);
+    std::vector<int32_t> nc(n), ni(size_t(n) * 3), nw(size_t(n) * 3), idx(n), xr;
     int32_t npl[GPCC_MAX_LODS], nl = 0;
-    int rc = gpcc_lod_build(
-      ctx, &lp, xyz.data(), n, nc.data(), ni.data(), nw.data(), idx.data(), npl, &nl);
+    int rc;
+    if (inter) {
+      std::vector<int32_t> xyzFrame;
+      gpcc_shim::positions_of(attrInterPredParams.referencePointCloud, &xyzFrame);
+      xr.resize(size_t(n) * 3);
+      rc = gpcc_lod_build_inter(
+        ctx, &lp, xyz.data(), n, xyzFrame.data(), nFrame, abh.attrInterPredSearchRange,
+        attrInterPredParams.frameDistance, nc.data(), ni.data(), nw.data(), idx.data(), npl, &nl,
+        xr.data());
+    } else
+      rc = gpcc_lod_build(
+        ctx, &lp, xyz.data(), n, nc.data(), ni.data(), nw.data(), idx.data(), npl, &nl);
     if (rc == GPCC_OK) {
       _aps = aps;
       _abh = abh;
@@ -62,10 +79,14 @@ AttributeLods::generate(
         p.predMode = 0;
         p.neighborCount = nc[i];
         for (int k = 0; k < 3; k++) {
+          const bool inFrame = inter && xr[3 * size_t(i) + k] != 0;
           p.neighbors[k].predictorIndex = ni[3 * size_t(i) + k];
           p.neighbors[k].weight = nw[3 * size_t(i) + k];
-          p.neighbors[k].pointIndex = k < nc[i] ? idx[ni[3 * size_t(i) + k]] : 0;
-          p.neighbors[k].interFrameRef = false;
+          // (updatePredictors PCCTMC3Common.h:2286-2293: pointIndex is the neighbour's point --
+          // of the reference frame, which predictorIndex then names too, for such a neighbour)
+          p.neighbors[k].pointIndex =
+            k < nc[i] ? (inFrame ? ni[3 * size_t(i) + k] : idx[ni[3 * size_t(i) + k]]) : 0;
+          p.neighbors[k].interFrameRef = inFrame;
         }
       }
       indexes.assign(idx.begin(), idx.end());

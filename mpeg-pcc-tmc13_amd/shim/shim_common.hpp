@@ -59,9 +59,11 @@ inline bool
 flatten_lod(
   const pcc::AttributeParameterSet& aps, const pcc::AttributeBrickHeader& abh,
   int minGeomNodeSizeLog2, const pcc::AttributeInterPredParams& inter,
-  gpcc_lod_params* lp)
+  gpcc_lod_params* lp, bool inter_allowed = false)
 {
-  if (inter.enableAttrInterPred || minGeomNodeSizeLog2 > 0)
+  // (attribute inter prediction: only the caller that has an entry for it says so --
+  // AttributeLods::generate -> gpcc_lod_build_inter)
+  if ((inter.enableAttrInterPred && !inter_allowed) || minGeomNodeSizeLog2 > 0)
     return false;
   if (aps.num_detail_levels_minus1 + 1 >= GPCC_MAX_LODS)
     return false;

@@ -139,10 +139,10 @@ def pred_inter(forward, pp, lod, attrs_ref, attrs=None, values=None):
 
 
 def ref_inter_roundtrip(lp, transform, qp, bitdepth, direct, xyz, attrs, xyz_ref, attrs_ref, search_range,
-                        frame_distance=1, threshold=64):
+                        frame_distance=1, threshold=64, lib=None):
     """the reference operator (encode + decode) with attribute inter prediction, one component
-    -> (payload, recon_enc, recon_dec)"""
-    lib = ol.ref().lib
+    -> (payload, recon_enc, recon_dec).  `lib`: another build of the same harness (libtmc3_shim.so)."""
+    lib = lib or ol.ref().lib
     lib.ref_inter_roundtrip.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, i32p, i32p,
                                         C.c_int32, i32p, i32p, C.c_int32, C.c_int32, C.c_int32, i32p, i32p, u8p, C.c_int32]
     xyz = np.ascontiguousarray(xyz, dtype=np.int32)

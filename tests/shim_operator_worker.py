@@ -47,6 +47,27 @@ def pred_case(case):
     return xyz, attrs, lp, pp, thr, qp
 
 
+def inter_case(case):
+    """a slice with attribute inter prediction (transform 1 / 2, one component): the frame is the cloud
+    jittered with a tenth of its points gone"""
+    from mpeg_pcc_tmc13_amd import lod_params, synth
+    if case["cloud"] == "dense":
+        xyz, attrs = synth.dense_cloud(case["n"], seed=case["seed"], bits=case.get("bits", 9))
+    else:
+        xyz, attrs = synth.lidar_cloud(case["n"], seed=case["seed"])
+    attrs = attrs[:, :1].copy()
+    if attrs.max() > 255:
+        attrs = attrs >> 8
+    rng = np.random.default_rng(case["seed"])
+    keep = rng.random(len(xyz)) > 0.1
+    xr = np.clip(xyz + rng.integers(-2, 3, size=xyz.shape), 0, None)[keep].astype(np.int32)
+    ar = np.clip(attrs + rng.integers(-6, 7, size=attrs.shape), 0, 255)[keep].astype(np.int32)
+    lp = lod_params(lifting=case["transform"] == 2, intra_range=0 if case["transform"] == 2 else 64)
+    if case["transform"] == 1:
+        lp.intra_lod_prediction_skip_layers = 0
+    return xyz, attrs, xr, ar, lp
+
+
 def digest(a):
     return hashlib.md5(np.ascontiguousarray(a).tobytes()).hexdigest()
 
@@ -59,7 +80,12 @@ def main():
     lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", case.get("lib", "libtmc3_shim.so")))
     import time
     t0 = time.time()
-    if case["transform"] == 1:
+    if case.get("inter"):
+        xyz, attrs, xr, ar, lp = inter_case(case)
+        t0 = time.time()
+        payload, rec_enc, rec_dec = lh.ref_inter_roundtrip(lp, case["transform"], case["qp"], 8, case.get("direct", 3), xyz, attrs,
+                                                           xr, ar, case.get("search_range", 128), 1, threshold=4, lib=lib)
+    elif case["transform"] == 1:
         xyz, attrs, lp, pp, thr, qp = pred_case(case)
         t0 = time.time()
         payload, rec_enc, rec_dec, _ = lh.ref_pred_roundtrip(lp, pp, thr, qp, 0, xyz, attrs, lib=lib)

@@ -52,7 +52,11 @@ def unmodified(case):
     import lod_helpers as lh
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import shim_operator_worker as w
-    if case["transform"] == 1:
+    if case.get("inter"):
+        xyz, attrs, xr, ar, lp = w.inter_case(case)
+        payload, rec_enc, rec_dec = lh.ref_inter_roundtrip(lp, case["transform"], case["qp"], 8, case.get("direct", 3), xyz, attrs,
+                                                           xr, ar, case.get("search_range", 128), 1, threshold=4)
+    elif case["transform"] == 1:
         xyz, attrs, lp, pp, thr, qp = w.pred_case(case)
         payload, rec_enc, rec_dec, _ = lh.ref_pred_roundtrip(lp, pp, thr, qp, 0, xyz, attrs)
     else:
@@ -62,6 +66,27 @@ def unmodified(case):
             1, xyz, attrs)
     np.testing.assert_array_equal(rec_enc, rec_dec)  # the reference's own conformance criterion
     return hashlib.md5(payload).hexdigest(), len(payload), w.digest(rec_enc)
+
+
+# attribute inter prediction: the LoD structure of such a slice comes from
+# gpcc_lod_build_inter through AttributeLods::generate; the transform over it is the reference's
+INTER_CASES = {
+    "inter_lifting_refl_lidar_40k": dict(inter=1, cloud="lidar", n=40_000, seed=21, transform=2, qp=28),
+    "inter_lifting_refl_dense_30k": dict(inter=1, cloud="dense", n=30_000, seed=22, transform=2, qp=10, search_range=64),
+    "inter_pred_refl_lidar_30k": dict(inter=1, cloud="lidar", n=30_000, seed=23, transform=1, qp=16, direct=3),
+}
+
+
+@needs
+def test_operator_with_shims_inter_slice_falls_back_without_gpu():
+    from mpeg_pcc_tmc13_amd import _lib
+    if _lib.load().gpcc_device_count() > 0:
+        pytest.skip("a GPU is present")
+    case = dict(INTER_CASES["inter_lifting_refl_lidar_40k"], n=5000)
+    got, err = run_worker(case, strict=False)
+    md5, ln, rec = unmodified(case)
+    assert (got["payload_md5"], got["payload_len"], got["rec_enc_md5"], got["rec_dec_md5"]) == (md5, ln, rec, rec)
+    assert got["lod_device"] == 0 and got["lod_cpu"] == 2
 
 
 @needs

@@ -111,3 +111,27 @@ def test_inter_frame_reflectance_lifting_vs_oracle():
     r = subprocess.run([sys.executable, "-c", LIFT_WORKER, ROOT], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     assert json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])["cases"] == 8
+
+
+def _inter_cases():
+    import test_shim_operator as tso
+    return list(tso.INTER_CASES)
+
+
+@pytest.mark.parametrize("name", _inter_cases())
+def test_operator_inter_slice_with_the_lod_search_on_the_device(name):
+    """The reference's whole attribute operator (encode + decode) on a slice with attribute inter
+    prediction, linked with the shim TUs (oracle/_ref/libtmc3_shim.so): AttributeLods::generate builds
+    the structure -- reference-frame neighbours included -- with gpcc_lod_build_inter, the reference's
+    own lifting / predicting drivers run over it.  Payload and reconstructions byte-identical to the
+    unmodified build, the device counted once per direction, no fallback (GPCC_STRICT=1)."""
+    import test_shim_operator as tso
+    if not (os.path.exists(tso.SHIM) and tso.ol.ref_available()):
+        pytest.skip("libtmc3_shim.so / libtmc3_ref.so not built")
+    case = tso.INTER_CASES[name]
+    got, err = tso.run_worker(case, strict=True)
+    md5, ln, rec = tso.unmodified(case)
+    assert got["payload_len"] == ln and got["payload_md5"] == md5, "attribute payload differs from the unmodified build"
+    assert got["rec_enc_md5"] == rec and got["rec_dec_md5"] == rec
+    assert "falls back" not in err
+    assert (got["lod_device"], got["lod_cpu"]) == (2, 0)
