@@ -23,9 +23,7 @@
 #pragma once
 
 #include "raht_common.hpp"
-#ifndef GPCC_EMU  // (tests/emu: the buffer-resource builtins have no CPU counterpart)
 #include "raht_subnode.hpp"
-#endif
 #include "lift_kernels.hpp"
 
 namespace gpcc {
@@ -325,7 +323,6 @@ lod_cell_keys_kernel(LodCtx cx)
 // neighbour is folded into a bit mask of eliminated points at once and nothing
 // else is kept of it (no per-lane neighbour lists in LDS; 168 registers, three
 // waves per SIMD -- at four the prologue's 19 lock-step bisections spill).
-#ifndef GPCC_EMU
 #ifndef GPCC_LOD_SUB_WAVES
 #define GPCC_LOD_SUB_WAVES 3
 #endif
@@ -642,7 +639,6 @@ lod_subsample_distance_kernel(LodCtx cx)
     }
   }
 }
-#endif  // GPCC_EMU
 
 // ---- nearest-neighbour search ----------------------------------------------
 struct NnCtx {

@@ -38,7 +38,11 @@ constexpr uint32_t kCxSlotMask = (1u << kCxSlotBits) - 1;
 constexpr int32_t kCxMaxPoints = 1 << (kCxSlotBits - 1);
 
 // payload of one 16-byte buffer load / store (mailbox granules)
+#ifdef GPCC_EMU  // (tests/emu: a plain struct with the same layout and member names)
+typedef emu_u32x4 u32x4;
+#else
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#endif
 
 struct TreeView {
   int32_t nlev;         // level arrays in use (top one has 1 node / slice)

@@ -24,6 +24,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <math.h>
 
 #define __host__
 #define __device__
@@ -288,6 +289,38 @@ inline T atomicCAS(T* p, U cmp, V v) { T o = *p; if (o == (T)cmp) *p = (T)v; ret
 #define __hip_atomic_exchange(p, v, order, scope) atomicExch((p), (v))
 
 // ---- bit helpers -------------------------------------------------------------------
+// ---- buffer instructions (the 16-byte mail-box granules of the dependency-ordered kernels) ----
+// A resource is base + size; a load outside it returns zeros and a store there is dropped,
+// as the hardware does.  One 16-byte access is one memcpy: whole, like the granule on the device.
+struct emu_u32x4 {
+  uint32_t x, y, z, w;
+};
+struct emu_rsrc {
+  char* base;
+  uint32_t bytes;
+};
+inline emu_rsrc emu_make_buffer_rsrc(const void* p, int, int num_bytes, int)
+{
+  return emu_rsrc{(char*)const_cast<void*>(p), (uint32_t)num_bytes};
+}
+inline emu_u32x4 emu_raw_buffer_load_b128(emu_rsrc r, int voffset, int soffset, int)
+{
+  emu_u32x4 v{0, 0, 0, 0};
+  const uint32_t off = (uint32_t)voffset + (uint32_t)soffset;
+  if (off + 16 <= r.bytes)
+    memcpy(&v, r.base + off, 16);
+  return v;
+}
+inline void emu_raw_buffer_store_b128(emu_u32x4 v, emu_rsrc r, int voffset, int soffset, int)
+{
+  const uint32_t off = (uint32_t)voffset + (uint32_t)soffset;
+  if (off + 16 <= r.bytes)
+    memcpy(r.base + off, &v, 16);
+}
+#define __builtin_amdgcn_make_buffer_rsrc(...) emu_make_buffer_rsrc(__VA_ARGS__)
+#define __builtin_amdgcn_raw_buffer_load_b128(...) emu_raw_buffer_load_b128(__VA_ARGS__)
+#define __builtin_amdgcn_raw_buffer_store_b128(...) emu_raw_buffer_store_b128(__VA_ARGS__)
+
 inline int __popc(unsigned x) { return __builtin_popcount(x); }
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }

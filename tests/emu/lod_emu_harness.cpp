@@ -135,8 +135,9 @@ lod_emu_scalable_build(
 // lod_nn_search_kernel<false, true> + lod_finalise_inter_kernel + the frame preparation, as
 // lod_build_core launches them.  The level loop below is this harness' own (the library's is
 // HIP host code inside gpcc_attr_mi355.hip) and covers the periodic and the centroid
-// sub-samplers; the distance sub-sampler uses buffer instructions the emulator does not model --
-// the search, which is what inter prediction changes, does not depend on who made the lists.
+// sub-samplers: the distance sub-sampler's workgroups wait for one another (eight ticket
+// classes), and the emulator runs one workgroup at a time -- the search, which is what inter
+// prediction changes, does not depend on who made the lists.
 extern "C" int
 lod_emu_inter_build(
   const gpcc_lod_params* lp, const int32_t* xyz, int32_t n, const int32_t* xyz_ref, int32_t n_ref,
