@@ -468,6 +468,30 @@ int gpcc_pred_inverse(
   const int32_t* neigh_weight, const int32_t* indexes, const int32_t* qp_off,
   int32_t* attrs, const int32_t* values, const int8_t* icp_coeffs);
 
+/* The reflectance predicting transform over such a structure
+ * (encodeReflectancesPred / decodeReflectancesPred with enableAttrInterPred,
+ * AttributeEncoder.cpp:749-853, AttributeDecoder.cpp:328-400): every neighbour
+ * value the coder reads -- the prediction, the eligibility test of the direct
+ * predictors, their evaluation -- is the reference frame's reflectance for a
+ * flagged neighbour, and such a neighbour takes no quantisation-weight share.
+ * Arguments as gpcc_lift_forward_inter; values as gpcc_pred_forward / _inverse.
+ * STATUS (round 3): the DAG pass in its inter build and the spare-entry
+ * arrangement run under the CPU emulator against the oracle
+ * (tests/test_emu_lod.py); first hardware run: tests/test_zz_gpu_inter_lod.py
+ * in the round-end tier. */
+int gpcc_pred_forward_inter(
+  gpcc_ctx* ctx, const gpcc_pred_params* params, int32_t n,
+  const int32_t* neigh_count, const int32_t* neigh_index,
+  const int32_t* neigh_weight, const int32_t* inter_ref, const int32_t* indexes,
+  int32_t* attrs, const int32_t* attrs_ref, int32_t n_ref, int32_t* values);
+int gpcc_pred_inverse_inter(
+  gpcc_ctx* ctx, const gpcc_pred_params* params, int32_t n,
+  const int32_t* neigh_count, const int32_t* neigh_index,
+  const int32_t* neigh_weight, const int32_t* inter_ref, const int32_t* indexes,
+  int32_t* attrs, const int32_t* attrs_ref, int32_t n_ref,
+  const int32_t* values);
+
+
 /* Replaces the body of encodeColorsPred / encodeReflectancesPred minus the
  * entropy calls: attrs in source / out reconstruction, values [n][c] out (the
  * prediction mode in the low bits of the magnitudes, encodePredModeColor /

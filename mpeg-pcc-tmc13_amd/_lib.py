@@ -17,7 +17,7 @@ ABI_SYMBOLS = [
     "gpcc_raht_forward", "gpcc_raht_inverse", "gpcc_attr_morton_sort",
     "gpcc_dev_raht_forward", "gpcc_dev_raht_inverse", "gpcc_dev_attr_morton_sort",
     "gpcc_ctx_set_profiling", "gpcc_ctx_kernel_times", "gpcc_ctx_stats",
-    "gpcc_lift_forward", "gpcc_lift_inverse", "gpcc_lod_compute_weights", "gpcc_lod_build", "gpcc_lod_build_inter", "gpcc_lift_forward_inter", "gpcc_lift_inverse_inter", "gpcc_estimate_dist2", "gpcc_recolour", "gpcc_raht_encode_attr", "gpcc_raht_decode_attr",
+    "gpcc_lift_forward", "gpcc_lift_inverse", "gpcc_lod_compute_weights", "gpcc_lod_build", "gpcc_lod_build_inter", "gpcc_lift_forward_inter", "gpcc_lift_inverse_inter", "gpcc_pred_forward_inter", "gpcc_pred_inverse_inter", "gpcc_estimate_dist2", "gpcc_recolour", "gpcc_raht_encode_attr", "gpcc_raht_decode_attr",
     "gpcc_lift_encode_attr", "gpcc_lift_decode_attr", "gpcc_zero_run_pack", "gpcc_raht_encode_attr_packed",
     "gpcc_dev_lod_build", "gpcc_dev_lift_encode_attr", "gpcc_dev_lift_decode_attr",
     "gpcc_multi_create", "gpcc_multi_destroy", "gpcc_multi_num_devices", "gpcc_multi_uses_rccl", "gpcc_multi_rccl_selftest",
@@ -98,6 +98,8 @@ def load():
     lib.gpcc_lod_build.argtypes = [vp, C.POINTER(LodParams), vp, i32, vp, vp, vp, vp, vp, C.POINTER(i32)]
     for f in (lib.gpcc_lift_forward_inter, lib.gpcc_lift_inverse_inter):
         f.argtypes = [vp, C.POINTER(LiftParams), i32, vp, vp, vp, vp, vp, vp, vp, i32, vp]
+    for f in (lib.gpcc_pred_forward_inter, lib.gpcc_pred_inverse_inter):
+        f.argtypes = [vp, C.POINTER(PredParams), i32, vp, vp, vp, vp, vp, vp, vp, i32, vp]
     lib.gpcc_lod_build_inter.argtypes = [vp, C.POINTER(LodParams), vp, i32, vp, i32, i32, i32, vp, vp, vp, vp, vp,
                                          C.POINTER(i32), vp]
     for name in ("gpcc_raht_encode_attr", "gpcc_raht_decode_attr"):

@@ -1394,13 +1394,13 @@ check_pred_params(const gpcc_pred_params* p, int n, int c, bool encoder)
 }
 
 size_t
-pred_scratch_bytes(int n)
+pred_scratch_bytes(int n, int n_frame = 0)
 {
   Arena ar;
-  ar.take<int32_t>(n);
-  ar.take<int32_t>(n);
-  ar.take<unsigned long long>(n);
-  ar.take<unsigned long long>(n);
+  ar.take<int32_t>((size_t)n + n_frame);
+  ar.take<int32_t>((size_t)n + n_frame);
+  ar.take<unsigned long long>((size_t)n + n_frame);
+  ar.take<unsigned long long>((size_t)n + n_frame);
   ar.take<uint32_t>((size_t)n * 4);
   ar.take<int32_t>(64);
   ar.take<unsigned long long>(GPCC_MAX_LODS * 18);
@@ -1413,6 +1413,7 @@ pred_scratch_bytes(int n)
   ar.take<uint8_t>((size_t)n + 1);
   ar.take<int32_t>((size_t)n + 1);
   ar.take<long long>((size_t)n / kRcScanBlock + 2);
+  ar.take<int32_t>((size_t)n_frame + 1);
   return ar.used;
 }
 
@@ -1427,7 +1428,11 @@ template<int C>
 int
 launch_pred(
   gpcc_ctx* ctx, bool encoder, const gpcc_pred_params* p, int n, const PredDev& d,
-  int8_t* d_icp, char* scratch)
+  int8_t* d_icp, char* scratch,
+  // attribute inter prediction (n_frame > 0, one component): h_frame [n_frame] the reference
+  // frame's reflectances (host memory); the caller has pointed the neighbours that live in
+  // that frame at n + r (PredCtx::frame_attr)
+  int n_frame = 0, const int32_t* h_frame = nullptr)
 {
   hipStream_t st = ctx->stream;
   PredCtx cx{};
@@ -1491,10 +1496,10 @@ launch_pred(
   Arena ar;
   ar.base = scratch;
   ar.cap = ~size_t(0);
-  cx.indeg = ar.take<int32_t>(n);
-  cx.recv = ar.take<int32_t>(n);
-  cx.acc = ar.take<unsigned long long>(n);
-  cx.qw = ar.take<unsigned long long>(n);
+  cx.indeg = ar.take<int32_t>((size_t)n + n_frame);
+  cx.recv = ar.take<int32_t>((size_t)n + n_frame);
+  cx.acc = ar.take<unsigned long long>((size_t)n + n_frame);
+  cx.qw = ar.take<unsigned long long>((size_t)n + n_frame);
   cx.rec = ar.take<uint32_t>((size_t)n * 4);
   int32_t* small = ar.take<int32_t>(64);
   cx.ticket = small;
@@ -1513,6 +1518,19 @@ launch_pred(
   uint8_t* ev_up = ar.take<uint8_t>((size_t)n + 1);
   int32_t* ev_state = ar.take<int32_t>((size_t)n + 1);
   long long* scan_sums = ar.take<long long>((size_t)n / kRcScanBlock + 2);
+  int32_t* d_frame = ar.take<int32_t>((size_t)n_frame + 1);
+  if (n_frame > 0) {
+    HIP_TRY(h2d_user(ctx, d_frame, h_frame, sizeof(int32_t) * (size_t)n_frame, st));
+    cx.frame_attr = d_frame;
+  }
+  // the DAG pass: its inter-prediction build where neighbours may live in the reference frame
+#define GPCC_PRED_DAG(ENC)                                                          \
+  do {                                                                              \
+    if (n_frame > 0)                                                                \
+      pred_dag_kernel<C, ENC, true><<<std::max(pgrid, 1), 256, 0, st>>>(cx);        \
+    else                                                                            \
+      pred_dag_kernel<C, ENC><<<std::max(pgrid, 1), 256, 0, st>>>(cx);              \
+  } while (0)
   if (deciding) {
     // log2 of every integer the rate estimate can ask for, from THIS host's libm (the
     // reference's own log2): once per context
@@ -1559,9 +1577,9 @@ launch_pred(
   if (!deciding) {
     Timer t(ctx, "pred_dag");
     if (encoder)
-      pred_dag_kernel<C, true><<<std::max(pgrid, 1), 256, 0, st>>>(cx);
+      GPCC_PRED_DAG(true);
     else
-      pred_dag_kernel<C, false><<<std::max(pgrid, 1), 256, 0, st>>>(cx);
+      GPCC_PRED_DAG(false);
   } else {
     // the DAG pass and the rate model's trajectory, iterated to their fixed point
     int32_t* flag = small + 24;
@@ -1578,7 +1596,7 @@ launch_pred(
       HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int32_t), st));
       {
         Timer t(ctx, "pred_dag");
-        pred_dag_kernel<C, true><<<std::max(pgrid, 1), 256, 0, st>>>(cx);
+        GPCC_PRED_DAG(true);
       }
       int32_t changed = 1;
       {
@@ -1615,6 +1633,7 @@ launch_pred(
       return pred_encoder_unsettled();
     }
   }
+#undef GPCC_PRED_DAG
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(ctx->h_error, cx.error, sizeof(int32_t), hipMemcpyDeviceToHost, st));
   return GPCC_OK;
@@ -1635,7 +1654,9 @@ int
 host_pred(
   gpcc_ctx* ctx, bool encoder, const gpcc_pred_params* p, int n, int c, const int32_t* nc,
   const int32_t* ni, const int32_t* nw, const int32_t* indexes, const int32_t* qp_off,
-  int32_t* attrs, int32_t* values, int8_t* icp)
+  int32_t* attrs, int32_t* values, int8_t* icp,
+  // attribute inter prediction (null: none), as host_lift
+  const int32_t* inter_ref = nullptr, const int32_t* attrs_ref = nullptr, int n_frame = 0)
 {
   if (!ctx)
     return fail(GPCC_ERR_INVALID_ARG, "ctx is null");
@@ -1647,12 +1668,36 @@ host_pred(
   const bool icp_on = c == 3 && p->inter_component_prediction_enabled_flag;
   if (icp_on && !icp)
     return fail(GPCC_ERR_INVALID_ARG, "icp_coeffs is null");
+  if (inter_ref) {
+    if (!attrs_ref || n_frame <= 0 || n_frame > (1 << 27))
+      return fail(GPCC_ERR_INVALID_ARG, "reference frame: null, empty or too large");
+    if (c != 1 || p->scalable_lifting_enabled_flag)
+      return fail(
+        GPCC_ERR_UNSUPPORTED,
+        "inter prediction exists in the reference's reflectance predicting driver only, and not over a scalable structure");
+  } else
+    n_frame = 0;
   for (int i = 0; i < n; i++) {
     if (nc[i] < 0 || nc[i] > 3 || indexes[i] < 0 || indexes[i] >= n)
       return fail(GPCC_ERR_INVALID_ARG, "bad neighbour count / index table");
-    for (int j = 0; j < nc[i]; j++)
-      if (ni[3 * (size_t)i + j] < 0 || ni[3 * (size_t)i + j] >= i)
+    for (int j = 0; j < nc[i]; j++) {
+      const int32_t v = ni[3 * (size_t)i + j];
+      if (inter_ref && inter_ref[3 * (size_t)i + j]) {
+        if (v < 0 || v >= n_frame)
+          return fail(GPCC_ERR_INVALID_ARG, "a neighbour outside the reference frame");
+      } else if (v < 0 || v >= i)
         return fail(GPCC_ERR_INVALID_ARG, "a neighbour does not precede its predictor");
+    }
+  }
+  // neighbours in the reference frame are addressed behind the n predictors (launch_pred)
+  std::vector<int32_t> ni_frame;
+  if (inter_ref) {
+    ni_frame.assign(ni, ni + (size_t)n * 3);
+    for (int i = 0; i < n; i++)
+      for (int j = 0; j < nc[i]; j++)
+        if (inter_ref[3 * (size_t)i + j])
+          ni_frame[3 * (size_t)i + j] += n;
+    ni = ni_frame.data();
   }
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
@@ -1672,7 +1717,7 @@ host_pred(
     d.values = ar.take<int32_t>(N * c);
     d_icp = ar.take<int8_t>(GPCC_MAX_LODS * 3);
     scratch = ar.base ? ar.base + ar.used : nullptr;
-    ar.used += pred_scratch_bytes(n);
+    ar.used += pred_scratch_bytes(n, n_frame);
   };
   Arena m;
   carve(m);
@@ -1698,7 +1743,7 @@ host_pred(
     if (icp_on)
       HIP_TRY(hipMemcpyAsync(d_icp, icp, GPCC_MAX_LODS * 3, hipMemcpyHostToDevice, st));
   }
-  rcode = c == 1 ? launch_pred<1>(ctx, encoder, p, n, d, d_icp, scratch)
+  rcode = c == 1 ? launch_pred<1>(ctx, encoder, p, n, d, d_icp, scratch, n_frame, attrs_ref)
                  : launch_pred<3>(ctx, encoder, p, n, d, d_icp, scratch);
   if (rcode)
     return rcode;
@@ -3388,6 +3433,39 @@ gpcc_lift_inverse_inter(
     host_lift(
       ctx, false, params, n, 1, neigh_count, neigh_index, neigh_weight, indexes, nullptr, attrs,
       const_cast<int32_t*>(coeffs), nullptr, inter_ref, attrs_ref, n_ref),
+    n);
+}
+
+int
+gpcc_pred_forward_inter(
+  gpcc_ctx* ctx, const gpcc_pred_params* params, int32_t n, const int32_t* neigh_count,
+  const int32_t* neigh_index, const int32_t* neigh_weight, const int32_t* inter_ref,
+  const int32_t* indexes, int32_t* attrs, const int32_t* attrs_ref, int32_t n_ref, int32_t* values)
+{
+  if (!inter_ref)
+    return counted(ctx, fail(GPCC_ERR_INVALID_ARG, "inter_ref is null"), n);
+  return counted(
+    ctx,
+    host_pred(
+      ctx, true, params, n, 1, neigh_count, neigh_index, neigh_weight, indexes, nullptr, attrs, values,
+      nullptr, inter_ref, attrs_ref, n_ref),
+    n);
+}
+
+int
+gpcc_pred_inverse_inter(
+  gpcc_ctx* ctx, const gpcc_pred_params* params, int32_t n, const int32_t* neigh_count,
+  const int32_t* neigh_index, const int32_t* neigh_weight, const int32_t* inter_ref,
+  const int32_t* indexes, int32_t* attrs, const int32_t* attrs_ref, int32_t n_ref,
+  const int32_t* values)
+{
+  if (!inter_ref)
+    return counted(ctx, fail(GPCC_ERR_INVALID_ARG, "inter_ref is null"), n);
+  return counted(
+    ctx,
+    host_pred(
+      ctx, false, params, n, 1, neigh_count, neigh_index, neigh_weight, indexes, nullptr, attrs,
+      const_cast<int32_t*>(values), nullptr, inter_ref, attrs_ref, n_ref),
     n);
 }
 

@@ -80,6 +80,14 @@ struct PredCtx {
   int32_t packed_ok;  // quant_neigh_weight >= 0 and their sum < 256
   int32_t* error;
   unsigned long long* icp_sums;  // [GPCC_MAX_LODS][18]: 8 weights x {k=1,2}, orig x {1,2}
+  // attribute inter prediction (pred_dag_kernel<.., true>, one component): a neighbour index
+  // >= n names entry (index - n) of the reference frame; its value is always there
+  // (predictReflectance PCCTMC3Common.h:555-585, predModeEligibleRefl
+  // AttributeCommon.cpp:176-210, decidePredModeRefl AttributeEncoder.cpp:663-717 all read the
+  // frame's reflectance for such a neighbour).  indeg / recv / acc / qw have n_frame spare
+  // entries behind the n predictors: the shares such a neighbour would be skipped for
+  // (computeQuantizationWeights :913-914) land there.
+  const int32_t* frame_attr;  // [n_frame]
 };
 
 __device__ __forceinline__ int
@@ -152,12 +160,19 @@ pred_quant_weights_body(const PredCtx& cx)
         if (j < cnt) {
           nb[j] = cx.ni[3 * (size_t)i + j];
           const int64_t t = (int64_t)(cx.n - 1 - nb[j]) - base;
-          tl[j] = t < 64 ? (int)t : 64;
+          // (t < 0: a neighbour in the reference frame, addressed behind the n predictors --
+          // its share goes the memory way, into an entry nobody reads)
+          tl[j] = t >= 0 && t < 64 ? (int)t : 64;
         }
     }
+    // (the wavefront is in lock step here: every slot is cleared before a lane counts into
+    // another lane's, every count is in before a lane reads its own -- said to the compiler,
+    // and to the CPU emulator of tests/emu, with wave barriers; no instruction on the device)
+    __builtin_amdgcn_wave_barrier();
     for (int j = 0; j < 3; j++)
       if (tl[j] < 64)
         __hip_atomic_fetch_add(&lneed[wv][tl[j]], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __builtin_amdgcn_wave_barrier();
     const int need_l = __hip_atomic_load(&lneed[wv][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     const int need_g = need - need_l;
     bool gdone = !pending || need_g == 0;
@@ -539,7 +554,7 @@ pred_values_diff_kernel(const int32_t* __restrict__ values, int32_t* __restrict_
 }
 
 // ---- reconstruction: the DAG walked forward --------------------------------
-template<int C, bool ENC>
+template<int C, bool ENC, bool INTER = false>
 __global__ __launch_bounds__(256) void
 pred_dag_kernel(PredCtx cx)
 {
@@ -605,6 +620,14 @@ pred_dag_kernel(PredCtx cx)
         nbv[j][k] = 0;
     uint32_t have = 0;  // neighbours received
     const uint32_t want = live ? (1u << cnt) - 1 : 0;
+    if (INTER) {
+      // neighbours in the reference frame: their values do not wait for anybody
+      for (int j = 0; j < 3; j++)
+        if (j < cnt && nidx[j] >= cx.n) {
+          nbv[j][0] = cx.frame_attr[nidx[j] - cx.n];
+          have |= 1u << j;
+        }
+    }
     int32_t myrec[C];
     for (int k = 0; k < C; k++)
       myrec[k] = 0;
@@ -615,7 +638,7 @@ pred_dag_kernel(PredCtx cx)
       // neighbours inside the claim: lane to lane
       for (int j = 0; j < 3; j++) {
         const int src = nidx[j] - base;
-        const bool inw = j < cnt && src >= 0;
+        const bool inw = j < cnt && src >= 0 && (!INTER || nidx[j] < cx.n);
         const int sl = inw ? src : lane;
         const int d = __shfl(mydone, sl);
         int32_t v[C];

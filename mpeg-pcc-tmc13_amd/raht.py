@@ -206,6 +206,23 @@ class Context:
                       ix.ctypes.data, a.ctypes.data, ar.ctypes.data, len(ar), co.ctypes.data))
         return co, a
 
+    def pred_inter(self, forward, params, lod, attrs_ref, attrs=None, values=None):
+        """the reflectance predicting transform with neighbours in a reference frame (lod as
+        lod_build_inter returns it) -> (values [n,1] coding order, recon [n,1] point order)"""
+        n = len(lod["nc"])
+        nc = np.ascontiguousarray(lod["nc"], dtype=np.int32)
+        ni = np.ascontiguousarray(lod["ni"], dtype=np.int32)
+        nw = np.ascontiguousarray(lod["w"], dtype=np.int32)
+        xr = np.ascontiguousarray(lod["ref"], dtype=np.int32)
+        ix = np.ascontiguousarray(lod["indexes"], dtype=np.int32)
+        ar = np.ascontiguousarray(attrs_ref, dtype=np.int32).reshape(-1)
+        a = np.ascontiguousarray(attrs, dtype=np.int32).copy() if forward else np.zeros((n, 1), np.int32)
+        v = np.zeros((n, 1), np.int32) if forward else np.ascontiguousarray(values, dtype=np.int32).copy()
+        fn = self._lib.gpcc_pred_forward_inter if forward else self._lib.gpcc_pred_inverse_inter
+        _lib.check(fn(self._h, C.byref(params), n, nc.ctypes.data, ni.ctypes.data, nw.ctypes.data, xr.ctypes.data,
+                      ix.ctypes.data, a.ctypes.data, ar.ctypes.data, len(ar), v.ctypes.data))
+        return v, a
+
     def estimate_dist2(self, xyz, sampling_period=100, search_range=128, percentile=0.85):
         """pcc::estimateDist2 (encoder.cpp:1203 uses period 100, range 128) -> shift bits"""
         xyz = np.ascontiguousarray(xyz, dtype=np.int32)

@@ -23,7 +23,7 @@ struct Fiber {
   uint64_t val = 0;
 };
 
-constexpr size_t kStack = 192 * 1024;
+constexpr size_t kStack = 1024 * 1024;
 std::vector<Fiber> g_fibers;
 std::vector<char*> g_stacks;
 ucontext_t g_sched;

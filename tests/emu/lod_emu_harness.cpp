@@ -432,3 +432,87 @@ lift_emu_inter(
     free(b);
   return 0;
 }
+
+// ---- the reflectance predicting transform with neighbours in a reference frame ---------------
+// pred_dag_kernel<1, ENC, true> with the arrangement host_pred / launch_pred use: flagged
+// neighbours point behind the n predictors (PredCtx::frame_attr), the share arrays have spare
+// entries there.  Decoder, and the encoder without direct predictors (with them the library
+// iterates this pass and its rate model's scan; the pass is the same).  One QP layer.  The
+// persistent kernels run as ONE workgroup here (the emulator runs workgroups one after another).
+#include "pred_kernels.hpp"
+
+extern "C" int
+pred_emu_inter(
+  const gpcc_pred_params* p, int32_t encoder, int32_t n, const int32_t* nc, const int32_t* ni,
+  const int32_t* nw, const int32_t* inter_ref, const int32_t* indexes, int32_t* attrs,
+  const int32_t* attrs_ref, int32_t n_ref, int32_t* values)
+{
+  if (p->num_qp_layers != 1 || p->scalable_lifting_enabled_flag || n <= 0 || n_ref <= 0
+      || (encoder && p->max_num_direct_predictors > 0))
+    return -1;
+  std::vector<void*> blocks;
+  const size_t N = (size_t)n, NE = N + (size_t)n_ref;
+  int32_t* d_ni = carve<int32_t>(&blocks, 3 * N);
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j < 3; j++)
+      d_ni[3 * i + j] = ni[3 * i + j] + (j < nc[i] && inter_ref[3 * i + j] ? n : 0);
+  PredCtx cx{};
+  cx.n = n;
+  cx.c = 1;
+  cx.num_lods = p->num_lods;
+  for (int l = 0; l < p->num_lods; l++)
+    cx.npl[l] = p->num_points_in_lod[l];
+  cx.num_ranges = 1;
+  cx.max_levels = p->max_num_detail_levels;
+  cx.bitdepth = p->bitdepth;
+  cx.num_qp_layers = 1;
+  memcpy(cx.layer_qp, p->layer_qp, sizeof(cx.layer_qp));
+  cx.max_qp = p->max_qp;
+  cx.max_direct = p->max_num_direct_predictors;
+  cx.avg_disabled = p->direct_avg_predictor_disabled_flag != 0;
+  cx.threshold = p->adaptive_prediction_threshold;
+  cx.icp_enabled = 0;
+  for (int k = 0; k < 3; k++)
+    cx.qnw[k] = p->quant_neigh_weight[k];
+  cx.nc = nc;
+  cx.ni = d_ni;
+  cx.nw = nw;
+  cx.indexes = indexes;
+  cx.qp_off = nullptr;
+  cx.attrs = attrs;
+  cx.values = values;
+  cx.icp = carve<int8_t>(&blocks, GPCC_MAX_LODS * 3);
+  cx.indeg = carve<int32_t>(&blocks, NE);
+  cx.recv = carve<int32_t>(&blocks, NE);
+  cx.acc = carve<unsigned long long>(&blocks, NE);
+  cx.qw = carve<unsigned long long>(&blocks, NE);
+  cx.rec = carve<uint32_t>(&blocks, 4 * N);
+  memset(cx.indeg, 0, sizeof(int32_t) * NE);
+  memset(cx.recv, 0, sizeof(int32_t) * NE);
+  memset(cx.acc, 0, sizeof(unsigned long long) * NE);
+  memset(cx.qw, 0, sizeof(unsigned long long) * NE);
+  memset(cx.rec, 0, sizeof(uint32_t) * 4 * N);
+  int32_t* small = carve<int32_t>(&blocks, 64);
+  memset(small, 0, sizeof(int32_t) * 64);
+  cx.ticket = small;
+  cx.error = small + 8;
+  cx.wide = small + 16;
+  cx.packed_ok = cx.qnw[0] >= 0 && cx.qnw[1] >= 0 && cx.qnw[2] >= 0 && cx.qnw[0] + cx.qnw[1] + cx.qnw[2] < 256;
+  cx.icp_sums = carve<unsigned long long>(&blocks, GPCC_MAX_LODS * 18);
+  cx.tag = 1;
+  cx.frame_attr = attrs_ref;
+  hipLaunchKernelGGL(pred_indegree_kernel, dim3(lod_grid(n, 256)), dim3(256), 0, nullptr, cx);
+  if (cx.qnw[0] || cx.qnw[1] || cx.qnw[2])
+    hipLaunchKernelGGL(pred_quant_weights_kernel, dim3(1), dim3(256), 0, nullptr, cx);
+  else
+    for (int i = 0; i < n; i++)
+      cx.qw[i] = 256;
+  if (encoder)
+    hipLaunchKernelGGL((pred_dag_kernel<1, true, true>), dim3(1), dim3(256), 0, nullptr, cx);
+  else
+    hipLaunchKernelGGL((pred_dag_kernel<1, false, true>), dim3(1), dim3(256), 0, nullptr, cx);
+  const int err = *cx.error;
+  for (void* b : blocks)
+    free(b);
+  return err ? -7 : 0;
+}

@@ -27,7 +27,26 @@ def lib():
         _lib.lift_emu_inter.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _i32p, _i32p, _i32p, _i32p, _i32p, _i32p, _i32p,
                                         C.c_int32, _i32p]
         _lib.lift_emu_inter.restype = C.c_int
+        _lib.pred_emu_inter.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _i32p, _i32p, _i32p, _i32p, _i32p, _i32p, _i32p,
+                                        C.c_int32, _i32p]
+        _lib.pred_emu_inter.restype = C.c_int
     return _lib
+
+
+def pred_inter(forward, pp, lod, attrs_ref, attrs=None, values=None):
+    """the reflectance predicting transform with neighbours in a reference frame: the library's DAG
+    pass (decoder; encoder without direct predictors) under the emulator -> (values [n,1], recon [n,1])"""
+    n = len(lod["nc"])
+    a = np.ascontiguousarray(attrs, dtype=np.int32).copy().reshape(-1) if forward else np.zeros(n, np.int32)
+    v = np.zeros(n, np.int32) if forward else np.ascontiguousarray(values, dtype=np.int32).copy().reshape(-1)
+    ar = np.ascontiguousarray(attrs_ref, dtype=np.int32).reshape(-1)
+    rc = lib().pred_emu_inter(C.addressof(pp), int(forward), n, np.ascontiguousarray(lod["nc"], dtype=np.int32),
+                              np.ascontiguousarray(lod["ni"], dtype=np.int32).reshape(-1),
+                              np.ascontiguousarray(np.asarray(lod["w"]).astype(np.int32)).reshape(-1),
+                              np.ascontiguousarray(lod["ref"], dtype=np.int32).reshape(-1),
+                              np.ascontiguousarray(lod["indexes"], dtype=np.int32), a, ar, len(ar), v)
+    assert rc == 0, rc
+    return v.reshape(n, 1), a.reshape(n, 1)
 
 
 def lift_inter(forward, lf, lod, attrs_ref, attrs=None, coeffs=None):

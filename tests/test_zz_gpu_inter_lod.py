@@ -135,3 +135,50 @@ def test_operator_inter_slice_with_the_lod_search_on_the_device(name):
     assert got["rec_enc_md5"] == rec and got["rec_dec_md5"] == rec
     assert "falls back" not in err
     assert (got["lod_device"], got["lod_cpu"]) == (2, 0)
+
+
+PRED_WORKER = r'''
+import json, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import conftest
+import numpy as np
+import lod_helpers as lh
+from mpeg_pcc_tmc13_amd import context, lod_params, pred_params, synth
+ctx = context(0)
+rng = np.random.default_rng(7)
+cases = 0
+for xyz, attrs in (synth.lidar_cloud(9000, seed=61), synth.dense_cloud(6000, seed=3, bits=7), synth.random_cloud(5, seed=2, bits=3),
+                   synth.lidar_cloud(200000, seed=62)):
+    attrs = attrs[:, :1].copy()
+    if attrs.max() > 255:
+        attrs = attrs >> 8
+    keep = rng.random(len(xyz)) > 0.1 if len(xyz) > 5 else np.ones(len(xyz), bool)
+    xr = np.clip(xyz + rng.integers(-2, 3, size=xyz.shape), 0, None)[keep].astype(np.int32)
+    ar = np.clip(attrs + rng.integers(-6, 7, size=attrs.shape), 0, 255)[keep].astype(np.int32)
+    lp = lod_params(lifting=False, intra_range=64)
+    lp.intra_lod_prediction_skip_layers = 0
+    lod = lh.oracle_lod_generate_inter(xyz, xr, lp, 64, 1)
+    g = ctx.lod_build_inter(lp, xyz, xr, 64, 1)
+    for k in ("npl", "indexes", "nc", "ni", "ref"):
+        assert np.array_equal(g[k], lod[k]), k
+    for direct, qp, qnw in ((3, 4, (0, 0, 0)), (3, 28, (0, 0, 0)), (0, 16, (25, 12, 12)), (1, 10, (25, 12, 12))):
+        pp = pred_params(lod["npl"], qp=qp, chroma_offset=0, bitdepth=8, threshold=4, direct=direct, icp=False,
+                         quant_neigh_weight=qnw, max_levels=lp.num_detail_levels_minus1 + 1)
+        v, rec, modes = lh.pred_inter(True, pp, lod, ar, attrs=attrs)
+        gv, grec = ctx.pred_inter(True, pp, g, ar, attrs=attrs)
+        assert np.array_equal(gv, v) and np.array_equal(grec, rec), ("encoder", len(xyz), direct, qp)
+        _, gdec = ctx.pred_inter(False, pp, g, ar, values=v)
+        assert np.array_equal(gdec, rec), ("decoder", len(xyz), direct, qp)
+        cases += 1
+print(json.dumps(dict(cases=cases)))
+'''
+
+
+def test_inter_frame_reflectance_predicting_transform_vs_oracle():
+    """gpcc_pred_forward_inter / gpcc_pred_inverse_inter over gpcc_lod_build_inter's structure == the
+    oracle (whose values are the symbols of the reference operator's bitstream, tests/test_oracle_pred.py):
+    the CTC encoder with direct predictors -- chosen in the reference frame too --, the decoder, neighbour
+    shares of the quantisation weights."""
+    r = subprocess.run([sys.executable, "-c", PRED_WORKER, ROOT], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    assert json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])["cases"] == 16
