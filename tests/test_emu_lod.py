@@ -140,3 +140,28 @@ def test_inter_frame_predicting_transform_under_the_emulator():
                 ev, erec = el.pred_inter(True, pp, lod, ar, attrs=attrs)
                 np.testing.assert_array_equal(ev, v)
                 np.testing.assert_array_equal(erec, rec)
+
+
+def test_intra_predicting_transform_kernels_under_the_emulator():
+    """The same kernels on an intra structure (no neighbour flagged): the quantisation-weight kernel with
+    neighbour shares -- packed count / sum words, LDS slots inside a claim -- and the DAG pass, decoder and
+    encoder without direct predictors, == the oracle."""
+    from mpeg_pcc_tmc13_amd import lod_params, pred_params, synth
+    for xyz, attrs in (synth.lidar_cloud(2500, seed=5), synth.dense_cloud(3000, seed=3, bits=7)):
+        attrs = attrs[:, :1].copy()
+        if attrs.max() > 255:
+            attrs = attrs >> 8
+        lp = lod_params(lifting=False, intra_range=64)
+        lp.intra_lod_prediction_skip_layers = 0
+        lod = dict(lh.oracle_lod_generate(xyz, lp))
+        lod["ref"] = np.zeros((len(xyz), 3), np.int32)
+        for direct, qnw in ((0, (25, 12, 12)), (0, (120, 80, 60)), (3, (16, 8, 4))):
+            pp = pred_params(lod["npl"], qp=16, chroma_offset=0, bitdepth=8, threshold=4, direct=direct, icp=False,
+                             quant_neigh_weight=qnw, max_levels=lp.num_detail_levels_minus1 + 1)
+            v, rec, _, modes = lh.oracle_pred(True, pp, lod, attrs=attrs)
+            _, dec = el.pred_inter(False, pp, lod, attrs[:1], values=v)
+            np.testing.assert_array_equal(dec, rec, err_msg=f"decoder direct={direct} qnw={qnw}")
+            if direct == 0:
+                ev, erec = el.pred_inter(True, pp, lod, attrs[:1], attrs=attrs)
+                np.testing.assert_array_equal(ev, v)
+                np.testing.assert_array_equal(erec, rec)
