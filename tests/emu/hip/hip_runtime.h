@@ -63,7 +63,11 @@ enum OpKind { kOpBallot = 1, kOpShfl, kOpBarrier, kOpSleep };
 struct Uint3 { unsigned x, y, z; };
 extern Uint3 g_block_idx, g_block_dim, g_grid_dim;
 Uint3 cur_thread_idx();
+Uint3 cur_block_idx();
 int cur_lane();
+// how many workgroups of a launch run together (default 1 = one after another); more than one
+// only for kernels without __shared__ data (see emu_core.cpp)
+void set_concurrent_blocks(unsigned n);
 
 // Rendezvous of the live lanes of the calling fiber's wavefront: every lane
 // contributes `v`; on return snap[0..63] holds all contributions (0 for lanes
@@ -100,7 +104,7 @@ inline T from_bits(uint64_t b)
 }  // namespace emu
 
 #define threadIdx (emu::cur_thread_idx())
-#define blockIdx (emu::g_block_idx)
+#define blockIdx (emu::cur_block_idx())
 #define blockDim (emu::g_block_dim)
 #define gridDim (emu::g_grid_dim)
 

@@ -133,11 +133,8 @@ lod_emu_scalable_build(
 
 // ---- attribute inter prediction ---------------------------------------------------------
 // lod_nn_search_kernel<false, true> + lod_finalise_inter_kernel + the frame preparation, as
-// lod_build_core launches them.  The level loop below is this harness' own (the library's is
-// HIP host code inside gpcc_attr_mi355.hip) and covers the periodic and the centroid
-// sub-samplers: the distance sub-sampler's workgroups wait for one another (eight ticket
-// classes), and the emulator runs one workgroup at a time -- the search, which is what inter
-// prediction changes, does not depend on who made the lists.
+// lod_build_core launches them, with all three sub-samplers.  The level loop below is this
+// harness' own (the library's is HIP host code inside gpcc_attr_mi355.hip).
 extern "C" int
 lod_emu_inter_build(
   const gpcc_lod_params* lp, const int32_t* xyz, int32_t n, const int32_t* xyz_ref, int32_t n_ref,
@@ -145,9 +142,11 @@ lod_emu_inter_build(
   int32_t* neigh_weight, int32_t* indexes, int32_t* num_points_in_lod, int32_t* num_lods,
   int32_t* inter_ref)
 {
-  if (lp->scalable_lifting_enabled_flag || (lp->lod_decimation_type != 1 && lp->lod_decimation_type != 2) || n <= 0
-      || n_ref <= 0)
+  if (lp->scalable_lifting_enabled_flag || lp->lod_decimation_type < 0 || lp->lod_decimation_type > 2 || n <= 0 || n_ref < 0)
     return -1;
+  // n_ref == 0: the intra build (lod_nn_search_kernel<false, false>, lod_finalise_kernel, the
+  // block's own search ranges)
+  const bool inter = n_ref > 0;
   std::vector<void*> blocks;
   const size_t N = (size_t)n, NF = (size_t)n_ref;
   auto sorted = [&](const int32_t* p, size_t cnt, int64_t* code, int32_t* order) {
@@ -198,12 +197,20 @@ lod_emu_inter_build(
   memset(d_counts, 0, sizeof(int32_t) * 64);
   memset(d_scan, 0, sizeof(unsigned long long) * 1024);
   long long* d_atlas_limit = carve<long long>(&blocks, 1);
+  // the distance sub-sampler's cells
+  int32_t* d_cell_first = carve<int32_t>(&blocks, N + 2);
+  int32_t* d_positions = carve<int32_t>(&blocks, N + 1);
+  int64_t* d_cell_key = carve<int64_t>(&blocks, N + 1);
+  uint32_t* d_cell_state = carve<uint32_t>(&blocks, 4 * (N + 1));
+  memset(d_cell_state, 0, sizeof(uint32_t) * 4 * (N + 1));
+  int32_t* d_small = carve<int32_t>(&blocks, 64);
+  memset(d_small, 0, sizeof(int32_t) * 64);
   int32_t* box_ret[3][2];
   int32_t* box_ref[3][2];
   int32_t* box_frame[3][2];
   boxes_of(n, box_ret);
   boxes_of(n, box_ref);
-  boxes_of(n_ref, box_frame);
+  boxes_of(inter ? n_ref : 1, box_frame);
   int32_t* d_pred_count = carve<int32_t>(&blocks, N);
   int32_t* d_pred_point = carve<int32_t>(&blocks, 3 * N);
   uint64_t* d_pred_dist2 = carve<uint64_t>(&blocks, 3 * N);
@@ -215,7 +222,8 @@ lod_emu_inter_build(
   // the reference frame
   int64_t* d_fcode = carve<int64_t>(&blocks, NF);
   int32_t* d_forder = carve<int32_t>(&blocks, NF);
-  sorted(xyz_ref, NF, d_fcode, d_forder);
+  if (inter)
+    sorted(xyz_ref, NF, d_fcode, d_forder);
   int32_t* d_fpos = carve<int32_t>(&blocks, 3 * NF);
   int32_t* d_fbpos = carve<int32_t>(&blocks, 3 * NF);
   int32_t* d_flist = carve<int32_t>(&blocks, NF + 1);
@@ -223,9 +231,11 @@ lod_emu_inter_build(
   const int b0 = lp->lod_neigh_bias[0], b1 = lp->lod_neigh_bias[1], b2 = lp->lod_neigh_bias[2];
   hipLaunchKernelGGL(lod_gather_pos_kernel, dim3(lod_grid(n, 256)), dim3(256), 0, nullptr, n, xyz,
                      (const int32_t*)d_order, b0, b1, b2, d_pos, d_bpos, d_list_a);
-  hipLaunchKernelGGL(lod_gather_pos_kernel, dim3(lod_grid(n_ref, 256)), dim3(256), 0, nullptr, n_ref, xyz_ref,
-                     (const int32_t*)d_forder, b0, b1, b2, d_fpos, d_fbpos, d_flist);
-  build_boxes(box_frame, d_flist, n_ref, d_fbpos);
+  if (inter) {
+    hipLaunchKernelGGL(lod_gather_pos_kernel, dim3(lod_grid(n_ref, 256)), dim3(256), 0, nullptr, n_ref, xyz_ref,
+                       (const int32_t*)d_forder, b0, b1, b2, d_fpos, d_fbpos, d_flist);
+    build_boxes(box_frame, d_flist, n_ref, d_fbpos);
+  }
 
   std::vector<int32_t> npl;
   npl.push_back(n);
@@ -242,7 +252,43 @@ lod_emu_inter_build(
       n_ref_l = n_in;
     } else {
       const int period = lp->lod_sampling_period[lod];
-      if (lp->lod_decimation_type == 1) {
+      if (lp->lod_decimation_type == 0) {
+        // subsampleByDistance as lod_build_core launches it; its workgroups (eight ticket
+        // classes) wait for one another: they run together here (no LDS in that kernel)
+        LodCtx lc{};
+        lc.n = n;
+        lc.code = d_code;
+        lc.order = d_order;
+        lc.pos = d_pos;
+        lc.bpos = d_bpos;
+        lc.input = d_input;
+        lc.n_in = n_in;
+        lc.shift3 = 3 * (shift_bits0 + 1);
+        lc.boundary = std::min(63, lc.shift3 + 21);
+        lc.radius2 = (int64_t)3 << (shift_bits0 << 1);
+        lc.cell_first = d_cell_first;
+        lc.cell_key = d_cell_key;
+        lc.cell_state = d_cell_state;
+        lc.ticket = d_small;
+        lc.error = d_small + 8;
+        lc.epoch = lod + 1;
+        lc.flags = d_flags;
+        hipLaunchKernelGGL(lod_flag_cell_heads_kernel, dim3(lod_grid(n_in, 256)), dim3(256), 0, nullptr, lc, d_heads, d_positions);
+        scan_epoch++;
+        const int g0 = (int)std::min<int64_t>(1024, ((int64_t)n_in + 1023) / 1024);
+        hipLaunchKernelGGL(lod_partition_kernel, dim3(std::max(g0, 1)), dim3(256), 0, nullptr, n_in, (const uint8_t*)d_heads,
+                           (const int32_t*)d_positions, d_cell_first, (int32_t*)nullptr, d_counts, d_scan, scan_epoch);
+        const int ncell = d_counts[0];
+        d_cell_first[ncell] = n_in;
+        memset(d_small, 0, sizeof(int32_t) * 8);
+        lc.ncell = ncell;
+        hipLaunchKernelGGL(lod_cell_keys_kernel, dim3(lod_grid(ncell, 256)), dim3(256), 0, nullptr, lc);
+        emu::set_concurrent_blocks(8);
+        hipLaunchKernelGGL(lod_subsample_distance_kernel, dim3(8), dim3(256), 0, nullptr, lc);
+        emu::set_concurrent_blocks(1);
+        if (d_small[8])
+          return -7;
+      } else if (lp->lod_decimation_type == 1) {
         hipLaunchKernelGGL(lod_flag_periodic_kernel, dim3(lod_grid(n_in, 256)), dim3(256), 0, nullptr, n_in, period, d_flags);
       } else {
         LodCtx lc{};
@@ -288,8 +334,8 @@ lod_emu_inter_build(
       nc.shift3 = 3 * (1 + shift_bits0);
       nc.boundary = std::min(63, nc.shift3 + 21);
       nc.distribution = lp->prediction_with_distribution_enabled;
-      nc.range_inter = search_range;
-      nc.range_intra = search_range;
+      nc.range_inter = inter ? search_range : lp->inter_lod_search_range;
+      nc.range_intra = inter ? search_range : lp->intra_lod_search_range;
       nc.intra = lod >= lp->intra_lod_prediction_skip_layers;
       nc.max_neigh = lp->num_pred_nearest_neighbours_minus1 + 1;
       for (int lev = 0; lev < 3; lev++)
@@ -321,21 +367,35 @@ lod_emu_inter_build(
       *d_atlas_limit = INT64_MAX;
       if (n_ret > 0)
         hipLaunchKernelGGL(lod_atlas_limit_kernel, dim3(lod_grid(n_ret, 256)), dim3(256), 0, nullptr, nc, d_atlas_limit);
-      hipLaunchKernelGGL((lod_nn_search_kernel<false, true>), dim3(lod_grid(n_ref_l, 256)), dim3(256), 0, nullptr, nc);
+      if (inter)
+        hipLaunchKernelGGL((lod_nn_search_kernel<false, true>), dim3(lod_grid(n_ref_l, 256)), dim3(256), 0, nullptr, nc);
+      else
+        hipLaunchKernelGGL((lod_nn_search_kernel<false, false>), dim3(lod_grid(n_ref_l, 256)), dim3(256), 0, nullptr, nc);
     }
     if (n_ret > 0)
       npl.push_back(n_ret);
     std::swap(d_input, d_ret);
     n_in = n_ret;
   }
-  hipLaunchKernelGGL(lod_finalise_inter_kernel, dim3(lod_grid(n, 256)), dim3(256), 0, nullptr, n, d_pred_count,
-                     (const int32_t*)d_pred_point, (const int32_t*)d_pt2pred, d_pred_dist2, d_neigh_index, d_inter_ref,
-                     frame_distance);
+  if (inter)
+    hipLaunchKernelGGL(lod_finalise_inter_kernel, dim3(lod_grid(n, 256)), dim3(256), 0, nullptr, n, d_pred_count,
+                       (const int32_t*)d_pred_point, (const int32_t*)d_pt2pred, d_pred_dist2, d_neigh_index, d_inter_ref,
+                       frame_distance);
+  else {
+    hipLaunchKernelGGL(lod_finalise_kernel, dim3(lod_grid(n, 256)), dim3(256), 0, nullptr, n, 0, d_pred_count,
+                       (const int32_t*)d_pred_point, (const int32_t*)d_pt2pred, d_pred_dist2, d_neigh_index);
+    memset(d_inter_ref, 0, sizeof(int32_t) * 3 * N);
+  }
   hipLaunchKernelGGL(lod_compute_weights_kernel, dim3(lod_grid(n, 256)), dim3(256), 0, nullptr, n, d_pred_count,
                      (const uint64_t*)d_pred_dist2, d_weight);
-  if (lp->attr_encoding == 1 && lp->pred_weight_blending_enabled_flag)
-    hipLaunchKernelGGL(lod_blend_weights_inter_kernel, dim3(lod_grid(n, 256)), dim3(256), 0, nullptr, n,
-                       (const int32_t*)d_pred_count, (const int32_t*)d_pred_point, xyz, xyz_ref, d_weight);
+  if (lp->attr_encoding == 1 && lp->pred_weight_blending_enabled_flag) {
+    if (inter)
+      hipLaunchKernelGGL(lod_blend_weights_inter_kernel, dim3(lod_grid(n, 256)), dim3(256), 0, nullptr, n,
+                         (const int32_t*)d_pred_count, (const int32_t*)d_pred_point, xyz, xyz_ref, d_weight);
+    else
+      hipLaunchKernelGGL(lod_blend_weights_kernel, dim3(lod_grid(n, 256)), dim3(256), 0, nullptr, n,
+                         (const int32_t*)d_pred_count, (const int32_t*)d_pred_point, xyz, d_weight);
+  }
   memcpy(neigh_count, d_pred_count, sizeof(int32_t) * N);
   memcpy(neigh_index, d_neigh_index, sizeof(int32_t) * 3 * N);
   memcpy(neigh_weight, d_weight, sizeof(int32_t) * 3 * N);

@@ -84,6 +84,14 @@ def inter_build(lp, xyz, xyz_ref, search_range, frame_distance=1):
     return dict(nc=nc, ni=ni, w=w, indexes=idx, npl=npl[:nl.value].copy(), ref=ref)
 
 
+def intra_build(lp, xyz):
+    """the ordinary (intra, non-scalable) LoD build -- all three sub-samplers, the distance one with its
+    workgroups running together -- under the emulator -> dict as lod_helpers.oracle_lod_generate"""
+    o = inter_build(lp, xyz, np.zeros((0, 3), np.int32), 0, 0)
+    del o["ref"]
+    return o
+
+
 def scalable_build(lp, xyz):
     """-> dict as lod_helpers.oracle_lod_generate (weights int32)"""
     xyz = np.ascontiguousarray(xyz, dtype=np.int32)

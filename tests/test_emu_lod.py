@@ -52,7 +52,8 @@ def test_scalable_lod_build_larger_cloud():
 
 INTER = [dict(decimation=1), dict(decimation=2), dict(decimation=1, distribution=False), dict(decimation=2, bias=(1, 2, 1)),
          dict(decimation=1, neighbours=2), dict(decimation=2, lifting=False, intra_range=64, blend=True),
-         dict(decimation=1, levels=1), dict(decimation=2, sampling_period=3, dist2=1)]
+         dict(decimation=1, levels=1), dict(decimation=2, sampling_period=3, dist2=1),
+         dict(), dict(dist2=1, distribution=False), dict(lifting=False, intra_range=64, blend=True)]   # (the distance sub-sampler)
 
 
 @pytest.mark.parametrize("vi", range(len(INTER)))
@@ -165,3 +166,26 @@ def test_intra_predicting_transform_kernels_under_the_emulator():
                 ev, erec = el.pred_inter(True, pp, lod, attrs[:1], attrs=attrs)
                 np.testing.assert_array_equal(ev, v)
                 np.testing.assert_array_equal(erec, rec)
+
+
+INTRA = [dict(), dict(dist2=1), dict(distribution=False), dict(decimation=1), dict(decimation=2),
+         dict(lifting=False, intra_range=64, blend=True), dict(bias=(1, 2, 1)), dict(levels=3), dict(inter_range=8), dict(neighbours=2)]
+
+
+@pytest.mark.parametrize("vi", range(len(INTRA)))
+def test_ordinary_lod_build_under_the_emulator(vi):
+    """The default LoD build as the library's kernels run it, on the CPU: the distance sub-sampler -- a
+    dependency-ordered kernel whose workgroups wait for one another through tickets and 16-byte
+    mail-box granules, run here with its eight workgroups alive together --, the periodic and the
+    centroid ones, the neighbour search, finalise, weights, blending == the oracle."""
+    from mpeg_pcc_tmc13_amd import lod_params
+    kw = INTRA[vi]
+    for name, xyz in clouds():
+        lp = lod_params(**kw)
+        if kw.get("lifting") is False:
+            lp.intra_lod_prediction_skip_layers = 0
+        o = lh.oracle_lod_generate(xyz, lp)
+        e = el.intra_build(lp, xyz)
+        for k in ("npl", "indexes", "nc", "ni"):
+            np.testing.assert_array_equal(e[k], o[k], err_msg=f"{name} {kw} {k}")
+        np.testing.assert_array_equal(e["w"].astype(np.uint32), (o["w"] & 0xffffffff).astype(np.uint32), err_msg=f"{name} {kw} w")
