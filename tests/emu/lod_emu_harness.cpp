@@ -496,9 +496,8 @@ lift_emu_inter(
 // ---- the reflectance predicting transform with neighbours in a reference frame ---------------
 // pred_dag_kernel<1, ENC, true> with the arrangement host_pred / launch_pred use: flagged
 // neighbours point behind the n predictors (PredCtx::frame_attr), the share arrays have spare
-// entries there.  Decoder, and the encoder without direct predictors (with them the library
-// iterates this pass and its rate model's scan; the pass is the same).  One QP layer.  The
-// persistent kernels run as ONE workgroup here (the emulator runs workgroups one after another).
+// entries there.  Decoder and encoder, the latter's iteration over the rate model included.  One
+// QP layer.  The persistent kernels run as ONE workgroup here.
 #include "pred_kernels.hpp"
 
 extern "C" int
@@ -507,8 +506,7 @@ pred_emu_inter(
   const int32_t* nw, const int32_t* inter_ref, const int32_t* indexes, int32_t* attrs,
   const int32_t* attrs_ref, int32_t n_ref, int32_t* values)
 {
-  if (p->num_qp_layers != 1 || p->scalable_lifting_enabled_flag || n <= 0 || n_ref <= 0
-      || (encoder && p->max_num_direct_predictors > 0))
+  if (p->num_qp_layers != 1 || p->scalable_lifting_enabled_flag || n <= 0 || n_ref <= 0)
     return -1;
   std::vector<void*> blocks;
   const size_t N = (size_t)n, NE = N + (size_t)n_ref;
@@ -567,12 +565,60 @@ pred_emu_inter(
   else
     for (int i = 0; i < n; i++)
       cx.qw[i] = 256;
-  if (encoder)
+  int unsettled = 0;
+  if (encoder && cx.max_direct > 0) {
+    // the encoder with direct predictors, as launch_pred iterates it (gpcc_attr_mi355.hip): the
+    // DAG pass with the rate model before every predictor, then that model's trajectory from the
+    // values the pass produced, until the values stop changing.  The inclusive scan the library
+    // runs on the device (rc_scan) is a host loop here.
+    std::vector<double> log2tab((size_t)kRateScale + 1);
+    for (int v = 0; v <= kRateScale; v++)
+      log2tab[v] = log2((double)v);
+    int32_t* rm = carve<int32_t>(&blocks, 6 * N);
+    int32_t* src_copy = carve<int32_t>(&blocks, N);
+    int32_t* prev_values = carve<int32_t>(&blocks, N);
+    int32_t* ev_rank = carve<int32_t>(&blocks, N + 1);
+    uint8_t* ev_up = carve<uint8_t>(&blocks, N + 1);
+    int32_t* ev_state = carve<int32_t>(&blocks, N + 1);
+    int32_t* flag = small + 24;
+    memcpy(src_copy, attrs, sizeof(int32_t) * N);
+    memset(prev_values, 0, sizeof(int32_t) * N);
+    cx.src = src_copy;
+    cx.rm = rm;
+    cx.log2tab = log2tab.data();
+    hipLaunchKernelGGL(pred_rate_init_kernel, dim3(lod_grid(n, 256)), dim3(256), 0, nullptr, rm, n);
+    bool settled = false;
+    for (int pass = 0; pass < 64 && !settled; pass++) {
+      cx.tag = (uint32_t)(pass + 1);
+      memset(cx.ticket, 0, 8 * sizeof(int32_t));
+      *flag = 0;
+      hipLaunchKernelGGL((pred_dag_kernel<1, true, true>), dim3(1), dim3(256), 0, nullptr, cx);
+      hipLaunchKernelGGL(pred_values_diff_kernel, dim3(lod_grid(n, 256)), dim3(256), 0, nullptr, (const int32_t*)cx.values,
+                         prev_values, N, flag);
+      if (pass > 0 && !*flag) {
+        settled = true;
+        break;
+      }
+      const int chunks = n / kRateChunk + 1;
+      hipLaunchKernelGGL(pred_rate_scan_kernel, dim3((chunks + 63) / 64), dim3(64), 0, nullptr, (const int32_t*)cx.values, 1,
+                         (const uint8_t*)nullptr, n, (const int32_t*)nullptr, rm, 6, 0);
+      hipLaunchKernelGGL(pred_rate_flags_kernel, dim3(lod_grid(n, 256)), dim3(256), 0, nullptr, (const int32_t*)cx.values, n, 1, 0, ev_rank);
+      for (size_t i = 1; i <= N; i++)
+        ev_rank[i] += ev_rank[i - 1];
+      hipLaunchKernelGGL(pred_rate_events_kernel, dim3(lod_grid(n, 256)), dim3(256), 0, nullptr, (const int32_t*)cx.values, n, 1, 0,
+                         (const int32_t*)ev_rank, ev_up);
+      hipLaunchKernelGGL(pred_rate_scan_kernel, dim3((chunks + 63) / 64), dim3(64), 0, nullptr, (const int32_t*)nullptr, 0,
+                         (const uint8_t*)ev_up, n, (const int32_t*)(ev_rank + n), ev_state, 1, 1);
+      hipLaunchKernelGGL(pred_rate_gather_kernel, dim3(lod_grid(n, 256)), dim3(256), 0, nullptr, (const int32_t*)ev_rank,
+                         (const int32_t*)ev_state, n, 0, rm);
+    }
+    unsettled = !settled;
+  } else if (encoder)
     hipLaunchKernelGGL((pred_dag_kernel<1, true, true>), dim3(1), dim3(256), 0, nullptr, cx);
   else
     hipLaunchKernelGGL((pred_dag_kernel<1, false, true>), dim3(1), dim3(256), 0, nullptr, cx);
-  const int err = *cx.error;
+  const int err = *cx.error ? 1 : (unsettled ? 2 : 0);
   for (void* b : blocks)
     free(b);
-  return err ? -7 : 0;
+  return err ? -6 - err : 0;
 }
