@@ -77,11 +77,12 @@ private:
   {
     const int c = desc.attr_num_dimensions_minus1 + 1;
     const int n = int(cloud.getPointCount());
-    if ((c != 1 && c != 3) || n <= 0 || inter.enableAttrInterPred)
+    const bool interSlice = inter.enableAttrInterPred;   // (one component: the reflectance drivers)
+    if ((c != 1 && c != 3) || n <= 0 || (interSlice && c != 1))
       return false;
     gpcc_ctx* ctx = process_context("the attribute decoder");
     gpcc_lod_params lod;
-    if (!ctx || !flatten_lod(aps, abh, minGeomNodeSizeLog2, inter, &lod))
+    if (!ctx || !flatten_lod(aps, abh, minGeomNodeSizeLog2, inter, &lod, true))
       return false;
     const QpSet qpSet = deriveQpSet(desc, aps, abh);
     const bool lifting = aps.attr_encoding == AttributeEncoding::kLiftingTransform;
@@ -107,7 +108,34 @@ private:
     std::vector<int32_t> xyz, attrs(size_t(c) * n);
     positions_of(cloud, &xyz);
     int rc;
-    if (lifting) {
+    InterStructure is;
+    if (interSlice) {
+      rc = build_inter_structure(ctx, lod, xyz, n, abh, inter, &is);
+      if (!rc && lifting) {
+        lp.bitdepth = desc.bitdepth;
+        lp.fixed_point_qp_offset = qpSet.fixedPointQpOffset;
+        lp.num_lods = is.nl;
+        for (int l = 0; l < is.nl; l++)
+          lp.num_points_in_lod[l] = is.npl[l];
+        rc = gpcc_lift_inverse_inter(
+          ctx, &lp, n, is.nc.data(), is.ni.data(), is.nw.data(), is.xr.data(), is.idx.data(), attrs.data(),
+          is.attrsFrame.data(), is.nFrame, values.data());
+      } else if (!rc) {
+        pp.bitdepth = desc.bitdepth;
+        pp.max_num_direct_predictors = aps.max_num_direct_predictors;
+        pp.direct_avg_predictor_disabled_flag = aps.direct_avg_predictor_disabled_flag;
+        pp.adaptive_prediction_threshold = aps.adaptivePredictionThreshold(desc);
+        for (int k = 0; k < 3; k++)
+          pp.quant_neigh_weight[k] = aps.quant_neigh_weight[k];
+        pp.max_num_detail_levels = aps.maxNumDetailLevels();
+        pp.num_lods = is.nl;
+        for (int l = 0; l < is.nl; l++)
+          pp.num_points_in_lod[l] = is.npl[l];
+        rc = gpcc_pred_inverse_inter(
+          ctx, &pp, n, is.nc.data(), is.ni.data(), is.nw.data(), is.xr.data(), is.idx.data(), attrs.data(),
+          is.attrsFrame.data(), is.nFrame, values.data());
+      }
+    } else if (lifting) {
       lp.bitdepth = desc.bitdepth;
       lp.fixed_point_qp_offset = qpSet.fixedPointQpOffset;
       lp.last_component_prediction_enabled_flag = abh.lcpPresent(desc, aps);

@@ -10,7 +10,9 @@
 // stays in the link, reachable through the renamed factory) and adds this
 // translation unit, which defines makeAttributeEncoder() with the original
 // signature and returns an AttributeEncoderIntf that
-//   * for a lifting / predicting slice without inter prediction and QP regions
+//   * for a lifting / predicting slice without QP regions (with attribute inter prediction:
+//     one component, no slice-level inter / intra decision -- gpcc_lod_build_inter +
+//     gpcc_lift_forward_inter / gpcc_pred_forward_inter)
 //     runs LoD build + transform (gpcc_lift_encode_attr / gpcc_pred_encode_attr),
 //     zero-run formation (gpcc_zero_run_pack) and binarisation
 //     (gpcc_binarise_symbols) on the MI355X, and then replays the binary
@@ -84,11 +86,14 @@ private:
   {
     const int c = desc.attr_num_dimensions_minus1 + 1;
     const int n = int(cloud.getPointCount());
-    if ((c != 1 && c != 3) || n <= 0 || inter.enableAttrInterPred || inter.codeAttributeSecondPass())
+    // attribute inter prediction: one component, and without the slice-level inter / intra
+    // decision (which codes the slice twice and compares, AttributeEncoder.cpp:520-585)
+    const bool interSlice = inter.enableAttrInterPred;
+    if ((c != 1 && c != 3) || n <= 0 || inter.codeAttributeSecondPass() || (interSlice && c != 1))
       return false;
     gpcc_ctx* ctx = process_context("the attribute encoder");
     gpcc_lod_params lod;
-    if (!ctx || !flatten_lod(aps, abh, 0, inter, &lod))
+    if (!ctx || !flatten_lod(aps, abh, 0, inter, &lod, true))
       return false;
     const QpSet qpSet = deriveQpSet(desc, aps, abh);
     const bool lifting = aps.attr_encoding == AttributeEncoding::kLiftingTransform;
@@ -100,7 +105,41 @@ private:
     // ---- LoD build + transform: the values of every predictor in coding order ----
     int8_t lcp[GPCC_MAX_LODS] = {};
     int8_t icp[GPCC_MAX_LODS][3] = {};
-    if (lifting) {
+    InterStructure is;
+    if (interSlice && build_inter_structure(ctx, lod, xyz, n, abh, inter, &is))
+      return declined();
+    if (interSlice && lifting) {
+      gpcc_lift_params lp{};
+      if (!flatten_qp(qpSet, &lp))
+        return false;
+      lp.bitdepth = desc.bitdepth;
+      lp.fixed_point_qp_offset = qpSet.fixedPointQpOffset;
+      lp.num_lods = is.nl;
+      for (int l = 0; l < is.nl; l++)
+        lp.num_points_in_lod[l] = is.npl[l];
+      if (gpcc_lift_forward_inter(
+            ctx, &lp, n, is.nc.data(), is.ni.data(), is.nw.data(), is.xr.data(), is.idx.data(), attrs.data(),
+            is.attrsFrame.data(), is.nFrame, values.data()))
+        return declined();
+    } else if (interSlice) {
+      gpcc_pred_params pp{};
+      if (!flatten_qp(qpSet, &pp))
+        return false;
+      pp.bitdepth = desc.bitdepth;
+      pp.max_num_direct_predictors = aps.max_num_direct_predictors;
+      pp.direct_avg_predictor_disabled_flag = aps.direct_avg_predictor_disabled_flag;
+      pp.adaptive_prediction_threshold = aps.adaptivePredictionThreshold(desc);
+      for (int k = 0; k < 3; k++)
+        pp.quant_neigh_weight[k] = aps.quant_neigh_weight[k];
+      pp.max_num_detail_levels = aps.maxNumDetailLevels();
+      pp.num_lods = is.nl;
+      for (int l = 0; l < is.nl; l++)
+        pp.num_points_in_lod[l] = is.npl[l];
+      if (gpcc_pred_forward_inter(
+            ctx, &pp, n, is.nc.data(), is.ni.data(), is.nw.data(), is.xr.data(), is.idx.data(), attrs.data(),
+            is.attrsFrame.data(), is.nFrame, values.data()))
+        return declined();
+    } else if (lifting) {
       gpcc_lift_params lp{};
       if (!flatten_qp(qpSet, &lp))
         return false;

@@ -148,6 +148,40 @@ store_attributes(const std::vector<int32_t>& a, int c, pcc::PCCPointSet3* cloud)
   }
 }
 
+// A slice with attribute inter prediction (one component: the reference's reflectance
+// drivers): the LoD structure with neighbours in the reference frame
+// (gpcc_lod_build_inter) and what the transforms over it need
+struct InterStructure {
+  std::vector<int32_t> nc, ni, nw, idx, xr, attrsFrame;
+  int32_t npl[GPCC_MAX_LODS];
+  int32_t nl = 0;
+  int nFrame = 0;
+};
+
+inline int
+build_inter_structure(
+  gpcc_ctx* ctx, const gpcc_lod_params& lod, const std::vector<int32_t>& xyz, int n,
+  const pcc::AttributeBrickHeader& abh, const pcc::AttributeInterPredParams& inter, InterStructure* s)
+{
+  const auto& frame = inter.referencePointCloud;
+  s->nFrame = int(frame.getPointCount());
+  if (s->nFrame <= 0 || !frame.hasReflectances())
+    return GPCC_ERR_UNSUPPORTED;
+  std::vector<int32_t> xyzFrame;
+  positions_of(frame, &xyzFrame);
+  s->attrsFrame.resize(s->nFrame);
+  for (int i = 0; i < s->nFrame; i++)
+    s->attrsFrame[i] = frame.getReflectance(i);
+  s->nc.resize(n);
+  s->ni.resize(size_t(n) * 3);
+  s->nw.resize(size_t(n) * 3);
+  s->idx.resize(n);
+  s->xr.resize(size_t(n) * 3);
+  return gpcc_lod_build_inter(
+    ctx, &lod, xyz.data(), n, xyzFrame.data(), s->nFrame, abh.attrInterPredSearchRange, inter.frameDistance,
+    s->nc.data(), s->ni.data(), s->nw.data(), s->idx.data(), s->npl, &s->nl, s->xr.data());
+}
+
 // The context models of an attribute slice by the ids gpcc_binarise_symbols
 // writes: 0..4 ctxRunLen, 5..18 ctxCoeffGtN[2][7], 19..24 ctxCoeffRemPrefix[2][3],
 // 25..30 ctxCoeffRemSuffix[2][3] (the declaration order of AttributeContexts)

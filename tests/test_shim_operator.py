@@ -157,6 +157,18 @@ def test_operator_factories_fall_back_without_gpu():
 
 
 @needs3
+def test_operator_factories_inter_slice_falls_back_without_gpu():
+    from mpeg_pcc_tmc13_amd import _lib
+    if _lib.load().gpcc_device_count() > 0:
+        pytest.skip("a GPU is present")
+    case = dict(INTER_CASES["inter_pred_refl_lidar_30k"], n=4000, lib="libtmc3_shim3.so")
+    got, err = run_worker(case, strict=False)
+    md5, ln, rec = unmodified(case)
+    assert (got["payload_md5"], got["payload_len"], got["rec_enc_md5"], got["rec_dec_md5"]) == (md5, ln, rec, rec)
+    assert (got["enc_device"], got["enc_cpu"], got["dec_device"], got["dec_cpu"]) == (0, 1, 0, 1)
+
+
+@needs3
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", list(CASES3))
 def test_operator_bitstream_identical_with_device_coders_inside(name):

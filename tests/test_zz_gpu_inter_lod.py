@@ -182,3 +182,23 @@ def test_inter_frame_reflectance_predicting_transform_vs_oracle():
     r = subprocess.run([sys.executable, "-c", PRED_WORKER, ROOT], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
     assert json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])["cases"] == 16
+
+
+@pytest.mark.parametrize("name", _inter_cases())
+def test_operator_inter_slice_with_the_device_coders_inside(name):
+    """The same slices through the operator factories (oracle/_ref/libtmc3_shim3.so): LoD structure with
+    the reference frame, lifting / predicting transform over it (gpcc_lod_build_inter +
+    gpcc_lift_forward_inter / gpcc_pred_forward_inter, the decoder's counterparts), zero runs and
+    binarisation on the MI355X, the decisions on the reference's arithmetic coder -- payload and
+    reconstructions byte-identical to the unmodified build, no fallback (GPCC_STRICT=1)."""
+    import test_shim_operator as tso
+    if not (os.path.exists(tso.SHIM3) and tso.ol.ref_available()):
+        pytest.skip("libtmc3_shim3.so / libtmc3_ref.so not built")
+    case = dict(tso.INTER_CASES[name], lib="libtmc3_shim3.so")
+    got, err = tso.run_worker(case, strict=True)
+    md5, ln, rec = tso.unmodified(case)
+    assert got["payload_len"] == ln and got["payload_md5"] == md5, "attribute payload differs from the unmodified build"
+    assert got["rec_enc_md5"] == rec and got["rec_dec_md5"] == rec
+    assert "falls back" not in err
+    assert (got["enc_device"], got["enc_cpu"], got["dec_device"], got["dec_cpu"]) == (1, 0, 1, 0)
+    assert (got["lod_device"], got["lod_cpu"]) == (0, 0)   # the structure is built inside the coders' calls
