@@ -314,9 +314,10 @@ int gpcc_lod_build(
  * (GPCC_ERR_UNSUPPORTED).
  * STATUS (round 3): bit-exact against the oracle on the MI355X
  * (tests/test_zz_gpu_inter_lod.py) and under the CPU wavefront emulator
- * (tests/test_emu_lod.py).  No transform entry consumes inter_ref yet: the
- * lifting / predicting transforms over such a structure exist in the oracle
- * only, and the shims keep inter slices on the reference path. */
+ * (tests/test_emu_lod.py).  Consumers: gpcc_lift_forward_inter /
+ * gpcc_pred_forward_inter (and the inverses) below; the shims call it for
+ * slices with attribute inter prediction (seam 2: AttributeLods::generate,
+ * seam 3: the operator factories). */
 int gpcc_lod_build_inter(
   gpcc_ctx* ctx, const gpcc_lod_params* params, const int32_t* xyz, int32_t n,
   const int32_t* xyz_ref, int32_t n_ref, int32_t search_range,
