@@ -3251,6 +3251,21 @@ gpcc_estimate_dist2_impl(
 
 }  // extern "C"
 
+#if GPCC_FIN_VAR == 2
+extern "C" int
+gpcc_debug_fin(unsigned int* out, int reset)
+{
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gpcc::g_fin_dbg), sizeof(gpcc::g_fin_dbg)) != hipSuccess)
+    return -1;
+  if (reset) {
+    unsigned int z[4 + 4 * 60] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(gpcc::g_fin_dbg), z, sizeof(z)) != hipSuccess)
+      return -1;
+  }
+  return 0;
+}
+#endif
+
 #ifdef GPCC_SUB_PROF
 extern "C" int
 gpcc_debug_sub_prof(unsigned long long* out, int reset)

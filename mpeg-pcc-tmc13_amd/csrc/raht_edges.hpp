@@ -170,20 +170,70 @@ struct FinishCtx {
   const SharedLut* lut;
 };
 
+#ifndef GPCC_FIN_VAR
+#define GPCC_FIN_VAR 0
+#endif
+#if GPCC_FIN_VAR == 2
+// [0] checks, [1] mismatching words after the barrier, [2] at the end, then records of
+// {phase << 16 | word, workgroup, LDS value, global value}
+__device__ unsigned int g_fin_dbg[4 + 4 * 60];
+__device__ __forceinline__ void
+fin_check_lut(const SharedLut* s, const SharedLut* g, int phase)
+{
+  const volatile uint32_t* l = reinterpret_cast<const volatile uint32_t*>(s);
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(g);
+  if (threadIdx.x == 0)
+    atomicAdd(&g_fin_dbg[0], 1u);
+  for (int i = threadIdx.x; i < (int)(sizeof(SharedLut) / 4); i += blockDim.x) {
+    const uint32_t a = l[i], b = __builtin_nontemporal_load(&src[i]);
+    if (a != b) {
+      const unsigned k = atomicAdd(&g_fin_dbg[1 + phase], 1u);
+      if (k < 60) {
+        g_fin_dbg[4 + 4 * k + 0] = (unsigned)phase << 16 | (unsigned)i;
+        g_fin_dbg[4 + 4 * k + 1] = blockIdx.x;
+        g_fin_dbg[4 + 4 * k + 2] = a;
+        g_fin_dbg[4 + 4 * k + 3] = b;
+      }
+    }
+  }
+}
+#endif
+
 template<int C>
+#if GPCC_FIN_VAR == 5
+[[clang::optnone]] __attribute__((noinline))
+#endif
 __global__ __launch_bounds__(256) void
 finish_kernel(FinishCtx cx)
 {
   if (tree_failed(cx.tv))
     return;
   // The tables are read where lut_init_kernel left them (3 KB, cache resident; the chains of
-  // duplicates that use them are rare).  An LDS copy staged per workgroup, as in the level
-  // kernels, gave WRONG first coefficients of long duplicate chains on the device in large
-  // batches, not reproducibly (tests/stress/stress_cx_batch.py; C = 1, ~70 % of the runs of one
-  // batch) while the emulator, a host sync in front of the launch, a second barrier and a
-  // closing barrier changed nothing and an in-kernel comparison of the two tables' results made
-  // it disappear: the cause was not found, this form has run the stress clean.
+  // duplicates that use them are rare).  The form with an LDS copy staged per workgroup, as in the
+  // level kernels, gave WRONG coefficients of long duplicate chains on the MI355X in large batches
+  // (round 3).  Round 4 (profiles/r04_finish_lds_root_cause.txt): the staged copy is bit-identical to
+  // the global tables, and THE SAME MACHINE CODE is right or wrong depending only on the wavefront's
+  // register allocation in the kernel descriptor -- 56 VGPRs, all used, as the compiler arrives at for
+  // that form: 70-80 % of the runs of the pinned batches wrong, every lane of a wavefront in the same
+  // loop iterations; 64 / 72 / 80 registers, no instruction changed: none (0 / 198).  Nothing at
+  // source level is wrong; an LDS form, if ever wanted, pads its allocation (GPCC_FIN_VAR 8 below).
+#if GPCC_FIN_VAR >= 1
+  // experiment builds (tools/fin_lds_experiment.py): the LDS form that failed in round 3 and
+  // variants of it; GPCC_FIN_VAR 2 adds checks of the staged copy against the global tables
+  // (right behind the barrier and when the workgroup's threads leave), counted in g_fin_dbg
+  __shared__ SharedLut lut_s;
+  load_lut(&lut_s, cx.lut);
+  const SharedLut& lut = lut_s;
+#if GPCC_FIN_VAR == 2
+  fin_check_lut(&lut_s, cx.lut, 0);
+#endif
+#if GPCC_FIN_VAR == 8
+  // the same machine code in a 64-register allocation instead of the 56 the compiler arrives at
+  asm volatile("" ::: "v63");
+#endif
+#else
   const SharedLut& lut = *cx.lut;
+#endif
   const TreeView& tv = cx.tv;
   const gpcc_raht_params* __restrict__ prm = cx.params;
   const bool haar = prm->integer_haar_enable_flag != 0;
@@ -273,8 +323,15 @@ finish_kernel(FinishCtx cx)
     int cidx = (any_level ? sc->num_unique : 0) + (f0 - pt0) - jl;
     for (int wv = weight - 1; wv > 0; wv--, cidx++) {
       int64_t a = 0, b = 0;
-      if (!haar)
+      if (!haar) {
+#if GPCC_FIN_VAR == 4
+        int one = 1;  // opaque: nothing of the (w, 1) butterfly is hoisted out of the loops
+        asm volatile("" : "+v"(one));
+        raht_coeffs(wv, one, lut, &a, &b);
+#else
         raht_coeffs(wv, 1, lut, &a, &b);
+#endif
+      }
 #pragma unroll
       for (int k = 0; k < C; k++) {
         const Quantizer qk = q[k ? 1 : 0];
@@ -287,7 +344,11 @@ finish_kernel(FinishCtx cx)
             t0 = attr_sum[k];
             t1 = t1 - t0;  // HaarKernel::fwdTransform high-pass
           } else {
+#if GPCC_FIN_VAR == 6   // the source attribute read past the CU's L1
+            t1 = fp_from_int(__hip_atomic_load(&cx.attrs[(size_t)(f0 + wv) * C + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#else
             t1 = fp_from_int(cx.attrs[(size_t)(f0 + wv) * C + k]);
+#endif
             attr_sum[k] -= t1;
             t0 = scale_rsqrt(attr_sum[k], wv, lut);
             t1 = fp_mul(t1, a) - fp_mul(b, t0);
@@ -312,6 +373,9 @@ finish_kernel(FinishCtx cx)
         const int64_t o1 = ext ? t1 : fp_round(t1);
         cx.attrs[(size_t)(f0 + wv) * C + k] =
           ext ? (int32_t)((o1 + kFpHalf) >> kFpFrac) : (int32_t)o1;
+#if GPCC_FIN_VAR == 7   // every reconstruction store drained before the next source load
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
         if (wv == 1) {
           const int64_t o0 = ext ? t0 : fp_round(t0);
           cx.attrs[(size_t)f0 * C + k] =
@@ -320,6 +384,9 @@ finish_kernel(FinishCtx cx)
       }
     }
   }
+#if GPCC_FIN_VAR == 2
+  fin_check_lut(&lut_s, cx.lut, 1);
+#endif
 }
 
 }  // namespace gpcc

@@ -75,6 +75,11 @@ def main():
     print("%-64s %5s %7s %3s %6s %6s %6s %14s %11s %7s %8s %4s %4s %6s" % hdr)
     for r in sorted(rows, key=lambda r: -r[5]):
         print("%-64s %5d %7d %3d %6d %6d %6d %14d %11d %7d %8d %4d %4d %6d" % r)
+    # an exactly-fitting 56-register wavefront is what the LDS form of finish_kernel failed in on the
+    # MI355X (profiles/r04_finish_lds_root_cause.txt): a kernel that lands there WITH tables in LDS pads
+    # its allocation (asm volatile("" ::: "v63"))
+    a56 = [r for r in rows if (r[1] + 7) // 8 * 8 == 56]
+    print("# kernels with a 56-register allocation: " + (", ".join("%s (lds %d)" % (r[0], r[4]) for r in a56) or "none"))
 
 
 if __name__ == "__main__":
