@@ -43,7 +43,9 @@ typedef enum gpcc_status {
   GPCC_ERR_NO_DEVICE = -3,     /* no gfx950 device / HIP runtime failure     */
   GPCC_ERR_OUT_OF_MEMORY = -4,
   GPCC_ERR_HIP = -5,           /* a HIP call failed; see gpcc_last_error()   */
-  GPCC_ERR_UNSORTED = -6       /* Morton codes not ascending                 */
+  GPCC_ERR_UNSORTED = -6,      /* Morton codes not ascending                 */
+  GPCC_ERR_RANGE = -7          /* device tier: values left the range of the fast arithmetic path
+                                  (gpcc_ctx_set_fast_arith); nothing was written */
 } gpcc_status;
 
 /* Flattened RahtPredictionParams (hls.h:439-466) + QpSet
@@ -104,6 +106,16 @@ size_t gpcc_ctx_workspace_bytes(const gpcc_ctx* ctx);
  * bits) of the batches that follow; 0 = unknown (63).  Bounds the number of
  * octree levels that are launched; the host tier derives it itself. */
 int gpcc_ctx_set_morton_bits(gpcc_ctx* ctx, int32_t bits);
+
+/* The sub-node prediction kernels (the reference's default flags) compute in doubles where doubles
+ * are exact -- every product of the Q15 transform below 2^53: attributes of the bit depth max_qp
+ * states (51 + 6 (B - 8), tmc3/quantization.cpp:151) in slices with 2 B + ceil(log2 n) <= 36 -- and
+ * in int64 otherwise; the results are the same bits (csrc/raht_arith.hpp).  The kernels check the
+ * magnitudes: a call whose values leave the range (attributes wider than max_qp says, a decoder fed
+ * arbitrary coefficients) writes nothing; the host tier then repeats it in int64 by itself, the
+ * device tier reports GPCC_ERR_RANGE at the next synchronisation.  on = 0: int64 always
+ * (also GPCC_F64=0 in the environment).  Default: on. */
+int gpcc_ctx_set_fast_arith(gpcc_ctx* ctx, int32_t on);
 
 /* What the context's entries have done since it was created -- lets an
  * integrator (and tests/test_shim_dropin.py) tell the device path from a

@@ -141,6 +141,14 @@ struct gpcc_ctx {
   int cx_stage_flip = 0;
   // downloads into the caller's pageable memory go through this pinned buffer (d2h_user)
   void* h_bounce = nullptr;
+  // arithmetic back end of the dependency kernels (raht_arith.hpp): doubles where they are exact
+  // (GPCC_F64=0 in the environment or gpcc_ctx_set_fast_arith(ctx, 0): int64 everywhere);
+  // force_exact: the host tier's second attempt after GPCC_ERR_RANGE
+  bool fast_arith = [] {
+    const char* e = getenv("GPCC_F64");
+    return !(e && e[0] == '0');
+  }();
+  bool force_exact = false;
   // profiling
   bool profiling = false;
   struct Span {
@@ -243,6 +251,7 @@ struct Plan {
   uint32_t* mbox = nullptr;
   unsigned long long* rdoq_state = nullptr;
   bool sub = false;
+  bool f64 = false;  // the sub-node kernels in ArithF64 (decided by dev_transform)
   // decoder with sub-node prediction: one launch over all levels (raht_pipe.hpp)
   bool pipe = false;
   int num_rtiles = 0;
@@ -697,7 +706,10 @@ launch_transform(
       }
       {
         Timer t(ctx, "pipe_synth");
-        raht_pipe_synth_kernel<C><<<kSubGrid, 256, 0, st>>>(lc, px);
+        if (pl.f64)
+          raht_pipe_synth_kernel<C, ArithF64><<<kSubGrid, 256, 0, st>>>(lc, px);
+        else
+          raht_pipe_synth_kernel<C><<<kSubGrid, 256, 0, st>>>(lc, px);
       }
       {
         Timer t(ctx, "pipe_leaf");
@@ -762,13 +774,19 @@ launch_transform(
       kSubGrid, std::max<int64_t>(8, (parents / (GPCC_SUB_BLOCKS_PER_WG) + 7) / 8 * 8));
     if (!encoder) {
       Timer t(ctx, level_name("level_sub_synth", li));
-      raht_level_sub_kernel<C, kSynth><<<sgrid, 256, 0, st>>>(lc);
+      if (pl.f64)
+        raht_level_sub_kernel<C, kSynth, ArithF64><<<sgrid, 256, 0, st>>>(lc);
+      else
+        raht_level_sub_kernel<C, kSynth><<<sgrid, 256, 0, st>>>(lc);
     } else if (pl.haar) {
       Timer t(ctx, level_name("level_sub_fused", li));
       raht_level_sub_kernel<C, kFused><<<sgrid, 256, 0, st>>>(lc);
     } else {
       Timer t(ctx, level_name("level_sub_lossy", li));
-      raht_level_sub_kernel<C, kLossySub><<<sgrid, 256, 0, st>>>(lc);
+      if (pl.f64)
+        raht_level_sub_kernel<C, kLossySub, ArithF64><<<sgrid, 256, 0, st>>>(lc);
+      else
+        raht_level_sub_kernel<C, kLossySub><<<sgrid, 256, 0, st>>>(lc);
     }
   }
 
@@ -853,6 +871,11 @@ check_device_error(gpcc_ctx* ctx)
     const int code = *ctx->h_error;
     *ctx->h_error = 0;
     hipMemsetAsync(ctx->d_error, 0, sizeof(int32_t), ctx->stream);
+    if (code == 3)
+      return fail(
+        GPCC_ERR_RANGE,
+        "values beyond the range of the fast arithmetic path (attributes wider than max_qp's bit "
+        "depth says?); nothing was written -- gpcc_ctx_set_fast_arith(ctx, 0) and call again");
     if (code == 2)
       return fail(
         GPCC_ERR_INVALID_ARG,
@@ -945,9 +968,20 @@ dev_transform(
     pl.pipe = pipe_on && !encoder && pl.sub && !pl.has_qp && s == 1;
   }
   pl.num_rtiles = 0;
-  for (int i = 0; i < s; i++)
+  int64_t n_max = 1;
+  for (int i = 0; i < s; i++) {
     pl.num_rtiles +=
       (int)((offsets[i + 1] - offsets[i] + kRdoqTile - 1) / kRdoqTile);
+    n_max = std::max(n_max, offsets[i + 1] - offsets[i]);
+  }
+  {
+    // ArithF64 where B-bit attributes (B from max_qp = 51 + 6 (B - 8), tmc3/quantization.cpp:151)
+    // in slices of n points keep every product exact: values reach 2^(B + 15) sqrt(n), the kernels'
+    // check sits at 2^34 (raht_arith.hpp) -- 2 B + ceil(log2 n) <= 36 leaves it a factor two
+    const int bdepth = 8 + std::max(0, (params->max_qp - 51 + 5) / 6);
+    pl.f64 = ctx->fast_arith && !ctx->force_exact && pl.sub && !pl.haar && params->raht_extension
+      && 2 * bdepth + bitlen64((uint64_t)(n_max - 1)) <= 36;
+  }
 
   Arena measure;
   carve(measure, pl);
@@ -1038,6 +1072,15 @@ host_transform(
     return GPCC_OK;
   };
   int r = run();
+  if (r == GPCC_ERR_RANGE) {
+    // the caller's buffers are untouched: once more in int64 arithmetic
+    cleanup();
+    d_m = nullptr;
+    d_q = d_a = d_c = nullptr;
+    ctx->force_exact = true;
+    r = run();
+    ctx->force_exact = false;
+  }
   cleanup();
   return r;
 }
@@ -1916,6 +1959,15 @@ size_t
 gpcc_ctx_workspace_bytes(const gpcc_ctx* ctx)
 {
   return ctx ? ctx->arena.cap : 0;
+}
+
+int
+gpcc_ctx_set_fast_arith(gpcc_ctx* ctx, int32_t on)
+{
+  if (!ctx)
+    return fail(GPCC_ERR_INVALID_ARG, "ctx is null");
+  ctx->fast_arith = on != 0;
+  return GPCC_OK;
 }
 
 int

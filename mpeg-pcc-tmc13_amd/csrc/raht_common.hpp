@@ -153,6 +153,22 @@ shfl_i64(int64_t v, int src)
   return ((int64_t)hi << 32) | (uint32_t)lo;
 }
 
+// the same for a value of either arithmetic back end (raht_arith.hpp): int64_t or double
+template<class T>
+__device__ __forceinline__ T
+shfl_xor_v(T v, int mask)
+{
+  static_assert(sizeof(T) == 8, "64-bit values");
+  return __builtin_bit_cast(T, shfl_xor_i64(__builtin_bit_cast(int64_t, v), mask));
+}
+template<class T>
+__device__ __forceinline__ T
+shfl_v(T v, int src)
+{
+  static_assert(sizeof(T) == 8, "64-bit values");
+  return __builtin_bit_cast(T, shfl_i64(__builtin_bit_cast(int64_t, v), src));
+}
+
 // OR / sum / max over the 8 lanes of a group (lanes g*8 .. g*8+7)
 __device__ __forceinline__ uint32_t
 group8_or(uint32_t v)

@@ -31,6 +31,7 @@
 // arithmetic on the same values, only the waiting differs.
 #pragma once
 
+#include "raht_arith.hpp"
 #include "raht_subnode.hpp"
 
 namespace gpcc {
@@ -226,10 +227,15 @@ pipe_leaf_kernel(LevelCtx ctx, PipeCtx px)
   }
 }
 
-template<int C>
+// A = the arithmetic back end (raht_arith.hpp).  The granules keep int64 values whatever A is
+// (the prepasses, the coarse levels and pipe_leaf read and write them): a value is converted
+// where it is loaded or stored, hand-offs inside a wavefront stay in A's registers.
+template<int C, class A = ArithI64>
 __global__ __launch_bounds__(256, C == 3 ? GPCC_SUB_SYNTH3_WAVES : 4) void
 raht_pipe_synth_kernel(LevelCtx ctx, PipeCtx px)
 {
+  typedef typename A::T VT;
+  typedef typename A::Coef VC;
   __shared__ SharedLut lut_s;
   if (tree_failed(ctx.tv))
     return;
@@ -241,9 +247,10 @@ raht_pipe_synth_kernel(LevelCtx ctx, PipeCtx px)
   const int t = threadIdx.x & 7;
   const int lane = lane_id();
   const int gbase = threadIdx.x & 56;
-  const bool haar = prm->integer_haar_enable_flag != 0;
-  const bool ext = prm->raht_extension != 0;
+  const bool haar = !A::kF64 && prm->integer_haar_enable_flag != 0;
+  const bool ext = A::kF64 || prm->raht_extension != 0;
   const int cls = blockIdx.x & 7;
+  bool in_range = true;  // (ArithF64: the magnitudes that bound every product, raht_arith.hpp)
   const auto grsrc = __builtin_amdgcn_make_buffer_rsrc(
     px.g, 0, (int)((size_t)px.total * C * 16), 0x00020000);
   const auto ursrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -307,7 +314,7 @@ raht_pipe_synth_kernel(LevelCtx ctx, PipeCtx px)
     prof.mark(0, lane);  // block located, children, weights
     // ---- butterfly weights + coefficients (mkWeightTree :742) ----------
     int32_t wl[3], wr[3];
-    int64_t ca[3], cb[3];
+    VC ca[3], cb[3];
     int32_t cw = w;
 #pragma unroll
     for (int st = 0; st < 3; st++) {
@@ -316,14 +323,16 @@ raht_pipe_synth_kernel(LevelCtx ctx, PipeCtx px)
       const bool left = !(t & bit);
       wl[st] = left ? cw : pw;
       wr[st] = left ? pw : cw;
-      ca[st] = cb[st] = 0;
+      int64_t ia = 0, ib = 0;
       if (wl[st] && wr[st]) {
         if (!haar)
-          raht_coeffs(wl[st], wr[st], lut, &ca[st], &cb[st]);
+          raht_coeffs(wl[st], wr[st], lut, &ia, &ib);
         cw = wl[st] + wr[st];
       } else {
         cw = left ? wl[st] + wr[st] : 0;
       }
+      ca[st] = A::coef(ia);
+      cb[st] = A::coef(ib);
     }
 
     // ---- inter-level prediction gating (tmc3/RAHT.cpp:1391-1432): the
@@ -333,10 +342,10 @@ raht_pipe_synth_kernel(LevelCtx ctx, PipeCtx px)
     const bool pred_in_level = on && inherit_dc && prm->raht_prediction_enabled_flag != 0;
     bool enable_pred = pred_in_level;
     int neigh_count = 0;
-    int64_t pred[C];
+    VT pred[C];
 #pragma unroll
     for (int k = 0; k < C; k++)
-      pred[k] = 0;
+      pred[k] = A::zero();
     bool want_search = false;
     if (pred_in_level) {
       if (ext && nchild == 1) {
@@ -461,17 +470,19 @@ raht_pipe_synth_kernel(LevelCtx ctx, PipeCtx px)
       }
       qpset_quantizers(prm, e.qp_layer, ac0, ac1, qa);
     }
-    int32_t nrm_sq = 0, nrm_rs = 0, nrm_shift = 0;
+    int32_t nrm_sq_i = 0, nrm_rs_i = 0, nrm_shift = 0;
     if (!haar && w > 1) {
-      nrm_sq = (int32_t)sqrt_weight(w, lut);
+      nrm_sq_i = (int32_t)sqrt_weight(w, lut);
       if (w < kSmallN) {
-        nrm_rs = lut.norm_rs[w];
+        nrm_rs_i = lut.norm_rs[w];
       } else {
         const uint64_t w64 = (uint64_t)w;
         nrm_shift = w64 > 1024 ? ilog2_u64(w64 - 1) >> 1 : 0;
-        nrm_rs = (int32_t)(irsqrt(w64, lut.rsqrt) >> (40 - nrm_shift - kFpFrac));
+        nrm_rs_i = (int32_t)(irsqrt(w64, lut.rsqrt) >> (40 - nrm_shift - kFpFrac));
       }
     }
+    const VC nrm_sq = A::coef(nrm_sq_i), nrm_rs = A::coef(nrm_rs_i);
+    const typename A::Quant qaa[2] = {A::quant(qa[0]), A::quant(qa[1])};
     int32_t qc[C];
 #pragma unroll
     for (int k = 0; k < C; k++)
@@ -602,50 +613,55 @@ raht_pipe_synth_kernel(LevelCtx ctx, PipeCtx px)
     }
 
     prof.mark(4, lane);  // stage A2
-    int64_t dc[C];
+    VT dc[C];
 #pragma unroll
     for (int k = 0; k < C; k++) {
       const int64_t val = own_us[k];
-      dc[k] = (on && inherit_dc && t == 0)
-        ? (ext ? val : (val > 0 ? val << (kFpFrac - 2) : -((-val) << (kFpFrac - 2))))
-        : 0;
+      dc[k] = A::from_i64(
+        (on && inherit_dc && t == 0)
+          ? (ext ? val : (val > 0 ? val << (kFpFrac - 2) : -((-val) << (kFpFrac - 2))))
+          : 0);
+      in_range = in_range && A::below(dc[k], A::kInvLimit);
     }
 
     int wsum = 0;
-    int64_t lim_lo = 0, lim_hi = 0;
+    VT lim_lo = A::zero(), lim_hi = A::zero();
     // intraDcPred, the seven neighbours that never use child values
     // (tmc3/RAHT.cpp:463-502 with parentOnlyCheckMaxIdx = 7)
 #pragma unroll
     for (int i = 0; i < 7; i++) {
       int q;
-      int64_t v[C];
+      VT v[C];
       if (i == 0) {
         q = j;
 #pragma unroll
         for (int k = 0; k < C; k++)
-          v[k] = shfl_i64(own_v[k], gbase);
+          v[k] = A::from_i64(shfl_i64(own_v[k], gbase));
       } else {
         q = __shfl(pn[0], gbase | (i - 1));
 #pragma unroll
         for (int k = 0; k < C; k++)
-          v[k] = shfl_i64(nbv[0][k], gbase | (i - 1));
+          v[k] = A::from_i64(shfl_i64(nbv[0][k], gbase | (i - 1)));
       }
+#pragma unroll
+      for (int k = 0; k < C; k++)
+        in_range = in_range && A::below(v[k], A::kRecLimit);
       if (!run || q < 0)
         continue;
       if (i) {
-        if (10 * v[0] <= lim_lo || 10 * v[0] >= lim_hi)
+        if (A::muli(v[0], 10) <= lim_lo || A::muli(v[0], 10) >= lim_hi)
           continue;
       } else {
-        lim_lo = 2 * v[0];
-        lim_hi = 25 * v[0];
+        lim_lo = A::muli(v[0], 2);
+        lim_hi = A::muli(v[0], 25);
       }
       if (has && ((neigh_mask(i) >> t) & 1)) {
-        const int64_t pw = prm->pred_weight_parent[i];
-        wsum += (int)pw;
-        const int64_t mul = ext ? pw : (pw << kFpFrac);
+        const int pw = prm->pred_weight_parent[i];
+        wsum += pw;
+        const int mul = ext ? pw : (pw << kFpFrac);
 #pragma unroll
         for (int k = 0; k < C; k++)
-          pred[k] += v[k] * mul;
+          pred[k] += A::muli(v[k], mul);
       }
     }
 
@@ -681,13 +697,15 @@ raht_pipe_synth_kernel(LevelCtx ctx, PipeCtx px)
       const int q = __shfl(pn[sl], owner);
       const int qc0 = __shfl(nb_c0[sl], owner);
       const uint32_t qocc = __shfl(nb_occ[sl], owner);
-      int64_t v[C];
+      VT v[C];
 #pragma unroll
-      for (int k = 0; k < C; k++)
-        v[k] = shfl_i64(nbv[sl][k], owner);
+      for (int k = 0; k < C; k++) {
+        v[k] = A::from_i64(shfl_i64(nbv[sl][k], owner));
+        in_range = in_range && A::below(v[k], A::kRecLimit);
+      }
       if (!run || q < 0)
         continue;
-      if (10 * v[0] <= lim_lo || 10 * v[0] >= lim_hi)
+      if (A::muli(v[0], 10) <= lim_lo || A::muli(v[0], 10) >= lim_hi)
         continue;
       if (has && ((neigh_mask(i) >> t) & 1)) {
         const int sh = occu_shift(i12);
@@ -709,12 +727,12 @@ raht_pipe_synth_kernel(LevelCtx ctx, PipeCtx px)
               wsrc_b |= (uint32_t)pg << (3 * (i12 - 10));
           }
         } else {
-          const int64_t pwp = prm->pred_weight_parent[i];
-          wsum += (int)pwp;
-          const int64_t mul = ext ? pwp : (pwp << kFpFrac);
+          const int pwp = prm->pred_weight_parent[i];
+          wsum += pwp;
+          const int mul = ext ? pwp : (pwp << kFpFrac);
 #pragma unroll
           for (int k = 0; k < C; k++)
-            pred[k] += v[k] * mul;
+            pred[k] += A::muli(v[k], mul);
         }
       }
     }
@@ -758,24 +776,27 @@ raht_pipe_synth_kernel(LevelCtx ctx, PipeCtx px)
         for (int k = 0; k < C; k++)
           ok = ok && gq[q4][k].z == px.tag;
         if (ok) {
-          const int64_t pwc = prm->pred_weight_child[i12];
-          const int64_t mul = ext ? pwc : (pwc << kFpFrac);
+          const int pwc = prm->pred_weight_child[i12];
+          const int mul = ext ? pwc : (pwc << kFpFrac);
 #pragma unroll
-          for (int k = 0; k < C; k++)
-            pred[k] += (int64_t)(((uint64_t)gq[q4][k].y << 32) | gq[q4][k].x) * mul;
+          for (int k = 0; k < C; k++) {
+            const VT cv = A::from_i64((int64_t)(((uint64_t)gq[q4][k].y << 32) | gq[q4][k].x));
+            in_range = in_range && A::below(cv, A::kRecLimit);
+            pred[k] += A::muli(cv, mul);
+          }
           pend &= ~(1u << i12);
         }
       }
     }
-    const int64_t pdiv = pred_divisor(wsum > 0 ? wsum : 1);
+    const VC pdiv = A::coef(pred_divisor(wsum > 0 ? wsum : 1));
 
     prof.mark(5, lane);  // parent-level terms, children sources, first polls
     // ---- the dependency loop (raht_subnode.hpp, decoder) --------------------
     int stage = on ? 0 : 3;
-    int64_t pt[C];
+    VT pt[C];
 #pragma unroll
     for (int k = 0; k < C; k++)
-      pt[k] = 0;
+      pt[k] = A::zero();
     while (__any(stage != 3)) {
       bool progressed = false;
       if (__any(stage == 0 && inw)) {
@@ -788,16 +809,16 @@ raht_pipe_synth_kernel(LevelCtx ctx, PipeCtx px)
           const int sh = occu_shift(i12);
           const int srcl = (pg << 3) | ((i12 < 9 ? t + sh : t - sh) & 7);
           const int pst = __shfl(stage, srcl);
-          int64_t v[C];
+          VT v[C];
 #pragma unroll
           for (int k = 0; k < C; k++)
-            v[k] = shfl_i64(pt[k], srcl);
+            v[k] = shfl_v(pt[k], srcl);
           if (mine && pst == 3) {
-            const int64_t pwc = prm->pred_weight_child[i12];
-            const int64_t mul = ext ? pwc : (pwc << kFpFrac);
+            const int pwc = prm->pred_weight_child[i12];
+            const int mul = ext ? pwc : (pwc << kFpFrac);
 #pragma unroll
             for (int k = 0; k < C; k++)
-              pred[k] += v[k] * mul;
+              pred[k] += A::muli(v[k], mul);
             pend &= ~(1u << i12);
             inw &= ~(1u << i12);
           }
@@ -807,7 +828,7 @@ raht_pipe_synth_kernel(LevelCtx ctx, PipeCtx px)
       if (pm) {
         const int slot = __ffs(pm) - 1;
         int32_t row = 0;
-        int64_t pwc = 0;
+        int pwc = 0;
 #pragma unroll
         for (int i12 = 0; i12 < 12; i12++) {
           if (slot == i12) {
@@ -824,10 +845,13 @@ raht_pipe_synth_kernel(LevelCtx ctx, PipeCtx px)
         for (int k = 0; k < C; k++)
           ok = ok && g[k].z == px.tag;
         if (ok) {
-          const int64_t mul = ext ? pwc : (pwc << kFpFrac);
+          const int mul = ext ? pwc : (pwc << kFpFrac);
 #pragma unroll
-          for (int k = 0; k < C; k++)
-            pred[k] += (int64_t)(((uint64_t)g[k].y << 32) | g[k].x) * mul;
+          for (int k = 0; k < C; k++) {
+            const VT cv = A::from_i64((int64_t)(((uint64_t)g[k].y << 32) | g[k].x));
+            in_range = in_range && A::below(cv, A::kRecLimit);
+            pred[k] += A::muli(cv, mul);
+          }
           pend &= ~(1u << slot);
         }
       }
@@ -837,23 +861,28 @@ raht_pipe_synth_kernel(LevelCtx ctx, PipeCtx px)
       if (__any(nready)) {
         progressed = true;
         // ---- (P) normalise the prediction, transform -----------------------
-        int64_t pw_[C];
+        VT pw_[C];
 #pragma unroll
         for (int k = 0; k < C; k++)
           pw_[k] = pred[k];
         if (run && has) {
 #pragma unroll
           for (int k = 0; k < C; k++) {
-            pw_[k] = fp_mul_c(pw_[k], pdiv);
-            if (haar)
-              pw_[k] = (pw_[k] >> kFpFrac) << kFpFrac;
+            pw_[k] = A::mulc(pw_[k], pdiv);
+            if constexpr (!A::kF64) {
+              if (haar)
+                pw_[k] = (pw_[k] >> kFpFrac) << kFpFrac;
+            }
           }
         }
         if (!haar && w > 1 && enable_pred) {
 #pragma unroll
           for (int k = 0; k < C; k++)
-            pw_[k] = fp_mul_c(pw_[k], (int64_t)nrm_sq);
+            pw_[k] = A::mulc(pw_[k], nrm_sq);
         }
+#pragma unroll
+        for (int k = 0; k < C; k++)
+          in_range = in_range && A::below(pw_[k], A::kFwdLimit);
 #pragma unroll
         for (int st = 0; st < 3; st++) {
           const int bit = 1 << st;
@@ -862,15 +891,17 @@ raht_pipe_synth_kernel(LevelCtx ctx, PipeCtx px)
           const bool swap = !wl[st] && wr[st];
 #pragma unroll
           for (int k = 0; k < C; k++) {
-            const int64_t own = pw_[k], oth = shfl_xor_i64(own, bit);
+            const VT own = pw_[k], oth = shfl_xor_v(own, bit);
             if (enable_pred) {
               if (both) {
                 if (haar) {
-                  const int64_t hf = left ? oth - own : own - oth;
-                  pw_[k] = left ? own + ((hf >> (1 + kFpFrac)) << kFpFrac) : hf;
+                  if constexpr (!A::kF64) {
+                    const int64_t hf = left ? oth - own : own - oth;
+                    pw_[k] = left ? own + ((hf >> (1 + kFpFrac)) << kFpFrac) : hf;
+                  }
                 } else {
-                  pw_[k] = left ? fp_mul_c(oth, cb[st]) + fp_mul_c(own, ca[st])
-                                : fp_mul_c(own, ca[st]) - fp_mul_c(oth, cb[st]);
+                  pw_[k] = left ? A::mulc(oth, cb[st]) + A::mulc(own, ca[st])
+                                : A::mulc(own, ca[st]) - A::mulc(oth, cb[st]);
                 }
               } else if (swap) {
                 pw_[k] = oth;
@@ -890,20 +921,23 @@ raht_pipe_synth_kernel(LevelCtx ctx, PipeCtx px)
       if (__any(can)) {
         progressed = true;
         // ---- (W) coefficients, DC, inverse transform, commit ---------------
-        int64_t pw_[C];
+        VT pw_[C];
 #pragma unroll
         for (int k = 0; k < C; k++)
           pw_[k] = pt[k];
         if (coded && can) {
 #pragma unroll
           for (int k = 0; k < C; k++)
-            pw_[k] += fp_from_int(dequantize(qa[k ? 1 : 0], (int64_t)qc[k]));
+            pw_[k] += A::dequant_fp(qaa[k ? 1 : 0], qc[k]);
         }
         if (on && inherit_dc && t == 0) {
 #pragma unroll
           for (int k = 0; k < C; k++)
             pw_[k] = dc[k];
         }
+#pragma unroll
+        for (int k = 0; k < C; k++)
+          in_range = in_range && A::below(pw_[k], A::kInvLimit);
 #pragma unroll
         for (int st = 2; st >= 0; st--) {
           const int bit = 1 << st;
@@ -912,15 +946,17 @@ raht_pipe_synth_kernel(LevelCtx ctx, PipeCtx px)
           const bool swap = !wl[st] && wr[st];
 #pragma unroll
           for (int k = 0; k < C; k++) {
-            const int64_t own = pw_[k], oth = shfl_xor_i64(own, bit);
+            const VT own = pw_[k], oth = shfl_xor_v(own, bit);
             if (both) {
               if (haar) {
-                const int64_t lf = left ? own : oth, hf = left ? oth : own;
-                const int64_t lv = lf - ((hf >> (1 + kFpFrac)) << kFpFrac);
-                pw_[k] = left ? lv : hf + lv;
+                if constexpr (!A::kF64) {
+                  const int64_t lf = left ? own : oth, hf = left ? oth : own;
+                  const int64_t lv = lf - ((hf >> (1 + kFpFrac)) << kFpFrac);
+                  pw_[k] = left ? lv : hf + lv;
+                }
               } else {
-                pw_[k] = left ? fp_mul_c(own, ca[st]) - fp_mul_c(oth, cb[st])
-                              : fp_mul_c(oth, cb[st]) + fp_mul_c(own, ca[st]);
+                pw_[k] = left ? A::mulc(own, ca[st]) - A::mulc(oth, cb[st])
+                              : A::mulc(oth, cb[st]) + A::mulc(own, ca[st]);
               }
             } else if (swap) {
               pw_[k] = oth;
@@ -932,17 +968,18 @@ raht_pipe_synth_kernel(LevelCtx ctx, PipeCtx px)
           const int uc = cbase + child;
 #pragma unroll
           for (int k = 0; k < C; k++) {
-            int64_t v = pw_[k];
+            VT v = pw_[k];
             if (!haar && w > 1)
-              v = fp_mul_c(v >> nrm_shift, (int64_t)nrm_rs);
-            v = ext ? v : fp_round(v);
+              v = A::mulc(A::shr(v, nrm_shift), nrm_rs);
+            v = ext ? v : A::round_int(v);
             pt[k] = v;  // read by later groups of this wavefront once stage == 3
-            const u32x4 gr = {(uint32_t)v, (uint32_t)((uint64_t)v >> 32), px.tag, nn};
+            const int64_t vi = A::to_i64(v);
+            const u32x4 gr = {(uint32_t)vi, (uint32_t)((uint64_t)vi >> 32), px.tag, nn};
             __builtin_amdgcn_raw_buffer_store_b128(gr, grsrc, (uc * C + k) * 16, 0, /*sc1*/ 16);
           }
 #pragma unroll
           for (int k = 0; k < C; k++) {
-            const int64_t us = ext ? pw_[k] : fp_round(pw_[k] * 4);
+            const int64_t us = A::to_i64(ext ? pw_[k] : A::round_int(A::muli(pw_[k], 4)));
             const u32x4 ur = {(uint32_t)us, (uint32_t)((uint64_t)us >> 32), px.tag, 0u};
             __builtin_amdgcn_raw_buffer_store_b128(ur, ursrc, (uc * C + k) * 16, 0, /*sc1*/ 16);
           }
@@ -962,6 +999,9 @@ raht_pipe_synth_kernel(LevelCtx ctx, PipeCtx px)
     }
     prof.mark(6, lane);  // the loop
   }
+  // ArithF64: a value left the exact range -- see raht_subnode.hpp
+  if (A::kF64 && __any(!in_range) && lane == 0)
+    atomicCAS(ctx.error, 0, 3);
 }
 
 }  // namespace gpcc

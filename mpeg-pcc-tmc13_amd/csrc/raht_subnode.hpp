@@ -41,6 +41,7 @@
 // block with a reset, the slice start, or `reach` reset-free coefficients.
 #pragma once
 
+#include "raht_arith.hpp"
 #include "raht_levels.hpp"
 
 namespace gpcc {
@@ -113,14 +114,22 @@ store_agent_i64(int64_t* p, int64_t v)
 #ifndef GPCC_SUB_SLEEP
 #define GPCC_SUB_SLEEP 4
 #endif
+#ifndef GPCC_SUB_LOSSY_WAVES
+#define GPCC_SUB_LOSSY_WAVES 3
+#endif
 #ifndef GPCC_SUB_SYNTH3_WAVES
 #define GPCC_SUB_SYNTH3_WAVES 4
 #endif
-template<int C, int MODE>
-__global__ __launch_bounds__(256, MODE == kLossySub ? 3 : (C == 3 ? GPCC_SUB_SYNTH3_WAVES : 4)) void
+// A = the arithmetic back end (raht_arith.hpp): ArithI64, or ArithF64 for batches whose values stay
+// in the range where doubles are exact (extension on, no integer Haar; the kernel checks).
+template<int C, int MODE, class A = ArithI64>
+__global__ __launch_bounds__(256, MODE == kLossySub ? GPCC_SUB_LOSSY_WAVES : (C == 3 ? GPCC_SUB_SYNTH3_WAVES : 4)) void
 raht_level_sub_kernel(LevelCtx ctx)
 {
   static_assert(MODE == kSynth || MODE == kFused || MODE == kLossySub, "mode");
+  static_assert(!(A::kF64 && MODE == kFused), "integer Haar is integer arithmetic");
+  typedef typename A::T VT;
+  typedef typename A::Coef VC;
   constexpr bool kLossy = MODE == kLossySub;
   __shared__ SharedLut lut_s;
   if (tree_failed(ctx.tv))
@@ -136,9 +145,10 @@ raht_level_sub_kernel(LevelCtx ctx)
   const int t = threadIdx.x & 7;
   const int lane = lane_id();
   const int gbase = threadIdx.x & 56;  // first lane of this 8-lane group
-  const bool haar = prm->integer_haar_enable_flag != 0;
-  const bool ext = prm->raht_extension != 0;
+  const bool haar = !A::kF64 && prm->integer_haar_enable_flag != 0;
+  const bool ext = A::kF64 || prm->raht_extension != 0;
   const int32_t epoch = li + 1;
+  bool in_range = true;  // (ArithF64: the magnitudes that bound every product, raht_arith.hpp)
   const int cls = blockIdx.x & 7;
 
   const int num_work = ctx.work_count[li];
@@ -188,10 +198,10 @@ raht_level_sub_kernel(LevelCtx ctx)
     const int child = c0 + popc32(occ & ((1u << t) - 1));
     const int64_t crow = (int64_t)pt0 + (child - sc0);
     int32_t w = 0;
-    int64_t src[C];
+    VT src[C];
 #pragma unroll
     for (int k = 0; k < C; k++)
-      src[k] = 0;
+      src[k] = A::zero();
     if (has) {
       const int f0 = tv.fp[li][child], f1 = tv.fp[li][child + 1];
       w = f1 - f0;
@@ -200,11 +210,11 @@ raht_level_sub_kernel(LevelCtx ctx)
           const int32_t* lf = ctx.haar_lf[li];
 #pragma unroll
           for (int k = 0; k < C; k++)
-            src[k] = fp_from_int(lf[(size_t)child * C + k]);
+            src[k] = A::from_int(lf[(size_t)child * C + k]);
         } else {
 #pragma unroll
           for (int k = 0; k < C; k++)
-            src[k] = fp_from_int((int32_t)(
+            src[k] = A::from_int((int32_t)(
               (uint32_t)ctx.attr_prefix[(size_t)f1 * C + k]
               - (uint32_t)ctx.attr_prefix[(size_t)f0 * C + k]));
         }
@@ -265,7 +275,7 @@ raht_level_sub_kernel(LevelCtx ctx)
 
     // ---- butterfly weights + coefficients (mkWeightTree :742) ----------
     int32_t wl[3], wr[3];
-    int64_t ca[3], cb[3];
+    VC ca[3], cb[3];
     int32_t cw = w;
 #pragma unroll
     for (int st = 0; st < 3; st++) {
@@ -274,14 +284,16 @@ raht_level_sub_kernel(LevelCtx ctx)
       const bool left = !(t & bit);
       wl[st] = left ? cw : pw;
       wr[st] = left ? pw : cw;
-      ca[st] = cb[st] = 0;
+      int64_t ia = 0, ib = 0;
       if (wl[st] && wr[st]) {
         if (!haar)
-          raht_coeffs(wl[st], wr[st], lut, &ca[st], &cb[st]);
+          raht_coeffs(wl[st], wr[st], lut, &ia, &ib);
         cw = wl[st] + wr[st];
       } else {
         cw = left ? wl[st] + wr[st] : 0;
       }
+      ca[st] = A::coef(ia);
+      cb[st] = A::coef(ib);
     }
 
     // ---- inter-level prediction (tmc3/RAHT.cpp:1391-1432) --------------
@@ -290,10 +302,10 @@ raht_level_sub_kernel(LevelCtx ctx)
       on && inherit_dc && prm->raht_prediction_enabled_flag != 0;
     bool enable_pred = pred_in_level;
     int neigh_count = 0;
-    int64_t pred[C];
+    VT pred[C];
 #pragma unroll
     for (int k = 0; k < C; k++)
-      pred[k] = 0;
+      pred[k] = A::zero();
 
     bool do_search = false;
     if (pred_in_level) {
@@ -405,24 +417,30 @@ raht_level_sub_kernel(LevelCtx ctx)
     // depend on the weight alone; on the chain they were a table look-up or
     // an irsqrt evaluation per hop): sqrt(w) for the prediction, the
     // (shift, 1/sqrt(w)) pair of scale_rsqrt for the reconstruction
-    int32_t nrm_sq = 0, nrm_rs = 0, nrm_shift = 0;
+    int32_t nrm_sq_i = 0, nrm_rs_i = 0, nrm_shift = 0;
     if (!haar && w > 1) {
-      nrm_sq = (int32_t)sqrt_weight(w, lut);
+      nrm_sq_i = (int32_t)sqrt_weight(w, lut);
       if (w < kSmallN) {
-        nrm_rs = lut.norm_rs[w];
+        nrm_rs_i = lut.norm_rs[w];
       } else {
         const uint64_t w64 = (uint64_t)w;
         nrm_shift = w64 > 1024 ? ilog2_u64(w64 - 1) >> 1 : 0;
-        nrm_rs = (int32_t)(irsqrt(w64, lut.rsqrt) >> (40 - nrm_shift - kFpFrac));
+        nrm_rs_i = (int32_t)(irsqrt(w64, lut.rsqrt) >> (40 - nrm_shift - kFpFrac));
       }
     }
+    const VC nrm_sq = A::coef(nrm_sq_i), nrm_rs = A::coef(nrm_rs_i);
+    const typename A::Quant qaa[2] = {A::quant(qa[0]), A::quant(qa[1])};
     if (kEnc) {
-      // forward butterflies of the source (normalised first unless Haar)
+      // forward butterflies of the source (normalised first unless Haar:
+      // scale_rsqrt, tmc3/RAHT.cpp:1474-1481)
       if (!haar && w > 1) {
 #pragma unroll
         for (int k = 0; k < C; k++)
-          src[k] = scale_rsqrt(src[k], w, lut);
+          src[k] = A::mulc(A::shr(src[k], nrm_shift), nrm_rs);
       }
+#pragma unroll
+      for (int k = 0; k < C; k++)
+        in_range = in_range && A::below(src[k], A::kFwdLimit);
 #pragma unroll
       for (int st = 0; st < 3; st++) {
         const int bit = 1 << st;
@@ -431,14 +449,16 @@ raht_level_sub_kernel(LevelCtx ctx)
         const bool swap = !wl[st] && wr[st];
 #pragma unroll
         for (int k = 0; k < C; k++) {
-          const int64_t own = src[k], oth = shfl_xor_i64(own, bit);
+          const VT own = src[k], oth = shfl_xor_v(own, bit);
           if (both) {
             if (haar) {
-              const int64_t hf = left ? oth - own : own - oth;
-              src[k] = left ? own + ((hf >> (1 + kFpFrac)) << kFpFrac) : hf;
+              if constexpr (!A::kF64) {
+                const int64_t hf = left ? oth - own : own - oth;
+                src[k] = left ? own + ((hf >> (1 + kFpFrac)) << kFpFrac) : hf;
+              }
             } else {
-              src[k] = left ? fp_mul_c(oth, cb[st]) + fp_mul_c(own, ca[st])
-                            : fp_mul_c(own, ca[st]) - fp_mul_c(oth, cb[st]);
+              src[k] = left ? A::mulc(oth, cb[st]) + A::mulc(own, ca[st])
+                            : A::mulc(own, ca[st]) - A::mulc(oth, cb[st]);
             }
           } else if (swap) {
             src[k] = oth;
@@ -464,18 +484,20 @@ raht_level_sub_kernel(LevelCtx ctx)
     Quantizer qr[2] = {{1, 1}, {1, 1}};
     if (kLossy && coded)
       qpset_quantizers(prm, e.qp_layer, nq0, nq1, qr);
+    const typename A::Quant qra[2] = {A::quant(qr[0]), A::quant(qr[1])};
     bool lin_known = false;
     int lin = -1;
-    int64_t dc[C];
+    VT dc[C];
 #pragma unroll
     for (int k = 0; k < C; k++)
-      dc[k] = 0;
+      dc[k] = A::zero();
     if (on && inherit_dc && t == 0) {
 #pragma unroll
       for (int k = 0; k < C; k++) {
         const int64_t val = par2(ctx.rec_us, par_par)[prow * C + k];
-        dc[k] = ext ? val
-                    : (val > 0 ? val << (kFpFrac - 2) : -((-val) << (kFpFrac - 2)));
+        dc[k] = A::from_i64(
+          ext ? val : (val > 0 ? val << (kFpFrac - 2) : -((-val) << (kFpFrac - 2))));
+        in_range = in_range && A::below(dc[k], A::kInvLimit);
       }
     }
 
@@ -483,7 +505,7 @@ raht_level_sub_kernel(LevelCtx ctx)
     const int64_t* __restrict__ prec = par2(ctx.rec, par_par);
     const int64_t rbase = (int64_t)pt0 - sp0;
     int wsum = 0;
-    int64_t lim_lo = 0, lim_hi = 0;
+    VT lim_lo = A::zero(), lim_hi = A::zero();
     // intraDcPred, the seven neighbours that never use child values
     // (tmc3/RAHT.cpp:463-502 with parentOnlyCheckMaxIdx = 7)
 #pragma unroll
@@ -495,24 +517,26 @@ raht_level_sub_kernel(LevelCtx ctx)
         q = __shfl(pn[0], gbase | (i - 1));
       if (!run || q < 0)
         continue;
-      int64_t v[C];
+      VT v[C];
 #pragma unroll
-      for (int k = 0; k < C; k++)
-        v[k] = prec[(rbase + q) * C + k];
+      for (int k = 0; k < C; k++) {
+        v[k] = A::from_i64(prec[(rbase + q) * C + k]);
+        in_range = in_range && A::below(v[k], A::kRecLimit);
+      }
       if (i) {
-        if (10 * v[0] <= lim_lo || 10 * v[0] >= lim_hi)
+        if (A::muli(v[0], 10) <= lim_lo || A::muli(v[0], 10) >= lim_hi)
           continue;
       } else {
-        lim_lo = 2 * v[0];
-        lim_hi = 25 * v[0];
+        lim_lo = A::muli(v[0], 2);
+        lim_hi = A::muli(v[0], 25);
       }
       if (has && ((neigh_mask(i) >> t) & 1)) {
-        const int64_t pw = prm->pred_weight_parent[i];
-        wsum += (int)pw;
-        const int64_t mul = ext ? pw : (pw << kFpFrac);
+        const int pw = prm->pred_weight_parent[i];
+        wsum += pw;
+        const int mul = ext ? pw : (pw << kFpFrac);
 #pragma unroll
         for (int k = 0; k < C; k++)
-          pred[k] += v[k] * mul;
+          pred[k] += A::muli(v[k], mul);
       }
     }
 
@@ -527,18 +551,20 @@ raht_level_sub_kernel(LevelCtx ctx)
     int nb_c0[3] = {0, 0, 0};
     uint32_t nb_occ[3] = {0, 0, 0};
     int nb_single[3] = {0, 0, 0};
-    int64_t nb_v[3][C];
+    VT nb_v[3][C];
 #pragma unroll
     for (int slot = 0; slot < 3; slot++) {
 #pragma unroll
       for (int k = 0; k < C; k++)
-        nb_v[slot][k] = 0;
+        nb_v[slot][k] = A::zero();
       const int i = 1 + t + 8 * slot;
       if (run && i >= 7 && i < 19 && pn[slot] >= 0) {
         const int q = pn[slot];
 #pragma unroll
-        for (int k = 0; k < C; k++)
-          nb_v[slot][k] = prec[(rbase + q) * C + k];
+        for (int k = 0; k < C; k++) {
+          nb_v[slot][k] = A::from_i64(prec[(rbase + q) * C + k]);
+          in_range = in_range && A::below(nb_v[slot][k], A::kRecLimit);
+        }
         if (q < j) {  // processed before this block: its children count
           const int qc0 = tv.fc[li + 1][q];
           nb_c0[slot] = qc0;
@@ -568,13 +594,13 @@ raht_level_sub_kernel(LevelCtx ctx)
       const int qc0 = __shfl(nb_c0[sl], owner);
       const uint32_t qocc = __shfl(nb_occ[sl], owner);
       const int single = __shfl(nb_single[sl], owner);
-      int64_t v[C];
+      VT v[C];
 #pragma unroll
       for (int k = 0; k < C; k++)
-        v[k] = shfl_i64(nb_v[sl][k], owner);
+        v[k] = shfl_v(nb_v[sl][k], owner);
       if (!run || q < 0)
         continue;
-      if (10 * v[0] <= lim_lo || 10 * v[0] >= lim_hi)
+      if (A::muli(v[0], 10) <= lim_lo || A::muli(v[0], 10) >= lim_hi)
         continue;
       if (has && ((neigh_mask(i) >> t) & 1)) {
         const int sh = occu_shift(i12);
@@ -583,14 +609,17 @@ raht_level_sub_kernel(LevelCtx ctx)
         if (child_ok) {
           const int cidx_n = qc0 + popc32(qocc & ((1u << cpos) - 1));
           const int64_t nrow = (int64_t)pt0 + (cidx_n - sc0);
-          const int64_t pwc = prm->pred_weight_child[i12];
-          wsum += (int)pwc;
+          const int pwc = prm->pred_weight_child[i12];
+          wsum += pwc;
           if (single) {
             // copied by the prepass launch: an ordinary load
-            const int64_t mul = ext ? pwc : (pwc << kFpFrac);
+            const int mul = ext ? pwc : (pwc << kFpFrac);
 #pragma unroll
-            for (int k = 0; k < C; k++)
-              pred[k] += par2(ctx.rec, cur_par)[nrow * C + k] * mul;
+            for (int k = 0; k < C; k++) {
+              const VT cv = A::from_i64(par2(ctx.rec, cur_par)[nrow * C + k]);
+              in_range = in_range && A::below(cv, A::kRecLimit);
+              pred[k] += A::muli(cv, mul);
+            }
           } else {
             nrow12[i12] = (int32_t)nrow;
             pend |= 1u << i12;
@@ -607,16 +636,16 @@ raht_level_sub_kernel(LevelCtx ctx)
             }
           }
         } else {
-          const int64_t pwp = prm->pred_weight_parent[i];
-          wsum += (int)pwp;
-          const int64_t mul = ext ? pwp : (pwp << kFpFrac);
+          const int pwp = prm->pred_weight_parent[i];
+          wsum += pwp;
+          const int mul = ext ? pwp : (pwp << kFpFrac);
 #pragma unroll
           for (int k = 0; k < C; k++)
-            pred[k] += v[k] * mul;
+            pred[k] += A::muli(v[k], mul);
         }
       }
     }
-    const int64_t pdiv = pred_divisor(wsum > 0 ? wsum : 1);
+    const VC pdiv = A::coef(pred_divisor(wsum > 0 ? wsum : 1));
     const auto mrsrc = __builtin_amdgcn_make_buffer_rsrc(
       ctx.mbox, 0, (int)((size_t)tv.n_total * C * 16), 0x00020000);
 
@@ -630,7 +659,7 @@ raht_level_sub_kernel(LevelCtx ctx)
     // commit.
     int stage = on ? 0 : 3;
     unsigned spins = 0;
-    int64_t pt[C];          // transformed prediction of this position
+    VT pt[C];               // transformed prediction of this position
     int32_t qc[C];          // tentative quantised coefficients (encoder) / coded ones (decoder)
     uint32_t dr = kDescZero;  // RDOQ descriptor of rank t (lossy encoder)
     bool hyp_done = false, hyp_same = false, zr_h = false;  // cached two-hypothesis outcome
@@ -640,7 +669,7 @@ raht_level_sub_kernel(LevelCtx ctx)
     int outk = 0, outv = -1;   // outgoing RDOQ state: 0 unknown, 1 transparent, 2 final (= outv)
 #pragma unroll
     for (int k = 0; k < C; k++) {
-      pt[k] = 0;
+      pt[k] = A::zero();
       // decoder: the coded coefficients are input -- fetched here, not on the chain
       qc[k] = (!kEnc && coded) ? cplane[(size_t)k * n_s] : 0;
     }
@@ -659,16 +688,16 @@ raht_level_sub_kernel(LevelCtx ctx)
           const int sh = occu_shift(i12);
           const int srcl = (pg << 3) | ((i12 < 9 ? t + sh : t - sh) & 7);
           const int pst = __shfl(stage, srcl);
-          int64_t v[C];
+          VT v[C];
 #pragma unroll
           for (int k = 0; k < C; k++)
-            v[k] = shfl_i64(pt[k], srcl);
+            v[k] = shfl_v(pt[k], srcl);
           if (mine && pst == 3) {
-            const int64_t pwc = prm->pred_weight_child[i12];
-            const int64_t mul = ext ? pwc : (pwc << kFpFrac);
+            const int pwc = prm->pred_weight_child[i12];
+            const int mul = ext ? pwc : (pwc << kFpFrac);
 #pragma unroll
             for (int k = 0; k < C; k++)
-              pred[k] += v[k] * mul;
+              pred[k] += A::muli(v[k], mul);
             pend &= ~(1u << i12);
             inw &= ~(1u << i12);
           }
@@ -683,7 +712,7 @@ raht_level_sub_kernel(LevelCtx ctx)
       if (pm) {
         const int slot = __ffs(pm) - 1;
         int32_t row = 0;
-        int64_t pwc = 0;
+        int pwc = 0;
 #pragma unroll
         for (int i12 = 0; i12 < 12; i12++) {
           if (slot == i12) {
@@ -700,10 +729,11 @@ raht_level_sub_kernel(LevelCtx ctx)
         for (int k = 0; k < C; k++)
           ok = ok && g[k].z == ctx.mtag;
         if (ok) {
-          const int64_t mul = ext ? pwc : (pwc << kFpFrac);
+          // (a granule carries the value in the launch's arithmetic: every reader is this launch)
+          const int mul = ext ? pwc : (pwc << kFpFrac);
 #pragma unroll
           for (int k = 0; k < C; k++)
-            pred[k] += (int64_t)(((uint64_t)g[k].y << 32) | g[k].x) * mul;
+            pred[k] += A::muli(__builtin_bit_cast(VT, ((uint64_t)g[k].y << 32) | g[k].x), mul);
           pend &= ~(1u << slot);
         }
       }
@@ -714,23 +744,28 @@ raht_level_sub_kernel(LevelCtx ctx)
       if (__any(nready)) {
         progressed = true;
         // ---- (P) normalise the prediction, transform -----------------------
-        int64_t pw_[C];
+        VT pw_[C];
 #pragma unroll
         for (int k = 0; k < C; k++)
           pw_[k] = pred[k];
         if (run && has) {
 #pragma unroll
           for (int k = 0; k < C; k++) {
-            pw_[k] = fp_mul_c(pw_[k], pdiv);
-            if (haar)
-              pw_[k] = (pw_[k] >> kFpFrac) << kFpFrac;
+            pw_[k] = A::mulc(pw_[k], pdiv);
+            if constexpr (!A::kF64) {
+              if (haar)
+                pw_[k] = (pw_[k] >> kFpFrac) << kFpFrac;
+            }
           }
         }
         if (!haar && w > 1 && enable_pred) {
 #pragma unroll
           for (int k = 0; k < C; k++)
-            pw_[k] = fp_mul_c(pw_[k], (int64_t)nrm_sq);
+            pw_[k] = A::mulc(pw_[k], nrm_sq);
         }
+#pragma unroll
+        for (int k = 0; k < C; k++)
+          in_range = in_range && A::below(pw_[k], A::kFwdLimit);
 #pragma unroll
         for (int st = 0; st < 3; st++) {
           const int bit = 1 << st;
@@ -739,15 +774,17 @@ raht_level_sub_kernel(LevelCtx ctx)
           const bool swap = !wl[st] && wr[st];
 #pragma unroll
           for (int k = 0; k < C; k++) {
-            const int64_t own = pw_[k], oth = shfl_xor_i64(own, bit);
+            const VT own = pw_[k], oth = shfl_xor_v(own, bit);
             if (enable_pred) {
               if (both) {
                 if (haar) {
-                  const int64_t hf = left ? oth - own : own - oth;
-                  pw_[k] = left ? own + ((hf >> (1 + kFpFrac)) << kFpFrac) : hf;
+                  if constexpr (!A::kF64) {
+                    const int64_t hf = left ? oth - own : own - oth;
+                    pw_[k] = left ? own + ((hf >> (1 + kFpFrac)) << kFpFrac) : hf;
+                  }
                 } else {
-                  pw_[k] = left ? fp_mul_c(oth, cb[st]) + fp_mul_c(own, ca[st])
-                                : fp_mul_c(own, ca[st]) - fp_mul_c(oth, cb[st]);
+                  pw_[k] = left ? A::mulc(oth, cb[st]) + A::mulc(own, ca[st])
+                                : A::mulc(own, ca[st]) - A::mulc(oth, cb[st]);
                 }
               } else if (swap) {
                 pw_[k] = oth;
@@ -766,12 +803,13 @@ raht_level_sub_kernel(LevelCtx ctx)
           int rate_coeff = 0;
 #pragma unroll
           for (int k = 0; k < C; k++) {
-            const int64_t res = enable_pred ? src[k] - pw_[k] : src[k];
-            const int64_t co = fp_round(res);
-            qn_[k] = (int32_t)quantize(qa[k ? 1 : 0], co * 256);
+            const VT res = enable_pred ? src[k] - pw_[k] : src[k];
+            const VT co = A::round_int(res);
+            qn_[k] = A::quantize(qaa[k ? 1 : 0], co);
             if (kLossy) {
-              dist2 += co * co;
-              int64_t aq = q_same ? (int64_t)qn_[k] : quantize(qr[k ? 1 : 0], co * 256);
+              const int64_t coi = A::to_small(co);  // (|co| < 2^21 inside the checked range)
+              dist2 += coi * coi;
+              int64_t aq = q_same ? (int64_t)qn_[k] : (int64_t)A::quantize(qra[k ? 1 : 0], co);
               aq = aq < 0 ? -aq : aq;
               sum_coeff += aq;
               rate_coeff += rate_log_small(aq);
@@ -982,7 +1020,7 @@ raht_level_sub_kernel(LevelCtx ctx)
       if (__any(can)) {
         progressed = true;
         // ---- (W) coefficients, DC, inverse transform, commit ---------------
-        int64_t pw_[C];
+        VT pw_[C];
 #pragma unroll
         for (int k = 0; k < C; k++)
           pw_[k] = pt[k];
@@ -992,14 +1030,14 @@ raht_level_sub_kernel(LevelCtx ctx)
         if (coded && can) {
 #pragma unroll
           for (int k = 0; k < C; k++) {
-            int64_t co;
+            int32_t co;
             if (kEnc) {
               co = zero_me ? 0 : qc[k];
-              cplane[(size_t)k * n_s] = (int32_t)co;
+              cplane[(size_t)k * n_s] = co;
             } else {
               co = qc[k];
             }
-            pw_[k] += fp_from_int(dequantize(qa[k ? 1 : 0], co));
+            pw_[k] += A::dequant_fp(qaa[k ? 1 : 0], co);
           }
         }
         if (on && inherit_dc && t == 0) {
@@ -1008,6 +1046,9 @@ raht_level_sub_kernel(LevelCtx ctx)
             pw_[k] = dc[k];
         }
 #pragma unroll
+        for (int k = 0; k < C; k++)
+          in_range = in_range && A::below(pw_[k], A::kInvLimit);
+#pragma unroll
         for (int st = 2; st >= 0; st--) {
           const int bit = 1 << st;
           const bool left = !(t & bit);
@@ -1015,15 +1056,17 @@ raht_level_sub_kernel(LevelCtx ctx)
           const bool swap = !wl[st] && wr[st];
 #pragma unroll
           for (int k = 0; k < C; k++) {
-            const int64_t own = pw_[k], oth = shfl_xor_i64(own, bit);
+            const VT own = pw_[k], oth = shfl_xor_v(own, bit);
             if (both) {
               if (haar) {
-                const int64_t lf = left ? own : oth, hf = left ? oth : own;
-                const int64_t lv = lf - ((hf >> (1 + kFpFrac)) << kFpFrac);
-                pw_[k] = left ? lv : hf + lv;
+                if constexpr (!A::kF64) {
+                  const int64_t lf = left ? own : oth, hf = left ? oth : own;
+                  const int64_t lv = lf - ((hf >> (1 + kFpFrac)) << kFpFrac);
+                  pw_[k] = left ? lv : hf + lv;
+                }
               } else {
-                pw_[k] = left ? fp_mul_c(own, ca[st]) - fp_mul_c(oth, cb[st])
-                              : fp_mul_c(oth, cb[st]) + fp_mul_c(own, ca[st]);
+                pw_[k] = left ? A::mulc(own, ca[st]) - A::mulc(oth, cb[st])
+                              : A::mulc(oth, cb[st]) + A::mulc(own, ca[st]);
               }
             } else if (swap) {
               pw_[k] = oth;
@@ -1035,22 +1078,23 @@ raht_level_sub_kernel(LevelCtx ctx)
         // poll (one 16-byte write-through store: value + tag, untorn)
         if (can && has) {
           // the granules first: they are what the next hop of the chain waits for
-          int64_t vn[C];
+          VT vn[C];
 #pragma unroll
           for (int k = 0; k < C; k++) {
-            int64_t v = pw_[k];
+            VT v = pw_[k];
             if (!haar && w > 1)
-              v = fp_mul_c(v >> nrm_shift, (int64_t)nrm_rs);
-            v = ext ? v : fp_round(v);
+              v = A::mulc(A::shr(v, nrm_shift), nrm_rs);
+            v = ext ? v : A::round_int(v);
             vn[k] = v;
             pt[k] = v;  // read by later groups of this wavefront once stage == 3
-            const u32x4 gr = {(uint32_t)v, (uint32_t)((uint64_t)v >> 32), ctx.mtag, 0u};
+            const uint64_t vb = __builtin_bit_cast(uint64_t, v);
+            const u32x4 gr = {(uint32_t)vb, (uint32_t)(vb >> 32), ctx.mtag, 0u};
             __builtin_amdgcn_raw_buffer_store_b128(gr, mrsrc, (int)((crow * C + k) * 16), 0, /*sc1*/ 16);
           }
 #pragma unroll
           for (int k = 0; k < C; k++) {
-            par2(ctx.rec_us, cur_par)[crow * C + k] = ext ? pw_[k] : fp_round(pw_[k] * 4);
-            par2(ctx.rec, cur_par)[crow * C + k] = vn[k];
+            par2(ctx.rec_us, cur_par)[crow * C + k] = A::to_i64(ext ? pw_[k] : A::round_int(A::muli(pw_[k], 4)));
+            par2(ctx.rec, cur_par)[crow * C + k] = A::to_i64(vn[k]);
           }
           par2(ctx.nneigh, cur_par)[crow] = inherit_dc ? neigh_count : 19;
         }
@@ -1071,6 +1115,11 @@ raht_level_sub_kernel(LevelCtx ctx)
     }
     prof.round_end(lane, li);
   }
+  // ArithF64: a value left the range in which doubles are exact -- the sticky word stops every
+  // later kernel of the call (the source attributes stay intact) and the call is redone with
+  // ArithI64 (host tier) or reports GPCC_ERR_RANGE (device tier)
+  if (A::kF64 && __any(!in_range) && lane == 0)
+    atomicCAS(ctx.error, 0, 3);
 }
 
 }  // namespace gpcc

@@ -49,6 +49,10 @@ class Context:
     def set_morton_bits(self, bits):
         _lib.check(self._lib.gpcc_ctx_set_morton_bits(self._h, int(bits)))
 
+    def set_fast_arith(self, on):
+        """doubles where they are exact (default) / int64 always in the sub-node kernels"""
+        _lib.check(self._lib.gpcc_ctx_set_fast_arith(self._h, int(bool(on))))
+
     def set_profiling(self, on):
         _lib.check(self._lib.gpcc_ctx_set_profiling(self._h, int(bool(on))))
 
