@@ -148,6 +148,13 @@ raht_level_sub_kernel(LevelCtx ctx)
   const bool haar = !A::kF64 && prm->integer_haar_enable_flag != 0;
   const bool ext = A::kF64 || prm->raht_extension != 0;
   const int32_t epoch = li + 1;
+  // the wavefront's mailbox: values of the children committed in the current round
+  __shared__ unsigned long long wmail_s[4 * 64 * C];
+  unsigned long long* wm = wmail_s + (threadIdx.x >> 6) * (64 * C);
+  int pwc12[12];
+#pragma unroll
+  for (int i12 = 0; i12 < 12; i12++)
+    pwc12[i12] = prm->pred_weight_child[i12];
   bool in_range = true;  // (ArithF64: the magnitudes that bound every product, raht_arith.hpp)
   const int cls = blockIdx.x & 7;
 
@@ -350,6 +357,31 @@ raht_level_sub_kernel(LevelCtx ctx)
         }
       }
       const int64_t* __restrict__ pkey = tv.key[li + 1];
+#ifdef GPCC_EXP_SEARCH2  // (experiment: what the search costs -- it is done twice, same result)
+      {
+        int l2[3] = {lo[0], lo[1], lo[2]}, h2[3] = {hi[0], hi[1], hi[2]};
+        while (__any((l2[0] < h2[0]) | (l2[1] < h2[1]) | (l2[2] < h2[2]))) {
+#pragma unroll
+          for (int slot = 0; slot < 3; slot++) {
+            const int mid = l2[slot] + ((h2[slot] - l2[slot]) >> 1);
+            const int64_t kv = l2[slot] < h2[slot] ? pkey[mid] : 0;
+            if (l2[slot] < h2[slot]) {
+              if (kv < want[slot])
+                l2[slot] = mid + 1;
+              else
+                h2[slot] = mid;
+            }
+          }
+        }
+        // the second search starts where the first one ended up saying it should (a dependency, no change)
+#pragma unroll
+        for (int slot = 0; slot < 3; slot++) {
+          int a2 = l2[slot];
+          asm volatile("" : "+v"(a2));
+          lo[slot] += a2 ^ l2[slot];
+        }
+      }
+#endif
       while (__any((lo[0] < hi[0]) | (lo[1] < hi[1]) | (lo[2] < hi[2]))) {
         int mid[3];
         int64_t kv[3];
@@ -654,19 +686,25 @@ raht_level_sub_kernel(LevelCtx ctx)
     //          results cached in registers
     // stage 1: waiting for the RDOQ state L (lossy encoder only)
     // stage 3: committed
-    // A waiting iteration costs only the polls; the expensive part (P) runs
-    // when a group becomes neighbour-ready, the commit part (W) when one can
-    // commit.
+    // A waiting iteration costs the polls and a handful of tests; (P) runs when a group
+    // becomes neighbour-ready, the RDOQ evaluation (Z) when a group has its descriptors or
+    // learns the incoming state, the commit part (W) when one can commit.  Children of
+    // blocks of THIS wavefront are handed over through the wavefront's LDS mailbox.
     int stage = on ? 0 : 3;
     unsigned spins = 0;
     VT pt[C];               // transformed prediction of this position
     int32_t qc[C];          // tentative quantised coefficients (encoder) / coded ones (decoder)
     uint32_t dr = kDescZero;  // RDOQ descriptor of rank t (lossy encoder)
-    bool hyp_done = false, hyp_same = false, zr_h = false;  // cached two-hypothesis outcome
-    uint32_t res_h = 0;
-    int need = 0;       // reach of the block's thresholds before its first coefficient
-    int look = wi - 1;  // look-back cursor
+    // RDOQ of the block (group-uniform): zs 0 = descriptors not there yet, 1 = the decisions
+    // wait for the incoming last reset, 2 = decided (zero_r valid)
+    int zs = 0;
+    bool zero_r = false;
+    uint32_t dmask = 0;     // definite resets of the block, by rank
+    bool lin_exact = false; // lin is the incoming last reset itself (not only a bound that settles the block)
+    int need = 0;           // reach of the block's thresholds before its first coefficient
+    int look = wi - 1;      // look-back cursor
     int outk = 0, outv = -1;   // outgoing RDOQ state: 0 unknown, 1 transparent, 2 final (= outv)
+    unsigned long long done = 0;  // children of this round whose value lies in the mailbox (wave-uniform)
 #pragma unroll
     for (int k = 0; k < C; k++) {
       pt[k] = A::zero();
@@ -677,29 +715,30 @@ raht_level_sub_kernel(LevelCtx ctx)
     while (__any(stage != 3)) {
       bool progressed = false;
       prof.iter_begin();
-      // ---- (X) awaited children of blocks of this wavefront: registers ----
-      if (__any(stage == 0 && inw)) {
+      // ---- (X) awaited children of blocks of this wavefront: the mailbox ----
+      {
+        uint32_t mi = stage == 0 ? (pend & inw) : 0u;
+        while (__any(mi != 0)) {
+          const bool act = mi != 0;
+          const int slot = act ? __ffs(mi) - 1 : 0;
+          mi &= mi - 1;
+          const uint32_t pg = (slot < 10 ? wsrc_a >> (3 * slot) : wsrc_b >> (3 * (slot - 10))) & 7u;
+          // occuShift of findNeighbours (tmc3/RAHT.cpp:377), three bits each
+          constexpr unsigned long long kShifts = 06ull | 05ull << 3 | 04ull << 6 | 03ull << 9 | 02ull << 12
+            | 01ull << 15 | 03ull << 18 | 01ull << 21 | 02ull << 24 | 01ull << 27 | 02ull << 30 | 03ull << 33;
+          const int sh = (int)((kShifts >> (3 * slot)) & 7);
+          const int srcl = (int)(pg << 3) | ((slot < 9 ? t + sh : t - sh) & 7);
+          if (act && ((done >> srcl) & 1)) {
+            int pwc = 0;
 #pragma unroll
-        for (int i12 = 0; i12 < 12; i12++) {
-          const bool mine = stage == 0 && ((inw >> i12) & 1);
-          if (!__any(mine))
-            continue;
-          const int pg = (i12 < 10 ? wsrc_a >> (3 * i12) : wsrc_b >> (3 * (i12 - 10))) & 7;
-          const int sh = occu_shift(i12);
-          const int srcl = (pg << 3) | ((i12 < 9 ? t + sh : t - sh) & 7);
-          const int pst = __shfl(stage, srcl);
-          VT v[C];
-#pragma unroll
-          for (int k = 0; k < C; k++)
-            v[k] = shfl_v(pt[k], srcl);
-          if (mine && pst == 3) {
-            const int pwc = prm->pred_weight_child[i12];
+            for (int i12 = 0; i12 < 12; i12++)
+              pwc = slot == i12 ? pwc12[i12] : pwc;
             const int mul = ext ? pwc : (pwc << kFpFrac);
 #pragma unroll
             for (int k = 0; k < C; k++)
-              pred[k] += A::muli(v[k], mul);
-            pend &= ~(1u << i12);
-            inw &= ~(1u << i12);
+              pred[k] += A::muli(__builtin_bit_cast(VT, wm[srcl * C + k]), mul);
+            pend &= ~(1u << slot);
+            inw &= ~(1u << slot);
           }
         }
       }
@@ -708,6 +747,9 @@ raht_level_sub_kernel(LevelCtx ctx)
       // iteration costs ONE memory round trip however many different
       // neighbours the 64 lanes wait for (polling slot after slot made it
       // as many round trips as there were slots in use).
+      // (Skipping the poll in an iteration that has a group ready to compute -- so that a chain
+      // inside the wavefront never stalls on a memory round trip -- was measured: 7.22 / 4.17 ms
+      // against 6.98 / 3.95, arrivals from other wavefronts are what the frame waits for.)
       const uint32_t pm = stage == 0 ? (pend & ~inw) : 0u;
       if (pm) {
         const int slot = __ffs(pm) - 1;
@@ -853,117 +895,101 @@ raht_level_sub_kernel(LevelCtx ctx)
       }
 
       // ---- (Z) RDOQ state: can the stage-1 groups commit? ----------------
+      // (tmc3/RAHT.cpp:1618-1669 restated in raht_rdoq.hpp: rank r resets iff it is a definite
+      // reset, or run-dependent with a reset in [r - thr, r - 1]; the block's resets for an incoming
+      // last reset l0 are the least fixed point, reached in as many sweeps as failures chain.)
       prof.mark<1>();
       bool can = stage == 1;
-      bool zero_r = false;
       if (kLossy) {
         const bool rvalid = t < ncoef;
         const bool rz = dr >> 31;
         const uint32_t rthr = dr & kDescNever;
-        const bool isdef = rvalid && !rz && rthr == kDescNever;
         const bool isthr = rvalid && !rz && rthr != kDescNever && rthr != 0;
+        const bool dep = rvalid && rthr != kDescNever && rthr != 0;  // its zeroing depends on the run
         const int ci = cfirst + t;  // slice-relative index of rank t
-        // least fixed point of "fails iff a reset lies in its window" for an
-        // incoming last-reset index l0 (see raht_rdoq.hpp)
-        auto resolve = [&](int l0, uint32_t* resets_out) -> int {
-          uint32_t resets = group8_bits(isdef);
-          int lhat = l0;
-#pragma unroll
-          for (int it = 0; it < 8; it++) {
-            const uint32_t below = resets & ((1u << t) - 1);
-            lhat = below ? cfirst + (31 - __clz(below)) : l0;
-            const bool fail = isthr && !((resets >> t) & 1)
-              && (uint32_t)(ci - lhat) <= rthr;
-            const uint32_t more = group8_bits(fail);
-            if (!more)
+        const uint32_t below = (1u << t) - 1u;
+        // sweeps run in wave-uniform control flow; lanes of groups that do not take part pass act = false
+        auto resets_for = [&](int l0, bool act) -> uint32_t {
+          uint32_t resets = dmask;
+          for (;;) {
+            const uint32_t bb = resets & below;
+            const int lhat = bb ? cfirst + (31 - __clz(bb)) : l0;
+            const bool fail = act && isthr && !((resets >> t) & 1) && (uint32_t)(ci - lhat) <= rthr;
+            const unsigned long long m = __ballot(fail);
+            if (!m)
               break;
-            resets |= more;
+            resets |= (uint32_t)(m >> gbase) & 0xffu;
           }
-          const uint32_t below = resets & ((1u << t) - 1);
-          lhat = below ? cfirst + (31 - __clz(below)) : l0;
-          *resets_out = resets;
-          return ci - 1 - lhat;  // zero-run length seen by rank t
+          return resets;
         };
-        uint32_t resets = res_h;
-        zero_r = zr_h;
-        if (stage == 1 && !lin_known && !hyp_done) {
-          // the two extreme hypotheses for the incoming L (once per block);
-          // a block without any run-dependent coefficient skips them
-          uint32_t ra, rb;
-          bool fa, fb;
-          if (!group8_any(rvalid && rthr != kDescNever && rthr != 0)) {
-            ra = rb = group8_bits(isdef);
-            fa = fb = rvalid && rthr == 0;
-          } else {
-            const int tza = resolve(-1, &ra);
-            const int tzb = resolve(cfirst - 1, &rb);
-            fa = rvalid && rthr != kDescNever && (uint32_t)tza >= rthr;
-            fb = rvalid && rthr != kDescNever && (uint32_t)tzb >= rthr;
-          }
-          hyp_same = !group8_any(fa != fb) && ra == rb;
-          hyp_done = true;
-          resets = res_h = rb;
-          zero_r = zr_h = fb;
-          const int la = ra ? 31 - __clz(ra) : -1, lb = rb ? 31 - __clz(rb) : -1;
-          if (ra && la == lb) {
-            outk = 2;  // outgoing L known before the decisions are
-            outv = cfirst + lb;
-          } else if (hyp_same && !ra) {
-            outk = 1;  // no reset either way: L passes through
-          }
-          // how far before the block's first coefficient a reset still matters:
-          // rank t with threshold thr looks at [ci - thr, ci - 1]
-          // (also the all-zero coefficients whose tentative value is non-zero:
-          // they never reset, but whether they are zeroed depends on the run)
-          need = group8_max((rvalid && rthr != kDescNever && rthr != 0) ? (int)rthr - t : 0);
-          if (!hyp_same && outk == 2 && t == 0)
-            // decisions still open, outgoing L already certain: successors go on
-            __hip_atomic_store(
-              &ctx.rdoq_state[wi], ((unsigned long long)epoch << 48) | (2ull << 32) | (uint32_t)outv,
-              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        // ---- a block whose decisions depend on L finds it by a BOUNDED
-        // look-back: only a reset within `need` coefficients before the block
-        // matters, so the walk over the predecessors' state words ends at the
-        // first block with a reset (exact L), at the slice start, or as soon
-        // as `need` coefficients of reset-free blocks have been passed
-        // (any older L gives the same decisions).  Predecessors that are
-        // themselves undecided are waited for -- that is the only chain.
-        const bool want = stage == 1 && !lin_known && !hyp_same;
-        // (a) predecessors inside the wavefront, from registers
-        if (__any(want)) {
-          const unsigned long long lead = 0x0101010101010101ull;
-          const unsigned long long below = (1ull << gbase) - 1;
-          for (int pass = 0; pass < 8; pass++) {
-            if (stage == 1 && lin_known && outk != 3) {
-              uint32_t rr;
-              resolve(lin, &rr);
-              outk = rr ? 3 : 1;  // settled with the true L: final, or reset-free
-              outv = rr ? cfirst + (31 - __clz(rr)) : outv;
+        auto zeroed = [&](uint32_t resets, int l0) -> bool {
+          const uint32_t bb = resets & below;
+          const int lhat = bb ? cfirst + (31 - __clz(bb)) : l0;
+          return rvalid && rthr != kDescNever && (uint32_t)(ci - 1 - lhat) >= rthr;
+        };
+        // a block that has just got its descriptors
+        const bool entry = stage == 1 && zs == 0;
+        if (__any(entry)) {
+          const bool isdef = rvalid && !rz && rthr == kDescNever;
+          const uint32_t dm = group8_bits(entry && isdef);
+          const bool tany = group8_any(entry && dep);
+          if (entry) {
+            dmask = dm;
+            zs = 1;
+            if (cfirst == e.coeff_base) {
+              // the slice's first coded block of the level: the state the previous level left
+              lin = ctx.slice_l[((li + 1) & 1) * tv.num_slices + s];
+              lin_known = lin_exact = true;
+            } else if (!tany) {
+              // no coefficient looks at the run: decided, and what the block does to L is known
+              zero_r = rvalid && rthr == 0;
+              zs = 2;
+              outk = dm ? 2 : 1;
+              outv = dm ? cfirst + (31 - __clz(dm)) : outv;
             }
-            const unsigned long long nt = __ballot(outk != 1) & lead & below;
-            const int pl = nt ? 63 - __clzll((long long)nt) : 0;
-            const int pk = __shfl(outk, pl);
-            const int pv = __shfl(outv, pl);
-            const int ps = __shfl(s, pl);
-            const bool w2 = stage == 1 && !lin_known && !hyp_same;
-            const bool found = w2 && nt != 0 && pk >= 2 && ps == s;
-            if (!__any(found))
-              break;
-            if (found) {
-              lin = pv;
-              lin_known = true;
+          }
+          // the others: the two extreme hypotheses for the incoming L, once
+          const bool hyp = entry && zs == 1 && !lin_known;
+          if (__any(hyp)) {
+            const uint32_t ra = resets_for(-1, hyp);
+            const uint32_t rb = resets_for(cfirst - 1, hyp);
+            const bool fa = zeroed(ra, -1), fb = zeroed(rb, cfirst - 1);
+            const bool same = !group8_any(hyp && fa != fb) && ra == rb;
+            const int la = ra ? 31 - __clz(ra) : -1, lb = rb ? 31 - __clz(rb) : -1;
+            const int nd = group8_max((hyp && dep) ? (int)rthr - t : 0);
+            if (hyp) {
+              need = nd;
+              if (same) {
+                zero_r = fb;
+                zs = 2;
+                outk = ra ? 2 : 1;
+                outv = ra ? cfirst + la : outv;
+              } else if (ra && la == lb) {
+                // decisions still open, outgoing L already certain: successors go on
+                outk = 2;
+                outv = cfirst + lb;
+                if (t == 0)
+                  __hip_atomic_store(
+                    &ctx.rdoq_state[wi], ((unsigned long long)epoch << 48) | (2ull << 32) | (uint32_t)outv,
+                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              }
             }
           }
         }
-        // (b) the state words in memory, 8 predecessors per step
-        if (stage == 1 && !lin_known && !hyp_same) {
-          for (int step = 0; step < 4 && !lin_known; step++) {
-            const int k = look - t;
-            const int kc = k < 0 ? 0 : k;
-            const unsigned long long sv =
-              __hip_atomic_load(&ctx.rdoq_state[kc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const bool boundary = k < 0 || ctx.worklist[kc] < sp0;
+        if (__any(stage == 1 && zs == 1)) {
+          // ---- the incoming L: predecessors in memory (a wavefront's first groups), 8 per step;
+          // only a reset within `need` coefficients before the block matters ----
+          const bool wantm = stage == 1 && zs == 1 && !lin_known;
+          if (__any(wantm)) {
+            const int kk = look - t;
+            const int kc = kk < 0 ? 0 : kk;
+            unsigned long long sv = 0;
+            int wl_k = 0;
+            if (wantm) {
+              sv = __hip_atomic_load(&ctx.rdoq_state[kc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              wl_k = ctx.worklist[kc];
+            }
+            const bool boundary = kk < 0 || wl_k < sp0;
             const bool cur_ep = (sv >> 48) == (unsigned long long)epoch;
             // kind: 0 pending, 1 reset-free (value = its first coefficient),
             // 2 final (value = L), 3 slice start, 5 far enough
@@ -971,42 +997,70 @@ raht_level_sub_kernel(LevelCtx ctx)
             const int val = (int)(uint32_t)sv;
             if (kind == 1 && cfirst - val >= need)
               kind = 5;
-            const uint32_t stop = group8_bits(kind != 1);
-            if (!stop) {
-              look -= 8;
-              continue;
-            }
-            const int first = __ffs(stop) - 1;  // nearest predecessor that decides
+            const uint32_t stop = group8_bits(wantm && kind != 1);
+            const int first = stop ? __ffs(stop) - 1 : 0;
             const int fkind = __shfl(kind, gbase | first);
             const int fval = __shfl(val, gbase | first);
-            if (fkind == 2) {
-              lin = fval;
-              lin_known = true;
-            } else if (fkind == 3) {
-              lin = ctx.slice_l[((li + 1) & 1) * tv.num_slices + s];  // as the previous level left it
-              lin_known = true;
-            } else if (fkind == 5) {
-              lin = fval - 1;  // stands for "no reset within reach"
-              lin_known = true;
-            } else {
-              look -= first;  // undecided: everything nearer is reset-free
-              break;
+            if (wantm) {
+              if (!stop) {
+                look -= 8;
+                progressed = true;  // (the walk goes on at once)
+              } else if (fkind == 2) {
+                lin = fval;
+                lin_known = lin_exact = true;
+              } else if (fkind == 3) {
+                lin = ctx.slice_l[((li + 1) & 1) * tv.num_slices + s];  // as the previous level left it
+                lin_known = lin_exact = true;
+              } else if (fkind == 5) {
+                lin = fval - 1;  // stands for "no reset within reach"
+                lin_known = true;
+              } else {
+                look -= first;  // undecided: everything nearer is reset-free
+              }
             }
           }
-          if (lin_known)
-            progressed = true;
+          // ---- groups that know L settle; what they leave may settle the next group of the
+          // wavefront in the same iteration (registers, no memory) ----
+          const unsigned long long lead = 0x0101010101010101ull;
+          const unsigned long long before = (1ull << gbase) - 1;
+          for (int pass = 0; pass < 8; pass++) {
+            const bool settle = stage == 1 && zs == 1 && lin_known;
+            if (__any(settle)) {
+              const uint32_t rr = resets_for(lin, settle);
+              if (settle) {
+                zero_r = zeroed(rr, lin);
+                zs = 2;
+                if (rr) {
+                  outk = 2;
+                  outv = cfirst + (31 - __clz(rr));
+                } else if (lin_exact) {
+                  outk = 2;   // the state passes through unchanged, and it is known
+                  outv = lin;
+                } else {
+                  outk = 1;
+                }
+              }
+            }
+            const bool w2 = stage == 1 && zs == 1 && !lin_known;
+            if (!__any(w2))
+              break;
+            const unsigned long long nt = __ballot(outk != 1) & lead & before;
+            const int pl = nt ? 63 - __clzll((long long)nt) : 0;
+            const int pk = __shfl(outk, pl);
+            const int pv = __shfl(outv, pl);
+            const bool found = w2 && nt != 0 && pk == 2;
+            if (found) {
+              lin = pv;
+              lin_known = lin_exact = true;
+            }
+            if (!__any(found))
+              break;
+          }
         }
-        if (stage == 1 && lin_known) {
-          const int tz = resolve(lin, &resets);
-          zero_r = rvalid && rthr != kDescNever && (uint32_t)tz >= rthr;
-          outk = resets ? 3 : 1;
-          outv = resets ? cfirst + (31 - __clz(resets)) : outv;
-        } else if (!hyp_same) {
-          can = false;
-        }
+        can = stage == 1 && zs == 2;
         if (can && t == 0) {
-          // what this block does to L: its last reset, or nothing (then the
-          // word carries the block's first coefficient index for the walk)
+          // what this block does to L: its last reset (or the known state passing through), or
+          // nothing (then the word carries the block's first coefficient index for the walk)
           const unsigned long long ep = (unsigned long long)epoch << 48;
           const unsigned long long word =
             outk >= 2 ? ep | (2ull << 32) | (uint32_t)outv : ep | (1ull << 32) | (uint32_t)cfirst;
@@ -1086,8 +1140,8 @@ raht_level_sub_kernel(LevelCtx ctx)
               v = A::mulc(A::shr(v, nrm_shift), nrm_rs);
             v = ext ? v : A::round_int(v);
             vn[k] = v;
-            pt[k] = v;  // read by later groups of this wavefront once stage == 3
             const uint64_t vb = __builtin_bit_cast(uint64_t, v);
+            wm[lane * C + k] = vb;  // read by later groups of this wavefront once `done` says so
             const u32x4 gr = {(uint32_t)vb, (uint32_t)(vb >> 32), ctx.mtag, 0u};
             __builtin_amdgcn_raw_buffer_store_b128(gr, mrsrc, (int)((crow * C + k) * 16), 0, /*sc1*/ 16);
           }
@@ -1102,12 +1156,13 @@ raht_level_sub_kernel(LevelCtx ctx)
           stage = 3;
       }
 
+      done |= __ballot(can && has);
       prof.mark<3>();
       if (!progressed) {
         prof.idle();
         if (++spins > (1u << 21)) {
           if (lane == 0)
-            atomicExch(ctx.error, 1);  // fail loudly instead of hanging
+            atomicExch(ctx.error, 1);  // fail loudly instead of hanging the GPU
           break;
         }
         __builtin_amdgcn_s_sleep(GPCC_SUB_SLEEP);
