@@ -2,14 +2,23 @@
  *
  * CPU restatement of pcc::recolour (tmc3/pointset_processing.cpp:926-957:
  * recolourColour :253-594, recolourReflectance :618-916) in the form the device
- * kernels use: exact k-nearest-neighbour search over a uniform grid instead of the
- * nanoflann k-d tree, every floating-point expression of the reference evaluated
- * in double in the reference's order, and ONE rule where the reference's outcome
- * depends on container internals: among equidistant candidates the lower point
- * index comes first (nanoflann keeps whichever its tree visits first; std::sort
- * leaves equal keys in unspecified order).  The device path has to match this file
- * bit for bit; this file matches the compiled reference (oracle/_ref) wherever no
- * tie decides -- tests/test_oracle_recolour.py measures both.
+ * kernels use.  The reference's outcome depends on the ORDER in which its containers
+ * hand over equidistant candidates, so the containers are restated too:
+ *   - the nanoflann k-d tree (dependencies/nanoflann/nanoflann.hpp: divideTree :872,
+ *     middleSplit_ :922, planeSplit :972, leaf size 10) built LEVEL BY LEVEL, every
+ *     plane split as rank arithmetic (the i-th misplaced index from the left changes
+ *     places with the i-th from the right: what the two-pointer loop does, without
+ *     the loop) -- the form a GPU can run;
+ *   - its search (searchLevel :1308, KNNResultSet::addPoint :175) as an explicit
+ *     stack walk: the same child first, the same pruning expression, candidates of
+ *     equal distance in visiting order;
+ *   - the backward lists in source order, sorted by std::sort's algorithm (libstdc++
+ *     11: introsort with a median-of-three pivot, heap sort at the depth limit,
+ *     insertion sort for ranges of at most 16 -- NOT stable beyond 16 entries);
+ * and every floating-point expression of the reference evaluated in double in the
+ * reference's order.  The device path has to match this file bit for bit; this file
+ * matches the compiled reference (oracle/_ref) everywhere, ties included --
+ * tests/test_oracle_recolour.py.
  *
  * Only tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke() may use it. */
 #include <math.h>
@@ -20,174 +29,430 @@
 #include "gpcc_attr_mi355.h"
 
 #define RC_MAXK 8
+#define KD_LEAF 10
+#define KD_MAX_DEPTH 120
+
+/* ---- the k-d tree ------------------------------------------------------------------ */
+typedef struct {
+  int32_t left, right;   /* its range of vind */
+  int32_t child1, child2; /* node indices, -1 for a leaf */
+  int32_t feat;
+  double divlow, divhigh; /* nanoflann.hpp:910-911: the children's TIGHT bounds along feat */
+  double lo[3], hi[3];    /* the box handed down (build only: cut planes of the ancestors) */
+} KdNode;
 
 typedef struct {
-  int shift;           /* cell side = 1 << shift */
-  int dim[3];          /* cells per axis */
-  int lo[3];           /* first cell coordinate */
-  int32_t* start;      /* [cells + 1] */
-  int32_t* items;      /* [n] point indices, ascending inside a cell */
   const int32_t* xyz;
   int n;
-} Grid;
+  int32_t* vind;
+  KdNode* nodes;
+  int nnodes;
+  double root_lo[3], root_hi[3];
+} KdTree;
+
+/* planeSplit's two-pointer loop (nanoflann.hpp:972-998) as rank arithmetic: with m entries
+ * that belong left, the i-th entry of ind[0, m) that does not belong there (ascending) and
+ * the i-th entry of ind[m, count) that belongs left (DESCENDING) change places. */
+static void
+hoare_by_rank(int32_t* ind, int count, const uint8_t* goes_left, int32_t* tmp)
+{
+  int m = 0;
+  for (int i = 0; i < count; i++)
+    m += goes_left[i];
+  int nl = 0, nr = 0;
+  int32_t* lpos = tmp;
+  int32_t* rpos = tmp + count;
+  for (int i = 0; i < m; i++)
+    if (!goes_left[i])
+      lpos[nl++] = i;
+  for (int i = count - 1; i >= m; i--)
+    if (goes_left[i])
+      rpos[nr++] = i;
+  for (int i = 0; i < nl; i++) {
+    const int32_t t = ind[lpos[i]];
+    ind[lpos[i]] = ind[rpos[i]];
+    ind[rpos[i]] = t;
+  }
+}
 
 static int
-grid_build(Grid* g, const int32_t* xyz, int n)
+kd_build(KdTree* kt, const int32_t* xyz, int n)
 {
-  int mn[3], mx[3];
-  for (int k = 0; k < 3; k++)
-    mn[k] = mx[k] = xyz[k];
-  for (int i = 1; i < n; i++)
-    for (int k = 0; k < 3; k++) {
-      if (xyz[3 * i + k] < mn[k])
-        mn[k] = xyz[3 * i + k];
-      if (xyz[3 * i + k] > mx[k])
-        mx[k] = xyz[3 * i + k];
+  kt->xyz = xyz;
+  kt->n = n;
+  kt->vind = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
+  kt->nodes = (KdNode*)malloc(sizeof(KdNode) * (2 * (size_t)n + 1));
+  int32_t* tmp = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)n);
+  uint8_t* flag = (uint8_t*)malloc((size_t)n);
+  if (!kt->vind || !kt->nodes || !tmp || !flag)
+    return -1;
+  for (int i = 0; i < n; i++)
+    kt->vind[i] = i;
+  KdNode* root = &kt->nodes[0];
+  root->left = 0;
+  root->right = n;
+  for (int a = 0; a < 3; a++) {
+    int mn = xyz[a], mx = xyz[a];
+    for (int i = 1; i < n; i++) {
+      const int v = xyz[3 * i + a];
+      mn = v < mn ? v : mn;
+      mx = v > mx ? v : mx;
     }
-  /* the smallest cell for which the table stays below ~4 n cells */
-  int shift = 0;
-  for (;; shift++) {
-    double cells = 1;
-    for (int k = 0; k < 3; k++)
-      cells *= (double)((mx[k] >> shift) - (mn[k] >> shift) + 1);
-    if (cells <= 4.0 * n + 64)
-      break;
+    root->lo[a] = kt->root_lo[a] = (double)mn;
+    root->hi[a] = kt->root_hi[a] = (double)mx;
   }
-  g->shift = shift;
-  g->xyz = xyz;
-  g->n = n;
-  size_t cells = 1;
-  for (int k = 0; k < 3; k++) {
-    g->lo[k] = mn[k] >> shift;
-    g->dim[k] = (mx[k] >> shift) - g->lo[k] + 1;
-    cells *= (size_t)g->dim[k];
+  kt->nnodes = 1;
+  /* breadth first: node k's children are appended while k is visited */
+  for (int k = 0; k < kt->nnodes; k++) {
+    KdNode* nd = &kt->nodes[k];
+    const int count = nd->right - nd->left;
+    int32_t* ind = kt->vind + nd->left;
+    nd->child1 = nd->child2 = -1;
+    nd->feat = 0;
+    nd->divlow = nd->divhigh = 0.0;
+    if (count <= KD_LEAF)
+      continue;
+    /* middleSplit_ (:922-961) */
+    double mn[3], mx[3];
+    for (int a = 0; a < 3; a++) {
+      int lo = xyz[3 * ind[0] + a], hi = lo;
+      for (int i = 1; i < count; i++) {
+        const int v = xyz[3 * ind[i] + a];
+        lo = v < lo ? v : lo;
+        hi = v > hi ? v : hi;
+      }
+      mn[a] = (double)lo;
+      mx[a] = (double)hi;
+    }
+    const double EPS = 0.00001;
+    double max_span = nd->hi[0] - nd->lo[0];
+    for (int a = 1; a < 3; a++) {
+      const double span = nd->hi[a] - nd->lo[a];
+      if (span > max_span)
+        max_span = span;
+    }
+    double max_spread = -1;
+    int feat = 0;
+    for (int a = 0; a < 3; a++) {
+      const double span = nd->hi[a] - nd->lo[a];
+      if (span >= (1 - EPS) * max_span) {
+        const double spread = mx[a] - mn[a];
+        if (spread > max_spread) {
+          feat = a;
+          max_spread = spread;
+        }
+      }
+    }
+    const double split = (nd->lo[feat] + nd->hi[feat]) / 2;
+    const double cut = split < mn[feat] ? mn[feat] : (split > mx[feat] ? mx[feat] : split);
+    int lim1 = 0, lim2 = 0;
+    for (int i = 0; i < count; i++) {
+      const double v = (double)xyz[3 * ind[i] + feat];
+      flag[i] = v < cut;
+      lim1 += v < cut;
+      lim2 += v <= cut;
+    }
+    hoare_by_rank(ind, count, flag, tmp);
+    for (int i = lim1; i < count; i++)
+      flag[i - lim1] = (double)xyz[3 * ind[i] + feat] <= cut;
+    hoare_by_rank(ind + lim1, count - lim1, flag, tmp);
+    const int half = count / 2;
+    const int idx = lim1 > half ? lim1 : (lim2 < half ? lim2 : half);
+    /* children: the box cut at the plane (divideTree :900-908) */
+    KdNode* c1 = &kt->nodes[kt->nnodes];
+    KdNode* c2 = &kt->nodes[kt->nnodes + 1];
+    nd->child1 = kt->nnodes;
+    nd->child2 = kt->nnodes + 1;
+    kt->nnodes += 2;
+    nd->feat = feat;
+    for (int a = 0; a < 3; a++) {
+      c1->lo[a] = c2->lo[a] = nd->lo[a];
+      c1->hi[a] = c2->hi[a] = nd->hi[a];
+    }
+    c1->hi[feat] = cut;
+    c2->lo[feat] = cut;
+    c1->left = nd->left;
+    c1->right = c2->left = nd->left + idx;
+    c2->right = nd->right;
+    /* the recursion returns the children's tight boxes in place of the ones handed down */
+    int lmax = xyz[3 * ind[0] + feat], rmin = xyz[3 * ind[idx] + feat];
+    for (int i = 1; i < idx; i++) {
+      const int v = xyz[3 * ind[i] + feat];
+      lmax = v > lmax ? v : lmax;
+    }
+    for (int i = idx + 1; i < count; i++) {
+      const int v = xyz[3 * ind[i] + feat];
+      rmin = v < rmin ? v : rmin;
+    }
+    nd->divlow = (double)lmax;
+    nd->divhigh = (double)rmin;
   }
-  g->start = (int32_t*)calloc(cells + 1, sizeof(int32_t));
-  g->items = (int32_t*)malloc(sizeof(int32_t) * (size_t)n);
-  if (!g->start || !g->items)
-    return -1;
-#define CELL(i)                                                                      \
-  ((((size_t)((xyz[3 * (i)] >> shift) - g->lo[0])) * g->dim[1]                      \
-    + (size_t)((xyz[3 * (i) + 1] >> shift) - g->lo[1]))                             \
-     * g->dim[2]                                                                     \
-   + (size_t)((xyz[3 * (i) + 2] >> shift) - g->lo[2]))
-  for (int i = 0; i < n; i++)
-    g->start[CELL(i) + 1]++;
-  for (size_t c = 0; c < cells; c++)
-    g->start[c + 1] += g->start[c];
-  int32_t* cur = (int32_t*)malloc(sizeof(int32_t) * cells);
-  if (!cur)
-    return -1;
-  memcpy(cur, g->start, sizeof(int32_t) * cells);
-  for (int i = 0; i < n; i++)
-    g->items[cur[CELL(i)]++] = i;
-#undef CELL
-  free(cur);
+  free(flag);
+  free(tmp);
   return 0;
 }
 
 static void
-grid_free(Grid* g)
+kd_free(KdTree* kt)
 {
-  free(g->start);
-  free(g->items);
+  free(kt->vind);
+  free(kt->nodes);
 }
 
-/* candidate (d2, idx) into the ascending list of at most k entries; ties by index */
+/* KNNResultSet::addPoint (:175-199): behind every entry that is not farther */
 static void
-knn_insert(double* d2, int32_t* idx, int* count, int k, double d, int32_t i)
+knn_add(double* d2, int32_t* idx, int* count, int k, double d, int32_t i)
 {
   int pos = *count;
-  if (pos == k) {
-    if (d > d2[k - 1] || (d == d2[k - 1] && i > idx[k - 1]))
-      return;
-    pos = k - 1;
-  } else {
-    (*count)++;
-  }
-  while (pos > 0 && (d2[pos - 1] > d || (d2[pos - 1] == d && idx[pos - 1] > i))) {
-    d2[pos] = d2[pos - 1];
-    idx[pos] = idx[pos - 1];
+  while (pos > 0 && d2[pos - 1] > d) {
+    if (pos < k) {
+      d2[pos] = d2[pos - 1];
+      idx[pos] = idx[pos - 1];
+    }
     pos--;
   }
-  d2[pos] = d;
-  idx[pos] = i;
+  if (pos < k) {
+    d2[pos] = d;
+    idx[pos] = i;
+  }
+  if (*count < k)
+    (*count)++;
 }
 
-/* the k nearest points of g to q: ring after ring of cells around q's cell until
- * the k-th distance is not larger than what any unvisited cell can offer */
+/* findNeighbors (:1200-1215) + searchLevel (:1308-1365) with the recursion as a stack:
+ * phase 0 = the node is entered, 1 = the nearer child has returned, 2 = the other one has */
 static int
-knn(const Grid* g, const double q[3], int k, double* d2, int32_t* idx)
+kd_search(const KdTree* kt, const double q[3], int k, double* d2, int32_t* idx)
 {
-  const int cs = 1 << g->shift;
-  int cq[3];
-  for (int a = 0; a < 3; a++)
-    cq[a] = (int)floor(q[a] / cs) - g->lo[a];
-  int count = 0;
-  /* no point can be nearer than the distance of q to the grid's box */
-  int maxr = 0;
+  struct {
+    int32_t node, phase;
+    double mind, dst;
+  } st[KD_MAX_DEPTH];
+  double dists[3] = {0.0, 0.0, 0.0};
+  double distsq = 0.0;
   for (int a = 0; a < 3; a++) {
-    int far = cq[a] > g->dim[a] - 1 - cq[a] ? cq[a] : g->dim[a] - 1 - cq[a];
-    if (far < 0)
-      far = -far;
-    if (far > maxr)
-      maxr = far;
-  }
-  for (int r = 0; r <= maxr; r++) {
-    for (int dx = -r; dx <= r; dx++) {
-      const int cx = cq[0] + dx;
-      if (cx < 0 || cx >= g->dim[0])
-        continue;
-      for (int dy = -r; dy <= r; dy++) {
-        const int cy = cq[1] + dy;
-        if (cy < 0 || cy >= g->dim[1])
-          continue;
-        const int shell = (dx == -r || dx == r || dy == -r || dy == r);
-        for (int dz = -r; dz <= r; dz += (shell || r == 0) ? 1 : 2 * r) {
-          const int cz = cq[2] + dz;
-          if (cz < 0 || cz >= g->dim[2])
-            continue;
-          const size_t c = ((size_t)cx * g->dim[1] + (size_t)cy) * g->dim[2] + (size_t)cz;
-          for (int32_t e = g->start[c]; e < g->start[c + 1]; e++) {
-            const int32_t i = g->items[e];
-            /* nanoflann L2_Simple_Adaptor: result += diff * diff, x then y then z */
-            double s = 0.0;
-            for (int a = 0; a < 3; a++) {
-              const double diff = q[a] - (double)g->xyz[3 * i + a];
-              s += diff * diff;
-            }
-            knn_insert(d2, idx, &count, k, s, i);
-          }
-        }
-      }
+    if (q[a] < kt->root_lo[a]) {
+      dists[a] = (q[a] - kt->root_lo[a]) * (q[a] - kt->root_lo[a]);
+      distsq += dists[a];
     }
-    /* a point of ring r + 1 or beyond differs by more than r * cs in some axis */
-    const double bound = (double)r * cs;
-    if (count == k && d2[k - 1] <= bound * bound)
-      break;
+    if (q[a] > kt->root_hi[a]) {
+      dists[a] = (q[a] - kt->root_hi[a]) * (q[a] - kt->root_hi[a]);
+      distsq += dists[a];
+    }
+  }
+  int count = 0;
+  d2[k - 1] = 1.7976931348623157e308;  /* KNNResultSet::init */
+  int sp = 0;
+  st[0].node = 0;
+  st[0].phase = 0;
+  st[0].mind = distsq;
+  st[0].dst = 0.0;
+  while (sp >= 0) {
+    const KdNode* nd = &kt->nodes[st[sp].node];
+    if (nd->child1 < 0) {
+      const double worst = d2[k - 1];
+      for (int e = nd->left; e < nd->right; e++) {
+        const int32_t i = kt->vind[e];
+        double s = 0.0;
+        for (int a = 0; a < 3; a++) {
+          const double diff = q[a] - (double)kt->xyz[3 * i + a];
+          s += diff * diff;
+        }
+        if (s < worst)
+          knn_add(d2, idx, &count, k, s, i);
+      }
+      sp--;
+      continue;
+    }
+    const int f = nd->feat;
+    const double val = q[f];
+    const double diff1 = val - nd->divlow, diff2 = val - nd->divhigh;
+    const int first_is_1 = (diff1 + diff2) < 0;
+    if (st[sp].phase == 0) {
+      st[sp].phase = 1;
+      if (sp + 1 >= KD_MAX_DEPTH)
+        return -1;
+      st[sp + 1].node = first_is_1 ? nd->child1 : nd->child2;
+      st[sp + 1].phase = 0;
+      st[sp + 1].mind = st[sp].mind;
+      sp++;
+    } else if (st[sp].phase == 1) {
+      const double cut_dist = first_is_1 ? (val - nd->divhigh) * (val - nd->divhigh)
+                                         : (val - nd->divlow) * (val - nd->divlow);
+      const double dst = dists[f];
+      const double mind = st[sp].mind + cut_dist - dst;
+      dists[f] = cut_dist;
+      st[sp].dst = dst;
+      st[sp].phase = 2;
+      if (mind <= d2[k - 1]) {
+        st[sp + 1].node = first_is_1 ? nd->child2 : nd->child1;
+        st[sp + 1].phase = 0;
+        st[sp + 1].mind = mind;
+        sp++;
+      }
+    } else {
+      dists[f] = st[sp].dst;
+      sp--;
+    }
   }
   return count;
 }
 
-static double
-clipd(double v, double lo, double hi)
-{
-  return v < lo ? lo : (v > hi ? hi : v);
-}
-
+/* ---- std::sort(first, last, by distance) as libstdc++ 11 does it (bits/stl_algo.h:
+ *      __introsort_loop, __unguarded_partition_pivot, __final_insertion_sort; bits/stl_heap.h) */
 typedef struct {
   double dist;
   int32_t src;
 } BwdEntry;
 
-static int
-bwd_cmp(const void* a, const void* b)
+#define LESS(a, b) ((a).dist < (b).dist)
+static void
+ss_swap(BwdEntry* a, BwdEntry* b)
 {
-  const BwdEntry* x = (const BwdEntry*)a;
-  const BwdEntry* y = (const BwdEntry*)b;
-  if (x->dist != y->dist)
-    return x->dist < y->dist ? -1 : 1;
-  return x->src < y->src ? -1 : (x->src > y->src ? 1 : 0);
+  const BwdEntry t = *a;
+  *a = *b;
+  *b = t;
+}
+
+static void
+ss_adjust_heap(BwdEntry* first, int hole, int len, BwdEntry value)
+{
+  const int top = hole;
+  int child = hole;
+  while (child < (len - 1) / 2) {
+    child = 2 * (child + 1);
+    if (LESS(first[child], first[child - 1]))
+      child--;
+    first[hole] = first[child];
+    hole = child;
+  }
+  if ((len & 1) == 0 && child == (len - 2) / 2) {
+    child = 2 * (child + 1);
+    first[hole] = first[child - 1];
+    hole = child - 1;
+  }
+  int parent = (hole - 1) / 2;
+  while (hole > top && LESS(first[parent], value)) {
+    first[hole] = first[parent];
+    hole = parent;
+    parent = (hole - 1) / 2;
+  }
+  first[hole] = value;
+}
+
+int oracle_std_sort_heap_calls = 0;  /* (test support: the depth-limit path was exercised) */
+
+static void
+ss_heap_sort(BwdEntry* first, int len)
+{
+  oracle_std_sort_heap_calls++;
+  if (len >= 2)
+    for (int parent = (len - 2) / 2;; parent--) {
+      ss_adjust_heap(first, parent, len, first[parent]);
+      if (parent == 0)
+        break;
+    }
+  for (int last = len - 1; last >= 1; last--) {
+    const BwdEntry value = first[last];
+    first[last] = first[0];
+    ss_adjust_heap(first, 0, last, value);
+  }
+}
+
+static void
+ss_insertion(BwdEntry* a, int from, int n, int guarded)
+{
+  for (int i = from; i < n; i++) {
+    const BwdEntry v = a[i];
+    if (guarded && LESS(v, a[0])) {
+      for (int j = i; j > 0; j--)
+        a[j] = a[j - 1];
+      a[0] = v;
+    } else {
+      int j = i;
+      while (LESS(v, a[j - 1])) {
+        a[j] = a[j - 1];
+        j--;
+      }
+      a[j] = v;
+    }
+  }
+}
+
+void
+oracle_std_sort_by_dist(BwdEntry* a, int n)
+{
+  if (n < 2)
+    return;
+  int depth = 0;
+  for (int m = n; m > 1; m >>= 1)
+    depth++;
+  depth *= 2;
+  /* the recursion on [cut, last) as a stack of (first, last, depth) */
+  struct {
+    int first, last, depth;
+  } st[64];
+  int sp = 0;
+  st[0].first = 0;
+  st[0].last = n;
+  st[0].depth = depth;
+  while (sp >= 0) {
+    int first = st[sp].first, last = st[sp].last, dl = st[sp].depth;
+    sp--;
+    while (last - first > 16) {
+      if (dl == 0) {
+        ss_heap_sort(a + first, last - first);
+        break;
+      }
+      dl--;
+      BwdEntry *r = a + first, *x = a + first + 1, *y = a + first + (last - first) / 2, *z = a + last - 1;
+      if (LESS(*x, *y)) {
+        if (LESS(*y, *z))
+          ss_swap(r, y);
+        else if (LESS(*x, *z))
+          ss_swap(r, z);
+        else
+          ss_swap(r, x);
+      } else if (LESS(*x, *z))
+        ss_swap(r, x);
+      else if (LESS(*y, *z))
+        ss_swap(r, z);
+      else
+        ss_swap(r, y);
+      int i = first + 1, j = last;
+      for (;;) {
+        while (LESS(a[i], a[first]))
+          i++;
+        j--;
+        while (LESS(a[first], a[j]))
+          j--;
+        if (!(i < j))
+          break;
+        ss_swap(a + i, a + j);
+        i++;
+      }
+      /* the right part is sorted by the recursive call FIRST; the order of the two parts does
+       * not matter (disjoint ranges), so it simply goes on the stack */
+      sp++;
+      st[sp].first = i;
+      st[sp].last = last;
+      st[sp].depth = dl;
+      last = i;
+    }
+  }
+  if (n > 16) {
+    ss_insertion(a, 1, 16, 1);
+    ss_insertion(a, 16, n, 0);
+  } else {
+    ss_insertion(a, 1, n, 1);
+  }
+}
+#undef LESS
+
+static double
+clipd(double v, double lo, double hi)
+{
+  return v < lo ? lo : (v > hi ? hi : v);
 }
 
 int
@@ -214,8 +479,8 @@ oracle_recolour(
   const double max_a_f = p->max_attribute_dist2_fwd < 512 ? p->max_attribute_dist2_fwd : big;
   const double max_a_b = p->max_attribute_dist2_bwd < 512 ? p->max_attribute_dist2_bwd : big;
 
-  Grid gs, gt;
-  if (grid_build(&gs, src_xyz, ns) || grid_build(&gt, tgt_xyz, nt))
+  KdTree gs, gt;
+  if (kd_build(&gs, src_xyz, ns) || kd_build(&gt, tgt_xyz, nt))
     return -4;
   int32_t* ref1 = (int32_t*)malloc(sizeof(int32_t) * (size_t)nt * c);
   int32_t* cnt = (int32_t*)calloc((size_t)nt + 1, sizeof(int32_t));
@@ -229,7 +494,9 @@ oracle_recolour(
       q[a] = (double)(tgt_xyz[3 * t + a] + offset[a]) * t2s;
     double d2[RC_MAXK];
     int32_t idx[RC_MAXK];
-    const int n = knn(&gs, q, kf, d2, idx);
+    const int n = kd_search(&gs, q, kf, d2, idx);
+    if (n < 0)
+      return -5;
     int32_t* out = ref1 + (size_t)t * c;
     if (p->skip_avg_if_identical_fwd && d2[0] < 0.0001) {
       for (int k = 0; k < c; k++)
@@ -293,7 +560,9 @@ oracle_recolour(
       q[a] = (double)src_xyz[3 * s + a] * s2t - (double)offset[a];
     double d2[RC_MAXK];
     int32_t idx[RC_MAXK];
-    const int n = knn(&gt, q, kb, d2, idx);
+    const int n = kd_search(&gt, q, kb, d2, idx);
+    if (n < 0)
+      return -5;
     for (int i = 0; i < kb; i++) {
       const int ok = i < n && d2[i] <= max_g_b;
       bt[(size_t)s * kb + i] = ok ? idx[i] : -1;
@@ -331,7 +600,8 @@ oracle_recolour(
         out[k] = c1[k];
       continue;
     }
-    qsort(l, (size_t)n, sizeof(BwdEntry), bwd_cmp);
+    /* filled in source order (the loop above), then std::sort by distance (:416-422) */
+    oracle_std_sort_by_dist(l, n);
     double cen2[3] = {0.0, 0.0, 0.0};
     int done = 0;
     if (p->skip_avg_if_identical_bwd && l[0].dist < 0.0001) {
@@ -429,93 +699,24 @@ oracle_recolour(
   free(bt);
   free(cnt);
   free(ref1);
-  grid_free(&gs);
-  grid_free(&gt);
+  kd_free(&gs);
+  kd_free(&gt);
   return 0;
 }
 
-/* Where a TIE decides (the only places the reference may differ from this file):
- * flags[t] |= 1  the forward search of target t has equidistant candidates at the
- *                K-th place;
- *          |= 2  a source point has equidistant targets at the last place of its
- *                backward search and t is one of them;
- *          |= 4  the backward list of t holds equal distances (summation / truncation
- *                order).  Test support only. */
-int
-oracle_recolour_ties(
-  const gpcc_recolour_params* p, const int32_t* src_xyz, int32_t ns, const int32_t* tgt_xyz,
-  int32_t nt, float scale_f, const int32_t offset[3], uint8_t* flags)
+/* the restated sort on separate arrays (test support: compared with std::sort itself) */
+void
+oracle_std_sort_pairs(double* dist, int32_t* src, int32_t n)
 {
-  const int kf = p->num_neighbours_fwd, kb = p->num_neighbours_bwd;
-  if (kf < 1 || kf > RC_MAXK || kb < 1 || kb > RC_MAXK)
-    return -2;
-  const double s2t = (double)scale_f;
-  const double t2s = 1.0 / s2t;
-  Grid gs, gt;
-  if (grid_build(&gs, src_xyz, ns) || grid_build(&gt, tgt_xyz, nt))
-    return -4;
-  memset(flags, 0, (size_t)nt);
-  enum { TIEK = 24 };
-  double d2[TIEK];
-  int32_t idx[TIEK];
-  for (int t = 0; t < nt; t++) {
-    double q[3];
-    for (int a = 0; a < 3; a++)
-      q[a] = (double)(tgt_xyz[3 * t + a] + offset[a]) * t2s;
-    if (ns > kf) {
-      const int n = knn(&gs, q, kf + 1, d2, idx);
-      if (n == kf + 1 && d2[kf] == d2[kf - 1])
-        flags[t] |= 1;
-      /* equal distances inside the set: the order of the weighted sum */
-      for (int i = 0; i + 1 < kf; i++)
-        if (d2[i] == d2[i + 1])
-          flags[t] |= 8;
-    }
+  BwdEntry* a = (BwdEntry*)malloc(sizeof(BwdEntry) * (size_t)(n > 0 ? n : 1));
+  for (int i = 0; i < n; i++) {
+    a[i].dist = dist[i];
+    a[i].src = src[i];
   }
-  int32_t* et = (int32_t*)malloc(sizeof(int32_t) * ((size_t)ns * kb + 1));
-  double* ed = (double*)malloc(sizeof(double) * ((size_t)ns * kb + 1));
-  size_t ne = 0;
-  for (int s = 0; s < ns; s++) {
-    double q[3];
-    for (int a = 0; a < 3; a++)
-      q[a] = (double)src_xyz[3 * s + a] * s2t - (double)offset[a];
-    /* (a source point between lattice positions has up to 8 equidistant targets) */
-    const int want = nt > TIEK ? TIEK : nt;
-    const int n = knn(&gt, q, want, d2, idx);
-    if (n > kb && d2[kb] == d2[kb - 1])
-      for (int i = 0; i < n; i++)
-        if (d2[i] == d2[kb - 1])
-          flags[idx[i]] |= 2;
-    for (int i = 0; i < kb && i < n; i++) {
-      et[ne] = idx[i];
-      ed[ne] = d2[i];
-      ne++;
-    }
+  oracle_std_sort_by_dist(a, n);
+  for (int i = 0; i < n; i++) {
+    dist[i] = a[i].dist;
+    src[i] = a[i].src;
   }
-  /* equal distances inside a target's list: bucket the entries by target */
-  {
-    int32_t* cnt = (int32_t*)calloc((size_t)nt + 1, sizeof(int32_t));
-    for (size_t i = 0; i < ne; i++)
-      cnt[et[i] + 1]++;
-    for (int t = 0; t < nt; t++)
-      cnt[t + 1] += cnt[t];
-    double* by = (double*)malloc(sizeof(double) * (ne + 1));
-    int32_t* cur = (int32_t*)malloc(sizeof(int32_t) * ((size_t)nt + 1));
-    memcpy(cur, cnt, sizeof(int32_t) * (size_t)nt);
-    for (size_t i = 0; i < ne; i++)
-      by[cur[et[i]]++] = ed[i];
-    for (int t = 0; t < nt; t++)
-      for (int i = cnt[t]; i < cnt[t + 1]; i++)
-        for (int j = i + 1; j < cnt[t + 1]; j++)
-          if (by[i] == by[j])
-            flags[t] |= 4;
-    free(cur);
-    free(by);
-    free(cnt);
-  }
-  free(ed);
-  free(et);
-  grid_free(&gs);
-  grid_free(&gt);
-  return 0;
+  free(a);
 }

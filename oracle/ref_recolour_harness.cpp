@@ -72,3 +72,26 @@ ref_recolour(
   }
   return 0;
 }
+
+// The sort pcc::recolour applies to its backward lists (pointset_processing.cpp:416-422:
+// std::sort with a comparator on the distance alone) on a caller's (distance, source) pairs --
+// what the restated sort of oracle/recolour_oracle.c is compared with.
+#include <algorithm>
+#include <vector>
+
+extern "C" void
+ref_std_sort_by_dist(double* dist, int32_t* src, int32_t n)
+{
+  struct DistSrc {
+    double dist;
+    int32_t src;
+  };
+  std::vector<DistSrc> v(n);
+  for (int i = 0; i < n; i++)
+    v[i] = DistSrc{dist[i], src[i]};
+  std::sort(v.begin(), v.end(), [](const DistSrc& a, const DistSrc& b) { return a.dist < b.dist; });
+  for (int i = 0; i < n; i++) {
+    dist[i] = v[i].dist;
+    src[i] = v[i].src;
+  }
+}

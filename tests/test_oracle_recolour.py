@@ -1,9 +1,8 @@
 """CPU tier: the recolour restatement (oracle/recolour_oracle.c) against the compiled
-reference's own pcc::recolour (oracle/_ref, when present).  The restatement orders
-equidistant candidates by point index where the reference's outcome depends on its
-k-d tree / std::sort internals; it must be IDENTICAL wherever no tie decides -- the
-oracle marks those places itself (oracle_recolour_ties) -- and on tie-free geometry
-everywhere."""
+reference's own pcc::recolour (oracle/_ref, when present).  The restatement rebuilds the
+reference's containers -- nanoflann's k-d tree and search order, libstdc++'s std::sort --
+so it must be IDENTICAL everywhere, on dyadic scales (the CTC's positionQuantizationScale
+values: most candidates are equidistant there) as on generic ones."""
 import ctypes as C
 
 import numpy as np
@@ -12,23 +11,12 @@ import pytest
 import oracle_loader as ol
 from mpeg_pcc_tmc13_amd import recolour_params, synth
 
-_i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
-_u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
 pytestmark = pytest.mark.skipif(not ol.ref_available(), reason="compiled reference (oracle/_ref) not present")
 
 
 def requantise(xyz, scale):
     """the coded geometry of a lossy-geometry encode: positions scaled, rounded, unique"""
     return np.unique(np.rint(xyz.astype(np.float64) * scale).astype(np.int32), axis=0)
-
-
-def tie_flags(p, xyz, tgt, scale):
-    f = ol.oracle().fn("recolour_ties", C.c_int, [C.c_void_p, _i32p, C.c_int32, _i32p, C.c_int32, C.c_float, _i32p, _u8p])
-    fl = np.zeros(len(tgt), dtype=np.uint8)
-    assert f(C.addressof(p), np.ascontiguousarray(xyz, dtype=np.int32).reshape(-1), len(xyz),
-             np.ascontiguousarray(tgt, dtype=np.int32).reshape(-1), len(tgt), scale,
-             np.zeros(3, dtype=np.int32), fl) == 0
-    return fl
 
 
 def cloud(kind, n, seed):
@@ -45,35 +33,28 @@ VARIANTS = [dict(), dict(max_attr_fwd=200.0), dict(max_attr_bwd=300.0), dict(ski
 @pytest.mark.parametrize("kind", ["dense", "lidar"])
 @pytest.mark.parametrize("vi", range(len(VARIANTS)))
 def test_identical_on_generic_scales(kind, vi):
-    """a scale factor that is not a power of two leaves (next to) no equidistant
-    candidates: the restatement equals the reference outside the flagged points"""
+    """a scale factor that is not a power of two: few equidistant candidates"""
     xyz, a = cloud(kind, 20000, 3 + vi)
     scale = 0.37 if kind == "dense" else 0.013
     tgt = requantise(xyz, scale)
     p = recolour_params(bitdepth=8, **VARIANTS[vi])
     ref = ol.ref().recolour(p, xyz, a, tgt, scale=scale)
     ora = ol.oracle().recolour(p, xyz, a, tgt, scale=scale)
-    bad = np.any(ref != ora, axis=1)
-    assert not np.any(bad & (tie_flags(p, xyz, tgt, scale) == 0))
-    assert bad.mean() < 0.002
+    assert np.array_equal(ref, ora)
 
 
 @pytest.mark.parametrize("kind,scale,kw", [("dense", 0.5, {}), ("dense", 0.25, dict(k_bwd=2)), ("lidar", 0.25, {}),
                                            ("dense", 0.5, dict(max_attr_bwd=300.0, max_attr_fwd=200.0, skip_bwd=True)),
                                            ("dense", 1.0, {})])
-def test_differences_are_confined_to_ties(kind, scale, kw):
-    """dyadic scales (the CTC's positionQuantizationScale values) put many candidates
-    at equal distances: every difference from the reference sits on a flagged point"""
+def test_identical_on_dyadic_scales(kind, scale, kw):
+    """dyadic scales put many candidates at equal distances: the order the reference's
+    k-d tree visits them in, and std::sort's order of equal keys, decide"""
     xyz, a = cloud(kind, 20000, 3)
     tgt = requantise(xyz, scale)
     p = recolour_params(bitdepth=8, **kw)
     ref = ol.ref().recolour(p, xyz, a, tgt, scale=scale)
     ora = ol.oracle().recolour(p, xyz, a, tgt, scale=scale)
-    bad = np.any(ref != ora, axis=1)
-    fl = tie_flags(p, xyz, tgt, scale)
-    assert not np.any(bad & (fl == 0))
-    # and a tie moves a value by no more than the spread of the tied neighbours
-    assert np.abs(ref - ora).max() <= 24
+    assert np.array_equal(ref, ora)
 
 
 def test_offset_and_bitdepth():
@@ -83,4 +64,83 @@ def test_offset_and_bitdepth():
     p = recolour_params(bitdepth=10)
     ref = ol.ref().recolour(p, xyz, a, tgt, scale=scale, offset=off)
     ora = ol.oracle().recolour(p, xyz, a, tgt, scale=scale, offset=off)
-    assert (np.any(ref != ora, axis=1)).mean() < 0.002
+    assert np.array_equal(ref, ora)
+
+
+def _sort_pairs(lib, name, dist, src):
+    f = getattr(lib, name)
+    f.restype = None
+    f.argtypes = [np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS"),
+                  np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS"), C.c_int32]
+    d, s = dist.copy(), src.copy()
+    f(d, s, len(d))
+    return d, s
+
+
+def _organ_pipe(n):
+    """keys that drive a median-of-three quicksort to its depth limit (heap sort takes over)"""
+    half = n // 2
+    return np.concatenate([np.arange(half), np.arange(n - half)[::-1]]).astype(np.float64)
+
+
+def test_restated_sort_is_std_sort():
+    """std::sort leaves equal keys in an order that depends on its algorithm (introsort,
+    median-of-three pivot, heap sort at the depth limit, insertion sort up to 16 entries): the
+    restatement follows it exactly -- random keys with many ties, runs, organ pipes, all sizes
+    around the thresholds"""
+    rng = np.random.default_rng(11)
+    cases = []
+    for n in list(range(0, 40)) + [63, 64, 65, 100, 257, 1000, 4099, 20000]:
+        for levels in (1, 2, 3, 5, 17, 1 << 20):
+            cases.append(rng.integers(0, levels, n).astype(np.float64))
+        cases.append(np.arange(n, dtype=np.float64))
+        cases.append(np.arange(n, dtype=np.float64)[::-1].copy())
+        cases.append(_organ_pipe(n))
+        cases.append(np.floor(_organ_pipe(n) / 3))
+    # median-of-three killer sequences
+    for n in (64, 500, 3000):
+        k = n // 2
+        a = np.zeros(n)
+        for i in range(1, k + 1):
+            if i % 2:
+                a[i - 1] = i
+                a[i] = k + i
+            a[k + i - 1] = 2 * i
+        cases.append(a)
+        cases.append(np.floor(a / 4))
+    for keys in cases:
+        src = np.arange(len(keys), dtype=np.int32)
+        rd, rs = _sort_pairs(ol.ref().lib, "ref_std_sort_by_dist", keys, src)
+        od, os_ = _sort_pairs(ol.oracle().lib, "oracle_std_sort_pairs", keys, src)
+        assert np.array_equal(rd, od) and np.array_equal(rs, os_), len(keys)
+    assert C.c_int.in_dll(ol.oracle().lib, "oracle_std_sort_heap_calls").value > 0
+
+
+@pytest.mark.parametrize("kind,n,scale,kw", [
+    ("dense", 60000, 0.125, {}),                      # backward lists of 60+ entries: std::sort's partition path
+    ("dense", 60000, 0.125, dict(k_bwd=4, max_attr_bwd=400.0)),
+    ("dense", 200000, 0.5, {}),
+    ("lidar", 150000, 0.5, dict(k_fwd=8, k_bwd=2)),
+    ("lidar", 150000, 0.03125, {}),
+    ("dense", 50000, 0.75, {}), ("dense", 50000, 0.9375, dict(k_bwd=3)),
+    ("dense", 50000, 2.0, {}),                         # a finer target grid
+])
+def test_identical_at_size(kind, n, scale, kw):
+    xyz, a = cloud(kind, n, 21)
+    tgt = requantise(xyz, scale)
+    p = recolour_params(bitdepth=8, **kw)
+    assert np.array_equal(ol.ref().recolour(p, xyz, a, tgt, scale=scale),
+                          ol.oracle().recolour(p, xyz, a, tgt, scale=scale))
+
+
+def test_duplicate_source_positions():
+    """points at identical positions: the split planes fall back to the middle index
+    (nanoflann.hpp:958-960) and every neighbour comes with equidistant twins"""
+    xyz, a = synth.dense_cloud(20000, seed=5, bits=7)
+    xyz = np.concatenate([xyz, xyz[::3], xyz[::7]])
+    a = np.concatenate([a, (a[::3] + 9) % 256, (a[::7] + 31) % 256]).astype(a.dtype)
+    for scale in (1.0, 0.5):
+        tgt = requantise(xyz, scale)
+        p = recolour_params(bitdepth=8)
+        assert np.array_equal(ol.ref().recolour(p, xyz, a, tgt, scale=scale),
+                              ol.oracle().recolour(p, xyz, a, tgt, scale=scale))
