@@ -956,15 +956,17 @@ dev_transform(
   {
     static const bool pipe_on = [] {
       const char* e = getenv("GPCC_PIPE");
-      return !(e && e[0] == '0');
+      return e && e[0] == '1';
     }();
-    // The cross-level walk covers the decoder without region QPs (what the
-    // reference's CTC configurations decode), one slice per call: it shortens
-    // the critical path of ONE dependency DAG (4.2 against 5.0 ms for the 1 M
-    // lidar frame) but every round pays two more polling stages, and a batch is
+    // The cross-level walk (opt-in since round 4: GPCC_PIPE=1) covers the decoder
+    // without region QPs, one slice per call: it shortens the critical path of ONE
+    // dependency DAG, but every round pays two more polling stages, and a batch is
     // bound by the rounds' wave time, not by a chain -- there the level-by-level
     // kernels interleave the slices' chains (2 / 3 / 5 / 10 frames: 6.0 / 7.2 /
-    // 9.5 / 15.1 ms against 8.1 / 11.4 / 18.7 / 36.6).
+    // 9.5 / 15.1 ms against 8.1 / 11.4 / 18.7 / 36.6).  Round 2 measured it ahead for
+    // the single 1 M lidar frame (4.2 against 5.0 ms); with the level kernels in
+    // doubles and their lean loop (round 4) it is behind: 4.80 against 4.28 ms
+    // (kernel + prepass), headline 12.41 -> 11.77 ms.
     pl.pipe = pipe_on && !encoder && pl.sub && !pl.has_qp && s == 1;
   }
   pl.num_rtiles = 0;
@@ -1455,7 +1457,7 @@ pred_scratch_bytes(int n, int n_frame = 0)
   ar.take<int32_t>((size_t)n + 1);
   ar.take<uint8_t>((size_t)n + 1);
   ar.take<int32_t>((size_t)n + 1);
-  ar.take<long long>((size_t)n / kRcScanBlock + 2);
+  ar.take<long long>((size_t)n / kKdScanBlock + 2);
   ar.take<int32_t>((size_t)n_frame + 1);
   return ar.used;
 }
@@ -1560,7 +1562,7 @@ launch_pred(
   int32_t* ev_rank = ar.take<int32_t>((size_t)n + 1);
   uint8_t* ev_up = ar.take<uint8_t>((size_t)n + 1);
   int32_t* ev_state = ar.take<int32_t>((size_t)n + 1);
-  long long* scan_sums = ar.take<long long>((size_t)n / kRcScanBlock + 2);
+  long long* scan_sums = ar.take<long long>((size_t)n / kKdScanBlock + 2);
   int32_t* d_frame = ar.take<int32_t>((size_t)n_frame + 1);
   if (n_frame > 0) {
     HIP_TRY(h2d_user(ctx, d_frame, h_frame, sizeof(int32_t) * (size_t)n_frame, st));
@@ -4607,52 +4609,54 @@ namespace {
 int
 rc_scan(gpcc_ctx* ctx, int32_t* a, size_t n, long long* sums)
 {
-  hipStream_t st = ctx->stream;
-  const int nblk = (int)((n + kRcScanBlock - 1) / kRcScanBlock);
-  rc_scan_sums_kernel<<<nblk, 256, 0, st>>>(a, n, sums);
-  rc_scan_blocks_kernel<<<1, 1024, 0, st>>>(sums, nblk);
-  rc_scan_apply_kernel<<<nblk, 256, 0, st>>>(a, n, sums);
-  HIP_TRY(hipGetLastError());
+  HIP_TRY(kd_scan(ctx->stream, a, n, sums));
   return GPCC_OK;
 }
 
-// Cell side of a cloud's table.  It starts at the smallest side for which the table has
-// at most 32 cells per point; a sparse cloud -- a lidar sweep fills a sliver of its bounding
-// box: with 4 cells per point its cells were 2 048 voxels wide and held thousands of points
-// each -- is refined while an occupied cell holds more than 24 points on average (up to
-// 1 024 cells per point / 2^28 cells).  A dense surface stays: finer cells make it visit
-// a second ring of 98 cells for its eight neighbours (measured: 8.5 -> 13.7 ms forward).
-double
-rc_cells_at(const int32_t box[6], int shift)
-{
-  double cells = 1;
-  for (int k = 0; k < 3; k++)
-    cells *= (double)((box[3 + k] >> shift) - (box[k] >> shift) + 1);
-  return cells;
-}
+// the working set of one tree's build, from the context's pool (recolour_kdtree.hpp)
+struct KdAlloc {
+  KdBuild b{};
+  std::vector<void*> blocks;
+};
 
-// smallest shift whose table has at most per_point cells per point (and 2^28 cells)
 int
-rc_shift_for(const int32_t box[6], int n, double per_point)
+kd_alloc(gpcc_ctx* ctx, KdAlloc* ka, const int32_t* d_xyz, int n)
 {
-  int shift = 0;
-  while (!(rc_cells_at(box, shift) <= per_point * n + 64 && rc_cells_at(box, shift) <= (double)(1 << 28)))
-    shift++;
-  return shift;
+  const size_t N = (size_t)n, M = 2 * N + 2;
+  auto take = [&](void** p, size_t bytes) -> hipError_t {
+    hipError_t e = pool_malloc(ctx, p, bytes);
+    if (e == hipSuccess)
+      ka->blocks.push_back(*p);
+    return e;
+  };
+  KdBuild& b = ka->b;
+  b.t.xyz = d_xyz;
+  b.t.n = n;
+  HIP_TRY(take((void**)&b.t.vind, sizeof(int32_t) * N));
+  HIP_TRY(take((void**)&b.t.nodes, sizeof(KdNode) * M));
+  HIP_TRY(take((void**)&b.pnode, sizeof(int32_t) * N));
+  HIP_TRY(take((void**)&b.rng, sizeof(int32_t) * 2 * M));
+  HIP_TRY(take((void**)&b.parent, sizeof(int32_t) * M));
+  HIP_TRY(take((void**)&b.box, sizeof(double) * 6 * M));
+  HIP_TRY(take((void**)&b.mm, sizeof(int32_t) * 6 * M));
+  HIP_TRY(take((void**)&b.cut, sizeof(double) * M));
+  HIP_TRY(take((void**)&b.lim, sizeof(int32_t) * 2 * M));
+  HIP_TRY(take((void**)&b.split, sizeof(int32_t) * M));
+  HIP_TRY(take((void**)&b.flag, sizeof(int32_t) * (N + 1)));
+  HIP_TRY(take((void**)&b.tmp_l, sizeof(int32_t) * N));
+  HIP_TRY(take((void**)&b.tmp_r, sizeof(int32_t) * N));
+  HIP_TRY(take((void**)&b.sums, sizeof(long long) * ((N + 1) / kKdScanBlock + 2)));
+  HIP_TRY(take((void**)&b.counters, sizeof(int32_t) * 4));
+  return GPCC_OK;
 }
 
 void
-rc_plan_grid(const int32_t box[6], int n, int shift, RcGrid* g, size_t* cells_out)
+kd_release(gpcc_ctx* ctx, KdAlloc* ka, bool keep_tree)
 {
-  g->shift = shift;
-  g->n = n;
-  size_t cells = 1;
-  for (int k = 0; k < 3; k++) {
-    g->lo[k] = box[k] >> shift;
-    g->dim[k] = (box[3 + k] >> shift) - g->lo[k] + 1;
-    cells *= (size_t)g->dim[k];
-  }
-  *cells_out = cells;
+  for (void* q : ka->blocks)
+    if (!(keep_tree && (q == (void*)ka->b.t.vind || q == (void*)ka->b.t.nodes)))
+      pool_free(ctx, q);
+  ka->blocks.clear();
 }
 
 int
@@ -4683,16 +4687,17 @@ recolour_impl(
   hipStream_t st = ctx->stream;
 
   int32_t *d_sx = nullptr, *d_sa = nullptr, *d_tx = nullptr, *d_out = nullptr, *d_box = nullptr;
-  int32_t *d_sstart = nullptr, *d_sitems = nullptr, *d_tstart = nullptr, *d_titems = nullptr, *d_cur = nullptr;
   int32_t *d_ref1 = nullptr, *d_bt = nullptr, *d_lstart = nullptr, *d_lcur = nullptr, *d_lsrc = nullptr;
   double *d_bd = nullptr, *d_ldist = nullptr;
   long long* d_sums = nullptr;
+  KdAlloc ks, kt;
   auto cleanup = [&]() {
-    for (void* q : {(void*)d_sx, (void*)d_sa, (void*)d_tx, (void*)d_out, (void*)d_box, (void*)d_sstart,
-                    (void*)d_sitems, (void*)d_tstart, (void*)d_titems, (void*)d_cur, (void*)d_ref1,
+    for (void* q : {(void*)d_sx, (void*)d_sa, (void*)d_tx, (void*)d_out, (void*)d_box, (void*)d_ref1,
                     (void*)d_bt, (void*)d_lstart, (void*)d_lcur, (void*)d_lsrc, (void*)d_bd, (void*)d_ldist,
                     (void*)d_sums})
       pool_free(ctx, q);
+    kd_release(ctx, &ks, false);
+    kd_release(ctx, &kt, false);
   };
   auto run = [&]() -> int {
     HIP_TRY(pool_malloc(ctx, (void**)&d_sx, sizeof(int32_t) * 3 * (size_t)ns));
@@ -4728,20 +4733,31 @@ recolour_impl(
     cx.t2s = 1.0 / (double)scale;
     for (int k = 0; k < 3; k++)
       cx.off[k] = offset[k];
-    // the tables are sized for the finest side a refinement may reach
-    const int s_first = rc_shift_for(h_box, ns, 32.0), s_last = rc_shift_for(h_box, ns, 1024.0);
-    const int t_first = rc_shift_for(h_box + 6, nt, 32.0), t_last = rc_shift_for(h_box + 6, nt, 1024.0);
-    size_t scells = (size_t)rc_cells_at(h_box, s_last), tcells = (size_t)rc_cells_at(h_box + 6, t_last);
-    cx.src.xyz = d_sx;
-    cx.tgt.xyz = d_tx;
     cx.src_attrs = d_sa;
-    const size_t mcells = std::max(scells, tcells);
+
+    // ---- the two k-d trees (the reference builds the target's first, then the source's: the
+    //      order does not matter) ---------------------------------------------------------------
+    for (int which = 0; which < 2; which++) {
+      KdAlloc& ka = which ? kt : ks;
+      Timer t(ctx, "rc_kdtree");
+      int r = kd_alloc(ctx, &ka, which ? d_tx : d_sx, which ? nt : ns);
+      if (r)
+        return r;
+      int depth = 0, nodes = 0;
+      HIP_TRY(kd_build_levels(ka.b, d_box + 6 * which, st, &depth, &nodes));
+      if (depth > kKdMaxDepth)
+        return fail(GPCC_ERR_UNSUPPORTED, "k-d tree deeper than 64 levels: it stays on the reference CPU path");
+      KdTree& tr = which ? cx.tgt : cx.src;
+      tr = ka.b.t;
+      for (int k = 0; k < 3; k++) {
+        tr.root_lo[k] = (double)h_box[6 * which + k];
+        tr.root_hi[k] = (double)h_box[6 * which + 3 + k];
+      }
+      kd_release(ctx, &ka, true);  // (the build's working set goes back to the pool; index array and nodes stay)
+      ka.blocks.push_back((void*)tr.vind);
+      ka.blocks.push_back((void*)tr.nodes);
+    }
     const size_t total_cap = (size_t)ns * kb;
-    HIP_TRY(pool_malloc(ctx, (void**)&d_sstart, sizeof(int32_t) * (scells + 1)));
-    HIP_TRY(pool_malloc(ctx, (void**)&d_sitems, sizeof(int32_t) * (size_t)ns));
-    HIP_TRY(pool_malloc(ctx, (void**)&d_tstart, sizeof(int32_t) * (tcells + 1)));
-    HIP_TRY(pool_malloc(ctx, (void**)&d_titems, sizeof(int32_t) * (size_t)nt));
-    HIP_TRY(pool_malloc(ctx, (void**)&d_cur, sizeof(int32_t) * mcells));
     HIP_TRY(pool_malloc(ctx, (void**)&d_ref1, sizeof(int32_t) * (size_t)c * nt));
     HIP_TRY(pool_malloc(ctx, (void**)&d_bt, sizeof(int32_t) * total_cap));
     HIP_TRY(pool_malloc(ctx, (void**)&d_bd, sizeof(double) * total_cap));
@@ -4749,12 +4765,7 @@ recolour_impl(
     HIP_TRY(pool_malloc(ctx, (void**)&d_lcur, sizeof(int32_t) * (size_t)nt));
     HIP_TRY(pool_malloc(ctx, (void**)&d_ldist, sizeof(double) * total_cap));
     HIP_TRY(pool_malloc(ctx, (void**)&d_lsrc, sizeof(int32_t) * total_cap));
-    const size_t max_scan = std::max<size_t>(mcells + 1, (size_t)nt + 1);
-    HIP_TRY(pool_malloc(ctx, (void**)&d_sums, sizeof(long long) * (max_scan / kRcScanBlock + 2)));
-    cx.src.start = d_sstart;
-    cx.src.items = d_sitems;
-    cx.tgt.start = d_tstart;
-    cx.tgt.items = d_titems;
+    HIP_TRY(pool_malloc(ctx, (void**)&d_sums, sizeof(long long) * (((size_t)nt + 1) / kKdScanBlock + 2)));
     cx.ref1 = d_ref1;
     cx.bt = d_bt;
     cx.bd = d_bd;
@@ -4764,34 +4775,6 @@ recolour_impl(
     cx.lsrc = d_lsrc;
     cx.out = d_out;
 
-    // ---- the two cell tables ----------------------------------------------------------
-    for (int which = 0; which < 2; which++) {
-      RcGrid& g = which ? cx.tgt : cx.src;
-      const int32_t* box = which ? h_box + 6 : h_box;
-      const int npts = which ? nt : ns;
-      Timer t(ctx, "rc_cells");
-      size_t cells = 0;
-      for (int shift = which ? t_first : s_first;; shift--) {
-        rc_plan_grid(box, npts, shift, &g, &cells);
-        HIP_TRY(hipMemsetAsync(g.start, 0, sizeof(int32_t) * (cells + 1), st));
-        rc_cell_count_kernel<<<grid_for(g.n, 256), 256, 0, st>>>(g);
-        if (shift == (which ? t_last : s_last))
-          break;
-        unsigned long long load = 0;
-        unsigned long long* d_load = (unsigned long long*)d_sums;
-        HIP_TRY(hipMemsetAsync(d_load, 0, sizeof(unsigned long long), st));
-        rc_cell_load_kernel<<<grid_for((int64_t)std::min<size_t>(cells, 1 << 30), 256), 256, 0, st>>>(g.start, cells, d_load);
-        HIP_TRY(hipMemcpyAsync(&load, d_load, sizeof(load), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        if ((double)load <= kRcMaxCellLoad * (double)npts)
-          break;
-      }
-      HIP_TRY(hipMemsetAsync(d_cur, 0, sizeof(int32_t) * cells, st));
-      int r = rc_scan(ctx, g.start, cells + 1, d_sums);
-      if (r)
-        return r;
-      rc_cell_fill_kernel<<<grid_for(g.n, 256), 256, 0, st>>>(g, d_cur);
-    }
     // ---- forward, backward, lists, blend ------------------------------------------------
     {
       Timer t(ctx, "rc_forward");

@@ -2,51 +2,38 @@
 // (pcc::recolour, tmc3/pointset_processing.cpp:926-957: recolourColour :253-594,
 // recolourReflectance :618-916) on the device.
 //
-// The reference searches two nanoflann k-d trees point by point.  Here both clouds
-// get a DENSE CELL TABLE over their bounding box (cell side 2^shift: at most 32 cells per
-// point, refined for sparse clouds while an occupied cell holds more than 24 points;
-// count / scan / fill, three launches),
-// and a thread finds the exact K nearest points of its query by visiting the cells
-// ring after ring around the query's cell until the K-th distance is not larger
-// than anything an unvisited cell can hold.  Distances, weights, centroids and the
-// +-search_range refinement are the reference's double-precision expressions in the
-// reference's order (no contraction into fused multiply-adds); equidistant
-// candidates are ordered by point index (the one place where the reference's
-// outcome depends on its containers: see include/gpcc_attr_mi355.h).
+// The reference searches two nanoflann k-d trees point by point and sorts its backward
+// lists with std::sort; where candidates are equidistant (a voxelised cloud at a dyadic
+// scale: at nearly every point) its result is the ORDER those containers produce.  Both
+// are therefore rebuilt: recolour_kdtree.hpp builds nanoflann's trees level by level and
+// walks them in nanoflann's order; the backward lists are put into the reference's
+// insertion order (source index) and sorted by libstdc++'s algorithm (introsort with a
+// median-of-three pivot, heap sort at the depth limit, insertion sort up to 16 entries --
+// not stable beyond 16).  Distances, weights, centroids and the +-search_range refinement
+// are the reference's double-precision expressions in the reference's order (no
+// contraction into fused multiply-adds).  Identical to the reference, ties included.
 //
 //   rc_bbox          bounding box of a cloud                          (atomics)
-//   rc_cell_count / rc_scan_* / rc_cell_fill     the cell table
+//   kd_*             the two trees (recolour_kdtree.hpp)
 //   rc_forward       per target point: K nearest source points, blended colour
 //   rc_backward      per source point: its nearest target points -> (target, dist)
 //   rc_list_fill     the backward lists, one contiguous range per target
-//   rc_blend         per target point: list sorted by (distance, source), centroid,
-//                    refinement
+//   rc_blend         per target point: list in the reference's order, centroid, refinement
 #pragma once
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "gpcc_attr_mi355.h"
+#include "recolour_kdtree.hpp"
 
 namespace gpcc {
 
 constexpr int kRcMaxK = 8;
-// refine the cell side while the cell an average point sits in holds more than this
-constexpr double kRcMaxCellLoad = 12.0;
-constexpr int kRcScanBlock = 2048;  // elements per workgroup of the scan
-
-struct RcGrid {
-  const int32_t* xyz;   // [n][3]
-  int32_t n;
-  int32_t shift;
-  int32_t lo[3], dim[3];
-  int32_t* start;       // [cells + 1]
-  int32_t* items;       // [n]
-};
 
 struct RcCtx {
   gpcc_recolour_params p;
-  RcGrid src, tgt;
+  KdTree src, tgt;
   const int32_t* src_attrs;  // [ns][c]
   int32_t c;
   double s2t, t2s;
@@ -60,13 +47,6 @@ struct RcCtx {
   int32_t* lsrc;       // [total]
   int32_t* out;        // [nt][c]
 };
-
-__device__ __forceinline__ size_t
-rc_cell(const RcGrid& g, int x, int y, int z)
-{
-  return ((size_t)((x >> g.shift) - g.lo[0]) * g.dim[1] + (size_t)((y >> g.shift) - g.lo[1])) * g.dim[2]
-    + (size_t)((z >> g.shift) - g.lo[2]);
-}
 
 // ---- bounding box ---------------------------------------------------------------
 __global__ __launch_bounds__(256) void
@@ -93,234 +73,6 @@ rc_bbox_kernel(const int32_t* __restrict__ xyz, int n, int32_t* box /* min[3], m
       atomicMin(&box[k], mn[k]);
       atomicMax(&box[3 + k], mx[k]);
     }
-  }
-}
-
-// ---- cell table --------------------------------------------------------------------
-__global__ __launch_bounds__(256) void
-rc_cell_count_kernel(RcGrid g)
-{
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < g.n; i += gridDim.x * blockDim.x)
-    atomicAdd(&g.start[rc_cell(g, g.xyz[3 * i], g.xyz[3 * i + 1], g.xyz[3 * i + 2]) + 1], 1);
-}
-
-// sum over cells of count^2 (start[c + 1] still holds the cell's count here): divided by
-// the number of points it is the load of the cell an average POINT sits in, which is what
-// a query pays per cell it opens -- the mean over cells hides the crowded ones
-__global__ __launch_bounds__(256) void
-rc_cell_load_kernel(const int32_t* __restrict__ start, size_t cells, unsigned long long* load)
-{
-  unsigned long long acc = 0;
-  for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < cells; c += (size_t)gridDim.x * blockDim.x) {
-    const unsigned long long k = (unsigned)start[c + 1];
-    acc += k * k;
-  }
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1)
-    acc += __shfl_xor(acc, d);
-  if ((threadIdx.x & 63) == 0 && acc)
-    atomicAdd(load, acc);
-}
-
-__global__ __launch_bounds__(256) void
-rc_cell_fill_kernel(RcGrid g, int32_t* cursor)
-{
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < g.n; i += gridDim.x * blockDim.x) {
-    const size_t c = rc_cell(g, g.xyz[3 * i], g.xyz[3 * i + 1], g.xyz[3 * i + 2]);
-    g.items[g.start[c] + atomicAdd(&cursor[c], 1)] = i;
-  }
-}
-
-// inclusive scan of a[0..n) in place (a[0] stays: the arrays carry a leading zero),
-// three launches: block sums, their scan by one workgroup, the blocks again
-__global__ __launch_bounds__(256) void
-rc_scan_sums_kernel(const int32_t* __restrict__ a, size_t n, long long* __restrict__ sums)
-{
-  __shared__ long long w[4];
-  const size_t base = (size_t)blockIdx.x * kRcScanBlock;
-  long long s = 0;
-  for (int k = 0; k < kRcScanBlock / 256; k++) {
-    const size_t i = base + (size_t)k * 256 + threadIdx.x;
-    s += i < n ? a[i] : 0;
-  }
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1)
-    s += __shfl_xor(s, d);
-  if ((threadIdx.x & 63) == 0)
-    w[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x == 0)
-    sums[blockIdx.x] = w[0] + w[1] + w[2] + w[3];
-}
-
-__global__ __launch_bounds__(1024) void
-rc_scan_blocks_kernel(long long* sums, int nblocks)
-{
-  __shared__ long long part[1024];
-  const int per = (nblocks + 1023) / 1024;
-  const int b0 = threadIdx.x * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
-  long long s = 0;
-  for (int b = b0; b < b1; b++)
-    s += sums[b];
-  part[threadIdx.x] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    long long run = 0;
-    for (int i = 0; i < 1024; i++) {
-      const long long v = part[i];
-      part[i] = run;
-      run += v;
-    }
-  }
-  __syncthreads();
-  long long run = part[threadIdx.x];
-  for (int b = b0; b < b1; b++) {
-    const long long v = sums[b];
-    sums[b] = run;
-    run += v;
-  }
-}
-
-__global__ __launch_bounds__(256) void
-rc_scan_apply_kernel(int32_t* a, size_t n, const long long* __restrict__ sums)
-{
-  __shared__ int wsum[4];
-  const size_t base = (size_t)blockIdx.x * kRcScanBlock;
-  int run = (int)sums[blockIdx.x];
-  const int lane = threadIdx.x & 63;
-  for (int k = 0; k < kRcScanBlock / 256; k++) {
-    const size_t i = base + (size_t)k * 256 + threadIdx.x;
-    const int v = i < n ? a[i] : 0;
-    int inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const int o = __shfl_up(inc, d);
-      if (lane >= d)
-        inc += o;
-    }
-    __syncthreads();
-    if (lane == 63)
-      wsum[threadIdx.x >> 6] = inc;
-    __syncthreads();
-    int off = run;
-    for (int w = 0; w < (int)(threadIdx.x >> 6); w++)
-      off += wsum[w];
-    if (i < n)
-      a[i] = off + inc;
-    run += wsum[0] + wsum[1] + wsum[2] + wsum[3];
-  }
-}
-
-// ---- exact K nearest neighbours -----------------------------------------------------
-// (K = the list's capacity, a template parameter: the kernels are built for 1, 2, 4 and 8 -- with
-// the one list of 8 the forward kernel took 256 registers and 1.9 KB of scratch per lane, one
-// wavefront per SIMD, and the backward kernel, which keeps ONE neighbour, carried seven idle ones)
-template<int K>
-struct RcKnn {
-  double d[K];
-  int32_t i[K];
-  int count;
-};
-
-// (d2, idx) into the ascending list; equal distances by index; entries beyond the
-// k-th fall off.  Static register indices only.
-template<int K>
-__device__ __forceinline__ void
-rc_insert(RcKnn<K>& r, int k, double d, int32_t idx)
-{
-  // where it goes: the number of entries that come before it
-  int pos = 0;
-#pragma unroll
-  for (int p = 0; p < K; p++)
-    pos += (p < r.count && (r.d[p] < d || (r.d[p] == d && r.i[p] < idx))) ? 1 : 0;
-  if (pos >= k)
-    return;
-#pragma unroll
-  for (int p = K - 1; p > 0; p--) {
-    if (p > pos) {
-      r.d[p] = r.d[p - 1];
-      r.i[p] = r.i[p - 1];
-    }
-  }
-#pragma unroll
-  for (int p = 0; p < K; p++) {
-    if (p == pos) {
-      r.d[p] = d;
-      r.i[p] = idx;
-    }
-  }
-  r.count = r.count < k ? r.count + 1 : k;
-}
-
-template<int K>
-__device__ __forceinline__ double
-rc_kth(const RcKnn<K>& r, int k)
-{
-  double v = r.d[0];
-#pragma unroll
-  for (int p = 1; p < K; p++)
-    v = p == k - 1 ? r.d[p] : v;
-  return v;
-}
-
-template<int K>
-__device__ __forceinline__ void
-rc_knn(const RcGrid& g, const double q[3], int k, RcKnn<K>& r)
-{
-#pragma clang fp contract(off)
-  const int cs = 1 << g.shift;
-  int cq[3];
-#pragma unroll
-  for (int a = 0; a < 3; a++)
-    cq[a] = (int)floor(q[a] / cs) - g.lo[a];
-  r.count = 0;
-#pragma unroll
-  for (int p = 0; p < K; p++) {
-    r.d[p] = 0.0;
-    r.i[p] = 0;
-  }
-  int maxr = 0;
-#pragma unroll
-  for (int a = 0; a < 3; a++) {
-    int far = cq[a] > g.dim[a] - 1 - cq[a] ? cq[a] : g.dim[a] - 1 - cq[a];
-    far = far < 0 ? -far : far;
-    maxr = far > maxr ? far : maxr;
-  }
-  for (int rr = 0; rr <= maxr; rr++) {
-    for (int dx = -rr; dx <= rr; dx++) {
-      const int cx = cq[0] + dx;
-      if (cx < 0 || cx >= g.dim[0])
-        continue;
-      for (int dy = -rr; dy <= rr; dy++) {
-        const int cy = cq[1] + dy;
-        if (cy < 0 || cy >= g.dim[1])
-          continue;
-        const bool shell = dx == -rr || dx == rr || dy == -rr || dy == rr;
-        const int step = (shell || rr == 0) ? 1 : 2 * rr;
-        for (int dz = -rr; dz <= rr; dz += step) {
-          const int cz = cq[2] + dz;
-          if (cz < 0 || cz >= g.dim[2])
-            continue;
-          const size_t c = ((size_t)cx * g.dim[1] + (size_t)cy) * g.dim[2] + (size_t)cz;
-          const int e1 = g.start[c + 1];
-          for (int e = g.start[c]; e < e1; e++) {
-            const int32_t i = g.items[e];
-            // nanoflann's L2 adaptor: result += diff * diff, x then y then z
-            double s = 0.0;
-#pragma unroll
-            for (int a = 0; a < 3; a++) {
-              const double diff = q[a] - (double)g.xyz[3 * i + a];
-              s += diff * diff;
-            }
-            rc_insert(r, k, s, i);
-          }
-        }
-      }
-    }
-    // a point of ring rr + 1 or beyond differs by more than rr * cs in some axis
-    const double bound = (double)rr * cs;
-    if (r.count == k && rc_kth(r, k) <= bound * bound)
-      break;
   }
 }
 
@@ -356,7 +108,7 @@ rc_forward_kernel(RcCtx cx)
   for (int a = 0; a < 3; a++)
     q[a] = (double)(cx.tgt.xyz[3 * t + a] + cx.off[a]) * cx.t2s;
   RcKnn<K> r;
-  rc_knn<K>(cx.src, q, kf, r);
+  rc_kd_search<K>(cx.src, q, kf, r);
   // the neighbours' attributes, nearest first
   int32_t col[K][C];
 #pragma unroll
@@ -454,7 +206,7 @@ rc_backward_kernel(RcCtx cx)
   for (int a = 0; a < 3; a++)
     q[a] = (double)cx.src.xyz[3 * s + a] * cx.s2t - (double)cx.off[a];
   RcKnn<K> r;
-  rc_knn<K>(cx.tgt, q, kb, r);
+  rc_kd_search<K>(cx.tgt, q, kb, r);
 #pragma unroll
   for (int i = 0; i < K; i++) {
     if (i < kb) {
@@ -484,6 +236,161 @@ rc_list_fill_kernel(RcCtx cx)
   }
 }
 
+// ---- std::sort(first, last, by distance) as libstdc++ does it (bits/stl_algo.h: __introsort_loop,
+//      __unguarded_partition_pivot, __final_insertion_sort; bits/stl_heap.h), on the pair of arrays
+//      (distance, source) of one list.  Checked against std::sort itself: tests/test_oracle_recolour.py
+//      pins the C restatement this follows, tests/test_gpu_recolour.py the device against both.
+__device__ __forceinline__ void
+rc_ss_swap(double* d, int32_t* s, int a, int b)
+{
+  const double td = d[a];
+  const int32_t ts = s[a];
+  d[a] = d[b];
+  s[a] = s[b];
+  d[b] = td;
+  s[b] = ts;
+}
+
+__device__ inline void
+rc_ss_adjust_heap(double* d, int32_t* s, int hole, int len, double vd, int32_t vs)
+{
+  const int top = hole;
+  int child = hole;
+  while (child < (len - 1) / 2) {
+    child = 2 * (child + 1);
+    if (d[child] < d[child - 1])
+      child--;
+    d[hole] = d[child];
+    s[hole] = s[child];
+    hole = child;
+  }
+  if ((len & 1) == 0 && child == (len - 2) / 2) {
+    child = 2 * (child + 1);
+    d[hole] = d[child - 1];
+    s[hole] = s[child - 1];
+    hole = child - 1;
+  }
+  int parent = (hole - 1) / 2;
+  while (hole > top && d[parent] < vd) {
+    d[hole] = d[parent];
+    s[hole] = s[parent];
+    hole = parent;
+    parent = (hole - 1) / 2;
+  }
+  d[hole] = vd;
+  s[hole] = vs;
+}
+
+__device__ inline void
+rc_ss_heap_sort(double* d, int32_t* s, int len)
+{
+  if (len >= 2)
+    for (int parent = (len - 2) / 2;; parent--) {
+      rc_ss_adjust_heap(d, s, parent, len, d[parent], s[parent]);
+      if (parent == 0)
+        break;
+    }
+  for (int last = len - 1; last >= 1; last--) {
+    const double vd = d[last];
+    const int32_t vs = s[last];
+    d[last] = d[0];
+    s[last] = s[0];
+    rc_ss_adjust_heap(d, s, 0, last, vd, vs);
+  }
+}
+
+// entries [from, n) into the sorted prefix; `guarded`: an entry below the first one goes to the front
+__device__ inline void
+rc_ss_insertion(double* d, int32_t* s, int from, int n, bool guarded)
+{
+  for (int i = from; i < n; i++) {
+    const double vd = d[i];
+    const int32_t vs = s[i];
+    int j = i;
+    if (guarded && vd < d[0]) {
+      for (; j > 0; j--) {
+        d[j] = d[j - 1];
+        s[j] = s[j - 1];
+      }
+    } else {
+      while (vd < d[j - 1]) {
+        d[j] = d[j - 1];
+        s[j] = s[j - 1];
+        j--;
+      }
+    }
+    d[j] = vd;
+    s[j] = vs;
+  }
+}
+
+__device__ inline void
+rc_std_sort(double* d, int32_t* s, int n)
+{
+  if (n < 2)
+    return;
+  if (n > 16) {
+    int depth = 0;
+    for (int m = n; m > 1; m >>= 1)
+      depth++;
+    depth *= 2;
+    // the recursive call on [cut, last) as a stack; the two parts are disjoint ranges, their order is free
+    int st_first[64], st_last[64], st_depth[64];
+    int sp = 0;
+    st_first[0] = 0;
+    st_last[0] = n;
+    st_depth[0] = depth;
+    while (sp >= 0) {
+      const int first = st_first[sp];
+      int last = st_last[sp], dl = st_depth[sp];
+      sp--;
+      while (last - first > 16) {
+        if (dl == 0) {
+          rc_ss_heap_sort(d + first, s + first, last - first);
+          break;
+        }
+        dl--;
+        // median of first + 1, middle, last - 1 to the front
+        const int x = first + 1, y = first + (last - first) / 2, z = last - 1;
+        if (d[x] < d[y]) {
+          if (d[y] < d[z])
+            rc_ss_swap(d, s, first, y);
+          else if (d[x] < d[z])
+            rc_ss_swap(d, s, first, z);
+          else
+            rc_ss_swap(d, s, first, x);
+        } else if (d[x] < d[z])
+          rc_ss_swap(d, s, first, x);
+        else if (d[y] < d[z])
+          rc_ss_swap(d, s, first, z);
+        else
+          rc_ss_swap(d, s, first, y);
+        int i = first + 1, j = last;
+        for (;;) {
+          while (d[i] < d[first])
+            i++;
+          j--;
+          while (d[first] < d[j])
+            j--;
+          if (!(i < j))
+            break;
+          rc_ss_swap(d, s, i, j);
+          i++;
+        }
+        sp++;
+        st_first[sp] = i;
+        st_last[sp] = last;
+        st_depth[sp] = dl;
+        last = i;
+      }
+    }
+    rc_ss_insertion(d, s, 1, 16, true);
+    rc_ss_insertion(d, s, 16, n, false);
+  } else {
+    rc_ss_insertion(d, s, 1, n, true);
+  }
+}
+
 // ---- blend and refinement (:426-592 / 768-914) ---------------------------------------
 template<int C>
 __global__ __launch_bounds__(256) void
@@ -507,13 +414,13 @@ rc_blend_kernel(RcCtx cx)
       out[k] = c1[k];
     return;
   }
-  // the list by (distance, source index): insertion sort in place (the fill order is
-  // whatever the atomics made it)
+  // the reference pushes a target's entries in source order (:397-412; the fill order here is
+  // whatever the atomics made it), then std::sort orders them by distance alone (:416-422)
   for (int i = 1; i < n; i++) {
     const double d = ld[i];
     const int32_t s = ls[i];
     int j = i;
-    while (j > 0 && (ld[j - 1] > d || (ld[j - 1] == d && ls[j - 1] > s))) {
+    while (j > 0 && ls[j - 1] > s) {
       ld[j] = ld[j - 1];
       ls[j] = ls[j - 1];
       j--;
@@ -521,6 +428,7 @@ rc_blend_kernel(RcCtx cx)
     ld[j] = d;
     ls[j] = s;
   }
+  rc_std_sort(ld, ls, n);
   const double max_a = rc_limit(p.max_attribute_dist2_bwd);
   const double clip_max = (double)((1 << p.bitdepth) - 1);
   double cen2[C];

@@ -1,6 +1,6 @@
-"""The decoder with sub-node prediction has two device paths: the walk across
-levels in one launch (raht_pipe.hpp, default for slices without region QPs) and
-the level-by-level kernels (region QPs, GPCC_PIPE=0).  Every decoder test of
+"""The decoder with sub-node prediction has two device paths: the level-by-level
+kernels (the default since round 4) and the walk across levels in one launch
+(raht_pipe.hpp, GPCC_PIPE=1, slices without region QPs).  Every decoder test of
 the suite runs the first; this file runs the second on the same cases and pins
 the two against each other on batches."""
 import os
@@ -14,8 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def test_level_by_level_decoder_on_the_golden_and_subnode_cases():
-    env = dict(os.environ, GPCC_PIPE="0")
+def test_cross_level_decoder_on_the_golden_and_subnode_cases():
+    env = dict(os.environ, GPCC_PIPE="1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_raht.py"), "-x", "-q",
                         "-m", "gpu", "-k", "golden or subnode"], capture_output=True, text=True, timeout=900, env=env,
                        cwd=ROOT)

@@ -22,9 +22,14 @@ pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not ins
 def kernels(tmp_path_factory):
     out = str(tmp_path_factory.mktemp("isa") / "gpcc.s")
     src = os.path.join(ROOT, "mpeg-pcc-tmc13_amd", "csrc", "gpcc_attr_mi355.hip")
-    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-w",
-                    "-I" + os.path.join(ROOT, "include"), "-I" + os.path.dirname(src),
-                    "-S", "--cuda-device-only", "-o", out, src], check=True, timeout=900)
+    pre = os.environ.get("GPCC_ISA_LISTING")  # (a listing made beforehand: tools/isa_audit.py)
+    if pre and os.path.exists(pre) and os.path.getmtime(pre) >= max(
+            os.path.getmtime(os.path.join(os.path.dirname(src), f)) for f in os.listdir(os.path.dirname(src))):
+        out = pre
+    else:
+        subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-w",
+                        "-I" + os.path.join(ROOT, "include"), "-I" + os.path.dirname(src),
+                        "-S", "--cuda-device-only", "-o", out, src], check=True, timeout=900)
     bodies, cur = {}, None
     for ln in open(out):
         m = re.match(r"^(_Z\w+):\s*; @", ln)
@@ -47,11 +52,19 @@ def loop_region(body):
     return body[polls[0]:sleeps[0]]
 
 
-# mode 1 = decoder, 2 = integer-Haar encoder, 3 = lossy encoder (LevelMode)
-@pytest.mark.parametrize("c,mode", [(1, 1), (1, 2), (1, 3), (3, 1), (3, 3)])
-def test_only_polls_wait_on_vector_memory(kernels, c, mode):
-    name = f"_ZN4gpcc21raht_level_sub_kernelILi{c}ELi{mode}EEEvNS_8LevelCtxE"
-    region = loop_region(kernels[name])
+def kernel_name(c, mode, arith):
+    return f"_ZN4gpcc21raht_level_sub_kernelILi{c}ELi{mode}ENS_8Arith{arith}EEEvNS_8LevelCtxE"
+
+
+# mode 1 = decoder, 2 = integer-Haar encoder, 3 = lossy encoder (LevelMode); the arithmetic back
+# end is int64 fixed point or doubles where they are exact (raht_arith.hpp)
+CASES = [(1, 1, "I64"), (1, 1, "F64"), (1, 2, "I64"), (1, 3, "I64"), (1, 3, "F64"), (3, 1, "I64"),
+         (3, 1, "F64"), (3, 3, "I64"), (3, 3, "F64")]
+
+
+@pytest.mark.parametrize("c,mode,arith", CASES)
+def test_only_polls_wait_on_vector_memory(kernels, c, mode, arith):
+    region = loop_region(kernels[kernel_name(c, mode, arith)])
     loads = [s for s in region if re.match(r"(global_load|flat_load|buffer_load)", s)]
     polls = [s for s in loads if s.startswith("buffer_load_dwordx4") and "sc1" in s]
     others = [s for s in loads if s not in polls]
@@ -59,28 +72,31 @@ def test_only_polls_wait_on_vector_memory(kernels, c, mode):
     assert not [s for s in region if s.startswith("flat_")]
     if mode == 3:
         # the bounded RDOQ look-back: state word (sc1), its worklist entry, the slice's carried L
-        assert len(others) <= 3, others
+        # (read where a block gets its descriptors and where the walk reaches the slice's start)
+        assert len(others) <= 4, others
         assert any("sc1" in s for s in others)
     else:
         assert not others, others
 
 
-@pytest.mark.parametrize("c,mode", [
-    (1, 1), (1, 2), (1, 3), (3, 1),
-    pytest.param(3, 3, marks=pytest.mark.xfail(
-        reason="the lossy C=3 kernel (168 registers at 3 waves/SIMD) still reloads spilled "
-               "registers inside the loop -- scratch loads are vector memory too; DESIGN.md section 7",
-        strict=False))])
-def test_no_spill_reloads_inside_the_loop(kernels, c, mode):
-    name = f"_ZN4gpcc21raht_level_sub_kernelILi{c}ELi{mode}EEEvNS_8LevelCtxE"
-    region = loop_region(kernels[name])
+_SPILLS = pytest.mark.xfail(
+    reason="the lossy C=3 kernel (168 registers at 3 waves/SIMD) still reloads spilled "
+           "registers inside the loop -- scratch loads are vector memory too; DESIGN.md section 7",
+    strict=False)
+
+
+@pytest.mark.parametrize("c,mode,arith", [
+    (1, 1, "I64"), (1, 1, "F64"), (1, 2, "I64"), (1, 3, "I64"), (1, 3, "F64"), (3, 1, "I64"), (3, 1, "F64"),
+    pytest.param(3, 3, "I64", marks=_SPILLS), pytest.param(3, 3, "F64", marks=_SPILLS)])
+def test_no_spill_reloads_inside_the_loop(kernels, c, mode, arith):
+    region = loop_region(kernels[kernel_name(c, mode, arith)])
     assert not [s for s in region if s.startswith("scratch_load")]
 
 
 def test_group_exchanges_are_dpp(kernels):
     """butterfly exchanges and group reductions inside the loop are DPP moves;
     ds_bpermute is left to exchanges with a run-time source lane"""
-    body = kernels["_ZN4gpcc21raht_level_sub_kernelILi1ELi1EEEvNS_8LevelCtxE"]
+    body = kernels[kernel_name(1, 1, "F64")]
     region = loop_region(body)
     assert sum("_dpp" in s for s in region) >= 12
     assert sum("ds_bpermute" in s for s in body) < 140
