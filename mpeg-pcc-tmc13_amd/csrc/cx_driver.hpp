@@ -24,6 +24,7 @@ namespace gpcc {
 struct CxWork {
   int n = 0, s = 0, c = 0, nlev = 0;
   bool encoder = false;
+  bool f64 = false;  // the level kernels in ArithF64 (raht_arith.hpp; decided by the caller)
   TreeView tv{};
   CxLists cl{};
   int32_t* pt_off = nullptr;
@@ -174,10 +175,14 @@ cx_run(
     }();
     if (top_on && li_start - li_lo + 1 >= 2) {
       auto t = prof(w.encoder ? "cx_top_enc" : "cx_top_dec", -1);
-      if (w.encoder)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(cx_top_kernel<C, true>), dim3(1), dim3(256), 0, st, cx, li_start, li_lo);
+      if (w.encoder && w.f64)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(cx_top_kernel<C, true, ArithF64>), dim3(1), dim3(256), 0, st, cx, li_start, li_lo);
+      else if (w.encoder)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(cx_top_kernel<C, true, ArithI64>), dim3(1), dim3(256), 0, st, cx, li_start, li_lo);
+      else if (w.f64)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(cx_top_kernel<C, false, ArithF64>), dim3(1), dim3(256), 0, st, cx, li_start, li_lo);
       else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(cx_top_kernel<C, false>), dim3(1), dim3(256), 0, st, cx, li_start, li_lo);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(cx_top_kernel<C, false, ArithI64>), dim3(1), dim3(256), 0, st, cx, li_start, li_lo);
       li_start = li_lo - 1;
     }
   }
@@ -188,10 +193,14 @@ cx_run(
     cx.li = li;
     const int ntiles = (nr + kCxG - 1) / kCxG;
     auto t = prof(w.encoder ? "cx_level_enc" : "cx_level_dec", li);
-    if (w.encoder)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(cx_level_kernel<C, true>), dim3((ntiles + 3) / 4), dim3(256), 0, st, cx);
+    if (w.encoder && w.f64)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(cx_level_kernel<C, true, ArithF64>), dim3((ntiles + 3) / 4), dim3(256), 0, st, cx);
+    else if (w.encoder)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(cx_level_kernel<C, true, ArithI64>), dim3((ntiles + 3) / 4), dim3(256), 0, st, cx);
+    else if (w.f64)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(cx_level_kernel<C, false, ArithF64>), dim3((ntiles + 3) / 4), dim3(256), 0, st, cx);
     else
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(cx_level_kernel<C, false>), dim3((ntiles + 3) / 4), dim3(256), 0, st, cx);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(cx_level_kernel<C, false, ArithI64>), dim3((ntiles + 3) / 4), dim3(256), 0, st, cx);
   }
 
   FinishCtx fc{};
@@ -200,6 +209,7 @@ cx_run(
   fc.sched = w.sched;
   fc.attr_prefix = w.attr_prefix;
   fc.slot_rec = w.rec;
+  fc.slot_f64 = w.f64 ? 1 : 0;
   fc.hold0 = cl.hold[0];
   fc.attrs = d_attrs;
   fc.coeffs = d_coeffs;

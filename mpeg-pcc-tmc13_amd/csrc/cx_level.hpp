@@ -18,9 +18,17 @@
 //     as in raht_rdoq.hpp) -- one launch per level instead of analyze / resolve /
 //     synthesis, and no transformed prediction written to memory and read back.
 // Wavefronts do not synchronise with each other (no barrier after the table load).
+//
+// Round 4: the arithmetic is a template parameter (raht_arith.hpp).  The pass is bound by
+// VALU issue, and half of that was 64 x 32-bit fixed-point products on the quarter-rate
+// 32-bit multiplier; with ArithF64 a product is fma + trunc on doubles that hold the same
+// integers (exact below 2^53; the kernels check the magnitudes and a slice that leaves the
+// range is redone in int64).  The value slots then hold the doubles' bit patterns -- every
+// reader is a launch of the same call with the same back end (finish converts).
 #pragma once
 
 #include "cx_tree.hpp"
+#include "raht_arith.hpp"
 #include "raht_levels.hpp"
 #include "raht_rdoq.hpp"
 
@@ -36,7 +44,7 @@ struct CxCtx {
   const gpcc_raht_params* params;
   const SliceSched* sched;
   const int32_t* attr_prefix;  // P[N+1][C] (encoder)
-  int64_t* val;                // [2N][C] unscaled reconstruction of every value slot
+  int64_t* val;                // [2N][C] unscaled reconstruction of every value slot (the back end's bits)
   int64_t* rec;                // [2N][C] scaled reconstruction
   int32_t* nn;                 // [2N]    numParentNeigh of the node that was reconstructed there
   int32_t* coeffs;             // planar per slice
@@ -195,10 +203,18 @@ cx_norm(int32_t w, const SharedLut& L)
   return r;
 }
 
-__device__ __forceinline__ int64_t
-cx_scale(int64_t v, const CxNorm& nm)
+template<class A>
+__device__ __forceinline__ typename A::T
+cx_scale(typename A::T v, const CxNorm& nm, typename A::Coef rs)
 {
-  return fp_mul_c(v >> nm.shift, nm.rs);
+  return A::mulc(A::shr(v, nm.shift), rs);
+}
+
+template<class VT>
+__device__ __forceinline__ VT
+cx_bperm_v(int src_lane, VT v)
+{
+  return __builtin_bit_cast(VT, cx_bperm_i64(src_lane, __builtin_bit_cast(int64_t, v)));
 }
 
 // butterfly coefficients of (wl, wr) (RahtKernel, tmc3/RAHT.cpp:596-604) given the
@@ -335,10 +351,13 @@ cx_level_setup(const CxCtx& cx, CxSmem& sm, int li)
 }
 
 // ---- one tile of level li: the wavefront's work -------------------------------------------
-template<int C, bool ENC>
+template<int C, bool ENC, class A>
 __device__ __forceinline__ void
 cx_level_tile(const CxCtx& cx, CxSmem& sm, int li, int tile)
 {
+  typedef typename A::T VT;
+  typedef typename A::Coef VC;
+  bool in_range = true;  // (ArithF64: the magnitudes that bound every product, raht_arith.hpp)
   const TreeView& tv = cx.tv;
   const int L = li + 1;
   const int lane = lane_id();
@@ -427,30 +446,31 @@ cx_level_tile(const CxCtx& cx, CxSmem& sm, int li, int tile)
 
   // source sum of the child: difference of the modular prefix sums (the reference
   // accumulates these sums in `int` as well, tmc3/RAHT.cpp:131,196)
-  int64_t src[C];
+  VT src[C];
 #pragma unroll
   for (int k = 0; k < C; k++)
-    src[k] = 0;
+    src[k] = A::zero();
   if (ENC) {
 #pragma unroll
     for (int k = 0; k < C; k++)
-      src[k] = fp_from_int((int32_t)(
+      src[k] = A::from_int((int32_t)(
         (uint32_t)cx.attr_prefix[(size_t)fb * C + k] - (uint32_t)cx.attr_prefix[(size_t)fa * C + k]));
   }
 
   // the parent's values.  numParentNeigh: 19 when the parent came down a chain
   // through a level its slice processes (the single-child copy sets it,
   // tmc3/RAHT.cpp:1382-1401), else what its own block left
-  int64_t pval[C], prec[C];
+  VT pval[C], prec[C];
   int pneigh = 0;
 #pragma unroll
   for (int k = 0; k < C; k++)
-    pval[k] = prec[k] = 0;
+    pval[k] = prec[k] = A::zero();
   if (inherit_dc) {
 #pragma unroll
     for (int k = 0; k < C; k++) {
-      pval[k] = cx.val[(size_t)pslot * C + k];
-      prec[k] = cx.rec[(size_t)pslot * C + k];
+      pval[k] = __builtin_bit_cast(VT, cx.val[(size_t)pslot * C + k]);
+      prec[k] = __builtin_bit_cast(VT, cx.rec[(size_t)pslot * C + k]);
+      in_range = in_range && A::below(pval[k], A::kInvLimit) && A::below(prec[k], A::kRecLimit);
     }
     const uint32_t through = ptop > L ? (sl.procmask >> L) & ((1u << (ptop - L)) - 1u) : 0u;
     pneigh = through ? 19 : cx.nn[pslot];
@@ -550,60 +570,68 @@ cx_level_tile(const CxCtx& cx, CxSmem& sm, int li, int tile)
   }
 
   // ---- intraDcPred for this child (tmc3/RAHT.cpp:421-589, parent-level part) ---------
-  int64_t pred[C];
+  VT pred[C];
 #pragma unroll
   for (int k = 0; k < C; k++)
-    pred[k] = 0;
+    pred[k] = A::zero();
   {
     const bool run = enable_pred;
     uint32_t nh[6];
 #pragma unroll
     for (int t = 0; t < 6; t++)
       nh[t] = (run && nq[t] >= 0) ? cx.cl.hold[L][nq[t]] : 0u;
-    int64_t nv[6][C];
+    VT nv[6][C];
 #pragma unroll
     for (int t = 0; t < 6; t++)
 #pragma unroll
-      for (int k = 0; k < C; k++)
-        nv[t][k] = (run && nq[t] >= 0) ? cx.rec[(size_t)(nh[t] & kCxSlotMask) * C + k] : 0;
+      for (int k = 0; k < C; k++) {
+        nv[t][k] = (run && nq[t] >= 0) ? __builtin_bit_cast(VT, cx.rec[(size_t)(nh[t] & kCxSlotMask) * C + k])
+                                       : A::zero();
+        in_range = in_range && A::below(nv[t][k], A::kRecLimit);
+      }
     if (run) {
-      const int64_t lim_lo = 2 * prec[0], lim_hi = 25 * prec[0];
+      const VT lim_lo = A::muli(prec[0], 2), lim_hi = A::muli(prec[0], 25);
       int wsum = sm.pw[0];
 #pragma unroll
       for (int k = 0; k < C; k++)
-        pred[k] = prec[k] * (int64_t)sm.pw[0];
+        pred[k] = A::muli(prec[k], sm.pw[0]);
 #pragma unroll
       for (int t = 0; t < 6; t++) {
-        if (nq[t] >= 0 && !(10 * nv[t][0] <= lim_lo || 10 * nv[t][0] >= lim_hi)) {
-          const int64_t pwt = sm.pw[sm.nid[oct][t]];
-          wsum += (int)pwt;
+        if (nq[t] >= 0 && !(A::muli(nv[t][0], 10) <= lim_lo || A::muli(nv[t][0], 10) >= lim_hi)) {
+          const int pwt = sm.pw[sm.nid[oct][t]];
+          wsum += pwt;
 #pragma unroll
           for (int k = 0; k < C; k++)
-            pred[k] += nv[t][k] * pwt;
+            pred[k] += A::muli(nv[t][k], pwt);
         }
       }
-      const int64_t div = pred_divisor(wsum);
+      const VC div = A::coef(pred_divisor(wsum));
 #pragma unroll
       for (int k = 0; k < C; k++)
-        pred[k] = fp_mul_c(pred[k], div);
+        pred[k] = A::mulc(pred[k], div);
     }
   }
 
   prof.mark(2);  // prediction gathers + sums
   // ---- normalise (tmc3/RAHT.cpp:1445-1499) -------------------------------------------
   const CxNorm nm = cx_norm(on ? w : 1, lut);
+  const VC nm_rs = A::coef(nm.rs);
   if (on && w > 1) {
     if (ENC) {
 #pragma unroll
       for (int k = 0; k < C; k++)
-        src[k] = cx_scale(src[k], nm);
+        src[k] = cx_scale<A>(src[k], nm, nm_rs);
     }
     if (enable_pred) {
+      const VC nm_sq = A::coef(nm.sq);
 #pragma unroll
       for (int k = 0; k < C; k++)
-        pred[k] = fp_mul_c(pred[k], nm.sq);
+        pred[k] = A::mulc(pred[k], nm_sq);
     }
   }
+#pragma unroll
+  for (int k = 0; k < C; k++)
+    in_range = in_range && (!on || (A::below(src[k], A::kFwdLimit) && A::below(pred[k], A::kFwdLimit)));
 
   // ---- forward butterflies (fwdTransformBlock222, tmc3/RAHT.cpp:671-701; weights as
   //      mkWeightTree :742).  A value stays in its lane; `pos` is where it sits in
@@ -644,18 +672,19 @@ cx_level_tile(const CxCtx& cx, CxSmem& sm, int li, int tile)
     st_lane[st] = from;
     st_a[st] = (int32_t)ca;
     st_b[st] = (int32_t)cb;
+    const VC fa_ = A::coef(ca), fb_ = A::coef(cb);
 #pragma unroll
     for (int k = 0; k < C; k++) {
       if (ENC) {
-        const int64_t own = src[k], oth = cx_bperm_i64(from, own);
+        const VT own = src[k], oth = cx_bperm_v(from, own);
         if (partner)
-          src[k] = left ? fp_mul_c(oth, cb) + fp_mul_c(own, ca) : fp_mul_c(own, ca) - fp_mul_c(oth, cb);
+          src[k] = left ? A::mulc(oth, fb_) + A::mulc(own, fa_) : A::mulc(own, fa_) - A::mulc(oth, fb_);
       }
       {
-        const int64_t own = pred[k], oth = cx_bperm_i64(from, own);
+        const VT own = pred[k], oth = cx_bperm_v(from, own);
         // (a block's lanes share enable_pred)
         if (partner && enable_pred)
-          pred[k] = left ? fp_mul_c(oth, cb) + fp_mul_c(own, ca) : fp_mul_c(own, ca) - fp_mul_c(oth, cb);
+          pred[k] = left ? A::mulc(oth, fb_) + A::mulc(own, fa_) : A::mulc(own, fa_) - A::mulc(oth, fb_);
       }
     }
     if (partner) {
@@ -708,6 +737,7 @@ cx_level_tile(const CxCtx& cx, CxSmem& sm, int li, int tile)
     inv_lambda = 1.0 / (double)lambda;
   }
 
+  const typename A::Quant qaa[2] = {A::quant(qa[0]), A::quant(qa[1])};
   int32_t qco[C];
 #pragma unroll
   for (int k = 0; k < C; k++)
@@ -721,17 +751,19 @@ cx_level_tile(const CxCtx& cx, CxSmem& sm, int li, int tile)
         for (int k = 0; k < C; k++)
           src[k] -= pred[k];
       }
+      const typename A::Quant qra[2] = {A::quant(qr[0]), A::quant(qr[1])};
       int64_t sum_coeff = 0, dist2 = 0;
       int rate_coeff = 0;
 #pragma unroll
       for (int k = 0; k < C; k++) {
-        const int64_t co = fp_round(src[k]);
-        dist2 += co * co;
-        int64_t aq = quantize(qr[k ? 1 : 0], co * 256);
+        const VT co = A::round_int(src[k]);
+        const int64_t coi = A::to_small(co);  // (|co| < 2^20 inside the checked range)
+        dist2 += coi * coi;
+        int64_t aq = A::quantize(qra[k ? 1 : 0], co);
         aq = aq < 0 ? -aq : aq;
         sum_coeff += aq;
         rate_coeff += rate_log_small(aq);
-        qco[k] = (int32_t)quantize(qa[k ? 1 : 0], co * 256);
+        qco[k] = A::quantize(qaa[k ? 1 : 0], co);
       }
       d = kDescNever;
       if (sum_coeff < 3) {
@@ -929,12 +961,12 @@ cx_level_tile(const CxCtx& cx, CxSmem& sm, int li, int tile)
   if (!enable_pred) {
 #pragma unroll
     for (int k = 0; k < C; k++)
-      pred[k] = 0;
+      pred[k] = A::zero();
   }
   if (coded) {
 #pragma unroll
     for (int k = 0; k < C; k++)
-      pred[k] += fp_from_int(dequantize(qa[k ? 1 : 0], qco[k]));
+      pred[k] += A::dequant_fp(qaa[k ? 1 : 0], qco[k]);
   }
   if (on && inherit_dc && pos == 0) {
 #pragma unroll
@@ -942,15 +974,18 @@ cx_level_tile(const CxCtx& cx, CxSmem& sm, int li, int tile)
       pred[k] = pval[k];  // (tmc3/RAHT.cpp:1727-1742, extension)
   }
 
+#pragma unroll
+  for (int k = 0; k < C; k++)
+    in_range = in_range && (!on || A::below(pred[k], A::kInvLimit));
   // ---- inverse butterflies (tmc3/RAHT.cpp:707-737) -------------------------------------
 #pragma unroll
   for (int st = 2; st >= 0; st--) {
-    const int64_t ca = st_a[st], cb = st_b[st];
+    const VC ca = A::coef(st_a[st]), cb = A::coef(st_b[st]);
 #pragma unroll
     for (int k = 0; k < C; k++) {
-      const int64_t own = pred[k], oth = cx_bperm_i64(st_lane[st], own);
+      const VT own = pred[k], oth = cx_bperm_v(st_lane[st], own);
       if (st_both[st])
-        pred[k] = st_left[st] ? fp_mul_c(own, ca) - fp_mul_c(oth, cb) : fp_mul_c(oth, cb) + fp_mul_c(own, ca);
+        pred[k] = st_left[st] ? A::mulc(own, ca) - A::mulc(oth, cb) : A::mulc(oth, cb) + A::mulc(own, ca);
     }
   }
 
@@ -958,16 +993,21 @@ cx_level_tile(const CxCtx& cx, CxSmem& sm, int li, int tile)
   if (on) {
 #pragma unroll
     for (int k = 0; k < C; k++) {
-      int64_t v = pred[k];
-      cx.val[(size_t)cslot * C + k] = v;
+      VT v = pred[k];
+      cx.val[(size_t)cslot * C + k] = __builtin_bit_cast(int64_t, v);
       if (w > 1)
-        v = cx_scale(v, nm);
-      cx.rec[(size_t)cslot * C + k] = v;
+        v = cx_scale<A>(v, nm, nm_rs);
+      cx.rec[(size_t)cslot * C + k] = __builtin_bit_cast(int64_t, v);
     }
     cx.nn[cslot] = inherit_dc ? neigh_count : 19;
   }
   prof.mark(8);  // inverse butterflies, stores
   prof.count(12, 1);
+  // ArithF64: a value left the range in which doubles are exact -- the sticky word stops every later
+  // kernel of the call (the source attributes stay intact) and the call is redone with ArithI64
+  // (host tier) or reports GPCC_ERR_RANGE (device tier)
+  if (A::kF64 && __any(!in_range) && lane == 0)
+    atomicCAS(tv.error, 0, 3);
 }
 
 // One launch per level: a wavefront per tile.  Wavefronts per SIMD, measured on ten 1 M-point
@@ -975,7 +1015,7 @@ cx_level_tile(const CxCtx& cx, CxSmem& sm, int li, int tile)
 // registers) 3.38 / 3.24; at most 4: 3.50 / 3.17; at most 5: 3.36 / 2.93; 5-6: 3.30 / 2.91; exactly
 // 6: 3.37 / 2.80 -- so the encoder is asked for 5-6 and the one-component decoder for 6 (with more components six
 // wavefronts spill).
-template<int C, bool ENC>
+template<int C, bool ENC, class A = ArithI64>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ENC || C > 1) ? 5 : 6, 6))) void
 cx_level_kernel(CxCtx cx)
 {
@@ -983,7 +1023,7 @@ cx_level_kernel(CxCtx cx)
   if (tree_failed(cx.tv))
     return;
   cx_level_setup<C>(cx, sm, cx.li);
-  cx_level_tile<C, ENC>(cx, sm, cx.li, (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
+  cx_level_tile<C, ENC, A>(cx, sm, cx.li, (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
 }
 
 // The top levels -- a few tiles each, and a level needs the one above it -- in ONE launch of
@@ -993,7 +1033,7 @@ cx_level_kernel(CxCtx cx)
 // wrote are made visible to the whole workgroup (fence: write back, invalidate the L1) and
 // the level's tables are rebuilt.  Saves a launch and its latency per level: 7 of the 17
 // launches of a 10 x 1 M-point batch, 10 of a single frame's.
-template<int C, bool ENC>
+template<int C, bool ENC, class A = ArithI64>
 __global__ __launch_bounds__(256) void
 cx_top_kernel(CxCtx cx, int li_hi, int li_lo)
 {
@@ -1005,7 +1045,7 @@ cx_top_kernel(CxCtx cx, int li_hi, int li_lo)
     cx_level_setup<C>(cx, sm, li);
     const int ntiles = (cx.cl.tab->nr[li] + kCxG - 1) / kCxG;
     for (int tile = wave; tile < ntiles; tile += 4)
-      cx_level_tile<C, ENC>(cx, sm, li, tile);
+      cx_level_tile<C, ENC, A>(cx, sm, li, tile);
     __threadfence();
     __syncthreads();
   }

@@ -338,6 +338,7 @@ __global__ __launch_bounds__(256) void
 cx_emit_kernel(
   TreeView tv, const int32_t* __restrict__ attrs, CxLists cl, int32_t* attr_prefix)
 {
+  GPCC_VGPR_FLOOR_64();
   if (tree_failed(tv))
     return;
   const int lane = lane_id();

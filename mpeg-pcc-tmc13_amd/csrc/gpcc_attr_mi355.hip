@@ -925,6 +925,24 @@ dev_transform(
       w.c = c;
       w.nlev = std::min((bits + 2) / 3 + 1, (int)kMaxLevels);
       w.encoder = encoder;
+      {
+        // ArithF64 (raht_arith.hpp) is available to the compact level pass under the same condition as
+        // to the sub-node kernels below, but it is not the default here: measured on ten 1 M-point slices
+        // (round 4) the encoder is SLOWER in doubles (cx_level_enc 2.66 against 2.33 ms: 96 registers and
+        // 28 bytes of scratch at five wavefronts per SIMD, against 83 and none) and the decoder the same
+        // (1.98 / 2.03 ms) -- the pass spends its issue slots on the neighbour search, not on the
+        // products.  GPCC_CX_F64=1 selects it (tests/test_gpu_arith.py runs both).
+        static const bool cx_f64 = [] {
+          const char* e = getenv("GPCC_CX_F64");
+          return e && e[0] == '1';
+        }();
+        int64_t n_max = 1;
+        for (int i = 0; i < s; i++)
+          n_max = std::max(n_max, offsets[i + 1] - offsets[i]);
+        const int bdepth = 8 + std::max(0, (params->max_qp - 51 + 5) / 6);
+        w.f64 = cx_f64 && ctx->fast_arith && !ctx->force_exact
+          && 2 * bdepth + bitlen64((uint64_t)(n_max - 1)) <= 36;
+      }
       size_t used = 0;
       cx_carve([&](size_t bytes) { used += (bytes + 255) & ~size_t(255); return (char*)nullptr; }, w);
       rcode = ensure_arena(ctx, used);

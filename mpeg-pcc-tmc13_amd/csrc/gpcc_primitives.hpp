@@ -13,6 +13,20 @@
 
 #define GPCC_HD __host__ __device__ __forceinline__
 
+// A floor of 64 vector registers for a kernel's wavefronts.  finish_kernel in the 56-register
+// allocation its code arrives at gave wrong duplicate-chain coefficients on the MI355X in large
+// batches -- the SAME machine code is clean with 64 / 72 / 80 registers allocated, no instruction
+// changed (profiles/r04_finish_lds_root_cause.txt: asm re-assembly with only the descriptor edited).
+// Round 4 saw it again after an unrelated edit had changed the kernel's instruction stream (the
+// table form that had "never failed" did, in the pinned batch 144), so every kernel whose allocation
+// falls into that class (49..56 registers) and that runs long per-lane loops is raised to 64; it costs
+// nothing (eight wavefronts per SIMD either way).  tools/isa_audit.py lists the kernels of the class.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GPCC_VGPR_FLOOR_64() asm volatile("" ::: "v63")
+#else
+#define GPCC_VGPR_FLOOR_64() ((void)0)
+#endif
+
 namespace gpcc {
 
 constexpr int kFpFrac = 15;                 // FixedPoint::kFracBits

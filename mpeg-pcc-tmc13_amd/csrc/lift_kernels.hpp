@@ -351,6 +351,7 @@ template<int C>
 __global__ __launch_bounds__(256) void
 lift_quantise_kernel(LiftCtx cx, int encoder)
 {
+  GPCC_VGPR_FLOOR_64();
   __shared__ RsqrtLut lut;
   for (int i = threadIdx.x; i < 96; i += blockDim.x) {
     lut.r3[i] = cx.rsqrt->r3[i];

@@ -558,6 +558,7 @@ template<int C, bool ENC, bool INTER = false>
 __global__ __launch_bounds__(256) void
 pred_dag_kernel(PredCtx cx)
 {
+  GPCC_VGPR_FLOOR_64();
   const int lane = lane_id();
   const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(
     cx.rec, 0, (int)((size_t)cx.n * 16), 0x00020000);

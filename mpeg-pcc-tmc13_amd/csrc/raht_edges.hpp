@@ -60,6 +60,7 @@ template<int C>
 __global__ __launch_bounds__(256) void
 ascend_level_kernel(AscendCtx cx)
 {
+  GPCC_VGPR_FLOOR_64();
   const TreeView& tv = cx.tv;
   if (tree_failed(tv))
     return;
@@ -163,6 +164,7 @@ struct FinishCtx {
   const int32_t* dqp[2];
   // compact level pass (cx_level.hpp): the leaves' values live in value slots
   const int64_t* slot_rec;  // [2N][C] or null
+  int32_t slot_f64;         // the slots hold doubles' bit patterns (the pass ran in ArithF64)
   const uint32_t* hold0;    // [M0] slot of every leaf
   int32_t* attrs;   // in: source (encoder), out: reconstruction
   int32_t* coeffs;
@@ -206,6 +208,7 @@ template<int C>
 __global__ __launch_bounds__(256) void
 finish_kernel(FinishCtx cx)
 {
+  GPCC_VGPR_FLOOR_64();
   if (tree_failed(cx.tv))
     return;
   // The tables are read where lut_init_kernel left them (3 KB, cache resident; the chains of
@@ -279,6 +282,11 @@ finish_kernel(FinishCtx cx)
       rec[k] = !any_level ? 0
         : (cx.slot_rec ? cx.slot_rec[(size_t)(cx.hold0[j] & kCxSlotMask) * C + k]
                        : cx.rec[par][row * C + k]);
+    if (cx.slot_rec && cx.slot_f64) {
+#pragma unroll
+      for (int k = 0; k < C; k++)
+        rec[k] = (int64_t)__builtin_bit_cast(double, rec[k]);
+    }
 
     if (weight == 1) {
 #pragma unroll

@@ -397,6 +397,7 @@ __global__ __launch_bounds__(256) void
 rc_blend_kernel(RcCtx cx)
 {
 #pragma clang fp contract(off)
+  GPCC_VGPR_FLOOR_64();
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= cx.tgt.n)
     return;

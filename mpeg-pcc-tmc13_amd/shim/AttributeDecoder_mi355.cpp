@@ -10,9 +10,12 @@
 // reconstruction, so the whole slice is parsed first -- the reference's own
 // arithmetic decoder and context models, the residual syntax of shim_common.hpp --
 // and ONE device call (gpcc_lift_decode_attr / gpcc_pred_decode_attr: LoD build +
-// inverse transform) turns the values into the attributes.  Every other slice
-// (RAHT -- seam 1 --, raw, inter prediction, a partial geometry octree) goes to
-// the reference's decoder unchanged.
+// inverse transform) turns the values into the attributes.  Since round 4 an intra RAHT
+// slice without QP regions is decoded the same way (decodeColorsRaht / decodeReflectancesRaht
+// :613-674, 527-609): symbols parsed, then gpcc_raht_decode_attr -- Morton codes, sort,
+// inverse transform, clip, scatter -- in one device call.  Every other slice (raw, RAHT with
+// inter prediction or QP regions -- seam 1 --, a partial geometry octree) goes to the
+// reference's decoder unchanged.
 //
 // Built against the reference's headers; contains no reference code.
 #include <memory>
@@ -47,6 +50,7 @@ public:
   {
     const bool ours = aps.attr_encoding == AttributeEncoding::kLiftingTransform
       || aps.attr_encoding == AttributeEncoding::kPredictingTransform;
+    _first.note(aps, abh, inter);  // (shim_common.hpp FirstLods: what the reference's object would cache)
     if (ours) {
       // (scalable lifting: whole slices only -- no points skipped by a partial decode)
       const bool whole =
@@ -58,6 +62,12 @@ public:
       g_dec_cpu++;
       strict_check("the lifting / predicting attribute decoder");
     }
+    if (aps.attr_encoding == AttributeEncoding::kRAHTransform
+        && raht_on_device(sps, desc, aps, abh, payload, payloadLen, ctxtMem, cloud, inter)) {
+      g_dec_device++;
+      return;
+    }
+    ScopedLodOverride build_as_cached(_first);
     _cpu->decode(
       sps, desc, aps, abh, geom_num_points_minus1, minGeomNodeSizeLog2, payload, payloadLen,
       ctxtMem, cloud, inter);
@@ -65,7 +75,7 @@ public:
 
   bool isReusable(const AttributeParameterSet& aps, const AttributeBrickHeader& abh) const override
   {
-    return _cpu->isReusable(aps, abh);
+    return _first.reusable(aps, abh);
   }
 
 private:
@@ -82,7 +92,9 @@ private:
       return false;
     gpcc_ctx* ctx = process_context("the attribute decoder");
     gpcc_lod_params lod;
-    if (!ctx || !flatten_lod(aps, abh, minGeomNodeSizeLog2, inter, &lod, true))
+    if (_first.inter != interSlice)
+      return false;
+    if (!ctx || !flatten_lod(_first.aps, _first.abh, minGeomNodeSizeLog2, inter, &lod, true))
       return false;
     const QpSet qpSet = deriveQpSet(desc, aps, abh);
     const bool lifting = aps.attr_encoding == AttributeEncoding::kLiftingTransform;
@@ -110,7 +122,7 @@ private:
     int rc;
     InterStructure is;
     if (interSlice) {
-      rc = build_inter_structure(ctx, lod, xyz, n, abh, inter, &is);
+      rc = build_inter_structure(ctx, lod, xyz, n, _first.abh, inter, &is);
       if (!rc && lifting) {
         lp.bitdepth = desc.bitdepth;
         lp.fixed_point_qp_offset = qpSet.fixedPointQpOffset;
@@ -170,7 +182,56 @@ private:
     return true;
   }
 
+  // ---- an intra RAHT slice -----------------------------------------------------------------
+  bool raht_on_device(
+    const SequenceParameterSet& sps, const AttributeDescription& desc,
+    const AttributeParameterSet& aps, const AttributeBrickHeader& abh, const char* payload,
+    size_t payloadLen, AttributeContexts& ctxtMem, PCCPointSet3& cloud, AttributeInterPredParams& inter)
+  {
+    const int c = desc.attr_num_dimensions_minus1 + 1;
+    const int n = int(cloud.getPointCount());
+    if ((c != 1 && c != 3) || n <= 0 || inter.enableAttrInterPred)
+      return false;
+    const QpSet qpSet = deriveQpSet(desc, aps, abh);
+    gpcc_raht_params rp;
+    if (!qpSet.regions.empty() || !flatten_raht(aps.rahtPredParams, qpSet, aps.raht_extension, inter, &rp))
+      return false;
+    gpcc_ctx* ctx = process_context("the attribute decoder");
+    if (!ctx)
+      return false;
+    SliceContexts models(ctxtMem);
+    EntropyDecoder ac;
+    ac.setBuffer(payloadLen, payload);
+    ac.enableBypassStream(sps.cabac_bypass_stream_enabled_flag);
+    ac.setBypassBinCodingWithoutProbUpdate(sps.bypass_bin_coding_without_prob_update);
+    ac.start();
+    // the symbols come point by point in Morton order; the transform reads them planar [c][n]
+    std::vector<int32_t> values(size_t(c) * n), coeffs;
+    models.parse_slice(ac, n, c, values.data());
+    ac.stop();
+    const int32_t* co = values.data();
+    if (c == 3) {
+      coeffs.resize(size_t(c) * n);
+      for (int i = 0; i < n; i++)
+        for (int k = 0; k < 3; k++)
+          coeffs[size_t(k) * n + i] = values[size_t(3) * i + k];
+      co = coeffs.data();
+    }
+    std::vector<int32_t> xyz, attrs(size_t(c) * n);
+    positions_of(cloud, &xyz);
+    const int rc = gpcc_raht_decode_attr(ctx, &rp, xyz.data(), attrs.data(), co, n, c, desc.bitdepth);
+    if (rc) {
+      if (rc != GPCC_ERR_UNSUPPORTED)
+        std::fprintf(stderr, "gpcc: %s; the attribute decoder falls back to the CPU\n", gpcc_last_error());
+      return false;
+    }
+    store_attributes(attrs, c, &cloud);
+    ctxtMem = models.saved();
+    return true;
+  }
+
   std::unique_ptr<AttributeDecoderIntf> _cpu;
+  FirstLods _first;
 };
 
 }  // namespace

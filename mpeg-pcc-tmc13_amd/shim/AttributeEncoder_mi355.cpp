@@ -1,11 +1,12 @@
 // AttributeEncoder_mi355.cpp -- seam 3, encoder side: the operator behind
 //   pcc::makeAttributeEncoder()                       (tmc3/Attribute.h:107,
 //                                                      AttributeEncoder.cpp:456-460)
-// for the LIFTING and PREDICTING transforms.  The reference's slice drivers for
-// those (encodeColorsLift / encodeReflectancesLift AttributeEncoder.cpp:1379-1494,
-// 1543-1648; encodeColorsPred / encodeReflectancesPred :1075-1210, 749-853) are
-// private members that interleave transform and entropy coder, so they are not
-// a link seam; the FACTORY is.  The integrator compiles tmc3/AttributeEncoder.cpp
+// for the LIFTING and PREDICTING transforms and, since round 4, for RAHT slices.  The
+// reference's slice drivers (encodeColorsLift / encodeReflectancesLift
+// AttributeEncoder.cpp:1379-1494, 1543-1648; encodeColorsPred / encodeReflectancesPred
+// :1075-1210, 749-853; encodeColorsTransformRaht / encodeReflectancesTransformRaht
+// :1306-1375, 1214-1302) are private members that interleave transform and entropy coder,
+// so they are not a link seam; the FACTORY is.  The integrator compiles tmc3/AttributeEncoder.cpp
 // with -DmakeAttributeEncoder=makeAttributeEncoderCpu (the reference class
 // stays in the link, reachable through the renamed factory) and adds this
 // translation unit, which defines makeAttributeEncoder() with the original
@@ -20,8 +21,12 @@
 //     what AttributeEncoder::encode (:466-634) does around its drivers
 //     (deriveQpSet, the brick header, the payload, the saved contexts) is
 //     repeated here through the reference's public functions;
-//   * hands every other slice (RAHT -- which reaches the device through seam 1 --,
-//     raw, inter prediction, ...) to the reference's encoder unchanged.
+//   * for an intra RAHT slice without QP regions runs the WHOLE slice driver on the device
+//     (gpcc_raht_encode_attr_packed: Morton codes, sort, transform, clip, scatter, zero runs)
+//     + gpcc_binarise_symbols, and replays the decisions the same way -- through seam 1 alone
+//     the reference's host-side std::sort and entropy loop were 127 of the slice's 143 ms;
+//   * hands every other slice (raw, RAHT with inter prediction or QP regions -- which still
+//     reach the device's transform through seam 1 --, ...) to the reference's encoder unchanged.
 //
 // Built against the reference's headers; contains no reference code.
 #include <memory>
@@ -59,6 +64,7 @@ public:
   {
     const bool ours = aps.attr_encoding == AttributeEncoding::kLiftingTransform
       || aps.attr_encoding == AttributeEncoding::kPredictingTransform;
+    _first.note(aps, abh, inter);  // (the structure this object's reference twin would cache from here on)
     if (ours) {
       if (on_device(sps, desc, aps, abh, ctxtMem, cloud, payload, inter)) {
         g_enc_device++;
@@ -67,14 +73,20 @@ public:
       g_enc_cpu++;
       strict_check("the lifting / predicting attribute encoder");
     }
+    // RAHT: declined slices (inter prediction, QP regions) are not counted as fall-backs of
+    // this seam -- the reference's driver then calls seam 1, which keeps its own counters
+    if (aps.attr_encoding == AttributeEncoding::kRAHTransform
+        && raht_on_device(sps, desc, aps, abh, ctxtMem, cloud, payload, inter)) {
+      g_enc_device++;
+      return;
+    }
+    ScopedLodOverride build_as_cached(_first);
     _cpu->encode(sps, desc, aps, abh, ctxtMem, cloud, payload, inter);
   }
 
-  // the LoD structure is built with every slice on the device and not kept, so
-  // what decides is the reference encoder's own cache (slices it coded itself)
   bool isReusable(const AttributeParameterSet& aps, const AttributeBrickHeader& abh) const override
   {
-    return _cpu->isReusable(aps, abh);
+    return _first.reusable(aps, abh);
   }
 
 private:
@@ -93,7 +105,10 @@ private:
       return false;
     gpcc_ctx* ctx = process_context("the attribute encoder");
     gpcc_lod_params lod;
-    if (!ctx || !flatten_lod(aps, abh, 0, inter, &lod, true))
+    // the structure: of the parameters the reference's cache was (would have been) built with
+    if (_first.inter != interSlice)
+      return false;
+    if (!ctx || !flatten_lod(_first.aps, _first.abh, 0, inter, &lod, true))
       return false;
     const QpSet qpSet = deriveQpSet(desc, aps, abh);
     const bool lifting = aps.attr_encoding == AttributeEncoding::kLiftingTransform;
@@ -106,7 +121,7 @@ private:
     int8_t lcp[GPCC_MAX_LODS] = {};
     int8_t icp[GPCC_MAX_LODS][3] = {};
     InterStructure is;
-    if (interSlice && build_inter_structure(ctx, lod, xyz, n, abh, inter, &is))
+    if (interSlice && build_inter_structure(ctx, lod, xyz, n, _first.abh, inter, &is))
       return declined();
     if (interSlice && lifting) {
       gpcc_lift_params lp{};
@@ -216,6 +231,74 @@ private:
     return true;
   }
 
+  // ---- an intra RAHT slice: what AttributeEncoder::encode (:466-634) does around
+  //      encode{Colors,Reflectances}TransformRaht, with the driver itself on the device ---------
+  bool raht_on_device(
+    const SequenceParameterSet& sps, const AttributeDescription& desc,
+    const AttributeParameterSet& aps, AttributeBrickHeader& abh,
+    AttributeContexts& ctxtMem, PCCPointSet3& cloud, PayloadBuffer* payload,
+    AttributeInterPredParams& inter)
+  {
+    const int c = desc.attr_num_dimensions_minus1 + 1;
+    const int n = int(cloud.getPointCount());
+    if ((c != 1 && c != 3) || n <= 0 || inter.enableAttrInterPred || inter.codeAttributeSecondPass())
+      return false;
+    const QpSet qpSet = deriveQpSet(desc, aps, abh);
+    gpcc_raht_params rp;
+    // (QP regions: the one-call entry takes the region offsets as zero)
+    if (!qpSet.regions.empty() || !flatten_raht(aps.rahtPredParams, qpSet, aps.raht_extension, inter, &rp))
+      return false;
+    gpcc_ctx* ctx = process_context("the attribute encoder");
+    if (!ctx)
+      return false;
+    std::vector<int32_t> xyz, attrs;
+    positions_of(cloud, &xyz);
+    attributes_of(cloud, c, &attrs);
+    std::vector<int32_t> runs(n), syms(size_t(c) * n);
+    int32_t num_symbols = 0, trailing = 0;
+    if (gpcc_raht_encode_attr_packed(
+          ctx, &rp, xyz.data(), attrs.data(), runs.data(), syms.data(), &num_symbols, &trailing, n, c,
+          desc.bitdepth))
+      return declined();
+    int64_t num_bins = 0;
+    std::vector<uint8_t> bins(size_t(num_symbols) * (c == 3 ? 24 : 12) + 1024);
+    int rc = gpcc_binarise_symbols(
+      ctx, runs.data(), syms.data(), num_symbols, trailing, c, bins.data(), int64_t(bins.size()), &num_bins);
+    if (rc && num_bins > int64_t(bins.size())) {
+      bins.resize(size_t(num_bins));
+      rc = gpcc_binarise_symbols(
+        ctx, runs.data(), syms.data(), num_symbols, trailing, c, bins.data(), int64_t(bins.size()), &num_bins);
+    }
+    if (rc)
+      return declined();
+
+    // ---- nothing can decline any more: header, payload, contexts, reconstruction ---------
+    if (c == 1)
+      inter.paramsForInterRAHT.FilterTaps.clear();  // (:1236: the reflectance driver does, the colour one does not)
+    abh.raht_attr_layer_code_mode = inter.attr_layer_code_mode;
+    SliceContexts models(ctxtMem);
+    EntropyEncoder ac;
+    ac.setBuffer(n * 3 * 2 + 1024, nullptr);
+    ac.enableBypassStream(sps.cabac_bypass_stream_enabled_flag);
+    ac.setBypassBinCodingWithoutProbUpdate(sps.bypass_bin_coding_without_prob_update);
+    ac.start();
+    for (int64_t i = 0; i < num_bins; i++) {
+      const int id = bins[i] >> 1, bin = bins[i] & 1;
+      if (id == 31)
+        ac.encode(bin);
+      else
+        ac.encode(bin, models.model(id));
+    }
+    const uint32_t len = ac.stop();
+    abh.RAHTFilterTaps.assign(
+      inter.paramsForInterRAHT.FilterTaps.begin(), inter.paramsForInterRAHT.FilterTaps.end());
+    write(sps, aps, abh, payload);
+    payload->insert(payload->end(), ac.buffer(), ac.buffer() + len);
+    ctxtMem = models.saved();
+    store_attributes(attrs, c, &cloud);
+    return true;
+  }
+
   static bool declined()
   {
     if (gpcc_last_error()[0])
@@ -224,6 +307,7 @@ private:
   }
 
   std::unique_ptr<AttributeEncoderIntf> _cpu;
+  FirstLods _first;
 };
 
 }  // namespace

@@ -37,10 +37,16 @@ namespace pcc {
 
 void
 AttributeLods::generate(
-  const AttributeParameterSet& aps, const AttributeBrickHeader& abh,
+  const AttributeParameterSet& aps_in, const AttributeBrickHeader& abh_in,
   int geom_num_points_minus1, int minGeomNodeSizeLog2,
   const PCCPointSet3& cloud, const AttributeInterPredParams& attrInterPredParams)
 {
+  // (seam 3 hands a slice to the reference's coder whose cache is empty although its object has
+  // coded a LoD-based attribute on the device: the structure of THAT attribute's parameters,
+  // shim_common.hpp FirstLods)
+  const auto& ov = gpcc_shim::lod_override();
+  const AttributeParameterSet& aps = ov.aps ? *ov.aps : aps_in;
+  const AttributeBrickHeader& abh = ov.abh ? *ov.abh : abh_in;
   gpcc_lod_params lp;
   gpcc_ctx* ctx = gpcc_shim::process_context("the LoD build");
   const int n = int(cloud.getPointCount());

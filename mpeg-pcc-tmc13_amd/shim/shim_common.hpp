@@ -92,6 +92,128 @@ flatten_lod(
   return true;
 }
 
+// The LoD structure an attribute coder object of the reference CACHES: AttributeEncoder / AttributeDecoder
+// generate `_lods` for the first LoD-based attribute they code and every later attribute coded by the same
+// object runs over that structure (AttributeEncoder.cpp:484-490, AttributeDecoder.cpp:217-221:
+// `if (aps.lodParametersPresent() && _lods.empty()) _lods.generate(...)`), whatever its own parameter set
+// says; the caller replaces the object when AttributeLods::isReusable (AttributeCommon.cpp:76-139) says
+// no -- a test that does NOT compare attr_encoding (weight blending and the search inside a LoD belong to
+// the predicting transform), predictionWithDistributionEnabled or the inter-prediction state.  The device
+// entries build the structure with every call, so the factories' objects remember under WHICH parameters
+// the reference's cached structure was built and build with those.
+struct FirstLods {
+  bool have = false;
+  pcc::AttributeParameterSet aps;
+  pcc::AttributeBrickHeader abh;
+  bool inter = false;
+
+  void note(
+    const pcc::AttributeParameterSet& a, const pcc::AttributeBrickHeader& b,
+    const pcc::AttributeInterPredParams& ip)
+  {
+    if (have || !a.lodParametersPresent())
+      return;
+    have = true;
+    aps = a;
+    abh = b;
+    inter = ip.enableAttrInterPred;
+  }
+
+  // AttributeLods::isReusable over what `note` recorded: the interface contract of
+  // AttributeEncoderIntf::isReusable (Attribute.h:101-103), field by field as the reference compares them
+  bool reusable(const pcc::AttributeParameterSet& a, const pcc::AttributeBrickHeader& b) const
+  {
+    if (!have || !a.lodParametersPresent())
+      return true;
+    if (aps.scalable_lifting_enabled_flag || a.scalable_lifting_enabled_flag)
+      return false;
+    return aps.num_pred_nearest_neighbours_minus1 == a.num_pred_nearest_neighbours_minus1
+      && aps.inter_lod_search_range == a.inter_lod_search_range
+      && aps.intra_lod_search_range == a.intra_lod_search_range
+      && aps.num_detail_levels_minus1 == a.num_detail_levels_minus1 && aps.lodNeighBias == a.lodNeighBias
+      && aps.lod_decimation_type == a.lod_decimation_type
+      && aps.dist2 + abh.attr_dist2_delta == a.dist2 + b.attr_dist2_delta
+      && aps.lodSamplingPeriod == a.lodSamplingPeriod
+      && aps.intra_lod_prediction_skip_layers == a.intra_lod_prediction_skip_layers
+      && aps.canonical_point_order_flag == a.canonical_point_order_flag
+      && aps.max_points_per_sort_log2_plus1 == a.max_points_per_sort_log2_plus1
+      && aps.pred_weight_blending_enabled_flag == a.pred_weight_blending_enabled_flag;
+  }
+};
+
+// While a factory object hands a slice to the reference's coder, the structure that coder generates must
+// be the one its cache WOULD hold: seam 2 (AttributeLods_mi355.cpp) builds with these parameter sets
+// instead of the ones it is called with.  (One instance per shared object; the reference is single threaded.)
+struct LodOverride {
+  const pcc::AttributeParameterSet* aps = nullptr;
+  const pcc::AttributeBrickHeader* abh = nullptr;
+};
+inline LodOverride&
+lod_override()
+{
+  static LodOverride o;
+  return o;
+}
+struct ScopedLodOverride {
+  explicit ScopedLodOverride(const FirstLods& f)
+  {
+    if (f.have) {
+      lod_override().aps = &f.aps;
+      lod_override().abh = &f.abh;
+    }
+  }
+  ~ScopedLodOverride() { lod_override() = LodOverride{}; }
+};
+
+// RahtPredictionParams + QpSet (hls.h, quantization.h:124-139) -> gpcc_raht_params, for an intra slice.
+// false: the block cannot express these parameters (or the slice uses attribute inter prediction,
+// which is not on the device for RAHT) -> CPU path
+inline bool
+flatten_raht(
+  const pcc::RahtPredictionParams& rp, const pcc::QpSet& qs, bool extension,
+  const pcc::AttributeInterPredParams& inter, gpcc_raht_params* p)
+{
+  if (inter.enableAttrInterPred)
+    return false;
+  if (rp.predWeightParent.size() != 19)
+    return false;
+  if (rp.raht_subnode_prediction_enabled_flag && rp.predWeightChild.size() != 12)
+    return false;
+  if (qs.layers.empty() || qs.layers.size() > GPCC_MAX_QP_LAYERS)
+    return false;
+  if (qs.rahtAcCoeffQps.size() > GPCC_MAX_AC_QP_LAYERS)
+    return false;
+  *p = gpcc_raht_params{};
+  p->raht_prediction_enabled_flag = rp.raht_prediction_enabled_flag;
+  p->integer_haar_enable_flag = rp.integer_haar_enable_flag;
+  p->raht_prediction_threshold0 = rp.raht_prediction_threshold0;
+  p->raht_prediction_threshold1 = rp.raht_prediction_threshold1;
+  p->raht_subnode_prediction_enabled_flag = rp.raht_subnode_prediction_enabled_flag;
+  p->raht_prediction_search_range = rp.raht_prediction_search_range;
+  for (int i = 0; i < 19; i++)
+    p->pred_weight_parent[i] = rp.predWeightParent[i];
+  for (size_t i = 0; i < 12 && i < rp.predWeightChild.size(); i++)
+    p->pred_weight_child[i] = rp.predWeightChild[i];
+  p->raht_extension = extension;
+  p->num_qp_layers = int(qs.layers.size());
+  for (size_t i = 0; i < qs.layers.size(); i++) {
+    p->layer_qp[i][0] = qs.layers[i][0];
+    p->layer_qp[i][1] = qs.layers[i][1];
+  }
+  p->max_qp = qs.maxQp;
+  p->fixed_point_qp_offset = qs.fixedPointQpOffset;
+  p->num_ac_qp_layers = int(qs.rahtAcCoeffQps.size());
+  for (size_t i = 0; i < qs.rahtAcCoeffQps.size(); i++) {
+    if (qs.rahtAcCoeffQps[i].size() != 7)
+      return false;
+    for (int j = 0; j < 7; j++) {
+      p->ac_qp_offset[i][j][0] = qs.rahtAcCoeffQps[i][j][0];
+      p->ac_qp_offset[i][j][1] = qs.rahtAcCoeffQps[i][j][1];
+    }
+  }
+  return true;
+}
+
 // QpSet (quantization.h:124-139) -> the layer table of gpcc_lift_params /
 // gpcc_pred_params.  false: more layers than the block holds, or QP regions
 // (the one-call entries take the region offsets as zero)

@@ -23,6 +23,7 @@ cx_emu_supported(const gpcc_raht_params* p, int has_qp, int64_t n)
 }
 
 // attrs: in source (encoder) / out reconstruction; coeffs: planar per slice
+// encoder: bit 0 = encoder, bit 1 = the level kernels in ArithF64 (raht_arith.hpp)
 extern "C" int
 cx_emu_transform(
   const gpcc_raht_params* params, int encoder, int32_t num_slices, const int64_t* offsets,
@@ -35,7 +36,8 @@ cx_emu_transform(
   w.c = c;
   const int bits = morton_bits > 0 ? std::min(morton_bits, 63) : 63;
   w.nlev = std::min((bits + 2) / 3 + 1, (int)kMaxLevels);
-  w.encoder = encoder != 0;
+  w.encoder = (encoder & 1) != 0;
+  w.f64 = (encoder & 2) != 0;
   std::vector<void*> blocks;
   cx_carve(
     [&](size_t bytes) {
@@ -232,10 +234,10 @@ cx_emu_check_coeffs(int64_t max_exhaustive, int64_t num_random, uint64_t seed)
     if (nm.sq != sqrt_weight((int32_t)w, *lut))
       fail("sqrt_weight", w, 0, nm.sq, sqrt_weight((int32_t)w, *lut));
     const int64_t v = 123456789 + 7919 * w;
-    if (w > 1 && cx_scale(v, nm) != scale_rsqrt(v, (int32_t)w, *lut))
-      fail("scale_rsqrt", w, 0, cx_scale(v, nm), scale_rsqrt(v, (int32_t)w, *lut));
-    if (w > 1 && cx_scale(-v, nm) != scale_rsqrt(-v, (int32_t)w, *lut))
-      fail("scale_rsqrt(-)", w, 0, cx_scale(-v, nm), scale_rsqrt(-v, (int32_t)w, *lut));
+    if (w > 1 && cx_scale<ArithI64>(v, nm, nm.rs) != scale_rsqrt(v, (int32_t)w, *lut))
+      fail("scale_rsqrt", w, 0, cx_scale<ArithI64>(v, nm, nm.rs), scale_rsqrt(v, (int32_t)w, *lut));
+    if (w > 1 && cx_scale<ArithI64>(-v, nm, nm.rs) != scale_rsqrt(-v, (int32_t)w, *lut))
+      fail("scale_rsqrt(-)", w, 0, cx_scale<ArithI64>(-v, nm, nm.rs), scale_rsqrt(-v, (int32_t)w, *lut));
   }
   uint64_t x = seed | 1;
   auto rnd = [&]() {

@@ -176,6 +176,27 @@ def ref_operator_roundtrip(lp, transform, rp, qp, chroma, bitdepth, lcp, xyz, at
     return pay[:ln].tobytes(), re.reshape(n, c), rd.reshape(n, c)
 
 
+def ref_two_attr_roundtrip(lp_a, transform_a, lp_b, transform_b, qp, xyz, colours, refl, lib=None):
+    """colour (parameter set A) then reflectance (B) of one slice through the operator the way the
+    reference's encoder / decoder drive it: the same coder object serves B when isReusable(B) says so.
+    -> (both payloads back to back, (rec colour, rec reflectance) of the encoder, of the decoder,
+    (encoder object kept, decoder object kept))"""
+    lib = lib or ol.ref().lib
+    lib.ref_two_attr_roundtrip.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, i32p, i32p, i32p,
+                                           C.c_int32, i32p, i32p, i32p, i32p, u8p, C.c_int32, i32p]
+    xyz = np.ascontiguousarray(xyz, dtype=np.int32)
+    colours = np.ascontiguousarray(colours, dtype=np.int32)
+    refl = np.ascontiguousarray(refl, dtype=np.int32).reshape(-1)
+    n = len(xyz)
+    out = [np.zeros(3 * n, np.int32), np.zeros(n, np.int32), np.zeros(3 * n, np.int32), np.zeros(n, np.int32)]
+    pay = np.zeros(n * 4 * 8 + 8192, np.uint8)
+    reused = np.zeros(2, np.int32)
+    ln = lib.ref_two_attr_roundtrip(C.addressof(lp_a), transform_a, C.addressof(lp_b), transform_b, qp, xyz.reshape(-1),
+                                    colours.reshape(-1), refl, n, out[0], out[1], out[2], out[3], pay, pay.size, reused)
+    assert 0 < ln <= pay.size
+    return pay[:ln].tobytes(), (out[0].reshape(n, 3), out[1]), (out[2].reshape(n, 3), out[3]), tuple(int(v) for v in reused)
+
+
 def oracle_estimate_dist2(xyz, period=100, search_range=128, percentile=0.85):
     lib = ol.oracle().lib
     xyz = np.ascontiguousarray(xyz, dtype=np.int32)

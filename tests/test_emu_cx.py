@@ -21,14 +21,20 @@ def test_case_table_has_eligible_cases():
     assert len(ELIGIBLE) >= 6
 
 
+# both arithmetic back ends of the level kernels (raht_arith.hpp): int64 fixed point, and doubles
+# where they are exact (what the library picks for attributes of at most 10 bits)
+F64 = pytest.mark.parametrize("f64", [False, True], ids=["i64", "f64"])
+
+
+@F64
 @pytest.mark.parametrize("case", ELIGIBLE, ids=[c["name"] for c in ELIGIBLE])
-def test_emulated_kernels_match_the_oracle(case):
+def test_emulated_kernels_match_the_oracle(case, f64):
     p, morton, attrs, _ = rc.make_inputs(case)
     o_co, o_rec = ol.oracle().raht_forward(p, morton, attrs)
-    co, rec = emu.forward(p, morton, attrs)
+    co, rec = emu.forward(p, morton, attrs, f64=f64)
     assert np.array_equal(co, o_co)
     assert np.array_equal(rec, o_rec)
-    assert np.array_equal(emu.inverse(p, morton, o_co, attrs.shape[1]), o_rec)
+    assert np.array_equal(emu.inverse(p, morton, o_co, attrs.shape[1], f64=f64), o_rec)
 
 
 VARIANTS = [dict(search_range=8), dict(threshold0=4, threshold1=10), dict(weights=(4, 2, 1, 3, 1)),
@@ -37,9 +43,10 @@ VARIANTS = [dict(search_range=8), dict(threshold0=4, threshold1=10), dict(weight
             dict(qp=40, bitdepth=10), dict(qp=10), dict(prediction=False, qp=28)]
 
 
+@F64
 @pytest.mark.parametrize("vi", range(len(VARIANTS)))
 @pytest.mark.parametrize("c", [1, 3])
-def test_parameter_variants(vi, c):
+def test_parameter_variants(vi, c, f64):
     kw = dict(VARIANTS[vi])
     kw.setdefault("subnode", False)
     xyz, attrs = synth.random_cloud(n=1500 + 100 * vi, seed=20 + vi, bits=5, c=c,
@@ -47,9 +54,9 @@ def test_parameter_variants(vi, c):
     morton, attrs, _ = synth.sort_by_morton(xyz, attrs)
     p = raht_params(**kw)
     o_co, o_rec = ol.oracle().raht_forward(p, morton, attrs)
-    co, rec = emu.forward(p, morton, attrs)
+    co, rec = emu.forward(p, morton, attrs, f64=f64)
     assert np.array_equal(co, o_co) and np.array_equal(rec, o_rec)
-    assert np.array_equal(emu.inverse(p, morton, o_co, c), o_rec)
+    assert np.array_equal(emu.inverse(p, morton, o_co, c, f64=f64), o_rec)
 
 
 def _batch(sizes, c, seed):
@@ -71,12 +78,13 @@ def _batch(sizes, c, seed):
 @pytest.mark.parametrize("sizes,c", [([1, 2, 3, 700, 57, 64, 5000, 1, 333, 9, 2100], 1),
                                      (list(np.random.default_rng(5).integers(1, 40, size=150)), 3)],
                          ids=["ragged11", "tiny150"])
-def test_ragged_batches(sizes, c):
+@F64
+def test_ragged_batches(sizes, c, f64):
     """slices of 1..5000 points in one batch (more than 64 slices: the plans are read
     from memory instead of LDS), every slice against the oracle"""
     p = raht_params(subnode=False, search_range=2500)
     parts, morton, attrs, offs = _batch(sizes, c, 30)
-    co, rec = emu.forward(p, morton, attrs, offsets=offs)
+    co, rec = emu.forward(p, morton, attrs, offsets=offs, f64=f64)
     dec_in = np.zeros_like(co)
     for i, (m, a) in enumerate(parts):
         o_co, o_rec = ol.oracle().raht_forward(p, m, a)
@@ -84,11 +92,12 @@ def test_ragged_batches(sizes, c):
         assert np.array_equal(co[c * s0:c * s1], o_co), f"slice {i}"
         assert np.array_equal(rec[s0:s1], o_rec), f"slice {i}"
         dec_in[c * s0:c * s1] = o_co
-    assert np.array_equal(emu.inverse(p, morton, dec_in, c, offsets=offs), rec)
+    assert np.array_equal(emu.inverse(p, morton, dec_in, c, offsets=offs, f64=f64), rec)
 
 
+@F64
 @pytest.mark.parametrize("c", [1, 3])
-def test_long_duplicate_chains_late_in_a_batch(c):
+def test_long_duplicate_chains_late_in_a_batch(c, f64):
     """slices of a handful of voxels with a hundred points each (finish_kernel's chains of
     (w, 1) transforms, weights beyond the small-weight tables) behind larger slices: the
     shape whose first chain coefficients came out wrong on the device in round 3
@@ -103,8 +112,8 @@ def test_long_duplicate_chains_late_in_a_batch(c):
         ms.append(m)
         as_.append(a)
     offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
-    co, rec = emu.forward(p, np.concatenate(ms), np.concatenate(as_), offsets)
-    inv = emu.inverse(p, np.concatenate(ms), co, c, offsets)
+    co, rec = emu.forward(p, np.concatenate(ms), np.concatenate(as_), offsets, f64=f64)
+    inv = emu.inverse(p, np.concatenate(ms), co, c, offsets, f64=f64)
     o = ol.oracle()
     for i, n in enumerate(sizes):
         o_co, o_rec = o.raht_forward(p, ms[i], as_[i])
@@ -112,6 +121,22 @@ def test_long_duplicate_chains_late_in_a_batch(c):
         assert np.array_equal(co[c * b:c * (b + n)], o_co), f"slice {i}"
         assert np.array_equal(rec[b:b + n], o_rec), f"slice {i}"
         assert np.array_equal(inv[b:b + n], o_rec), f"slice {i}"
+
+
+def test_values_beyond_the_exact_range_are_reported():
+    """ArithF64 with attributes far wider than the dispatcher admits (24 bits): the kernels' range
+    check raises the sticky word (the harness returns -103) instead of handing out a different result;
+    the same input in int64 is the oracle's"""
+    rng = np.random.default_rng(3)
+    xyz, _ = synth.random_cloud(n=3000, seed=77, bits=5, c=1)
+    attrs = rng.integers(0, 1 << 24, size=(len(xyz), 1)).astype(np.int32)
+    morton, attrs, _ = synth.sort_by_morton(xyz, attrs)
+    p = raht_params(subnode=False, qp=40)
+    with pytest.raises(AssertionError):
+        emu.forward(p, morton, attrs, f64=True)
+    o_co, o_rec = ol.oracle().raht_forward(p, morton, attrs)
+    co, rec = emu.forward(p, morton, attrs)
+    assert np.array_equal(co, o_co) and np.array_equal(rec, o_rec)
 
 
 @pytest.mark.parametrize("n,bits,slices", [(1000, 12, 1), (5000, 30, 1), (3000, 9, 3), (70000, 36, 2),

@@ -52,6 +52,14 @@ def unmodified(case):
     import lod_helpers as lh
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import shim_operator_worker as w
+    if case.get("two_attr"):
+        xyz, col, refl, lpa, ta, lpb, tb = w.two_attr_case(case)
+        payload, enc2, dec2, reused = lh.ref_two_attr_roundtrip(lpa, ta, lpb, tb, case["qp"], xyz, col, refl)
+        rec_enc = np.concatenate([enc2[0].reshape(-1), enc2[1]])
+        rec_dec = np.concatenate([dec2[0].reshape(-1), dec2[1]])
+        np.testing.assert_array_equal(rec_enc, rec_dec)
+        assert reused == tuple(case.get("expect_reused", (1, 1)))
+        return hashlib.md5(payload).hexdigest(), len(payload), w.digest(rec_enc)
     if case.get("inter"):
         xyz, attrs, xr, ar, lp = w.inter_case(case)
         payload, rec_enc, rec_dec = lh.ref_inter_roundtrip(lp, case["transform"], case["qp"], 8, case.get("direct", 3), xyz, attrs,
@@ -139,7 +147,13 @@ CASES3 = {
     "pred_lidar_refl_ctc": dict(transform=1, pred_case="lidar_refl_ctc"),
     "pred_dense_nodirect_qnw": dict(transform=1, pred_case="dense_nodirect_qnw"),
     "pred_dense_scalable": dict(transform=1, pred_case="dense_scalable"),
+    # RAHT slices (round 4): the whole slice driver on the device -- Morton sort, transform, zero runs,
+    # binarisation -- colour and reflectance, default flags / sub-node prediction off / integer Haar
     "raht_colour_sub0": dict(cloud="dense", n=60_000, seed=6, transform=0, qp=40, chroma=-1, subnode=0, search_range=50000),
+    "raht_colour_100k": dict(cloud="dense", n=100_000, seed=4, transform=0, qp=34, chroma=-1, subnode=1, search_range=50000),
+    "raht_refl_lidar_100k": dict(cloud="lidar", n=100_000, seed=5, transform=0, qp=34, chroma=0, subnode=1, search_range=2500),
+    "raht_haar_lossless": dict(cloud="dense", n=50_000, seed=7, transform=0, qp=4, chroma=0, subnode=1, haar=1, search_range=50000),
+    "raht_refl_lidar_qp22": dict(cloud="lidar", n=80_000, seed=12, transform=0, qp=22, chroma=0, subnode=1, search_range=2500),
 }
 
 
@@ -173,8 +187,8 @@ def test_operator_factories_inter_slice_falls_back_without_gpu():
 @pytest.mark.parametrize("name", list(CASES3))
 def test_operator_bitstream_identical_with_device_coders_inside(name):
     """makeAttributeEncoder() / makeAttributeDecoder() of the drop-in build: transform, zero
-    runs and binarisation of a lifting / predicting slice on the MI355X, the decisions on the
-    reference's arithmetic coder -- payload and reconstructions byte-identical to the unmodified
+    runs and binarisation of a lifting / predicting / RAHT slice on the MI355X, the decisions on
+    the reference's arithmetic coder -- payload and reconstructions byte-identical to the unmodified
     build, the device counted once per direction, no fallback (GPCC_STRICT=1)."""
     case = dict(CASES3[name], lib="libtmc3_shim3.so")
     got, err = run_worker(case, strict=True)
@@ -182,11 +196,69 @@ def test_operator_bitstream_identical_with_device_coders_inside(name):
     assert got["payload_len"] == ln and got["payload_md5"] == md5, "attribute payload differs from the unmodified build"
     assert got["rec_enc_md5"] == rec and got["rec_dec_md5"] == rec
     assert "falls back" not in err
-    if case["transform"] == 0:
-        # RAHT slices pass through the factories' objects to the reference coder and seam 1
-        assert (got["raht_device"], got["raht_cpu"]) == (2, 0)
-        assert (got["enc_device"], got["enc_cpu"], got["dec_device"], got["dec_cpu"]) == (0, 0, 0, 0)
-    else:
-        assert (got["enc_device"], got["enc_cpu"], got["dec_device"], got["dec_cpu"]) == (1, 0, 1, 0)
-        # the LoD structure is built inside the one-call entries: AttributeLods::generate is not reached
-        assert (got["lod_device"], got["lod_cpu"]) == (0, 0)
+    assert (got["enc_device"], got["enc_cpu"], got["dec_device"], got["dec_cpu"]) == (1, 0, 1, 0)
+    # everything happens inside the one-call entries: neither AttributeLods::generate (seam 2) nor the
+    # reference's RAHT slice drivers (and with them seam 1) are reached
+    assert (got["lod_device"], got["lod_cpu"]) == (0, 0)
+    assert (got["raht_device"], got["raht_cpu"]) == (0, 0)
+
+
+# ---- the coder object's cached LoD structure: the second attribute of a slice runs over the
+#      structure built for the FIRST whenever AttributeLods::isReusable passes -- which does not look at
+#      attr_encoding (weight blending, the search inside a LoD: predicting transform only) or at
+#      predictionWithDistributionEnabled ---------------------------------------------------------------
+TWO_ATTR = {
+    # colour: predicting transform with blended weights; reflectance: lifting over THOSE weights
+    "pred_then_lifting": dict(two_attr=1, n=40_000, seed=31, qp=28, transforms=(1, 2)),
+    # the other way round: the predicting transform runs over a lifting structure (weights not blended)
+    "lifting_then_pred": dict(two_attr=1, n=40_000, seed=32, qp=28, transforms=(2, 1)),
+    # both lifting; B asks for the distribution-aware third neighbour, A's structure has none
+    "distribution_flag_differs": dict(two_attr=1, n=40_000, seed=33, qp=34, transforms=(2, 2),
+                                      lod_a=dict(prediction_with_distribution_enabled=0),
+                                      lod_b=dict(prediction_with_distribution_enabled=1)),
+    # a field isReusable does compare: the objects are replaced, every attribute gets its own structure
+    "neighbour_count_differs": dict(two_attr=1, n=30_000, seed=34, qp=34, transforms=(2, 2),
+                                    lod_b=dict(num_pred_nearest_neighbours_minus1=1), expect_reused=(0, 0)),
+}
+
+
+@needs3
+def test_two_attribute_cases_differ_from_fresh_structures():
+    """the cases are not vacuous: coding B over its own fresh structure gives another payload"""
+    import lod_helpers as lh
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import shim_operator_worker as w
+    case = dict(TWO_ATTR["pred_then_lifting"], n=6000)
+    xyz, col, refl, lpa, ta, lpb, tb = w.two_attr_case(case)
+    both, _, _, reused = lh.ref_two_attr_roundtrip(lpa, ta, lpb, tb, case["qp"], xyz, col, refl)
+    assert reused == (1, 1)
+    alone, _, _ = lh.ref_operator_roundtrip(lpb, tb, w.make_case(dict(cloud="dense", n=10, seed=1, qp=28, chroma=0, subnode=1,
+                                                                       search_range=8, transform=2))[2],
+                                            case["qp"], 0, 8, 0, xyz, refl.reshape(-1, 1))
+    assert not both.endswith(alone)
+
+
+@needs3
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(TWO_ATTR))
+def test_second_attribute_runs_over_the_first_attributes_structure(name):
+    case = dict(TWO_ATTR[name], lib="libtmc3_shim3.so")
+    got, err = run_worker(case, strict=True)
+    md5, ln, rec = unmodified(case)
+    assert got["payload_len"] == ln and got["payload_md5"] == md5, "payloads differ from the unmodified build"
+    assert got["rec_enc_md5"] == rec and got["rec_dec_md5"] == rec
+    assert got["reused"] == list(case.get("expect_reused", (1, 1)))
+    assert (got["enc_device"], got["enc_cpu"], got["dec_device"], got["dec_cpu"]) == (2, 0, 2, 0)
+
+
+@needs3
+def test_two_attributes_on_a_cpu_box():
+    """without a GPU the factories hand both attributes to the reference's objects: same bitstream"""
+    from mpeg_pcc_tmc13_amd import _lib
+    if _lib.load().gpcc_device_count() > 0:
+        pytest.skip("a GPU is present")
+    case = dict(TWO_ATTR["pred_then_lifting"], n=5000, lib="libtmc3_shim3.so")
+    got, err = run_worker(case, strict=False)
+    md5, ln, rec = unmodified(case)
+    assert (got["payload_md5"], got["payload_len"], got["rec_enc_md5"], got["rec_dec_md5"]) == (md5, ln, rec, rec)
+    assert got["reused"] == [1, 1]
