@@ -319,6 +319,35 @@ def main():
                 "value": round(n / dt1 / 1e6, 3), "unit": "Mpoints/s",
                 "ms_per_step": round(dt1 * 1e3, 3), "steps": k1,
                 "roundtrip_decoder_equals_encoder_recon": b.roundtrip_ok()}
+        if not args.no_extras and args.direction == "both" and not args.haar:
+            # ---- the headline frame where the entropy is not trivial: at qp 34 the smooth S-lidar
+            #      reflectance codes to a 907-byte payload (nearly every coefficient zero: neither the
+            #      undecided band of the RDOQ nor the zero-run / binarisation front end carry load);
+            #      qp 22 and qp 10 put most coefficients through them.  Cost across qp, same kernels. ---
+            out["qp_sweep"] = {}
+            for q in (22, 10):
+                pq = params_for(args.cloud, args.subnode, False, qp=q)
+
+                def stepq():
+                    b.forward(pq)
+                    b.inverse(pq)
+                dtq = timed(torch, dev, stepq, 5)
+                b.forward(pq)
+                torch.cuda.synchronize(dev)
+                co = b.d_coeffs
+                nz = float((co != 0).sum().item()) / co.numel()
+                # the entropy front end on the device: zero runs + binarisation of this frame's coefficients
+                t0 = time.perf_counter()
+                h_co = co.cpu().numpy()
+                runs, syms, trailing = ctx.zero_run_pack(h_co, n, c, planar=True)
+                bins = ctx.binarise_symbols(runs, syms, trailing, c)
+                front_ms = (time.perf_counter() - t0) * 1e3
+                b.inverse(pq)
+                out["qp_sweep"][f"qp{q}"] = {
+                    "value": round(n / dtq / 1e6, 3), "unit": "Mpoints/s", "ms_per_step": round(dtq * 1e3, 3),
+                    "nonzero_coefficient_fraction": round(nz, 4), "symbols": int(len(runs)), "bins": int(len(bins)),
+                    "entropy_front_end_ms_host_tier": round(front_ms, 2),
+                    "roundtrip_decoder_equals_encoder_recon": b.roundtrip_ok()}
         if not args.no_extras:
             out["raht_forward_10M"] = forward_10m(torch, dev, ctx, params_for, frames)
             out["hbm_calibration"] = hbm_calibration(torch, dev)
@@ -718,6 +747,9 @@ def predicting_leg(ctx, args):
                           "encode_ms": round(t_e * 1e3, 2), "decode_ms": round(t_d * 1e3, 2),
                           "value": round(tot / (t_e + t_d) / 1e6, 3), "unit": "Mpoints/s (encode + decode, LoD build included)",
                           "roundtrip_decoder_equals_encoder_recon": bool(torch.equal(d_attrs, d_dec))}
+    # the encoder's fixed-point iteration over everything this leg coded: a slice that does not settle
+    # within the pass limit (64) would be declined to the CPU
+    res["encoder_pass_statistics"] = ctx.pred_pass_stats()
     return res
 
 

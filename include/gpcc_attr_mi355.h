@@ -130,6 +130,13 @@ typedef struct gpcc_ctx_stats_t {
 } gpcc_ctx_stats_t;
 int gpcc_ctx_stats(const gpcc_ctx* ctx, gpcc_ctx_stats_t* out);
 
+/* The predicting encoder with direct predictors iterates its reconstruction pass and the rate
+ * model's trajectory to their fixed point (see gpcc_pred_forward); a slice that has not settled
+ * within the pass limit (64) is declined.  out[0] slices coded that way since the context was
+ * created, out[1] passes over all of them, out[2] the most passes one slice took, out[3] slices
+ * declined at the limit (none observed so far: bench.py's predicting leg reports these). */
+int gpcc_ctx_pred_pass_stats(const gpcc_ctx* ctx, int64_t out[4]);
+
 /* ------------------------------------------------------------------ */
 /* host tier: one slice, host buffers, synchronous                      */
 

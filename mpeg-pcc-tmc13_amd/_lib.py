@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("GPCC_LIB_PATH") or os.path.join(PKG_DIR, "libgpcc_att
 ABI_SYMBOLS = [
     "gpcc_raht_set_prediction_weights", "gpcc_abi_version", "gpcc_last_error",
     "gpcc_device_count", "gpcc_ctx_create", "gpcc_ctx_destroy",
-    "gpcc_ctx_synchronize", "gpcc_ctx_workspace_bytes", "gpcc_ctx_set_morton_bits", "gpcc_ctx_set_fast_arith",
+    "gpcc_ctx_synchronize", "gpcc_ctx_workspace_bytes", "gpcc_ctx_set_morton_bits", "gpcc_ctx_set_fast_arith", "gpcc_ctx_pred_pass_stats",
     "gpcc_raht_forward", "gpcc_raht_inverse", "gpcc_attr_morton_sort",
     "gpcc_dev_raht_forward", "gpcc_dev_raht_inverse", "gpcc_dev_attr_morton_sort",
     "gpcc_ctx_set_profiling", "gpcc_ctx_kernel_times", "gpcc_ctx_stats",
@@ -76,6 +76,7 @@ def load():
     lib.gpcc_ctx_workspace_bytes.restype = C.c_size_t
     lib.gpcc_ctx_set_morton_bits.argtypes = [vp, i32]
     lib.gpcc_ctx_set_fast_arith.argtypes = [vp, i32]
+    lib.gpcc_ctx_pred_pass_stats.argtypes = [vp, C.POINTER(C.c_int64)]
     lib.gpcc_ctx_set_profiling.argtypes = [vp, C.c_int]
     lib.gpcc_ctx_kernel_times.argtypes = [vp, C.POINTER(KernelTime), i32]
     lib.gpcc_ctx_stats.argtypes = [vp, C.POINTER(CtxStats)]

@@ -120,7 +120,12 @@ struct gpcc_ctx {
   CxLevelTab* h_cxtab = nullptr;  // pinned: blocks / real children per level (compact level pass)
   double* d_log2 = nullptr;       // log2 of 0 .. 2^20 from the host's libm (predicting encoder's rate model)
   int pred_passes = 0;            // passes the last predicting encode with direct predictors took
+  int64_t pred_pass_stats[4] = {0, 0, 0, 0};  // slices, passes, most passes, declined at the limit
   hipEvent_t ev_stats = nullptr;  // recorded behind schedule_kernel
+  // recolour: the second tree's build runs on a stream of its own (recolour_kdtree.hpp KdLevelLoop)
+  hipStream_t kd_stream = nullptr;
+  hipEvent_t kd_event = nullptr;
+  int32_t* h_kd = nullptr;        // pinned: 2 x 4 counters
   // what the entries did since the context was created (gpcc_ctx_stats)
   gpcc_ctx_stats_t stats{};
   // device buffers of the host tiers, kept between calls (pool_malloc)
@@ -1689,6 +1694,10 @@ launch_pred(
       }
     }
     ctx->pred_passes = passes;
+    ctx->pred_pass_stats[0]++;
+    ctx->pred_pass_stats[1] += passes;
+    ctx->pred_pass_stats[2] = std::max<int64_t>(ctx->pred_pass_stats[2], passes);
+    ctx->pred_pass_stats[3] += settled ? 0 : 1;
     if (!settled) {
       // the caller's attrs hold a reconstruction that is not the reference's: restore the source
       HIP_TRY(hipMemcpyAsync(d.attrs, src_copy, sizeof(int32_t) * (size_t)n * C, hipMemcpyDeviceToDevice, st));
@@ -1942,6 +1951,12 @@ gpcc_ctx_destroy(gpcc_ctx* ctx)
     hipHostFree(ctx->h_stats);
   if (ctx->h_cxtab)
     hipHostFree(ctx->h_cxtab);
+  if (ctx->h_kd)
+    hipHostFree(ctx->h_kd);
+  if (ctx->kd_event)
+    hipEventDestroy(ctx->kd_event);
+  if (ctx->kd_stream)
+    hipStreamDestroy(ctx->kd_stream);
   if (ctx->d_log2)
     hipFree(ctx->d_log2);
   if (ctx->ev_stats)
@@ -1972,6 +1987,23 @@ gpcc_ctx_stats(const gpcc_ctx* ctx, gpcc_ctx_stats_t* out)
   if (!ctx || !out)
     return fail(GPCC_ERR_INVALID_ARG, "ctx / out is null");
   *out = ctx->stats;
+  return GPCC_OK;
+}
+
+extern "C" int
+gpcc_ctx_pred_pass_stats(const gpcc_ctx* ctx, int64_t out[4])
+{
+  if (!ctx || !out)
+    return fail(GPCC_ERR_INVALID_ARG, "ctx or out is null");
+  // (the lanes of the device tier are contexts of their own: their slices are added up)
+  for (int k = 0; k < 4; k++)
+    out[k] = ctx->pred_pass_stats[k];
+  for (const gpcc_ctx* lane : ctx->lanes) {
+    out[0] += lane->pred_pass_stats[0];
+    out[1] += lane->pred_pass_stats[1];
+    out[2] = std::max(out[2], lane->pred_pass_stats[2]);
+    out[3] += lane->pred_pass_stats[3];
+  }
   return GPCC_OK;
 }
 
@@ -4665,6 +4697,7 @@ kd_alloc(gpcc_ctx* ctx, KdAlloc* ka, const int32_t* d_xyz, int n)
   HIP_TRY(take((void**)&b.tmp_r, sizeof(int32_t) * N));
   HIP_TRY(take((void**)&b.sums, sizeof(long long) * ((N + 1) / kKdScanBlock + 2)));
   HIP_TRY(take((void**)&b.counters, sizeof(int32_t) * 4));
+  HIP_TRY(take((void**)&b.sub_list, sizeof(int32_t) * 2 * (N / 11 + 2)));
   return GPCC_OK;
 }
 
@@ -4753,27 +4786,51 @@ recolour_impl(
       cx.off[k] = offset[k];
     cx.src_attrs = d_sa;
 
-    // ---- the two k-d trees (the reference builds the target's first, then the source's: the
-    //      order does not matter) ---------------------------------------------------------------
-    for (int which = 0; which < 2; which++) {
-      KdAlloc& ka = which ? kt : ks;
+    // ---- the two k-d trees, built together: the source's on the context's stream, the target's on
+    //      a second one (a level is a handful of small launches and a look at the node counter) ------
+    {
       Timer t(ctx, "rc_kdtree");
-      int r = kd_alloc(ctx, &ka, which ? d_tx : d_sx, which ? nt : ns);
+      if (!ctx->kd_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&ctx->kd_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&ctx->kd_event, hipEventDisableTiming));
+        HIP_TRY(hipHostMalloc((void**)&ctx->h_kd, 8 * sizeof(int32_t)));
+      }
+      int r = kd_alloc(ctx, &ks, d_sx, ns);
+      if (!r)
+        r = kd_alloc(ctx, &kt, d_tx, nt);
       if (r)
         return r;
-      int depth = 0, nodes = 0;
-      HIP_TRY(kd_build_levels(ka.b, d_box + 6 * which, st, &depth, &nodes));
-      if (depth > kKdMaxDepth)
-        return fail(GPCC_ERR_UNSUPPORTED, "k-d tree deeper than 64 levels: it stays on the reference CPU path");
-      KdTree& tr = which ? cx.tgt : cx.src;
-      tr = ka.b.t;
-      for (int k = 0; k < 3; k++) {
-        tr.root_lo[k] = (double)h_box[6 * which + k];
-        tr.root_hi[k] = (double)h_box[6 * which + 3 + k];
+      // (the second stream starts behind the uploads and the bounding boxes)
+      HIP_TRY(hipEventRecord(ctx->kd_event, st));
+      HIP_TRY(hipStreamWaitEvent(ctx->kd_stream, ctx->kd_event, 0));
+      KdLevelLoop loop[2];
+      HIP_TRY(loop[0].begin(ks.b, d_box, st, ctx->h_kd));
+      HIP_TRY(loop[1].begin(kt.b, d_box + 6, ctx->kd_stream, ctx->h_kd + 4));
+      while (!loop[0].done() || !loop[1].done()) {
+        for (int w = 0; w < 2; w++)
+          if (!loop[w].done())
+            HIP_TRY(loop[w].launch());
+        for (int w = 0; w < 2; w++)
+          if (!loop[w].done())
+            HIP_TRY(loop[w].finish());
       }
-      kd_release(ctx, &ka, true);  // (the build's working set goes back to the pool; index array and nodes stay)
-      ka.blocks.push_back((void*)tr.vind);
-      ka.blocks.push_back((void*)tr.nodes);
+      // (the context's stream goes on behind the second one)
+      HIP_TRY(hipEventRecord(ctx->kd_event, ctx->kd_stream));
+      HIP_TRY(hipStreamWaitEvent(st, ctx->kd_event, 0));
+      for (int which = 0; which < 2; which++) {
+        if (loop[which].tree_depth() > kKdMaxDepth)
+          return fail(GPCC_ERR_UNSUPPORTED, "k-d tree deeper than 64 levels: it stays on the reference CPU path");
+        KdAlloc& ka = which ? kt : ks;
+        KdTree& tr = which ? cx.tgt : cx.src;
+        tr = ka.b.t;
+        for (int k = 0; k < 3; k++) {
+          tr.root_lo[k] = (double)h_box[6 * which + k];
+          tr.root_hi[k] = (double)h_box[6 * which + 3 + k];
+        }
+        kd_release(ctx, &ka, true);  // (the build's working set goes back to the pool; index array and nodes stay)
+        ka.blocks.push_back((void*)tr.vind);
+        ka.blocks.push_back((void*)tr.nodes);
+      }
     }
     const size_t total_cap = (size_t)ns * kb;
     HIP_TRY(pool_malloc(ctx, (void**)&d_ref1, sizeof(int32_t) * (size_t)c * nt));

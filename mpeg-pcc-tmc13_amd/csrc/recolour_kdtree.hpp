@@ -36,6 +36,9 @@ namespace gpcc {
 constexpr int kKdLeaf = 10;       // KDTreeVectorOfVectorsAdaptor(3, cloud, 10)
 constexpr int kKdMaxDepth = 64;   // deeper trees are declined (the search stack lives in scratch)
 constexpr int kKdScanBlock = 2048;
+// A node of at most this many points leaves the level-by-level build: ONE WAVEFRONT finishes its
+// whole subtree in LDS (kd_subtree_kernel) -- the lower two thirds of a tree's levels in one launch.
+constexpr int kKdSub = 2048;
 
 // what the search reads: 32 bytes per node
 struct KdNode {
@@ -68,7 +71,9 @@ struct KdBuild {
   int32_t* tmp_l;    // [n]
   int32_t* tmp_r;    // [n]
   long long* sums;   // [n / kKdScanBlock + 2]
-  int32_t* counters; // [0] nodes created, [1] internal nodes of the level just split
+  int32_t* counters; // [0] nodes created, [1] internal nodes of the level just split, [2] subtree roots,
+                     // [3] the deepest level a subtree reached
+  int32_t* sub_list; // [2][n / 11 + 2] roots of the subtrees kd_subtree_kernel finishes, then their levels
 };
 
 __device__ __forceinline__ int
@@ -188,6 +193,8 @@ kd_init_kernel(KdBuild b, const int32_t* __restrict__ bbox)
     }
     b.counters[0] = 1;
     b.counters[1] = 0;
+    b.counters[2] = 0;
+    b.counters[3] = 0;
     b.flag[0] = 0;
   }
 }
@@ -244,7 +251,7 @@ kd_minmax_kernel(KdBuild b)
 // nodes [nb, ne) of the level: the parent's divlow / divhigh (:910-911: the bounds the recursion
 // RETURNS, i.e. the children's tight ones), leaf or the cut of middleSplit_ (:922-954)
 __global__ __launch_bounds__(256) void
-kd_split_kernel(KdBuild b, int nb, int ne)
+kd_split_kernel(KdBuild b, int nb, int ne, int level)
 {
 #pragma clang fp contract(off)
   const int k = nb + blockIdx.x * blockDim.x + threadIdx.x;
@@ -263,11 +270,15 @@ kd_split_kernel(KdBuild b, int nb, int ne)
   KdNode nd;
   nd.divlow = nd.divhigh = 0.0;
   nd.pad = 0;
-  if (right - left <= kKdLeaf) {
+  if (right - left <= kKdSub) {
+    // a wavefront finishes this subtree (kd_subtree_kernel); the level loop sees a leaf
     nd.a = left;
     nd.b = right;
     nd.feat = -1;
     b.t.nodes[k] = nd;
+    const int slot = atomicAdd(&b.counters[2], 1);
+    b.sub_list[slot] = k;
+    b.sub_list[b.t.n / 11 + 2 + slot] = level;
     return;
   }
   const double* bx = b.box + 6 * k;
@@ -487,54 +498,349 @@ kd_assign_kernel(KdBuild b)
   b.pnode[x] = nd.feat < 0 ? -1 : (x < b.split[node] ? nd.a : nd.a + 1);
 }
 
-// The level loop.  `bbox` = min[3], max[3] of the cloud on the device; the host learns the number
-// of nodes after every level (one small copy + synchronisation per level).
-// Returns hipSuccess and *depth_out = levels (> kKdMaxDepth: the caller declines).
+// ---- a whole subtree by one wavefront ----------------------------------------------------
+// The root's points (<= kKdSub) are taken into LDS under LOCAL ids: coordinates by local id, `v` the
+// permutation of local ids that planeSplit shuffles.  The wavefront walks the subtree depth first
+// (the right child waits on a stack); every node is the reference's middleSplit_ / planeSplit with
+// the lanes over the node's range: bounds by reduction, lim1 / lim2 by ballots, a plane split as two
+// lists -- the misplaced positions of the left zone ascending, those of the right zone descending --
+// whose i-th entries change places.  Node ids come from the build's counter (two per split).
+struct KdSubSmem {
+  int32_t v[kKdSub];
+  int32_t gid[kKdSub];
+  int32_t c[3][kKdSub];
+  int32_t ml[kKdSub / 2 + 64], mr[kKdSub / 2 + 64];
+  int32_t st_node[kKdMaxDepth + 2], st_l[kKdMaxDepth + 2], st_r[kKdMaxDepth + 2], st_lv[kKdMaxDepth + 2];
+  double st_box[kKdMaxDepth + 2][6];
+};
+
+__device__ __forceinline__ int
+kd_wave_min(int x)
+{
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_xor(x, d);
+    x = o < x ? o : x;
+  }
+  return x;
+}
+__device__ __forceinline__ int
+kd_wave_max(int x)
+{
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_xor(x, d);
+    x = o > x ? o : x;
+  }
+  return x;
+}
+
+// one of planeSplit's loops on v[lo, hi): goes_left(coordinate) decides, m = entries that go left
+template<class Pred>
+__device__ __forceinline__ void
+kd_sub_split(KdSubSmem& sm, int lo, int hi, int m, const int32_t* __restrict__ cf, Pred goes_left)
+{
+  const int lane = kd_lane();
+  const int zb = lo + m;
+  // misplaced positions of the left zone, ascending
+  int nl = 0;
+  for (int base = lo; base < zb; base += 64) {
+    const int x = base + lane;
+    const bool mis = x < zb && !goes_left(cf[sm.v[x]]);
+    const unsigned long long bal = __ballot(mis);
+    if (mis)
+      sm.ml[nl + __popcll(bal & ((1ull << lane) - 1ull))] = x;
+    nl += __popcll(bal);
+  }
+  // ... of the right zone, descending
+  int nr = 0;
+  for (int top = hi; top > zb; top -= 64) {
+    const int x = top - 1 - lane;
+    const bool mis = x >= zb && goes_left(cf[sm.v[x]]);
+    const unsigned long long bal = __ballot(mis);
+    if (mis)
+      sm.mr[nr + __popcll(bal & ((1ull << lane) - 1ull))] = x;
+    nr += __popcll(bal);
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int i = lane; i < nl; i += 64) {
+    const int a = sm.ml[i], b = sm.mr[i];
+    const int32_t t = sm.v[a];
+    sm.v[a] = sm.v[b];
+    sm.v[b] = t;
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+__global__ __launch_bounds__(64) void
+kd_subtree_kernel(KdBuild b, int nsub)
+{
+#pragma clang fp contract(off)
+  __shared__ KdSubSmem sm;
+  const int lane = kd_lane();
+  if ((int)blockIdx.x >= nsub)
+    return;
+  const int root = b.sub_list[blockIdx.x];
+  const int L = b.rng[2 * root], R = b.rng[2 * root + 1];
+  const int cnt = R - L;
+  for (int i = lane; i < cnt; i += 64) {
+    const int p = b.t.vind[L + i];
+    sm.v[i] = i;
+    sm.gid[i] = p;
+    sm.c[0][i] = b.t.xyz[3 * p];
+    sm.c[1][i] = b.t.xyz[3 * p + 1];
+    sm.c[2][i] = b.t.xyz[3 * p + 2];
+  }
+  if (lane < 6)
+    sm.st_box[0][lane] = b.box[6 * root + lane];
+  if (lane == 0) {
+    sm.st_node[0] = root;
+    sm.st_l[0] = 0;
+    sm.st_r[0] = cnt;
+    sm.st_lv[0] = b.sub_list[b.t.n / 11 + 2 + blockIdx.x];
+  }
+  __builtin_amdgcn_wave_barrier();
+  int sp = 0, deepest = 0;
+  while (sp >= 0) {
+    const int node = sm.st_node[sp], l = sm.st_l[sp], r = sm.st_r[sp], lv = sm.st_lv[sp];
+    deepest = lv > deepest ? lv : deepest;
+    double bx[6];
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+      bx[a] = sm.st_box[sp][a];
+    __builtin_amdgcn_wave_barrier();  // (the entry is read by every lane before it is overwritten)
+    sp--;
+    const int count = r - l;
+    if (count <= kKdLeaf) {
+      if (lane == 0) {
+        KdNode nd;
+        nd.divlow = nd.divhigh = 0.0;
+        nd.a = L + l;
+        nd.b = L + r;
+        nd.feat = -1;
+        nd.pad = 0;
+        b.t.nodes[node] = nd;
+      }
+      continue;
+    }
+    // middleSplit_ (:922-961): tight bounds of the node's points
+    int mn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, mx[3] = {-0x7fffffff, -0x7fffffff, -0x7fffffff};
+    for (int x = l + lane; x < r; x += 64) {
+      const int id = sm.v[x];
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        const int cv = sm.c[a][id];
+        mn[a] = cv < mn[a] ? cv : mn[a];
+        mx[a] = cv > mx[a] ? cv : mx[a];
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      mn[a] = kd_wave_min(mn[a]);
+      mx[a] = kd_wave_max(mx[a]);
+    }
+    const double EPS = 0.00001;
+    double max_span = bx[3] - bx[0];
+#pragma unroll
+    for (int a = 1; a < 3; a++) {
+      const double span = bx[3 + a] - bx[a];
+      max_span = span > max_span ? span : max_span;
+    }
+    double max_spread = -1;
+    int feat = 0;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      const double span = bx[3 + a] - bx[a];
+      if (span >= (1 - EPS) * max_span) {
+        const double spread = (double)mx[a] - (double)mn[a];
+        if (spread > max_spread) {
+          feat = a;
+          max_spread = spread;
+        }
+      }
+    }
+    const double lo_f = feat == 0 ? bx[0] : (feat == 1 ? bx[1] : bx[2]);
+    const double hi_f = feat == 0 ? bx[3] : (feat == 1 ? bx[4] : bx[5]);
+    const int mn_f = feat == 0 ? mn[0] : (feat == 1 ? mn[1] : mn[2]);
+    const int mx_f = feat == 0 ? mx[0] : (feat == 1 ? mx[1] : mx[2]);
+    const double split = (lo_f + hi_f) / 2;
+    const double cut = split < (double)mn_f ? (double)mn_f : (split > (double)mx_f ? (double)mx_f : split);
+    const int32_t* __restrict__ cf = sm.c[feat];
+    int lim1 = 0, lim2 = 0;
+    for (int base = l; base < r; base += 64) {
+      const int x = base + lane;
+      const double cv = x < r ? (double)cf[sm.v[x]] : 0.0;
+      lim1 += __popcll(__ballot(x < r && cv < cut));
+      lim2 += __popcll(__ballot(x < r && cv <= cut));
+    }
+    // planeSplit (:972-998): < cut to the front, then == cut in front of > cut
+    kd_sub_split(sm, l, r, lim1, cf, [cut](int32_t cv) { return (double)cv < cut; });
+    kd_sub_split(sm, l + lim1, r, lim2 - lim1, cf, [cut](int32_t cv) { return (double)cv <= cut; });
+    const int half = count / 2;
+    const int idx = lim1 > half ? lim1 : (lim2 < half ? lim2 : half);
+    // divlow / divhigh (:910-911): what the recursion returns -- the children's tight bounds along feat
+    int lmax = -0x7fffffff, rmin = 0x7fffffff;
+    for (int x = l + lane; x < r; x += 64) {
+      const int cv = cf[sm.v[x]];
+      if (x < l + idx)
+        lmax = cv > lmax ? cv : lmax;
+      else
+        rmin = cv < rmin ? cv : rmin;
+    }
+    lmax = kd_wave_max(lmax);
+    rmin = kd_wave_min(rmin);
+    int c1 = 0;
+    if (lane == 0)
+      c1 = atomicAdd(&b.counters[0], 2);
+    c1 = __shfl(c1, 0);
+    if (lane == 0) {
+      KdNode nd;
+      nd.divlow = (double)lmax;
+      nd.divhigh = (double)rmin;
+      nd.a = c1;
+      nd.b = 0;
+      nd.feat = feat;
+      nd.pad = 0;
+      b.t.nodes[node] = nd;
+      // the right child waits, the left one is next (divideTree :900-908: the box cut at the plane)
+      sm.st_node[sp + 1] = c1 + 1;
+      sm.st_l[sp + 1] = l + idx;
+      sm.st_r[sp + 1] = r;
+      sm.st_lv[sp + 1] = lv + 1;
+      sm.st_node[sp + 2] = c1;
+      sm.st_l[sp + 2] = l;
+      sm.st_r[sp + 2] = l + idx;
+      sm.st_lv[sp + 2] = lv + 1;
+    }
+    if (lane < 6) {
+      // lane a < 3: lo[a], lane 3 + a: hi[a] of the two children's boxes
+      const bool is_lo = lane < 3;
+      const int a = is_lo ? lane : lane - 3;
+      double vr = lane == 0 ? bx[0] : lane == 1 ? bx[1] : lane == 2 ? bx[2] : lane == 3 ? bx[3] : lane == 4 ? bx[4] : bx[5];
+      double vl = vr;
+      if (a == feat) {
+        if (is_lo)
+          vr = cut;  // right child: lo[feat] = cut
+        else
+          vl = cut;  // left child: hi[feat] = cut
+      }
+      sm.st_box[sp + 1][lane] = vr;
+      sm.st_box[sp + 2][lane] = vl;
+    }
+    __builtin_amdgcn_wave_barrier();
+    sp += 2;
+    if (sp >= kKdMaxDepth || lv + 1 > kKdMaxDepth) {
+      // deeper than the search's stack allows: the caller declines
+      if (lane == 0)
+        atomicMax(&b.counters[3], kKdMaxDepth + 1);
+      return;
+    }
+  }
+  if (lane == 0)
+    atomicMax(&b.counters[3], deepest);
+  for (int i = lane; i < cnt; i += 64)
+    b.t.vind[L + i] = sm.gid[sm.v[i]];
+}
+
+// The level loop as a stepper, so that the builds of the two trees of a recolour call advance together
+// on two streams (each level is a handful of small launches: one build alone leaves the device idle).
+// `bbox` = min[3], max[3] of the cloud on the device; `h` = four ints of PINNED host memory through which
+// the host learns the number of nodes after every level.
+struct KdLevelLoop {
+  KdBuild b{};
+  hipStream_t st = nullptr;
+  volatile int32_t* h = nullptr;
+  int nb = 0, ne = 1, depth = 0, phase = 0;  // phase 0: levels, 1: subtrees launched, 2: done
+
+  hipError_t begin(const KdBuild& build, const int32_t* bbox, hipStream_t stream, int32_t* pinned4)
+  {
+    b = build;
+    st = stream;
+    h = pinned4;
+    nb = 0;
+    ne = 1;
+    depth = 0;
+    phase = 0;
+    hipLaunchKernelGGL(kd_init_kernel, dim3((b.t.n + 255) / 256), dim3(256), 0, st, b, bbox);
+    return hipGetLastError();
+  }
+  bool done() const { return phase == 2; }
+
+  // enqueue the next piece of work and the copy of the counters behind it
+  hipError_t launch()
+  {
+    const int n = b.t.n;
+    const int pgrid = (n + 255) / 256;
+    const int sgrid = std::min(pgrid, 2048);
+    if (phase == 0) {
+      depth++;
+      const int ngrid = (ne - nb + 255) / 256;
+      hipLaunchKernelGGL(kd_minmax_kernel, dim3(sgrid), dim3(256), 0, st, b);
+      hipLaunchKernelGGL(kd_split_kernel, dim3(ngrid), dim3(256), 0, st, b, nb, ne, depth);
+      if (depth <= kKdMaxDepth) {
+        hipLaunchKernelGGL(kd_count_kernel, dim3(sgrid), dim3(256), 0, st, b);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(kd_flag_kernel<0>), dim3(pgrid), dim3(256), 0, st, b);
+        hipError_t e = kd_scan(st, b.flag, (size_t)n + 1, b.sums);
+        if (e != hipSuccess)
+          return e;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(kd_exchange_kernel<0, false>), dim3(pgrid), dim3(256), 0, st, b);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(kd_exchange_kernel<0, true>), dim3(pgrid), dim3(256), 0, st, b);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(kd_flag_kernel<1>), dim3(pgrid), dim3(256), 0, st, b);
+        e = kd_scan(st, b.flag, (size_t)n + 1, b.sums);
+        if (e != hipSuccess)
+          return e;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(kd_exchange_kernel<1, false>), dim3(pgrid), dim3(256), 0, st, b);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(kd_exchange_kernel<1, true>), dim3(pgrid), dim3(256), 0, st, b);
+        hipLaunchKernelGGL(kd_children_kernel, dim3(ngrid), dim3(256), 0, st, b, nb, ne);
+        hipLaunchKernelGGL(kd_assign_kernel, dim3(pgrid), dim3(256), 0, st, b);
+      }
+    } else if (phase == 1) {
+      // the subtrees: one wavefront each
+      hipLaunchKernelGGL(kd_subtree_kernel, dim3((int)h[2]), dim3(64), 0, st, b, (int)h[2]);
+    }
+    return hipMemcpyAsync((void*)h, b.counters, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st);
+  }
+
+  // wait for what launch() enqueued and decide what comes next
+  hipError_t finish()
+  {
+    hipError_t e = hipStreamSynchronize(st);
+    if (e != hipSuccess)
+      return e;
+    if (phase == 0) {
+      const int created = h[0];
+      if (created == ne || depth > kKdMaxDepth) {
+        // every node of the level was a leaf (or went to the subtree list)
+        phase = h[2] > 0 && depth <= kKdMaxDepth ? 1 : 2;
+      } else {
+        nb = ne;
+        ne = created;
+      }
+    } else if (phase == 1) {
+      phase = 2;
+    }
+    return hipGetLastError();
+  }
+  // levels counted from 1 at the root: what the search's stack must hold
+  int tree_depth() const { return std::max(depth, (int)h[3]); }
+  int nodes() const { return (int)h[0]; }
+};
+
+// one tree alone (tests, the emulator harness)
 inline hipError_t
 kd_build_levels(const KdBuild& b, const int32_t* bbox, hipStream_t st, int* depth_out, int* nodes_out)
 {
-  const int n = b.t.n;
-  const int pgrid = (n + 255) / 256;
-  const int sgrid = std::min(pgrid, 2048);
-  hipLaunchKernelGGL(kd_init_kernel, dim3(pgrid), dim3(256), 0, st, b, bbox);
-  int nb = 0, ne = 1, depth = 0;
-  for (;;) {
-    depth++;
-    const int ngrid = (ne - nb + 255) / 256;
-    hipLaunchKernelGGL(kd_minmax_kernel, dim3(sgrid), dim3(256), 0, st, b);
-    hipLaunchKernelGGL(kd_split_kernel, dim3(ngrid), dim3(256), 0, st, b, nb, ne);
-    if (depth > kKdMaxDepth)
-      break;
-    hipLaunchKernelGGL(kd_count_kernel, dim3(sgrid), dim3(256), 0, st, b);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(kd_flag_kernel<0>), dim3(pgrid), dim3(256), 0, st, b);
-    hipError_t e = kd_scan(st, b.flag, (size_t)n + 1, b.sums);
-    if (e != hipSuccess)
-      return e;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(kd_exchange_kernel<0, false>), dim3(pgrid), dim3(256), 0, st, b);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(kd_exchange_kernel<0, true>), dim3(pgrid), dim3(256), 0, st, b);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(kd_flag_kernel<1>), dim3(pgrid), dim3(256), 0, st, b);
-    e = kd_scan(st, b.flag, (size_t)n + 1, b.sums);
-    if (e != hipSuccess)
-      return e;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(kd_exchange_kernel<1, false>), dim3(pgrid), dim3(256), 0, st, b);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(kd_exchange_kernel<1, true>), dim3(pgrid), dim3(256), 0, st, b);
-    hipLaunchKernelGGL(kd_children_kernel, dim3(ngrid), dim3(256), 0, st, b, nb, ne);
-    hipLaunchKernelGGL(kd_assign_kernel, dim3(pgrid), dim3(256), 0, st, b);
-    int32_t created = 0;
-    e = hipMemcpyAsync(&created, b.counters, sizeof(int32_t), hipMemcpyDeviceToHost, st);
-    if (e != hipSuccess)
-      return e;
-    e = hipStreamSynchronize(st);
-    if (e != hipSuccess)
-      return e;
-    if (created == ne)
-      break;  // every node of the level was a leaf
-    nb = ne;
-    ne = created;
+  int32_t h[4] = {0, 0, 0, 0};
+  KdLevelLoop loop;
+  hipError_t e = loop.begin(b, bbox, st, h);
+  while (e == hipSuccess && !loop.done()) {
+    e = loop.launch();
+    if (e == hipSuccess)
+      e = loop.finish();
   }
-  *depth_out = depth;
-  *nodes_out = ne;
-  return hipGetLastError();
+  *depth_out = loop.tree_depth();
+  *nodes_out = loop.nodes();
+  return e;
 }
 
 // ---- search -----------------------------------------------------------------------------

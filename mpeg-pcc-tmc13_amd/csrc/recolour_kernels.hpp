@@ -25,6 +25,7 @@
 #include <stdint.h>
 
 #include "gpcc_attr_mi355.h"
+#include "gpcc_primitives.hpp"
 #include "recolour_kdtree.hpp"
 
 namespace gpcc {

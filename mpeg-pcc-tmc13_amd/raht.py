@@ -53,6 +53,13 @@ class Context:
         """doubles where they are exact (default) / int64 always in the sub-node kernels"""
         _lib.check(self._lib.gpcc_ctx_set_fast_arith(self._h, int(bool(on))))
 
+    def pred_pass_stats(self):
+        """{slices, passes, most_passes, declined_at_the_limit} of the predicting encoder's fixed-point
+        iteration (direct predictors) since the context was created"""
+        out = (C.c_int64 * 4)()
+        _lib.check(self._lib.gpcc_ctx_pred_pass_stats(self._h, out))
+        return dict(zip(("slices", "passes", "most_passes", "declined_at_the_limit"), (int(v) for v in out)))
+
     def set_profiling(self, on):
         _lib.check(self._lib.gpcc_ctx_set_profiling(self._h, int(bool(on))))
 

@@ -45,6 +45,7 @@ build_tree(std::vector<void*>* blocks, const int32_t* xyz, int n, const int32_t*
   b.tmp_r = carve<int32_t>(blocks, N);
   b.sums = carve<long long>(blocks, (N + 1) / kKdScanBlock + 2);
   b.counters = carve<int32_t>(blocks, 4);
+  b.sub_list = carve<int32_t>(blocks, 2 * (N / 11 + 2));
   int nodes = 0;
   if (kd_build_levels(b, box, nullptr, depth, &nodes) != hipSuccess)
     return -1;

@@ -20,7 +20,7 @@ frames = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 direction = sys.argv[2] if len(sys.argv) > 2 else "forward"
 dev = torch.device("cuda:0")
 ctx = context(0)
-p = raht_params(qp=34, subnode=True, search_range=2500)
+p = raht_params(qp=int(os.environ.get("QP", "34")), subnode=True, search_range=2500)
 fr = []
 for f in range(frames):
     xyz, a = synth.lidar_cloud(1_000_000, seed=1 + f)
