@@ -34,6 +34,7 @@ extern "C" {
 #define GPCC_MAX_POINTS (1 << 29) /* 32-bit device indices, stride <= 3 */
 
 #define GPCC_MAX_QP_LAYERS 32
+#define GPCC_MAX_QP_REGIONS 8   /* attr_num_regions a slice header can carry here */
 #define GPCC_MAX_AC_QP_LAYERS 32
 
 typedef enum gpcc_status {
@@ -84,6 +85,10 @@ void gpcc_raht_set_prediction_weights(gpcc_raht_params* p, const int32_t w[5]);
 int gpcc_abi_version(void);
 /* Human readable description of the most recent failure on this thread. */
 const char* gpcc_last_error(void);
+/* Forgets the calling thread's message (a caller that reports "the last error" of a sequence of calls
+ * clears it in front of the sequence: the shim TUs do, so that a decline without a message of its own
+ * never repeats an earlier slice's). */
+void gpcc_clear_last_error(void);
 /* Number of usable gfx950 devices (0 if none / no HIP runtime). */
 int gpcc_device_count(void);
 
@@ -229,6 +234,16 @@ typedef struct gpcc_lift_params {
    * (computeQuantizationWeightsScalable, PCCTMC3Common.h:858-891, whole
    * slices: minGeomNodeSizeLog2 = 0) */
   int32_t scalable_lifting_enabled_flag;
+  /* QP regions of the slice (AttributeBrickHeader::qpRegions -> QpSet::regions,
+   * tmc3/quantization.cpp:100-117), for the entries that build the LoD structure themselves
+   * (gpcc_*_encode_attr / _decode_attr, gpcc_dev_*, gpcc_multi_*): every point's offset is derived
+   * from its position on the device as QpSet::regionQpOffset does (:195-204: the first region that
+   * contains it, bounds inclusive).  gpcc_lift_forward / gpcc_pred_forward and their inverses take the
+   * offsets as an array instead and ignore these. */
+  int32_t num_qp_regions; /* 0 .. GPCC_MAX_QP_REGIONS */
+  int32_t qp_region_min[GPCC_MAX_QP_REGIONS][3];
+  int32_t qp_region_max[GPCC_MAX_QP_REGIONS][3];
+  int32_t qp_region_offset[GPCC_MAX_QP_REGIONS][2];
 } gpcc_lift_params;
 
 /* The predictors of AttributeLods (AttributeCommon.h:89-94) as flat arrays in
@@ -404,7 +419,8 @@ int gpcc_ctx_kernel_times(
  *          reconstruction; decode out: clipped reconstruction
  *   coeffs planar [c][n] in Morton order, exactly what the entropy loop reads
  * Region QP offsets (QpSet::regionQpOffset) are taken as zero, as in every CTC
- * configuration; use gpcc_attr_morton_sort + gpcc_raht_forward for regions. */
+ * configuration; use gpcc_attr_morton_sort + gpcc_raht_forward for regions (the LoD-based
+ * one-call entries below take the regions in their parameter blocks). */
 int gpcc_raht_encode_attr(
   gpcc_ctx* ctx, const gpcc_raht_params* params, const int32_t* xyz,
   int32_t* attrs, int32_t* coeffs, int32_t n, int32_t c, int32_t bitdepth);
@@ -466,6 +482,16 @@ typedef struct gpcc_pred_params {
                                           * (computeQuantizationWeightsScalable,
                                           * PCCTMC3Common.h:858-891; whole slices) instead
                                           * of quant_neigh_weight */
+  /* QP regions of the slice (AttributeBrickHeader::qpRegions -> QpSet::regions,
+   * tmc3/quantization.cpp:100-117), for the entries that build the LoD structure themselves
+   * (gpcc_*_encode_attr / _decode_attr, gpcc_dev_*, gpcc_multi_*): every point's offset is derived
+   * from its position on the device as QpSet::regionQpOffset does (:195-204: the first region that
+   * contains it, bounds inclusive).  gpcc_lift_forward / gpcc_pred_forward and their inverses take the
+   * offsets as an array instead and ignore these. */
+  int32_t num_qp_regions; /* 0 .. GPCC_MAX_QP_REGIONS */
+  int32_t qp_region_min[GPCC_MAX_QP_REGIONS][3];
+  int32_t qp_region_max[GPCC_MAX_QP_REGIONS][3];
+  int32_t qp_region_offset[GPCC_MAX_QP_REGIONS][2];
 } gpcc_pred_params;
 
 /* Replaces decodeColorsPred / decodeReflectancesPred after the entropy decode
@@ -535,10 +561,8 @@ int gpcc_pred_forward(
  * gpcc_lift_encode_attr / gpcc_lift_decode_attr: AttributeLods::generate
  * (with blendWeights when the APS asks for it) and the transform in one call,
  * the predictors never leave the device.  pred: in tools / QP; out num_lods,
- * num_points_in_lod of the structure that was built.  Region QP offsets are
- * taken as zero by these one-call entries and by gpcc_dev_pred_* (a slice with a
- * region QP box goes through gpcc_lod_build + gpcc_pred_forward / _inverse, which
- * take qp_off). */
+ * num_points_in_lod of the structure that was built.  QP regions: the
+ * qp_region_* fields of the parameter block (round 4). */
 int gpcc_pred_encode_attr(
   gpcc_ctx* ctx, const gpcc_lod_params* lod, gpcc_pred_params* pred,
   const int32_t* xyz, int32_t* attrs, int32_t* values, int8_t* icp_coeffs,

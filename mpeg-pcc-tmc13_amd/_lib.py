@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("GPCC_LIB_PATH") or os.path.join(PKG_DIR, "libgpcc_att
 
 # every symbol the header declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
-    "gpcc_raht_set_prediction_weights", "gpcc_abi_version", "gpcc_last_error",
+    "gpcc_raht_set_prediction_weights", "gpcc_abi_version", "gpcc_last_error", "gpcc_clear_last_error",
     "gpcc_device_count", "gpcc_ctx_create", "gpcc_ctx_destroy",
     "gpcc_ctx_synchronize", "gpcc_ctx_workspace_bytes", "gpcc_ctx_set_morton_bits", "gpcc_ctx_set_fast_arith", "gpcc_ctx_pred_pass_stats",
     "gpcc_raht_forward", "gpcc_raht_inverse", "gpcc_attr_morton_sort",

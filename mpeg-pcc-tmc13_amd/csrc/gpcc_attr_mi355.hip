@@ -146,6 +146,9 @@ struct gpcc_ctx {
   int cx_stage_flip = 0;
   // downloads into the caller's pageable memory go through this pinned buffer (d2h_user)
   void* h_bounce = nullptr;
+  hipEvent_t ev_bounce[2] = {nullptr, nullptr};  // recorded behind the last upload out of each half
+  bool bounce_busy[2] = {false, false};
+  int bounce_turn = 0;
   // arithmetic back end of the dependency kernels (raht_arith.hpp): doubles where they are exact
   // (GPCC_F64=0 in the environment or gpcc_ctx_set_fast_arith(ctx, 0): int64 everywhere);
   // force_exact: the host tier's second attempt after GPCC_ERR_RANGE
@@ -401,32 +404,65 @@ constexpr size_t kBounceMin = (size_t)64 << 10;
 // pins a page of the caller (it is those pins, read-only, that a later download trips over --
 // this library's or anybody else's in the process).  The buffer is free again when the call
 // returns.
+// The two halves of the buffer are tracked by events: a half is waited for only when it is taken
+// again (by the next chunk, the next upload or a download), so consecutive uploads of a call overlap
+// with each other's DMA and with the kernels enqueued between them -- until round 3 every upload ended
+// with a full stream synchronisation, which also waited for every kernel before it.
+hipError_t
+bounce_ready(gpcc_ctx* ctx)
+{
+  if (!ctx->h_bounce) {
+    hipError_t e = hipHostMalloc(&ctx->h_bounce, 2 * kBounceBytes);
+    if (e != hipSuccess)
+      return e;
+    for (int h = 0; h < 2; h++) {
+      e = hipEventCreateWithFlags(&ctx->ev_bounce[h], hipEventDisableTiming);
+      if (e != hipSuccess)
+        return e;
+      ctx->bounce_busy[h] = false;
+    }
+  }
+  return hipSuccess;
+}
+
+// the half's last upload has left it
+hipError_t
+bounce_take(gpcc_ctx* ctx, int half)
+{
+  if (!ctx->bounce_busy[half])
+    return hipSuccess;
+  ctx->bounce_busy[half] = false;
+  return hipEventSynchronize(ctx->ev_bounce[half]);
+}
+
 hipError_t
 h2d_user(gpcc_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t st)
 {
   if (bytes < kBounceMin)
     return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
-  if (!ctx->h_bounce) {
-    hipError_t e = hipHostMalloc(&ctx->h_bounce, 2 * kBounceBytes);
-    if (e != hipSuccess)
-      return e;
-  }
+  hipError_t e = bounce_ready(ctx);
+  if (e != hipSuccess)
+    return e;
   size_t off = 0;
-  for (int turn = 0; off < bytes; turn++) {
-    if (turn >= 2) {  // the copy out of this half, two turns ago, has to be over
-      hipError_t e = hipStreamSynchronize(st);
-      if (e != hipSuccess)
-        return e;
-    }
-    const size_t chunk = std::min(kBounceBytes, bytes - off);
-    char* buf = (char*)ctx->h_bounce + (size_t)(turn & 1) * kBounceBytes;
-    memcpy(buf, (const char*)src + off, chunk);
-    hipError_t e = hipMemcpyAsync((char*)dst + off, buf, chunk, hipMemcpyHostToDevice, st);
+  while (off < bytes) {
+    const int half = ctx->bounce_turn;
+    ctx->bounce_turn ^= 1;
+    e = bounce_take(ctx, half);
     if (e != hipSuccess)
       return e;
+    const size_t chunk = std::min(kBounceBytes, bytes - off);
+    char* buf = (char*)ctx->h_bounce + (size_t)half * kBounceBytes;
+    memcpy(buf, (const char*)src + off, chunk);
+    e = hipMemcpyAsync((char*)dst + off, buf, chunk, hipMemcpyHostToDevice, st);
+    if (e != hipSuccess)
+      return e;
+    e = hipEventRecord(ctx->ev_bounce[half], st);
+    if (e != hipSuccess)
+      return e;
+    ctx->bounce_busy[half] = true;
     off += chunk;
   }
-  return hipStreamSynchronize(st);
+  return hipSuccess;
 }
 
 hipError_t
@@ -434,11 +470,9 @@ d2h_user(gpcc_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t st
 {
   if (bytes < kBounceMin)
     return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st);
-  if (!ctx->h_bounce) {
-    hipError_t e = hipHostMalloc(&ctx->h_bounce, 2 * kBounceBytes);
-    if (e != hipSuccess)
-      return e;
-  }
+  hipError_t e = bounce_ready(ctx);
+  if (e != hipSuccess)
+    return e;
   // two halves in turn: the CPU empties one while the next chunk arrives in the other
   size_t off = 0, prev_off = 0, prev_bytes = 0;
   int half = 0;
@@ -447,14 +481,17 @@ d2h_user(gpcc_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t st
     char* buf = (char*)ctx->h_bounce + (size_t)half * kBounceBytes;
     if (off < bytes) {
       chunk = std::min(kBounceBytes, bytes - off);
-      hipError_t e = hipMemcpyAsync(buf, (const char*)src + off, chunk, hipMemcpyDeviceToHost, st);
+      e = bounce_take(ctx, half);  // (an upload may still be reading this half)
+      if (e != hipSuccess)
+        return e;
+      e = hipMemcpyAsync(buf, (const char*)src + off, chunk, hipMemcpyDeviceToHost, st);
       if (e != hipSuccess)
         return e;
     }
     if (prev_bytes)  // (its copy was waited for at the end of the previous turn)
       memcpy((char*)dst + prev_off, (char*)ctx->h_bounce + (size_t)(half ^ 1) * kBounceBytes, prev_bytes);
     if (chunk) {
-      hipError_t e = hipStreamSynchronize(st);
+      e = hipStreamSynchronize(st);
       if (e != hipSuccess)
         return e;
     }
@@ -1858,6 +1895,12 @@ gpcc_last_error(void)
   return g_last_error.c_str();
 }
 
+extern "C" void
+gpcc_clear_last_error(void)
+{
+  g_last_error.clear();
+}
+
 int
 gpcc_device_count(void)
 {
@@ -1967,6 +2010,9 @@ gpcc_ctx_destroy(gpcc_ctx* ctx)
     hipHostFree(ctx->h_cx_stage);
   if (ctx->h_bounce)
     hipHostFree(ctx->h_bounce);
+  for (int h = 0; h < 2; h++)
+    if (ctx->ev_bounce[h])
+      hipEventDestroy(ctx->ev_bounce[h]);
   if (ctx->own_stream)
     hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -2350,6 +2396,7 @@ struct LodDeviceOut {
   int32_t* indexes = nullptr;      // [n] predictor -> point
   int32_t* error = nullptr;        // device error word of the sub-sampling kernel
   int32_t* inter_ref = nullptr;    // [n][3] neighbour lives in the reference frame (inter builds only)
+  const int32_t* xyz = nullptr;    // [n][3] the positions in POINT order, on the device
   std::vector<int32_t> npl;        // cumulative LoD sizes, coarse to fine
   size_t arena_end = 0;            // first free byte behind the build's workspace
 };
@@ -2361,6 +2408,33 @@ struct LodInterFrame {
   int32_t search_range;    // abh.attrInterPredSearchRange: replaces both LoD search ranges
   int32_t frame_distance;  // AttributeInterPredParams::frameDistance
 };
+
+// -> the per-point offsets in `where` (device, [n][2]), or null when the block names no region
+template<class Params>
+int
+qp_regions_to_points(
+  const Params* p, const int32_t* d_xyz, int n, int32_t* where, hipStream_t st, const int32_t** out)
+{
+  *out = nullptr;
+  if (p->num_qp_regions == 0)
+    return GPCC_OK;
+  if (p->num_qp_regions < 0 || p->num_qp_regions > GPCC_MAX_QP_REGIONS)
+    return fail(GPCC_ERR_INVALID_ARG, "num_qp_regions out of range");
+  QpRegionSet rs{};
+  rs.n = p->num_qp_regions;
+  for (int r = 0; r < rs.n; r++) {
+    for (int k = 0; k < 3; k++) {
+      rs.lo[r][k] = p->qp_region_min[r][k];
+      rs.hi[r][k] = p->qp_region_max[r][k];
+    }
+    rs.off[r][0] = p->qp_region_offset[r][0];
+    rs.off[r][1] = p->qp_region_offset[r][1];
+  }
+  qp_region_fill_kernel<<<grid_for(n, 256), 256, 0, st>>>(d_xyz, n, rs, where);
+  HIP_TRY(hipGetLastError());
+  *out = where;
+  return GPCC_OK;
+}
 
 // AttributeLods::generate on the device; results stay there.  `extra_bytes`
 // are reserved behind the workspace for the caller (same arena, no regrowth).
@@ -2824,6 +2898,7 @@ lod_build_core(
     }
     HIP_TRY(hipGetLastError());
     out->count = d_pred_count;
+    out->xyz = d_xyz;
     out->neigh_index = d_neigh_index;
     out->weight = d_weight;
     out->indexes = d_indexes;
@@ -2921,7 +2996,7 @@ pred_attr_driver(
     return fail(GPCC_ERR_INVALID_ARG, "icp_coeffs is null");
   const size_t N = (size_t)(n > 0 ? n : 0);
   const size_t extra = ((N * c * sizeof(int32_t) + 255) & ~size_t(255)) * 2 + 512
-    + pred_scratch_bytes(n > 0 ? n : 1) + 1024;
+    + pred_scratch_bytes(n > 0 ? n : 1) + 1024 + N * 8 + 256;
   LodDeviceOut o;
   int r = lod_build_core(ctx, lod, xyz, n, extra, &o);
   if (r)
@@ -2941,7 +3016,9 @@ pred_attr_driver(
   d.ni = o.neigh_index;
   d.nw = o.weight;
   d.indexes = o.indexes;
-  d.qp_off = nullptr;
+  r = qp_regions_to_points(pred, o.xyz, n, ar.take<int32_t>(N * 2), st, &d.qp_off);
+  if (r)
+    return r;
   d.attrs = ar.take<int32_t>(N * c);
   d.values = ar.take<int32_t>(N * c);
   int8_t* d_icp = ar.take<int8_t>(GPCC_MAX_LODS * 3);
@@ -2995,7 +3072,7 @@ lift_attr_driver(
     return fail(GPCC_ERR_INVALID_ARG, "lcp_coeffs is null");
   const size_t N = (size_t)(n > 0 ? n : 0);
   const size_t extra = ((N * c * sizeof(int32_t) + 255) & ~size_t(255)) * 2 + 256
-    + lift_scratch_bytes(n > 0 ? n : 1, c) + 1024;
+    + lift_scratch_bytes(n > 0 ? n : 1, c) + 1024 + N * 8 + 256;
   LodDeviceOut o;
   int r = lod_build_core(ctx, lod, xyz, n, extra, &o);
   if (r)
@@ -3015,7 +3092,9 @@ lift_attr_driver(
   d.ni = o.neigh_index;
   d.nw = o.weight;
   d.indexes = o.indexes;
-  d.qp_off = nullptr;
+  r = qp_regions_to_points(lift, o.xyz, n, ar.take<int32_t>(N * 2), st, &d.qp_off);
+  if (r)
+    return r;
   d.attrs = ar.take<int32_t>(N * c);
   d.coeffs = ar.take<int32_t>(N * c);
   int8_t* d_lcp = ar.take<int8_t>(GPCC_MAX_LODS);
@@ -3900,7 +3979,7 @@ dev_lift_attr(
     const bool lcp_on = c == 3 && lf->last_component_prediction_enabled_flag;
     const size_t b = (size_t)offsets[s], N = (size_t)(offsets[s + 1] - offsets[s]);
     const int32_t n = (int32_t)N;
-    const size_t extra = 512 + lift_scratch_bytes(n, c) + 1024;
+    const size_t extra = 512 + lift_scratch_bytes(n, c) + 1024 + N * 8 + 256;
     LodDeviceOut o;
     r = lod_build_core(lane, lod, d_xyz + 3 * b, n, extra, &o, true);
     if (r)
@@ -3919,7 +3998,9 @@ dev_lift_attr(
     d.ni = o.neigh_index;
     d.nw = o.weight;
     d.indexes = o.indexes;
-    d.qp_off = nullptr;
+    r = qp_regions_to_points(lf, o.xyz, n, ar.take<int32_t>(N * 2), st, &d.qp_off);
+    if (r)
+      return r;
     d.attrs = d_attrs + b * c;    // the caller's buffers, in place
     d.coeffs = d_coeffs + b * c;
     int8_t* d_lcp = ar.take<int8_t>(GPCC_MAX_LODS);
@@ -3968,7 +4049,7 @@ dev_pred_attr(
     const bool icp_on = c == 3 && pp->inter_component_prediction_enabled_flag;
     const size_t b = (size_t)offsets[s], N = (size_t)(offsets[s + 1] - offsets[s]);
     const int32_t n = (int32_t)N;
-    const size_t extra = 1024 + pred_scratch_bytes(n) + 1024;
+    const size_t extra = 1024 + pred_scratch_bytes(n) + 1024 + N * 8 + 256;
     LodDeviceOut o;
     int r = lod_build_core(lane, lod, d_xyz + 3 * b, n, extra, &o, true);
     if (r)
@@ -3987,7 +4068,9 @@ dev_pred_attr(
     d.ni = o.neigh_index;
     d.nw = o.weight;
     d.indexes = o.indexes;
-    d.qp_off = nullptr;
+    r = qp_regions_to_points(pp, o.xyz, n, ar.take<int32_t>(N * 2), st, &d.qp_off);
+    if (r)
+      return r;
     d.attrs = d_attrs + b * c;  // the caller's buffers, in place
     d.values = d_values + b * c;
     int8_t* d_icp = ar.take<int8_t>(GPCC_MAX_LODS * 3);

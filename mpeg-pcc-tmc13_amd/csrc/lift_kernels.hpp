@@ -418,4 +418,35 @@ lift_writeback_kernel(LiftCtx cx)
   }
 }
 
+// QP regions of a slice (the qp_region_* fields of gpcc_lift_params / gpcc_pred_params) -> the region
+// offset of every POINT, as QpSet::regionQpOffset (tmc3/quantization.cpp:195-204) gives it: the first
+// region that contains the point, bounds inclusive (Box3::contains, PCCMath.h:469-474)
+struct QpRegionSet {
+  int32_t n;
+  int32_t lo[GPCC_MAX_QP_REGIONS][3], hi[GPCC_MAX_QP_REGIONS][3], off[GPCC_MAX_QP_REGIONS][2];
+};
+
+__global__ __launch_bounds__(256) void
+qp_region_fill_kernel(const int32_t* __restrict__ xyz, int n, QpRegionSet rs, int32_t* __restrict__ qp_off)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n)
+    return;
+  const int x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
+  int o0 = 0, o1 = 0;
+  bool found = false;
+  for (int r = 0; r < rs.n; r++) {
+    const bool in = !(x < rs.lo[r][0] || x > rs.hi[r][0] || y < rs.lo[r][1] || y > rs.hi[r][1] || z < rs.lo[r][2]
+                      || z > rs.hi[r][2]);
+    if (in && !found) {
+      found = true;
+      o0 = rs.off[r][0];
+      o1 = rs.off[r][1];
+    }
+  }
+  qp_off[2 * (size_t)i] = o0;
+  qp_off[2 * (size_t)i + 1] = o1;
+}
+
+
 }  // namespace gpcc

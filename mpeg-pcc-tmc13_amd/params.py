@@ -6,6 +6,7 @@ cfg/octree-raht-ctc-*.yaml)."""
 import ctypes as C
 
 GPCC_MAX_QP_LAYERS = 32
+GPCC_MAX_QP_REGIONS = 8
 GPCC_MAX_AC_QP_LAYERS = 32
 
 
@@ -101,7 +102,38 @@ class LiftParams(C.Structure):
         ("max_qp", C.c_int32),
         ("fixed_point_qp_offset", C.c_int32),
         ("scalable_lifting_enabled_flag", C.c_int32),
+        ("num_qp_regions", C.c_int32),
+        ("qp_region_min", (C.c_int32 * 3) * GPCC_MAX_QP_REGIONS),
+        ("qp_region_max", (C.c_int32 * 3) * GPCC_MAX_QP_REGIONS),
+        ("qp_region_offset", (C.c_int32 * 2) * GPCC_MAX_QP_REGIONS),
     ]
+
+
+def set_qp_regions(p, regions):
+    """regions: [((x0, y0, z0), (x1, y1, z1), (offset_luma, offset_chroma)), ...] -- the boxes' bounds
+    inclusive, the first region that contains a point counts (QpSet::regionQpOffset)"""
+    assert len(regions) <= GPCC_MAX_QP_REGIONS
+    p.num_qp_regions = len(regions)
+    for r, (lo, hi, off) in enumerate(regions):
+        for k in range(3):
+            p.qp_region_min[r][k] = int(lo[k])
+            p.qp_region_max[r][k] = int(hi[k])
+        p.qp_region_offset[r][0] = int(off[0])
+        p.qp_region_offset[r][1] = int(off[1])
+    return p
+
+
+def region_offsets(xyz, regions):
+    """the same as a per-point array [n][2] (what gpcc_lift_forward / gpcc_pred_forward take)"""
+    import numpy as np
+    xyz = np.asarray(xyz)
+    out = np.zeros((len(xyz), 2), dtype=np.int32)
+    done = np.zeros(len(xyz), dtype=bool)
+    for lo, hi, off in regions:
+        inside = np.all((xyz >= np.asarray(lo)) & (xyz <= np.asarray(hi)), axis=1) & ~done
+        out[inside] = off
+        done |= inside
+    return out
 
 
 def lift_params(num_points_in_lod, qp=34, chroma_offset=-1, bitdepth=8, lcp=True, layers=None, scalable=False):
@@ -143,6 +175,10 @@ class PredParams(C.Structure):
         ("quant_neigh_weight", C.c_int32 * 3),
         ("max_num_detail_levels", C.c_int32),
         ("scalable_lifting_enabled_flag", C.c_int32),
+        ("num_qp_regions", C.c_int32),
+        ("qp_region_min", (C.c_int32 * 3) * GPCC_MAX_QP_REGIONS),
+        ("qp_region_max", (C.c_int32 * 3) * GPCC_MAX_QP_REGIONS),
+        ("qp_region_offset", (C.c_int32 * 2) * GPCC_MAX_QP_REGIONS),
     ]
 
 

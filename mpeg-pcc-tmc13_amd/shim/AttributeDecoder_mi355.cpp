@@ -50,6 +50,7 @@ public:
   {
     const bool ours = aps.attr_encoding == AttributeEncoding::kLiftingTransform
       || aps.attr_encoding == AttributeEncoding::kPredictingTransform;
+    gpcc_clear_last_error();  // (what a decline of THIS slice reports is this slice's)
     _first.note(aps, abh, inter);  // (shim_common.hpp FirstLods: what the reference's object would cache)
     if (ours) {
       // (scalable lifting: whole slices only -- no points skipped by a partial decode)
@@ -97,6 +98,8 @@ private:
     if (!ctx || !flatten_lod(_first.aps, _first.abh, minGeomNodeSizeLog2, inter, &lod, true))
       return false;
     const QpSet qpSet = deriveQpSet(desc, aps, abh);
+    if (interSlice && !qpSet.regions.empty())
+      return false;  // (the entries with a reference frame take no QP regions)
     const bool lifting = aps.attr_encoding == AttributeEncoding::kLiftingTransform;
     gpcc_lift_params lp{};
     gpcc_pred_params pp{};

@@ -64,6 +64,7 @@ public:
   {
     const bool ours = aps.attr_encoding == AttributeEncoding::kLiftingTransform
       || aps.attr_encoding == AttributeEncoding::kPredictingTransform;
+    gpcc_clear_last_error();  // (what a decline of THIS slice reports is this slice's)
     _first.note(aps, abh, inter);  // (the structure this object's reference twin would cache from here on)
     if (ours) {
       if (on_device(sps, desc, aps, abh, ctxtMem, cloud, payload, inter)) {
@@ -111,6 +112,8 @@ private:
     if (!ctx || !flatten_lod(_first.aps, _first.abh, 0, inter, &lod, true))
       return false;
     const QpSet qpSet = deriveQpSet(desc, aps, abh);
+    if (interSlice && !qpSet.regions.empty())
+      return false;  // (the entries with a reference frame take no QP regions)
     const bool lifting = aps.attr_encoding == AttributeEncoding::kLiftingTransform;
 
     std::vector<int32_t> xyz, attrs, values(size_t(c) * n);
@@ -228,6 +231,11 @@ private:
     payload->insert(payload->end(), ac.buffer(), ac.buffer() + len);
     ctxtMem = models.saved();
     store_attributes(attrs, c, &cloud);
+    // (the reference's reflectance drivers leave the slice's distortion estimate for the slice-level
+    // inter / intra decision here, AttributeEncoder.cpp:760, 826, 1554; such slices are declined above --
+    // codeAttributeSecondPass -- so nothing reads it: zero, not a value of an earlier slice)
+    if (c == 1)
+      inter.distEstimate = 0.;
     return true;
   }
 

@@ -214,15 +214,23 @@ flatten_raht(
   return true;
 }
 
-// QpSet (quantization.h:124-139) -> the layer table of gpcc_lift_params /
-// gpcc_pred_params.  false: more layers than the block holds, or QP regions
-// (the one-call entries take the region offsets as zero)
+// QpSet (quantization.h:124-139) -> the layer table and the QP regions of gpcc_lift_params /
+// gpcc_pred_params.  false: more layers or regions than the block holds
 template<class Params>
 inline bool
 flatten_qp(const pcc::QpSet& qpSet, Params* p)
 {
-  if (!qpSet.regions.empty() || qpSet.layers.empty() || qpSet.layers.size() > GPCC_MAX_QP_LAYERS)
+  if (qpSet.layers.empty() || qpSet.layers.size() > GPCC_MAX_QP_LAYERS || qpSet.regions.size() > GPCC_MAX_QP_REGIONS)
     return false;
+  p->num_qp_regions = int(qpSet.regions.size());
+  for (int r = 0; r < p->num_qp_regions; r++) {
+    for (int k = 0; k < 3; k++) {
+      p->qp_region_min[r][k] = qpSet.regions[r].region.min[k];
+      p->qp_region_max[r][k] = qpSet.regions[r].region.max[k];
+    }
+    p->qp_region_offset[r][0] = qpSet.regions[r].qpOffset[0];
+    p->qp_region_offset[r][1] = qpSet.regions[r].qpOffset[1];
+  }
   p->num_qp_layers = int(qpSet.layers.size());
   for (int l = 0; l < p->num_qp_layers; l++) {
     p->layer_qp[l][0] = qpSet.layers[l][0];
@@ -287,8 +295,10 @@ build_inter_structure(
 {
   const auto& frame = inter.referencePointCloud;
   s->nFrame = int(frame.getPointCount());
-  if (s->nFrame <= 0 || !frame.hasReflectances())
+  if (s->nFrame <= 0 || !frame.hasReflectances()) {
+    std::fprintf(stderr, "gpcc: the reference frame of this slice has no reflectances; it stays on the CPU\n");
     return GPCC_ERR_UNSUPPORTED;
+  }
   std::vector<int32_t> xyzFrame;
   positions_of(frame, &xyzFrame);
   s->attrsFrame.resize(s->nFrame);

@@ -176,6 +176,18 @@ def ref_operator_roundtrip(lp, transform, rp, qp, chroma, bitdepth, lcp, xyz, at
     return pay[:ln].tobytes(), re.reshape(n, c), rd.reshape(n, c)
 
 
+def ref_set_qp_region(region, lib=None):
+    """the QP region of the attribute brick headers the harness builds from here on: None, or
+    (origin xyz, size xyz, (qp offset luma, chroma)) -- regionOrigin / regionSize / attr_region_qp_offset"""
+    lib = lib or ol.ref().lib
+    lib.ref_set_qp_region.argtypes = [C.c_int32, i32p]
+    lib.ref_set_qp_region.restype = None
+    flat = np.zeros(8, np.int32)
+    if region is not None:
+        flat[:] = list(region[0]) + list(region[1]) + list(region[2])
+    lib.ref_set_qp_region(int(region is not None), flat)
+
+
 def ref_two_attr_roundtrip(lp_a, transform_a, lp_b, transform_b, qp, xyz, colours, refl, lib=None):
     """colour (parameter set A) then reflectance (B) of one slice through the operator the way the
     reference's encoder / decoder drive it: the same coder object serves B when isReusable(B) says so.

@@ -98,6 +98,8 @@ def main():
     lib = C.CDLL(os.path.join(ROOT, "oracle", "_ref", case.get("lib", "libtmc3_shim.so")))
     import time
     t0 = time.time()
+    if case.get("region"):
+        lh.ref_set_qp_region(case["region"], lib=lib)
     extra = {}
     if case.get("two_attr"):
         xyz, col, refl, lpa, ta, lpb, tb = two_attr_case(case)
