@@ -779,19 +779,21 @@ typedef struct gpcc_recolour_params {
  * distances in double exactly as nanoflann's L2 adaptor sums them); backward:
  * every source point is appended to the list of its nearest target points; then
  * the blend and the +-search_range refinement of pointset_processing.cpp.
- * PARITY: all arithmetic is the reference's (double, same order) and the
- * neighbour SETS are exact; what differs is the choice among EQUIDISTANT
- * candidates -- nanoflann keeps whichever its k-d tree visits first, std::sort
- * leaves equal distances in an unspecified order; this library orders ties by
- * point index.  Results are identical wherever no tie decides (K-th place of the
- * forward search, nearest place of the backward search, truncation of a backward
- * list) and within the spread of the tied candidates' attributes elsewhere;
- * oracle/recolour_oracle.c is the bit-exact statement of this rule
+ * PARITY: identical to the reference, equidistant candidates included.  All arithmetic is the
+ * reference's (double, same order); where candidates are at EQUAL distance -- on a voxelised cloud
+ * at a dyadic scale: at nearly every point -- the reference's result is the order its containers
+ * produce, so they are rebuilt on the device: nanoflann's k-d trees (leaf size 10: divideTree /
+ * middleSplit_ / planeSplit, dependencies/nanoflann/nanoflann.hpp:872-998) level by level, its search
+ * (searchLevel :1308, KNNResultSet::addPoint :175) as a stack walk that visits candidates in
+ * nanoflann's order, and the backward lists in source order sorted by libstdc++'s std::sort
+ * (introsort, not stable beyond 16 entries).  oracle/recolour_oracle.c restates the same and is
+ * pinned to the compiled reference (tests/test_oracle_recolour.py); the device equals both
  * (tests/test_gpu_recolour.py).  Needs ns >= num_neighbours_fwd and
  * nt >= num_neighbours_bwd (else GPCC_ERR_UNSUPPORTED); a finite
  * max_geometry_dist2_fwd (< 512) is GPCC_ERR_UNSUPPORTED as well: the reference then
  * shrinks its result vectors for every LATER target point too (they live outside
- * its loop, :292-309), state that is not reproduced.  Host tier. */
+ * its loop, :292-309), state that is not reproduced; a k-d tree deeper than 64 levels is
+ * declined too (the search's stack).  Host tier. */
 int gpcc_recolour(
   gpcc_ctx* ctx, const gpcc_recolour_params* params, const int32_t* src_xyz,
   const int32_t* src_attrs, int32_t ns, const int32_t* tgt_xyz, int32_t nt,

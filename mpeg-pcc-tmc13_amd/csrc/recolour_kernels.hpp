@@ -124,6 +124,35 @@ rc_forward_kernel(RcCtx cx)
       out[k] = col[0][k];
     return;
   }
+  // the largest attribute distance among the first m neighbours, for every m, computed ONCE (the
+  // reference recomputes all pairs for every candidate count, :341-349 / 692-699): pm[m] = max over
+  // i, j < m, both orders (colour differences wrap in 16 bits there: Vec3<attr_t> - Vec3<attr_t>,
+  // tmc3/PCCMath.h:280; reflectances are subtracted as int)
+  double pm[K + 1];
+#pragma unroll
+  for (int m = 0; m <= K; m++)
+    pm[m] = 2.2250738585072014e-308;
+  if (ALIMIT) {
+#pragma unroll
+    for (int m = 2; m <= K; m++) {
+      double best = pm[m - 1];
+#pragma unroll
+      for (int j = 0; j < m - 1; j++) {
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < C; k++) {
+          const int32_t di = col[m - 1][k] - col[j][k];
+          const double d1 = C == 3 ? (double)(uint16_t)di : (double)di;
+          const double d2 = C == 3 ? (double)(uint16_t)(-di) : (double)(-di);
+          s1 += d1 * d1;
+          s2 += d2 * d2;
+        }
+        best = s1 > best ? s1 : best;
+        best = s2 > best ? s2 : best;
+      }
+      pm[m] = best;
+    }
+  }
   for (int nn = r.count; nn > 0; nn--) {
     if (nn == 1) {
 #pragma unroll
@@ -131,25 +160,10 @@ rc_forward_kernel(RcCtx cx)
         out[k] = col[0][k];
       return;
     }
-    // (colour differences wrap in 16 bits there: Vec3<attr_t> - Vec3<attr_t>,
-    // tmc3/PCCMath.h:280; reflectances are subtracted as int)
-    double maxa = 2.2250738585072014e-308;
-    if (ALIMIT)
+    double maxa = pm[1];
 #pragma unroll
-    for (int i = 0; i < K; i++)
-#pragma unroll
-      for (int j = 0; j < K; j++) {
-        if (i < nn && j < nn) {
-          double s = 0.0;
-#pragma unroll
-          for (int k = 0; k < C; k++) {
-            const int32_t di = col[i][k] - col[j][k];
-            const double d = C == 3 ? (double)(uint16_t)di : (double)di;
-            s += d * d;
-          }
-          maxa = s > maxa ? s : maxa;
-        }
-      }
+    for (int m = 2; m <= K; m++)
+      maxa = nn == m ? pm[m] : maxa;
     if (maxa > max_a)
       continue;
     double acc[C];

@@ -82,10 +82,10 @@ def test_duplicates_offset_and_small_clouds():
 
 
 def test_several_levels_above_the_subtrees():
-    """30 k points: four to five levels of the level-by-level build, then the wavefront-per-subtree
-    kernel (<= 2 048 points each) -- a lidar sweep (uneven splits) and a dense cloud at a dyadic scale"""
+    """18 k points: four levels of the level-by-level build, then the wavefront-per-subtree kernel
+    (<= 2 048 points each) -- a lidar sweep (uneven splits) and a dense cloud at a dyadic scale"""
     for kind, scale in (("lidar", 0.25), ("dense", 0.5)):
-        xyz, a = synth.lidar_cloud(30000, seed=8) if kind == "lidar" else synth.dense_cloud(30000, seed=8, bits=8)
+        xyz, a = synth.lidar_cloud(18000, seed=8) if kind == "lidar" else synth.dense_cloud(18000, seed=8, bits=8)
         tgt = requantise(xyz, scale)
         p = recolour_params(bitdepth=8)
         got = emu_recolour(p, xyz, a, tgt, scale=scale)
