@@ -4766,7 +4766,8 @@ kd_alloc(gpcc_ctx* ctx, KdAlloc* ka, const int32_t* d_xyz, int n)
   b.t.xyz = d_xyz;
   b.t.n = n;
   HIP_TRY(take((void**)&b.t.vind, sizeof(int32_t) * N));
-  HIP_TRY(take((void**)&b.t.nodes, sizeof(KdNode) * M));
+  b.node_cap = (int32_t)kd_node_capacity(N);
+  HIP_TRY(take((void**)&b.t.nodes, sizeof(KdNode) * kd_node_capacity(N)));
   HIP_TRY(take((void**)&b.pnode, sizeof(int32_t) * N));
   HIP_TRY(take((void**)&b.rng, sizeof(int32_t) * 2 * M));
   HIP_TRY(take((void**)&b.parent, sizeof(int32_t) * M));

@@ -38,7 +38,9 @@ constexpr int kKdMaxDepth = 64;   // deeper trees are declined (the search stack
 constexpr int kKdScanBlock = 2048;
 // A node of at most this many points leaves the level-by-level build: ONE WAVEFRONT finishes its
 // whole subtree in LDS (kd_subtree_kernel) -- the lower two thirds of a tree's levels in one launch.
-constexpr int kKdSub = 2048;
+// (2 048: 53 KB of LDS per wavefront, three wavefronts per CU, 3.1 ms per launch for a 1 M-point cloud --
+// a subtree is a chain of dependent LDS accesses, so what counts is how many run side by side.)
+constexpr int kKdSub = 1024;
 
 // what the search reads: 32 bytes per node
 struct KdNode {
@@ -52,13 +54,24 @@ struct KdTree {
   const int32_t* xyz;  // [n][3]
   int32_t n;
   int32_t* vind;       // [n] nanoflann's index permutation
-  KdNode* nodes;       // [2n + 1]
+  KdNode* nodes;       // [kd_node_capacity(n)]
   double root_lo[3], root_hi[3];
 };
 
-// the build's working set (capacity 2n + 1 nodes; node ids in order of creation)
+// A tree of n points has at most 2n - 1 nodes.  The subtrees take their node ids in one block each (2 per
+// point, one atomic per subtree instead of one per split -- the counter is a single address every
+// wavefront of the launch would queue on), so the ids have gaps: the levels above the subtrees hold
+// fewer than n / 8 nodes as long as the depth stays within kKdMaxDepth (each has more than kKdSub points).
+inline size_t
+kd_node_capacity(size_t n)
+{
+  return 2 * n + n / 4 + 64;
+}
+
+// the build's working set (the arrays of the level loop hold 2n + 2 nodes; node ids in order of creation)
 struct KdBuild {
   KdTree t;
+  int32_t node_cap;  // entries of t.nodes
   int32_t* pnode;    // [n] node of every POSITION of vind at the level being split, -1 = in a leaf
   int32_t* rng;      // [nodes][2] left, right
   int32_t* parent;   // [nodes]
@@ -80,6 +93,27 @@ __device__ __forceinline__ int
 kd_lane()
 {
   return (int)(threadIdx.x & 63);
+}
+
+__device__ __forceinline__ int
+kd_wave_min(int x)
+{
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_xor(x, d);
+    x = o < x ? o : x;
+  }
+  return x;
+}
+__device__ __forceinline__ int
+kd_wave_max(int x)
+{
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_xor(x, d);
+    x = o > x ? o : x;
+  }
+  return x;
 }
 
 // ---- scan (inclusive, in place; the arrays carry a leading zero) -----------------------
@@ -199,17 +233,39 @@ kd_init_kernel(KdBuild b, const int32_t* __restrict__ bbox)
   }
 }
 
-// Every launch over positions runs whole wavefronts through a loop of uniform length: lanes
-// beyond n carry node -1.  A wavefront whose lanes all sit in ONE node (the upper levels: always)
-// reduces in registers and issues one set of atomics.
+// kd_minmax / kd_count: a wavefront takes a CONTIGUOUS chunk of kKdChunk positions and keeps what it has
+// gathered for the node it is in across its rounds -- the nodes of a level are contiguous ranges, so at
+// the upper levels a wavefront issues ONE set of atomics (with a round of positions per wavefront and
+// launch it was 16 000 wavefronts on the same six words: 0.4-1.3 ms per launch for a 1 M-point cloud,
+// half of the build).  A round whose lanes sit in different nodes falls back to atomics per lane.
+constexpr int kKdChunk = 1024;
+
 __global__ __launch_bounds__(256) void
 kd_minmax_kernel(KdBuild b)
 {
   const int n = b.t.n;
-  const int stride = gridDim.x * blockDim.x;
-  const int rounds = (n + stride - 1) / stride;
-  for (int r = 0; r < rounds; r++) {
-    const int x = r * stride + blockIdx.x * blockDim.x + threadIdx.x;
+  const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const int lane = kd_lane();
+  const int x0 = wave * kKdChunk;
+  int run_node = -1;  // the node the running bounds belong to (wave-uniform)
+  int rmn[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, rmx[3] = {-0x7fffffff, -0x7fffffff, -0x7fffffff};
+  auto flush = [&]() {
+    if (run_node >= 0) {
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        const int mn = kd_wave_min(rmn[a]), mx = kd_wave_max(rmx[a]);
+        if (lane == 0) {
+          atomicMin(&b.mm[6 * run_node + a], mn);
+          atomicMax(&b.mm[6 * run_node + 3 + a], mx);
+        }
+        rmn[a] = 0x7fffffff;
+        rmx[a] = -0x7fffffff;
+      }
+    }
+    run_node = -1;
+  };
+  for (int r = 0; r < kKdChunk / 64; r++) {
+    const int x = x0 + r * 64 + lane;
     const int node = x < n ? b.pnode[x] : -1;
     int v[3] = {0, 0, 0};
     if (node >= 0) {
@@ -224,28 +280,28 @@ kd_minmax_kernel(KdBuild b)
     const int first = __ffsll((long long)live) - 1;
     const int node0 = __shfl(node, first);
     if (__all(node < 0 || node == node0)) {
+      if (node0 != run_node)
+        flush();
+      run_node = node0;
+      if (node >= 0) {
 #pragma unroll
-      for (int a = 0; a < 3; a++) {
-        int mn = node >= 0 ? v[a] : 0x7fffffff, mx = node >= 0 ? v[a] : -0x7fffffff;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-          const int o0 = __shfl_xor(mn, d), o1 = __shfl_xor(mx, d);
-          mn = o0 < mn ? o0 : mn;
-          mx = o1 > mx ? o1 : mx;
-        }
-        if (kd_lane() == first) {
-          atomicMin(&b.mm[6 * node0 + a], mn);
-          atomicMax(&b.mm[6 * node0 + 3 + a], mx);
+        for (int a = 0; a < 3; a++) {
+          rmn[a] = v[a] < rmn[a] ? v[a] : rmn[a];
+          rmx[a] = v[a] > rmx[a] ? v[a] : rmx[a];
         }
       }
-    } else if (node >= 0) {
+    } else {
+      flush();
+      if (node >= 0) {
 #pragma unroll
-      for (int a = 0; a < 3; a++) {
-        atomicMin(&b.mm[6 * node + a], v[a]);
-        atomicMax(&b.mm[6 * node + 3 + a], v[a]);
+        for (int a = 0; a < 3; a++) {
+          atomicMin(&b.mm[6 * node + a], v[a]);
+          atomicMax(&b.mm[6 * node + 3 + a], v[a]);
+        }
       }
     }
   }
+  flush();
 }
 
 // nodes [nb, ne) of the level: the parent's divlow / divhigh (:910-911: the bounds the recursion
@@ -334,10 +390,20 @@ __global__ __launch_bounds__(256) void
 kd_count_kernel(KdBuild b)
 {
   const int n = b.t.n;
-  const int stride = gridDim.x * blockDim.x;
-  const int rounds = (n + stride - 1) / stride;
-  for (int r = 0; r < rounds; r++) {
-    const int x = r * stride + blockIdx.x * blockDim.x + threadIdx.x;
+  const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  const int lane = kd_lane();
+  const int x0 = wave * kKdChunk;
+  int run_node = -1, c1 = 0, c2 = 0;  // (wave-uniform)
+  auto flush = [&]() {
+    if (run_node >= 0 && lane == 0) {
+      atomicAdd(&b.lim[2 * run_node], c1);
+      atomicAdd(&b.lim[2 * run_node + 1], c2);
+    }
+    run_node = -1;
+    c1 = c2 = 0;
+  };
+  for (int r = 0; r < kKdChunk / 64; r++) {
+    const int x = x0 + r * 64 + lane;
     int node = x < n ? b.pnode[x] : -1;
     int feat = -1;
     if (node >= 0)
@@ -358,17 +424,22 @@ kd_count_kernel(KdBuild b)
     const bool uniform = __all(node < 0 || node == node0);
     const unsigned long long blt = __ballot(lt), ble = __ballot(le);
     if (uniform) {
-      if (kd_lane() == first) {
-        atomicAdd(&b.lim[2 * node0], __popcll(blt));
-        atomicAdd(&b.lim[2 * node0 + 1], __popcll(ble));
+      if (node0 != run_node)
+        flush();
+      run_node = node0;
+      c1 += __popcll(blt);
+      c2 += __popcll(ble);
+    } else {
+      flush();
+      if (node >= 0) {
+        if (lt)
+          atomicAdd(&b.lim[2 * node], 1);
+        if (le)
+          atomicAdd(&b.lim[2 * node + 1], 1);
       }
-    } else if (node >= 0) {
-      if (lt)
-        atomicAdd(&b.lim[2 * node], 1);
-      if (le)
-        atomicAdd(&b.lim[2 * node + 1], 1);
     }
   }
+  flush();
 }
 
 // One of planeSplit's two loops over a node's range [lo, right): the zone [lo, zb) is where the
@@ -504,7 +575,7 @@ kd_assign_kernel(KdBuild b)
 // (the right child waits on a stack); every node is the reference's middleSplit_ / planeSplit with
 // the lanes over the node's range: bounds by reduction, lim1 / lim2 by ballots, a plane split as two
 // lists -- the misplaced positions of the left zone ascending, those of the right zone descending --
-// whose i-th entries change places.  Node ids come from the build's counter (two per split).
+// whose i-th entries change places.  Node ids come from a block taken from the build's counter.
 struct KdSubSmem {
   int32_t v[kKdSub];
   int32_t gid[kKdSub];
@@ -513,27 +584,6 @@ struct KdSubSmem {
   int32_t st_node[kKdMaxDepth + 2], st_l[kKdMaxDepth + 2], st_r[kKdMaxDepth + 2], st_lv[kKdMaxDepth + 2];
   double st_box[kKdMaxDepth + 2][6];
 };
-
-__device__ __forceinline__ int
-kd_wave_min(int x)
-{
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int o = __shfl_xor(x, d);
-    x = o < x ? o : x;
-  }
-  return x;
-}
-__device__ __forceinline__ int
-kd_wave_max(int x)
-{
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int o = __shfl_xor(x, d);
-    x = o > x ? o : x;
-  }
-  return x;
-}
 
 // one of planeSplit's loops on v[lo, hi): goes_left(coordinate) decides, m = entries that go left
 template<class Pred>
@@ -600,6 +650,18 @@ kd_subtree_kernel(KdBuild b, int nsub)
     sm.st_lv[0] = b.sub_list[b.t.n / 11 + 2 + blockIdx.x];
   }
   __builtin_amdgcn_wave_barrier();
+  // the subtree's node ids: one block, two per point
+  int next_id = 0;
+  if (cnt > kKdLeaf) {
+    if (lane == 0)
+      next_id = atomicAdd(&b.counters[0], 2 * cnt);
+    next_id = __shfl(next_id, 0);
+    if (next_id + 2 * cnt > b.node_cap) {
+      if (lane == 0)
+        atomicMax(&b.counters[3], kKdMaxDepth + 1);  // (the caller declines)
+      return;
+    }
+  }
   int sp = 0, deepest = 0;
   while (sp >= 0) {
     const int node = sm.st_node[sp], l = sm.st_l[sp], r = sm.st_r[sp], lv = sm.st_lv[sp];
@@ -689,10 +751,8 @@ kd_subtree_kernel(KdBuild b, int nsub)
     }
     lmax = kd_wave_max(lmax);
     rmin = kd_wave_min(rmin);
-    int c1 = 0;
-    if (lane == 0)
-      c1 = atomicAdd(&b.counters[0], 2);
-    c1 = __shfl(c1, 0);
+    const int c1 = next_id;
+    next_id += 2;
     if (lane == 0) {
       KdNode nd;
       nd.divlow = (double)lmax;
@@ -771,7 +831,7 @@ struct KdLevelLoop {
   {
     const int n = b.t.n;
     const int pgrid = (n + 255) / 256;
-    const int sgrid = std::min(pgrid, 2048);
+    const int sgrid = ((n + kKdChunk - 1) / kKdChunk + 3) / 4;  // one wavefront per chunk of positions
     if (phase == 0) {
       depth++;
       const int ngrid = (ne - nb + 255) / 256;

@@ -31,7 +31,8 @@ build_tree(std::vector<void*>* blocks, const int32_t* xyz, int n, const int32_t*
   b.t.xyz = xyz;
   b.t.n = n;
   b.t.vind = carve<int32_t>(blocks, N);
-  b.t.nodes = carve<KdNode>(blocks, M);
+  b.node_cap = (int32_t)kd_node_capacity(N);
+  b.t.nodes = carve<KdNode>(blocks, kd_node_capacity(N));
   b.pnode = carve<int32_t>(blocks, N);
   b.rng = carve<int32_t>(blocks, 2 * M);
   b.parent = carve<int32_t>(blocks, M);
@@ -58,7 +59,8 @@ build_tree(std::vector<void*>* blocks, const int32_t* xyz, int n, const int32_t*
 }
 }  // namespace
 
-// -> number of nodes (or < 0); vind[n], and per node {a, b, feat} + divlow / divhigh in creation order
+// -> node ids handed out (or < 0; ids have gaps: size the arrays by 2n + n/4 + 64); vind[n], and per node
+// {a, b, feat} + divlow / divhigh
 extern "C" int
 rc_emu_kdtree(const int32_t* xyz, int32_t n, int32_t* vind, int32_t* node_abf, double* node_div)
 {

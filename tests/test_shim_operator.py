@@ -49,10 +49,19 @@ def run_worker(case, strict):
 
 
 def unmodified(case):
+    """payload md5 / length / reconstruction digest of the unmodified build for the case"""
+    import lod_helpers as lh
+    lh.ref_set_qp_region(case.get("region"))
+    try:
+        return _unmodified(case)
+    finally:
+        lh.ref_set_qp_region(None)  # (the harness keeps the region for every header it builds: other tests share it)
+
+
+def _unmodified(case):
     import lod_helpers as lh
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import shim_operator_worker as w
-    lh.ref_set_qp_region(case.get("region"))
     if case.get("two_attr"):
         xyz, col, refl, lpa, ta, lpb, tb = w.two_attr_case(case)
         payload, enc2, dec2, reused = lh.ref_two_attr_roundtrip(lpa, ta, lpb, tb, case["qp"], xyz, col, refl)
