@@ -167,6 +167,41 @@ int gpcc_raht_inverse(
   const int32_t* qp_off, int32_t* attrs, const int32_t* coeffs, int32_t n,
   int32_t c);
 
+/* RAHT with attribute inter prediction: replaces pcc::regionAdaptiveHierarchicalTransform /
+ * ...InverseTransform (RAHT.h:47-69) called with attrInterPredParams.enableAttrInterPred and a reference
+ * frame in paramsForInterRAHT (PCCTMC3Common.h:236-298; RAHT.cpp:849-972 estimate_layer_filter,
+ * :1165-1198 the two trees in lock step, :1256-1347 per-layer decision, filter taps and block matching,
+ * :1504-1549 the frame's block as prediction, :1810-1829 the decision).
+ *   morton_ref [n_ref], attrs_ref [n_ref*c]  the reference frame, Morton order (paramsForInterRAHT.
+ *                                            mortonCode / attributes)
+ *   layer_modes [32], num_modes   attr_layer_code_mode: written by the encoder, read by the decoder
+ *   filter_taps [32], num_taps    FilterTaps (quantised): written by the encoder when
+ *                                 enable_filter_estimation, read by the decoder
+ * Everything else as gpcc_raht_forward / _inverse.  On the device: slices WITHOUT sub-node prediction
+ * (raht_subnode_prediction_enabled_flag = 0 or raht_prediction_enabled_flag = 0) and without the integer
+ * Haar kernel or region QP offsets; the rest returns GPCC_ERR_UNSUPPORTED (the CPU keeps it).  The
+ * per-layer decision compares two sums of doubles the reference accumulates in coding order with log2 of
+ * the HOST's libm inside: the library fills its log2 table from the same libm and adds in the same order
+ * (csrc/raht_inter.hpp); a coefficient magnitude beyond the table (2^20) returns GPCC_ERR_UNSUPPORTED. */
+typedef struct gpcc_raht_inter_params {
+  int32_t raht_inter_prediction_depth_minus1;
+  int32_t raht_enable_inter_intra_layer_rdo;
+  int32_t enable_filter_estimation;
+  int32_t skip_init_layers_for_filtering;
+} gpcc_raht_inter_params;
+
+int gpcc_raht_forward_inter(
+  gpcc_ctx* ctx, const gpcc_raht_params* params, const gpcc_raht_inter_params* inter,
+  const int64_t* morton, int32_t* attrs, int32_t* coeffs, int32_t n, int32_t c,
+  const int64_t* morton_ref, const int32_t* attrs_ref, int32_t n_ref,
+  int32_t* layer_modes, int32_t* num_modes, int32_t* filter_taps, int32_t* num_taps);
+
+int gpcc_raht_inverse_inter(
+  gpcc_ctx* ctx, const gpcc_raht_params* params, const gpcc_raht_inter_params* inter,
+  const int64_t* morton, int32_t* attrs, const int32_t* coeffs, int32_t n, int32_t c,
+  const int64_t* morton_ref, const int32_t* attrs_ref, int32_t n_ref,
+  const int32_t* layer_modes, int32_t num_modes, const int32_t* filter_taps, int32_t num_taps);
+
 /* Replaces the Morton-code + std::sort(MortonCodeWithIndex) prologue of
  * encode/decode{Colors,Reflectances}TransformRaht
  * (AttributeEncoder.cpp:1225-1229,1316-1321; AttributeDecoder.cpp:538-542,

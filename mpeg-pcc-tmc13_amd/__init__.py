@@ -5,7 +5,7 @@ loaded under the importable alias ``mpeg_pcc_tmc13_amd`` by
 ``__graft_entry__.load_package()`` / ``tests/conftest.py``.
 """
 from . import params, synth  # noqa: F401
-from .params import (LiftParams, LodParams, PredParams, RahtParams, RecolourParams, lift_params,  # noqa: F401
+from .params import (LiftParams, LodParams, PredParams, RahtInterParams, RahtParams, RecolourParams, lift_params,  # noqa: F401
                      lod_params, pred_params, raht_params, recolour_params)
 
 

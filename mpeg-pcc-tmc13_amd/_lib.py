@@ -15,6 +15,7 @@ ABI_SYMBOLS = [
     "gpcc_device_count", "gpcc_ctx_create", "gpcc_ctx_destroy",
     "gpcc_ctx_synchronize", "gpcc_ctx_workspace_bytes", "gpcc_ctx_set_morton_bits", "gpcc_ctx_set_fast_arith", "gpcc_ctx_pred_pass_stats",
     "gpcc_raht_forward", "gpcc_raht_inverse", "gpcc_attr_morton_sort",
+    "gpcc_raht_forward_inter", "gpcc_raht_inverse_inter",
     "gpcc_dev_raht_forward", "gpcc_dev_raht_inverse", "gpcc_dev_attr_morton_sort",
     "gpcc_ctx_set_profiling", "gpcc_ctx_kernel_times", "gpcc_ctx_stats",
     "gpcc_lift_forward", "gpcc_lift_inverse", "gpcc_lod_compute_weights", "gpcc_lod_build", "gpcc_lod_build_inter", "gpcc_lift_forward_inter", "gpcc_lift_inverse_inter", "gpcc_pred_forward_inter", "gpcc_pred_inverse_inter", "gpcc_estimate_dist2", "gpcc_recolour", "gpcc_raht_encode_attr", "gpcc_raht_decode_attr",
@@ -84,6 +85,8 @@ def load():
     lib.gpcc_raht_set_prediction_weights.restype = None
     for name in ("gpcc_raht_forward", "gpcc_raht_inverse"):
         getattr(lib, name).argtypes = [vp, pp, vp, vp, vp, vp, i32, i32]
+    lib.gpcc_raht_forward_inter.argtypes = [vp, pp, vp, vp, vp, vp, i32, i32, vp, vp, i32, vp, C.POINTER(i32), vp, C.POINTER(i32)]
+    lib.gpcc_raht_inverse_inter.argtypes = [vp, pp, vp, vp, vp, vp, i32, i32, vp, vp, i32, vp, i32, vp, i32]
     lib.gpcc_attr_morton_sort.argtypes = [vp, vp, i32, vp, vp]
     for name in ("gpcc_dev_raht_forward", "gpcc_dev_raht_inverse"):
         getattr(lib, name).argtypes = [vp, pp, i32, i64p, vp, vp, vp, vp, i32]

@@ -41,6 +41,7 @@
 #include "raht_tile.hpp"
 #include "raht_tree.hpp"
 #include "cx_driver.hpp"
+#include "raht_inter_driver.hpp"
 #include "lift_kernels.hpp"
 #include "lod_kernels.hpp"
 #include "lod_scalable.hpp"
@@ -519,6 +520,21 @@ ensure_arena(gpcc_ctx* ctx, size_t bytes)
   return GPCC_OK;
 }
 
+// log2 of every integer the rate estimates can ask for (0 .. 2^20), from THIS host's libm -- the
+// reference's own log2: once per context (predicting encoder's rate model, inter-frame RAHT's per-layer decision)
+int
+ensure_log2(gpcc_ctx* ctx)
+{
+  if (!ctx->d_log2) {
+    std::vector<double> tab(((size_t)1 << 20) + 1);
+    for (size_t v = 0; v < tab.size(); v++)
+      tab[v] = log2((double)v);
+    HIP_TRY(hipMalloc((void**)&ctx->d_log2, tab.size() * sizeof(double)));
+    HIP_TRY(hipMemcpy(ctx->d_log2, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
+  return GPCC_OK;
+}
+
 int
 check_params(const gpcc_raht_params* p, int c, bool encoder)
 {
@@ -918,6 +934,10 @@ check_device_error(gpcc_ctx* ctx)
         GPCC_ERR_RANGE,
         "values beyond the range of the fast arithmetic path (attributes wider than max_qp's bit "
         "depth says?); nothing was written -- gpcc_ctx_set_fast_arith(ctx, 0) and call again");
+    if (code == 4)
+      return fail(
+        GPCC_ERR_UNSUPPORTED,
+        "inter-frame RAHT: a coefficient magnitude beyond the rate estimate's log2 table; nothing was written");
     if (code == 2)
       return fail(
         GPCC_ERR_INVALID_ARG,
@@ -1147,6 +1167,168 @@ host_transform(
   return r;
 }
 
+
+// ---- RAHT with attribute inter prediction (raht_inter_driver.hpp): host tier -------------------
+template<int C>
+int
+launch_inter(
+  gpcc_ctx* ctx, InterWork& w, const InterTools& tl, const gpcc_raht_params* hp, const int64_t* d_ref_pos,
+  const int32_t* d_ref_attrs, int32_t* d_attrs, int32_t* d_coeffs)
+{
+  hipStream_t st = ctx->stream;
+  hipError_t e = inter_run<C>(
+    st, w, tl, hp, ctx->d_lut, ctx->d_log2, d_ref_pos, d_ref_attrs, d_attrs, d_coeffs, ctx->h_stats,
+    [&](const char* name, int li) { return Timer(ctx, li < 0 ? name : level_name(name, li)); },
+    [&]() -> hipError_t { return hipEventRecord(ctx->ev_stats, st); },
+    [&]() -> hipError_t { return hipEventSynchronize(ctx->ev_stats); });
+  if (e != hipSuccess)
+    return fail(GPCC_ERR_HIP, std::string("inter-frame RAHT: ") + hipGetErrorString(e));
+  if (ctx->h_error)
+    HIP_TRY(hipMemcpyAsync(ctx->h_error, ctx->d_error, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  return GPCC_OK;
+}
+
+int
+host_transform_inter(
+  gpcc_ctx* ctx, const gpcc_raht_params* params, const gpcc_raht_inter_params* inter, bool encoder,
+  const int64_t* morton, int32_t* attrs, int32_t* coeffs, int32_t n, int32_t c, const int64_t* morton_ref,
+  const int32_t* attrs_ref, int32_t n_ref, int32_t* layer_modes, int32_t* num_modes, int32_t* filter_taps,
+  int32_t* num_taps)
+{
+  if (!ctx)
+    return fail(GPCC_ERR_INVALID_ARG, "ctx is null");
+  if (!morton || !attrs || !coeffs || n <= 0 || !inter || !morton_ref || !attrs_ref || n_ref <= 0 || !layer_modes
+      || !num_modes || !filter_taps || !num_taps)
+    return fail(GPCC_ERR_INVALID_ARG, "null buffer or n <= 0");
+  if (n > kMaxPoints || n_ref > kMaxPoints)
+    return fail(GPCC_ERR_INVALID_ARG, "more than 2^29 points per call");
+  int rcode = check_params(params, c, encoder);
+  if (rcode)
+    return rcode;
+  if (!encoder && (*num_modes < 0 || *num_modes > 32 || *num_taps < 0 || *num_taps > 32))
+    return fail(GPCC_ERR_INVALID_ARG, "at most 32 layer modes / filter taps");
+  if (!inter_supported(params, n))
+    return fail(
+      GPCC_ERR_UNSUPPORTED,
+      "inter-frame RAHT on the device: not with sub-node prediction, the integer Haar kernel or a single point");
+  for (int i = 1; i < n; i++)
+    if (morton[i] < morton[i - 1])
+      return fail(GPCC_ERR_UNSORTED, "Morton codes are not ascending");
+  for (int i = 1; i < n_ref; i++)
+    if (morton_ref[i] < morton_ref[i - 1])
+      return fail(GPCC_ERR_UNSORTED, "Morton codes of the reference frame are not ascending");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  int rl = ensure_log2(ctx);
+  if (rl)
+    return rl;
+
+  InterWork w;
+  w.n = n;
+  w.c = c;
+  w.n_ref = n_ref;
+  w.encoder = encoder;
+  InterTools tl;
+  tl.depth_limit = inter->raht_inter_prediction_depth_minus1 + 1;
+  tl.layer_rdo = inter->raht_enable_inter_intra_layer_rdo != 0;
+  tl.filter_est = inter->enable_filter_estimation != 0;
+  tl.skip_layers = inter->skip_init_layers_for_filtering;
+  tl.bits_cur = bitlen64((uint64_t)(morton[0] ^ morton[n - 1]));
+  tl.bits_ref = n_ref <= 1 ? -1 : bitlen64((uint64_t)(morton_ref[0] ^ morton_ref[n_ref - 1]));
+  if (!encoder) {
+    tl.modes = layer_modes;
+    tl.num_modes = *num_modes;
+    tl.taps = filter_taps;
+    tl.num_taps = *num_taps;
+  }
+  w.nlev = std::min((std::max(tl.bits_cur, 1) + 2) / 3 + 1, (int)kMaxLevels);
+  size_t need = 0;
+  inter_carve(
+    [&](size_t bytes) {
+      need += (bytes + 255) & ~size_t(255);
+      return (char*)nullptr;
+    },
+    w);
+  char* work = nullptr;
+  int64_t* d_m = nullptr;
+  int64_t* d_mr = nullptr;
+  int32_t *d_a = nullptr, *d_c = nullptr, *d_ar = nullptr;
+  auto cleanup = [&]() {
+    pool_free(ctx, work);
+    pool_free(ctx, d_m);
+    pool_free(ctx, d_mr);
+    pool_free(ctx, d_a);
+    pool_free(ctx, d_c);
+    pool_free(ctx, d_ar);
+  };
+  auto run = [&]() -> int {
+    HIP_TRY(pool_malloc(ctx, (void**)&work, need + 256));
+    HIP_TRY(pool_malloc(ctx, (void**)&d_m, sizeof(int64_t) * n));
+    HIP_TRY(pool_malloc(ctx, (void**)&d_mr, sizeof(int64_t) * n_ref));
+    HIP_TRY(pool_malloc(ctx, (void**)&d_a, sizeof(int32_t) * n * c));
+    HIP_TRY(pool_malloc(ctx, (void**)&d_c, sizeof(int32_t) * n * c));
+    HIP_TRY(pool_malloc(ctx, (void**)&d_ar, sizeof(int32_t) * (size_t)n_ref * c));
+    size_t off = 0;
+    inter_carve(
+      [&](size_t bytes) {
+        char* p = work + off;
+        off += (bytes + 255) & ~size_t(255);
+        return p;
+      },
+      w);
+    w.tv.pos = d_m;
+    w.tv.error = ctx->d_error;
+    HIP_TRY(h2d_user(ctx, d_m, morton, sizeof(int64_t) * n, st));
+    HIP_TRY(h2d_user(ctx, d_mr, morton_ref, sizeof(int64_t) * n_ref, st));
+    HIP_TRY(h2d_user(ctx, d_ar, attrs_ref, sizeof(int32_t) * (size_t)n_ref * c, st));
+    if (encoder) {
+      HIP_TRY(h2d_user(ctx, d_a, attrs, sizeof(int32_t) * n * c, st));
+      HIP_TRY(hipMemsetAsync(d_c, 0, sizeof(int32_t) * n * c, st));
+    } else {
+      HIP_TRY(h2d_user(ctx, d_c, coeffs, sizeof(int32_t) * n * c, st));
+    }
+    const int32_t h_off[2] = {0, n};
+    const int32_t h_rt[2] = {0, w.num_rtiles};
+    HIP_TRY(hipMemcpyAsync(w.params, params, sizeof(*params), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(w.pt_off, h_off, sizeof(h_off), hipMemcpyHostToDevice, st));
+    if (w.rtile_base)
+      HIP_TRY(hipMemcpyAsync(w.rtile_base, h_rt, sizeof(h_rt), hipMemcpyHostToDevice, st));
+    int r = GPCC_ERR_INVALID_ARG;
+    switch (c) {
+    case 1: r = launch_inter<1>(ctx, w, tl, params, d_mr, d_ar, d_a, d_c); break;
+    case 2: r = launch_inter<2>(ctx, w, tl, params, d_mr, d_ar, d_a, d_c); break;
+    case 3: r = launch_inter<3>(ctx, w, tl, params, d_mr, d_ar, d_a, d_c); break;
+    }
+    if (r)
+      return r;
+    HIP_TRY(hipStreamSynchronize(st));
+    r = check_device_error(ctx);
+    if (r)
+      return r;
+    HIP_TRY(d2h_user(ctx, attrs, d_a, sizeof(int32_t) * n * c, st));
+    if (encoder) {
+      HIP_TRY(d2h_user(ctx, coeffs, d_c, sizeof(int32_t) * n * c, st));
+      RateState rs;
+      int32_t nt = 0;
+      HIP_TRY(hipMemcpyAsync(&rs, w.rs, sizeof(rs), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(&nt, w.num_taps, sizeof(nt), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(layer_modes, w.modes, 32 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(filter_taps, w.taps, 32 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      *num_modes = rs.num_modes;
+      *num_taps = nt;
+      for (int i = rs.num_modes; i < 32; i++)
+        layer_modes[i] = 0;
+      for (int i = nt; i < 32; i++)
+        filter_taps[i] = 0;
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    return GPCC_OK;
+  };
+  const int r = run();
+  cleanup();
+  return r;
+}
 
 // ---- lifting transform ---------------------------------------------------
 
@@ -1639,13 +1821,9 @@ launch_pred(
   if (deciding) {
     // log2 of every integer the rate estimate can ask for, from THIS host's libm (the
     // reference's own log2): once per context
-    if (!ctx->d_log2) {
-      std::vector<double> tab((size_t)kRateScale + 1);
-      for (int v = 0; v <= kRateScale; v++)
-        tab[v] = log2((double)v);
-      HIP_TRY(hipMalloc((void**)&ctx->d_log2, tab.size() * sizeof(double)));
-      HIP_TRY(hipMemcpy(ctx->d_log2, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
-    }
+    int rl = ensure_log2(ctx);
+    if (rl)
+      return rl;
     HIP_TRY(hipMemcpyAsync(src_copy, d.attrs, sizeof(int32_t) * (size_t)n * C, hipMemcpyDeviceToDevice, st));
     cx.src = src_copy;
     cx.rm = rm;
@@ -3546,6 +3724,35 @@ gpcc_raht_inverse(
   int32_t c)
 {
   return counted(ctx, gpcc_raht_inverse_impl(ctx, params, morton, qp_off, attrs, coeffs, n, c), n);
+}
+
+int
+gpcc_raht_forward_inter(
+  gpcc_ctx* ctx, const gpcc_raht_params* params, const gpcc_raht_inter_params* inter, const int64_t* morton,
+  int32_t* attrs, int32_t* coeffs, int32_t n, int32_t c, const int64_t* morton_ref, const int32_t* attrs_ref,
+  int32_t n_ref, int32_t* layer_modes, int32_t* num_modes, int32_t* filter_taps, int32_t* num_taps)
+{
+  return counted(
+    ctx,
+    host_transform_inter(
+      ctx, params, inter, true, morton, attrs, coeffs, n, c, morton_ref, attrs_ref, n_ref, layer_modes, num_modes,
+      filter_taps, num_taps),
+    n);
+}
+
+int
+gpcc_raht_inverse_inter(
+  gpcc_ctx* ctx, const gpcc_raht_params* params, const gpcc_raht_inter_params* inter, const int64_t* morton,
+  int32_t* attrs, const int32_t* coeffs, int32_t n, int32_t c, const int64_t* morton_ref, const int32_t* attrs_ref,
+  int32_t n_ref, const int32_t* layer_modes, int32_t num_modes, const int32_t* filter_taps, int32_t num_taps)
+{
+  int32_t nm = num_modes, nt = num_taps;
+  return counted(
+    ctx,
+    host_transform_inter(
+      ctx, params, inter, false, morton, attrs, const_cast<int32_t*>(coeffs), n, c, morton_ref, attrs_ref, n_ref,
+      const_cast<int32_t*>(layer_modes), &nm, const_cast<int32_t*>(filter_taps), &nt),
+    n);
 }
 
 int

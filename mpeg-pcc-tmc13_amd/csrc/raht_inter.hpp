@@ -1,0 +1,626 @@
+// raht_inter.hpp -- attribute inter prediction in RAHT (tmc3/RAHT.cpp:849-972, 1165-1198, 1256-1347,
+// 1504-1549, 1810-1829): what the level pass without sub-node prediction (raht_tile.hpp) needs on top of
+// the intra coder when a reference frame is given.
+//
+//   the frame's blocks   The reference descends a SECOND tree in lock step, each from its own top, and
+//                        matches the block of a parent against the frame's nodes with the same key.  The
+//                        frame's points are in Morton order, so that tree is never built here: the node
+//                        with key k at bit level lr is the run of points with pos >> lr == k -- two
+//                        bisections per child position, weight = length of the run, attribute sum = a
+//                        difference of the frame's modular prefix sums (the reference sums in `int` too).
+//                        The frame's block is transformed IN ITS OWN WEIGHTS by the same eight lanes and,
+//                        filtered by the level's tap, predicts every coefficient of the block
+//                        (inter_block below).
+//   two candidates       With raht_enable_inter_intra_layer_RDO the encoder codes a level twice -- with
+//                        the frame and without -- and keeps the cheaper one by an adaptive rate estimate
+//                        (PCCRAHTACCoefficientEntropyEstimate, RAHT.h:71-94): the analyze pass writes both
+//                        candidates (coefficients, RDOQ descriptors, transformed predictions), both zero-run
+//                        chains are resolved (raht_rdoq.hpp, twice), then the estimate:
+//                          rate_chain   the estimate's probabilities are a recurrence over ALL coefficients
+//                                       in coding order (p += (2^20 - p) >> 6 or p -= p >> 6: the shifts do
+//                                       not compose): one wavefront per chain (candidate x {p0, p1} x
+//                                       component) walks it in scalar registers, 64 coefficients per
+//                                       coalesced load, and records the state before every coefficient;
+//                          rate_bits    the cost of every coefficient from those states, in parallel
+//                                       (log2 from a table the HOST's libm filled -- the comparison of the
+//                                       two sums must come out as it does in the reference);
+//                          rate_sum     the reference adds the costs into a double in coding order: one
+//                                       lane per candidate does exactly that;
+//                          decide       the cheaper candidate's coefficients, prediction record, zero-run
+//                                       state and probabilities go on (inter_commit).
+//                        The chains are what a level costs (about 12 ms per 1 M coefficients); everything
+//                        else is the intra pass twice.
+//   estimated taps       (enableFilterEstimation) the level's tap is 128 * crosscorr / autocorr of the
+//                        first component's coefficients over every block that lines up (inter_tap_kernel:
+//                        integer sums, any order), quantised like a coefficient (inter_tap_finish_kernel).
+#pragma once
+
+#include "raht_levels.hpp"
+
+namespace gpcc {
+
+constexpr int kAcRateScaleLog = 20;
+constexpr uint32_t kAcRateScale = 1u << kAcRateScaleLog;
+constexpr int kAcRateTable = 1 << 20;  // log2 of 1 .. 2^20 (probabilities, and magnitudes the table covers)
+
+// first frame point whose node at bit level `sh` has a key >= k
+__device__ __forceinline__ int
+inter_lower_bound(const int64_t* __restrict__ pos, int n, int sh, uint64_t k)
+{
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = lo + ((hi - lo) >> 1);
+    if (((uint64_t)pos[mid] >> sh) < k)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+
+// The frame's block under the parent with key `pkey`, by the eight lanes of a group (lane t = child
+// position t; every lane of the wavefront calls).  *node: the frame has a node there (:1322-1347; the
+// caller excludes single-child blocks under the extension).  out[k]: the frame's coefficient at position
+// t -- its attribute sums normalised, transformed in the frame's own weights (:1533-1545) and filtered --
+// or 0 where the frame's block has none (fwdTransformBlock222 swaps values into place, :680-690, so a
+// position without a coefficient ends up holding what an empty position held: 0).
+template<int C>
+__device__ __forceinline__ void
+inter_block(const InterRef& ir, int64_t pkey, int t, bool on, const SharedLut& lut, bool* node, int64_t out[C])
+{
+  int32_t wr = 0;
+  int64_t v[C];
+#pragma unroll
+  for (int k = 0; k < C; k++)
+    v[k] = 0;
+  if (on) {
+    const uint64_t k0 = ((uint64_t)pkey << 3) + (uint64_t)t;
+    const int lo = inter_lower_bound(ir.pos, ir.n_ref, ir.lr, k0);
+    const int hi = inter_lower_bound(ir.pos, ir.n_ref, ir.lr, k0 + 1);
+    wr = hi - lo;
+    if (wr > 0) {
+#pragma unroll
+      for (int k = 0; k < C; k++)
+        v[k] = fp_from_int((int32_t)((uint32_t)ir.prefix[(size_t)hi * C + k] - (uint32_t)ir.prefix[(size_t)lo * C + k]));
+    }
+  }
+  *node = group8_bits(wr > 0) != 0;
+  if (wr > 1) {
+#pragma unroll
+    for (int k = 0; k < C; k++)
+      v[k] = scale_rsqrt(v[k], wr, lut);
+  }
+  int32_t cw = wr;
+#pragma unroll
+  for (int st = 0; st < 3; st++) {
+    const int bit = 1 << st;
+    const int32_t pw = lane_xor8(cw, bit);
+    const bool left = !(t & bit);
+    const int32_t wl = left ? cw : pw, wrr = left ? pw : cw;
+    const bool both = wl && wrr;
+    const bool swap = !wl && wrr;
+    int64_t ca = 0, cb = 0;
+    if (both)
+      raht_coeffs(wl, wrr, lut, &ca, &cb);
+#pragma unroll
+    for (int k = 0; k < C; k++) {
+      const int64_t own = v[k];
+      const int64_t oth = shfl_xor_i64(own, bit);
+      if (both)
+        v[k] = left ? fp_mul_c(oth, cb) + fp_mul_c(own, ca) : fp_mul_c(own, ca) - fp_mul_c(oth, cb);
+      else if (swap)
+        v[k] = oth;
+    }
+    cw = both ? wl + wrr : (left ? wl + wrr : 0);
+  }
+  const int64_t tap = ir.filtered ? (int64_t)*ir.tap : 128;
+#pragma unroll
+  for (int k = 0; k < C; k++)
+    out[k] = ir.filtered ? (v[k] * tap) >> 7 : v[k];
+}
+
+// ---- the rate estimate of the per-level decision ---------------------------------------------------
+// est 0 = the candidate with the frame ("cur"), est 1 = the intra candidate
+struct RateState {
+  int32_t p0[2][3], p1[2][3];  // the estimates' probabilities before the level
+  int32_t q0[2][3], q1[2][3];  // ... after it (rate_chain)
+  double bits[2];              // the level's cost per candidate (rate_sum)
+  int32_t itz;                 // the intra candidate's zero run behind its last dual level (:1252-1254)
+  int32_t intra_wins;          // the level's decision
+  int32_t num_modes;           // decisions taken so far
+  int32_t pad;
+};
+
+struct RateCtx {
+  TreeView tv;
+  const int32_t* plane[2];  // coefficients of the two candidates (planar, stride n)
+  int32_t n;
+  int32_t a, b;             // the level's coefficients
+  int32_t c;
+  int32_t* pb;              // [2 est][2 p0 / p1][C][n] probability in front of every coefficient
+  double* term;             // [2 est][n * C] cost of every (coefficient, component) in coding order
+  RateState* rs;
+  const double* log2tab;    // [kAcRateTable + 1] log2((double)x)
+  int32_t* slice_l;         // [1] the zero-run state of the candidate with the frame (raht_rdoq.hpp) ...
+  int32_t* islice_l;        // [1] ... and of the intra candidate
+  int32_t* modes;           // [32] attr_layer_code_mode, in order
+  // commit
+  int32_t* coeffs;
+  const int32_t* icoeffs;
+  int64_t* ptrans;
+  const int64_t* iptrans;
+  int32_t rows;             // children of the level (rows of the prediction record)
+};
+
+__global__ __launch_bounds__(64) void
+rate_init_kernel(RateState* rs)
+{
+  if (threadIdx.x == 0) {
+    for (int e = 0; e < 2; e++) {
+      for (int k = 0; k < 3; k++)
+        rs->p0[e][k] = rs->p1[e][k] = rs->q0[e][k] = rs->q1[e][k] = (int32_t)(kAcRateScale >> 1);
+      rs->bits[e] = 0.0;
+    }
+    rs->itz = 0;
+    rs->intra_wins = 0;
+    rs->num_modes = 0;
+    rs->pad = 0;
+  }
+}
+
+// in front of a dual level: the intra candidate's zero run is what ITS last level left (it is not updated
+// by the levels coded once in between, :1618-1669), as an index of the last reset (raht_rdoq.hpp)
+__global__ __launch_bounds__(64) void
+rate_level_begin_kernel(RateCtx cx)
+{
+  if (tree_failed(cx.tv))
+    return;
+  if (threadIdx.x == 0) {
+    cx.islice_l[0] = cx.a - 1 - cx.rs->itz;
+    cx.rs->bits[0] = cx.rs->bits[1] = 0.0;
+  }
+}
+
+// one workgroup (one wavefront) per chain: est x {p0, p1} x component
+__global__ __launch_bounds__(64) void
+rate_chain_kernel(RateCtx cx)
+{
+  if (tree_failed(cx.tv))
+    return;
+  const int lane = threadIdx.x & 63;
+  const int C = cx.c;
+  const int est = (int)blockIdx.x / (2 * C);
+  const int which = ((int)blockIdx.x % (2 * C)) / C;
+  const int k = (int)blockIdx.x % C;
+  const int count = cx.b - cx.a;
+  const int32_t* __restrict__ v = cx.plane[est] + (size_t)k * cx.n + cx.a;
+  int32_t* __restrict__ out = cx.pb + ((size_t)((est * 2 + which) * C + k)) * cx.n;
+  int p = which ? cx.rs->p1[est][k] : cx.rs->p0[est][k];
+  for (int base = 0; base < count; base += 64) {
+    const int i = base + lane;
+    const int32_t val = i < count ? v[i] : 0;
+    const unsigned long long nz = __ballot(val != 0);
+    const unsigned long long big = __ballot(val > 1 || val < -1);
+    const int m = count - base < 64 ? count - base : 64;
+    int rec = 0;
+    for (int u = 0; u < m; u++) {
+      rec = lane == u ? p : rec;
+      const bool isnz = (nz >> u) & 1;
+      const bool isbig = (big >> u) & 1;
+      const int up = (int)((kAcRateScale - (uint32_t)p) >> 6), dn = -(p >> 6);
+      if (which == 0)
+        p += isnz ? up : dn;
+      else if (isnz)
+        p += isbig ? up : dn;
+    }
+    if (i < count)
+      out[i] = rec;
+  }
+  if (lane == 0) {
+    if (which)
+      cx.rs->q1[est][k] = p;
+    else
+      cx.rs->q0[est][k] = p;
+  }
+}
+
+// PCCRAHTACCoefficientEntropyEstimate::costBits (RAHT.cpp:54-78): the same additions in the same order
+__global__ __launch_bounds__(256) void
+rate_bits_kernel(RateCtx cx)
+{
+#pragma clang fp contract(off)
+  if (tree_failed(cx.tv))
+    return;
+  const int C = cx.c;
+  const int count = cx.b - cx.a;
+  const double lg = (double)kAcRateScaleLog;
+  const double* __restrict__ T = cx.log2tab;
+  for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < 2 * (int64_t)count; x += (int64_t)gridDim.x * blockDim.x) {
+    const int est = x >= count;
+    const int i = (int)(x - (est ? count : 0));
+    for (int k = 0; k < C; k++) {
+      const int32_t value = cx.plane[est][(size_t)k * cx.n + cx.a + i];
+      const int p0 = cx.pb[((size_t)((est * 2 + 0) * C + k)) * cx.n + i];
+      const int p1 = cx.pb[((size_t)((est * 2 + 1) * C + k)) * cx.n + i];
+      double bits = 0;
+      bits += value ? lg - T[p0] : lg - T[kAcRateScale - (uint32_t)p0];
+      const int64_t mag = value < 0 ? -(int64_t)value : (int64_t)value;
+      if (mag) {
+        bits += mag > 1 ? lg - T[p1] : lg - T[kAcRateScale - (uint32_t)p1];
+        bits += 1;
+        if (mag > 1) {
+          if (mag - 1 > kAcRateTable) {
+            // a magnitude the table does not hold: the caller keeps the slice on the CPU
+            atomicCAS(cx.tv.error, 0, 4);
+          } else {
+            bits += 2.0 * T[mag - 1] + 1.0;
+          }
+        }
+      }
+      cx.term[(size_t)est * cx.n * C + (size_t)i * C + k] = bits;
+    }
+  }
+}
+
+// e->bits += bits, coefficient after coefficient (RAHT.cpp:77): one wavefront per estimate, 64 terms per
+// coalesced load, added by every lane alike
+__global__ __launch_bounds__(64) void
+rate_sum_kernel(RateCtx cx)
+{
+#pragma clang fp contract(off)
+  if (tree_failed(cx.tv))
+    return;
+  const int lane = threadIdx.x & 63;
+  const int est = blockIdx.x;
+  const int64_t total = (int64_t)(cx.b - cx.a) * cx.c;
+  const double* __restrict__ term = cx.term + (size_t)est * cx.n * cx.c;
+  double s = 0.0;
+  for (int64_t base = 0; base < total; base += 64) {
+    const int64_t i = base + lane;
+    const double x = i < total ? term[i] : 0.0;
+    const int64_t xb = __builtin_bit_cast(int64_t, x);
+    const int xlo = (int)(uint32_t)xb, xhi = (int)(xb >> 32);
+    const int m = total - base < 64 ? (int)(total - base) : 64;
+    for (int u = 0; u < m; u++) {
+      const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane(xlo, u);
+      const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane(xhi, u);
+      s += __builtin_bit_cast(double, (int64_t)(((uint64_t)hi << 32) | lo));
+    }
+  }
+  if (lane == 0)
+    cx.rs->bits[est] = s;
+}
+
+// the level's decision (RAHT.cpp:1810-1829)
+__global__ __launch_bounds__(64) void
+rate_decide_kernel(RateCtx cx)
+{
+  if (tree_failed(cx.tv))
+    return;
+  if (threadIdx.x != 0)
+    return;
+  RateState* rs = cx.rs;
+  const int wins = rs->bits[1] < rs->bits[0];
+  rs->intra_wins = wins;
+  if (rs->num_modes < 32)
+    cx.modes[rs->num_modes++] = !wins;
+  for (int k = 0; k < 3; k++) {
+    const int w0 = rs->q0[wins][k], w1 = rs->q1[wins][k];
+    rs->p0[0][k] = rs->p0[1][k] = w0;
+    rs->p1[0][k] = rs->p1[1][k] = w1;
+  }
+  const int lw = wins ? cx.islice_l[0] : cx.slice_l[0];
+  cx.slice_l[0] = lw;
+  rs->itz = cx.b - 1 - lw;
+}
+
+// ... and the intra candidate's coefficients and prediction record in place of the other's when it won
+__global__ __launch_bounds__(256) void
+inter_commit_kernel(RateCtx cx)
+{
+  if (tree_failed(cx.tv))
+    return;
+  if (!cx.rs->intra_wins)
+    return;
+  const int count = cx.b - cx.a;
+  const int64_t nco = (int64_t)count * cx.c;
+  const int64_t npt = (int64_t)cx.rows * cx.c;
+  for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < nco + npt; x += (int64_t)gridDim.x * blockDim.x) {
+    if (x < nco) {
+      const int k = (int)(x / count), i = (int)(x % count);
+      const size_t at = (size_t)k * cx.n + cx.a + i;
+      cx.coeffs[at] = cx.icoeffs[at];
+    } else {
+      cx.ptrans[x - nco] = cx.iptrans[x - nco];
+    }
+  }
+}
+
+__device__ __forceinline__ int64_t
+inter_wave_xor_i64(int64_t v, int mask)
+{
+  const int lo = __shfl_xor((int)(uint32_t)v, mask);
+  const int hi = __shfl_xor((int)(v >> 32), mask);
+  return ((int64_t)hi << 32) | (uint32_t)lo;
+}
+
+// ---- a filter tap of its own for the level (estimate_layer_filter, RAHT.cpp:849-972) ------------------
+// Eight lanes per parent of level li + 1, every parent (no staging: the pass runs once per level and is
+// bound by the bisections in the frame).  The current block and the frame's block are transformed each in
+// its own weights, FIRST COMPONENT only, without any prediction; over the coefficient positions of the
+// current block: autocorr += r * r, crosscorr += r * b (Q15 products in int64, as the reference's).
+// The reference walks the frame's nodes with a cursor that never rests on the LAST node of the level: a
+// block whose first frame node is that one is not seen (:872-884).
+struct TapCtx {
+  LevelCtx lc;
+  unsigned long long* acc;  // [2] autocorr, crosscorr (cleared by the caller)
+  int32_t* taps;            // [32] FilterTaps, quantised, in order
+  int32_t* num_taps;
+  int32_t* tap_out;         // the level's tap
+  int32_t qp_layer;
+};
+
+template<int C>
+__global__ __launch_bounds__(256) void
+inter_tap_kernel(TapCtx cx)
+{
+  __shared__ SharedLut lut;
+  const LevelCtx& ctx = cx.lc;
+  const TreeView& tv = ctx.tv;
+  if (tree_failed(tv))
+    return;
+  load_lut(&lut, ctx.lut);
+  const int li = ctx.li;
+  const ParamsConst prm = (ParamsConst)ctx.params;
+  const bool ext = prm->raht_extension != 0;
+  const bool inherit_dc = !ctx.sched[0].lvl[li].is_root;
+  const int np = tv.soff[li + 1][1];
+  const int t = threadIdx.x & 7;
+  const InterRef& ir = ctx.inter;
+  int64_t autoc = 0, crossc = 0;
+  const int groups = (int)(gridDim.x * blockDim.x) >> 3;
+  const int rounds = (np + groups - 1) / groups;
+  for (int r = 0; r < rounds; r++) {
+    const int j = r * groups + (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 3);
+    const bool on = j < np;
+    const int c0 = on ? tv.fc[li + 1][j] : 0;
+    const int nchild = on ? tv.fc[li + 1][j + 1] - c0 : 0;
+    const bool take = on && !(ext && nchild == 1);
+    const uint32_t occ = group8_or(t < nchild ? 1u << (int)(tv.key[li][c0 + t] & 7) : 0u);
+    const bool has = take && ((occ >> t) & 1);
+    const int child = c0 + popc32(occ & ((1u << t) - 1));
+    int32_t w = 0;
+    int64_t b = 0;
+    if (has) {
+      const int fa = tv.fp[li][child], fb = tv.fp[li][child + 1];
+      w = fb - fa;
+      b = fp_from_int((int32_t)((uint32_t)ctx.attr_prefix[(size_t)fb * C] - (uint32_t)ctx.attr_prefix[(size_t)fa * C]));
+    }
+    // the frame's block, first component
+    int32_t wr = 0;
+    int64_t rv = 0;
+    int hi = 0;
+    if (take) {
+      const uint64_t k0 = ((uint64_t)tv.key[li + 1][j] << 3) + (uint64_t)t;
+      const int lo = inter_lower_bound(ir.pos, ir.n_ref, ir.lr, k0);
+      hi = inter_lower_bound(ir.pos, ir.n_ref, ir.lr, k0 + 1);
+      wr = hi - lo;
+      if (wr > 0)
+        rv = fp_from_int((int32_t)((uint32_t)ir.prefix[(size_t)hi * C] - (uint32_t)ir.prefix[(size_t)lo * C]));
+    }
+    const uint32_t rocc = group8_bits(wr > 0);
+    // (the cursor's rule: the block's first frame node is not the last node of the level)
+    const int first_t = rocc ? __ffs((int)rocc) - 1 : 0;
+    const int hi_first = __shfl(hi, (int)((threadIdx.x & 56) | first_t));
+    const bool match = take && rocc != 0 && hi_first < ir.n_ref;
+    if (w > 1)
+      b = scale_rsqrt(b, w, lut);
+    if (wr > 1)
+      rv = scale_rsqrt(rv, wr, lut);
+    int32_t cw = w, cwr = wr;
+#pragma unroll
+    for (int st = 0; st < 3; st++) {
+      const int bit = 1 << st;
+      const bool left = !(t & bit);
+      {
+        const int32_t pw = lane_xor8(cw, bit);
+        const int32_t wl = left ? cw : pw, wrr = left ? pw : cw;
+        const bool both = wl && wrr, swap = !wl && wrr;
+        int64_t ca = 0, cb = 0;
+        if (both)
+          raht_coeffs(wl, wrr, lut, &ca, &cb);
+        const int64_t own = b;
+        const int64_t oth = shfl_xor_i64(own, bit);
+        if (both)
+          b = left ? fp_mul_c(oth, cb) + fp_mul_c(own, ca) : fp_mul_c(own, ca) - fp_mul_c(oth, cb);
+        else if (swap)
+          b = oth;
+        cw = both ? wl + wrr : (left ? wl + wrr : 0);
+      }
+      {
+        const int32_t pw = lane_xor8(cwr, bit);
+        const int32_t wl = left ? cwr : pw, wrr = left ? pw : cwr;
+        const bool both = wl && wrr, swap = !wl && wrr;
+        int64_t ca = 0, cb = 0;
+        if (both)
+          raht_coeffs(wl, wrr, lut, &ca, &cb);
+        const int64_t own = rv;
+        const int64_t oth = shfl_xor_i64(own, bit);
+        if (both)
+          rv = left ? fp_mul_c(oth, cb) + fp_mul_c(own, ca) : fp_mul_c(own, ca) - fp_mul_c(oth, cb);
+        else if (swap)
+          rv = oth;
+        cwr = both ? wl + wrr : (left ? wl + wrr : 0);
+      }
+    }
+    const bool counted = match && (t == 0 ? !inherit_dc : cw != 0);
+    if (counted && rv) {
+      autoc += (int64_t)((uint64_t)rv * (uint64_t)rv) >> kFpFrac;
+      crossc += (int64_t)((uint64_t)rv * (uint64_t)b) >> kFpFrac;
+    }
+  }
+  // one pair of atomics per wavefront
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) {
+    autoc += inter_wave_xor_i64(autoc, d);
+    crossc += inter_wave_xor_i64(crossc, d);
+  }
+  if ((threadIdx.x & 63) == 0 && (autoc || crossc)) {
+    atomicAdd(&cx.acc[0], (unsigned long long)autoc);
+    atomicAdd(&cx.acc[1], (unsigned long long)crossc);
+  }
+}
+
+// getFilterTap (RAHT.cpp:805-846): 128 * crosscorr / autocorr, the fraction by bisection of (mid * autocorr) >> 7
+__device__ __forceinline__ int
+filter_tap_of(int64_t autocorr, int64_t crosscorr)
+{
+  if (crosscorr == 0)
+    return 0;
+  const bool neg = crosscorr < 0;
+  crosscorr = neg ? -crosscorr : crosscorr;
+  if (crosscorr == autocorr)
+    return neg ? -128 : 128;
+  int64_t tapint = 0;
+  if (crosscorr >= autocorr) {
+    // (the reference subtracts in a loop)
+    tapint = 128 * (crosscorr / autocorr);
+    crosscorr %= autocorr;
+  }
+  if (crosscorr == 0)
+    return (int)(neg ? -tapint : tapint);
+  int lo = 0, hi = 128;
+  while (lo < hi - 1) {
+    const int mid = (lo + hi) >> 1;
+    const int64_t midval = (mid * autocorr) >> 7;
+    if (crosscorr == midval)
+      return (int)(neg ? -(tapint + mid) : (tapint + mid));
+    if (crosscorr < midval)
+      hi = mid;
+    else
+      lo = mid;
+  }
+  return (int)(neg ? -(tapint + lo) : (tapint + lo));
+}
+
+// the tap quantised like a coefficient of the level (:1287-1300)
+__global__ __launch_bounds__(64) void
+inter_tap_finish_kernel(TapCtx cx)
+{
+  if (tree_failed(cx.lc.tv))
+    return;
+  if (threadIdx.x != 0)
+    return;
+  const ParamsConst prm = (ParamsConst)cx.lc.params;
+  Quantizer tq[2];
+  qpset_quantizers(prm, cx.qp_layer, 0, 0, tq);
+  const int64_t autocorr = (int64_t)cx.acc[0], crosscorr = (int64_t)cx.acc[1];
+  const int orig = autocorr > 0 ? filter_tap_of(autocorr, crosscorr) : 128;
+  const int64_t qtap = quantize(tq[0], (int64_t)(128 - orig) * 256);
+  if (*cx.num_taps < 32)
+    cx.taps[(*cx.num_taps)++] = (int32_t)qtap;
+  *cx.tap_out = (int32_t)(128 - dequantize(tq[0], qtap));
+  cx.acc[0] = cx.acc[1] = 0;
+}
+
+// the decoder's tap of a level from the signalled value (:1301-1304); qtap < 0x7fffffff
+__global__ __launch_bounds__(64) void
+inter_tap_decode_kernel(const gpcc_raht_params* params, int qp_layer, int32_t qtap, int32_t* tap_out)
+{
+  if (threadIdx.x != 0)
+    return;
+  Quantizer tq[2];
+  qpset_quantizers((ParamsConst)params, qp_layer, 0, 0, tq);
+  *tap_out = (int32_t)(128 - dequantize(tq[0], (int64_t)qtap));
+}
+
+__global__ __launch_bounds__(64) void
+inter_set_word_kernel(int32_t* p, int32_t v)
+{
+  if (threadIdx.x == 0)
+    *p = v;
+}
+
+// modular prefix sums of the frame's attributes, [n + 1][C] (three launches: tile sums, their scan, emit)
+template<int C>
+__global__ __launch_bounds__(256) void
+frame_sum_kernel(const int32_t* __restrict__ a, int n, int32_t* __restrict__ tile)
+{
+  const int lane = lane_id();
+  const int wave = (int)(blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+  const int nwaves = (int)(gridDim.x * blockDim.x) / kWave;
+  const int ntiles = (n + kTilePoints - 1) / kTilePoints;
+  for (int tl = wave; tl < ntiles; tl += nwaves) {
+    uint32_t acc[C];
+#pragma unroll
+    for (int k = 0; k < C; k++)
+      acc[k] = 0;
+    for (int r = 0; r < kTilePoints / kWave; r++) {
+      const int i = tl * kTilePoints + r * kWave + lane;
+      if (i < n) {
+#pragma unroll
+        for (int k = 0; k < C; k++)
+          acc[k] += (uint32_t)a[(size_t)i * C + k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < C; k++) {
+      uint32_t v = acc[k];
+#pragma unroll
+      for (int d = 1; d < kWave; d <<= 1)
+        v += (uint32_t)__shfl_xor((int)v, d);
+      if (lane == 0)
+        tile[(size_t)tl * C + k] = (int32_t)v;
+    }
+  }
+}
+
+template<int C>
+__global__ __launch_bounds__(64) void
+frame_scan_kernel(int32_t* tile, int ntiles)
+{
+  const int lane = lane_id();
+  for (int k = 0; k < C; k++) {
+    uint32_t running = 0;
+    for (int t0 = 0; t0 < ntiles; t0 += kWave) {
+      const int tl = t0 + lane;
+      const uint32_t v = tl < ntiles ? (uint32_t)tile[(size_t)tl * C + k] : 0u;
+      const uint32_t inc = wave_incl_scan_u32(v);
+      if (tl < ntiles)
+        tile[(size_t)tl * C + k] = (int32_t)(running + inc - v);
+      running += (uint32_t)__shfl((int)inc, kWave - 1);
+    }
+  }
+}
+
+template<int C>
+__global__ __launch_bounds__(256) void
+frame_prefix_kernel(const int32_t* __restrict__ a, int n, const int32_t* __restrict__ tile, int32_t* __restrict__ prefix)
+{
+  const int lane = lane_id();
+  const int wave = (int)(blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+  const int nwaves = (int)(gridDim.x * blockDim.x) / kWave;
+  const int ntiles = (n + kTilePoints - 1) / kTilePoints;
+  for (int tl = wave; tl < ntiles; tl += nwaves) {
+    uint32_t run[C];
+#pragma unroll
+    for (int k = 0; k < C; k++)
+      run[k] = (uint32_t)tile[(size_t)tl * C + k];
+    for (int r = 0; r < kTilePoints / kWave; r++) {
+      const int i = tl * kTilePoints + r * kWave + lane;
+      const bool in = i < n;
+#pragma unroll
+      for (int k = 0; k < C; k++) {
+        const uint32_t v = in ? (uint32_t)a[(size_t)i * C + k] : 0u;
+        const uint32_t inc = wave_incl_scan_u32(v);
+        if (in)
+          prefix[(size_t)i * C + k] = (int32_t)(run[k] + inc - v);
+        if (i == n - 1)
+          prefix[(size_t)n * C + k] = (int32_t)(run[k] + inc);
+        run[k] += (uint32_t)__shfl((int)inc, kWave - 1);
+      }
+    }
+  }
+}
+
+}  // namespace gpcc

@@ -1,0 +1,424 @@
+// raht_inter_driver.hpp -- workspace layout and launch sequence of RAHT with attribute inter prediction
+// (raht_inter.hpp, raht_tile.hpp with INTER): one slice, no sub-node prediction, no integer Haar, no region
+// QP offsets.  Like cx_driver.hpp the sequence is a template over how the host learns the tree's shape, so
+// the same code runs under the CPU wavefront emulator of the test tier (tests/emu).
+//
+//   tree_count / tree_scan / tree_emit     level arrays of the current frame
+//   frame_sum / frame_scan / frame_prefix  modular prefix sums of the reference frame's attributes
+//   schedule                               level plan (no coarse levels: every level is a launch)
+//   per level, top down (tmc3/RAHT.cpp:1165-1345):
+//     [inter_tap + inter_tap_finish]       encoder, estimated taps
+//     encoder  tile<kAnalyze, INTER> -> rdoq_resolve [x 2 -> rate_chain / bits / sum / decide -> commit]
+//              -> tile<kSynthRec>
+//     decoder  tile<kSynth, INTER>
+//   finish                                 duplicates, write-back
+#pragma once
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+
+#include "raht_edges.hpp"
+#include "raht_inter.hpp"
+#include "raht_tile.hpp"
+#include "raht_tree.hpp"
+
+namespace gpcc {
+
+// AttributeInterPredParams / the APS fields of the tool (PCCTMC3Common.h:236-298, hls.h)
+struct InterTools {
+  int depth_limit = 0;   // raht_inter_prediction_depth_minus1 + 1
+  int layer_rdo = 0;     // raht_enable_inter_intra_layer_RDO
+  int filter_est = 0;    // enableFilterEstimation
+  int skip_layers = 0;   // skipInitLayersForFiltering
+  int bits_cur = 0;      // bit length of pos[0] ^ pos[n - 1] (the levels under the current tree's top) ...
+  int bits_ref = -1;     // ... and of the frame's; -1: the frame has a single point
+  // decoder: what the bitstream signalled
+  const int32_t* modes = nullptr;
+  int num_modes = 0;
+  const int32_t* taps = nullptr;
+  int num_taps = 0;
+};
+
+struct InterWork {
+  int n = 0, c = 0, nlev = 0, n_ref = 0;
+  bool encoder = false;
+  TreeView tv{};
+  int32_t* pt_off = nullptr;
+  uint32_t* tile_cnt = nullptr;
+  int32_t* tile_attr = nullptr;
+  int32_t* attr_prefix = nullptr;
+  SliceSched* sched = nullptr;
+  gpcc_raht_params* params = nullptr;
+  int64_t* rec[2] = {nullptr, nullptr};
+  int64_t* rec_us[2] = {nullptr, nullptr};
+  int32_t* nneigh[2] = {nullptr, nullptr};
+  uint32_t *desc = nullptr, *idesc = nullptr;
+  int64_t *ptrans = nullptr, *iptrans = nullptr;
+  int32_t* icoeffs = nullptr;
+  int32_t* rtile_base = nullptr;
+  unsigned long long *rtile_state = nullptr, *irtile_state = nullptr;
+  int32_t *slice_l = nullptr, *islice_l = nullptr;
+  int num_rtiles = 0;
+  int32_t* frame_tile = nullptr;
+  int32_t* frame_prefix = nullptr;
+  int32_t* tap_words = nullptr;  // [kMaxLevels]
+  int32_t* modes = nullptr;      // [32] then num (unused), taps [32], num_taps
+  int32_t* taps = nullptr;
+  int32_t* num_taps = nullptr;
+  unsigned long long* tap_acc = nullptr;
+  RateState* rs = nullptr;
+  int32_t* pb = nullptr;
+  double* term = nullptr;
+};
+
+inline bool
+inter_supported(const gpcc_raht_params* p, int64_t n)
+{
+  return !p->integer_haar_enable_flag && !(p->raht_prediction_enabled_flag && p->raht_subnode_prediction_enabled_flag)
+    && n >= 2;
+}
+
+// `take(bytes)` hands out 256-byte aligned storage (or only counts)
+template<class Take>
+void
+inter_carve(Take&& take, InterWork& w)
+{
+  const int n = w.n, c = w.c, nlev = w.nlev;
+  auto arr = [&](size_t count, size_t elem) { return take(count * elem); };
+  w.pt_off = (int32_t*)arr(2, 4);
+  for (int li = 0; li < nlev; li++) {
+    int64_t cap = n;
+    const int up = nlev - 1 - li;
+    if (up < 11) {
+      const int64_t full = (int64_t)1 << (3 * up);
+      cap = cap < full ? cap : full;
+    }
+    w.tv.cap[li] = (int32_t)cap;
+    w.tv.key[li] = (int64_t*)arr(cap + 1, 8);
+    w.tv.fp[li] = (int32_t*)arr(cap + 2, 4);
+    w.tv.fc[li] = (int32_t*)arr(cap + 2, 4);
+    w.tv.soff[li] = (int32_t*)arr(2, 4);
+  }
+  w.tv.nlev = nlev;
+  w.tv.num_slices = 1;
+  w.tv.n_total = n;
+  w.tv.num_tiles = (n + kTilePoints - 1) / kTilePoints;
+  w.tv.pt_off = w.pt_off;
+  w.tile_cnt = (uint32_t*)arr((size_t)w.tv.num_tiles * nlev, 4);
+  w.tile_attr = (int32_t*)arr((size_t)w.tv.num_tiles * c, 4);
+  w.attr_prefix = w.encoder ? (int32_t*)arr(((size_t)n + 1) * c, 4) : nullptr;
+  w.sched = (SliceSched*)arr(1, sizeof(SliceSched));
+  w.params = (gpcc_raht_params*)arr(1, sizeof(gpcc_raht_params));
+  for (int i = 0; i < 2; i++) {
+    w.rec[i] = (int64_t*)arr((size_t)n * c, 8);
+    w.rec_us[i] = (int64_t*)arr((size_t)n * c, 8);
+    w.nneigh[i] = (int32_t*)arr((size_t)n, 4);
+  }
+  w.num_rtiles = (n + kRdoqTile - 1) / kRdoqTile;
+  if (w.encoder) {
+    w.desc = (uint32_t*)arr((size_t)n, 4);
+    w.idesc = (uint32_t*)arr((size_t)n, 4);
+    w.ptrans = (int64_t*)arr((size_t)n * c, 8);
+    w.iptrans = (int64_t*)arr((size_t)n * c, 8);
+    w.icoeffs = (int32_t*)arr((size_t)n * c, 4);
+    w.rtile_base = (int32_t*)arr(2, 4);
+    w.rtile_state = (unsigned long long*)arr((size_t)w.num_rtiles + 1, 8);
+    w.irtile_state = (unsigned long long*)arr((size_t)w.num_rtiles + 1, 8);
+    w.slice_l = (int32_t*)arr(2, 4);
+    w.islice_l = (int32_t*)arr(2, 4);
+    w.rs = (RateState*)arr(1, sizeof(RateState));
+    w.pb = (int32_t*)arr((size_t)4 * c * n, 4);
+    w.term = (double*)arr((size_t)2 * c * n, 8);
+    w.tap_acc = (unsigned long long*)arr(2, 8);
+  }
+  const int ftiles = (w.n_ref + kTilePoints - 1) / kTilePoints;
+  w.frame_tile = (int32_t*)arr((size_t)ftiles * c + 1, 4);
+  w.frame_prefix = (int32_t*)arr(((size_t)w.n_ref + 1) * c, 4);
+  w.tap_words = (int32_t*)arr(kMaxLevels, 4);
+  w.modes = (int32_t*)arr(32, 4);
+  w.taps = (int32_t*)arr(32, 4);
+  w.num_taps = (int32_t*)arr(1, 4);
+}
+
+// Everything after the uploads of params / pt_off (= {0, n}) / rtile_base (= {0, tiles}) / the two frames.
+// d_modes_out / d_taps_out: nothing -- the caller reads w.modes, w.rs->num_modes, w.taps, w.num_taps.
+template<int C, class Prof, class Mark, class Wait>
+hipError_t
+inter_run(
+  hipStream_t st, InterWork& w, const InterTools& tl, const gpcc_raht_params* hp, const SharedLut* d_lut,
+  const double* d_log2tab, const int64_t* d_ref_pos, const int32_t* d_ref_attrs, int32_t* d_attrs, int32_t* d_coeffs,
+  TreeStats* stats, Prof&& prof, Mark&& mark, Wait&& wait)
+{
+  const TreeView tv = w.tv;
+  const int n = w.n;
+  const bool encoder = w.encoder;
+  const int32_t* sum_attrs = encoder ? d_attrs : nullptr;
+  const int tgrid = std::min(std::max((tv.num_tiles + 3) / 4, 1), 2048);
+  {
+    auto t = prof("tree_count", -1);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(tree_count_kernel<C>), dim3(tgrid), dim3(256), 0, st, tv, sum_attrs, w.tile_cnt, w.tile_attr);
+  }
+  {
+    auto t = prof("tree_scan", -1);
+    hipLaunchKernelGGL(
+      HIP_KERNEL_NAME(tree_scan_kernel<C>), dim3(1), dim3(1024), 0, st, tv, w.tile_cnt, w.tile_attr, w.attr_prefix,
+      sum_attrs != nullptr);
+  }
+  {
+    auto t = prof("tree_emit", -1);
+    hipLaunchKernelGGL(
+      HIP_KERNEL_NAME(tree_emit_kernel<C>), dim3(tgrid), dim3(256), 0, st, tv, sum_attrs, w.tile_cnt, w.tile_attr,
+      w.attr_prefix);
+  }
+  {
+    auto t = prof("schedule", -1);
+    hipLaunchKernelGGL(schedule_kernel, dim3(1), dim3(256), 0, st, tv, w.sched, (int)hp->num_qp_layers, 0, stats);
+  }
+  hipError_t e = mark();
+  if (e != hipSuccess)
+    return e;
+  {
+    auto t = prof("frame_prefix", -1);
+    const int ftiles = (w.n_ref + kTilePoints - 1) / kTilePoints;
+    const int fgrid = std::min(std::max((ftiles + 3) / 4, 1), 2048);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(frame_sum_kernel<C>), dim3(fgrid), dim3(256), 0, st, d_ref_attrs, w.n_ref, w.frame_tile);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(frame_scan_kernel<C>), dim3(1), dim3(64), 0, st, w.frame_tile, ftiles);
+    hipLaunchKernelGGL(
+      HIP_KERNEL_NAME(frame_prefix_kernel<C>), dim3(fgrid), dim3(256), 0, st, d_ref_attrs, w.n_ref, (const int32_t*)w.frame_tile,
+      w.frame_prefix);
+  }
+  if (encoder) {
+    e = hipMemsetAsync(w.rtile_state, 0, ((size_t)w.num_rtiles + 1) * 8, st);
+    if (e != hipSuccess)
+      return e;
+    e = hipMemsetAsync(w.irtile_state, 0, ((size_t)w.num_rtiles + 1) * 8, st);
+    if (e != hipSuccess)
+      return e;
+    e = hipMemsetAsync(w.slice_l, 0xff, 8, st);
+    if (e != hipSuccess)
+      return e;
+    e = hipMemsetAsync(w.islice_l, 0xff, 8, st);
+    if (e != hipSuccess)
+      return e;
+    e = hipMemsetAsync(w.tap_acc, 0, 16, st);
+    if (e != hipSuccess)
+      return e;
+    e = hipMemsetAsync(w.num_taps, 0, 4, st);
+    if (e != hipSuccess)
+      return e;
+    hipLaunchKernelGGL(rate_init_kernel, dim3(1), dim3(64), 0, st, w.rs);
+  }
+  e = wait();
+  if (e != hipSuccess)
+    return e;
+  const TreeStats ts = *stats;
+  const int top = ts.max_top;
+
+  LevelCtx lc{};
+  lc.tv = tv;
+  lc.params = w.params;
+  lc.sched = w.sched;
+  lc.attr_prefix = w.attr_prefix;
+  for (int i = 0; i < 2; i++) {
+    lc.rec[i] = w.rec[i];
+    lc.rec_us[i] = w.rec_us[i];
+    lc.nneigh[i] = w.nneigh[i];
+    lc.dqp[i] = nullptr;
+  }
+  lc.coeffs = d_coeffs;
+  lc.desc = w.desc;
+  lc.ptrans = w.ptrans;
+  lc.lut = d_lut;
+  lc.error = tv.error;
+  lc.slice_l = w.slice_l;
+  lc.inter.pos = d_ref_pos;
+  lc.inter.prefix = w.frame_prefix;
+  lc.inter.n_ref = w.n_ref;
+  lc.inter.idesc = w.idesc;
+  lc.inter.iptrans = w.iptrans;
+  lc.inter.icoeffs = w.icoeffs;
+
+  RdoqCtx rc{};
+  rc.tv = tv;
+  rc.sched = w.sched;
+  rc.tile_base = w.rtile_base;
+  rc.num_tiles = w.num_rtiles;
+  rc.c = C;
+
+  RateCtx rt{};
+  rt.tv = tv;
+  rt.plane[0] = d_coeffs;
+  rt.plane[1] = w.icoeffs;
+  rt.n = n;
+  rt.c = C;
+  rt.pb = w.pb;
+  rt.term = w.term;
+  rt.rs = w.rs;
+  rt.log2tab = d_log2tab;
+  rt.slice_l = w.slice_l;
+  rt.islice_l = w.islice_l;
+  rt.modes = w.modes;
+  rt.coeffs = d_coeffs;
+  rt.icoeffs = w.icoeffs;
+  rt.ptrans = w.ptrans;
+  rt.iptrans = w.iptrans;
+
+  static const int kFixedTaps[7] = {128, 128, 128, 127, 125, 121, 115};
+  int tree_depth = 0, depth = 0, qp_layer = 0, coeff = 0;
+  for (int li = top - 1; li >= 0; li--) {
+    const bool root = li == top - 1;
+    if (!root && ts.nodes[li] == ts.nodes[li + 1])
+      continue;
+    // (the plan of schedule_kernel, restated for the host's decisions: tmc3/RAHT.cpp:1165-1217, 1264-1265)
+    qp_layer = qp_layer + 1 < hp->num_qp_layers ? qp_layer + 1 : hp->num_qp_layers - 1;
+    const int a = coeff;
+    coeff += root ? ts.nodes[li] : ts.nodes[li] - ts.nodes[li + 1];
+    const int b = coeff;
+    const bool pred_in_level = !root && hp->raht_prediction_enabled_flag != 0;
+    const int lr = tl.bits_ref - tl.bits_cur + 3 * li;
+    const bool inter_on = tl.bits_ref >= 0 && lr >= 0 && lr <= 62 && tree_depth < tl.depth_limit;
+    const bool rdo_on = inter_on && tl.layer_rdo;
+    const bool cur_level =
+      pred_in_level && rdo_on && (encoder || (depth < tl.num_modes ? tl.modes[depth] != 0 : false));
+    const bool dual = encoder && cur_level;
+    const bool inter_blocks = inter_on && (cur_level || !pred_in_level);
+    const bool est_layer = inter_on && tl.filter_est && tree_depth >= tl.skip_layers;
+
+    lc.li = li;
+    lc.inter.lr = lr;
+    lc.inter.blocks = inter_blocks;
+    lc.inter.dual = dual;
+    lc.inter.filtered = tree_depth >= tl.skip_layers;
+    lc.inter.tap = w.tap_words + li;
+    // ---- the level's filter tap (:1283-1305) ---------------------------------------------
+    if (est_layer && encoder) {
+      auto t = prof("inter_tap", li);
+      TapCtx tc{};
+      tc.lc = lc;
+      tc.acc = w.tap_acc;
+      tc.taps = w.taps;
+      tc.num_taps = w.num_taps;
+      tc.tap_out = w.tap_words + li;
+      tc.qp_layer = qp_layer;
+      const int64_t parents = ts.nodes[li + 1];
+      const int grid = (int)std::min<int64_t>(std::max<int64_t>((parents + 31) / 32, 1), 1024);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(inter_tap_kernel<C>), dim3(grid), dim3(256), 0, st, tc);
+      hipLaunchKernelGGL(inter_tap_finish_kernel, dim3(1), dim3(64), 0, st, tc);
+    } else if (est_layer && tree_depth - tl.skip_layers < tl.num_taps) {
+      hipLaunchKernelGGL(
+        inter_tap_decode_kernel, dim3(1), dim3(64), 0, st, (const gpcc_raht_params*)w.params, qp_layer,
+        tl.taps[tree_depth - tl.skip_layers], w.tap_words + li);
+    } else {
+      const int tap = (inter_on && !tl.filter_est) ? kFixedTaps[tree_depth < 7 ? tree_depth : 6] : 128;
+      hipLaunchKernelGGL(inter_set_word_kernel, dim3(1), dim3(64), 0, st, w.tap_words + li, tap);
+    }
+
+    const int64_t parents = ts.nodes[li + 1];
+    const bool sparse = (int64_t)ts.nodes[li] * 8 <= parents * 9 && parents >= 64 * kTileTSparse;
+    const int tile_t = sparse ? kTileTSparse : kTileT;
+    const int ntiles = (int)((parents + tile_t - 1) / tile_t);
+    const int grid = std::min((ntiles + 7) / 8 * 8, 8192);
+#define GPCC_INTER_TILE(MODE, INTER)                                                                                       \
+  do {                                                                                                                     \
+    if (sparse)                                                                                                            \
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(raht_tile_kernel<C, MODE, kTileTSparse, INTER>), dim3(grid), dim3(kTileThreads), 0, st, lc); \
+    else                                                                                                                   \
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(raht_tile_kernel<C, MODE, kTileT, INTER>), dim3(grid), dim3(kTileThreads), 0, st, lc);       \
+  } while (0)
+    if (!encoder) {
+      auto t = prof("inter_synth", li);
+      GPCC_INTER_TILE(kSynth, true);
+    } else {
+      rt.a = a;
+      rt.b = b;
+      rt.rows = ts.nodes[li];
+      if (dual)
+        hipLaunchKernelGGL(rate_level_begin_kernel, dim3(1), dim3(64), 0, st, rt);
+      {
+        auto t = prof("inter_analyze", li);
+        GPCC_INTER_TILE(kAnalyze, true);
+      }
+#ifdef GPCC_EMU
+      if (getenv("GPCC_INTER_DBG") && li == atoi(getenv("GPCC_INTER_DBG")))
+        for (int i = a; i < b && i < a + 40; i++)
+          fprintf(stderr, "  before coef %d desc %08x value %d\n", i, w.desc[i], d_coeffs[i]);
+#endif
+      rc.li = li;
+      {
+        auto t = prof("rdoq_resolve", li);
+        rc.desc = w.desc;
+        rc.coeffs = d_coeffs;
+        rc.slice_l = w.slice_l;
+        rc.state = w.rtile_state;
+        hipLaunchKernelGGL(rdoq_resolve_kernel, dim3((w.num_rtiles + 3) / 4), dim3(256), 0, st, rc);
+        if (dual) {
+          rc.desc = w.idesc;
+          rc.coeffs = w.icoeffs;
+          rc.slice_l = w.islice_l;
+          rc.state = w.irtile_state;
+          hipLaunchKernelGGL(rdoq_resolve_kernel, dim3((w.num_rtiles + 3) / 4), dim3(256), 0, st, rc);
+        }
+      }
+      if (dual) {
+        {
+          auto t = prof("rate_chain", li);
+          hipLaunchKernelGGL(rate_chain_kernel, dim3(4 * C), dim3(64), 0, st, rt);
+        }
+        {
+          auto t = prof("rate_bits", li);
+          const int bgrid = (int)std::min<int64_t>(std::max<int64_t>((2 * (int64_t)(b - a) + 255) / 256, 1), 4096);
+          hipLaunchKernelGGL(rate_bits_kernel, dim3(bgrid), dim3(256), 0, st, rt);
+        }
+        {
+          auto t = prof("rate_sum", li);
+          hipLaunchKernelGGL(rate_sum_kernel, dim3(2), dim3(64), 0, st, rt);
+        }
+        {
+          auto t = prof("rate_decide", li);
+          hipLaunchKernelGGL(rate_decide_kernel, dim3(1), dim3(64), 0, st, rt);
+          const int64_t work = (int64_t)(b - a) * C + (int64_t)rt.rows * C;
+          const int cgrid = (int)std::min<int64_t>(std::max<int64_t>((work + 255) / 256, 1), 4096);
+          hipLaunchKernelGGL(inter_commit_kernel, dim3(cgrid), dim3(256), 0, st, rt);
+        }
+      }
+#ifdef GPCC_EMU
+      if (getenv("GPCC_INTER_DBG")) {
+        fprintf(stderr, "li %d coef [%d, %d) slice_l %d dual %d blocks %d\n", li, a, b, w.slice_l[0], (int)dual, (int)inter_blocks);
+        if (li == atoi(getenv("GPCC_INTER_DBG")))
+          for (int i = a; i < b && i < a + 40; i++)
+            fprintf(stderr, "  coef %d desc %08x value %d\n", i, w.desc[i], d_coeffs[i]);
+      }
+#endif
+      {
+        auto t = prof("inter_synth_rec", li);
+        GPCC_INTER_TILE(kSynthRec, false);
+      }
+    }
+#undef GPCC_INTER_TILE
+    if (pred_in_level && rdo_on)
+      depth++;
+    tree_depth++;
+  }
+
+  FinishCtx fc{};
+  fc.tv = tv;
+  fc.params = w.params;
+  fc.sched = w.sched;
+  fc.attr_prefix = w.attr_prefix;
+  for (int i = 0; i < 2; i++) {
+    fc.rec[i] = w.rec[i];
+    fc.dqp[i] = nullptr;
+  }
+  fc.attrs = d_attrs;
+  fc.coeffs = d_coeffs;
+  fc.encoder = encoder;
+  fc.lut = d_lut;
+  {
+    auto t = prof("finish", -1);
+    const int fgrid = std::min(std::max((tv.cap[0] + 255) / 256, 1), 2048);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(finish_kernel<C>), dim3(fgrid), dim3(256), 0, st, fc);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace gpcc

@@ -42,6 +42,25 @@ constexpr uint32_t kDescZero = 0x80000000u;   // all components quantise to 0
 // the sub-node kernel's dependency chain, behind its write-through stores.
 typedef const __attribute__((address_space(4))) gpcc_raht_params* ParamsConst;
 
+// Attribute inter prediction (raht_inter.hpp; tmc3/RAHT.cpp:1165-1198, 1283-1347, 1504-1549): what a level
+// launch needs of the reference frame.  The frame's tree is never built: its points are in Morton order, so
+// the node at bit level `lr` with key k is the run of points with pos >> lr == k (two bisections), its weight
+// the length of the run and its attribute sum a difference of the frame's modular prefix sums.
+struct InterRef {
+  const int64_t* pos;     // [n_ref] the frame's Morton codes, ascending (null: no inter prediction)
+  const int32_t* prefix;  // [n_ref + 1][C] modular prefix sums of its attributes
+  int32_t n_ref;
+  int32_t lr;             // bit level of the frame's nodes that line up with the CHILDREN of this launch
+  int32_t blocks;         // blocks are matched against the frame in this launch
+  int32_t dual;           // encoder: the level is coded twice, the second candidate without the frame
+  int32_t filtered;       // the level's filter tap applies (tree depth >= skipInitLayersForFiltering)
+  const int32_t* tap;     // the tap (a device word: fixed taps are written by the host, estimated ones by
+                          // inter_tap_finish_kernel)
+  uint32_t* idesc;        // the second candidate's RDOQ descriptors, ...
+  int64_t* iptrans;       // ... transformed prediction ...
+  int32_t* icoeffs;       // ... and coefficients (layouts of desc / ptrans / coeffs)
+};
+
 struct LevelCtx {
   TreeView tv;
   const gpcc_raht_params* params;  // device copy
@@ -71,6 +90,7 @@ struct LevelCtx {
   int32_t* error;                  // set when a bounded spin expires
   unsigned long long* rdoq_state;  // [cap] per worklist block: RDOQ hand-off word
   int32_t* slice_l;                // [2][S] last RDOQ reset carried between levels (sub-node path: by level parity)
+  InterRef inter;                  // attribute inter prediction (tile kernels instantiated with INTER)
 };
 
 // ctx.X[parity] with a per-lane parity, as a select between the two kernel

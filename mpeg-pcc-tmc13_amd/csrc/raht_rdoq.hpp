@@ -194,6 +194,9 @@ rdoq_resolve_kernel(RdoqCtx cx)
   int l_in = 0;
   if (gt == gt_first) {
     l_in = cx.slice_l[s];
+    // (every lane has read the word before lane 0 of a tile that is also the level's last overwrites it:
+    // lock step on the hardware, a rendezvous for the CPU emulator of the test tier)
+    __builtin_amdgcn_wave_barrier();
     l_out = status == kTileTransparent ? l_in : (status == kTileClosed ? l_out : replay(l_in));
     if (lane == 0)
       __hip_atomic_store(

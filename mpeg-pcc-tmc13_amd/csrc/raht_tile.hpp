@@ -49,6 +49,7 @@
 // few microseconds of work each.
 #pragma once
 
+#include "raht_inter.hpp"
 #include "raht_levels.hpp"
 #include "raht_rdoq.hpp"
 
@@ -259,8 +260,10 @@ window_lookup(const Smem& sm, int64_t want, int ga, int gb, int wlo, int whi, bo
 
 // One tile [j0, j1) of the parents of level li + 1 (children in level li).
 // All threads of the workgroup call it together.  `honor_coarse`: skip the
-// (slice, level) pairs the coarse kernel owns.
-template<int C, int MODE, typename Smem>
+// (slice, level) pairs the coarse kernel owns.  INTER: attribute inter prediction (raht_inter.hpp) -- the
+// blocks of a level are matched against the reference frame where ctx.inter says so, and the lossy encoder
+// writes a second, intra-only candidate of the level (ctx.inter.dual).
+template<int C, int MODE, bool INTER = false, typename Smem>
 __device__ __forceinline__ void
 tile_process(
   const LevelCtx& ctx, const int li, const int j0, const int j1, Smem& sm,
@@ -942,10 +945,38 @@ tile_process(
       for (int k = 0; k < C; k++)
         pred[k] = ctx.ptrans[trow * C + k];
     }
+    // ---- the reference frame's block (tmc3/RAHT.cpp:1322-1347, 1533-1545): where it exists it
+    //      predicts every coefficient of the block in place of the intra prediction; the intra
+    //      prediction stays the second candidate's (`ipred`, ctx.inter.dual) -------------------------
+    int64_t ipred[C];
+    bool enable_intra = false;
+    if (INTER && kSearch) {
+      enable_intra = enable_pred;
+#pragma unroll
+      for (int k = 0; k < C; k++)
+        ipred[k] = pred[k];
+      if (ctx.inter.blocks) {
+        bool inter_node;
+        int64_t pin[C];
+        inter_block<C>(ctx.inter, on ? sm.key[j - wlo] : 0, t, on, lut, &inter_node, pin);
+        if (inter_node) {
+#pragma unroll
+          for (int k = 0; k < C; k++)
+            pred[k] = pin[k];
+          enable_pred = on;
+        }
+      }
+    }
+    const bool dual = INTER && MODE == kAnalyze && ctx.inter.dual;
     if (MODE == kAnalyze && is_present) {
 #pragma unroll
       for (int k = 0; k < C; k++)
         ctx.ptrans[trow * C + k] = enable_pred ? pred[k] : 0;
+      if (dual) {
+#pragma unroll
+        for (int k = 0; k < C; k++)
+          ctx.inter.iptrans[trow * C + k] = enable_intra ? ipred[k] : 0;
+      }
     }
 
     if (coded) {
@@ -958,6 +989,39 @@ tile_process(
       qpset_quantizers(prm, e.qp_layer, nq0 + ac0, nq1 + ac1, qa);
 
       if (kEnc) {
+        if (dual) {
+          // the intra candidate of the level: residual, RDOQ statistics, coefficients (:1560-1616)
+          int64_t isrc[C];
+#pragma unroll
+          for (int k = 0; k < C; k++)
+            isrc[k] = enable_intra ? src[k] - ipred[k] : src[k];
+          Quantizer qr[2];
+          qpset_quantizers(prm, e.qp_layer, nq0, nq1, qr);
+          int64_t sum_coeff = 0, dist2 = 0;
+          int rate_coeff = 0;
+#pragma unroll
+          for (int k = 0; k < C; k++) {
+            const int64_t co = fp_round(isrc[k]);
+            dist2 += co * co;
+            int64_t aq = quantize(qr[k ? 1 : 0], co * 256);
+            aq = aq < 0 ? -aq : aq;
+            sum_coeff += aq;
+            rate_coeff += rate_log_small(aq);
+          }
+          uint32_t d = kDescNever;
+          if (sum_coeff < 3) {
+            const int64_t l0 = qr[0].step;
+            const int64_t lambda = l0 * l0 * (C == 1 ? 25 : 35);
+            d = rdoq_threshold(dist2, lambda, rate_coeff, (uint32_t)n_s);
+            if (sum_coeff == 0)
+              d |= kDescZero;
+          }
+          ctx.inter.idesc[(size_t)pt0 + cidx] = d;
+          int32_t* __restrict__ iplane = ctx.inter.icoeffs + (size_t)pt0 * C + cidx;
+#pragma unroll
+          for (int k = 0; k < C; k++)
+            iplane[(size_t)k * n_s] = (int32_t)quantize(qa[k ? 1 : 0], fp_round(isrc[k]) * 256);
+        }
         if (enable_pred) {
 #pragma unroll
           for (int k = 0; k < C; k++)
@@ -1072,7 +1136,7 @@ tile_process(
 // Workgroup b runs on XCD b % 8 (observed dispatch; locality only): every
 // XCD gets one contiguous eighth of the tiles, so the key windows of
 // neighbouring tiles meet in the same L2.
-template<int C, int MODE, int T>
+template<int C, int MODE, int T, bool INTER = false>
 __global__ __launch_bounds__(kTileThreads, T > kTileT ? 3 : (MODE == kSynthRec ? 6 : GPCC_TILE_WAVES)) void
 raht_tile_kernel(LevelCtx ctx)
 {
@@ -1093,7 +1157,7 @@ raht_tile_kernel(LevelCtx ctx)
   for (int tile = slot * chunk; tile < (slot + 1) * chunk && tile < ntiles; tile++) {
     const int j0 = tile * T;
     const int j1 = j0 + T < np ? j0 + T : np;
-    tile_process<C, MODE>(ctx, li, j0, j1, sm, true);
+    tile_process<C, MODE, INTER>(ctx, li, j0, j1, sm, true);
   }
 }
 

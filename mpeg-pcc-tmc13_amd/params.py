@@ -10,6 +10,17 @@ GPCC_MAX_QP_REGIONS = 8
 GPCC_MAX_AC_QP_LAYERS = 32
 
 
+class RahtInterParams(C.Structure):
+    """gpcc_raht_inter_params: the tools of attribute inter prediction in RAHT
+    (AttributeInterPredParamsForRAHT, PCCTMC3Common.h:236-250)"""
+    _fields_ = [
+        ("raht_inter_prediction_depth_minus1", C.c_int32),
+        ("raht_enable_inter_intra_layer_rdo", C.c_int32),
+        ("enable_filter_estimation", C.c_int32),
+        ("skip_init_layers_for_filtering", C.c_int32),
+    ]
+
+
 class RahtParams(C.Structure):
     _fields_ = [
         ("raht_prediction_enabled_flag", C.c_int32),

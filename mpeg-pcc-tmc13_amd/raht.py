@@ -102,6 +102,39 @@ class Context:
             rec.ctypes.data, co.ctypes.data, n, c))
         return rec
 
+    def raht_forward_inter(self, params: RahtParams, inter, morton, attrs, morton_ref, attrs_ref):
+        """RAHT with attribute inter prediction (gpcc_raht_forward_inter)
+        -> (coeffs int32 [c*n] planar, recon int32 [n, c], layer modes, filter taps)"""
+        morton = np.ascontiguousarray(morton, dtype=np.int64)
+        rec = np.ascontiguousarray(attrs, dtype=np.int32).copy()
+        n, c = rec.shape
+        mref = np.ascontiguousarray(morton_ref, dtype=np.int64)
+        aref = np.ascontiguousarray(attrs_ref, dtype=np.int32)
+        coeffs = np.zeros(c * n, dtype=np.int32)
+        modes, taps = np.zeros(32, np.int32), np.zeros(32, np.int32)
+        nm, nt = C.c_int32(0), C.c_int32(0)
+        _lib.check(self._lib.gpcc_raht_forward_inter(
+            self._h, C.byref(params), C.addressof(inter), morton.ctypes.data, rec.ctypes.data, coeffs.ctypes.data, n, c,
+            mref.ctypes.data, aref.ctypes.data, len(mref), modes.ctypes.data, C.byref(nm), taps.ctypes.data, C.byref(nt)))
+        return coeffs, rec, modes[:nm.value].copy(), taps[:nt.value].copy()
+
+    def raht_inverse_inter(self, params: RahtParams, inter, morton, coeffs, c, morton_ref, attrs_ref, modes, taps):
+        """-> recon int32 [n, c] (gpcc_raht_inverse_inter)"""
+        morton = np.ascontiguousarray(morton, dtype=np.int64)
+        n = morton.shape[0]
+        co = np.ascontiguousarray(coeffs, dtype=np.int32)
+        mref = np.ascontiguousarray(morton_ref, dtype=np.int64)
+        aref = np.ascontiguousarray(attrs_ref, dtype=np.int32)
+        m = np.zeros(32, np.int32)
+        t = np.zeros(32, np.int32)
+        m[:len(modes)] = modes
+        t[:len(taps)] = taps
+        rec = np.zeros((n, c), dtype=np.int32)
+        _lib.check(self._lib.gpcc_raht_inverse_inter(
+            self._h, C.byref(params), C.addressof(inter), morton.ctypes.data, rec.ctypes.data, co.ctypes.data, n, c,
+            mref.ctypes.data, aref.ctypes.data, len(mref), m.ctypes.data, len(modes), t.ctypes.data, len(taps)))
+        return rec
+
     def morton_sort(self, xyz):
         xyz = np.ascontiguousarray(xyz, dtype=np.int32)
         n = xyz.shape[0]
