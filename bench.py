@@ -364,6 +364,7 @@ def main():
             out["lifting"] = lifting_leg(ctx, args)
             out["predicting"] = predicting_leg(ctx, args)
             out["recolour"] = recolour_leg(ctx, args)
+            out["raht_inter"] = raht_inter_leg(ctx, args)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(frames[0], p, c)
 
@@ -522,6 +523,62 @@ def recolour_leg(ctx, args):
         # (a dyadic scale on a voxelised cloud has them at nearly every point) come out as the reference has them
         res["identical_to_cpu_fraction"] = round(float(np.all(got == ref, axis=1).mean()), 4)
         res["max_abs_difference"] = int(np.abs(got - ref).max())
+    return res
+
+
+def raht_inter_leg(ctx, args):
+    """RAHT with attribute inter prediction (gpcc_raht_forward_inter / _inverse_inter), one
+    1 M-point S-lidar reflectance frame predicted from a jittered copy of itself with 10 % of the points gone; the
+    reference's tools (per-layer inter / intra decision, estimated filter taps), levels without sub-node prediction.
+    Host tier (host buffers in and out, PCIe included).  Algorithmic bytes per point: 8 + 4c in, 4c + 4c out for the
+    frame being coded, 8 + 4c in for the reference frame."""
+    from mpeg_pcc_tmc13_amd import RahtInterParams, raht_params, synth
+    n = min(args.points, 1_000_000)
+    rng = np.random.default_rng(1)
+    xyz, attrs = synth.lidar_cloud(n, seed=7)
+    attrs = (attrs >> 8 if attrs.max() > 255 else attrs)[:, :1]
+    morton, a, _ = synth.sort_by_morton(xyz, attrs)
+    keep = rng.random(len(xyz)) > 0.1
+    xr = np.clip(xyz + rng.integers(-1, 2, size=xyz.shape), 0, None)[keep].astype(np.int32)
+    ar = np.clip(attrs + rng.integers(-4, 5, size=attrs.shape), 0, 255)[keep].astype(np.int32)
+    mref, aref, _ = synth.sort_by_morton(xr, ar)
+    p = raht_params(subnode=False)
+    ip = RahtInterParams(15, 1, 1, 3)
+    ctx.raht_forward_inter(p, ip, morton, a, mref, aref)  # warm-up (pool, log2 table)
+    ctx.set_profiling(True)
+    ctx.kernel_times()
+    t0 = time.perf_counter()
+    co, rec, modes, taps = ctx.raht_forward_inter(p, ip, morton, a, mref, aref)
+    t1 = time.perf_counter()
+    kt_f = ctx.kernel_times()
+    dec = ctx.raht_inverse_inter(p, ip, morton, co, 1, mref, aref, modes, taps)
+    t2 = time.perf_counter()
+    kt_i = ctx.kernel_times()
+    ctx.set_profiling(False)
+
+    def agg(kt):
+        o = {}
+        for name, (ms, _) in kt.items():
+            o[name.split("@")[0]] = round(o.get(name.split("@")[0], 0.0) + ms, 3)
+        return dict(sorted(o.items(), key=lambda kv: -kv[1])[:8])
+    res = {"workload": f"RAHT with attribute inter prediction, {len(morton)}-point S-lidar reflectance frame, reference frame of "
+                       f"{len(mref)} points, per-layer decision + estimated taps, sub-node prediction off, qp 34",
+           "forward_ms": round((t1 - t0) * 1e3, 2), "inverse_ms": round((t2 - t1) * 1e3, 2),
+           "value": round(2 * len(morton) / (t2 - t0) / 1e6, 2), "unit": "Mpoints/s (forward + inverse, host tier, PCIe included)",
+           "layer_modes": modes.tolist(), "filter_taps": taps.tolist(), "decoder_equals_encoder_recon": bool(np.array_equal(dec, rec)),
+           "forward_kernels_ms": agg(kt_f), "inverse_kernels_ms": agg(kt_i)}
+    if not args.no_cpu_baseline:
+        import ctypes as C
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_loader as ol
+        from test_oracle_raht_inter import run
+        lib, fn, kind = (ol.ref().lib, "ref_raht_inter", "reference") if ol.ref_available() else (ol.oracle().lib, "oracle_raht_inter", "port")
+        t0 = time.perf_counter()
+        rc, co_r, _, modes_r, taps_r = run(lib, fn, p, True, morton, a, None, mref, aref, 15, 1, 1, 3)
+        dt = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": round(len(morton) / dt / 1e6, 3), "unit": "Mpoints/s (forward)", "cores": 1, "kind": kind,
+                               "sample": f"the same frame, forward only, {dt:.2f} s"}
+        res["identical_to_cpu"] = bool(rc == 0 and np.array_equal(co, co_r) and np.array_equal(modes, modes_r) and np.array_equal(taps, taps_r))
     return res
 
 

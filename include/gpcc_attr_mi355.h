@@ -177,6 +177,7 @@ int gpcc_raht_inverse(
  *   layer_modes [32], num_modes   attr_layer_code_mode: written by the encoder, read by the decoder
  *   filter_taps [32], num_taps    FilterTaps (quantised): written by the encoder when
  *                                 enable_filter_estimation, read by the decoder
+ *                                 (the decoder accepts NULL for an array whose count is 0)
  * Everything else as gpcc_raht_forward / _inverse.  On the device: slices WITHOUT sub-node prediction
  * (raht_subnode_prediction_enabled_flag = 0 or raht_prediction_enabled_flag = 0) and without the integer
  * Haar kernel or region QP offsets; the rest returns GPCC_ERR_UNSUPPORTED (the CPU keeps it).  The

@@ -1197,9 +1197,12 @@ host_transform_inter(
 {
   if (!ctx)
     return fail(GPCC_ERR_INVALID_ARG, "ctx is null");
-  if (!morton || !attrs || !coeffs || n <= 0 || !inter || !morton_ref || !attrs_ref || n_ref <= 0 || !layer_modes
-      || !num_modes || !filter_taps || !num_taps)
+  if (!morton || !attrs || !coeffs || n <= 0)
     return fail(GPCC_ERR_INVALID_ARG, "null buffer or n <= 0");
+  if (!inter || !morton_ref || !attrs_ref || n_ref <= 0)
+    return fail(GPCC_ERR_INVALID_ARG, "inter-frame RAHT: no reference frame or no tools");
+  if (!layer_modes || !num_modes || !filter_taps || !num_taps)
+    return fail(GPCC_ERR_INVALID_ARG, "inter-frame RAHT: null layer_modes / filter_taps");
   if (n > kMaxPoints || n_ref > kMaxPoints)
     return fail(GPCC_ERR_INVALID_ARG, "more than 2^29 points per call");
   int rcode = check_params(params, c, encoder);
@@ -3747,6 +3750,12 @@ gpcc_raht_inverse_inter(
   int32_t n_ref, const int32_t* layer_modes, int32_t num_modes, const int32_t* filter_taps, int32_t num_taps)
 {
   int32_t nm = num_modes, nt = num_taps;
+  // (an empty std::vector hands over a null pointer)
+  static const int32_t none[1] = {0};
+  if (!layer_modes && num_modes == 0)
+    layer_modes = none;
+  if (!filter_taps && num_taps == 0)
+    filter_taps = none;
   return counted(
     ctx,
     host_transform_inter(

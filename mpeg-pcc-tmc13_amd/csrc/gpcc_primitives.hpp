@@ -27,6 +27,14 @@
 #define GPCC_VGPR_FLOOR_64() ((void)0)
 #endif
 
+// an ordered group of `n` instructions of the classes in `mask` for the machine scheduler
+// (__builtin_amdgcn_sched_group_barrier: 0x002 VALU, 0x100 LDS read); nothing on the host and under the emulator
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GPCC_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+#else
+#define GPCC_SCHED_GROUP(mask, n) ((void)0)
+#endif
+
 namespace gpcc {
 
 constexpr int kFpFrac = 15;                 // FixedPoint::kFracBits

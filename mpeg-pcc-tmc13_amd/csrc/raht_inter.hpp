@@ -16,20 +16,21 @@
 //                        (PCCRAHTACCoefficientEntropyEstimate, RAHT.h:71-94): the analyze pass writes both
 //                        candidates (coefficients, RDOQ descriptors, transformed predictions), both zero-run
 //                        chains are resolved (raht_rdoq.hpp, twice), then the estimate:
-//                          rate_chain   the estimate's probabilities are a recurrence over ALL coefficients
-//                                       in coding order (p += (2^20 - p) >> 6 or p -= p >> 6: the shifts do
-//                                       not compose): one wavefront per chain (candidate x {p0, p1} x
-//                                       component) walks it in scalar registers, 64 coefficients per
-//                                       coalesced load, and records the state before every coefficient;
-//                          rate_bits    the cost of every coefficient from those states, in parallel
-//                                       (log2 from a table the HOST's libm filled -- the comparison of the
-//                                       two sums must come out as it does in the reference);
+//                          rate_pack / rate_p1 / rate_p0_bits   the estimate's probabilities are recurrences
+//                                       over ALL coefficients in coding order (p += (2^20 - p) >> 6 or
+//                                       p -= p >> 6: the shifts do not compose).  probResGt1 moves only at
+//                                       non-zero coefficients: one wavefront walks those; probResGt0 moves at
+//                                       every coefficient: threads take chunks and find their starting state
+//                                       by running the (monotone) recurrence from its two extreme states
+//                                       until they meet; the cost of every coefficient follows (log2 from a
+//                                       table the HOST's libm filled -- the comparison of the two sums must
+//                                       come out as it does in the reference);
 //                          rate_sum     the reference adds the costs into a double in coding order: one
-//                                       lane per candidate does exactly that;
+//                                       wavefront per candidate does exactly that;
 //                          decide       the cheaper candidate's coefficients, prediction record, zero-run
 //                                       state and probabilities go on (inter_commit).
-//                        The chains are what a level costs (about 12 ms per 1 M coefficients); everything
-//                        else is the intra pass twice.
+//                        The sum is what a level costs (a dependent double addition per coefficient and
+//                        component); everything else is the intra pass twice.
 //   estimated taps       (enableFilterEstimation) the level's tap is 128 * crosscorr / autocorr of the
 //                        first component's coefficients over every block that lines up (inter_tap_kernel:
 //                        integer sums, any order), quantised like a coefficient (inter_tap_finish_kernel).
@@ -123,7 +124,7 @@ inter_block(const InterRef& ir, int64_t pkey, int t, bool on, const SharedLut& l
 // est 0 = the candidate with the frame ("cur"), est 1 = the intra candidate
 struct RateState {
   int32_t p0[2][3], p1[2][3];  // the estimates' probabilities before the level
-  int32_t q0[2][3], q1[2][3];  // ... after it (rate_chain)
+  int32_t q0[2][3], q1[2][3];  // ... after it (rate_p0_bits, rate_p1)
   double bits[2];              // the level's cost per candidate (rate_sum)
   int32_t itz;                 // the intra candidate's zero run behind its last dual level (:1252-1254)
   int32_t intra_wins;          // the level's decision
@@ -137,7 +138,10 @@ struct RateCtx {
   int32_t n;
   int32_t a, b;             // the level's coefficients
   int32_t c;
-  int32_t* pb;              // [2 est][2 p0 / p1][C][n] probability in front of every coefficient
+  int32_t* pb;              // [2 est][C][n] probResGt1 in front of every NON-ZERO coefficient
+  unsigned long long* nzw;  // [2 est][C][wstride] flags of the level's coefficients, 64 per word: non-zero ...
+  unsigned long long* bigw; // ... magnitude above 1
+  int32_t wstride;
   double* term;             // [2 est][n * C] cost of every (coefficient, component) in coding order
   RateState* rs;
   const double* log2tab;    // [kAcRateTable + 1] log2((double)x)
@@ -151,6 +155,14 @@ struct RateCtx {
   const int64_t* iptrans;
   int32_t rows;             // children of the level (rows of the prediction record)
 };
+
+__device__ __forceinline__ unsigned long long
+rate_readlane_u64(unsigned long long v, int src)
+{
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
+  return ((unsigned long long)hi << 32) | lo;
+}
 
 __global__ __launch_bounds__(64) void
 rate_init_kernel(RateState* rs)
@@ -181,74 +193,148 @@ rate_level_begin_kernel(RateCtx cx)
   }
 }
 
-// one workgroup (one wavefront) per chain: est x {p0, p1} x component
-__global__ __launch_bounds__(64) void
-rate_chain_kernel(RateCtx cx)
+// flags of the level's coefficients, 64 per word: non-zero, magnitude above 1
+__global__ __launch_bounds__(256) void
+rate_pack_kernel(RateCtx cx)
 {
   if (tree_failed(cx.tv))
     return;
   const int lane = threadIdx.x & 63;
   const int C = cx.c;
-  const int est = (int)blockIdx.x / (2 * C);
-  const int which = ((int)blockIdx.x % (2 * C)) / C;
-  const int k = (int)blockIdx.x % C;
   const int count = cx.b - cx.a;
-  const int32_t* __restrict__ v = cx.plane[est] + (size_t)k * cx.n + cx.a;
-  int32_t* __restrict__ out = cx.pb + ((size_t)((est * 2 + which) * C + k)) * cx.n;
-  int p = which ? cx.rs->p1[est][k] : cx.rs->p0[est][k];
-  for (int base = 0; base < count; base += 64) {
-    const int i = base + lane;
-    const int32_t val = i < count ? v[i] : 0;
+  const int words = (count + 63) >> 6;
+  const int64_t total = (int64_t)2 * C * words;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t x = wave; x < total; x += nwaves) {
+    const int est = (int)(x / ((int64_t)C * words));
+    const int k = (int)((x / words) % C);
+    const int wd = (int)(x % words);
+    const int i = wd * 64 + lane;
+    const int32_t val = i < count ? cx.plane[est][(size_t)k * cx.n + cx.a + i] : 0;
     const unsigned long long nz = __ballot(val != 0);
     const unsigned long long big = __ballot(val > 1 || val < -1);
-    const int m = count - base < 64 ? count - base : 64;
-    int rec = 0;
-    for (int u = 0; u < m; u++) {
-      rec = lane == u ? p : rec;
-      const bool isnz = (nz >> u) & 1;
-      const bool isbig = (big >> u) & 1;
-      const int up = (int)((kAcRateScale - (uint32_t)p) >> 6), dn = -(p >> 6);
-      if (which == 0)
-        p += isnz ? up : dn;
-      else if (isnz)
-        p += isbig ? up : dn;
+    if (lane == 0) {
+      cx.nzw[((size_t)est * C + k) * cx.wstride + wd] = nz;
+      cx.bigw[((size_t)est * C + k) * cx.wstride + wd] = big;
     }
-    if (i < count)
-      out[i] = rec;
-  }
-  if (lane == 0) {
-    if (which)
-      cx.rs->q1[est][k] = p;
-    else
-      cx.rs->q0[est][k] = p;
   }
 }
 
-// PCCRAHTACCoefficientEntropyEstimate::costBits (RAHT.cpp:54-78): the same additions in the same order
+// probResGt1 steps only at the non-zero coefficients (resStatUpdate, RAHT.cpp:80-91): one wavefront per
+// (estimate, component) walks the flag words -- 64 words per load, the set bits of a word one after the other
+// in scalar registers -- and records the state in front of every non-zero coefficient.  Cost: words + events.
+__global__ __launch_bounds__(64) void
+rate_p1_kernel(RateCtx cx)
+{
+  if (tree_failed(cx.tv))
+    return;
+  const int lane = threadIdx.x & 63;
+  const int C = cx.c;
+  const int est = (int)blockIdx.x / C;
+  const int k = (int)blockIdx.x % C;
+  const int count = cx.b - cx.a;
+  const int words = (count + 63) >> 6;
+  const unsigned long long* __restrict__ nzw = cx.nzw + ((size_t)est * C + k) * cx.wstride;
+  const unsigned long long* __restrict__ bigw = cx.bigw + ((size_t)est * C + k) * cx.wstride;
+  int32_t* __restrict__ out = cx.pb + ((size_t)est * C + k) * cx.n;
+  int p = cx.rs->p1[est][k];
+  for (int wb = 0; wb < words; wb += 64) {
+    const int wd = wb + lane;
+    const unsigned long long mynz = wd < words ? nzw[wd] : 0ull;
+    const unsigned long long mybig = wd < words ? bigw[wd] : 0ull;
+    unsigned long long busy = __ballot(mynz != 0);
+    while (busy) {
+      const int j = __ffsll((long long)busy) - 1;
+      busy &= busy - 1;
+      const unsigned long long nz = rate_readlane_u64(mynz, j);
+      const unsigned long long big = rate_readlane_u64(mybig, j);
+      unsigned long long m = nz;
+      int rec = 0;
+      while (m) {
+        const int u = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        rec = lane == u ? p : rec;
+        p += ((big >> u) & 1) ? (int)((kAcRateScale - (uint32_t)p) >> 6) : -(p >> 6);
+      }
+      if ((nz >> lane) & 1)
+        out[(size_t)(wb + j) * 64 + lane] = rec;
+    }
+  }
+  if (lane == 0)
+    cx.rs->q1[est][k] = p;
+}
+
+// probResGt0 steps at EVERY coefficient, up (p += (2^20 - p) >> 6) where it is non-zero, down (p -= p >> 6)
+// where it is zero.  Both steps are monotone in p and every reachable state lies between their fixed points
+// 63 and 2^20 - 63, so a thread that takes a chunk of the level does not need the state at the chunk's start
+// from its predecessor: it runs the recurrence from the two extremes over a window in front of the chunk, the
+// true state stays between the two runs, and where they have met (about 900 steps) it is known exactly; a
+// window that was too short is quadrupled, at worst back to the level's first coefficient, where the state is
+// the one the previous level left.  (The predicting encoder's rate model is resolved the same way,
+// pred_kernels.hpp.)  With the state in hand the thread writes the cost of its coefficients
+// (PCCRAHTACCoefficientEntropyEstimate::updateCostBits, RAHT.cpp:54-78: the same additions in the same order).
+constexpr int kAcRateChunk = 256;
+
+__device__ __forceinline__ int
+rate_p0_step(int p, bool nz)
+{
+  return nz ? p + (int)((kAcRateScale - (uint32_t)p) >> 6) : p - (p >> 6);
+}
+
 __global__ __launch_bounds__(256) void
-rate_bits_kernel(RateCtx cx)
+rate_p0_bits_kernel(RateCtx cx)
 {
 #pragma clang fp contract(off)
   if (tree_failed(cx.tv))
     return;
   const int C = cx.c;
   const int count = cx.b - cx.a;
+  const int chunks = (count + kAcRateChunk - 1) / kAcRateChunk;
+  const int64_t total = (int64_t)2 * C * chunks;
   const double lg = (double)kAcRateScaleLog;
   const double* __restrict__ T = cx.log2tab;
-  for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < 2 * (int64_t)count; x += (int64_t)gridDim.x * blockDim.x) {
-    const int est = x >= count;
-    const int i = (int)(x - (est ? count : 0));
-    for (int k = 0; k < C; k++) {
-      const int32_t value = cx.plane[est][(size_t)k * cx.n + cx.a + i];
-      const int p0 = cx.pb[((size_t)((est * 2 + 0) * C + k)) * cx.n + i];
-      const int p1 = cx.pb[((size_t)((est * 2 + 1) * C + k)) * cx.n + i];
+  for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < total; x += (int64_t)gridDim.x * blockDim.x) {
+    const int est = (int)(x / ((int64_t)C * chunks));
+    const int k = (int)((x / chunks) % C);
+    const int chunk = (int)(x % chunks);
+    const unsigned long long* __restrict__ nzw = cx.nzw + ((size_t)est * C + k) * cx.wstride;
+    const unsigned long long* __restrict__ bigw = cx.bigw + ((size_t)est * C + k) * cx.wstride;
+    const int start = chunk * kAcRateChunk;
+    const int end = start + kAcRateChunk < count ? start + kAcRateChunk : count;
+    int p = cx.rs->p0[est][k];
+    if (start > 0) {
+      int win = 1024;
+      for (;;) {
+        const int from = start - win > 0 ? start - win : 0;
+        int lo = from ? 63 : p, hi = from ? (int)(kAcRateScale - 63) : p;
+        for (int i = from; i < start; i++) {
+          const bool nz = (nzw[i >> 6] >> (i & 63)) & 1;
+          lo = rate_p0_step(lo, nz);
+          hi = rate_p0_step(hi, nz);
+        }
+        if (lo == hi) {
+          p = lo;
+          break;
+        }
+        win *= 4;
+      }
+    }
+    const int32_t* __restrict__ plane = cx.plane[est] + (size_t)k * cx.n + cx.a;
+    const int32_t* __restrict__ pb1 = cx.pb + ((size_t)est * C + k) * cx.n;
+    double* __restrict__ term = cx.term + (size_t)est * cx.n * C;
+    for (int i = start; i < end; i++) {
+      const bool nz = (nzw[i >> 6] >> (i & 63)) & 1;
       double bits = 0;
-      bits += value ? lg - T[p0] : lg - T[kAcRateScale - (uint32_t)p0];
-      const int64_t mag = value < 0 ? -(int64_t)value : (int64_t)value;
-      if (mag) {
-        bits += mag > 1 ? lg - T[p1] : lg - T[kAcRateScale - (uint32_t)p1];
+      bits += nz ? lg - T[p] : lg - T[kAcRateScale - (uint32_t)p];
+      if (nz) {
+        const bool big = (bigw[i >> 6] >> (i & 63)) & 1;
+        const int p1 = pb1[i];
+        bits += big ? lg - T[p1] : lg - T[kAcRateScale - (uint32_t)p1];
         bits += 1;
-        if (mag > 1) {
+        if (big) {
+          const int32_t value = plane[i];
+          const int64_t mag = value < 0 ? -(int64_t)value : (int64_t)value;
           if (mag - 1 > kAcRateTable) {
             // a magnitude the table does not hold: the caller keeps the slice on the CPU
             atomicCAS(cx.tv.error, 0, 4);
@@ -257,35 +343,145 @@ rate_bits_kernel(RateCtx cx)
           }
         }
       }
-      cx.term[(size_t)est * cx.n * C + (size_t)i * C + k] = bits;
+      term[(size_t)i * C + k] = bits;
+      p = rate_p0_step(p, nz);
     }
+    if (end == count)
+      cx.rs->q0[est][k] = p;
   }
 }
 
-// e->bits += bits, coefficient after coefficient (RAHT.cpp:77): one wavefront per estimate, 64 terms per
-// coalesced load, added by every lane alike
+// e->bits += bits, coefficient after coefficient (RAHT.cpp:77): the additions are a chain no other order
+// reproduces, so one wavefront per estimate does them, every lane alike.  The terms come in by coalesced loads,
+// 512 at a time into LDS (the next 512 in flight meanwhile), and are read back with the same address in every
+// lane (a broadcast read, its latency off the chain): what is left per term is one dependent v_add_f64.
+constexpr int kAcSumChunk = 512;
+
 __global__ __launch_bounds__(64) void
 rate_sum_kernel(RateCtx cx)
 {
 #pragma clang fp contract(off)
+  __shared__ double buf[2][kAcSumChunk];
   if (tree_failed(cx.tv))
     return;
   const int lane = threadIdx.x & 63;
   const int est = blockIdx.x;
   const int64_t total = (int64_t)(cx.b - cx.a) * cx.c;
   const double* __restrict__ term = cx.term + (size_t)est * cx.n * cx.c;
-  double s = 0.0;
-  for (int64_t base = 0; base < total; base += 64) {
-    const int64_t i = base + lane;
-    const double x = i < total ? term[i] : 0.0;
-    const int64_t xb = __builtin_bit_cast(int64_t, x);
-    const int xlo = (int)(uint32_t)xb, xhi = (int)(xb >> 32);
-    const int m = total - base < 64 ? (int)(total - base) : 64;
-    for (int u = 0; u < m; u++) {
-      const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane(xlo, u);
-      const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane(xhi, u);
-      s += __builtin_bit_cast(double, (int64_t)(((uint64_t)hi << 32) | lo));
+  const int64_t nchunks = (total + kAcSumChunk - 1) / kAcSumChunk;
+  double r[kAcSumChunk / 64];
+  auto load = [&](int64_t c) {
+#pragma unroll
+    for (int j = 0; j < kAcSumChunk / 64; j++) {
+      const int64_t i = c * kAcSumChunk + j * 64 + lane;
+      r[j] = i < total ? term[i] : 0.0;
     }
+  };
+  auto store = [&](int which) {
+#pragma unroll
+    for (int j = 0; j < kAcSumChunk / 64; j++)
+      buf[which][j * 64 + lane] = r[j];
+  };
+  double s = 0.0;
+  if (nchunks > 0) {
+    load(0);
+    store(0);
+  }
+  __syncthreads();
+  for (int64_t c = 0; c < nchunks; c++) {
+    if (c + 1 < nchunks)
+      load(c + 1);
+    const double* __restrict__ cur = buf[c & 1];
+    const int64_t left = total - c * kAcSumChunk;
+    if (left >= kAcSumChunk) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      // 32 terms at a time: their sixteen LDS reads are issued together, the additions follow as the reads
+      // arrive.  Written out as machine code: left to the compiler every read ends up in front of its own two
+      // additions -- whatever the source order or the scheduler hints -- and the chain waits an LDS round trip
+      // per pair (measured: 27 cycles per term against 9 here; the addition itself has 8 cycles of latency).
+      typedef __attribute__((address_space(3))) const double LdsDouble;
+      uint32_t addr = (uint32_t)(uintptr_t)(LdsDouble*)cur;
+      for (int u0 = 0; u0 < kAcSumChunk; u0 += 32, addr += 32 * 8) {
+        asm volatile(
+          "ds_read_b128 v[64:67], %1\n\t"
+          "ds_read_b128 v[68:71], %1 offset:16\n\t"
+          "ds_read_b128 v[72:75], %1 offset:32\n\t"
+          "ds_read_b128 v[76:79], %1 offset:48\n\t"
+          "ds_read_b128 v[80:83], %1 offset:64\n\t"
+          "ds_read_b128 v[84:87], %1 offset:80\n\t"
+          "ds_read_b128 v[88:91], %1 offset:96\n\t"
+          "ds_read_b128 v[92:95], %1 offset:112\n\t"
+          "ds_read_b128 v[96:99], %1 offset:128\n\t"
+          "ds_read_b128 v[100:103], %1 offset:144\n\t"
+          "ds_read_b128 v[104:107], %1 offset:160\n\t"
+          "ds_read_b128 v[108:111], %1 offset:176\n\t"
+          "ds_read_b128 v[112:115], %1 offset:192\n\t"
+          "ds_read_b128 v[116:119], %1 offset:208\n\t"
+          "ds_read_b128 v[120:123], %1 offset:224\n\t"
+          "ds_read_b128 v[124:127], %1 offset:240\n\t"
+          "s_waitcnt lgkmcnt(15)\n\t"
+          "v_add_f64 %0, %0, v[64:65]\n\t"
+          "v_add_f64 %0, %0, v[66:67]\n\t"
+          "s_waitcnt lgkmcnt(14)\n\t"
+          "v_add_f64 %0, %0, v[68:69]\n\t"
+          "v_add_f64 %0, %0, v[70:71]\n\t"
+          "s_waitcnt lgkmcnt(13)\n\t"
+          "v_add_f64 %0, %0, v[72:73]\n\t"
+          "v_add_f64 %0, %0, v[74:75]\n\t"
+          "s_waitcnt lgkmcnt(12)\n\t"
+          "v_add_f64 %0, %0, v[76:77]\n\t"
+          "v_add_f64 %0, %0, v[78:79]\n\t"
+          "s_waitcnt lgkmcnt(11)\n\t"
+          "v_add_f64 %0, %0, v[80:81]\n\t"
+          "v_add_f64 %0, %0, v[82:83]\n\t"
+          "s_waitcnt lgkmcnt(10)\n\t"
+          "v_add_f64 %0, %0, v[84:85]\n\t"
+          "v_add_f64 %0, %0, v[86:87]\n\t"
+          "s_waitcnt lgkmcnt(9)\n\t"
+          "v_add_f64 %0, %0, v[88:89]\n\t"
+          "v_add_f64 %0, %0, v[90:91]\n\t"
+          "s_waitcnt lgkmcnt(8)\n\t"
+          "v_add_f64 %0, %0, v[92:93]\n\t"
+          "v_add_f64 %0, %0, v[94:95]\n\t"
+          "s_waitcnt lgkmcnt(7)\n\t"
+          "v_add_f64 %0, %0, v[96:97]\n\t"
+          "v_add_f64 %0, %0, v[98:99]\n\t"
+          "s_waitcnt lgkmcnt(6)\n\t"
+          "v_add_f64 %0, %0, v[100:101]\n\t"
+          "v_add_f64 %0, %0, v[102:103]\n\t"
+          "s_waitcnt lgkmcnt(5)\n\t"
+          "v_add_f64 %0, %0, v[104:105]\n\t"
+          "v_add_f64 %0, %0, v[106:107]\n\t"
+          "s_waitcnt lgkmcnt(4)\n\t"
+          "v_add_f64 %0, %0, v[108:109]\n\t"
+          "v_add_f64 %0, %0, v[110:111]\n\t"
+          "s_waitcnt lgkmcnt(3)\n\t"
+          "v_add_f64 %0, %0, v[112:113]\n\t"
+          "v_add_f64 %0, %0, v[114:115]\n\t"
+          "s_waitcnt lgkmcnt(2)\n\t"
+          "v_add_f64 %0, %0, v[116:117]\n\t"
+          "v_add_f64 %0, %0, v[118:119]\n\t"
+          "s_waitcnt lgkmcnt(1)\n\t"
+          "v_add_f64 %0, %0, v[120:121]\n\t"
+          "v_add_f64 %0, %0, v[122:123]\n\t"
+          "s_waitcnt lgkmcnt(0)\n\t"
+          "v_add_f64 %0, %0, v[124:125]\n\t"
+          "v_add_f64 %0, %0, v[126:127]\n\t"
+          : "+v"(s)
+          : "v"(addr)
+          : "memory", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127");
+      }
+#else
+      for (int u = 0; u < kAcSumChunk; u++)
+        s += cur[u];
+#endif
+    } else {
+      for (int u = 0; u < (int)left; u++)
+        s += cur[u];
+    }
+    if (c + 1 < nchunks)
+      store((int)((c + 1) & 1));
+    __syncthreads();
   }
   if (lane == 0)
     cx.rs->bits[est] = s;

@@ -8,7 +8,7 @@
 //   schedule                               level plan (no coarse levels: every level is a launch)
 //   per level, top down (tmc3/RAHT.cpp:1165-1345):
 //     [inter_tap + inter_tap_finish]       encoder, estimated taps
-//     encoder  tile<kAnalyze, INTER> -> rdoq_resolve [x 2 -> rate_chain / bits / sum / decide -> commit]
+//     encoder  tile<kAnalyze, INTER> -> rdoq_resolve [x 2 -> rate_pack / p1 / p0_bits / sum / decide -> commit]
 //              -> tile<kSynthRec>
 //     decoder  tile<kSynth, INTER>
 //   finish                                 duplicates, write-back
@@ -69,6 +69,8 @@ struct InterWork {
   RateState* rs = nullptr;
   int32_t* pb = nullptr;
   double* term = nullptr;
+  unsigned long long *nzw = nullptr, *bigw = nullptr;
+  int wstride = 0;
 };
 
 inline bool
@@ -127,7 +129,10 @@ inter_carve(Take&& take, InterWork& w)
     w.slice_l = (int32_t*)arr(2, 4);
     w.islice_l = (int32_t*)arr(2, 4);
     w.rs = (RateState*)arr(1, sizeof(RateState));
-    w.pb = (int32_t*)arr((size_t)4 * c * n, 4);
+    w.pb = (int32_t*)arr((size_t)2 * c * n, 4);
+    w.wstride = (n + 63) / 64 + 1;
+    w.nzw = (unsigned long long*)arr((size_t)2 * c * w.wstride, 8);
+    w.bigw = (unsigned long long*)arr((size_t)2 * c * w.wstride, 8);
     w.term = (double*)arr((size_t)2 * c * n, 8);
     w.tap_acc = (unsigned long long*)arr(2, 8);
   }
@@ -252,6 +257,9 @@ inter_run(
   rt.n = n;
   rt.c = C;
   rt.pb = w.pb;
+  rt.nzw = w.nzw;
+  rt.bigw = w.bigw;
+  rt.wstride = w.wstride;
   rt.term = w.term;
   rt.rs = w.rs;
   rt.log2tab = d_log2tab;
@@ -361,13 +369,14 @@ inter_run(
       }
       if (dual) {
         {
-          auto t = prof("rate_chain", li);
-          hipLaunchKernelGGL(rate_chain_kernel, dim3(4 * C), dim3(64), 0, st, rt);
-        }
-        {
-          auto t = prof("rate_bits", li);
-          const int bgrid = (int)std::min<int64_t>(std::max<int64_t>((2 * (int64_t)(b - a) + 255) / 256, 1), 4096);
-          hipLaunchKernelGGL(rate_bits_kernel, dim3(bgrid), dim3(256), 0, st, rt);
+          auto t = prof("rate_states", li);
+          const int words = (b - a + 63) / 64;
+          const int pgrid = (int)std::min<int64_t>(std::max<int64_t>(((int64_t)2 * C * words + 3) / 4, 1), 4096);
+          hipLaunchKernelGGL(rate_pack_kernel, dim3(pgrid), dim3(256), 0, st, rt);
+          hipLaunchKernelGGL(rate_p1_kernel, dim3(2 * C), dim3(64), 0, st, rt);
+          const int chunks = (b - a + kAcRateChunk - 1) / kAcRateChunk;
+          const int bgrid = (int)std::min<int64_t>(std::max<int64_t>(((int64_t)2 * C * chunks + 255) / 256, 1), 4096);
+          hipLaunchKernelGGL(rate_p0_bits_kernel, dim3(bgrid), dim3(256), 0, st, rt);
         }
         {
           auto t = prof("rate_sum", li);

@@ -7,8 +7,13 @@
 // (call sites: AttributeEncoder.cpp:1273,1341; AttributeDecoder.cpp:595,658)
 // with the reference's own signatures, flattens the reference's parameter
 // structs into the POD block of include/gpcc_attr_mi355.h and runs the slice
-// on the MI355X through the C ABI.  When the device path declines a slice
-// (GPCC_ERR_UNSUPPORTED: inter prediction)
+// on the MI355X through the C ABI -- slices with attribute inter prediction
+// (attrInterPredParams.enableAttrInterPred) through gpcc_raht_forward_inter /
+// gpcc_raht_inverse_inter with the reference frame of paramsForInterRAHT, the
+// per-layer modes and filter taps appended to / read from the same vectors the
+// reference's function uses (RAHT.cpp:1293, 1820-1825; :1260, 1303).  When the
+// device path declines a slice (GPCC_ERR_UNSUPPORTED: inter prediction together
+// with sub-node prediction, the integer Haar kernel or region QP offsets)
 // or no GPU is present it calls the reference's CPU implementation, which
 // the integrator keeps in the link under a suffixed name (see
 // RAHT.cpp is compiled with
@@ -86,8 +91,6 @@ flatten(
   const RahtPredictionParams& rp, const QpSet& qs, bool extension,
   const AttributeInterPredParams& inter, gpcc_raht_params* p)
 {
-  if (inter.enableAttrInterPred)
-    return false;  // inter-frame RAHT is not on the device
   if (rp.predWeightParent.size() != 19)
     return false;
   if (
@@ -140,6 +143,21 @@ qp_offsets_or_null(const Qps* q, int n)
   return nullptr;
 }
 
+// the tools of attribute inter prediction (AttributeInterPredParamsForRAHT, PCCTMC3Common.h:236-250)
+gpcc_raht_inter_params
+inter_tools(const AttributeInterPredParams& inter)
+{
+  const auto& ir = inter.paramsForInterRAHT;
+  gpcc_raht_inter_params ip;
+  ip.raht_inter_prediction_depth_minus1 = ir.raht_inter_prediction_depth_minus1;
+  ip.raht_enable_inter_intra_layer_rdo = ir.raht_enable_inter_intra_layer_RDO;
+  ip.enable_filter_estimation = ir.enableFilterEstimation;
+  ip.skip_init_layers_for_filtering = ir.skipInitLayersForFiltering;
+  return ip;
+}
+
+static_assert(sizeof(int) == sizeof(int32_t), "the reference's int vectors are handed over as int32_t");
+
 }  // namespace
 
 void
@@ -154,9 +172,27 @@ regionAdaptiveHierarchicalTransform(
   if (
     ctx && voxelCount > 0
     && flatten(rahtPredParams, qpset, rahtExtension, attrInterPredParams, &p)) {
-    int rc = gpcc_raht_forward(
-      ctx, &p, mortonCode, qp_offsets_or_null(pointQpOffsets, voxelCount),
-      attributes, coefficients, voxelCount, attribCount);
+    int rc;
+    if (attrInterPredParams.enableAttrInterPred) {
+      auto& ir = attrInterPredParams.paramsForInterRAHT;
+      const gpcc_raht_inter_params ip = inter_tools(attrInterPredParams);
+      int32_t modes[32], taps[32], num_modes = 0, num_taps = 0;
+      rc = qp_offsets_or_null(pointQpOffsets, voxelCount) || ir.voxelCount <= 0
+        ? GPCC_ERR_UNSUPPORTED
+        : gpcc_raht_forward_inter(
+            ctx, &p, &ip, mortonCode, attributes, coefficients, voxelCount, attribCount, ir.mortonCode.data(),
+            reinterpret_cast<const int32_t*>(ir.attributes.data()), ir.voxelCount, modes, &num_modes, taps, &num_taps);
+      if (rc == GPCC_OK) {
+        for (int i = 0; i < num_modes; i++)
+          attrInterPredParams.attr_layer_code_mode.push_back(modes[i]);
+        for (int i = 0; i < num_taps; i++)
+          ir.FilterTaps.push_back(taps[i]);
+      }
+    } else {
+      rc = gpcc_raht_forward(
+        ctx, &p, mortonCode, qp_offsets_or_null(pointQpOffsets, voxelCount),
+        attributes, coefficients, voxelCount, attribCount);
+    }
     if (rc == GPCC_OK) {
       g_device_calls++;
       return;
@@ -182,9 +218,24 @@ regionAdaptiveHierarchicalInverseTransform(
   if (
     ctx && voxelCount > 0
     && flatten(rahtPredParams, qpset, rahtExtension, attrInterPredParams, &p)) {
-    int rc = gpcc_raht_inverse(
-      ctx, &p, mortonCode, qp_offsets_or_null(pointQpOffsets, voxelCount),
-      attributes, coefficients, voxelCount, attribCount);
+    int rc;
+    if (attrInterPredParams.enableAttrInterPred) {
+      const auto& ir = attrInterPredParams.paramsForInterRAHT;
+      const gpcc_raht_inter_params ip = inter_tools(attrInterPredParams);
+      const auto& modes = attrInterPredParams.attr_layer_code_mode;
+      rc = qp_offsets_or_null(pointQpOffsets, voxelCount) || ir.voxelCount <= 0 || modes.size() > 32
+          || ir.FilterTaps.size() > 32
+        ? GPCC_ERR_UNSUPPORTED
+        : gpcc_raht_inverse_inter(
+            ctx, &p, &ip, mortonCode, attributes, coefficients, voxelCount, attribCount, ir.mortonCode.data(),
+            reinterpret_cast<const int32_t*>(ir.attributes.data()), ir.voxelCount,
+            reinterpret_cast<const int32_t*>(modes.data()), int32_t(modes.size()),
+            reinterpret_cast<const int32_t*>(ir.FilterTaps.data()), int32_t(ir.FilterTaps.size()));
+    } else {
+      rc = gpcc_raht_inverse(
+        ctx, &p, mortonCode, qp_offsets_or_null(pointQpOffsets, voxelCount),
+        attributes, coefficients, voxelCount, attribCount);
+    }
     if (rc == GPCC_OK) {
       g_device_calls++;
       return;

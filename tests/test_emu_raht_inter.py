@@ -37,6 +37,10 @@ def check(lib, p, morton, attrs, mref, aref, depth, rdo, fest, skip, tag):
     return modes_o, taps_o
 
 
+# GPCC_EMU_FULL=1: the clouds and frame / tool combinations of tests/test_gpu_raht_inter.py (40 CPU-minutes);
+# the default tier runs the small clouds with a subset of the combinations
+FULL = os.environ.get("GPCC_EMU_FULL") == "1"
+
 VARIANTS = [dict(subnode=False), dict(prediction=False), dict(subnode=False, qp=22), dict(subnode=False, extension=False),
             dict(subnode=False, qp=46, chroma_offset=0)]
 
@@ -51,15 +55,19 @@ def test_emulated_inter_raht(lib, vi, rdo, fest):
     for name, xyz, attrs in clouds():
         if name == "one":
             continue
+        if not FULL:
+            if name in ("lidar", "dups") or (vi and (rdo, fest) != (1, 1)):
+                continue
+            xyz, attrs = xyz[:900], attrs[:900]
         morton, a_sorted, _ = synth.sort_by_morton(xyz, attrs)
-        for shift, jitter in ((0, 2), (0, 40), (40, 6)):
+        for shift, jitter in ((0, 2), (0, 40), (40, 6)) if FULL else ((0, 2), (40, 6)):
             mref, aref = frame_of(xyz, attrs, rng, shift=shift, jitter=jitter)
-            for depth, skip in ((15, 0), (2, 3), (15, 3)):
+            for depth, skip in ((15, 0), (2, 3), (15, 3)) if FULL else ((15, 3),):
                 m, t = check(lib, raht_params(**kw), morton, a_sorted, mref, aref, depth, rdo, fest, skip,
                              f"{name} {kw} shift{shift} jitter{jitter} depth{depth} skip{skip} rdo{rdo} fest{fest}")
                 seen_modes.update(m.tolist())
                 seen_taps.update(t.tolist())
-    if rdo and kw.get("prediction", True):
+    if rdo and kw.get("prediction", True) and FULL:
         assert seen_modes == {0, 1}, seen_modes
-    if fest:
+    if fest and FULL:
         assert len(seen_taps) > 1, seen_taps

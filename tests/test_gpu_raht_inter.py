@@ -94,3 +94,84 @@ def test_declined_configurations():
         with pytest.raises(GpccError) as e:
             ctx.raht_forward_inter(raht_params(**kw), inter_params(15, 1, 0, 0), morton, a_sorted, morton, a_sorted)
         assert e.value.code == -2, e.value
+
+
+
+# ---- seam 1 with inter slices: libtmc3_shim.so in a process of its own (tests/raht_inter_shim_worker.py), the
+#      unmodified libtmc3_ref.so here ---------------------------------------------------------------------------
+def _shim_worker(what, tmp_path):
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, "oracle", "_ref", "libtmc3_shim.so")):
+        pytest.skip("libtmc3_shim.so absent")
+    out = str(tmp_path / "shim.npz")
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "raht_inter_shim_worker.py"), what, out],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return np.load(out, allow_pickle=True), r.stderr
+
+
+def seam1_cases():
+    from mpeg_pcc_tmc13_amd import raht_params, synth
+    rng = np.random.default_rng(5)
+    xyz, attrs = synth.dense_cloud(30000, seed=9, bits=8)
+    morton, a_sorted, _ = synth.sort_by_morton(xyz, attrs)
+    mref, aref = frame_of(xyz, attrs, rng, jitter=4)
+    # (parameters, layer decision, estimated taps, runs on the device)
+    cases = [(dict(subnode=False), 1, 1, True), (dict(subnode=False), 1, 0, True), (dict(prediction=False), 0, 0, True),
+             (dict(), 1, 0, False)]
+    return morton, a_sorted, mref, aref, [(raht_params(**kw), rdo, fest, dev) for kw, rdo, fest, dev in cases]
+
+
+def test_seam1_runs_inter_slices_on_the_device(tmp_path):
+    """the reference's own callers' entry points (pcc::regionAdaptiveHierarchicalTransform / ...Inverse..., replaced
+    by shim/RAHT_mi355.cpp) with attrInterPredParams.enableAttrInterPred: the device runs the slice, the modes and
+    taps land in the reference's vectors, everything equals the unmodified library's; with sub-node prediction the
+    device declines and the reference's CPU function keeps the slice"""
+    if not ol.ref_available():
+        pytest.skip("compiled reference absent")
+    got, log = _shim_worker("function", tmp_path)
+    morton, a_sorted, mref, aref, cases = seam1_cases()
+    for i, (p, rdo, fest, dev) in enumerate(cases):
+        rc, co_r, rec_r, modes_r, taps_r = run(ol.ref().lib, "ref_raht_inter", p, True, morton, a_sorted, None, mref, aref, 15, rdo, fest, 3)
+        assert rc == 0
+        np.testing.assert_array_equal(got[f"co{i}"], co_r)
+        np.testing.assert_array_equal(got[f"rec{i}"], rec_r)
+        np.testing.assert_array_equal(got[f"modes{i}"], modes_r)
+        np.testing.assert_array_equal(got[f"taps{i}"], taps_r)
+        np.testing.assert_array_equal(got[f"dec{i}"], rec_r)
+        assert tuple(got[f"calls{i}"]) == ((2, 0) if dev else (0, 2)), (i, got[f"calls{i}"], log)
+
+
+def operator_case():
+    from mpeg_pcc_tmc13_amd import synth
+    rng = np.random.default_rng(11)
+    xyz, attrs = synth.lidar_cloud(60000, seed=61)
+    attrs = attrs[:, :1].copy()
+    if attrs.max() > 255:
+        attrs = attrs >> 8
+    keep = rng.random(len(xyz)) > 0.1
+    xr = np.clip(xyz + rng.integers(-1, 2, size=xyz.shape), 0, None)[keep].astype(np.int32)
+    ar = np.clip(attrs + rng.integers(-6, 7, size=attrs.shape), 0, 255)[keep].astype(np.int32)
+    return xyz, attrs, xr, ar
+
+
+def test_operator_with_inter_raht_on_the_device(tmp_path):
+    """AttributeEncoder::encode (encodeReflectancesTransformRaht with a reference frame) + AttributeDecoder::decode of
+    the library with the link seams replaced: the attribute brick's payload, the reconstructions, the signalled modes
+    and taps equal the unmodified operator's, and the RAHT calls ran on the device"""
+    from test_oracle_raht_inter import _operator_roundtrip
+    from mpeg_pcc_tmc13_amd import raht_params
+    if not ol.ref_available():
+        pytest.skip("compiled reference absent")
+    got, log = _shim_worker("operator", tmp_path)
+    xyz, attrs, xr, ar = operator_case()
+    for i, (rdo, fest) in enumerate(((1, 1), (0, 0))):
+        want = _operator_roundtrip(raht_params(subnode=False), 34, xyz, attrs, xr, ar, 15, rdo, fest, 3)
+        assert got[f"payload{i}"].tobytes() == want[0], "payload"
+        for j, name in enumerate(("enc", "dec", "modes", "taps")):
+            np.testing.assert_array_equal(got[f"{name}{i}"], want[1 + j])
+        calls = tuple(got[f"calls{i}"])
+        assert calls[0] >= 2 and calls[1] == 0, (calls, log)

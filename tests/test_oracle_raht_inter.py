@@ -177,9 +177,9 @@ def test_inter_raht_with_the_integer_haar_kernel(rdo, fest):
                           f"{name} {kw} shift{shift} jitter{jitter} depth{depth} rdo{rdo} fest{fest}")
 
 
-def _operator_roundtrip(rp, qp, xyz, attrs, xyz_ref, attrs_ref, depth, rdo, fest, skip):
+def _operator_roundtrip(rp, qp, xyz, attrs, xyz_ref, attrs_ref, depth, rdo, fest, skip, lib=None):
     u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
-    f = ol.ref().lib.ref_raht_inter_roundtrip
+    f = (lib or ol.ref().lib).ref_raht_inter_roundtrip
     f.restype = C.c_int
     f.argtypes = [C.c_void_p, C.c_int32, C.c_int32, i32p, i32p, C.c_int32, i32p, i32p, C.c_int32, C.c_int32, C.c_int32,
                   C.c_int32, C.c_int32, i32p, i32p, u8p, C.c_int32, i32p, C.POINTER(C.c_int32), i32p, C.POINTER(C.c_int32)]

@@ -4,5 +4,5 @@ set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 O=gpurun_out/${1:-r04_inter}; mkdir -p $O
-( time timeout 1500 python -m pytest tests/test_gpu_raht_inter.py -m gpu -x -q ) > $O/pytest.log 2>&1; echo "rc $?" >> $O/pytest.log; tail -n 25 $O/pytest.log
+( time timeout 1500 python -m pytest tests/test_gpu_raht_inter.py -m gpu -q ) > $O/pytest.log 2>&1; echo "rc $?" >> $O/pytest.log; tail -n 25 $O/pytest.log
 timeout 600 python tools/raht_inter_time.py > $O/inter_time.txt 2>&1; tail -n 30 $O/inter_time.txt
