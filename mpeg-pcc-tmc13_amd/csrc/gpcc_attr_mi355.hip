@@ -1213,7 +1213,7 @@ host_transform_inter(
   if (!inter_supported(params, n))
     return fail(
       GPCC_ERR_UNSUPPORTED,
-      "inter-frame RAHT on the device: not with sub-node prediction, the integer Haar kernel or a single point");
+      "inter-frame RAHT on the device: not with the integer Haar kernel or a single point");
   for (int i = 1; i < n; i++)
     if (morton[i] < morton[i - 1])
       return fail(GPCC_ERR_UNSORTED, "Morton codes are not ascending");
@@ -1231,6 +1231,7 @@ host_transform_inter(
   w.c = c;
   w.n_ref = n_ref;
   w.encoder = encoder;
+  w.sub = inter_sub(params);
   InterTools tl;
   tl.depth_limit = inter->raht_inter_prediction_depth_minus1 + 1;
   tl.layer_rdo = inter->raht_enable_inter_intra_layer_rdo != 0;

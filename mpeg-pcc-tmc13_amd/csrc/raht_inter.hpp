@@ -147,6 +147,7 @@ struct RateCtx {
   const double* log2tab;    // [kAcRateTable + 1] log2((double)x)
   int32_t* slice_l;         // [1] the zero-run state of the candidate with the frame (raht_rdoq.hpp) ...
   int32_t* islice_l;        // [1] ... and of the intra candidate
+  int32_t* islice_pair;     // [2] both entries of the intra candidate's state (the dependency kernels keep one per level parity)
   int32_t* modes;           // [32] attr_layer_code_mode, in order
   // commit
   int32_t* coeffs;
@@ -188,7 +189,7 @@ rate_level_begin_kernel(RateCtx cx)
   if (tree_failed(cx.tv))
     return;
   if (threadIdx.x == 0) {
-    cx.islice_l[0] = cx.a - 1 - cx.rs->itz;
+    cx.islice_pair[0] = cx.islice_pair[1] = cx.a - 1 - cx.rs->itz;
     cx.rs->bits[0] = cx.rs->bits[1] = 0.0;
   }
 }

@@ -11,6 +11,11 @@
 //     encoder  tile<kAnalyze, INTER> -> rdoq_resolve [x 2 -> rate_pack / p1 / p0_bits / sum / decide -> commit]
 //              -> tile<kSynthRec>
 //     decoder  tile<kSynth, INTER>
+//   with sub-node prediction (the reference's default flag) the level kernels are the dependency kernels
+//   (raht_subnode.hpp) instead:
+//     encoder  prepass -> level_sub<kLossySub, INTER> [+ level_sub<kLossySub> on a second workspace: the intra
+//              candidate, whose reconstruction feeds ITS later blocks -> rate_* / decide -> commit_sub]
+//     decoder  prepass -> level_sub<kSynth, INTER>
 //   finish                                 duplicates, write-back
 #pragma once
 #include <algorithm>
@@ -19,6 +24,7 @@
 
 #include "raht_edges.hpp"
 #include "raht_inter.hpp"
+#include "raht_subnode.hpp"
 #include "raht_tile.hpp"
 #include "raht_tree.hpp"
 
@@ -71,13 +77,28 @@ struct InterWork {
   double* term = nullptr;
   unsigned long long *nzw = nullptr, *bigw = nullptr;
   int wstride = 0;
+  // sub-node prediction: the dependency kernels' workspace, and a second one for the intra candidate
+  bool sub = false;
+  int32_t* worklist = nullptr;
+  int32_t* work_count = nullptr;  // [kMaxLevels] then tickets [kMaxLevels][8]
+  int32_t* ticket2 = nullptr;     // [kMaxLevels][8]
+  unsigned long long* scan_state = nullptr;
+  uint8_t* pocc = nullptr;
+  uint32_t *mbox = nullptr, *mbox2 = nullptr;
+  unsigned long long *rdoq_state = nullptr, *rdoq_state2 = nullptr;
+  int64_t *irec = nullptr, *irec_us = nullptr;
 };
 
 inline bool
 inter_supported(const gpcc_raht_params* p, int64_t n)
 {
-  return !p->integer_haar_enable_flag && !(p->raht_prediction_enabled_flag && p->raht_subnode_prediction_enabled_flag)
-    && n >= 2;
+  return !p->integer_haar_enable_flag && n >= 2;
+}
+
+inline bool
+inter_sub(const gpcc_raht_params* p)
+{
+  return p->raht_prediction_enabled_flag && p->raht_subnode_prediction_enabled_flag;
 }
 
 // `take(bytes)` hands out 256-byte aligned storage (or only counts)
@@ -136,6 +157,21 @@ inter_carve(Take&& take, InterWork& w)
     w.term = (double*)arr((size_t)2 * c * n, 8);
     w.tap_acc = (unsigned long long*)arr(2, 8);
   }
+  if (w.sub) {
+    w.worklist = (int32_t*)arr((size_t)n + 1, 4);
+    w.work_count = (int32_t*)arr(kMaxLevels * 9, 4);
+    w.ticket2 = (int32_t*)arr(kMaxLevels * 8, 4);
+    w.scan_state = (unsigned long long*)arr(1024, 8);
+    w.pocc = (uint8_t*)arr((size_t)n + 1, 1);
+    w.mbox = (uint32_t*)arr((size_t)n * c * 4, 4);
+    if (w.encoder) {
+      w.mbox2 = (uint32_t*)arr((size_t)n * c * 4, 4);
+      w.rdoq_state = (unsigned long long*)arr((size_t)n + 1, 8);
+      w.rdoq_state2 = (unsigned long long*)arr((size_t)n + 1, 8);
+      w.irec = (int64_t*)arr((size_t)n * c, 8);
+      w.irec_us = (int64_t*)arr((size_t)n * c, 8);
+    }
+  }
   const int ftiles = (w.n_ref + kTilePoints - 1) / kTilePoints;
   w.frame_tile = (int32_t*)arr((size_t)ftiles * c + 1, 4);
   w.frame_prefix = (int32_t*)arr(((size_t)w.n_ref + 1) * c, 4);
@@ -143,6 +179,44 @@ inter_carve(Take&& take, InterWork& w)
   w.modes = (int32_t*)arr(32, 4);
   w.taps = (int32_t*)arr(32, 4);
   w.num_taps = (int32_t*)arr(1, 4);
+}
+
+constexpr int kInterSubGrid = 1024;  // dependency kernels: resident workgroups (as the intra path's)
+
+// rows of a level's reconstruction from one workspace to the other: in front of the intra candidate's launch
+// (what the prepass copied), and back when that candidate won (`when` null: always)
+struct SubCopyCtx {
+  TreeView tv;
+  const int64_t *src, *src_us;
+  int64_t *dst, *dst_us;
+  int64_t count;
+  const int32_t* when;
+};
+
+inline int
+sub_copy_grid(int64_t count)
+{
+  return (int)std::min<int64_t>(std::max<int64_t>((count + 255) / 256, 1), 4096);
+}
+
+__global__ __launch_bounds__(256) void
+inter_sub_copy_kernel(SubCopyCtx cx)
+{
+  if (tree_failed(cx.tv))
+    return;
+  if (cx.when && !*cx.when)
+    return;
+  for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < cx.count; x += (int64_t)gridDim.x * blockDim.x) {
+    cx.dst[x] = cx.src[x];
+    cx.dst_us[x] = cx.src_us[x];
+  }
+}
+
+__global__ __launch_bounds__(64) void
+inter_pair_sync_kernel(int32_t* pair, int which)
+{
+  if (threadIdx.x == 0)
+    pair[which ^ 1] = pair[which];
 }
 
 // Everything after the uploads of params / pt_off (= {0, n}) / rtile_base (= {0, tiles}) / the two frames.
@@ -213,6 +287,31 @@ inter_run(
       return e;
     hipLaunchKernelGGL(rate_init_kernel, dim3(1), dim3(64), 0, st, w.rs);
   }
+  if (w.sub) {
+    e = hipMemsetAsync(w.work_count, 0, kMaxLevels * 9 * sizeof(int32_t), st);
+    if (e != hipSuccess)
+      return e;
+    e = hipMemsetAsync(w.ticket2, 0, kMaxLevels * 8 * sizeof(int32_t), st);
+    if (e != hipSuccess)
+      return e;
+    e = hipMemsetAsync(w.scan_state, 0, 1024 * sizeof(unsigned long long), st);
+    if (e != hipSuccess)
+      return e;
+    e = hipMemsetAsync(w.mbox, 0, (size_t)n * C * 16, st);
+    if (e != hipSuccess)
+      return e;
+    if (encoder) {
+      e = hipMemsetAsync(w.mbox2, 0, (size_t)n * C * 16, st);
+      if (e != hipSuccess)
+        return e;
+      e = hipMemsetAsync(w.rdoq_state, 0, ((size_t)n + 1) * 8, st);
+      if (e != hipSuccess)
+        return e;
+      e = hipMemsetAsync(w.rdoq_state2, 0, ((size_t)n + 1) * 8, st);
+      if (e != hipSuccess)
+        return e;
+    }
+  }
   e = wait();
   if (e != hipSuccess)
     return e;
@@ -242,6 +341,15 @@ inter_run(
   lc.inter.idesc = w.idesc;
   lc.inter.iptrans = w.iptrans;
   lc.inter.icoeffs = w.icoeffs;
+  if (w.sub) {
+    lc.worklist = w.worklist;
+    lc.work_count = w.work_count;
+    lc.scan_state = w.scan_state;
+    lc.pocc = w.pocc;
+    lc.mbox = w.mbox;
+    lc.ticket = w.work_count + kMaxLevels;
+    lc.rdoq_state = w.rdoq_state;
+  }
 
   RdoqCtx rc{};
   rc.tv = tv;
@@ -265,6 +373,7 @@ inter_run(
   rt.log2tab = d_log2tab;
   rt.slice_l = w.slice_l;
   rt.islice_l = w.islice_l;
+  rt.islice_pair = w.islice_l;
   rt.modes = w.modes;
   rt.coeffs = d_coeffs;
   rt.icoeffs = w.icoeffs;
@@ -272,7 +381,7 @@ inter_run(
   rt.iptrans = w.iptrans;
 
   static const int kFixedTaps[7] = {128, 128, 128, 127, 125, 121, 115};
-  int tree_depth = 0, depth = 0, qp_layer = 0, coeff = 0;
+  int tree_depth = 0, depth = 0, qp_layer = 0, coeff = 0, parity = 1;
   for (int li = top - 1; li >= 0; li--) {
     const bool root = li == top - 1;
     if (!root && ts.nodes[li] == ts.nodes[li + 1])
@@ -282,6 +391,7 @@ inter_run(
     const int a = coeff;
     coeff += root ? ts.nodes[li] : ts.nodes[li] - ts.nodes[li + 1];
     const int b = coeff;
+    parity ^= 1;  // (the reconstruction buffer this level writes, schedule_kernel)
     const bool pred_in_level = !root && hp->raht_prediction_enabled_flag != 0;
     const int lr = tl.bits_ref - tl.bits_cur + 3 * li;
     const bool inter_on = tl.bits_ref >= 0 && lr >= 0 && lr <= 62 && tree_depth < tl.depth_limit;
@@ -319,6 +429,99 @@ inter_run(
     } else {
       const int tap = (inter_on && !tl.filter_est) ? kFixedTaps[tree_depth < 7 ? tree_depth : 6] : 128;
       hipLaunchKernelGGL(inter_set_word_kernel, dim3(1), dim3(64), 0, st, w.tap_words + li, tap);
+    }
+
+    if (w.sub) {
+      // ---- the dependency kernels (raht_subnode.hpp) ------------------------------------------
+      const int64_t parents = ts.nodes[li + 1];
+      lc.mtag = (uint32_t)(li + 1);
+      {
+        auto t = prof("level_prepass", li);
+        hipLaunchKernelGGL(
+          HIP_KERNEL_NAME(raht_level_prepass_kernel<C>), dim3((int)std::min<int64_t>((parents + 1023) / 1024, 1024)), dim3(256),
+          0, st, lc);
+      }
+      const int sgrid = (int)std::min<int64_t>(kInterSubGrid, std::max<int64_t>(8, (parents / 64 + 7) / 8 * 8));
+#ifdef GPCC_EMU  // (the workgroups of a dependency kernel wait for one another: eight run together)
+#define GPCC_EMU_CONCURRENT(n) emu::set_concurrent_blocks(n)
+#else
+#define GPCC_EMU_CONCURRENT(n) ((void)0)
+#endif
+      if (!encoder) {
+        auto t = prof("inter_sub_synth", li);
+        GPCC_EMU_CONCURRENT(8);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(raht_level_sub_kernel<C, kSynth, ArithI64, true>), dim3(sgrid), dim3(256), 0, st, lc);
+        GPCC_EMU_CONCURRENT(1);
+      } else {
+        rt.a = a;
+        rt.b = b;
+        rt.rows = ts.nodes[li];
+        // the zero-run state the kernels read is the entry of the OTHER level parity (the prepass copies it
+        // over, raht_levels.hpp): both entries carry the state in front of the level
+        rt.slice_l = w.slice_l + (li & 1);
+        rt.islice_l = w.islice_l + (li & 1);
+        LevelCtx lb = lc;
+        if (dual) {
+          // the intra candidate: the same kernel without the frame, on a workspace of its own -- the children's
+          // reconstruction (what the prepass copied included), coefficients, mailbox, zero-run words, tickets
+          lb.rec[parity] = w.irec;
+          lb.rec_us[parity] = w.irec_us;
+          lb.coeffs = w.icoeffs;
+          lb.mbox = w.mbox2;
+          lb.rdoq_state = w.rdoq_state2;
+          lb.slice_l = w.islice_l;
+          lb.ticket = w.ticket2;
+          lb.inter.blocks = 0;
+          SubCopyCtx sc{tv, w.rec[parity], w.rec_us[parity], w.irec, w.irec_us, (int64_t)ts.nodes[li] * C, nullptr};
+          hipLaunchKernelGGL(rate_level_begin_kernel, dim3(1), dim3(64), 0, st, rt);
+          hipLaunchKernelGGL(inter_sub_copy_kernel, dim3(sub_copy_grid(sc.count)), dim3(256), 0, st, sc);
+        }
+        {
+          auto t = prof("inter_sub_lossy", li);
+          GPCC_EMU_CONCURRENT(8);
+          hipLaunchKernelGGL(HIP_KERNEL_NAME(raht_level_sub_kernel<C, kLossySub, ArithI64, true>), dim3(sgrid), dim3(256), 0, st, lc);
+          GPCC_EMU_CONCURRENT(1);
+        }
+        if (dual) {
+          {
+            auto t = prof("inter_sub_lossy_intra", li);
+            GPCC_EMU_CONCURRENT(8);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(raht_level_sub_kernel<C, kLossySub, ArithI64, false>), dim3(sgrid), dim3(256), 0, st, lb);
+            GPCC_EMU_CONCURRENT(1);
+          }
+          {
+            auto t = prof("rate_states", li);
+            const int words = (b - a + 63) / 64;
+            const int pgrid = (int)std::min<int64_t>(std::max<int64_t>(((int64_t)2 * C * words + 3) / 4, 1), 4096);
+            hipLaunchKernelGGL(rate_pack_kernel, dim3(pgrid), dim3(256), 0, st, rt);
+            hipLaunchKernelGGL(rate_p1_kernel, dim3(2 * C), dim3(64), 0, st, rt);
+            const int chunks = (b - a + kAcRateChunk - 1) / kAcRateChunk;
+            const int bgrid = (int)std::min<int64_t>(std::max<int64_t>(((int64_t)2 * C * chunks + 255) / 256, 1), 4096);
+            hipLaunchKernelGGL(rate_p0_bits_kernel, dim3(bgrid), dim3(256), 0, st, rt);
+          }
+          {
+            auto t = prof("rate_sum", li);
+            hipLaunchKernelGGL(rate_sum_kernel, dim3(2), dim3(64), 0, st, rt);
+          }
+          {
+            auto t = prof("rate_decide", li);
+            hipLaunchKernelGGL(rate_decide_kernel, dim3(1), dim3(64), 0, st, rt);
+            // the winner's coefficients (inter_commit with no prediction record) and reconstruction
+            RateCtx rcm = rt;
+            rcm.rows = 0;
+            const int64_t work = (int64_t)(b - a) * C;
+            hipLaunchKernelGGL(inter_commit_kernel, dim3((int)std::min<int64_t>(std::max<int64_t>((work + 255) / 256, 1), 4096)), dim3(256), 0, st, rcm);
+            SubCopyCtx sc{tv, w.irec, w.irec_us, w.rec[parity], w.rec_us[parity], (int64_t)ts.nodes[li] * C, &w.rs->intra_wins};
+            hipLaunchKernelGGL(inter_sub_copy_kernel, dim3(sub_copy_grid(sc.count)), dim3(256), 0, st, sc);
+          }
+        }
+        // the state in front of the next level in both entries (a level no slice processes is not launched here)
+        hipLaunchKernelGGL(inter_pair_sync_kernel, dim3(1), dim3(64), 0, st, w.slice_l, li & 1);
+      }
+      if (pred_in_level && rdo_on)
+        depth++;
+      tree_depth++;
+      continue;
     }
 
     const int64_t parents = ts.nodes[li + 1];

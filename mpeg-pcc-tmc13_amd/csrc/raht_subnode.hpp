@@ -42,6 +42,7 @@
 #pragma once
 
 #include "raht_arith.hpp"
+#include "raht_inter.hpp"
 #include "raht_levels.hpp"
 
 namespace gpcc {
@@ -122,7 +123,11 @@ store_agent_i64(int64_t* p, int64_t v)
 #endif
 // A = the arithmetic back end (raht_arith.hpp): ArithI64, or ArithF64 for batches whose values stay
 // in the range where doubles are exact (extension on, no integer Haar; the kernel checks).
-template<int C, int MODE, class A = ArithI64>
+// INTER: attribute inter prediction (raht_inter.hpp) -- where ctx.inter says so a block that lines up with
+// one of the reference frame takes the frame's coefficients as its prediction; such a block waits for nobody.
+// (The encoder's second, intra-only candidate of a level is a launch of the kernel WITHOUT the flag on a
+// workspace of its own: raht_inter_driver.hpp.)
+template<int C, int MODE, class A = ArithI64, bool INTER = false>
 __global__ __launch_bounds__(256, MODE == kLossySub ? GPCC_SUB_LOSSY_WAVES : (C == 3 ? GPCC_SUB_SYNTH3_WAVES : 4)) void
 raht_level_sub_kernel(LevelCtx ctx)
 {
@@ -149,8 +154,13 @@ raht_level_sub_kernel(LevelCtx ctx)
   const bool ext = A::kF64 || prm->raht_extension != 0;
   const int32_t epoch = li + 1;
   // the wavefront's mailbox: values of the children committed in the current round
+#ifdef GPCC_EMU  // (tests/emu: __shared__ is one static object, eight workgroups run together)
+  __shared__ unsigned long long wmail_s[8 * 4 * 64 * C];
+  unsigned long long* wm = wmail_s + ((blockIdx.x & 7) * 4 + (threadIdx.x >> 6)) * (64 * C);
+#else
   __shared__ unsigned long long wmail_s[4 * 64 * C];
   unsigned long long* wm = wmail_s + (threadIdx.x >> 6) * (64 * C);
+#endif
   int pwc12[12];
 #pragma unroll
   for (int i12 = 0; i12 < 12; i12++)
@@ -681,6 +691,32 @@ raht_level_sub_kernel(LevelCtx ctx)
     const auto mrsrc = __builtin_amdgcn_make_buffer_rsrc(
       ctx.mbox, 0, (int)((size_t)tv.n_total * C * 16), 0x00020000);
 
+    // ---- the reference frame's block (tmc3/RAHT.cpp:1322-1347, 1533-1545): where it exists it is the
+    //      prediction of every coefficient of the block, and nothing of this level is waited for ---------
+    bool use_inter = false;
+    VT ipin[C];
+#pragma unroll
+    for (int k = 0; k < C; k++)
+      ipin[k] = A::zero();
+    if constexpr (INTER) {
+      if (ctx.inter.blocks) {
+        bool node;
+        int64_t pin[C];
+        inter_block<C>(ctx.inter, on ? tv.key[li + 1][j] : 0, t, on, lut, &node, pin);
+        use_inter = node;
+#pragma unroll
+        for (int k = 0; k < C; k++) {
+          ipin[k] = A::from_i64(pin[k]);
+          in_range = in_range && (!node || A::below(ipin[k], A::kFwdLimit));
+        }
+        if (use_inter) {
+          pend = 0;
+          inw = 0;
+          enable_pred = on;
+        }
+      }
+    }
+
     // ---- the staged dependency loop -------------------------------------
     // stage 0: waiting for neighbour blocks   -> (P) predict + transform,
     //          results cached in registers
@@ -832,6 +868,13 @@ raht_level_sub_kernel(LevelCtx ctx)
                 pw_[k] = oth;
               }
             }
+          }
+        }
+        if constexpr (INTER) {
+          if (use_inter) {
+#pragma unroll
+            for (int k = 0; k < C; k++)
+              pw_[k] = ipin[k];
           }
         }
         // encoder: residual, tentative coefficient, RDOQ descriptor

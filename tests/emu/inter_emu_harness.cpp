@@ -44,6 +44,7 @@ inter_emu_raht(
   w.c = c;
   w.n_ref = n_ref;
   w.encoder = fwd != 0;
+  w.sub = inter_sub(params);
   InterTools tl;
   tl.depth_limit = depth_minus1 + 1;
   tl.layer_rdo = layer_rdo;

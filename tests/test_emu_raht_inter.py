@@ -42,7 +42,9 @@ def check(lib, p, morton, attrs, mref, aref, depth, rdo, fest, skip, tag):
 FULL = os.environ.get("GPCC_EMU_FULL") == "1"
 
 VARIANTS = [dict(subnode=False), dict(prediction=False), dict(subnode=False, qp=22), dict(subnode=False, extension=False),
-            dict(subnode=False, qp=46, chroma_offset=0)]
+            dict(subnode=False, qp=46, chroma_offset=0),
+            # the reference's default flag: sub-node prediction (the dependency kernels, two workspaces for the decision)
+            dict(), dict(extension=False), dict(qp=22)]
 
 
 @pytest.mark.parametrize("vi", range(len(VARIANTS)))
@@ -56,7 +58,7 @@ def test_emulated_inter_raht(lib, vi, rdo, fest):
         if name == "one":
             continue
         if not FULL:
-            if name in ("lidar", "dups") or (vi and (rdo, fest) != (1, 1)):
+            if name in ("lidar", "dups") or (vi not in (0, 5) and (rdo, fest) != (1, 1)):
                 continue
             xyz, attrs = xyz[:900], attrs[:900]
         morton, a_sorted, _ = synth.sort_by_morton(xyz, attrs)

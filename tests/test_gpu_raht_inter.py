@@ -12,7 +12,9 @@ from test_oracle_raht_inter import clouds, frame_of, run
 pytestmark = pytest.mark.gpu
 
 VARIANTS = [dict(subnode=False), dict(prediction=False), dict(subnode=False, qp=22), dict(subnode=False, extension=False),
-            dict(subnode=False, qp=46, chroma_offset=0)]
+            dict(subnode=False, qp=46, chroma_offset=0),
+            # the reference's default flag: sub-node prediction
+            dict(), dict(extension=False), dict(qp=22), dict(qp=46, chroma_offset=0)]
 
 
 def inter_params(depth, rdo, fest, skip):
@@ -80,8 +82,9 @@ def test_inter_raht_large_frames(kind, n, c):
     attrs = attrs[:, :c]
     morton, a_sorted, _ = synth.sort_by_morton(xyz, attrs)
     mref, aref = frame_of(xyz, attrs, rng, jitter=4)
-    for rdo, fest in ((1, 0), (1, 1)):
-        check(ctx, raht_params(subnode=False), morton, a_sorted, mref, aref, 15, rdo, fest, 3, f"{kind} rdo{rdo} fest{fest}")
+    for kw in (dict(subnode=False), dict()):
+        for rdo, fest in ((1, 0), (1, 1)):
+            check(ctx, raht_params(**kw), morton, a_sorted, mref, aref, 15, rdo, fest, 3, f"{kind} {kw} rdo{rdo} fest{fest}")
 
 
 def test_declined_configurations():
@@ -90,7 +93,7 @@ def test_declined_configurations():
     ctx = context(0)
     xyz, attrs = synth.dense_cloud(2000, seed=3, bits=6)
     morton, a_sorted, _ = synth.sort_by_morton(xyz, attrs)
-    for kw in (dict(), dict(haar=True, qp=4, chroma_offset=0, subnode=False)):
+    for kw in (dict(haar=True, qp=4, chroma_offset=0, subnode=False),):
         with pytest.raises(GpccError) as e:
             ctx.raht_forward_inter(raht_params(**kw), inter_params(15, 1, 0, 0), morton, a_sorted, morton, a_sorted)
         assert e.value.code == -2, e.value
@@ -121,15 +124,16 @@ def seam1_cases():
     mref, aref = frame_of(xyz, attrs, rng, jitter=4)
     # (parameters, layer decision, estimated taps, runs on the device)
     cases = [(dict(subnode=False), 1, 1, True), (dict(subnode=False), 1, 0, True), (dict(prediction=False), 0, 0, True),
-             (dict(), 1, 0, False)]
+             (dict(), 1, 0, True), (dict(haar=True, qp=4, chroma_offset=0, subnode=False), 1, 0, False)]
     return morton, a_sorted, mref, aref, [(raht_params(**kw), rdo, fest, dev) for kw, rdo, fest, dev in cases]
 
 
 def test_seam1_runs_inter_slices_on_the_device(tmp_path):
     """the reference's own callers' entry points (pcc::regionAdaptiveHierarchicalTransform / ...Inverse..., replaced
     by shim/RAHT_mi355.cpp) with attrInterPredParams.enableAttrInterPred: the device runs the slice, the modes and
-    taps land in the reference's vectors, everything equals the unmodified library's; with sub-node prediction the
-    device declines and the reference's CPU function keeps the slice"""
+    taps land in the reference's vectors, everything equals the unmodified library's (the reference's default flags
+    included: sub-node prediction + per-layer decision); with the integer Haar kernel the device declines and the
+    reference's CPU function keeps the slice"""
     if not ol.ref_available():
         pytest.skip("compiled reference absent")
     got, log = _shim_worker("function", tmp_path)
@@ -143,6 +147,10 @@ def test_seam1_runs_inter_slices_on_the_device(tmp_path):
         np.testing.assert_array_equal(got[f"taps{i}"], taps_r)
         np.testing.assert_array_equal(got[f"dec{i}"], rec_r)
         assert tuple(got[f"calls{i}"]) == ((2, 0) if dev else (0, 2)), (i, got[f"calls{i}"], log)
+
+
+# (parameters, per-layer decision, estimated taps); the second one is the reference's default configuration
+OPERATOR_CASES = [(dict(subnode=False), 1, 1), (dict(), 1, 0), (dict(subnode=False), 0, 0)]
 
 
 def operator_case():
@@ -168,8 +176,8 @@ def test_operator_with_inter_raht_on_the_device(tmp_path):
         pytest.skip("compiled reference absent")
     got, log = _shim_worker("operator", tmp_path)
     xyz, attrs, xr, ar = operator_case()
-    for i, (rdo, fest) in enumerate(((1, 1), (0, 0))):
-        want = _operator_roundtrip(raht_params(subnode=False), 34, xyz, attrs, xr, ar, 15, rdo, fest, 3)
+    for i, (kw, rdo, fest) in enumerate(OPERATOR_CASES):
+        want = _operator_roundtrip(raht_params(**kw), 34, xyz, attrs, xr, ar, 15, rdo, fest, 3)
         assert got[f"payload{i}"].tobytes() == want[0], "payload"
         for j, name in enumerate(("enc", "dec", "modes", "taps")):
             np.testing.assert_array_equal(got[f"{name}{i}"], want[1 + j])

@@ -53,7 +53,7 @@ def loop_region(body):
 
 
 def kernel_name(c, mode, arith):
-    return f"_ZN4gpcc21raht_level_sub_kernelILi{c}ELi{mode}ENS_8Arith{arith}EEEvNS_8LevelCtxE"
+    return f"_ZN4gpcc21raht_level_sub_kernelILi{c}ELi{mode}ENS_8Arith{arith}ELb0EEEvNS_8LevelCtxE"
 
 
 # mode 1 = decoder, 2 = integer-Haar encoder, 3 = lossy encoder (LevelMode); the arithmetic back

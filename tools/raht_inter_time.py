@@ -36,8 +36,8 @@ def main():
             xyz, attrs = synth.dense_cloud(n, seed=8, bits=10)
         morton, a, _ = synth.sort_by_morton(xyz, attrs)
         mref, aref = frame_of(xyz, attrs, rng)
-        p = raht_params(subnode=False)
-        for rdo, fest in ((0, 0), (1, 0), (1, 1)):
+        for sub, rdo, fest in ((0, 0, 0), (0, 1, 0), (0, 1, 1), (1, 0, 0), (1, 1, 0), (1, 1, 1)):
+            p = raht_params(subnode=bool(sub))
             ip = RahtInterParams(15, rdo, fest, 3)
             ctx.raht_forward_inter(p, ip, morton, a, mref, aref)
             ctx.set_profiling(True)
@@ -65,8 +65,8 @@ def main():
                     rc, co_r, _, modes_r, taps_r = run(ol.ref().lib, "ref_raht_inter", p, True, morton, a, None, mref, aref, 15, rdo, fest, 3)
                     row["cpu_reference_forward_s"] = round(time.perf_counter() - t0, 3)
                     row["identical_to_reference"] = bool(np.array_equal(co, co_r) and np.array_equal(modes, modes_r) and np.array_equal(taps, taps_r))
-            out[f"{kind}_rdo{rdo}_fest{fest}"] = row
-            print(kind, rdo, fest, json.dumps(row), flush=True)
+            out[f"{kind}_sub{sub}_rdo{rdo}_fest{fest}"] = row
+            print(kind, "subnode", sub, "decision", rdo, "estimated_taps", fest, json.dumps(row), flush=True)
 
 
 if __name__ == "__main__":
