@@ -178,9 +178,9 @@ int gpcc_raht_inverse(
  *   filter_taps [32], num_taps    FilterTaps (quantised): written by the encoder when
  *                                 enable_filter_estimation, read by the decoder
  *                                 (the decoder accepts NULL for an array whose count is 0)
- * Everything else as gpcc_raht_forward / _inverse.  On the device: slices WITHOUT sub-node prediction
- * (raht_subnode_prediction_enabled_flag = 0 or raht_prediction_enabled_flag = 0) and without the integer
- * Haar kernel or region QP offsets; the rest returns GPCC_ERR_UNSUPPORTED (the CPU keeps it).  The
+ * Everything else as gpcc_raht_forward / _inverse (no region QP offsets).  On the device: every parameter
+ * set but the integer Haar kernel (GPCC_ERR_UNSUPPORTED: the CPU keeps the slice) -- with sub-node
+ * prediction the dependency kernels, the encoder's two candidates of a level one after the other.  The
  * per-layer decision compares two sums of doubles the reference accumulates in coding order with log2 of
  * the HOST's libm inside: the library fills its log2 table from the same libm and adds in the same order
  * (csrc/raht_inter.hpp); a coefficient magnitude beyond the table (2^20) returns GPCC_ERR_UNSUPPORTED. */

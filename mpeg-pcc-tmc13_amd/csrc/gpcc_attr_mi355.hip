@@ -126,6 +126,7 @@ struct gpcc_ctx {
   // recolour: the second tree's build runs on a stream of its own (recolour_kdtree.hpp KdLevelLoop)
   hipStream_t kd_stream = nullptr;
   hipEvent_t kd_event = nullptr;
+  hipEvent_t inter_event = nullptr;  // inter-frame RAHT: the second candidate's stream joins the first
   int32_t* h_kd = nullptr;        // pinned: 2 x 4 counters
   // what the entries did since the context was created (gpcc_ctx_stats)
   gpcc_ctx_stats_t stats{};
@@ -1176,11 +1177,29 @@ launch_inter(
   const int32_t* d_ref_attrs, int32_t* d_attrs, int32_t* d_coeffs)
 {
   hipStream_t st = ctx->stream;
+  // the encoder's second candidate under sub-node prediction runs on the context's second stream
+  // (GPCC_INTER_STREAMS=0: one after the other); with the profiler on the spans are per stream order: sequential
+  InterStreams streams;
+  static const bool two = [] {
+    const char* ev = getenv("GPCC_INTER_STREAMS");
+    return !(ev && ev[0] == '0');
+  }();
+  if (two && w.sub && w.encoder && !ctx->profiling) {
+    if (!ctx->kd_stream)
+      HIP_TRY(hipStreamCreateWithFlags(&ctx->kd_stream, hipStreamNonBlocking));
+    if (!ctx->kd_event)
+      HIP_TRY(hipEventCreateWithFlags(&ctx->kd_event, hipEventDisableTiming));
+    if (!ctx->inter_event)
+      HIP_TRY(hipEventCreateWithFlags(&ctx->inter_event, hipEventDisableTiming));
+    streams.second = ctx->kd_stream;
+    streams.fork = ctx->kd_event;
+    streams.join = ctx->inter_event;
+  }
   hipError_t e = inter_run<C>(
     st, w, tl, hp, ctx->d_lut, ctx->d_log2, d_ref_pos, d_ref_attrs, d_attrs, d_coeffs, ctx->h_stats,
     [&](const char* name, int li) { return Timer(ctx, li < 0 ? name : level_name(name, li)); },
     [&]() -> hipError_t { return hipEventRecord(ctx->ev_stats, st); },
-    [&]() -> hipError_t { return hipEventSynchronize(ctx->ev_stats); });
+    [&]() -> hipError_t { return hipEventSynchronize(ctx->ev_stats); }, streams);
   if (e != hipSuccess)
     return fail(GPCC_ERR_HIP, std::string("inter-frame RAHT: ") + hipGetErrorString(e));
   if (ctx->h_error)
@@ -1329,7 +1348,22 @@ host_transform_inter(
     HIP_TRY(hipStreamSynchronize(st));
     return GPCC_OK;
   };
-  const int r = run();
+  // the intra candidate under sub-node prediction in doubles where they are exact (the rule of dev_transform)
+  {
+    const int bdepth = 8 + std::max(0, (params->max_qp - 51 + 5) / 6);
+    w.f64 = ctx->fast_arith && w.sub && encoder && params->raht_extension
+      && 2 * bdepth + bitlen64((uint64_t)(n - 1)) <= 36;
+  }
+  int r = run();
+  if (r == GPCC_ERR_RANGE && w.f64) {
+    // the caller's buffers are untouched: once more in int64 arithmetic
+    cleanup();
+    work = nullptr;
+    d_m = d_mr = nullptr;
+    d_a = d_c = d_ar = nullptr;
+    w.f64 = false;
+    r = run();
+  }
   cleanup();
   return r;
 }
@@ -2180,6 +2214,8 @@ gpcc_ctx_destroy(gpcc_ctx* ctx)
     hipHostFree(ctx->h_kd);
   if (ctx->kd_event)
     hipEventDestroy(ctx->kd_event);
+  if (ctx->inter_event)
+    hipEventDestroy(ctx->inter_event);
   if (ctx->kd_stream)
     hipStreamDestroy(ctx->kd_stream);
   if (ctx->d_log2)
@@ -5091,11 +5127,13 @@ recolour_impl(
     //      a second one (a level is a handful of small launches and a look at the node counter) ------
     {
       Timer t(ctx, "rc_kdtree");
-      if (!ctx->kd_stream) {
+      // (the stream and the event are shared with inter-frame RAHT's second candidate)
+      if (!ctx->kd_stream)
         HIP_TRY(hipStreamCreateWithFlags(&ctx->kd_stream, hipStreamNonBlocking));
+      if (!ctx->kd_event)
         HIP_TRY(hipEventCreateWithFlags(&ctx->kd_event, hipEventDisableTiming));
+      if (!ctx->h_kd)
         HIP_TRY(hipHostMalloc((void**)&ctx->h_kd, 8 * sizeof(int32_t)));
-      }
       int r = kd_alloc(ctx, &ks, d_sx, ns);
       if (!r)
         r = kd_alloc(ctx, &kt, d_tx, nt);

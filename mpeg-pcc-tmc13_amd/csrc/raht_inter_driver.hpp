@@ -79,6 +79,7 @@ struct InterWork {
   int wstride = 0;
   // sub-node prediction: the dependency kernels' workspace, and a second one for the intra candidate
   bool sub = false;
+  bool f64 = false;  // the intra candidate's dependency kernel in ArithF64 (raht_arith.hpp; decided by the caller)
   int32_t* worklist = nullptr;
   int32_t* work_count = nullptr;  // [kMaxLevels] then tickets [kMaxLevels][8]
   int32_t* ticket2 = nullptr;     // [kMaxLevels][8]
@@ -183,6 +184,19 @@ inter_carve(Take&& take, InterWork& w)
 
 constexpr int kInterSubGrid = 1024;  // dependency kernels: resident workgroups (as the intra path's)
 
+// A second stream for the encoder's intra candidate under sub-node prediction: the two candidates of a level are
+// independent dependency sweeps, each of which leaves most of the device idle, so they run side by side (the
+// waits inside a kernel are only ever for blocks a RUNNING workgroup has claimed: sharing the device cannot
+// stall either).  `second` null: one after the other (the emulator harness).
+struct InterStreams {
+#ifndef GPCC_EMU
+  hipStream_t second = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+#else
+  void* second = nullptr;
+#endif
+};
+
 // rows of a level's reconstruction from one workspace to the other: in front of the intra candidate's launch
 // (what the prepass copied), and back when that candidate won (`when` null: always)
 struct SubCopyCtx {
@@ -226,7 +240,7 @@ hipError_t
 inter_run(
   hipStream_t st, InterWork& w, const InterTools& tl, const gpcc_raht_params* hp, const SharedLut* d_lut,
   const double* d_log2tab, const int64_t* d_ref_pos, const int32_t* d_ref_attrs, int32_t* d_attrs, int32_t* d_coeffs,
-  TreeStats* stats, Prof&& prof, Mark&& mark, Wait&& wait)
+  TreeStats* stats, Prof&& prof, Mark&& mark, Wait&& wait, const InterStreams& streams = InterStreams())
 {
   const TreeView tv = w.tv;
   const int n = w.n;
@@ -476,6 +490,27 @@ inter_run(
           hipLaunchKernelGGL(rate_level_begin_kernel, dim3(1), dim3(64), 0, st, rt);
           hipLaunchKernelGGL(inter_sub_copy_kernel, dim3(sub_copy_grid(sc.count)), dim3(256), 0, st, sc);
         }
+        bool forked = false;
+#ifndef GPCC_EMU
+        if (dual && streams.second) {
+          // the intra candidate on the second stream, behind everything enqueued so far
+          hipError_t ef = hipEventRecord(streams.fork, st);
+          if (ef == hipSuccess)
+            ef = hipStreamWaitEvent(streams.second, streams.fork, 0);
+          if (ef != hipSuccess)
+            return ef;
+          if (w.f64)
+            hipLaunchKernelGGL(
+              HIP_KERNEL_NAME(raht_level_sub_kernel<C, kLossySub, ArithF64, false>), dim3(sgrid), dim3(256), 0, streams.second, lb);
+          else
+            hipLaunchKernelGGL(
+              HIP_KERNEL_NAME(raht_level_sub_kernel<C, kLossySub, ArithI64, false>), dim3(sgrid), dim3(256), 0, streams.second, lb);
+          ef = hipEventRecord(streams.join, streams.second);
+          if (ef != hipSuccess)
+            return ef;
+          forked = true;
+        }
+#endif
         {
           auto t = prof("inter_sub_lossy", li);
           GPCC_EMU_CONCURRENT(8);
@@ -483,12 +518,22 @@ inter_run(
           GPCC_EMU_CONCURRENT(1);
         }
         if (dual) {
-          {
+          if (!forked) {
             auto t = prof("inter_sub_lossy_intra", li);
             GPCC_EMU_CONCURRENT(8);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(raht_level_sub_kernel<C, kLossySub, ArithI64, false>), dim3(sgrid), dim3(256), 0, st, lb);
+            if (w.f64)
+              hipLaunchKernelGGL(HIP_KERNEL_NAME(raht_level_sub_kernel<C, kLossySub, ArithF64, false>), dim3(sgrid), dim3(256), 0, st, lb);
+            else
+              hipLaunchKernelGGL(HIP_KERNEL_NAME(raht_level_sub_kernel<C, kLossySub, ArithI64, false>), dim3(sgrid), dim3(256), 0, st, lb);
             GPCC_EMU_CONCURRENT(1);
           }
+#ifndef GPCC_EMU
+          if (forked) {
+            const hipError_t ej = hipStreamWaitEvent(st, streams.join, 0);
+            if (ej != hipSuccess)
+              return ej;
+          }
+#endif
           {
             auto t = prof("rate_states", li);
             const int words = (b - a + 63) / 64;

@@ -40,14 +40,16 @@ def main():
             p = raht_params(subnode=bool(sub))
             ip = RahtInterParams(15, rdo, fest, 3)
             ctx.raht_forward_inter(p, ip, morton, a, mref, aref)
-            ctx.set_profiling(True)
+            # wall time without the profiler (with it the encoder's two candidates run one after the other)
             t0 = time.perf_counter()
             co, rec, modes, taps = ctx.raht_forward_inter(p, ip, morton, a, mref, aref)
             t1 = time.perf_counter()
-            kt_f = ctx.kernel_times()
             dec = ctx.raht_inverse_inter(p, ip, morton, co, a.shape[1], mref, aref, modes, taps)
             t2 = time.perf_counter()
-            kt_i = ctx.kernel_times()
+            ctx.set_profiling(True)
+            ctx.kernel_times()
+            ctx.raht_forward_inter(p, ip, morton, a, mref, aref)
+            kt_f = ctx.kernel_times()
             ctx.set_profiling(False)
             agg = {}
             for name, (ms, _) in kt_f.items():
