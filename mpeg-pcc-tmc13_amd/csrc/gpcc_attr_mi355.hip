@@ -1229,10 +1229,6 @@ host_transform_inter(
     return rcode;
   if (!encoder && (*num_modes < 0 || *num_modes > 32 || *num_taps < 0 || *num_taps > 32))
     return fail(GPCC_ERR_INVALID_ARG, "at most 32 layer modes / filter taps");
-  if (!inter_supported(params, n))
-    return fail(
-      GPCC_ERR_UNSUPPORTED,
-      "inter-frame RAHT on the device: not with the integer Haar kernel or a single point");
   for (int i = 1; i < n; i++)
     if (morton[i] < morton[i - 1])
       return fail(GPCC_ERR_UNSORTED, "Morton codes are not ascending");
@@ -1264,7 +1260,14 @@ host_transform_inter(
     tl.taps = filter_taps;
     tl.num_taps = *num_taps;
   }
+  if (!inter_supported(params, n, tl))
+    return fail(
+      GPCC_ERR_UNSUPPORTED,
+      "inter-frame RAHT on the device: not a single point, nor the integer Haar kernel with estimated filter taps or "
+      "with trees that do not line up on octree levels");
   w.nlev = std::min((std::max(tl.bits_cur, 1) + 2) / 3 + 1, (int)kMaxLevels);
+  w.haar = params->integer_haar_enable_flag != 0;
+  w.nlev_ref = std::min((std::max(tl.bits_ref, 1) + 2) / 3 + 1, (int)kMaxLevels);
   size_t need = 0;
   inter_carve(
     [&](size_t bytes) {
@@ -1316,6 +1319,14 @@ host_transform_inter(
     HIP_TRY(hipMemcpyAsync(w.pt_off, h_off, sizeof(h_off), hipMemcpyHostToDevice, st));
     if (w.rtile_base)
       HIP_TRY(hipMemcpyAsync(w.rtile_base, h_rt, sizeof(h_rt), hipMemcpyHostToDevice, st));
+    const int32_t h_off_ref[2] = {0, n_ref};
+    if (w.haar) {
+      // (pageable sources: the copies are staged before the calls return)
+      if (w.haar_lf_tab)
+        HIP_TRY(hipMemcpyAsync(w.haar_lf_tab, w.haar_lf, sizeof(w.haar_lf), hipMemcpyHostToDevice, st));
+      HIP_TRY(hipMemcpyAsync(w.ref_lf_tab, w.ref_lf, sizeof(w.ref_lf), hipMemcpyHostToDevice, st));
+      HIP_TRY(hipMemcpyAsync(w.pt_off_ref, h_off_ref, sizeof(h_off_ref), hipMemcpyHostToDevice, st));
+    }
     int r = GPCC_ERR_INVALID_ARG;
     switch (c) {
     case 1: r = launch_inter<1>(ctx, w, tl, params, d_mr, d_ar, d_a, d_c); break;

@@ -120,6 +120,64 @@ inter_block(const InterRef& ir, int64_t pkey, int t, bool on, const SharedLut& l
     out[k] = ir.filtered ? (v[k] * tap) >> 7 : v[k];
 }
 
+// The same under the integer Haar kernel (HaarKernel, RAHT.cpp:642-668): the frame's node values come from
+// its own level arrays (InterRef::hkey ..), there is no normalisation and no filter tap ("the integer Haar
+// kernel takes the frame's coefficients as they are", :1520-1526).
+template<int C>
+__device__ __forceinline__ void
+inter_block_haar(const InterRef& ir, int64_t pkey, int t, bool on, bool* node, int64_t out[C])
+{
+  int32_t wr = 0;
+  int64_t v[C];
+#pragma unroll
+  for (int k = 0; k < C; k++)
+    v[k] = 0;
+  if (on) {
+    const int64_t want = (int64_t)(((uint64_t)pkey << 3) + (uint64_t)t);
+    int lo = 0, hi = ir.hsoff[1];
+    const int m = hi;
+    while (lo < hi) {
+      const int mid = lo + ((hi - lo) >> 1);
+      if (ir.hkey[mid] < want)
+        lo = mid + 1;
+      else
+        hi = mid;
+    }
+    if (lo < m && ir.hkey[lo] == want) {
+      wr = ir.hfp[lo + 1] - ir.hfp[lo];
+#pragma unroll
+      for (int k = 0; k < C; k++)
+        v[k] = fp_from_int(ir.hlf[(size_t)lo * C + k]);
+    }
+  }
+  *node = group8_bits(wr > 0) != 0;
+  int32_t cw = wr;
+#pragma unroll
+  for (int st = 0; st < 3; st++) {
+    const int bit = 1 << st;
+    const int32_t pw = lane_xor8(cw, bit);
+    const bool left = !(t & bit);
+    const int32_t wl = left ? cw : pw, wrr = left ? pw : cw;
+    const bool both = wl && wrr;
+    const bool swap = !wl && wrr;
+#pragma unroll
+    for (int k = 0; k < C; k++) {
+      const int64_t own = v[k];
+      const int64_t oth = shfl_xor_i64(own, bit);
+      if (both) {
+        const int64_t hf = left ? oth - own : own - oth;
+        v[k] = left ? own + ((hf >> (1 + kFpFrac)) << kFpFrac) : hf;
+      } else if (swap) {
+        v[k] = oth;
+      }
+    }
+    cw = both ? wl + wrr : (left ? wl + wrr : 0);
+  }
+#pragma unroll
+  for (int k = 0; k < C; k++)
+    out[k] = v[k];
+}
+
 // ---- the rate estimate of the per-level decision ---------------------------------------------------
 // est 0 = the candidate with the frame ("cur"), est 1 = the intra candidate
 struct RateState {

@@ -88,12 +88,32 @@ struct InterWork {
   uint32_t *mbox = nullptr, *mbox2 = nullptr;
   unsigned long long *rdoq_state = nullptr, *rdoq_state2 = nullptr;
   int64_t *irec = nullptr, *irec_us = nullptr;
+  // integer Haar kernel: low-pass values of every level of the current frame (encoder) and of the reference
+  // frame, which gets level arrays of its own; the pointer tables are filled by the caller (host copies beside)
+  bool haar = false;
+  int nlev_ref = 0;
+  int32_t* haar_lf[kMaxLevels] = {};
+  int32_t** haar_lf_tab = nullptr;
+  int32_t* dup_hf = nullptr;
+  TreeView tvr{};
+  int32_t* pt_off_ref = nullptr;
+  uint32_t* tile_cnt_ref = nullptr;
+  int32_t* ref_lf[kMaxLevels] = {};
+  int32_t** ref_lf_tab = nullptr;
+  int32_t* ref_dup_hf = nullptr;
 };
 
+// Under the integer Haar kernel the frame's nodes come from level arrays of its own: the two trees have to line
+// up on octree levels (they descend from their own tops, bit level B_ref - B + 3 level), and the estimated
+// filter taps (computed from RAHT butterflies of the Haar low-pass values) are not built.
 inline bool
-inter_supported(const gpcc_raht_params* p, int64_t n)
+inter_supported(const gpcc_raht_params* p, int64_t n, const InterTools& tl)
 {
-  return !p->integer_haar_enable_flag && n >= 2;
+  if (n < 2)
+    return false;
+  if (p->integer_haar_enable_flag)
+    return !tl.filter_est && (tl.bits_ref < 0 || (tl.bits_ref - tl.bits_cur) % 3 == 0);
+  return true;
 }
 
 inline bool
@@ -157,6 +177,42 @@ inter_carve(Take&& take, InterWork& w)
     w.bigw = (unsigned long long*)arr((size_t)2 * c * w.wstride, 8);
     w.term = (double*)arr((size_t)2 * c * n, 8);
     w.tap_acc = (unsigned long long*)arr(2, 8);
+  }
+  if (w.haar) {
+    if (w.encoder) {
+      for (int li = 0; li < nlev; li++)
+        w.haar_lf[li] = (int32_t*)arr((size_t)w.tv.cap[li] * c + 1, 4);
+      w.haar_lf_tab = (int32_t**)arr(kMaxLevels, sizeof(void*));
+      w.dup_hf = (int32_t*)arr((size_t)n * c + 1, 4);
+    }
+    const int nr = w.n_ref, nlr = w.nlev_ref;
+    w.pt_off_ref = (int32_t*)arr(2, 4);
+    for (int li = 0; li < nlr; li++) {
+      int64_t cap = nr;
+      const int up = nlr - 1 - li;
+      if (up < 11) {
+        const int64_t full = (int64_t)1 << (3 * up);
+        cap = cap < full ? cap : full;
+      }
+      w.tvr.cap[li] = (int32_t)cap;
+      w.tvr.key[li] = (int64_t*)arr(cap + 1, 8);
+      w.tvr.fp[li] = (int32_t*)arr(cap + 2, 4);
+      w.tvr.fc[li] = (int32_t*)arr(cap + 2, 4);
+      w.tvr.soff[li] = (int32_t*)arr(2, 4);
+      w.ref_lf[li] = (int32_t*)arr((size_t)cap * c + 1, 4);
+    }
+    w.tvr.nlev = nlr;
+    w.tvr.num_slices = 1;
+    w.tvr.n_total = nr;
+    w.tvr.num_tiles = (nr + kTilePoints - 1) / kTilePoints;
+    w.tvr.pt_off = w.pt_off_ref;
+    w.tile_cnt_ref = (uint32_t*)arr((size_t)w.tvr.num_tiles * nlr + 1, 4);
+    w.ref_lf_tab = (int32_t**)arr(kMaxLevels, sizeof(void*));
+    w.ref_dup_hf = (int32_t*)arr((size_t)nr * c + 1, 4);
+    if (w.encoder && !w.sub) {
+      w.irec = (int64_t*)arr((size_t)n * c, 8);
+      w.irec_us = (int64_t*)arr((size_t)n * c, 8);
+    }
   }
   if (w.sub) {
     w.worklist = (int32_t*)arr((size_t)n + 1, 4);
@@ -245,7 +301,8 @@ inter_run(
   const TreeView tv = w.tv;
   const int n = w.n;
   const bool encoder = w.encoder;
-  const int32_t* sum_attrs = encoder ? d_attrs : nullptr;
+  const bool haar = w.haar;
+  const int32_t* sum_attrs = (encoder && !haar) ? d_attrs : nullptr;
   const int tgrid = std::min(std::max((tv.num_tiles + 3) / 4, 1), 2048);
   {
     auto t = prof("tree_count", -1);
@@ -270,7 +327,7 @@ inter_run(
   hipError_t e = mark();
   if (e != hipSuccess)
     return e;
-  {
+  if (!haar) {
     auto t = prof("frame_prefix", -1);
     const int ftiles = (w.n_ref + kTilePoints - 1) / kTilePoints;
     const int fgrid = std::min(std::max((ftiles + 3) / 4, 1), 2048);
@@ -279,6 +336,47 @@ inter_run(
     hipLaunchKernelGGL(
       HIP_KERNEL_NAME(frame_prefix_kernel<C>), dim3(fgrid), dim3(256), 0, st, d_ref_attrs, w.n_ref, (const int32_t*)w.frame_tile,
       w.frame_prefix);
+  } else {
+    // integer Haar: the frame's level arrays and its low-pass values level by level (reduceUnique / reduceLevel
+    // with HaarKernel, tmc3/RAHT.cpp:108-205), likewise the current frame's for the encoder
+    auto t = prof("frame_tree", -1);
+    TreeView tvr = w.tvr;
+    tvr.pos = d_ref_pos;
+    tvr.error = tv.error;
+    w.tvr = tvr;
+    const int rgrid = std::min(std::max((tvr.num_tiles + 3) / 4, 1), 2048);
+    hipLaunchKernelGGL(
+      HIP_KERNEL_NAME(tree_count_kernel<C>), dim3(rgrid), dim3(256), 0, st, tvr, (const int32_t*)nullptr, w.tile_cnt_ref,
+      (int32_t*)nullptr);
+    hipLaunchKernelGGL(
+      HIP_KERNEL_NAME(tree_scan_kernel<C>), dim3(1), dim3(1024), 0, st, tvr, w.tile_cnt_ref, (int32_t*)nullptr, (int32_t*)nullptr, 0);
+    hipLaunchKernelGGL(
+      HIP_KERNEL_NAME(tree_emit_kernel<C>), dim3(rgrid), dim3(256), 0, st, tvr, (const int32_t*)nullptr,
+      (const uint32_t*)w.tile_cnt_ref, (const int32_t*)nullptr, (int32_t*)nullptr);
+    AscendCtx ar{};
+    ar.tv = tvr;
+    ar.attrs = d_ref_attrs;
+    ar.haar_lf = w.ref_lf_tab;
+    ar.dup_hf = w.ref_dup_hf;
+    ar.li = 0;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(ascend_leaf_kernel<C>), dim3(std::min(std::max((tvr.cap[0] + 255) / 256, 1), 4096)), dim3(256), 0, st, ar);
+    for (int li = 1; li < tvr.nlev; li++) {
+      ar.li = li;
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(ascend_level_kernel<C>), dim3(std::min(std::max((tvr.cap[li] + 255) / 256, 1), 4096)), dim3(256), 0, st, ar);
+    }
+    if (encoder) {
+      AscendCtx ac{};
+      ac.tv = tv;
+      ac.attrs = d_attrs;
+      ac.haar_lf = w.haar_lf_tab;
+      ac.dup_hf = w.dup_hf;
+      ac.li = 0;
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(ascend_leaf_kernel<C>), dim3(std::min(std::max((tv.cap[0] + 255) / 256, 1), 4096)), dim3(256), 0, st, ac);
+      for (int li = 1; li < tv.nlev; li++) {
+        ac.li = li;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(ascend_level_kernel<C>), dim3(std::min(std::max((tv.cap[li] + 255) / 256, 1), 4096)), dim3(256), 0, st, ac);
+      }
+    }
   }
   if (encoder) {
     e = hipMemsetAsync(w.rtile_state, 0, ((size_t)w.num_rtiles + 1) * 8, st);
@@ -337,6 +435,7 @@ inter_run(
   lc.params = w.params;
   lc.sched = w.sched;
   lc.attr_prefix = w.attr_prefix;
+  lc.haar_lf = (haar && encoder) ? w.haar_lf_tab : nullptr;
   for (int i = 0; i < 2; i++) {
     lc.rec[i] = w.rec[i];
     lc.rec_us[i] = w.rec_us[i];
@@ -408,7 +507,8 @@ inter_run(
     parity ^= 1;  // (the reconstruction buffer this level writes, schedule_kernel)
     const bool pred_in_level = !root && hp->raht_prediction_enabled_flag != 0;
     const int lr = tl.bits_ref - tl.bits_cur + 3 * li;
-    const bool inter_on = tl.bits_ref >= 0 && lr >= 0 && lr <= 62 && tree_depth < tl.depth_limit;
+    const bool inter_on = tl.bits_ref >= 0 && lr >= 0 && lr <= 62 && tree_depth < tl.depth_limit
+      && (!haar || lr / 3 < w.nlev_ref);
     const bool rdo_on = inter_on && tl.layer_rdo;
     const bool cur_level =
       pred_in_level && rdo_on && (encoder || (depth < tl.num_modes ? tl.modes[depth] != 0 : false));
@@ -422,6 +522,15 @@ inter_run(
     lc.inter.dual = dual;
     lc.inter.filtered = tree_depth >= tl.skip_layers;
     lc.inter.tap = w.tap_words + li;
+    if (haar && inter_on) {
+      const int lref = lr / 3;  // (the caller has checked that the two trees line up on octree levels)
+      lc.inter.hkey = w.tvr.key[lref];
+      lc.inter.hfp = w.tvr.fp[lref];
+      lc.inter.hlf = w.ref_lf[lref];
+      lc.inter.hsoff = w.tvr.soff[lref];
+    } else {
+      lc.inter.hkey = nullptr;
+    }
     // ---- the level's filter tap (:1283-1305) ---------------------------------------------
     if (est_layer && encoder) {
       auto t = prof("inter_tap", li);
@@ -499,7 +608,10 @@ inter_run(
             ef = hipStreamWaitEvent(streams.second, streams.fork, 0);
           if (ef != hipSuccess)
             return ef;
-          if (w.f64)
+          if (haar)
+            hipLaunchKernelGGL(
+              HIP_KERNEL_NAME(raht_level_sub_kernel<C, kFused, ArithI64, false>), dim3(sgrid), dim3(256), 0, streams.second, lb);
+          else if (w.f64)
             hipLaunchKernelGGL(
               HIP_KERNEL_NAME(raht_level_sub_kernel<C, kLossySub, ArithF64, false>), dim3(sgrid), dim3(256), 0, streams.second, lb);
           else
@@ -514,14 +626,19 @@ inter_run(
         {
           auto t = prof("inter_sub_lossy", li);
           GPCC_EMU_CONCURRENT(8);
-          hipLaunchKernelGGL(HIP_KERNEL_NAME(raht_level_sub_kernel<C, kLossySub, ArithI64, true>), dim3(sgrid), dim3(256), 0, st, lc);
+          if (haar)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(raht_level_sub_kernel<C, kFused, ArithI64, true>), dim3(sgrid), dim3(256), 0, st, lc);
+          else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(raht_level_sub_kernel<C, kLossySub, ArithI64, true>), dim3(sgrid), dim3(256), 0, st, lc);
           GPCC_EMU_CONCURRENT(1);
         }
         if (dual) {
           if (!forked) {
             auto t = prof("inter_sub_lossy_intra", li);
             GPCC_EMU_CONCURRENT(8);
-            if (w.f64)
+            if (haar)
+              hipLaunchKernelGGL(HIP_KERNEL_NAME(raht_level_sub_kernel<C, kFused, ArithI64, false>), dim3(sgrid), dim3(256), 0, st, lb);
+            else if (w.f64)
               hipLaunchKernelGGL(HIP_KERNEL_NAME(raht_level_sub_kernel<C, kLossySub, ArithF64, false>), dim3(sgrid), dim3(256), 0, st, lb);
             else
               hipLaunchKernelGGL(HIP_KERNEL_NAME(raht_level_sub_kernel<C, kLossySub, ArithI64, false>), dim3(sgrid), dim3(256), 0, st, lb);
@@ -584,6 +701,53 @@ inter_run(
     if (!encoder) {
       auto t = prof("inter_synth", li);
       GPCC_INTER_TILE(kSynth, true);
+    } else if (haar) {
+      // integer Haar: no RDOQ, coefficients and reconstruction in one pass (kFused); the intra candidate of a
+      // level is a second launch without the frame on a workspace of its own, as under sub-node prediction
+      rt.a = a;
+      rt.b = b;
+      rt.rows = 0;
+      rt.slice_l = w.slice_l;
+      rt.islice_l = w.islice_l;
+      {
+        auto t = prof("inter_fused", li);
+        GPCC_INTER_TILE(kFused, true);
+      }
+      if (dual) {
+        const LevelCtx la = lc;
+        lc.rec[parity] = w.irec;
+        lc.rec_us[parity] = w.irec_us;
+        lc.coeffs = w.icoeffs;
+        lc.inter.blocks = 0;
+        hipLaunchKernelGGL(rate_level_begin_kernel, dim3(1), dim3(64), 0, st, rt);
+        {
+          auto t = prof("inter_fused_intra", li);
+          GPCC_INTER_TILE(kFused, false);
+        }
+        lc = la;
+        {
+          auto t = prof("rate_states", li);
+          const int words = (b - a + 63) / 64;
+          const int pgrid = (int)std::min<int64_t>(std::max<int64_t>(((int64_t)2 * C * words + 3) / 4, 1), 4096);
+          hipLaunchKernelGGL(rate_pack_kernel, dim3(pgrid), dim3(256), 0, st, rt);
+          hipLaunchKernelGGL(rate_p1_kernel, dim3(2 * C), dim3(64), 0, st, rt);
+          const int chunks = (b - a + kAcRateChunk - 1) / kAcRateChunk;
+          const int bgrid = (int)std::min<int64_t>(std::max<int64_t>(((int64_t)2 * C * chunks + 255) / 256, 1), 4096);
+          hipLaunchKernelGGL(rate_p0_bits_kernel, dim3(bgrid), dim3(256), 0, st, rt);
+        }
+        {
+          auto t = prof("rate_sum", li);
+          hipLaunchKernelGGL(rate_sum_kernel, dim3(2), dim3(64), 0, st, rt);
+        }
+        {
+          auto t = prof("rate_decide", li);
+          hipLaunchKernelGGL(rate_decide_kernel, dim3(1), dim3(64), 0, st, rt);
+          const int64_t work = (int64_t)(b - a) * C;
+          hipLaunchKernelGGL(inter_commit_kernel, dim3((int)std::min<int64_t>(std::max<int64_t>((work + 255) / 256, 1), 4096)), dim3(256), 0, st, rt);
+          SubCopyCtx sc{tv, w.irec, w.irec_us, w.rec[parity], w.rec_us[parity], (int64_t)ts.nodes[li] * C, &w.rs->intra_wins};
+          hipLaunchKernelGGL(inter_sub_copy_kernel, dim3(sub_copy_grid(sc.count)), dim3(256), 0, st, sc);
+        }
+      }
     } else {
       rt.a = a;
       rt.b = b;
@@ -662,6 +826,8 @@ inter_run(
   fc.params = w.params;
   fc.sched = w.sched;
   fc.attr_prefix = w.attr_prefix;
+  fc.haar_lf = (haar && encoder) ? w.haar_lf_tab : nullptr;
+  fc.dup_hf = haar ? w.dup_hf : nullptr;
   for (int i = 0; i < 2; i++) {
     fc.rec[i] = w.rec[i];
     fc.dqp[i] = nullptr;

@@ -56,6 +56,13 @@ struct InterRef {
   int32_t filtered;       // the level's filter tap applies (tree depth >= skipInitLayersForFiltering)
   const int32_t* tap;     // the tap (a device word: fixed taps are written by the host, estimated ones by
                           // inter_tap_finish_kernel)
+  // integer Haar kernel: the frame's nodes cannot be sums -- its tree is reduced pass by pass with half
+  // differences (tmc3/RAHT.cpp:1065-1120 with HaarKernel) -- so the frame gets level arrays of its own
+  // (raht_tree.hpp + ascend_*_kernel) and a launch sees the level that lines up (bit level lr = 3 x level)
+  const int64_t* hkey;    // [hsoff[1]] keys of the frame's nodes at that level, ascending (null: not Haar)
+  const int32_t* hfp;     // [.. + 1] first point (weights are differences)
+  const int32_t* hlf;     // [..][C] low-pass values
+  const int32_t* hsoff;   // {0, number of nodes}
   uint32_t* idesc;        // the second candidate's RDOQ descriptors, ...
   int64_t* iptrans;       // ... transformed prediction ...
   int32_t* icoeffs;       // ... and coefficients (layouts of desc / ptrans / coeffs)

@@ -702,7 +702,10 @@ raht_level_sub_kernel(LevelCtx ctx)
       if (ctx.inter.blocks) {
         bool node;
         int64_t pin[C];
-        inter_block<C>(ctx.inter, on ? tv.key[li + 1][j] : 0, t, on, lut, &node, pin);
+        if (ctx.inter.hkey)
+          inter_block_haar<C>(ctx.inter, on ? tv.key[li + 1][j] : 0, t, on, &node, pin);
+        else
+          inter_block<C>(ctx.inter, on ? tv.key[li + 1][j] : 0, t, on, lut, &node, pin);
         use_inter = node;
 #pragma unroll
         for (int k = 0; k < C; k++) {

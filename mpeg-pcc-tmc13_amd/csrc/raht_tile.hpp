@@ -958,7 +958,10 @@ tile_process(
       if (ctx.inter.blocks) {
         bool inter_node;
         int64_t pin[C];
-        inter_block<C>(ctx.inter, on ? sm.key[j - wlo] : 0, t, on, lut, &inter_node, pin);
+        if (ctx.inter.hkey)
+          inter_block_haar<C>(ctx.inter, on ? sm.key[j - wlo] : 0, t, on, &inter_node, pin);
+        else
+          inter_block<C>(ctx.inter, on ? sm.key[j - wlo] : 0, t, on, lut, &inter_node, pin);
         if (inter_node) {
 #pragma unroll
           for (int k = 0; k < C; k++)

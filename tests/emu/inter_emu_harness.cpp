@@ -37,8 +37,6 @@ inter_emu_raht(
   int32_t layer_rdo, int32_t filter_est, int32_t skip_layers, int32_t* layer_modes, int32_t* num_modes,
   int32_t* filter_taps, int32_t* num_taps)
 {
-  if (!inter_supported(params, n))
-    return -2;
   InterWork w;
   w.n = n;
   w.c = c;
@@ -58,7 +56,11 @@ inter_emu_raht(
     tl.taps = filter_taps;
     tl.num_taps = *num_taps;
   }
+  if (!inter_supported(params, n, tl))
+    return -2;
   w.nlev = std::min((std::max(tl.bits_cur, 1) + 2) / 3 + 1, (int)kMaxLevels);
+  w.haar = params->integer_haar_enable_flag != 0;
+  w.nlev_ref = std::min((std::max(tl.bits_ref, 1) + 2) / 3 + 1, (int)kMaxLevels);
   std::vector<void*> blocks;
   inter_carve(
     [&](size_t bytes) {
@@ -79,6 +81,13 @@ inter_emu_raht(
     w.rtile_base[1] = w.num_rtiles;
   }
   memcpy(w.params, params, sizeof(*params));
+  if (w.haar) {
+    if (w.haar_lf_tab)
+      memcpy(w.haar_lf_tab, w.haar_lf, sizeof(w.haar_lf));
+    memcpy(w.ref_lf_tab, w.ref_lf, sizeof(w.ref_lf));
+    w.pt_off_ref[0] = 0;
+    w.pt_off_ref[1] = n_ref;
+  }
   SharedLut* lut = (SharedLut*)malloc(sizeof(SharedLut));
   hipLaunchKernelGGL(lut_init_kernel, dim3(1), dim3(256), 0, nullptr, lut);
   static std::vector<double> log2tab;

@@ -44,7 +44,9 @@ FULL = os.environ.get("GPCC_EMU_FULL") == "1"
 VARIANTS = [dict(subnode=False), dict(prediction=False), dict(subnode=False, qp=22), dict(subnode=False, extension=False),
             dict(subnode=False, qp=46, chroma_offset=0),
             # the reference's default flag: sub-node prediction (the dependency kernels, two workspaces for the decision)
-            dict(), dict(extension=False), dict(qp=22)]
+            dict(), dict(extension=False), dict(qp=22),
+            # the integer Haar kernel (the lossless configurations): the frame's own level arrays
+            dict(haar=True, qp=4, chroma_offset=0, subnode=False), dict(haar=True, qp=4, chroma_offset=0)]
 
 
 @pytest.mark.parametrize("vi", range(len(VARIANTS)))
@@ -52,18 +54,24 @@ VARIANTS = [dict(subnode=False), dict(prediction=False), dict(subnode=False, qp=
 def test_emulated_inter_raht(lib, vi, rdo, fest):
     from mpeg_pcc_tmc13_amd import raht_params, synth
     kw = VARIANTS[vi]
+    if kw.get("haar") and fest:
+        pytest.skip("declined: estimated taps under the integer Haar kernel")
     rng = np.random.default_rng(3)
     seen_modes, seen_taps = set(), set()
     for name, xyz, attrs in clouds():
         if name == "one":
             continue
         if not FULL:
-            if name in ("lidar", "dups") or (vi not in (0, 5) and (rdo, fest) != (1, 1)):
+            if name in ("lidar", "dups") or (vi not in (0, 5) and (rdo, fest) != ((1, 0) if kw.get("haar") else (1, 1))):
                 continue
             xyz, attrs = xyz[:900], attrs[:900]
         morton, a_sorted, _ = synth.sort_by_morton(xyz, attrs)
         for shift, jitter in ((0, 2), (0, 40), (40, 6)) if FULL else ((0, 2), (40, 6)):
             mref, aref = frame_of(xyz, attrs, rng, shift=shift, jitter=jitter)
+            if kw.get("haar") and len(mref) > 1 and (int(mref[0] ^ mref[-1]).bit_length() - int(morton[0] ^ morton[-1]).bit_length()) % 3:
+                # declined: the two trees do not line up on octree levels (raht_inter_driver.hpp, inter_supported)
+                assert run(lib, "inter_emu_raht", raht_params(**kw), True, morton, a_sorted, None, mref, aref, 15, rdo, fest, 3)[0] == -2
+                continue
             for depth, skip in ((15, 0), (2, 3), (15, 3)) if FULL else ((15, 3),):
                 m, t = check(lib, raht_params(**kw), morton, a_sorted, mref, aref, depth, rdo, fest, skip,
                              f"{name} {kw} shift{shift} jitter{jitter} depth{depth} skip{skip} rdo{rdo} fest{fest}")
