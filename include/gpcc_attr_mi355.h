@@ -181,8 +181,8 @@ int gpcc_raht_inverse(
  * Everything else as gpcc_raht_forward / _inverse (no region QP offsets).  On the device: every parameter
  * set, with sub-node prediction (the dependency kernels, the encoder's two candidates of a level as two
  * launches) and with the integer Haar kernel (the frame gets level arrays of its own) -- except, under the
- * Haar kernel, estimated filter taps and a frame whose tree height differs from the current one's by a
- * non-multiple of three bits (GPCC_ERR_UNSUPPORTED: the CPU keeps the slice).  The
+ * Haar kernel, a frame whose tree height differs from the current one's by a non-multiple of three bits
+ * (GPCC_ERR_UNSUPPORTED: the CPU keeps the slice).  The
  * per-layer decision compares two sums of doubles the reference accumulates in coding order with log2 of
  * the HOST's libm inside: the library fills its log2 table from the same libm and adds in the same order
  * (csrc/raht_inter.hpp); a coefficient magnitude beyond the table (2^20) returns GPCC_ERR_UNSUPPORTED. */

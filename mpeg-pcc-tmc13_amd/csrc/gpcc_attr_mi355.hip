@@ -1263,8 +1263,8 @@ host_transform_inter(
   if (!inter_supported(params, n, tl))
     return fail(
       GPCC_ERR_UNSUPPORTED,
-      "inter-frame RAHT on the device: not a single point, nor the integer Haar kernel with estimated filter taps or "
-      "with trees that do not line up on octree levels");
+      "inter-frame RAHT on the device: not a single point, nor the integer Haar kernel with trees that do not line up on "
+      "octree levels");
   w.nlev = std::min((std::max(tl.bits_cur, 1) + 2) / 3 + 1, (int)kMaxLevels);
   w.haar = params->integer_haar_enable_flag != 0;
   w.nlev_ref = std::min((std::max(tl.bits_ref, 1) + 2) / 3 + 1, (int)kMaxLevels);

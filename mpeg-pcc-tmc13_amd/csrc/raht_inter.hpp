@@ -649,13 +649,17 @@ inter_tap_kernel(TapCtx cx)
     if (has) {
       const int fa = tv.fp[li][child], fb = tv.fp[li][child + 1];
       w = fb - fa;
-      b = fp_from_int((int32_t)((uint32_t)ctx.attr_prefix[(size_t)fb * C] - (uint32_t)ctx.attr_prefix[(size_t)fa * C]));
+      // (under the integer Haar kernel the nodes hold low-pass values, and the estimate still runs RAHT
+      // butterflies over them: estimate_layer_filter knows no Haar kernel)
+      b = ir.hkey ? fp_from_int(ctx.haar_lf[li][(size_t)child * C])
+                  : fp_from_int((int32_t)((uint32_t)ctx.attr_prefix[(size_t)fb * C] - (uint32_t)ctx.attr_prefix[(size_t)fa * C]));
     }
     // the frame's block, first component
     int32_t wr = 0;
     int64_t rv = 0;
-    int hi = 0;
-    if (take) {
+    int hi = 0;        // what follows the node: a point index (or, integer Haar, a node index) ...
+    int hi_end = ir.n_ref;  // ... and where the level ends
+    if (take && !ir.hkey) {
       const uint64_t k0 = ((uint64_t)tv.key[li + 1][j] << 3) + (uint64_t)t;
       const int lo = inter_lower_bound(ir.pos, ir.n_ref, ir.lr, k0);
       hi = inter_lower_bound(ir.pos, ir.n_ref, ir.lr, k0 + 1);
@@ -663,11 +667,28 @@ inter_tap_kernel(TapCtx cx)
       if (wr > 0)
         rv = fp_from_int((int32_t)((uint32_t)ir.prefix[(size_t)hi * C] - (uint32_t)ir.prefix[(size_t)lo * C]));
     }
+    if (take && ir.hkey) {
+      const int64_t want = (int64_t)(((uint64_t)tv.key[li + 1][j] << 3) + (uint64_t)t);
+      int lo = 0, up = ir.hsoff[1];
+      hi_end = up;
+      while (lo < up) {
+        const int mid = lo + ((up - lo) >> 1);
+        if (ir.hkey[mid] < want)
+          lo = mid + 1;
+        else
+          up = mid;
+      }
+      if (lo < hi_end && ir.hkey[lo] == want) {
+        wr = ir.hfp[lo + 1] - ir.hfp[lo];
+        rv = fp_from_int(ir.hlf[(size_t)lo * C]);
+        hi = lo + 1;
+      }
+    }
     const uint32_t rocc = group8_bits(wr > 0);
     // (the cursor's rule: the block's first frame node is not the last node of the level)
     const int first_t = rocc ? __ffs((int)rocc) - 1 : 0;
     const int hi_first = __shfl(hi, (int)((threadIdx.x & 56) | first_t));
-    const bool match = take && rocc != 0 && hi_first < ir.n_ref;
+    const bool match = take && rocc != 0 && hi_first < hi_end;
     if (w > 1)
       b = scale_rsqrt(b, w, lut);
     if (wr > 1)

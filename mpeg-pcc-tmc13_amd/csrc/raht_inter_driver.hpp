@@ -104,15 +104,14 @@ struct InterWork {
 };
 
 // Under the integer Haar kernel the frame's nodes come from level arrays of its own: the two trees have to line
-// up on octree levels (they descend from their own tops, bit level B_ref - B + 3 level), and the estimated
-// filter taps (computed from RAHT butterflies of the Haar low-pass values) are not built.
+// up on octree levels (they descend from their own tops, bit level B_ref - B + 3 level).
 inline bool
 inter_supported(const gpcc_raht_params* p, int64_t n, const InterTools& tl)
 {
   if (n < 2)
     return false;
   if (p->integer_haar_enable_flag)
-    return !tl.filter_est && (tl.bits_ref < 0 || (tl.bits_ref - tl.bits_cur) % 3 == 0);
+    return tl.bits_ref < 0 || (tl.bits_ref - tl.bits_cur) % 3 == 0;
   return true;
 }
 

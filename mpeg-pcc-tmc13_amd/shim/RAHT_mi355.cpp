@@ -13,7 +13,7 @@
 // per-layer modes and filter taps appended to / read from the same vectors the
 // reference's function uses (RAHT.cpp:1293, 1820-1825; :1260, 1303).  When the
 // device path declines a slice (GPCC_ERR_UNSUPPORTED: inter prediction together
-// with region QP offsets, or the integer Haar kernel with estimated filter taps)
+// with region QP offsets)
 // or no GPU is present it calls the reference's CPU implementation, which
 // the integrator keeps in the link under a suffixed name (see
 // RAHT.cpp is compiled with

@@ -54,15 +54,13 @@ VARIANTS = [dict(subnode=False), dict(prediction=False), dict(subnode=False, qp=
 def test_emulated_inter_raht(lib, vi, rdo, fest):
     from mpeg_pcc_tmc13_amd import raht_params, synth
     kw = VARIANTS[vi]
-    if kw.get("haar") and fest:
-        pytest.skip("declined: estimated taps under the integer Haar kernel")
     rng = np.random.default_rng(3)
     seen_modes, seen_taps = set(), set()
     for name, xyz, attrs in clouds():
         if name == "one":
             continue
         if not FULL:
-            if name in ("lidar", "dups") or (vi not in (0, 5) and (rdo, fest) != ((1, 0) if kw.get("haar") else (1, 1))):
+            if name in ("lidar", "dups") or (vi not in (0, 5) and (rdo, fest) != (1, 1)):
                 continue
             xyz, attrs = xyz[:900], attrs[:900]
         morton, a_sorted, _ = synth.sort_by_morton(xyz, attrs)

@@ -50,8 +50,6 @@ def test_inter_raht_against_the_oracle(vi, rdo, fest):
     from mpeg_pcc_tmc13_amd import context, raht_params, synth
     ctx = context(0)
     kw = VARIANTS[vi]
-    if kw.get("haar") and fest:
-        pytest.skip("declined: estimated taps under the integer Haar kernel (test_declined_configurations)")
     rng = np.random.default_rng(3)
     seen_modes, seen_taps = set(), set()
     for name, xyz, attrs in clouds():
@@ -99,11 +97,8 @@ def test_declined_configurations():
     ctx = context(0)
     xyz, attrs = synth.dense_cloud(2000, seed=3, bits=6)
     morton, a_sorted, _ = synth.sort_by_morton(xyz, attrs)
-    # the integer Haar kernel with estimated filter taps, or with a frame whose tree does not line up on octree levels
+    # the integer Haar kernel with a frame whose tree does not line up on octree levels
     haar = raht_params(haar=True, qp=4, chroma_offset=0)
-    with pytest.raises(GpccError) as e:
-        ctx.raht_forward_inter(haar, inter_params(15, 1, 1, 0), morton, a_sorted, morton, a_sorted)
-    assert e.value.code == -2, e.value
     taller = morton.copy()
     taller[-1] |= 1 << (int(morton[0] ^ morton[-1]).bit_length() + 1)
     with pytest.raises(GpccError) as e:
@@ -145,7 +140,7 @@ def seam1_cases():
     # (parameters, layer decision, estimated taps, runs on the device)
     cases = [(dict(subnode=False), 1, 1, True), (dict(subnode=False), 1, 0, True), (dict(prediction=False), 0, 0, True),
              (dict(), 1, 0, True), (dict(haar=True, qp=4, chroma_offset=0), 1, 0, True),
-             (dict(haar=True, qp=4, chroma_offset=0, subnode=False), 1, 1, False)]
+             (dict(haar=True, qp=4, chroma_offset=0, subnode=False), 1, 1, True)]
     return morton, a_sorted, mref, aref, [(raht_params(**kw), rdo, fest, dev) for kw, rdo, fest, dev in cases]
 
 
@@ -153,8 +148,7 @@ def test_seam1_runs_inter_slices_on_the_device(tmp_path):
     """the reference's own callers' entry points (pcc::regionAdaptiveHierarchicalTransform / ...Inverse..., replaced
     by shim/RAHT_mi355.cpp) with attrInterPredParams.enableAttrInterPred: the device runs the slice, the modes and
     taps land in the reference's vectors, everything equals the unmodified library's (the reference's default flags
-    included: sub-node prediction + per-layer decision, and the integer Haar kernel); the integer Haar kernel with
-    estimated filter taps is declined and the reference's CPU function keeps the slice"""
+    included: sub-node prediction + per-layer decision, and the integer Haar kernel)"""
     if not ol.ref_available():
         pytest.skip("compiled reference absent")
     got, log = _shim_worker("function", tmp_path)
