@@ -20,15 +20,19 @@ pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not ins
 
 @pytest.fixture(scope="module")
 def kernels(tmp_path_factory):
+    """the kernels' gfx950 ISA: from a listing of the whole library made beforehand (GPCC_ISA_LISTING, tools/isa_audit.py)
+    when it is newer than the sources, else from tests/isa/sub_kernels.hip -- the same templates instantiated on their
+    own with the product's flags (seconds instead of the minutes the whole library takes)"""
     out = str(tmp_path_factory.mktemp("isa") / "gpcc.s")
-    src = os.path.join(ROOT, "mpeg-pcc-tmc13_amd", "csrc", "gpcc_attr_mi355.hip")
-    pre = os.environ.get("GPCC_ISA_LISTING")  # (a listing made beforehand: tools/isa_audit.py)
+    csrc = os.path.join(ROOT, "mpeg-pcc-tmc13_amd", "csrc")
+    src = os.path.join(ROOT, "tests", "isa", "sub_kernels.hip")
+    pre = os.environ.get("GPCC_ISA_LISTING")
     if pre and os.path.exists(pre) and os.path.getmtime(pre) >= max(
-            os.path.getmtime(os.path.join(os.path.dirname(src), f)) for f in os.listdir(os.path.dirname(src))):
+            os.path.getmtime(os.path.join(csrc, f)) for f in os.listdir(csrc)):
         out = pre
     else:
         subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-w",
-                        "-I" + os.path.join(ROOT, "include"), "-I" + os.path.dirname(src),
+                        "-I" + os.path.join(ROOT, "include"), "-I" + csrc,
                         "-S", "--cuda-device-only", "-o", out, src], check=True, timeout=900)
     bodies, cur = {}, None
     for ln in open(out):
