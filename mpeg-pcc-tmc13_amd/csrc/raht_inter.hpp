@@ -333,7 +333,9 @@ rate_p1_kernel(RateCtx cx)
 // the one the previous level left.  (The predicting encoder's rate model is resolved the same way,
 // pred_kernels.hpp.)  With the state in hand the thread writes the cost of its coefficients
 // (PCCRAHTACCoefficientEntropyEstimate::updateCostBits, RAHT.cpp:54-78: the same additions in the same order).
-constexpr int kAcRateChunk = 256;
+// (64 coefficients per thread: the chunk's table look-ups are a chain of round trips per thread, so what counts is
+// how many threads share the level -- with 256 per thread a 1 M-coefficient level kept 64 wavefronts busy: 1.4 ms)
+constexpr int kAcRateChunk = 64;
 
 __device__ __forceinline__ int
 rate_p0_step(int p, bool nz)
