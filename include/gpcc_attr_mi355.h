@@ -178,7 +178,8 @@ int gpcc_raht_inverse(
  *   filter_taps [32], num_taps    FilterTaps (quantised): written by the encoder when
  *                                 enable_filter_estimation, read by the decoder
  *                                 (the decoder accepts NULL for an array whose count is 0)
- * Everything else as gpcc_raht_forward / _inverse (no region QP offsets).  On the device: every parameter
+ * Everything else as gpcc_raht_forward / _inverse (qp_off: region QP offsets per point, NULL = none).  On the
+ * device: every parameter
  * set, with sub-node prediction (the dependency kernels, the encoder's two candidates of a level as two
  * launches) and with the integer Haar kernel (the frame gets level arrays of its own) -- except, under the
  * Haar kernel, a frame whose tree height differs from the current one's by a non-multiple of three bits
@@ -195,13 +196,13 @@ typedef struct gpcc_raht_inter_params {
 
 int gpcc_raht_forward_inter(
   gpcc_ctx* ctx, const gpcc_raht_params* params, const gpcc_raht_inter_params* inter,
-  const int64_t* morton, int32_t* attrs, int32_t* coeffs, int32_t n, int32_t c,
+  const int64_t* morton, const int32_t* qp_off, int32_t* attrs, int32_t* coeffs, int32_t n, int32_t c,
   const int64_t* morton_ref, const int32_t* attrs_ref, int32_t n_ref,
   int32_t* layer_modes, int32_t* num_modes, int32_t* filter_taps, int32_t* num_taps);
 
 int gpcc_raht_inverse_inter(
   gpcc_ctx* ctx, const gpcc_raht_params* params, const gpcc_raht_inter_params* inter,
-  const int64_t* morton, int32_t* attrs, const int32_t* coeffs, int32_t n, int32_t c,
+  const int64_t* morton, const int32_t* qp_off, int32_t* attrs, const int32_t* coeffs, int32_t n, int32_t c,
   const int64_t* morton_ref, const int32_t* attrs_ref, int32_t n_ref,
   const int32_t* layer_modes, int32_t num_modes, const int32_t* filter_taps, int32_t num_taps);
 

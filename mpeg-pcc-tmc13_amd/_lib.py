@@ -85,8 +85,8 @@ def load():
     lib.gpcc_raht_set_prediction_weights.restype = None
     for name in ("gpcc_raht_forward", "gpcc_raht_inverse"):
         getattr(lib, name).argtypes = [vp, pp, vp, vp, vp, vp, i32, i32]
-    lib.gpcc_raht_forward_inter.argtypes = [vp, pp, vp, vp, vp, vp, i32, i32, vp, vp, i32, vp, C.POINTER(i32), vp, C.POINTER(i32)]
-    lib.gpcc_raht_inverse_inter.argtypes = [vp, pp, vp, vp, vp, vp, i32, i32, vp, vp, i32, vp, i32, vp, i32]
+    lib.gpcc_raht_forward_inter.argtypes = [vp, pp, vp, vp, vp, vp, vp, i32, i32, vp, vp, i32, vp, C.POINTER(i32), vp, C.POINTER(i32)]
+    lib.gpcc_raht_inverse_inter.argtypes = [vp, pp, vp, vp, vp, vp, vp, i32, i32, vp, vp, i32, vp, i32, vp, i32]
     lib.gpcc_attr_morton_sort.argtypes = [vp, vp, i32, vp, vp]
     for name in ("gpcc_dev_raht_forward", "gpcc_dev_raht_inverse"):
         getattr(lib, name).argtypes = [vp, pp, i32, i64p, vp, vp, vp, vp, i32]

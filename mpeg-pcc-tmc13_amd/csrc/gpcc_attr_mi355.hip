@@ -1174,7 +1174,7 @@ template<int C>
 int
 launch_inter(
   gpcc_ctx* ctx, InterWork& w, const InterTools& tl, const gpcc_raht_params* hp, const int64_t* d_ref_pos,
-  const int32_t* d_ref_attrs, int32_t* d_attrs, int32_t* d_coeffs)
+  const int32_t* d_ref_attrs, int32_t* d_attrs, int32_t* d_coeffs, const int32_t* d_qp_off)
 {
   hipStream_t st = ctx->stream;
   // the encoder's second candidate under sub-node prediction runs on the context's second stream
@@ -1199,7 +1199,7 @@ launch_inter(
     st, w, tl, hp, ctx->d_lut, ctx->d_log2, d_ref_pos, d_ref_attrs, d_attrs, d_coeffs, ctx->h_stats,
     [&](const char* name, int li) { return Timer(ctx, li < 0 ? name : level_name(name, li)); },
     [&]() -> hipError_t { return hipEventRecord(ctx->ev_stats, st); },
-    [&]() -> hipError_t { return hipEventSynchronize(ctx->ev_stats); }, streams);
+    [&]() -> hipError_t { return hipEventSynchronize(ctx->ev_stats); }, streams, d_qp_off);
   if (e != hipSuccess)
     return fail(GPCC_ERR_HIP, std::string("inter-frame RAHT: ") + hipGetErrorString(e));
   if (ctx->h_error)
@@ -1210,7 +1210,7 @@ launch_inter(
 int
 host_transform_inter(
   gpcc_ctx* ctx, const gpcc_raht_params* params, const gpcc_raht_inter_params* inter, bool encoder,
-  const int64_t* morton, int32_t* attrs, int32_t* coeffs, int32_t n, int32_t c, const int64_t* morton_ref,
+  const int64_t* morton, const int32_t* qp_off, int32_t* attrs, int32_t* coeffs, int32_t n, int32_t c, const int64_t* morton_ref,
   const int32_t* attrs_ref, int32_t n_ref, int32_t* layer_modes, int32_t* num_modes, int32_t* filter_taps,
   int32_t* num_taps)
 {
@@ -1268,6 +1268,7 @@ host_transform_inter(
   w.nlev = std::min((std::max(tl.bits_cur, 1) + 2) / 3 + 1, (int)kMaxLevels);
   w.haar = params->integer_haar_enable_flag != 0;
   w.nlev_ref = std::min((std::max(tl.bits_ref, 1) + 2) / 3 + 1, (int)kMaxLevels);
+  w.has_qp = qp_off != nullptr;
   size_t need = 0;
   inter_carve(
     [&](size_t bytes) {
@@ -1278,8 +1279,9 @@ host_transform_inter(
   char* work = nullptr;
   int64_t* d_m = nullptr;
   int64_t* d_mr = nullptr;
-  int32_t *d_a = nullptr, *d_c = nullptr, *d_ar = nullptr;
+  int32_t *d_a = nullptr, *d_c = nullptr, *d_ar = nullptr, *d_q = nullptr;
   auto cleanup = [&]() {
+    pool_free(ctx, d_q);
     pool_free(ctx, work);
     pool_free(ctx, d_m);
     pool_free(ctx, d_mr);
@@ -1307,6 +1309,11 @@ host_transform_inter(
     HIP_TRY(h2d_user(ctx, d_m, morton, sizeof(int64_t) * n, st));
     HIP_TRY(h2d_user(ctx, d_mr, morton_ref, sizeof(int64_t) * n_ref, st));
     HIP_TRY(h2d_user(ctx, d_ar, attrs_ref, sizeof(int32_t) * (size_t)n_ref * c, st));
+    if (qp_off) {
+      HIP_TRY(pool_malloc(ctx, (void**)&d_q, sizeof(int32_t) * (size_t)n * 2));
+      HIP_TRY(h2d_user(ctx, d_q, qp_off, sizeof(int32_t) * (size_t)n * 2, st));
+      HIP_TRY(hipMemcpyAsync(w.asc_qp_tab, w.asc_qp, sizeof(w.asc_qp), hipMemcpyHostToDevice, st));
+    }
     if (encoder) {
       HIP_TRY(h2d_user(ctx, d_a, attrs, sizeof(int32_t) * n * c, st));
       HIP_TRY(hipMemsetAsync(d_c, 0, sizeof(int32_t) * n * c, st));
@@ -1329,9 +1336,9 @@ host_transform_inter(
     }
     int r = GPCC_ERR_INVALID_ARG;
     switch (c) {
-    case 1: r = launch_inter<1>(ctx, w, tl, params, d_mr, d_ar, d_a, d_c); break;
-    case 2: r = launch_inter<2>(ctx, w, tl, params, d_mr, d_ar, d_a, d_c); break;
-    case 3: r = launch_inter<3>(ctx, w, tl, params, d_mr, d_ar, d_a, d_c); break;
+    case 1: r = launch_inter<1>(ctx, w, tl, params, d_mr, d_ar, d_a, d_c, d_q); break;
+    case 2: r = launch_inter<2>(ctx, w, tl, params, d_mr, d_ar, d_a, d_c, d_q); break;
+    case 3: r = launch_inter<3>(ctx, w, tl, params, d_mr, d_ar, d_a, d_c, d_q); break;
     }
     if (r)
       return r;
@@ -1371,7 +1378,7 @@ host_transform_inter(
     cleanup();
     work = nullptr;
     d_m = d_mr = nullptr;
-    d_a = d_c = d_ar = nullptr;
+    d_a = d_c = d_ar = d_q = nullptr;
     w.f64 = false;
     r = run();
   }
@@ -3780,13 +3787,13 @@ gpcc_raht_inverse(
 int
 gpcc_raht_forward_inter(
   gpcc_ctx* ctx, const gpcc_raht_params* params, const gpcc_raht_inter_params* inter, const int64_t* morton,
-  int32_t* attrs, int32_t* coeffs, int32_t n, int32_t c, const int64_t* morton_ref, const int32_t* attrs_ref,
+  const int32_t* qp_off, int32_t* attrs, int32_t* coeffs, int32_t n, int32_t c, const int64_t* morton_ref, const int32_t* attrs_ref,
   int32_t n_ref, int32_t* layer_modes, int32_t* num_modes, int32_t* filter_taps, int32_t* num_taps)
 {
   return counted(
     ctx,
     host_transform_inter(
-      ctx, params, inter, true, morton, attrs, coeffs, n, c, morton_ref, attrs_ref, n_ref, layer_modes, num_modes,
+      ctx, params, inter, true, morton, qp_off, attrs, coeffs, n, c, morton_ref, attrs_ref, n_ref, layer_modes, num_modes,
       filter_taps, num_taps),
     n);
 }
@@ -3794,7 +3801,7 @@ gpcc_raht_forward_inter(
 int
 gpcc_raht_inverse_inter(
   gpcc_ctx* ctx, const gpcc_raht_params* params, const gpcc_raht_inter_params* inter, const int64_t* morton,
-  int32_t* attrs, const int32_t* coeffs, int32_t n, int32_t c, const int64_t* morton_ref, const int32_t* attrs_ref,
+  const int32_t* qp_off, int32_t* attrs, const int32_t* coeffs, int32_t n, int32_t c, const int64_t* morton_ref, const int32_t* attrs_ref,
   int32_t n_ref, const int32_t* layer_modes, int32_t num_modes, const int32_t* filter_taps, int32_t num_taps)
 {
   int32_t nm = num_modes, nt = num_taps;
@@ -3807,7 +3814,7 @@ gpcc_raht_inverse_inter(
   return counted(
     ctx,
     host_transform_inter(
-      ctx, params, inter, false, morton, attrs, const_cast<int32_t*>(coeffs), n, c, morton_ref, attrs_ref, n_ref,
+      ctx, params, inter, false, morton, qp_off, attrs, const_cast<int32_t*>(coeffs), n, c, morton_ref, attrs_ref, n_ref,
       const_cast<int32_t*>(layer_modes), &nm, const_cast<int32_t*>(filter_taps), &nt),
     n);
 }

@@ -88,6 +88,11 @@ struct InterWork {
   uint32_t *mbox = nullptr, *mbox2 = nullptr;
   unsigned long long *rdoq_state = nullptr, *rdoq_state2 = nullptr;
   int64_t *irec = nullptr, *irec_us = nullptr;
+  // region QP offsets: the node QPs averaged up the tree (per level) and handed down (tmc3/RAHT.cpp:185-189, 246-253)
+  bool has_qp = false;
+  int32_t* asc_qp[kMaxLevels] = {};
+  int32_t** asc_qp_tab = nullptr;
+  int32_t* dqp[2] = {nullptr, nullptr};
   // integer Haar kernel: low-pass values of every level of the current frame (encoder) and of the reference
   // frame, which gets level arrays of its own; the pointer tables are filled by the caller (host copies beside)
   bool haar = false;
@@ -176,6 +181,13 @@ inter_carve(Take&& take, InterWork& w)
     w.bigw = (unsigned long long*)arr((size_t)2 * c * w.wstride, 8);
     w.term = (double*)arr((size_t)2 * c * n, 8);
     w.tap_acc = (unsigned long long*)arr(2, 8);
+  }
+  if (w.has_qp) {
+    for (int li = 0; li < nlev; li++)
+      w.asc_qp[li] = (int32_t*)arr(((size_t)w.tv.cap[li] + 1) * 2, 4);
+    w.asc_qp_tab = (int32_t**)arr(kMaxLevels, sizeof(void*));
+    for (int i = 0; i < 2; i++)
+      w.dqp[i] = (int32_t*)arr((size_t)n * 2, 4);
   }
   if (w.haar) {
     if (w.encoder) {
@@ -295,7 +307,8 @@ hipError_t
 inter_run(
   hipStream_t st, InterWork& w, const InterTools& tl, const gpcc_raht_params* hp, const SharedLut* d_lut,
   const double* d_log2tab, const int64_t* d_ref_pos, const int32_t* d_ref_attrs, int32_t* d_attrs, int32_t* d_coeffs,
-  TreeStats* stats, Prof&& prof, Mark&& mark, Wait&& wait, const InterStreams& streams = InterStreams())
+  TreeStats* stats, Prof&& prof, Mark&& mark, Wait&& wait, const InterStreams& streams = InterStreams(),
+  const int32_t* d_qp_off = nullptr)
 {
   const TreeView tv = w.tv;
   const int n = w.n;
@@ -363,19 +376,26 @@ inter_run(
       ar.li = li;
       hipLaunchKernelGGL(HIP_KERNEL_NAME(ascend_level_kernel<C>), dim3(std::min(std::max((tvr.cap[li] + 255) / 256, 1), 4096)), dim3(256), 0, st, ar);
     }
-    if (encoder) {
-      AscendCtx ac{};
-      ac.tv = tv;
-      ac.attrs = d_attrs;
-      ac.haar_lf = w.haar_lf_tab;
-      ac.dup_hf = w.dup_hf;
-      ac.li = 0;
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(ascend_leaf_kernel<C>), dim3(std::min(std::max((tv.cap[0] + 255) / 256, 1), 4096)), dim3(256), 0, st, ac);
-      for (int li = 1; li < tv.nlev; li++) {
-        ac.li = li;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(ascend_level_kernel<C>), dim3(std::min(std::max((tv.cap[li] + 255) / 256, 1), 4096)), dim3(256), 0, st, ac);
-      }
+  }
+  // the current frame's ascent where it is not associative: Haar low-pass values (encoder), region QPs
+  if ((haar && encoder) || w.has_qp) {
+    auto t = prof("ascend", -1);
+    AscendCtx ac{};
+    ac.tv = tv;
+    ac.attrs = (haar && encoder) ? d_attrs : nullptr;
+    ac.qp_off = d_qp_off;
+    ac.haar_lf = (haar && encoder) ? w.haar_lf_tab : nullptr;
+    ac.asc_qp = w.has_qp ? w.asc_qp_tab : nullptr;
+    ac.dup_hf = w.dup_hf;
+    ac.dqp_root = w.dqp[1];
+    ac.li = 0;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(ascend_leaf_kernel<C>), dim3(std::min(std::max((tv.cap[0] + 255) / 256, 1), 4096)), dim3(256), 0, st, ac);
+    for (int li = 1; li < tv.nlev; li++) {
+      ac.li = li;
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(ascend_level_kernel<C>), dim3(std::min(std::max((tv.cap[li] + 255) / 256, 1), 4096)), dim3(256), 0, st, ac);
     }
+    if (w.has_qp)
+      hipLaunchKernelGGL(qp_root_kernel, dim3(1), dim3(64), 0, st, ac, (const SliceSched*)w.sched);
   }
   if (encoder) {
     e = hipMemsetAsync(w.rtile_state, 0, ((size_t)w.num_rtiles + 1) * 8, st);
@@ -435,11 +455,12 @@ inter_run(
   lc.sched = w.sched;
   lc.attr_prefix = w.attr_prefix;
   lc.haar_lf = (haar && encoder) ? w.haar_lf_tab : nullptr;
+  lc.asc_qp = w.has_qp ? w.asc_qp_tab : nullptr;
   for (int i = 0; i < 2; i++) {
     lc.rec[i] = w.rec[i];
     lc.rec_us[i] = w.rec_us[i];
     lc.nneigh[i] = w.nneigh[i];
-    lc.dqp[i] = nullptr;
+    lc.dqp[i] = w.dqp[i];
   }
   lc.coeffs = d_coeffs;
   lc.desc = w.desc;
@@ -827,9 +848,11 @@ inter_run(
   fc.attr_prefix = w.attr_prefix;
   fc.haar_lf = (haar && encoder) ? w.haar_lf_tab : nullptr;
   fc.dup_hf = haar ? w.dup_hf : nullptr;
+  fc.asc_qp = w.has_qp ? w.asc_qp_tab : nullptr;
+  fc.qp_off = d_qp_off;
   for (int i = 0; i < 2; i++) {
     fc.rec[i] = w.rec[i];
-    fc.dqp[i] = nullptr;
+    fc.dqp[i] = w.dqp[i];
   }
   fc.attrs = d_attrs;
   fc.coeffs = d_coeffs;

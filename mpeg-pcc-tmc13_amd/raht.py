@@ -102,7 +102,7 @@ class Context:
             rec.ctypes.data, co.ctypes.data, n, c))
         return rec
 
-    def raht_forward_inter(self, params: RahtParams, inter, morton, attrs, morton_ref, attrs_ref):
+    def raht_forward_inter(self, params: RahtParams, inter, morton, attrs, morton_ref, attrs_ref, qp_off=None):
         """RAHT with attribute inter prediction (gpcc_raht_forward_inter)
         -> (coeffs int32 [c*n] planar, recon int32 [n, c], layer modes, filter taps)"""
         morton = np.ascontiguousarray(morton, dtype=np.int64)
@@ -113,12 +113,14 @@ class Context:
         coeffs = np.zeros(c * n, dtype=np.int32)
         modes, taps = np.zeros(32, np.int32), np.zeros(32, np.int32)
         nm, nt = C.c_int32(0), C.c_int32(0)
+        q = None if qp_off is None else np.ascontiguousarray(qp_off, dtype=np.int32)
         _lib.check(self._lib.gpcc_raht_forward_inter(
-            self._h, C.byref(params), C.addressof(inter), morton.ctypes.data, rec.ctypes.data, coeffs.ctypes.data, n, c,
+            self._h, C.byref(params), C.addressof(inter), morton.ctypes.data, q.ctypes.data if q is not None else None,
+            rec.ctypes.data, coeffs.ctypes.data, n, c,
             mref.ctypes.data, aref.ctypes.data, len(mref), modes.ctypes.data, C.byref(nm), taps.ctypes.data, C.byref(nt)))
         return coeffs, rec, modes[:nm.value].copy(), taps[:nt.value].copy()
 
-    def raht_inverse_inter(self, params: RahtParams, inter, morton, coeffs, c, morton_ref, attrs_ref, modes, taps):
+    def raht_inverse_inter(self, params: RahtParams, inter, morton, coeffs, c, morton_ref, attrs_ref, modes, taps, qp_off=None):
         """-> recon int32 [n, c] (gpcc_raht_inverse_inter)"""
         morton = np.ascontiguousarray(morton, dtype=np.int64)
         n = morton.shape[0]
@@ -130,8 +132,10 @@ class Context:
         m[:len(modes)] = modes
         t[:len(taps)] = taps
         rec = np.zeros((n, c), dtype=np.int32)
+        q = None if qp_off is None else np.ascontiguousarray(qp_off, dtype=np.int32)
         _lib.check(self._lib.gpcc_raht_inverse_inter(
-            self._h, C.byref(params), C.addressof(inter), morton.ctypes.data, rec.ctypes.data, co.ctypes.data, n, c,
+            self._h, C.byref(params), C.addressof(inter), morton.ctypes.data, q.ctypes.data if q is not None else None,
+            rec.ctypes.data, co.ctypes.data, n, c,
             mref.ctypes.data, aref.ctypes.data, len(mref), m.ctypes.data, len(modes), t.ctypes.data, len(taps)))
         return rec
 

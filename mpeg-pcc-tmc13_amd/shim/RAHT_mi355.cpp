@@ -12,8 +12,8 @@
 // gpcc_raht_inverse_inter with the reference frame of paramsForInterRAHT, the
 // per-layer modes and filter taps appended to / read from the same vectors the
 // reference's function uses (RAHT.cpp:1293, 1820-1825; :1260, 1303).  When the
-// device path declines a slice (GPCC_ERR_UNSUPPORTED: inter prediction together
-// with region QP offsets)
+// device path declines a slice (GPCC_ERR_UNSUPPORTED: inter prediction under the
+// integer Haar kernel when the two trees do not line up on octree levels)
 // or no GPU is present it calls the reference's CPU implementation, which
 // the integrator keeps in the link under a suffixed name (see
 // RAHT.cpp is compiled with
@@ -177,10 +177,11 @@ regionAdaptiveHierarchicalTransform(
       auto& ir = attrInterPredParams.paramsForInterRAHT;
       const gpcc_raht_inter_params ip = inter_tools(attrInterPredParams);
       int32_t modes[32], taps[32], num_modes = 0, num_taps = 0;
-      rc = qp_offsets_or_null(pointQpOffsets, voxelCount) || ir.voxelCount <= 0
+      rc = ir.voxelCount <= 0
         ? GPCC_ERR_UNSUPPORTED
         : gpcc_raht_forward_inter(
-            ctx, &p, &ip, mortonCode, attributes, coefficients, voxelCount, attribCount, ir.mortonCode.data(),
+            ctx, &p, &ip, mortonCode, qp_offsets_or_null(pointQpOffsets, voxelCount), attributes, coefficients, voxelCount,
+            attribCount, ir.mortonCode.data(),
             reinterpret_cast<const int32_t*>(ir.attributes.data()), ir.voxelCount, modes, &num_modes, taps, &num_taps);
       if (rc == GPCC_OK) {
         for (int i = 0; i < num_modes; i++)
@@ -223,11 +224,11 @@ regionAdaptiveHierarchicalInverseTransform(
       const auto& ir = attrInterPredParams.paramsForInterRAHT;
       const gpcc_raht_inter_params ip = inter_tools(attrInterPredParams);
       const auto& modes = attrInterPredParams.attr_layer_code_mode;
-      rc = qp_offsets_or_null(pointQpOffsets, voxelCount) || ir.voxelCount <= 0 || modes.size() > 32
-          || ir.FilterTaps.size() > 32
+      rc = ir.voxelCount <= 0 || modes.size() > 32 || ir.FilterTaps.size() > 32
         ? GPCC_ERR_UNSUPPORTED
         : gpcc_raht_inverse_inter(
-            ctx, &p, &ip, mortonCode, attributes, coefficients, voxelCount, attribCount, ir.mortonCode.data(),
+            ctx, &p, &ip, mortonCode, qp_offsets_or_null(pointQpOffsets, voxelCount), attributes, coefficients, voxelCount,
+            attribCount, ir.mortonCode.data(),
             reinterpret_cast<const int32_t*>(ir.attributes.data()), ir.voxelCount,
             reinterpret_cast<const int32_t*>(modes.data()), int32_t(modes.size()),
             reinterpret_cast<const int32_t*>(ir.FilterTaps.data()), int32_t(ir.FilterTaps.size()));

@@ -1415,6 +1415,21 @@ oracle_raht_inter(
   return raht_process(fwd != 0, p, morton, NULL, attrs, coeffs, n, c, &ir);
 }
 
+/* ... with region QP offsets per point (QpSet::regionQpOffset), qp_off [n][2] */
+int
+oracle_raht_inter_qp(
+  const gpcc_raht_params* p, int32_t fwd, const int64_t* morton, int32_t* attrs, int32_t* coeffs,
+  int32_t n, int32_t c, const int64_t* morton_ref, const int32_t* attrs_ref, int32_t n_ref,
+  int32_t depth_minus1, int32_t layer_rdo, int32_t filter_est, int32_t skip_layers,
+  int32_t* layer_modes, int32_t* num_modes, int32_t* filter_taps, int32_t* num_taps, const int32_t* qp_off)
+{
+  if (!p || !morton || !attrs || !coeffs || n <= 0 || c < 1 || c > 3 || !morton_ref || !attrs_ref || n_ref <= 0)
+    return -1;
+  raht_inter_t ir = {morton_ref, attrs_ref, n_ref, depth_minus1 + 1, layer_rdo, filter_est, skip_layers,
+                     layer_modes, num_modes, filter_taps, num_taps};
+  return raht_process(fwd != 0, p, morton, qp_off, attrs, coeffs, n, c, &ir);
+}
+
 /* primitives exported for the pinning tests */
 int64_t oracle_morton_addr(int32_t x, int32_t y, int32_t z) { return morton_addr(x, y, z); }
 uint64_t oracle_morton3d_add(uint64_t a, uint64_t b) { return morton3d_add(a, b); }

@@ -138,11 +138,11 @@ ref_raht_inverse(
 // (skipInitLayersForFiltering).  layer_modes [<= 32] / filter_taps [<= 32]: written by the
 // encoder (counts in *num_modes / *num_taps), read by the decoder.
 int
-ref_raht_inter(
+ref_raht_inter_qp(
   const gpcc_raht_params* p, int32_t fwd, const int64_t* morton, int32_t* attrs, int32_t* coeffs,
   int32_t n, int32_t c, const int64_t* morton_ref, const int32_t* attrs_ref, int32_t n_ref,
   int32_t depth_minus1, int32_t layer_rdo, int32_t filter_est, int32_t skip_layers,
-  int32_t* layer_modes, int32_t* num_modes, int32_t* filter_taps, int32_t* num_taps)
+  int32_t* layer_modes, int32_t* num_modes, int32_t* filter_taps, int32_t* num_taps, const int32_t* qp_off)
 {
   if (!p || !morton || !attrs || !coeffs || n <= 0 || c < 1 || c > 3 || n_ref <= 0)
     return -1;
@@ -150,6 +150,9 @@ ref_raht_inter(
   pcc::QpSet qs;
   unflatten(*p, &rp, &qs);
   std::vector<pcc::Qps> qps(n, pcc::Qps{0, 0});
+  if (qp_off)  // (region QP offsets per point, QpSet::regionQpOffset)
+    for (int i = 0; i < n; i++)
+      qps[i] = pcc::Qps{qp_off[2 * i], qp_off[2 * i + 1]};
   std::vector<int64_t> mc(morton, morton + n);
   pcc::AttributeInterPredParams inter;
   inter.enableAttrInterPred = true;
@@ -183,6 +186,18 @@ ref_raht_inter(
       filter_taps[i] = ir.FilterTaps[i];
   }
   return 0;
+}
+
+int
+ref_raht_inter(
+  const gpcc_raht_params* p, int32_t fwd, const int64_t* morton, int32_t* attrs, int32_t* coeffs,
+  int32_t n, int32_t c, const int64_t* morton_ref, const int32_t* attrs_ref, int32_t n_ref,
+  int32_t depth_minus1, int32_t layer_rdo, int32_t filter_est, int32_t skip_layers,
+  int32_t* layer_modes, int32_t* num_modes, int32_t* filter_taps, int32_t* num_taps)
+{
+  return ref_raht_inter_qp(
+    p, fwd, morton, attrs, coeffs, n, c, morton_ref, attrs_ref, n_ref, depth_minus1, layer_rdo, filter_est, skip_layers,
+    layer_modes, num_modes, filter_taps, num_taps, nullptr);
 }
 
 // The Morton prologue of encodeColorsTransformRaht

@@ -30,12 +30,12 @@ bitlen(uint64_t v)
 }
 }  // namespace
 
-extern "C" int
-inter_emu_raht(
+static int
+inter_emu_core(
   const gpcc_raht_params* params, int32_t fwd, const int64_t* morton, int32_t* attrs, int32_t* coeffs, int32_t n,
   int32_t c, const int64_t* morton_ref, const int32_t* attrs_ref, int32_t n_ref, int32_t depth_minus1,
   int32_t layer_rdo, int32_t filter_est, int32_t skip_layers, int32_t* layer_modes, int32_t* num_modes,
-  int32_t* filter_taps, int32_t* num_taps)
+  int32_t* filter_taps, int32_t* num_taps, const int32_t* qp_off)
 {
   InterWork w;
   w.n = n;
@@ -60,6 +60,7 @@ inter_emu_raht(
     return -2;
   w.nlev = std::min((std::max(tl.bits_cur, 1) + 2) / 3 + 1, (int)kMaxLevels);
   w.haar = params->integer_haar_enable_flag != 0;
+  w.has_qp = qp_off != nullptr;
   w.nlev_ref = std::min((std::max(tl.bits_ref, 1) + 2) / 3 + 1, (int)kMaxLevels);
   std::vector<void*> blocks;
   inter_carve(
@@ -81,6 +82,8 @@ inter_emu_raht(
     w.rtile_base[1] = w.num_rtiles;
   }
   memcpy(w.params, params, sizeof(*params));
+  if (w.has_qp)
+    memcpy(w.asc_qp_tab, w.asc_qp, sizeof(w.asc_qp));
   if (w.haar) {
     if (w.haar_lf_tab)
       memcpy(w.haar_lf_tab, w.haar_lf, sizeof(w.haar_lf));
@@ -103,9 +106,9 @@ inter_emu_raht(
   hipError_t e;
   auto fetch = [&]() { return hipSuccess; };
   switch (c) {
-  case 1: e = inter_run<1>(nullptr, w, tl, params, lut, log2tab.data(), morton_ref, attrs_ref, attrs, coeffs, &stats, NoProf(), fetch, fetch); break;
-  case 2: e = inter_run<2>(nullptr, w, tl, params, lut, log2tab.data(), morton_ref, attrs_ref, attrs, coeffs, &stats, NoProf(), fetch, fetch); break;
-  default: e = inter_run<3>(nullptr, w, tl, params, lut, log2tab.data(), morton_ref, attrs_ref, attrs, coeffs, &stats, NoProf(), fetch, fetch); break;
+  case 1: e = inter_run<1>(nullptr, w, tl, params, lut, log2tab.data(), morton_ref, attrs_ref, attrs, coeffs, &stats, NoProf(), fetch, fetch, InterStreams(), qp_off); break;
+  case 2: e = inter_run<2>(nullptr, w, tl, params, lut, log2tab.data(), morton_ref, attrs_ref, attrs, coeffs, &stats, NoProf(), fetch, fetch, InterStreams(), qp_off); break;
+  default: e = inter_run<3>(nullptr, w, tl, params, lut, log2tab.data(), morton_ref, attrs_ref, attrs, coeffs, &stats, NoProf(), fetch, fetch, InterStreams(), qp_off); break;
   }
   if (fwd) {
     *num_modes = w.rs->num_modes;
@@ -119,4 +122,29 @@ inter_emu_raht(
   if (e != hipSuccess)
     return -5;
   return error ? -100 - error : 0;
+}
+
+extern "C" int
+inter_emu_raht(
+  const gpcc_raht_params* params, int32_t fwd, const int64_t* morton, int32_t* attrs, int32_t* coeffs, int32_t n,
+  int32_t c, const int64_t* morton_ref, const int32_t* attrs_ref, int32_t n_ref, int32_t depth_minus1,
+  int32_t layer_rdo, int32_t filter_est, int32_t skip_layers, int32_t* layer_modes, int32_t* num_modes,
+  int32_t* filter_taps, int32_t* num_taps)
+{
+  return inter_emu_core(
+    params, fwd, morton, attrs, coeffs, n, c, morton_ref, attrs_ref, n_ref, depth_minus1, layer_rdo, filter_est, skip_layers,
+    layer_modes, num_modes, filter_taps, num_taps, nullptr);
+}
+
+// ... with region QP offsets per point, [n][2] (arguments as oracle_raht_inter_qp)
+extern "C" int
+inter_emu_raht_qp(
+  const gpcc_raht_params* params, int32_t fwd, const int64_t* morton, int32_t* attrs, int32_t* coeffs, int32_t n,
+  int32_t c, const int64_t* morton_ref, const int32_t* attrs_ref, int32_t n_ref, int32_t depth_minus1,
+  int32_t layer_rdo, int32_t filter_est, int32_t skip_layers, int32_t* layer_modes, int32_t* num_modes,
+  int32_t* filter_taps, int32_t* num_taps, const int32_t* qp_off)
+{
+  return inter_emu_core(
+    params, fwd, morton, attrs, coeffs, n, c, morton_ref, attrs_ref, n_ref, depth_minus1, layer_rdo, filter_est, skip_layers,
+    layer_modes, num_modes, filter_taps, num_taps, qp_off);
 }

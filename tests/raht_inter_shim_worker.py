@@ -42,9 +42,14 @@ def main():
                         f"calls{i}": counters(lib) - c0})
     else:
         xyz, attrs, xr, ar = t.operator_case()
-        for i, (kw, rdo, fest) in enumerate(t.OPERATOR_CASES):
+        import lod_helpers as lh
+        for i, (kw, rdo, fest, region) in enumerate(t.OPERATOR_CASES):
             c0 = counters(lib)
-            pay, enc, dec, modes, taps = _operator_roundtrip(raht_params(**kw), 34, xyz, attrs, xr, ar, 15, rdo, fest, 3, lib=lib)
+            lh.ref_set_qp_region(region, lib=lib)
+            try:
+                pay, enc, dec, modes, taps = _operator_roundtrip(raht_params(**kw), 34, xyz, attrs, xr, ar, 15, rdo, fest, 3, lib=lib)
+            finally:
+                lh.ref_set_qp_region(None, lib=lib)
             res.update({f"payload{i}": np.frombuffer(pay, np.uint8), f"enc{i}": enc, f"dec{i}": dec, f"modes{i}": modes,
                         f"taps{i}": taps, f"calls{i}": counters(lib) - c0})
     np.savez(out, **res)

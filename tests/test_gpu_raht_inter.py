@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import oracle_loader as ol
-from test_oracle_raht_inter import clouds, frame_of, run
+from test_oracle_raht_inter import clouds, frame_of, region_offsets, run, run_qp
 
 pytestmark = pytest.mark.gpu
 
@@ -70,6 +70,42 @@ def test_inter_raht_against_the_oracle(vi, rdo, fest):
         assert seen_modes == {0, 1}, seen_modes
     if fest:
         assert len(seen_taps) > 1, seen_taps
+
+
+@pytest.mark.parametrize("kw", [dict(subnode=False), dict(), dict(haar=True, qp=4, chroma_offset=0), dict(subnode=False, extension=False),
+                                dict(qp=22)])
+def test_inter_raht_with_region_qp_offsets(kw):
+    """per-point QP offsets of a region (QpSet::regionQpOffset) together with inter prediction, against the oracle and
+    the compiled reference: every kernel family (tile, dependency, integer Haar)"""
+    from mpeg_pcc_tmc13_amd import context, raht_params, synth
+    ctx = context(0)
+    rng = np.random.default_rng(8)
+    for name, xyz, attrs in clouds():
+        if name in ("one", "tiny"):
+            continue
+        morton, a_sorted, order = synth.sort_by_morton(xyz, attrs)
+        q = region_offsets(xyz[order], rng)
+        mref, aref = frame_of(xyz, attrs, rng, jitter=4)
+        if kw.get("haar") and (int(mref[0] ^ mref[-1]).bit_length() - int(morton[0] ^ morton[-1]).bit_length()) % 3:
+            continue
+        for rdo, fest in ((1, 1), (1, 0), (0, 0)):
+            p = raht_params(**kw)
+            ip = inter_params(15, rdo, fest, 3)
+            rc, co_o, rec_o, modes_o, taps_o = run_qp(ol.oracle().lib, "oracle_raht_inter_qp", p, True, morton, a_sorted, None, mref, aref, 15, rdo, fest, 3, q)
+            assert rc == 0
+            co, rec, modes, taps = ctx.raht_forward_inter(p, ip, morton, a_sorted, mref, aref, qp_off=q)
+            np.testing.assert_array_equal(taps, taps_o)
+            np.testing.assert_array_equal(modes, modes_o)
+            np.testing.assert_array_equal(co, co_o)
+            np.testing.assert_array_equal(rec, rec_o)
+            dec = ctx.raht_inverse_inter(p, ip, morton, co_o, a_sorted.shape[1], mref, aref, modes_o, taps_o, qp_off=q)
+            np.testing.assert_array_equal(dec, rec_o)
+            if ol.ref_available():
+                rc, co_r, _, modes_r, taps_r = run_qp(ol.ref().lib, "ref_raht_inter_qp", p, True, morton, a_sorted, None, mref, aref, 15, rdo, fest, 3, q)
+                assert rc == 0
+                np.testing.assert_array_equal(co, co_r)
+                np.testing.assert_array_equal(modes, modes_r)
+                np.testing.assert_array_equal(taps, taps_r)
 
 
 @pytest.mark.parametrize("kind,n,c", [("dense", 200000, 3), ("lidar", 300000, 1)])
@@ -164,8 +200,11 @@ def test_seam1_runs_inter_slices_on_the_device(tmp_path):
         assert tuple(got[f"calls{i}"]) == ((2, 0) if dev else (0, 2)), (i, got[f"calls{i}"], log)
 
 
-# (parameters, per-layer decision, estimated taps); the second one is the reference's default configuration
-OPERATOR_CASES = [(dict(subnode=False), 1, 1), (dict(), 1, 0), (dict(subnode=False), 0, 0)]
+# (parameters, per-layer decision, estimated taps, QP region); the second one is the reference's default configuration,
+# the last carries a QP region in the attribute brick header (origin, size, (luma, chroma) offsets)
+OPERATOR_REGION = ((110000, 105000, 129000), (30000, 30000, 3000), (5, 0))  # (inside the lidar cloud of operator_case)
+OPERATOR_CASES = [(dict(subnode=False), 1, 1, None), (dict(), 1, 0, None), (dict(subnode=False), 0, 0, None),
+                  (dict(), 1, 0, OPERATOR_REGION)]
 
 
 def operator_case():
@@ -191,8 +230,18 @@ def test_operator_with_inter_raht_on_the_device(tmp_path):
         pytest.skip("compiled reference absent")
     got, log = _shim_worker("operator", tmp_path)
     xyz, attrs, xr, ar = operator_case()
-    for i, (kw, rdo, fest) in enumerate(OPERATOR_CASES):
-        want = _operator_roundtrip(raht_params(**kw), 34, xyz, attrs, xr, ar, 15, rdo, fest, 3)
+    import lod_helpers as lh
+    plain = None
+    for i, (kw, rdo, fest, region) in enumerate(OPERATOR_CASES):
+        lh.ref_set_qp_region(region)
+        try:
+            want = _operator_roundtrip(raht_params(**kw), 34, xyz, attrs, xr, ar, 15, rdo, fest, 3)
+        finally:
+            lh.ref_set_qp_region(None)
+        if region is None and (kw, rdo, fest) == (dict(), 1, 0):
+            plain = want[0]
+        if region is not None:
+            assert want[0] != plain, "the region changes nothing: not a test of it"
         assert got[f"payload{i}"].tobytes() == want[0], "payload"
         for j, name in enumerate(("enc", "dec", "modes", "taps")):
             np.testing.assert_array_equal(got[f"{name}{i}"], want[1 + j])

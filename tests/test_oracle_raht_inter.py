@@ -39,6 +39,40 @@ def run(lib, name, p, fwd, morton, attrs, coeffs, mref, aref, depth, rdo, fest, 
     return rc, co, a, m[:nm.value].copy(), t[:nt.value].copy()
 
 
+def run_qp(lib, name, p, fwd, morton, attrs, coeffs, mref, aref, depth, rdo, fest, skip, qp_off, modes=(), taps=()):
+    """run() for the entries that take region QP offsets per point (name + "_qp": one more argument, [n][2] or None)"""
+    f = getattr(lib, name)
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_int32, i64p, i32p, i32p, C.c_int32, C.c_int32, i64p, i32p, C.c_int32, C.c_int32,
+                  C.c_int32, C.c_int32, C.c_int32, i32p, C.POINTER(C.c_int32), i32p, C.POINTER(C.c_int32), C.c_void_p]
+    n, c = attrs.shape
+    a = np.ascontiguousarray(attrs, dtype=np.int32).copy() if fwd else np.zeros((n, c), np.int32)
+    co = np.zeros(n * c, np.int32) if fwd else np.ascontiguousarray(coeffs, dtype=np.int32).copy()
+    m = np.zeros(32, np.int32)
+    t = np.zeros(32, np.int32)
+    nm, nt = C.c_int32(0), C.c_int32(0)
+    if not fwd:
+        m[:len(modes)] = modes
+        nm.value = len(modes)
+        t[:len(taps)] = taps
+        nt.value = len(taps)
+    q = None if qp_off is None else np.ascontiguousarray(qp_off, dtype=np.int32)
+    rc = f(C.addressof(p), int(fwd), np.ascontiguousarray(morton, dtype=np.int64), a.reshape(-1), co, n, c,
+           np.ascontiguousarray(mref, dtype=np.int64), np.ascontiguousarray(aref, dtype=np.int32).reshape(-1), len(mref),
+           depth, rdo, fest, skip, m, C.byref(nm), t, C.byref(nt), None if q is None else q.ctypes.data)
+    return rc, co, a, m[:nm.value].copy(), t[:nt.value].copy()
+
+
+def region_offsets(xyz_sorted, rng):
+    """per-point QP offsets of a box-shaped region (QpSet::regionQpOffset): [n][2]"""
+    lo = xyz_sorted.min(0) + (xyz_sorted.max(0) - xyz_sorted.min(0)) // 4
+    hi = xyz_sorted.max(0) - (xyz_sorted.max(0) - xyz_sorted.min(0)) // 3
+    inside = np.all((xyz_sorted >= lo) & (xyz_sorted <= hi), axis=1)
+    q = np.zeros((len(xyz_sorted), 2), np.int32)
+    q[inside] = (int(rng.choice([-6, -3, 4, 7])), int(rng.choice([-4, 3])))
+    return q
+
+
 def frame_of(xyz, attrs, rng, amp=1, drop=0.1, jitter=6, shift=0):
     """a 'previous frame' in Morton order: positions jittered, a share of the points gone, attributes noisy"""
     from mpeg_pcc_tmc13_amd import synth
@@ -228,3 +262,34 @@ def test_inter_raht_oracle_gives_the_reference_operator_bitstream(rdo, fest):
             point_order = np.zeros(len(xyz), np.int32)
             point_order[order] = np.clip(rec[:, 0], 0, 255)
             np.testing.assert_array_equal(point_order, rec_enc)
+
+
+@pytest.mark.parametrize("kw", [dict(subnode=False), dict(), dict(haar=True, qp=4, chroma_offset=0)])
+def test_inter_raht_with_region_qp_offsets(kw):
+    """a QP region (per-point offsets, QpSet::regionQpOffset) together with attribute inter prediction: the node QPs
+    are averaged up the tree and handed down (RAHT.cpp:185-189, 246-253) while blocks are predicted from the frame"""
+    from mpeg_pcc_tmc13_amd import raht_params, synth
+    rng = np.random.default_rng(8)
+    o, r = ol.oracle().lib, ol.ref().lib
+    for name, xyz, attrs in clouds():
+        if name == "one":
+            continue
+        morton, a_sorted, order = synth.sort_by_morton(xyz, attrs)
+        q = region_offsets(xyz[order], rng)
+        mref, aref = frame_of(xyz, attrs, rng, jitter=4)
+        for rdo, fest in ((1, 0), (1, 1), (0, 0)):
+            p = raht_params(**kw)
+            rc, co_r, rec_r, modes_r, taps_r = run_qp(r, "ref_raht_inter_qp", p, True, morton, a_sorted, None, mref, aref, 15, rdo, fest, 3, q)
+            assert rc == 0
+            rc, co_o, rec_o, modes_o, taps_o = run_qp(o, "oracle_raht_inter_qp", p, True, morton, a_sorted, None, mref, aref, 15, rdo, fest, 3, q)
+            assert rc == 0
+            np.testing.assert_array_equal(modes_o, modes_r)
+            np.testing.assert_array_equal(taps_o, taps_r)
+            np.testing.assert_array_equal(co_o, co_r)
+            np.testing.assert_array_equal(rec_o, rec_r)
+            rc, _, dec_o, _, _ = run_qp(o, "oracle_raht_inter_qp", p, False, morton, a_sorted, co_r, mref, aref, 15, rdo, fest, 3, q, modes_r, taps_r)
+            assert rc == 0
+            np.testing.assert_array_equal(dec_o, rec_r)
+            # (the offsets matter)
+            if name == "dense":
+                assert not np.array_equal(co_r, run(r, "ref_raht_inter", p, True, morton, a_sorted, None, mref, aref, 15, rdo, fest, 3)[1])
