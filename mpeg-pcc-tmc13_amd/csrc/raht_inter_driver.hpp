@@ -19,8 +19,6 @@
 //   finish                                 duplicates, write-back
 #pragma once
 #include <algorithm>
-#include <cstdio>
-#include <cstdlib>
 
 #include "raht_edges.hpp"
 #include "raht_inter.hpp"
@@ -778,11 +776,6 @@ inter_run(
         auto t = prof("inter_analyze", li);
         GPCC_INTER_TILE(kAnalyze, true);
       }
-#ifdef GPCC_EMU
-      if (getenv("GPCC_INTER_DBG") && li == atoi(getenv("GPCC_INTER_DBG")))
-        for (int i = a; i < b && i < a + 40; i++)
-          fprintf(stderr, "  before coef %d desc %08x value %d\n", i, w.desc[i], d_coeffs[i]);
-#endif
       rc.li = li;
       {
         auto t = prof("rdoq_resolve", li);
@@ -822,14 +815,6 @@ inter_run(
           hipLaunchKernelGGL(inter_commit_kernel, dim3(cgrid), dim3(256), 0, st, rt);
         }
       }
-#ifdef GPCC_EMU
-      if (getenv("GPCC_INTER_DBG")) {
-        fprintf(stderr, "li %d coef [%d, %d) slice_l %d dual %d blocks %d\n", li, a, b, w.slice_l[0], (int)dual, (int)inter_blocks);
-        if (li == atoi(getenv("GPCC_INTER_DBG")))
-          for (int i = a; i < b && i < a + 40; i++)
-            fprintf(stderr, "  coef %d desc %08x value %d\n", i, w.desc[i], d_coeffs[i]);
-      }
-#endif
       {
         auto t = prof("inter_synth_rec", li);
         GPCC_INTER_TILE(kSynthRec, false);
