@@ -621,6 +621,8 @@ template<int C>
 __global__ __launch_bounds__(256) void
 inter_tap_kernel(TapCtx cx)
 {
+  // (50 registers: the allocation class in which finish_kernel's LDS tables miscompared, gpcc_primitives.hpp)
+  GPCC_VGPR_FLOOR_64();
   __shared__ SharedLut lut;
   const LevelCtx& ctx = cx.lc;
   const TreeView& tv = ctx.tv;

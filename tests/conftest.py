@@ -35,3 +35,32 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def pkg():
     return load_package()
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _uploads_from_pinned_memory():
+    """GPU tier only.  An asynchronous copy out of PAGEABLE host memory makes the ROCm runtime pin the pages on the
+    fly, read-only, and it keeps such pins: when a later download (anybody's in the process -- `tensor.cpu()`) lands on
+    heap addresses a freed numpy array had, the GPU writes to a read-only page and the process aborts ("Memory access
+    fault ... Write access to a read-only page"; the library routes its own transfers through a pinned bounce buffer for
+    this reason, csrc/gpcc_attr_mi355.hip h2d_user).  The tests' own uploads go torch.from_numpy(x).to(device): in one
+    long pytest process with hundreds of tests that is the same hazard (seen once in ~10 runs of the whole tier), so
+    here from_numpy hands out a pinned copy -- the upload then starts from memory the runtime never has to pin."""
+    try:
+        import torch
+    except ImportError:
+        yield
+        return
+    if not torch.cuda.is_available():
+        yield
+        return
+    orig = torch.from_numpy
+
+    def pinned(a):
+        t = orig(a)
+        return t.pin_memory() if t.numel() else t
+    torch.from_numpy = pinned
+    try:
+        yield
+    finally:
+        torch.from_numpy = orig
