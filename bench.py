@@ -94,8 +94,8 @@ class Batch:
         self.offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
         self.n = int(self.offsets[-1])
         self.bits = frames[0][2]
-        self.d_morton = torch.from_numpy(np.concatenate([f[0] for f in frames])).to(dev)
-        self.src = torch.from_numpy(np.concatenate([f[1] for f in frames]).reshape(-1)).to(dev)
+        self.d_morton = to_device(torch, np.concatenate([f[0] for f in frames]), dev)
+        self.src = to_device(torch, np.concatenate([f[1] for f in frames]).reshape(-1), dev)
         self.d_attrs = torch.empty_like(self.src)
         self.d_coeffs = torch.zeros(self.c * self.n, dtype=torch.int32, device=dev)
         self.d_dec = torch.empty_like(self.src)
@@ -142,6 +142,16 @@ def kernel_profile(torch, dev, ctx, fn, steps):
     kt = ctx.kernel_times()
     ctx.set_profiling(False)
     return {k: (v[0] / steps, v[1] / steps) for k, v in kt.items()}
+
+
+def to_device(torch, array, dev):
+    """an upload that starts from pinned memory: out of pageable memory the ROCm runtime pins the source pages on the
+    fly, read-only, and keeps the pins -- a later download onto reused heap addresses then faults (the library's own
+    transfers go through a pinned bounce buffer for the same reason, csrc/gpcc_attr_mi355.hip h2d_user)"""
+    t = torch.from_numpy(np.ascontiguousarray(array))
+    if dev.type == "cuda" and t.numel():
+        t = t.pin_memory()
+    return t.to(dev)
 
 
 def main():
@@ -622,8 +632,8 @@ def lifting_leg(ctx, args, torch=None, dev=None):
     offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
     n, c = int(offsets[-1]), 3
     lp = lod_params()
-    d_xyz = torch.from_numpy(np.concatenate([x for x, _ in clouds])).to(dev)
-    src = torch.from_numpy(np.concatenate([a for _, a in clouds]).reshape(-1)).to(dev)
+    d_xyz = to_device(torch, np.concatenate([x for x, _ in clouds]), dev)
+    src = to_device(torch, np.concatenate([a for _, a in clouds]).reshape(-1), dev)
     d_attrs, d_dec = torch.empty_like(src), torch.empty_like(src)
     d_co = torch.zeros(c * n, dtype=torch.int32, device=dev)
     d_lod = [torch.zeros(k * n, dtype=torch.int32, device=dev) for k in (1, 3, 3, 1)]
@@ -772,8 +782,8 @@ def predicting_leg(ctx, args):
     sizes = [len(cl[0]) for cl in clouds]
     offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
     tot = int(offs[-1])
-    d_xyz = torch.from_numpy(np.concatenate([cl[0] for cl in clouds])).to(dev)
-    src = torch.from_numpy(np.concatenate([cl[1] for cl in clouds]).reshape(-1)).to(dev)
+    d_xyz = to_device(torch, np.concatenate([cl[0] for cl in clouds]), dev)
+    src = to_device(torch, np.concatenate([cl[1] for cl in clouds]).reshape(-1), dev)
     d_attrs = torch.empty_like(src)
     d_vals = torch.zeros(3 * tot, dtype=torch.int32, device=dev)
     d_dec = torch.zeros(3 * tot, dtype=torch.int32, device=dev)
