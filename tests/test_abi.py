@@ -95,6 +95,9 @@ def test_null_context_is_rejected_everywhere(lib):
         lambda: lib.gpcc_lift_inverse_inter(z, C.byref(lf), 1, z, z, z, dummy, z, z, z, 1, z),
         lambda: lib.gpcc_pred_forward_inter(z, C.byref(pp), 1, z, z, z, dummy, z, z, z, 1, z),
         lambda: lib.gpcc_pred_inverse_inter(z, C.byref(pp), 1, z, z, z, dummy, z, z, z, 1, z),
+        # RAHT with attribute inter prediction (round 4)
+        lambda: lib.gpcc_raht_forward_inter(z, C.byref(rp), z, z, z, z, z, 1, 1, z, z, 1, z, C.byref(out), z, C.byref(out)),
+        lambda: lib.gpcc_raht_inverse_inter(z, C.byref(rp), z, z, z, z, z, 1, 1, z, z, 1, z, 0, z, 0),
     ]
     for i, f in enumerate(calls):
         assert f() == -1, f"entry {i}"
