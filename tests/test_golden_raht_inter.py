@@ -63,7 +63,7 @@ def emu():
     return C.CDLL(os.path.join(d, "libinter_emu.so"))
 
 
-@pytest.mark.parametrize("case", rc.CASES[::3], ids=[c[0] for c in rc.CASES[::3]])
+@pytest.mark.parametrize("case", rc.CASES[::6], ids=[c[0] for c in rc.CASES[::6]])
 def test_emulated_kernels_equal_the_reference_record(emu, case):
     through(emu, "inter_emu_raht_qp", case)
 
