@@ -30,7 +30,11 @@
 extern "C" {
 #endif
 
-#define GPCC_ABI_VERSION 4
+/* 5 (round 5): gpcc_lift_params / gpcc_pred_params grew by the qp_region_* fields (260 bytes each), GPCC_ERR_RANGE and the
+ * inter-frame RAHT entries were added.  A caller compares gpcc_abi_version() with this constant before its first call
+ * (the shim TUs do, shim/shim_common.hpp process_context): a library built from another header would read parameter
+ * blocks of another size. */
+#define GPCC_ABI_VERSION 5
 #define GPCC_MAX_POINTS (1 << 29) /* 32-bit device indices, stride <= 3 */
 
 #define GPCC_MAX_QP_LAYERS 32

@@ -9,6 +9,8 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # GPCC_LIB_PATH: an experiment build of the same library (tools/, parameter sweeps)
 LIB_PATH = os.environ.get("GPCC_LIB_PATH") or os.path.join(PKG_DIR, "libgpcc_attr_mi355.so")
 
+ABI_VERSION = 5  # GPCC_ABI_VERSION of include/gpcc_attr_mi355.h
+
 # every symbol the header declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "gpcc_raht_set_prediction_weights", "gpcc_abi_version", "gpcc_last_error", "gpcc_clear_last_error",
@@ -67,6 +69,9 @@ def load():
     vp, i32, i64p = C.c_void_p, C.c_int32, C.POINTER(C.c_int64)
     pp = C.POINTER(RahtParams)
     lib.gpcc_abi_version.restype = C.c_int
+    # the ctypes parameter blocks of params.py mirror THIS version of the header
+    if lib.gpcc_abi_version() != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} has ABI {lib.gpcc_abi_version()}, the Python mirror expects {ABI_VERSION}: rebuild")
     lib.gpcc_last_error.restype = C.c_char_p
     lib.gpcc_device_count.restype = C.c_int
     lib.gpcc_ctx_create.argtypes = [C.c_int, vp, C.POINTER(vp)]

@@ -89,18 +89,174 @@ grid_for(int64_t items, int per_block)
   return (int)((g + 7) / 8 * 8);  // xcd_chunk() wants a multiple of 8
 }
 
+// ---- guard bands (GPCC_GUARD=1 in the environment; debugging aid, off by default) ---------------------------
+// Every device allocation of the library gets a 4 KB canary band in front of it and behind it, and every
+// sub-allocation of a context's arena a 256-byte band behind it; the bands are filled with 0xA5 when they are made
+// and compared when the arena is carved again, when a pool block is released, in gpcc_ctx_synchronize and in
+// gpcc_ctx_destroy.  A kernel of the library that writes outside what it was given -- into the next
+// sub-allocation or into a neighbouring allocation of the process (torch's) -- then stops the process with a
+// message that names the allocation, instead of surfacing later as somebody else's fault.
+constexpr size_t kGuardOuter = 4096;
+constexpr size_t kGuardInner = 256;
+constexpr unsigned char kGuardByte = 0xA5;
+
+bool
+guard_mode()
+{
+  static const bool on = [] {
+    const char* e = getenv("GPCC_GUARD");
+    return e && e[0] == '1';
+  }();
+  return on;
+}
+
+struct GuardedBlock {
+  char* raw;       // what hipMalloc returned
+  size_t bytes;    // the user's bytes (bands excluded)
+  const char* tag;
+};
+std::mutex g_guard_mu;
+std::map<void*, GuardedBlock> g_guard_blocks;  // by user pointer
+unsigned long long g_guard_checks = 0;         // bands compared so far (gpcc_debug_guard_checks)
+
+[[noreturn]] void
+guard_violation(const char* what, const char* tag, size_t index, size_t offset, const unsigned char* got, size_t len)
+{
+  size_t first = 0, count = 0;
+  for (size_t i = 0; i < len; i++)
+    if (got[i] != kGuardByte) {
+      if (!count)
+        first = i;
+      count++;
+    }
+  fprintf(
+    stderr,
+    "gpcc: GUARD BAND OVERWRITTEN (%s, allocation '%s' #%zu, band at byte offset %zu): %zu of %zu bytes changed, "
+    "first at +%zu = 0x%02x\n",
+    what, tag, index, offset, count, len, first, got[first]);
+  fflush(stderr);
+  abort();
+}
+
+void
+guard_compare(const void* dev, size_t len, const char* what, const char* tag, size_t index, size_t offset)
+{
+  static thread_local std::vector<unsigned char> buf;
+  buf.resize(len);
+  if (hipMemcpy(buf.data(), dev, len, hipMemcpyDeviceToHost) != hipSuccess) {
+    fprintf(stderr, "gpcc: guard band of '%s' could not be read (%s)\n", tag, what);
+    abort();
+  }
+  g_guard_checks++;
+  for (size_t i = 0; i < len; i++)
+    if (buf[i] != kGuardByte)
+      guard_violation(what, tag, index, offset, buf.data(), len);
+}
+
+// hipMalloc / hipFree of the library (every persistent device allocation goes through these two)
+hipError_t
+guarded_malloc(void** out, size_t bytes, const char* tag)
+{
+  if (!guard_mode())
+    return hipMalloc(out, bytes);
+  char* raw = nullptr;
+  const size_t padded = (bytes + 255) & ~size_t(255);
+  hipError_t e = hipMalloc((void**)&raw, padded + 2 * kGuardOuter);
+  if (e != hipSuccess)
+    return e;
+  e = hipMemset(raw, kGuardByte, kGuardOuter);
+  if (e == hipSuccess)
+    e = hipMemset(raw + kGuardOuter + padded, kGuardByte, kGuardOuter);
+  if (e != hipSuccess) {
+    hipFree(raw);
+    return e;
+  }
+  *out = raw + kGuardOuter;
+  std::lock_guard<std::mutex> lock(g_guard_mu);
+  g_guard_blocks[*out] = {raw, padded, tag};
+  return hipSuccess;
+}
+
+void
+guarded_check(void* p, const char* what)
+{
+  if (!guard_mode() || !p)
+    return;
+  GuardedBlock b;
+  {
+    std::lock_guard<std::mutex> lock(g_guard_mu);
+    auto it = g_guard_blocks.find(p);
+    if (it == g_guard_blocks.end())
+      return;
+    b = it->second;
+  }
+  guard_compare(b.raw, kGuardOuter, what, b.tag, 0, 0);
+  guard_compare(b.raw + kGuardOuter + b.bytes, kGuardOuter, what, b.tag, 1, kGuardOuter + b.bytes);
+}
+
+hipError_t
+guarded_free(void* p)
+{
+  if (!guard_mode() || !p)
+    return hipFree(p);
+  guarded_check(p, "free");
+  char* raw = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_guard_mu);
+    auto it = g_guard_blocks.find(p);
+    if (it != g_guard_blocks.end()) {
+      raw = it->second.raw;
+      g_guard_blocks.erase(it);
+    }
+  }
+  return hipFree(raw ? (void*)raw : p);
+}
+
 struct Arena {
   char* base = nullptr;
   size_t cap = 0;
   size_t used = 0;
+  // guard mode: where the 256-byte bands of the current carving lie (shared by the copies of an arena that
+  // carve on behind a region, e.g. the lifting scratch behind the LoD workspace), and the stream they are filled on
+  std::vector<size_t>* bands = nullptr;
+  hipStream_t gstream = nullptr;
 
-  void reset() { used = 0; }
+  // the band behind a sub-allocation that ends at `used` (called with `used` already advanced)
+  void band()
+  {
+    if (!guard_mode())
+      return;
+    if (base && bands) {
+      hipMemsetAsync(base + used, kGuardByte, kGuardInner, gstream);
+      bands->push_back(used);
+    }
+    used += kGuardInner;
+  }
+  // compare and forget the bands of the carving that ends here (the stream is idle afterwards)
+  void check_bands(const char* what, bool keep = false)
+  {
+    if (!guard_mode() || !base || !bands)
+      return;
+    if (!bands->empty()) {
+      hipStreamSynchronize(gstream);
+      for (size_t i = 0; i < bands->size(); i++)
+        guard_compare(base + (*bands)[i], kGuardInner, what, "arena", i, (*bands)[i]);
+      if (!keep)
+        bands->clear();
+    }
+  }
+  void reset()
+  {
+    check_bands("arena carved again");
+    used = 0;
+  }
   template<typename T>
   T* take(size_t count)
   {
     size_t bytes = (count * sizeof(T) + 255) & ~size_t(255);
     T* p = base ? reinterpret_cast<T*>(base + used) : nullptr;
     used += bytes;
+    band();
     return p;
   }
 };
@@ -112,6 +268,7 @@ struct gpcc_ctx {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   Arena arena;
+  std::vector<size_t> arena_bands;  // guard mode (GPCC_GUARD=1): see Arena
   int morton_bits = 0;  // hint for the device tier, 0 = unknown
   SharedLut* d_lut = nullptr;  // small-weight tables, built once
   int32_t* h_error = nullptr;  // pinned: copy of the sticky device-side error word
@@ -176,6 +333,23 @@ struct gpcc_ctx {
 };
 
 namespace {
+
+// guard mode: every band the context owns (the stream is idle: the caller has synchronised)
+void
+guard_check_context(gpcc_ctx* ctx, const char* what)
+{
+  ctx->arena.check_bands(what, /*keep*/ true);
+  guarded_check(ctx->arena.base, what);
+  for (auto& b : ctx->pool)
+    guarded_check(b.ptr, what);
+  guarded_check(ctx->d_lut, what);
+  guarded_check(ctx->d_error, what);
+  guarded_check(ctx->d_log2, what);
+  for (gpcc_ctx* lane : ctx->lanes) {
+    hipStreamSynchronize(lane->stream);
+    guard_check_context(lane, what);
+  }
+}
 
 // "<kernel>@<level>" names for per-level timings (GPCC_PROFILE_LEVELS=1); the
 // strings live for the life of the process
@@ -365,7 +539,7 @@ pool_malloc(gpcc_ctx* ctx, void** out, size_t bytes)
   hipStreamSynchronize(ctx->stream);
   for (size_t i = 0; i < ctx->pool.size();) {
     if (!ctx->pool[i].used) {
-      hipFree(ctx->pool[i].ptr);
+      guarded_free(ctx->pool[i].ptr);
       ctx->pool.erase(ctx->pool.begin() + i);
     } else {
       i++;
@@ -373,7 +547,7 @@ pool_malloc(gpcc_ctx* ctx, void** out, size_t bytes)
   }
   const size_t cap = bytes + bytes / 8;
   void* p = nullptr;
-  hipError_t e = hipMalloc(&p, cap);
+  hipError_t e = guarded_malloc(&p, cap, "pool block");
   if (e != hipSuccess)
     return e;
   ctx->pool.push_back({p, cap, true});
@@ -387,8 +561,13 @@ pool_free(gpcc_ctx* ctx, void* p)
   if (!p)
     return;
   for (auto& b : ctx->pool)
-    if (b.ptr == p)
+    if (b.ptr == p) {
+      if (guard_mode()) {
+        hipStreamSynchronize(ctx->stream);
+        guarded_check(p, "pool block released");
+      }
       b.used = false;
+    }
 }
 
 // A result for the caller's (pageable) memory.  An asynchronous copy straight into pageable
@@ -508,15 +687,25 @@ d2h_user(gpcc_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t st
 int
 ensure_arena(gpcc_ctx* ctx, size_t bytes)
 {
+  if (guard_mode()) {
+    // the previous call's carving is over: its bands are compared before the workspace is laid out again
+    ctx->arena.bands = &ctx->arena_bands;
+    ctx->arena.gstream = ctx->stream;
+    ctx->arena.check_bands("next call");
+    if (ctx->arena.base) {
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      guarded_check(ctx->arena.base, "next call");
+    }
+  }
   if (ctx->arena.cap >= bytes)
     return GPCC_OK;
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   if (ctx->arena.base)
-    HIP_TRY(hipFree(ctx->arena.base));
+    HIP_TRY(guarded_free(ctx->arena.base));
   ctx->arena.base = nullptr;
   ctx->arena.cap = 0;
   size_t want = bytes + bytes / 8;
-  HIP_TRY(hipMalloc((void**)&ctx->arena.base, want));
+  HIP_TRY(guarded_malloc((void**)&ctx->arena.base, want, "arena"));
   ctx->arena.cap = want;
   return GPCC_OK;
 }
@@ -530,7 +719,7 @@ ensure_log2(gpcc_ctx* ctx)
     std::vector<double> tab(((size_t)1 << 20) + 1);
     for (size_t v = 0; v < tab.size(); v++)
       tab[v] = log2((double)v);
-    HIP_TRY(hipMalloc((void**)&ctx->d_log2, tab.size() * sizeof(double)));
+    HIP_TRY(guarded_malloc((void**)&ctx->d_log2, tab.size() * sizeof(double), "log2 table"));
     HIP_TRY(hipMemcpy(ctx->d_log2, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice));
   }
   return GPCC_OK;
@@ -2175,12 +2364,12 @@ gpcc_ctx_create(int device, void* stream, gpcc_ctx** out)
     }
     ctx->own_stream = true;
   }
-  if (hipMalloc((void**)&ctx->d_lut, sizeof(SharedLut)) != hipSuccess) {
+  if (guarded_malloc((void**)&ctx->d_lut, sizeof(SharedLut), "lut") != hipSuccess) {
     gpcc_ctx_destroy(ctx);
     return fail(GPCC_ERR_OUT_OF_MEMORY, "hipMalloc(lut)");
   }
   lut_init_kernel<<<1, 256, 0, ctx->stream>>>(ctx->d_lut);
-  if (hipMalloc((void**)&ctx->d_error, sizeof(int32_t)) != hipSuccess
+  if (guarded_malloc((void**)&ctx->d_error, sizeof(int32_t), "error word") != hipSuccess
       || hipMemsetAsync(ctx->d_error, 0, sizeof(int32_t), ctx->stream) != hipSuccess
       || hipHostMalloc((void**)&ctx->h_error, sizeof(int32_t)) != hipSuccess
       || hipHostMalloc((void**)&ctx->h_stats, sizeof(TreeStats)) != hipSuccess
@@ -2213,17 +2402,18 @@ gpcc_ctx_destroy(gpcc_ctx* ctx)
   }
   for (auto e : ctx->event_pool)
     hipEventDestroy(e);
+  ctx->arena.check_bands("context destroyed");
   if (ctx->arena.base)
-    hipFree(ctx->arena.base);
+    guarded_free(ctx->arena.base);
   for (auto& b : ctx->pool)
-    hipFree(b.ptr);
+    guarded_free(b.ptr);
   ctx->pool.clear();
   if (ctx->d_lut)
-    hipFree(ctx->d_lut);
+    guarded_free(ctx->d_lut);
   if (ctx->h_error)
     hipHostFree(ctx->h_error);
   if (ctx->d_error)
-    hipFree(ctx->d_error);
+    guarded_free(ctx->d_error);
   if (ctx->h_stats)
     hipHostFree(ctx->h_stats);
   if (ctx->h_cxtab)
@@ -2237,7 +2427,7 @@ gpcc_ctx_destroy(gpcc_ctx* ctx)
   if (ctx->kd_stream)
     hipStreamDestroy(ctx->kd_stream);
   if (ctx->d_log2)
-    hipFree(ctx->d_log2);
+    guarded_free(ctx->d_log2);
   if (ctx->ev_stats)
     hipEventDestroy(ctx->ev_stats);
   if (ctx->h_pinned)
@@ -2260,7 +2450,51 @@ gpcc_ctx_synchronize(gpcc_ctx* ctx)
   if (!ctx)
     return fail(GPCC_ERR_INVALID_ARG, "ctx is null");
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (guard_mode())
+    guard_check_context(ctx, "gpcc_ctx_synchronize");
   return check_device_error(ctx);
+}
+
+// bands compared so far in this process (0 unless GPCC_GUARD=1): lets a test tier prove the guards were armed
+extern "C" unsigned long long
+gpcc_debug_guard_checks(void)
+{
+  return g_guard_checks;
+}
+
+// guard mode's own test: writes 16 bytes past a pool block (mode 0) or past a sub-allocation of the arena
+// (mode 1) and releases / re-carves it -- with GPCC_GUARD=1 the process must stop with the GUARD BAND message
+// (tests/test_gpu_guard.py runs this in a child process); without guard mode nothing is checked.
+extern "C" int
+gpcc_debug_guard_selftest(gpcc_ctx* ctx, int mode)
+{
+  if (!ctx)
+    return fail(GPCC_ERR_INVALID_ARG, "ctx is null");
+  HIP_TRY(hipSetDevice(ctx->device));
+  if (mode == 0) {
+    void* p = nullptr;
+    HIP_TRY(pool_malloc(ctx, &p, 1024));
+    // (the pool rounds a request up by an eighth: the band starts behind the block's capacity)
+    size_t cap = 0;
+    for (auto& b : ctx->pool)
+      if (b.ptr == p)
+        cap = b.cap;
+    cap = (cap + 255) & ~size_t(255);
+    HIP_TRY(hipMemsetAsync((char*)p + cap, 0, 16, ctx->stream));
+    pool_free(ctx, p);
+  } else {
+    int r = ensure_arena(ctx, 1 << 16);
+    if (r)
+      return r;
+    ctx->arena.reset();
+    char* a = ctx->arena.take<char>(1000);
+    ctx->arena.take<char>(1000);
+    HIP_TRY(hipMemsetAsync(a + 1024, 0, 16, ctx->stream));
+    r = ensure_arena(ctx, 1 << 16);
+    if (r)
+      return r;
+  }
+  return GPCC_OK;
 }
 
 int
@@ -2731,6 +2965,8 @@ lod_build_core(
     // the reference frame (positions twice, biased positions, codes, order, list, boxes)
     // and the flags of the result
     const size_t mine = (size_t)n * (scalable ? 244 : 232) + 64 * 1024 + (frame ? NF * 56 + (size_t)n * 12 + 64 * 1024 : 0);
+    if (guard_mode())  // a 256-byte band behind every array here and behind the caller's few
+      extra_bytes += 96 * 1024;
     int rc0 = ensure_arena(ctx, sort_region + mine + extra_bytes);
     if (rc0)
       return rc0;
@@ -2742,6 +2978,13 @@ lod_build_core(
       return nullptr;
     void* p = ctx->arena.base + ar_used;
     ar_used += b;
+    if (guard_mode()) {  // (Arena::band() for this entry's own carving)
+      if (ar_used + kGuardInner > ctx->arena.cap)
+        return nullptr;
+      ctx->arena.used = ar_used;
+      ctx->arena.band();
+      ar_used = ctx->arena.used;
+    }
     return p;
   };
   auto run = [&]() -> int {

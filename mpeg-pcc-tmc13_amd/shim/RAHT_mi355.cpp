@@ -74,6 +74,13 @@ device_context()
   static bool tried = false;
   if (!tried) {
     tried = true;
+    // (the parameter blocks' sizes belong to the ABI version: see shim_common.hpp process_context)
+    if (gpcc_abi_version() != GPCC_ABI_VERSION) {
+      std::fprintf(
+        stderr, "gpcc: libgpcc_attr_mi355 has ABI %d, this binary was built against %d; RAHT stays on the CPU\n",
+        gpcc_abi_version(), GPCC_ABI_VERSION);
+      return nullptr;
+    }
     const char* dev = std::getenv("GPCC_DEVICE");
     if (gpcc_ctx_create(dev ? std::atoi(dev) : 0, nullptr, &ctx) != GPCC_OK) {
       std::fprintf(

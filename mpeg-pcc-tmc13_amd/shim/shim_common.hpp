@@ -32,6 +32,14 @@ process_context(const char* what)
   static bool tried = false;
   if (!tried) {
     tried = true;
+    // the library must have been built from THIS header: the parameter blocks are passed by pointer and their
+    // sizes changed between ABI versions (a shorter block would be read past its end)
+    if (gpcc_abi_version() != GPCC_ABI_VERSION) {
+      std::fprintf(
+        stderr, "gpcc: libgpcc_attr_mi355 has ABI %d, this binary was built against %d; %s stays on the CPU\n",
+        gpcc_abi_version(), GPCC_ABI_VERSION, what);
+      return nullptr;
+    }
     const char* dev = std::getenv("GPCC_DEVICE");
     if (gpcc_ctx_create(dev ? std::atoi(dev) : 0, nullptr, &ctx) != GPCC_OK) {
       std::fprintf(stderr, "gpcc: no MI355X context (%s); %s stays on the CPU\n", gpcc_last_error(), what);
