@@ -78,10 +78,13 @@ def dense_cloud(n, seed=1, bits=10, bitdepth=8, noise=12, dedup=True):
     return np.ascontiguousarray(xyz), np.ascontiguousarray(col)
 
 
-def lidar_cloud(n, seed=1, bits=18, rings=64, bitdepth=8, dedup=True):
+def lidar_cloud(n, seed=1, bits=18, rings=64, bitdepth=8, dedup=True, refl_noise=6):
     """S-lidar: `rings` laser rings swept over azimuth with range noise, on an
     18-bit grid (cfg/sequences-cat3.yaml geometry precision), 8-bit
-    reflectance.  Returns (xyz int32 [m,3], refl int32 [m,1])."""
+    reflectance.  Returns (xyz int32 [m,3], refl int32 [m,1]).
+    refl_noise: amplitude of the per-point noise on the smooth reflectance
+    field (6: the headline frame, nearly every coefficient quantises to zero
+    at qp 34; 48: a textured field, a few per cent of them survive)."""
     rng = np.random.default_rng(seed)
     side = float((1 << bits) - 1)
     over = int(n * 1.02) + 64 if dedup else n
@@ -99,7 +102,7 @@ def lidar_cloud(n, seed=1, bits=18, rings=64, bitdepth=8, dedup=True):
     p = np.stack([x, y, z], 1)
     p = (p + 125.0) / 250.0
     xyz = np.clip(np.rint(p * side), 0, side).astype(np.int32)
-    refl = 40 + 60 * (np.sin(0.15 * rng_m) + 1) + 30 * np.cos(5 * az) + rng.integers(-6, 7, over)
+    refl = 40 + 60 * (np.sin(0.15 * rng_m) + 1) + 30 * np.cos(5 * az) + rng.integers(-refl_noise, refl_noise + 1, over)
     refl = np.clip(np.rint(refl), 0, (1 << bitdepth) - 1).astype(np.int32)
     if dedup:
         codes = morton_codes(xyz)

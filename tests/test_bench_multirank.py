@@ -21,20 +21,43 @@ def free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.gpu
-def test_bench_two_ranks_one_json_line():
+def run_bench(world, points, c3, c4):
     env = dict(os.environ, GPCC_BENCH_BACKEND="gloo")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+    # (--verify-gather is the default for N > 1 since round 5)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--points", "200000", "--configs3-points", "150000", "--verify-gather"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+           os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
+           "--points", str(points), "--configs3-points", str(c3), "--configs4-points", str(c4)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
-    d = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_eight_ranks_share_the_gpu():
+    """the node's size: eight ranks (here sharing one device, gather through host memory) -- rendezvous, per-rank
+    frames, the gather, configs[3]'s frames and configs[4]'s ten slices sharded 2,2,1,1,1,1,1,1"""
+    d = run_bench(8, 60000, 50000, 40000)
+    assert d["n_gpus"] == 8 and d["scaling"] == "weak"
+    assert d["distributed"]["world_size"] == 8
+    assert d["config"]["roundtrip_decoder_equals_encoder_recon"] is True
+    assert d["config"]["gathered_equals_single_rank"] is True
+    assert d["configs3"]["roundtrip_decoder_equals_encoder_recon"] is True
+    c4 = d["configs4"]
+    assert c4["scaling"] == "strong" and sorted(c4["slices_per_rank"]) == [1, 1, 1, 1, 1, 1, 2, 2]
+    assert c4["ceiling"].startswith("at most 5.00x")
+    assert c4["roundtrip_decoder_equals_encoder_recon"] is True and c4["gathered_equals_single_rank"] is True
+    assert c4["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_one_json_line():
+    d = run_bench(2, 200000, 150000, 100000)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 2
     assert d["config"]["points_per_gpu_per_step"] == 200000
+    assert d["configs4"]["slices_per_rank"] == [5, 5] and d["configs4"]["gathered_equals_single_rank"] is True
     assert d["config"]["roundtrip_decoder_equals_encoder_recon"] is True
     assert d["value"] > 0 and "roofline" not in d  # per-kernel figures are an N=1 report
     # the coefficient buffers rank 0 gathered are what one GPU computes for the same frames

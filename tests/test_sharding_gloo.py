@@ -1,7 +1,9 @@
-"""CPU-only, world_size 2, gloo: the N>1 path of bench.py -- units sharded
-across ranks, transformed locally (here by the CPU oracle standing in for
-the GPU), coefficients gathered on rank 0 -- equals the single-process
-result unit by unit."""
+"""CPU-only, gloo, world sizes 2 and 8 (the node's size): the N>1 path of
+bench.py -- units sharded across ranks, transformed locally (here by the CPU
+oracle standing in for the GPU), coefficients gathered on rank 0 -- equals
+the single-process result unit by unit.  Ragged units, ranks with several
+units, ranks with NONE (3 units on 8 ranks: five ranks send an empty
+buffer), and configs[4]'s shape: ten slices on eight ranks (2,2,1,1,1,1,1,1)."""
 import os
 import socket
 import sys
@@ -75,4 +77,24 @@ def test_two_rank_gather_matches_single_process(tmp_path):
     port = _free_port()
     result = str(tmp_path / "result.txt")
     mp.spawn(_worker, args=(2, port, sizes, result), nprocs=2, join=True)
+    assert open(result).read() == "ok"
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("sizes", [
+    [700, 1, 1300],                                         # 3 units on 8 ranks: five ranks hold nothing
+    [900, 1100, 1000, 950, 1050, 1000, 980, 1020, 990, 1010],  # configs[4]: ten slices -> 2,2,1,1,1,1,1,1
+    [5, 2400, 17, 800, 800, 1, 64, 333, 1200, 9, 2, 1500, 40],  # ragged, 13 units
+], ids=["empty_ranks", "ten_slices", "ragged13"])
+def test_eight_rank_gather_matches_single_process(tmp_path, sizes):
+    from mpeg_pcc_tmc13_amd import sharding
+    assign = sharding.shard_units(sizes, 8)
+    assert sorted(u for r in assign for u in r) == list(range(len(sizes)))
+    if len(sizes) == 3:
+        assert sum(1 for r in assign if not r) == 5
+    if len(sizes) == 10:
+        assert sorted(len(r) for r in assign) == [1, 1, 1, 1, 1, 1, 2, 2]
+    port = _free_port()
+    result = str(tmp_path / "result.txt")
+    mp.spawn(_worker, args=(8, port, sizes, result), nprocs=8, join=True)
     assert open(result).read() == "ok"
