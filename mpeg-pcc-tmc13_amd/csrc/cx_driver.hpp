@@ -18,6 +18,7 @@
 
 #include "cx_level.hpp"
 #include "raht_edges.hpp"
+#include "raht_links.hpp"
 
 namespace gpcc {
 
@@ -37,6 +38,74 @@ struct CxWork {
   unsigned long long* tstate = nullptr;
   int32_t* slice_l = nullptr;
   int max_tiles = 0;
+  LinkView lv{};  // neighbour links (raht_links.hpp)
+};
+
+// GPCC_LINKS=0: the level kernels search their neighbours by bisection as until round 4 (A/B measurements)
+inline bool
+links_enabled()
+{
+  static const bool on = [] {
+    const char* e = getenv("GPCC_LINKS");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
+// storage of the neighbour links of a batch of n points in s slices: `take` as in cx_carve
+template<class Take>
+void
+link_carve(Take&& take, LinkView& lv, const TreeView& tv, int n, int s, int nlev)
+{
+  for (int li = 0; li < kMaxLevels; li++)
+    lv.occ[li] = nullptr;
+  for (int li = 1; li < nlev; li++)
+    lv.occ[li] = (uint8_t*)take((size_t)tv.cap[li] + 1);
+  lv.cap_rec = n / 2 + s + 1;
+  for (int i = 0; i < 2; i++) {
+    lv.lrec[i] = (int32_t*)take(((size_t)n + 1) * 4);
+    lv.rec[i] = (int32_t*)take((size_t)lv.cap_rec * kLinkRec * 4);
+  }
+  lv.cnt = (int32_t*)take(kMaxLevels * 4);
+}
+
+// The link passes of a call: the occupancy pass and the top levels at once, then level by level in step
+// with the level kernels that consume them -- the records of a level live in the buffers of its parity,
+// so level L may only be produced once the consumer of level L + 2 has been launched.
+struct LinkSchedule {
+  TreeView tv;
+  LinkView lv;
+  int next = -1;  // next level to produce
+
+  // `nodes[l]`: nodes per level as the host knows them; `first_need`: level of the first consumer's parents
+  template<class Prof>
+  void begin(hipStream_t st, const int32_t* nodes, int first_need, Prof&& prof)
+  {
+    auto t = prof("link_top", -1);
+    const int grid = std::min(std::max((nodes[1] + 255) / 256, 1), 2048);
+    hipMemsetAsync(lv.cnt, 0, kMaxLevels * sizeof(int32_t), st);
+    hipLaunchKernelGGL(link_occ_kernel, dim3(grid), dim3(256), 0, st, tv, lv);
+    // the single workgroup takes the levels whose parents number at most 2048, down to the first consumer's
+    int lk = tv.nlev - 1;
+    while (lk - 1 >= 1 && lk - 1 >= first_need && nodes[lk] <= 2048)
+      lk--;
+    hipLaunchKernelGGL(link_top_kernel, dim3(1), dim3(1024), 0, st, tv, lv, lk);
+    next = lk - 1;
+    this->nodes_ = nodes;
+  }
+  // everything the consumer of level `need` reads is enqueued when this returns
+  template<class Prof>
+  void produce(hipStream_t st, int need, Prof&& prof)
+  {
+    while (next >= need && next >= 1) {
+      auto t = prof("link_level", next);
+      const int parents = std::min(nodes_[next + 1], lv.cap_rec);
+      const int grid = std::min(std::max((parents + 255) / 256, 1), 1 << 16);
+      hipLaunchKernelGGL(link_level_kernel, dim3(grid), dim3(256), 0, st, tv, lv, next);
+      next--;
+    }
+  }
+  const int32_t* nodes_ = nullptr;
 };
 
 inline bool
@@ -65,7 +134,7 @@ cx_carve(Take&& take, CxWork& w)
     w.tv.cap[li] = (int32_t)cap;
     w.tv.key[li] = (int64_t*)arr(cap + 1, 8);
     w.tv.fp[li] = (int32_t*)arr(cap + 2, 4);
-    w.tv.fc[li] = nullptr;  // (the block lists carry the first children)
+    w.tv.fc[li] = (int32_t*)arr(cap + 2, 4);  // (the neighbour links descend through the first children)
     w.tv.soff[li] = (int32_t*)arr(s + 1, 4);
     w.cl.hold[li] = (uint32_t*)arr(cap + 1, 4);
   }
@@ -92,6 +161,7 @@ cx_carve(Take&& take, CxWork& w)
   w.max_tiles = n / kCxG + 2;
   w.tstate = (unsigned long long*)arr((size_t)w.max_tiles + 1, 8);
   w.slice_l = (int32_t*)arr(2 * (size_t)s, 4);
+  link_carve(take, w.lv, w.tv, n, s, nlev);
 }
 
 // Everything after the uploads of params / pt_off.  `prof(name, level)` returns a scoped
@@ -186,11 +256,23 @@ cx_run(
       li_start = li_lo - 1;
     }
   }
+  LinkSchedule links;
+  const bool use_links = links_enabled() && li_start >= 0;
+  if (use_links) {
+    links.tv = tv;
+    links.lv = w.lv;
+    links.begin(st, tab->nodes, li_start + 1, prof);
+  }
   for (int li = li_start; li >= 0; li--) {
     const int nr = tab->nr[li];
     if (nr <= 0)
       continue;
     cx.li = li;
+    if (use_links) {
+      links.produce(st, li + 1, prof);
+      cx.link_rec = w.lv.rec[(li + 1) & 1];
+      cx.link_lrec = w.lv.lrec[(li + 1) & 1];
+    }
     const int ntiles = (nr + kCxG - 1) / kCxG;
     auto t = prof(w.encoder ? "cx_level_enc" : "cx_level_dec", li);
     if (w.encoder && w.f64)

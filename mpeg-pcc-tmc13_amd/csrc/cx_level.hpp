@@ -30,6 +30,7 @@
 #include "cx_tree.hpp"
 #include "raht_arith.hpp"
 #include "raht_levels.hpp"
+#include "raht_links.hpp"
 #include "raht_rdoq.hpp"
 
 namespace gpcc {
@@ -52,6 +53,9 @@ struct CxCtx {
   unsigned long long* tstate;  // [tiles] RDOQ look-back words of this level
   int32_t* slice_l;            // [2][S] last RDOQ reset, by the level's parity in the slice's plan
   int32_t li;                  // children level of this launch
+  // neighbour links of the parents' level (raht_links.hpp); null: the lanes search by bisection
+  const int32_t* link_rec;
+  const int32_t* link_lrec;
 };
 
 struct CxSlice {
@@ -492,7 +496,21 @@ cx_level_tile(const CxCtx& cx, CxSmem& sm, int li, int tile)
   //      (findNeighbours, tmc3/RAHT.cpp:299-368; findNeighbour :272-293 is a
   //      lower_bound limited to raht_prediction_search_range entries either side) -----
   int nq[6];
-  {
+  if (cx.link_rec) {
+    // round 5: the parent's record holds its 18 neighbours (raht_links.hpp) -- one load per neighbour
+    // instead of a 12-step bisection; the search window is an index distance
+    const int64_t range = prm->raht_prediction_search_range;
+    const int rj = do_search ? cx.link_lrec[j] : 0;
+    uint32_t fmask = 0;
+#pragma unroll
+    for (int t = 0; t < 6; t++) {
+      const int id = sm.nid[oct][t];
+      nq[t] = do_search ? link_lookup(cx.link_rec, rj, id, j, range) : -1;
+      fmask |= nq[t] >= 0 ? 1u << id : 0u;
+    }
+    atomicOr(&wfound[bl], fmask);
+    __builtin_amdgcn_wave_barrier();
+  } else {
     const int64_t* __restrict__ pk = tv.key[L];
     constexpr uint64_t mz = 0x9249249249249249ull, my = mz << 1, mx = mz << 2;
     const int64_t range = prm->raht_prediction_search_range;

@@ -22,8 +22,9 @@
 //               index in level l + 1, first child (node of level l), rank of the
 //               block's first real child, and the block of every real-child rank --
 //               a wavefront of the level pass takes ~56 consecutive ranks (whole
-//               blocks), lane = child.  (They replace the first-child array fc of
-//               raht_tree.hpp, which this build does not write.)
+//               blocks), lane = child.  (The first-child array fc of raht_tree.hpp is
+//               written as well since round 5: the neighbour links of raht_links.hpp
+//               descend through it.)
 //
 // A point i with h(i) == l + 1 is a non-first child at level l; it is the SECOND
 // child of its block iff the head of level l before it also heads level l + 1.
@@ -43,6 +44,7 @@ struct CxLevelTab {
   int32_t roff[kMaxLevels + 1];  // first rank of level l in rb
   int32_t nb[kMaxLevels];        // blocks of level l
   int32_t nr[kMaxLevels];        // real children of level l
+  int32_t nodes[kMaxLevels];     // nodes of level l (the host sizes the link passes with it, raht_links.hpp)
 };
 
 struct CxLists {
@@ -324,6 +326,7 @@ cx_scan_fin_kernel(TreeView tv, CxLists cl, int32_t* attr_prefix, int has_attrs)
     cl.tab->roff[lane] = (int32_t)(nri - (nb + nf));
     cl.tab->nb[lane] = nb;
     cl.tab->nr[lane] = nb + nf;
+    cl.tab->nodes[lane] = m;
     cl.bq[(int)(nbi - nb) + lane + nb] = nb + nf;  // the level's sentinel
   }
   if (lane == 0)

@@ -302,6 +302,10 @@ struct gpcc_ctx {
   // the stream when a call starts)
   void* h_cx_stage = nullptr;
   size_t h_cx_stage_cap = 0;
+  // small parameter blocks / tables / result words of synchronous host-tier calls (inter-frame RAHT): a pinned
+  // block with a bump cursor, so that not even the small copies start from or land in the caller's pages or the stack
+  char* h_small = nullptr;
+  size_t h_small_used = 0;
   int cx_stage_flip = 0;
   // downloads into the caller's pageable memory go through this pinned buffer (d2h_user)
   void* h_bounce = nullptr;
@@ -682,6 +686,55 @@ d2h_user(gpcc_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t st
     half ^= 1;
   }
   return hipSuccess;
+}
+
+// Small transfers of a synchronous host-tier call through the context's pinned block (the discipline of
+// dev_transform's h_cx_stage: the runtime never touches the caller's pages or the stack).  small_reset() at the
+// start of the call; a download's slot is read after the call's stream synchronisation.
+constexpr size_t kSmallStage = 64 * 1024;
+
+hipError_t
+small_reset(gpcc_ctx* ctx)
+{
+  if (!ctx->h_small) {
+    hipError_t e = hipHostMalloc((void**)&ctx->h_small, kSmallStage);
+    if (e != hipSuccess)
+      return e;
+  }
+  ctx->h_small_used = 0;
+  return hipSuccess;
+}
+
+void*
+small_slot(gpcc_ctx* ctx, size_t bytes)
+{
+  const size_t b = (bytes + 63) & ~size_t(63);
+  if (!ctx->h_small || ctx->h_small_used + b > kSmallStage)
+    return nullptr;
+  void* p = ctx->h_small + ctx->h_small_used;
+  ctx->h_small_used += b;
+  return p;
+}
+
+hipError_t
+small_h2d(gpcc_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t st)
+{
+  void* slot = small_slot(ctx, bytes);
+  if (!slot)
+    return hipErrorOutOfMemory;
+  memcpy(slot, src, bytes);
+  return hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, st);
+}
+
+// the pinned slot the download lands in (valid once the stream has been synchronised)
+hipError_t
+small_d2h(gpcc_ctx* ctx, void** slot_out, const void* src, size_t bytes, hipStream_t st)
+{
+  void* slot = small_slot(ctx, bytes);
+  if (!slot)
+    return hipErrorOutOfMemory;
+  *slot_out = slot;
+  return hipMemcpyAsync(slot, src, bytes, hipMemcpyDeviceToHost, st);
 }
 
 int
@@ -1196,12 +1249,20 @@ dev_transform(
           && 2 * bdepth + bitlen64((uint64_t)(n_max - 1)) <= 36;
       }
       size_t used = 0;
-      cx_carve([&](size_t bytes) { used += (bytes + 255) & ~size_t(255); return (char*)nullptr; }, w);
+      // (guard mode: Arena::take puts a band behind every sub-allocation)
+      cx_carve(
+        [&](size_t bytes) {
+          used += ((bytes + 255) & ~size_t(255)) + (guard_mode() ? kGuardInner : 0);
+          return (char*)nullptr;
+        },
+        w);
       rcode = ensure_arena(ctx, used);
       if (rcode)
         return rcode;
       ctx->arena.reset();
       cx_carve([&](size_t bytes) { return ctx->arena.take<char>(bytes); }, w);
+      if (ctx->arena.used > ctx->arena.cap)
+        return fail(GPCC_ERR_OUT_OF_MEMORY, "compact level pass: workspace carved past the arena");
       switch (c) {
       case 1:
         return launch_cx<1>(ctx, w, params, offsets, (const int64_t*)d_morton, (int32_t*)d_attrs, (int32_t*)d_coeffs);
@@ -1479,6 +1540,7 @@ host_transform_inter(
     pool_free(ctx, d_ar);
   };
   auto run = [&]() -> int {
+    HIP_TRY(small_reset(ctx));
     HIP_TRY(pool_malloc(ctx, (void**)&work, need + 256));
     HIP_TRY(pool_malloc(ctx, (void**)&d_m, sizeof(int64_t) * n));
     HIP_TRY(pool_malloc(ctx, (void**)&d_mr, sizeof(int64_t) * n_ref));
@@ -1501,7 +1563,7 @@ host_transform_inter(
     if (qp_off) {
       HIP_TRY(pool_malloc(ctx, (void**)&d_q, sizeof(int32_t) * (size_t)n * 2));
       HIP_TRY(h2d_user(ctx, d_q, qp_off, sizeof(int32_t) * (size_t)n * 2, st));
-      HIP_TRY(hipMemcpyAsync(w.asc_qp_tab, w.asc_qp, sizeof(w.asc_qp), hipMemcpyHostToDevice, st));
+      HIP_TRY(small_h2d(ctx, w.asc_qp_tab, w.asc_qp, sizeof(w.asc_qp), st));
     }
     if (encoder) {
       HIP_TRY(h2d_user(ctx, d_a, attrs, sizeof(int32_t) * n * c, st));
@@ -1511,17 +1573,16 @@ host_transform_inter(
     }
     const int32_t h_off[2] = {0, n};
     const int32_t h_rt[2] = {0, w.num_rtiles};
-    HIP_TRY(hipMemcpyAsync(w.params, params, sizeof(*params), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(w.pt_off, h_off, sizeof(h_off), hipMemcpyHostToDevice, st));
+    HIP_TRY(small_h2d(ctx, w.params, params, sizeof(*params), st));
+    HIP_TRY(small_h2d(ctx, w.pt_off, h_off, sizeof(h_off), st));
     if (w.rtile_base)
-      HIP_TRY(hipMemcpyAsync(w.rtile_base, h_rt, sizeof(h_rt), hipMemcpyHostToDevice, st));
+      HIP_TRY(small_h2d(ctx, w.rtile_base, h_rt, sizeof(h_rt), st));
     const int32_t h_off_ref[2] = {0, n_ref};
     if (w.haar) {
-      // (pageable sources: the copies are staged before the calls return)
       if (w.haar_lf_tab)
-        HIP_TRY(hipMemcpyAsync(w.haar_lf_tab, w.haar_lf, sizeof(w.haar_lf), hipMemcpyHostToDevice, st));
-      HIP_TRY(hipMemcpyAsync(w.ref_lf_tab, w.ref_lf, sizeof(w.ref_lf), hipMemcpyHostToDevice, st));
-      HIP_TRY(hipMemcpyAsync(w.pt_off_ref, h_off_ref, sizeof(h_off_ref), hipMemcpyHostToDevice, st));
+        HIP_TRY(small_h2d(ctx, w.haar_lf_tab, w.haar_lf, sizeof(w.haar_lf), st));
+      HIP_TRY(small_h2d(ctx, w.ref_lf_tab, w.ref_lf, sizeof(w.ref_lf), st));
+      HIP_TRY(small_h2d(ctx, w.pt_off_ref, h_off_ref, sizeof(h_off_ref), st));
     }
     int r = GPCC_ERR_INVALID_ARG;
     switch (c) {
@@ -1538,13 +1599,16 @@ host_transform_inter(
     HIP_TRY(d2h_user(ctx, attrs, d_a, sizeof(int32_t) * n * c, st));
     if (encoder) {
       HIP_TRY(d2h_user(ctx, coeffs, d_c, sizeof(int32_t) * n * c, st));
-      RateState rs;
-      int32_t nt = 0;
-      HIP_TRY(hipMemcpyAsync(&rs, w.rs, sizeof(rs), hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipMemcpyAsync(&nt, w.num_taps, sizeof(nt), hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipMemcpyAsync(layer_modes, w.modes, 32 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipMemcpyAsync(filter_taps, w.taps, 32 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      void *p_rs, *p_nt, *p_modes, *p_taps;
+      HIP_TRY(small_d2h(ctx, &p_rs, w.rs, sizeof(RateState), st));
+      HIP_TRY(small_d2h(ctx, &p_nt, w.num_taps, sizeof(int32_t), st));
+      HIP_TRY(small_d2h(ctx, &p_modes, w.modes, 32 * sizeof(int32_t), st));
+      HIP_TRY(small_d2h(ctx, &p_taps, w.taps, 32 * sizeof(int32_t), st));
       HIP_TRY(hipStreamSynchronize(st));
+      const RateState rs = *(const RateState*)p_rs;
+      const int32_t nt = *(const int32_t*)p_nt;
+      memcpy(layer_modes, p_modes, 32 * sizeof(int32_t));
+      memcpy(filter_taps, p_taps, 32 * sizeof(int32_t));
       *num_modes = rs.num_modes;
       *num_taps = nt;
       for (int i = rs.num_modes; i < 32; i++)
@@ -2434,6 +2498,8 @@ gpcc_ctx_destroy(gpcc_ctx* ctx)
     hipHostFree(ctx->h_pinned);
   if (ctx->h_cx_stage)
     hipHostFree(ctx->h_cx_stage);
+  if (ctx->h_small)
+    hipHostFree(ctx->h_small);
   if (ctx->h_bounce)
     hipHostFree(ctx->h_bounce);
   for (int h = 0; h < 2; h++)
@@ -2471,6 +2537,8 @@ gpcc_debug_guard_selftest(gpcc_ctx* ctx, int mode)
   if (!ctx)
     return fail(GPCC_ERR_INVALID_ARG, "ctx is null");
   HIP_TRY(hipSetDevice(ctx->device));
+  if (!guard_mode())  // (without the bands the write below would leave the allocation: nothing to test)
+    return GPCC_OK;
   if (mode == 0) {
     void* p = nullptr;
     HIP_TRY(pool_malloc(ctx, &p, 1024));

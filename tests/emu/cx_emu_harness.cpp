@@ -218,6 +218,183 @@ cx_emu_check_tree(int32_t num_slices, const int64_t* offsets, const int64_t* mor
   return bad;
 }
 
+
+// ---- neighbour links (raht_links.hpp) against a direct computation --------------------------------
+// use_top = 0: the seed, then every level by its own launch, each level checked; 1: the levels the
+// driver would give the single-workgroup loop run there (its last two levels checked), the rest by launch
+extern "C" int
+cx_emu_check_links(int32_t num_slices, const int64_t* offsets, const int64_t* morton, int32_t morton_bits, int32_t use_top)
+{
+  CxWork w;
+  w.n = (int)offsets[num_slices];
+  w.s = num_slices;
+  w.c = 1;
+  const int bits = morton_bits > 0 ? std::min(morton_bits, 63) : 63;
+  w.nlev = std::min((bits + 2) / 3 + 1, (int)kMaxLevels);
+  w.encoder = false;
+  std::vector<void*> blocks;
+  cx_carve(
+    [&](size_t bytes) {
+      bytes = (bytes + 255) & ~size_t(255);
+      void* p = malloc(bytes + 256);
+      memset(p, 0xCD, bytes + 256);
+      blocks.push_back(p);
+      return (char*)p;
+    },
+    w);
+  int32_t error = 0;
+  w.tv.pos = morton;
+  w.tv.error = &error;
+  for (int i = 0; i <= num_slices; i++)
+    w.pt_off[i] = (int32_t)offsets[i];
+  const TreeView tv = w.tv;
+  const CxLists cl = w.cl;
+  const LinkView lv = w.lv;
+  const int ncol = 3 * w.nlev + 1;
+  const int tgrid = std::max((tv.num_tiles + 3) / 4, 1);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(cx_count_kernel<1>), dim3(tgrid), dim3(256), 0, nullptr, tv, (const int32_t*)nullptr, cl);
+  hipLaunchKernelGGL(cx_scan_kernel, dim3(ncol), dim3(256), 0, nullptr, tv, cl, ncol);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(cx_scan_fin_kernel<1>), dim3(1), dim3(64), 0, nullptr, tv, cl, (int32_t*)nullptr, 0);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(cx_emit_kernel<1>), dim3(tgrid), dim3(256), 0, nullptr, tv, (const int32_t*)nullptr, cl, (int32_t*)nullptr);
+  const int n = w.n, nlev = w.nlev;
+  int bad = 0;
+  auto fail = [&](const char* what, int l, int i, long long got, long long want) {
+    if (bad++ < 12)
+      fprintf(stderr, "link check: %s level %d index %d: got %lld want %lld\n", what, l, i, got, want);
+  };
+  // the levels, directly
+  std::vector<std::vector<int64_t>> keys(nlev);
+  std::vector<std::vector<int>> fps(nlev), sl_of(nlev);
+  for (int l = 0; l < nlev; l++)
+    for (int s = 0; s < num_slices; s++)
+      for (int i = (int)offsets[s]; i < (int)offsets[s + 1]; i++) {
+        const int64_t k = morton[i] >> (3 * l);
+        if (i == offsets[s] || k != (morton[i - 1] >> (3 * l))) {
+          keys[l].push_back(k);
+          fps[l].push_back(i);
+          sl_of[l].push_back(s);
+        }
+      }
+  for (int l = 0; l < nlev; l++) {
+    if ((int)keys[l].size() != tv.soff[l][num_slices])
+      fail("node count", l, 0, tv.soff[l][num_slices], (long long)keys[l].size());
+    fps[l].push_back(n);
+    if ((int)keys[l].size() != cl.tab->nodes[l])
+      fail("tab.nodes", l, 0, cl.tab->nodes[l], (long long)keys[l].size());
+  }
+  if (bad)
+    return bad;
+  // first children and occupancies
+  for (int l = 1; l < nlev; l++) {
+    const int m = (int)keys[l].size();
+    size_t c = 0;
+    for (int q = 0; q < m; q++) {
+      while (c < keys[l - 1].size() && fps[l - 1][c] < fps[l][q])
+        c++;
+      if (tv.fc[l][q] != (int)c)
+        fail("fc", l, q, tv.fc[l][q], (long long)c);
+    }
+    if (tv.fc[l][m] != (int)keys[l - 1].size())
+      fail("fc sentinel", l, m, tv.fc[l][m], (long long)keys[l - 1].size());
+  }
+  if (bad)
+    return bad;
+  memset(lv.cnt, 0, kMaxLevels * sizeof(int32_t));
+  hipLaunchKernelGGL(link_occ_kernel, dim3(3), dim3(256), 0, nullptr, tv, lv);
+  for (int l = 1; l < nlev; l++)
+    for (int q = 0; q < (int)keys[l].size(); q++) {
+      uint32_t occ = 0;
+      for (int c = tv.fc[l][q]; c < tv.fc[l][q + 1]; c++)
+        occ |= 1u << (int)(keys[l - 1][c] & 7);
+      if (lv.occ[l][q] != occ)
+        fail("occ", l, q, lv.occ[l][q], occ);
+    }
+  // a level's records against a direct look-up of the 18 keys inside the node's slice
+  auto step = [](int64_t k, int axis, int d) {  // one axis of the Morton key by +-1 (no wrap: out of range = absent)
+    int64_t v = 0;
+    for (int b = 0; b < 21; b++)
+      v |= ((k >> (3 * b + (2 - axis))) & 1) << b;
+    v += d;
+    if (v < 0 || v >= (1 << 21))
+      return (int64_t)-1;
+    int64_t r = k;
+    for (int b = 0; b < 21; b++) {
+      r &= ~((int64_t)1 << (3 * b + (2 - axis)));
+      r |= ((v >> b) & 1) << (3 * b + (2 - axis));
+    }
+    return r;
+  };
+  auto check_level = [&](int L) {
+    const int m = (int)keys[L].size();
+    int expect = 0;
+    for (int q = 0; q < m; q++)
+      if (fps[L][q + 1] - fps[L][q] > 1 || L == nlev - 1)
+        expect++;
+    if (lv.cnt[L] != expect)
+      fail("records", L, 0, lv.cnt[L], expect);
+    std::vector<char> seen(expect > 0 ? expect : 1, 0);
+    for (int q = 0; q < m; q++) {
+      if (!(fps[L][q + 1] - fps[L][q] > 1 || L == nlev - 1))
+        continue;
+      const int r = lv.lrec[L & 1][q];
+      if (r < 0 || r >= expect || seen[r]) {
+        fail("lrec", L, q, r, -1);
+        continue;
+      }
+      seen[r] = 1;
+      const int32_t* rec = lv.rec[L & 1] + (size_t)r * kLinkRec;
+      if (rec[18] != q)
+        fail("rec.node", L, q, rec[18], q);
+      const int s = sl_of[L][q];
+      for (int id = 1; id < 19; id++) {
+        int64_t k = keys[L][q];
+        for (int axis = 0; axis < 3 && k >= 0; axis++)
+          if (link_axis(id, axis))
+            k = step(k, axis, link_axis(id, axis));
+        int want = -1;
+        if (k >= 0) {
+          const int lo = tv.soff[L][s], hi = tv.soff[L][s + 1];
+          const auto it = std::lower_bound(keys[L].begin() + lo, keys[L].begin() + hi, k);
+          if (it != keys[L].begin() + hi && *it == k)
+            want = (int)(it - keys[L].begin());
+        }
+        if (rec[id - 1] != want)
+          fail("link", L, q * 100 + id, rec[id - 1], want);
+      }
+    }
+  };
+  if (!use_top) {
+    hipLaunchKernelGGL(link_top_kernel, dim3(1), dim3(1024), 0, nullptr, tv, lv, nlev - 1);
+    check_level(nlev - 1);
+    for (int L = nlev - 2; L >= 1; L--) {
+      hipLaunchKernelGGL(link_level_kernel, dim3(5), dim3(256), 0, nullptr, tv, lv, L);
+      check_level(L);
+    }
+  } else {
+    NoProf prof;
+    LinkSchedule ls;
+    ls.tv = tv;
+    ls.lv = lv;
+    std::vector<int32_t> nodes(kMaxLevels, 0);
+    for (int l = 0; l < nlev; l++)
+      nodes[l] = (int32_t)keys[l].size();
+    const int first_need = std::max(1, nlev - 4);
+    ls.begin(nullptr, nodes.data(), first_need, prof);
+    check_level(ls.next + 1);
+    if (ls.next + 2 <= nlev - 1)
+      check_level(ls.next + 2);
+    for (int need = first_need; need >= 1; need--) {
+      ls.produce(nullptr, need, prof);
+      check_level(need);
+    }
+  }
+  for (void* p : blocks)
+    free(p);
+  if (error)
+    return 1000 + error;
+  return bad;
+}
+
 // ---- the one-irsqrt forms of the weight constants against the reference forms ---------
 extern "C" int
 cx_emu_check_coeffs(int64_t max_exhaustive, int64_t num_random, uint64_t seed)

@@ -24,6 +24,8 @@ def lib():
         _lib.cx_emu_transform.restype = C.c_int
         _lib.cx_emu_check_tree.argtypes = [C.c_int32, _i64p, _i64p, C.c_int32]
         _lib.cx_emu_check_tree.restype = C.c_int
+        _lib.cx_emu_check_links.argtypes = [C.c_int32, _i64p, _i64p, C.c_int32, C.c_int32]
+        _lib.cx_emu_check_links.restype = C.c_int
         _lib.cx_emu_check_coeffs.argtypes = [C.c_int64, C.c_int64, C.c_uint64]
         _lib.cx_emu_check_coeffs.restype = C.c_int
         _lib.cx_emu_supported.argtypes = [C.c_void_p, C.c_int, C.c_int64]
@@ -65,6 +67,11 @@ def inverse(p, morton, coeffs, c, offsets=None, f64=False):
     rc = lib().cx_emu_transform(C.addressof(p), 2 if f64 else 0, len(offs) - 1, offs, morton, rec, co, c, _bits(morton, offs), None)
     assert rc == 0, rc
     return rec.reshape(n, c)
+
+
+def check_links(morton, offsets, bits, use_top):
+    offs = np.ascontiguousarray(offsets, dtype=np.int64)
+    return lib().cx_emu_check_links(len(offs) - 1, offs, np.ascontiguousarray(morton, dtype=np.int64), bits, int(use_top))
 
 
 def check_tree(morton, offsets, bits):

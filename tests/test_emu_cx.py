@@ -152,6 +152,23 @@ def test_tree_and_block_lists(n, bits, slices):
     assert emu.check_tree(m, offs, bits) == 0
 
 
+@pytest.mark.parametrize("n,bits,slices", [(700, 9, 1), (5000, 12, 1), (4000, 15, 3), (3000, 30, 2), (2500, 63, 1), (9, 6, 2),
+                                           (6000, 18, 1)])
+@pytest.mark.parametrize("use_top", [0, 1])
+def test_neighbour_links(n, bits, slices, use_top):
+    """raht_links.hpp: first children, occupancies and the 18 neighbour links of every node with more than one point,
+    level by level, against a direct look-up of the keys inside the node's slice (random codes incl. duplicates,
+    several slices; use_top: the driver's split between the single-workgroup loop and the per-level launches)"""
+    rng = np.random.default_rng(7 * n + bits)
+    m = rng.integers(0, 1 << bits, size=n, dtype=np.int64) if bits < 63 else rng.integers(0, (1 << 62) - 1, size=n, dtype=np.int64)
+    if n > 100:  # clusters: chains of single-child nodes between the branchings, duplicates
+        m[: n // 3] = (m[: n // 3] & ~np.int64(0x1FF)) | (m[: n // 3] & np.int64(7))
+    offs = [n * s // slices for s in range(slices + 1)]
+    for s in range(slices):
+        m[offs[s]:offs[s + 1]].sort()
+    assert emu.check_links(m, offs, bits, use_top) == 0
+
+
 def test_weight_constants_from_one_irsqrt():
     """cx_norm / cx_coeffs (one irsqrt per weight, irsqrt(w << 30) == irsqrt(w) >> 15)
     against sqrt_weight / scale_rsqrt / raht_coeffs of raht_levels.hpp"""
