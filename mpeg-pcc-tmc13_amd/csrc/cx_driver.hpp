@@ -41,73 +41,6 @@ struct CxWork {
   LinkView lv{};  // neighbour links (raht_links.hpp)
 };
 
-// GPCC_LINKS=0: the level kernels search their neighbours by bisection as until round 4 (A/B measurements)
-inline bool
-links_enabled()
-{
-  static const bool on = [] {
-    const char* e = getenv("GPCC_LINKS");
-    return !(e && e[0] == '0');
-  }();
-  return on;
-}
-
-// storage of the neighbour links of a batch of n points in s slices: `take` as in cx_carve
-template<class Take>
-void
-link_carve(Take&& take, LinkView& lv, const TreeView& tv, int n, int s, int nlev)
-{
-  for (int li = 0; li < kMaxLevels; li++)
-    lv.occ[li] = nullptr;
-  for (int li = 1; li < nlev; li++)
-    lv.occ[li] = (uint8_t*)take((size_t)tv.cap[li] + 1);
-  lv.cap_rec = n / 2 + s + 1;
-  for (int i = 0; i < 2; i++) {
-    lv.lrec[i] = (int32_t*)take(((size_t)n + 1) * 4);
-    lv.rec[i] = (int32_t*)take((size_t)lv.cap_rec * kLinkRec * 4);
-  }
-  lv.cnt = (int32_t*)take(kMaxLevels * 4);
-}
-
-// The link passes of a call: the occupancy pass and the top levels at once, then level by level in step
-// with the level kernels that consume them -- the records of a level live in the buffers of its parity,
-// so level L may only be produced once the consumer of level L + 2 has been launched.
-struct LinkSchedule {
-  TreeView tv;
-  LinkView lv;
-  int next = -1;  // next level to produce
-
-  // `nodes[l]`: nodes per level as the host knows them; `first_need`: level of the first consumer's parents
-  template<class Prof>
-  void begin(hipStream_t st, const int32_t* nodes, int first_need, Prof&& prof)
-  {
-    auto t = prof("link_top", -1);
-    const int grid = std::min(std::max((nodes[1] + 255) / 256, 1), 2048);
-    hipMemsetAsync(lv.cnt, 0, kMaxLevels * sizeof(int32_t), st);
-    hipLaunchKernelGGL(link_occ_kernel, dim3(grid), dim3(256), 0, st, tv, lv);
-    // the single workgroup takes the levels whose parents number at most 2048, down to the first consumer's
-    int lk = tv.nlev - 1;
-    while (lk - 1 >= 1 && lk - 1 >= first_need && nodes[lk] <= 2048)
-      lk--;
-    hipLaunchKernelGGL(link_top_kernel, dim3(1), dim3(1024), 0, st, tv, lv, lk);
-    next = lk - 1;
-    this->nodes_ = nodes;
-  }
-  // everything the consumer of level `need` reads is enqueued when this returns
-  template<class Prof>
-  void produce(hipStream_t st, int need, Prof&& prof)
-  {
-    while (next >= need && next >= 1) {
-      auto t = prof("link_level", next);
-      const int parents = std::min(nodes_[next + 1], lv.cap_rec);
-      const int grid = std::min(std::max((parents + 255) / 256, 1), 1 << 16);
-      hipLaunchKernelGGL(link_level_kernel, dim3(grid), dim3(256), 0, st, tv, lv, next);
-      next--;
-    }
-  }
-  const int32_t* nodes_ = nullptr;
-};
-
 inline bool
 cx_supported(const gpcc_raht_params* p, bool has_qp, int64_t n)
 {

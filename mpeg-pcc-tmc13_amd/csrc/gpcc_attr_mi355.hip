@@ -444,6 +444,8 @@ struct Plan {
   bool pipe = false;
   int num_rtiles = 0;
   std::vector<int32_t*> haar_lf, asc_qp;
+  LinkView lv{};  // neighbour links of the sub-node kernels (raht_links.hpp)
+  bool links = false;
 };
 
 // Carve the workspace.  With arena.base == nullptr this only measures.
@@ -519,6 +521,9 @@ carve(Arena& ar, Plan& pl)
     pl.rtile_state = ar.take<unsigned long long>(pl.num_rtiles + 1);
     pl.slice_l = ar.take<int32_t>(2 * (size_t)s);  // sub-node path: [level parity][S]
   }
+  pl.links = pl.sub && !pl.pipe && links_enabled();
+  if (pl.links)
+    link_carve([&](size_t bytes) { return ar.take<char>(bytes); }, pl.lv, pl.tv, n, s, nlev);
 }
 
 // Device buffers of the host tiers (uploads, downloads, scratch): a caching
@@ -1021,10 +1026,27 @@ launch_transform(
     }
   }
 
+  // neighbour links of the sub-node kernels (raht_links.hpp): the occupancy pass and the top levels now,
+  // every other level right before the level kernel that consumes it
+  LinkSchedule links;
+  auto link_prof = [&](const char* name, int li) { return Timer(ctx, li < 0 ? name : level_name(name, li)); };
+  // (without the RAHT extension a parent with ONE child -- and one point -- searches too: the links cover the
+  // nodes with more than one point only, those slices keep the bisection)
+  const bool use_links = pl.links && !piped && !tiles && first_level >= 1 && hp->raht_extension != 0;
+  if (use_links) {
+    links.tv = tv;
+    links.lv = pl.lv;
+    links.begin(st, ts.nodes, first_level, link_prof);
+  }
   for (int li = piped ? -1 : first_level - 1; li >= 0; li--) {
     lc.li = li;
     lc.mtag = (uint32_t)(li + 1);
     const int64_t parents = ts.nodes[li + 1];
+    if (use_links) {
+      links.produce(st, li + 1, link_prof);
+      lc.link_rec = pl.lv.rec[(li + 1) & 1];
+      lc.link_lrec = pl.lv.lrec[(li + 1) & 1];
+    }
     if (tiles) {
       // a level where almost every parent has a single child takes the large
       // tiles (raht_tile.hpp): the node counts tell

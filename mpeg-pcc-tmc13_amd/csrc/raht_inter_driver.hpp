@@ -22,6 +22,7 @@
 
 #include "raht_edges.hpp"
 #include "raht_inter.hpp"
+#include "raht_links.hpp"
 #include "raht_subnode.hpp"
 #include "raht_tile.hpp"
 #include "raht_tree.hpp"
@@ -77,6 +78,8 @@ struct InterWork {
   int wstride = 0;
   // sub-node prediction: the dependency kernels' workspace, and a second one for the intra candidate
   bool sub = false;
+  LinkView lv{};  // neighbour links of the dependency kernels (raht_links.hpp)
+  bool links = false;
   bool f64 = false;  // the intra candidate's dependency kernel in ArithF64 (raht_arith.hpp; decided by the caller)
   int32_t* worklist = nullptr;
   int32_t* work_count = nullptr;  // [kMaxLevels] then tickets [kMaxLevels][8]
@@ -223,6 +226,9 @@ inter_carve(Take&& take, InterWork& w)
       w.irec_us = (int64_t*)arr((size_t)n * c, 8);
     }
   }
+  w.links = w.sub && links_enabled();
+  if (w.links)
+    link_carve(take, w.lv, w.tv, n, 1, nlev);
   if (w.sub) {
     w.worklist = (int32_t*)arr((size_t)n + 1, 4);
     w.work_count = (int32_t*)arr(kMaxLevels * 9, 4);
@@ -511,6 +517,15 @@ inter_run(
   rt.ptrans = w.ptrans;
   rt.iptrans = w.iptrans;
 
+  LinkSchedule links;
+  // (without the RAHT extension a parent with one child -- and one point -- searches too: the links cover
+  // the nodes with more than one point only)
+  const bool use_links = w.links && top >= 1 && hp->raht_extension != 0;
+  if (use_links) {
+    links.tv = tv;
+    links.lv = w.lv;
+    links.begin(st, ts.nodes, top, prof);
+  }
   static const int kFixedTaps[7] = {128, 128, 128, 127, 125, 121, 115};
   int tree_depth = 0, depth = 0, qp_layer = 0, coeff = 0, parity = 1;
   for (int li = top - 1; li >= 0; li--) {
@@ -576,6 +591,11 @@ inter_run(
       // ---- the dependency kernels (raht_subnode.hpp) ------------------------------------------
       const int64_t parents = ts.nodes[li + 1];
       lc.mtag = (uint32_t)(li + 1);
+      if (use_links) {
+        links.produce(st, li + 1, prof);
+        lc.link_rec = w.lv.rec[(li + 1) & 1];
+        lc.link_lrec = w.lv.lrec[(li + 1) & 1];
+      }
       {
         auto t = prof("level_prepass", li);
         hipLaunchKernelGGL(

@@ -98,6 +98,9 @@ struct LevelCtx {
   unsigned long long* rdoq_state;  // [cap] per worklist block: RDOQ hand-off word
   int32_t* slice_l;                // [2][S] last RDOQ reset carried between levels (sub-node path: by level parity)
   InterRef inter;                  // attribute inter prediction (tile kernels instantiated with INTER)
+  // neighbour links of the parents' level (raht_links.hpp, sub-node kernels); null: bisection
+  const int32_t* link_rec;
+  const int32_t* link_lrec;
 };
 
 // ctx.X[parity] with a per-lane parity, as a select between the two kernel

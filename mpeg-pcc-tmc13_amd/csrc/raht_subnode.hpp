@@ -44,6 +44,7 @@
 #include "raht_arith.hpp"
 #include "raht_inter.hpp"
 #include "raht_levels.hpp"
+#include "raht_links.hpp"
 
 namespace gpcc {
 
@@ -337,7 +338,20 @@ raht_level_sub_kernel(LevelCtx ctx)
     }
     // (group-uniform; other groups of the wave idle through the shuffles)
     int pn[3] = {-1, -1, -1};  // neighbour i = 1 + t + 8*slot
-    {
+    if (ctx.link_rec) {
+      // round 5: the parent's record holds its 18 neighbours (raht_links.hpp) -- one load each instead of
+      // a 12-step bisection; findNeighbour's window (tmc3/RAHT.cpp:272-293) is an index distance
+      if (do_search) {
+        const int64_t range = prm->raht_prediction_search_range;
+        const int rj = ctx.link_lrec[j];
+#pragma unroll
+        for (int slot = 0; slot < 3; slot++) {
+          const int i = 1 + t + 8 * slot;
+          if (i < 19 && (occ & neigh_mask(i)))
+            pn[slot] = link_lookup(ctx.link_rec, rj, i, j, range);
+        }
+      }
+    } else {
       // the three lower_bound searches of a lane advance in lock step, so
       // their probes are in flight together (12 dependent steps, not 36)
       int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}, end[3] = {0, 0, 0};
