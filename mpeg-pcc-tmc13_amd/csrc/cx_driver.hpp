@@ -38,7 +38,8 @@ struct CxWork {
   unsigned long long* tstate = nullptr;
   int32_t* slice_l = nullptr;
   int max_tiles = 0;
-  LinkView lv{};  // neighbour links (raht_links.hpp)
+  LinkView lv{};  // neighbour links (raht_links.hpp), opt-in
+  bool links = false;  // decided by the caller before the workspace is carved (links_enabled())
 };
 
 inline bool
@@ -67,7 +68,8 @@ cx_carve(Take&& take, CxWork& w)
     w.tv.cap[li] = (int32_t)cap;
     w.tv.key[li] = (int64_t*)arr(cap + 1, 8);
     w.tv.fp[li] = (int32_t*)arr(cap + 2, 4);
-    w.tv.fc[li] = (int32_t*)arr(cap + 2, 4);  // (the neighbour links descend through the first children)
+    // (the block lists carry the first children; the neighbour links descend through fc)
+    w.tv.fc[li] = w.links ? (int32_t*)arr(cap + 2, 4) : nullptr;
     w.tv.soff[li] = (int32_t*)arr(s + 1, 4);
     w.cl.hold[li] = (uint32_t*)arr(cap + 1, 4);
   }
@@ -94,7 +96,8 @@ cx_carve(Take&& take, CxWork& w)
   w.max_tiles = n / kCxG + 2;
   w.tstate = (unsigned long long*)arr((size_t)w.max_tiles + 1, 8);
   w.slice_l = (int32_t*)arr(2 * (size_t)s, 4);
-  link_carve(take, w.lv, w.tv, n, s, nlev);
+  if (w.links)
+    link_carve(take, w.lv, w.tv, n, s, nlev);
 }
 
 // Everything after the uploads of params / pt_off.  `prof(name, level)` returns a scoped
@@ -190,7 +193,7 @@ cx_run(
     }
   }
   LinkSchedule links;
-  const bool use_links = links_enabled() && li_start >= 0;
+  const bool use_links = w.links && li_start >= 0;
   if (use_links) {
     links.tv = tv;
     links.lv = w.lv;

@@ -1270,6 +1270,7 @@ dev_transform(
         w.f64 = cx_f64 && ctx->fast_arith && !ctx->force_exact
           && 2 * bdepth + bitlen64((uint64_t)(n_max - 1)) <= 36;
       }
+      w.links = links_enabled();
       size_t used = 0;
       // (guard mode: Arena::take puts a band behind every sub-allocation)
       cx_carve(

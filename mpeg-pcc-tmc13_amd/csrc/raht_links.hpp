@@ -304,15 +304,16 @@ link_lookup(const int32_t* __restrict__ rec, int rj, int id, int j, int64_t rang
 
 // ---- host side: storage and launch order --------------------------------------------------------
 
-// GPCC_LINKS=0: the level kernels search their neighbours by bisection as until round 4 (A/B measurements)
+// GPCC_LINKS=1 turns the links on (read at every call).  They are OFF by default: measured on the MI355X
+// (profiles/r05_links_ab.txt) the consumers gain less than the passes cost -- compact level pass of 10 x 1 M
+// points 2.40 -> 2.02 ms, sub-node encoder 25.7 -> 24.7 ms, against 2.4 ms for the link passes (0.9 for a
+// single frame): the bisections they replace run in L2-resident keys that neighbouring lanes share, and
+// the level kernels are bound by instruction issue and by their dependency chains, not by those round trips.
 inline bool
 links_enabled()
 {
-  static const bool on = [] {
-    const char* e = getenv("GPCC_LINKS");
-    return !(e && e[0] == '0');
-  }();
-  return on;
+  const char* e = getenv("GPCC_LINKS");
+  return e && e[0] == '1';
 }
 
 // storage of the neighbour links of a batch of n points in s slices: `take` as in cx_carve

@@ -38,6 +38,7 @@ cx_emu_transform(
   w.nlev = std::min((bits + 2) / 3 + 1, (int)kMaxLevels);
   w.encoder = (encoder & 1) != 0;
   w.f64 = (encoder & 2) != 0;
+  w.links = (encoder & 4) != 0 || links_enabled();  // bit 2: with the neighbour links (raht_links.hpp)
   std::vector<void*> blocks;
   cx_carve(
     [&](size_t bytes) {
@@ -232,6 +233,7 @@ cx_emu_check_links(int32_t num_slices, const int64_t* offsets, const int64_t* mo
   const int bits = morton_bits > 0 ? std::min(morton_bits, 63) : 63;
   w.nlev = std::min((bits + 2) / 3 + 1, (int)kMaxLevels);
   w.encoder = false;
+  w.links = true;
   std::vector<void*> blocks;
   cx_carve(
     [&](size_t bytes) {

@@ -45,7 +45,7 @@ def supported(p, n, has_qp=False):
     return bool(lib().cx_emu_supported(C.addressof(p), int(has_qp), n))
 
 
-def forward(p, morton, attrs, offsets=None, f64=False):
+def forward(p, morton, attrs, offsets=None, f64=False, links=False):
     """-> (coeffs planar per slice, recon [n, c]) from the emulated kernels (f64: the level
     kernels in ArithF64; an out-of-range value makes the harness return -103)"""
     n, c = attrs.shape
@@ -53,18 +53,18 @@ def forward(p, morton, attrs, offsets=None, f64=False):
     morton = np.ascontiguousarray(morton, dtype=np.int64)
     rec = np.ascontiguousarray(attrs, dtype=np.int32).copy().reshape(-1)
     co = np.zeros(n * c, dtype=np.int32)
-    rc = lib().cx_emu_transform(C.addressof(p), 1 | (2 if f64 else 0), len(offs) - 1, offs, morton, rec, co, c, _bits(morton, offs), None)
+    rc = lib().cx_emu_transform(C.addressof(p), 1 | (2 if f64 else 0) | (4 if links else 0), len(offs) - 1, offs, morton, rec, co, c, _bits(morton, offs), None)
     assert rc == 0, rc
     return co, rec.reshape(n, c)
 
 
-def inverse(p, morton, coeffs, c, offsets=None, f64=False):
+def inverse(p, morton, coeffs, c, offsets=None, f64=False, links=False):
     n = len(morton)
     offs = np.ascontiguousarray([0, n] if offsets is None else offsets, dtype=np.int64)
     morton = np.ascontiguousarray(morton, dtype=np.int64)
     rec = np.zeros(n * c, dtype=np.int32)
     co = np.ascontiguousarray(coeffs, dtype=np.int32).copy()
-    rc = lib().cx_emu_transform(C.addressof(p), 2 if f64 else 0, len(offs) - 1, offs, morton, rec, co, c, _bits(morton, offs), None)
+    rc = lib().cx_emu_transform(C.addressof(p), (2 if f64 else 0) | (4 if links else 0), len(offs) - 1, offs, morton, rec, co, c, _bits(morton, offs), None)
     assert rc == 0, rc
     return rec.reshape(n, c)
 

@@ -24,6 +24,8 @@ def test_case_table_has_eligible_cases():
 # both arithmetic back ends of the level kernels (raht_arith.hpp): int64 fixed point, and doubles
 # where they are exact (what the library picks for attributes of at most 10 bits)
 F64 = pytest.mark.parametrize("f64", [False, True], ids=["i64", "f64"])
+# ... and with the opt-in neighbour links of raht_links.hpp (GPCC_LINKS=1) instead of the bisections
+LINKS = pytest.mark.parametrize("links", [False, True], ids=["bisect", "links"])
 
 
 @F64
@@ -43,10 +45,11 @@ VARIANTS = [dict(search_range=8), dict(threshold0=4, threshold1=10), dict(weight
             dict(qp=40, bitdepth=10), dict(qp=10), dict(prediction=False, qp=28)]
 
 
+@LINKS
 @F64
 @pytest.mark.parametrize("vi", range(len(VARIANTS)))
 @pytest.mark.parametrize("c", [1, 3])
-def test_parameter_variants(vi, c, f64):
+def test_parameter_variants(vi, c, f64, links):
     kw = dict(VARIANTS[vi])
     kw.setdefault("subnode", False)
     xyz, attrs = synth.random_cloud(n=1500 + 100 * vi, seed=20 + vi, bits=5, c=c,
@@ -54,9 +57,9 @@ def test_parameter_variants(vi, c, f64):
     morton, attrs, _ = synth.sort_by_morton(xyz, attrs)
     p = raht_params(**kw)
     o_co, o_rec = ol.oracle().raht_forward(p, morton, attrs)
-    co, rec = emu.forward(p, morton, attrs, f64=f64)
+    co, rec = emu.forward(p, morton, attrs, f64=f64, links=links)
     assert np.array_equal(co, o_co) and np.array_equal(rec, o_rec)
-    assert np.array_equal(emu.inverse(p, morton, o_co, c, f64=f64), o_rec)
+    assert np.array_equal(emu.inverse(p, morton, o_co, c, f64=f64, links=links), o_rec)
 
 
 def _batch(sizes, c, seed):
@@ -78,13 +81,14 @@ def _batch(sizes, c, seed):
 @pytest.mark.parametrize("sizes,c", [([1, 2, 3, 700, 57, 64, 5000, 1, 333, 9, 2100], 1),
                                      (list(np.random.default_rng(5).integers(1, 40, size=150)), 3)],
                          ids=["ragged11", "tiny150"])
+@LINKS
 @F64
-def test_ragged_batches(sizes, c, f64):
+def test_ragged_batches(sizes, c, f64, links):
     """slices of 1..5000 points in one batch (more than 64 slices: the plans are read
     from memory instead of LDS), every slice against the oracle"""
     p = raht_params(subnode=False, search_range=2500)
     parts, morton, attrs, offs = _batch(sizes, c, 30)
-    co, rec = emu.forward(p, morton, attrs, offsets=offs, f64=f64)
+    co, rec = emu.forward(p, morton, attrs, offsets=offs, f64=f64, links=links)
     dec_in = np.zeros_like(co)
     for i, (m, a) in enumerate(parts):
         o_co, o_rec = ol.oracle().raht_forward(p, m, a)
@@ -92,7 +96,7 @@ def test_ragged_batches(sizes, c, f64):
         assert np.array_equal(co[c * s0:c * s1], o_co), f"slice {i}"
         assert np.array_equal(rec[s0:s1], o_rec), f"slice {i}"
         dec_in[c * s0:c * s1] = o_co
-    assert np.array_equal(emu.inverse(p, morton, dec_in, c, offsets=offs, f64=f64), rec)
+    assert np.array_equal(emu.inverse(p, morton, dec_in, c, offsets=offs, f64=f64, links=links), rec)
 
 
 @F64

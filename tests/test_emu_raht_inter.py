@@ -108,11 +108,15 @@ def test_emulated_inter_raht_with_region_qp_offsets(lib, kw):
 
 @pytest.mark.parametrize("kw", [dict(), dict(extension=False), dict(qp=16), dict(haar=True, qp=4, chroma_offset=0),
                                 dict(subnode=False, extension=False), dict(subnode=False, haar=True, qp=4, chroma_offset=0)])
-def test_emulated_intra_level_kernels(lib, kw):
+@pytest.mark.parametrize("links", [False, True], ids=["bisect", "links"])
+def test_emulated_intra_level_kernels(lib, kw, links, monkeypatch):
     """the level kernels of the INTRA path under the emulator: with a depth limit of zero no level looks at the frame,
     and the driver runs the dependency kernels of the reference's default flags (raht_subnode.hpp: lossy, integer Haar,
     decoder) or the tile kernels exactly as gpcc_raht_forward / _inverse launch them -- against the plain intra oracle"""
     from mpeg_pcc_tmc13_amd import raht_params, synth
+    # (links: the opt-in neighbour links of raht_links.hpp in the dependency kernels -- the library reads the switch
+    # at every call)
+    monkeypatch.setenv("GPCC_LINKS", "1" if links else "0")
     o = ol.oracle()
     for name, xyz, attrs in clouds():
         if name in ("one", "lidar"):
