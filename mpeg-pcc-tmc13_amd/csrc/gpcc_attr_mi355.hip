@@ -1095,6 +1095,21 @@ launch_transform(
     // from 1 workgroup per 32 parents to the full grid, slower beyond 1 per 128)
     const int sgrid = (int)std::min<int64_t>(
       kSubGrid, std::max<int64_t>(8, (parents / (GPCC_SUB_BLOCKS_PER_WG) + 7) / 8 * 8));
+    // the lossy encoder's coarse levels are one serial chain of zero-run states: there a wavefront claims
+    // several consecutive rounds and hands the state on in registers (raht_subnode.hpp).  GPCC_SUB_CLAIM=R
+    // (rounds per claim, default 8; 1 = off), GPCC_SUB_CLAIM_PARENTS (levels with at most so many parents)
+    {
+      static const int claim_r = [] {
+        const char* e = getenv("GPCC_SUB_CLAIM");
+        const int v = e ? atoi(e) : 8;
+        return v < 1 ? 1 : (v > 64 ? 64 : v);
+      }();
+      static const int64_t claim_parents = [] {
+        const char* e = getenv("GPCC_SUB_CLAIM_PARENTS");
+        return e ? (int64_t)atoll(e) : (int64_t)100000;
+      }();
+      lc.claim_rounds = (encoder && !pl.haar && claim_r > 1 && parents <= claim_parents) ? claim_r : 1;
+    }
     if (!encoder) {
       Timer t(ctx, level_name("level_sub_synth", li));
       if (pl.f64)

@@ -101,6 +101,9 @@ struct LevelCtx {
   // neighbour links of the parents' level (raht_links.hpp, sub-node kernels); null: bisection
   const int32_t* link_rec;
   const int32_t* link_lrec;
+  // rounds of 8 blocks a wavefront of the sub-node kernels takes per claim: 0 / 1 = one round from one of
+  // eight tickets, R > 1 = R consecutive rounds from a single ticket (raht_subnode.hpp)
+  int32_t claim_rounds;
 };
 
 // ctx.X[parity] with a per-lane parity, as a select between the two kernel

@@ -170,20 +170,39 @@ raht_level_sub_kernel(LevelCtx ctx)
   const int cls = blockIdx.x & 7;
 
   const int num_work = ctx.work_count[li];
+  // Claims.  Normally a wavefront takes ONE round of 8 blocks, from one of eight tickets (workgroup index
+  // mod 8: rounds of the eight classes interleave).  Round 5: where ctx.claim_rounds = R > 1 -- the coarse
+  // levels, which the lossy encoder walks as ONE serial chain of blocks because nearly every block's zeroing
+  // decision needs the zero-run state its predecessor leaves (tmc3/RAHT.cpp:1618-1669) -- a wavefront takes R
+  // CONSECUTIVE rounds from a single ticket and works through them one after the other, carrying the zero-run
+  // state from a round's last block to the next round's first in registers: the hop between two wavefronts
+  // (a write-through store, a poll that finds it: ~3.3 us) is then paid once per 8 R blocks instead of once per
+  // 8.  Claims stay monotone (one counter), so every dependency still points into a claim that is running.
+  const int claim_rounds = ctx.claim_rounds > 1 ? ctx.claim_rounds : 1;
+  bool stop_all = false;
   for (;;) {
     int tk = 0;
     if (lane == 0)
-      tk = atomicAdd(&ctx.ticket[li * 8 + cls], 1);
+      tk = atomicAdd(&ctx.ticket[li * 8 + (claim_rounds > 1 ? 0 : cls)], 1);
     tk = __shfl(tk, 0);
-    const int64_t wround = (int64_t)tk * 8 + cls;
+    const int64_t wround0 = claim_rounds > 1 ? (int64_t)tk * claim_rounds : (int64_t)tk * 8 + cls;
+    if (wround0 * 8 >= num_work || stop_all)
+      break;
+    // the zero-run state behind the previous round of this claim, when it is known exactly
+    bool carry_known = false;
+    int carry_l = -1;
+   for (int sr = 0; sr < claim_rounds; sr++) {
+    const int64_t wround = wround0 + sr;
     if (wround * 8 >= num_work)
       break;
     SubProf prof;
     prof.round_begin();
     // a bounded wait has expired somewhere: the result is discarded anyway,
     // leave at once instead of spinning through every remaining round
-    if (__hip_atomic_load(ctx.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+    if (__hip_atomic_load(ctx.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+      stop_all = true;
       break;
+    }
     const int wi = (int)(wround * 8) + (lane >> 3);
     const bool live = wi < num_work;
     const int j = live ? ctx.worklist[wi] : 0;
@@ -1108,9 +1127,12 @@ raht_level_sub_kernel(LevelCtx ctx)
             const int pl = nt ? 63 - __clzll((long long)nt) : 0;
             const int pk = __shfl(outk, pl);
             const int pv = __shfl(outv, pl);
-            const bool found = w2 && nt != 0 && pk == 2;
+            // (nothing but reset-free blocks before this one in the round: the state the claim's previous
+            // round left, in registers)
+            const bool from_carry = w2 && nt == 0 && carry_known;
+            const bool found = (w2 && nt != 0 && pk == 2) || from_carry;
             if (found) {
-              lin = pv;
+              lin = from_carry ? carry_l : pv;
               lin_known = lin_exact = true;
             }
             if (!__any(found))
@@ -1229,6 +1251,19 @@ raht_level_sub_kernel(LevelCtx ctx)
       }
     }
     prof.round_end(lane, li);
+    if (kLossy && claim_rounds > 1) {
+      // what this round leaves for the claim's next one: the state behind its last block that knows it
+      // (every later block of the round is reset-free); a round of reset-free blocks that never learnt the
+      // incoming state leaves none -- the next round then walks the words in memory as any other claim does
+      const unsigned long long fin = __ballot(outk == 2) & 0x0101010101010101ull;
+      if (fin) {
+        carry_l = __shfl(outv, 63 - __clzll((long long)fin));
+        carry_known = true;
+      } else if (__any(outk == 1)) {
+        carry_known = false;
+      }
+    }
+   }
   }
   // ArithF64: a value left the range in which doubles are exact -- the sticky word stops every
   // later kernel of the call (the source attributes stay intact) and the call is redone with
