@@ -70,6 +70,9 @@ def parse():
                     help="points per slice of the N>1 configs[4] leg (ten slices, colour + reflectance)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--legs", default="",
+                    help="N=1: run ONLY these extra legs (comma separated: lifting,predicting,recolour,raht_inter) after "
+                         "the headline step -- for profiler passes of one leg (tools/r05_pmc.sh)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the alternative-flag, 10M-forward, calibration and lifting legs")
     return ap.parse_args()
@@ -428,6 +431,10 @@ def main():
                 "nonzero_coefficient_fraction": round(nzt, 4),
                 "roundtrip_decoder_equals_encoder_recon": bt.roundtrip_ok()}
             del bt
+        if args.legs:
+            for leg in args.legs.split(","):
+                out[leg] = {"lifting": lambda: lifting_leg(ctx, args), "predicting": lambda: predicting_leg(ctx, args),
+                            "recolour": lambda: recolour_leg(ctx, args), "raht_inter": lambda: raht_inter_leg(ctx, args)}[leg]()
         if not args.no_extras:
             out["raht_forward_10M"] = forward_10m(torch, dev, ctx, params_for, frames)
             out["hbm_calibration"] = hbm_calibration(torch, dev)
@@ -616,6 +623,7 @@ def forward_10m(torch, dev, ctx, params_for, first_frames):
             "roofline": {
                 "bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
+                "traffic": pmc_traffic(None, name, f"fwd10_sub{sub}"),
                 "launches_per_forward": round(launches, 1),
                 "algorithmic_bytes_per_launch": round(nbytes / launches),
                 "avg_launch_us": round(ms * 1e3 / launches, 2),
@@ -763,17 +771,22 @@ def hbm_calibration(torch, dev):
             "note": "torch device-to-device copy, read + write bytes; roofline.frac uses the nominal peak"}
 
 
-def pmc_traffic(args, kernel):
-    """HBM bytes per launch of the dominant kernel (FETCH_SIZE + WRITE_SIZE),
-    from the committed rocprofv3 PMC passes of this exact workload
-    (profiles/r04_pmc_traffic.json); None for any other workload or kernel.
-    PMC passes cannot run inside this process."""
-    path = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
-    default = (args.cloud == "lidar" and args.points == 1_000_000 and args.frames == 1 and args.subnode == 1
-               and args.qp == 34 and not args.haar and args.direction == "both")
-    if not default or not os.path.exists(path):
+def pmc_traffic(args, kernel, workload=None):
+    """HBM-side bytes per launch of a kernel (FETCH_SIZE + WRITE_SIZE of rocprofv3, separate --pmc passes) from the
+    committed counter passes of THIS workload at this round's HEAD (profiles/r05_pmc_traffic.json, made by
+    tools/r05_pmc.sh + tools/r05_pmc_json.py); None for any other workload or kernel.  PMC passes cannot run inside
+    this process.  Raw counter bytes: the guide's x2 correction of FETCH_SIZE applies to wide coalesced streams only,
+    and these kernels' traffic is 4..16-byte gathers, polls and write-through granules."""
+    path = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
+    if workload is None:
+        default = (args.cloud == "lidar" and args.points == 1_000_000 and args.frames == 1 and args.subnode == 1
+                   and args.qp == 34 and not args.haar and args.direction == "both")
+        if not default:
+            return None
+        workload = "headline"
+    if not os.path.exists(path):
         return None
-    rec = json.load(open(path)).get(kernel)
+    rec = json.load(open(path)).get(workload, {}).get(kernel)
     if rec is None:
         return None
     return rec["fetch_bytes_per_launch"] + rec["write_bytes_per_launch"]

@@ -624,6 +624,28 @@ int gpcc_raht_encode_attr_packed(
   int32_t* attrs, int32_t* runs, int32_t* values, int32_t* num_symbols,
   int32_t* trailing_run, int32_t n, int32_t c, int32_t bitdepth);
 
+/* QP regions of a slice (AttributeBrickHeader::qpRegions -> QpSet::regions, quantization.cpp:196-204): the
+ * offset of the FIRST box that contains a point is added to its layer QPs.  Field names as in
+ * gpcc_lift_params / gpcc_pred_params. */
+typedef struct gpcc_qp_regions {
+  int32_t num_qp_regions; /* 0 .. GPCC_MAX_QP_REGIONS */
+  int32_t qp_region_min[GPCC_MAX_QP_REGIONS][3];
+  int32_t qp_region_max[GPCC_MAX_QP_REGIONS][3];
+  int32_t qp_region_offset[GPCC_MAX_QP_REGIONS][2];
+} gpcc_qp_regions;
+
+/* The RAHT slice drivers with QP regions (round 5): gpcc_raht_encode_attr_packed / gpcc_raht_decode_attr with the
+ * per-point offsets the reference's drivers derive with qpSet.regionQpOffset (AttributeEncoder.cpp:1262, 1336;
+ * AttributeDecoder.cpp:585, 648) computed on the device from the positions.  regions == NULL or
+ * num_qp_regions == 0: exactly the entries without regions. */
+int gpcc_raht_encode_attr_packed_regions(
+  gpcc_ctx* ctx, const gpcc_raht_params* params, const gpcc_qp_regions* regions, const int32_t* xyz,
+  int32_t* attrs, int32_t* runs, int32_t* values, int32_t* num_symbols,
+  int32_t* trailing_run, int32_t n, int32_t c, int32_t bitdepth);
+int gpcc_raht_decode_attr_regions(
+  gpcc_ctx* ctx, const gpcc_raht_params* params, const gpcc_qp_regions* regions, const int32_t* xyz,
+  int32_t* attrs, const int32_t* coeffs, int32_t n, int32_t c, int32_t bitdepth);
+
 /* Zero-run formation of a coefficient stream: the part of the reference's
  * entropy loops that is not the arithmetic coder (AttributeEncoder.cpp:
  * 1279-1291 / 1347-1362 RAHT, 1458-1474 / 1617-1633 lifting).  A position

@@ -22,6 +22,7 @@ ABI_SYMBOLS = [
     "gpcc_ctx_set_profiling", "gpcc_ctx_kernel_times", "gpcc_ctx_stats",
     "gpcc_lift_forward", "gpcc_lift_inverse", "gpcc_lod_compute_weights", "gpcc_lod_build", "gpcc_lod_build_inter", "gpcc_lift_forward_inter", "gpcc_lift_inverse_inter", "gpcc_pred_forward_inter", "gpcc_pred_inverse_inter", "gpcc_estimate_dist2", "gpcc_recolour", "gpcc_raht_encode_attr", "gpcc_raht_decode_attr",
     "gpcc_lift_encode_attr", "gpcc_lift_decode_attr", "gpcc_zero_run_pack", "gpcc_raht_encode_attr_packed",
+    "gpcc_raht_encode_attr_packed_regions", "gpcc_raht_decode_attr_regions",
     "gpcc_dev_lod_build", "gpcc_dev_lift_encode_attr", "gpcc_dev_lift_decode_attr",
     "gpcc_multi_create", "gpcc_multi_destroy", "gpcc_multi_num_devices", "gpcc_multi_uses_rccl", "gpcc_multi_rccl_selftest",
     "gpcc_multi_raht_forward", "gpcc_multi_raht_inverse", "gpcc_binarise_symbols",
@@ -117,6 +118,8 @@ def load():
     for name in ("gpcc_lift_encode_attr", "gpcc_lift_decode_attr"):
         getattr(lib, name).argtypes = [vp, C.POINTER(LodParams), C.POINTER(LiftParams), vp, vp, vp, vp, vp, i32, i32]
     lib.gpcc_raht_encode_attr_packed.argtypes = [vp, pp, vp, vp, vp, vp, C.POINTER(i32), C.POINTER(i32), i32, i32, i32]
+    lib.gpcc_raht_encode_attr_packed_regions.argtypes = [vp, pp, vp, vp, vp, vp, vp, C.POINTER(i32), C.POINTER(i32), i32, i32, i32]
+    lib.gpcc_raht_decode_attr_regions.argtypes = [vp, pp, vp, vp, vp, vp, i32, i32, i32]
     lib.gpcc_zero_run_pack.argtypes = [vp, vp, i32, i32, i32, vp, vp, C.POINTER(i32), C.POINTER(i32)]
     lib.gpcc_estimate_dist2.argtypes = [vp, vp, i32, i32, i32, C.c_float, C.POINTER(i32)]
     lib.gpcc_recolour.argtypes = [vp, vp, vp, vp, i32, vp, i32, i32, C.c_float, C.POINTER(i32), vp]

@@ -1095,13 +1095,17 @@ launch_transform(
     // from 1 workgroup per 32 parents to the full grid, slower beyond 1 per 128)
     const int sgrid = (int)std::min<int64_t>(
       kSubGrid, std::max<int64_t>(8, (parents / (GPCC_SUB_BLOCKS_PER_WG) + 7) / 8 * 8));
-    // the lossy encoder's coarse levels are one serial chain of zero-run states: there a wavefront claims
-    // several consecutive rounds and hands the state on in registers (raht_subnode.hpp).  GPCC_SUB_CLAIM=R
-    // (rounds per claim, default 8; 1 = off), GPCC_SUB_CLAIM_PARENTS (levels with at most so many parents)
+    // Claims of several CONSECUTIVE rounds per wavefront with the zero-run state carried in registers
+    // (raht_subnode.hpp, ctx.claim_rounds): built and measured in round 5, bit-exact, and 10-20 x SLOWER
+    // (profiles/r05_claim_rounds_ab.txt: headline forward 7.5 -> 134 ms at 8 rounds per claim) -- a wavefront
+    // walks its rounds one after the other and each starts with the ~100 us of dependent loads of its prologue,
+    // which the one-round claims of many wavefronts overlap; the blocks of the NEXT claim wait for all of them.
+    // Opt-in for experiments only: GPCC_SUB_CLAIM=R (default 1), GPCC_SUB_CLAIM_PARENTS (levels with at most
+    // so many parents, default 100 000).
     {
       static const int claim_r = [] {
         const char* e = getenv("GPCC_SUB_CLAIM");
-        const int v = e ? atoi(e) : 8;
+        const int v = e ? atoi(e) : 1;
         return v < 1 ? 1 : (v > 64 ? 64 : v);
       }();
       static const int64_t claim_parents = [] {
@@ -3741,7 +3745,7 @@ slice_driver(
   gpcc_ctx* ctx, const gpcc_raht_params* params, bool encoder, const int32_t* xyz,
   int32_t* attrs, int32_t* coeffs, int32_t n, int32_t c, int32_t bitdepth,
   int32_t* runs = nullptr, int32_t* values = nullptr, int32_t* num_symbols = nullptr,
-  int32_t* trailing_run = nullptr)
+  int32_t* trailing_run = nullptr, const gpcc_qp_regions* regions = nullptr)
 {
   // packed: the encoder hands back (zero run, values) symbols instead of the
   // coefficient array
@@ -3766,10 +3770,13 @@ slice_driver(
   hipStream_t st = ctx->stream;
   const size_t N = (size_t)n;
   int32_t *d_xyz = nullptr, *d_order = nullptr, *d_pt = nullptr, *d_a = nullptr, *d_c = nullptr;
+  int32_t *d_qu = nullptr, *d_q = nullptr;  // QP-region offsets per point: input order, Morton order
   int64_t* d_m = nullptr;
   char* d_pack = nullptr;
   auto cleanup = [&]() {
     pool_free(ctx, d_pack);
+    pool_free(ctx, d_qu);
+    pool_free(ctx, d_q);
     pool_free(ctx, d_xyz);
     pool_free(ctx, d_order);
     pool_free(ctx, d_pt);
@@ -3805,7 +3812,20 @@ slice_driver(
     } else {
       HIP_TRY(h2d_user(ctx, d_c, coeffs, sizeof(int32_t) * N * c, st));
     }
-    int r = dev_transform(ctx, params, encoder, 1, offs, d_m, nullptr, d_a, d_c, c, bits);
+    // QP regions: the offset of the first box that holds the point (qpSet.regionQpOffset), in the order of
+    // the Morton codes like the attributes
+    const int32_t* d_qp = nullptr;
+    if (regions && regions->num_qp_regions != 0) {
+      HIP_TRY(pool_malloc(ctx, (void**)&d_qu, sizeof(int32_t) * 2 * N));
+      HIP_TRY(pool_malloc(ctx, (void**)&d_q, sizeof(int32_t) * 2 * N));
+      const int32_t* filled = nullptr;
+      int rq = qp_regions_to_points(regions, d_xyz, n, d_qu, st, &filled);
+      if (rq)
+        return rq;
+      attr_gather_kernel<<<grid_for(n, 256), 256, 0, st>>>(n, 2, d_order, d_qu, d_q);
+      d_qp = d_q;
+    }
+    int r = dev_transform(ctx, params, encoder, 1, offs, d_m, d_qp, d_a, d_c, c, bits);
     if (r)
       return r;
     {
@@ -3882,6 +3902,28 @@ gpcc_raht_encode_attr_packed_impl(
     return fail(GPCC_ERR_INVALID_ARG, "runs is null");
   return slice_driver(
     ctx, params, true, xyz, attrs, nullptr, n, c, bitdepth, runs, values, num_symbols, trailing_run);
+}
+
+static int
+gpcc_raht_encode_attr_packed_regions_impl(
+  gpcc_ctx* ctx, const gpcc_raht_params* params, const gpcc_qp_regions* regions, const int32_t* xyz,
+  int32_t* attrs, int32_t* runs, int32_t* values, int32_t* num_symbols, int32_t* trailing_run, int32_t n,
+  int32_t c, int32_t bitdepth)
+{
+  if (!runs)
+    return fail(GPCC_ERR_INVALID_ARG, "runs is null");
+  return slice_driver(
+    ctx, params, true, xyz, attrs, nullptr, n, c, bitdepth, runs, values, num_symbols, trailing_run, regions);
+}
+
+static int
+gpcc_raht_decode_attr_regions_impl(
+  gpcc_ctx* ctx, const gpcc_raht_params* params, const gpcc_qp_regions* regions, const int32_t* xyz,
+  int32_t* attrs, const int32_t* coeffs, int32_t n, int32_t c, int32_t bitdepth)
+{
+  return slice_driver(
+    ctx, params, false, xyz, attrs, const_cast<int32_t*>(coeffs), n, c, bitdepth, nullptr, nullptr, nullptr,
+    nullptr, regions);
 }
 
 static int
@@ -4396,6 +4438,27 @@ gpcc_raht_decode_attr(
   int32_t* attrs, const int32_t* coeffs, int32_t n, int32_t c, int32_t bitdepth)
 {
   return counted(ctx, gpcc_raht_decode_attr_impl(ctx, params, xyz, attrs, coeffs, n, c, bitdepth), n);
+}
+
+int
+gpcc_raht_encode_attr_packed_regions(
+  gpcc_ctx* ctx, const gpcc_raht_params* params, const gpcc_qp_regions* regions, const int32_t* xyz,
+  int32_t* attrs, int32_t* runs, int32_t* values, int32_t* num_symbols, int32_t* trailing_run, int32_t n,
+  int32_t c, int32_t bitdepth)
+{
+  return counted(
+    ctx,
+    gpcc_raht_encode_attr_packed_regions_impl(
+      ctx, params, regions, xyz, attrs, runs, values, num_symbols, trailing_run, n, c, bitdepth),
+    n);
+}
+
+int
+gpcc_raht_decode_attr_regions(
+  gpcc_ctx* ctx, const gpcc_raht_params* params, const gpcc_qp_regions* regions, const int32_t* xyz,
+  int32_t* attrs, const int32_t* coeffs, int32_t n, int32_t c, int32_t bitdepth)
+{
+  return counted(ctx, gpcc_raht_decode_attr_regions_impl(ctx, params, regions, xyz, attrs, coeffs, n, c, bitdepth), n);
 }
 
 int

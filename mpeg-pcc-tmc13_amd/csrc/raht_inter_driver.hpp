@@ -603,11 +603,11 @@ inter_run(
           0, st, lc);
       }
       const int sgrid = (int)std::min<int64_t>(kInterSubGrid, std::max<int64_t>(8, (parents / 64 + 7) / 8 * 8));
-      // (claims of several consecutive rounds at the lossy encoder's coarse levels, raht_subnode.hpp; the
-      // emulator tier sets GPCC_SUB_CLAIM itself to run both forms)
+      // (claims of several consecutive rounds, raht_subnode.hpp: an opt-in experiment -- measured slower --
+      // that the emulator tier keeps pinned by setting GPCC_SUB_CLAIM itself)
       {
         const char* ce = getenv("GPCC_SUB_CLAIM");
-        const int cr = ce ? atoi(ce) : 8;
+        const int cr = ce ? atoi(ce) : 1;
         lc.claim_rounds = (encoder && !haar && cr > 1 && parents <= 100000) ? (cr > 64 ? 64 : cr) : 1;
       }
 #ifdef GPCC_EMU  // (the workgroups of a dependency kernel wait for one another: eight run together)

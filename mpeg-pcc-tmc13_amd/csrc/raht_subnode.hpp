@@ -170,14 +170,14 @@ raht_level_sub_kernel(LevelCtx ctx)
   const int cls = blockIdx.x & 7;
 
   const int num_work = ctx.work_count[li];
-  // Claims.  Normally a wavefront takes ONE round of 8 blocks, from one of eight tickets (workgroup index
-  // mod 8: rounds of the eight classes interleave).  Round 5: where ctx.claim_rounds = R > 1 -- the coarse
-  // levels, which the lossy encoder walks as ONE serial chain of blocks because nearly every block's zeroing
-  // decision needs the zero-run state its predecessor leaves (tmc3/RAHT.cpp:1618-1669) -- a wavefront takes R
-  // CONSECUTIVE rounds from a single ticket and works through them one after the other, carrying the zero-run
-  // state from a round's last block to the next round's first in registers: the hop between two wavefronts
-  // (a write-through store, a poll that finds it: ~3.3 us) is then paid once per 8 R blocks instead of once per
-  // 8.  Claims stay monotone (one counter), so every dependency still points into a claim that is running.
+  // Claims.  A wavefront takes ONE round of 8 blocks, from one of eight tickets (workgroup index mod 8: rounds
+  // of the eight classes interleave).  Round 5 experiment, opt-in (ctx.claim_rounds = R > 1, GPCC_SUB_CLAIM): R
+  // CONSECUTIVE rounds from a single ticket, worked through one after the other with the lossy encoder's
+  // zero-run state (tmc3/RAHT.cpp:1618-1669) carried from a round's last block to the next round's first in
+  // registers, so that the hop between two wavefronts is paid once per 8 R blocks.  Bit-exact, and 10-20 x
+  // slower on the MI355X (profiles/r05_claim_rounds_ab.txt): the rounds of a claim start one after the other,
+  // each with its ~100 us prologue of dependent loads, and the next claim's blocks wait for all of them -- the
+  // one-round claims of many wavefronts overlap exactly that.  Kept for the record and pinned under the emulator.
   const int claim_rounds = ctx.claim_rounds > 1 ? ctx.claim_rounds : 1;
   bool stop_all = false;
   for (;;) {

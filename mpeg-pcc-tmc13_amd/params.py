@@ -120,6 +120,18 @@ class LiftParams(C.Structure):
     ]
 
 
+class QpRegions(C.Structure):
+    """gpcc_qp_regions: the QP regions of a slice for the RAHT slice drivers"""
+    _fields_ = [("num_qp_regions", C.c_int32),
+                ("qp_region_min", (C.c_int32 * 3) * GPCC_MAX_QP_REGIONS),
+                ("qp_region_max", (C.c_int32 * 3) * GPCC_MAX_QP_REGIONS),
+                ("qp_region_offset", (C.c_int32 * 2) * GPCC_MAX_QP_REGIONS)]
+
+
+def qp_regions(regions):
+    return set_qp_regions(QpRegions(), regions)
+
+
 def set_qp_regions(p, regions):
     """regions: [((x0, y0, z0), (x1, y1, z1), (offset_luma, offset_chroma)), ...] -- the boxes' bounds
     inclusive, the first region that contains a point counts (QpSet::regionQpOffset)"""

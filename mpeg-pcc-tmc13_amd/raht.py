@@ -454,6 +454,30 @@ class Context:
                                                           C.byref(tr), n, c, bitdepth))
         return runs[:m.value].copy(), vals[:m.value * c].reshape(m.value, c).copy(), tr.value, a
 
+    def raht_encode_attr_packed_regions(self, params, regions, xyz, attrs, bitdepth=8):
+        """raht_encode_attr_packed with QP regions (params.qp_regions(...)): the per-point offsets of
+        qpSet.regionQpOffset are derived on the device"""
+        xyz = np.ascontiguousarray(xyz, dtype=np.int32)
+        a = np.ascontiguousarray(attrs, dtype=np.int32).copy()
+        n, c = a.shape
+        runs = np.zeros(n, np.int32)
+        vals = np.zeros(n * c, np.int32)
+        m, tr = C.c_int32(), C.c_int32()
+        _lib.check(self._lib.gpcc_raht_encode_attr_packed_regions(
+            self._h, C.byref(params), C.byref(regions) if regions is not None else None, xyz.ctypes.data, a.ctypes.data,
+            runs.ctypes.data, vals.ctypes.data, C.byref(m), C.byref(tr), n, c, bitdepth))
+        return runs[:m.value].copy(), vals[:m.value * c].reshape(m.value, c).copy(), tr.value, a
+
+    def raht_decode_attr_regions(self, params, regions, xyz, coeffs, c, bitdepth=8):
+        xyz = np.ascontiguousarray(xyz, dtype=np.int32)
+        n = xyz.shape[0]
+        co = np.ascontiguousarray(coeffs, dtype=np.int32)
+        a = np.zeros((n, c), dtype=np.int32)
+        _lib.check(self._lib.gpcc_raht_decode_attr_regions(
+            self._h, C.byref(params), C.byref(regions) if regions is not None else None, xyz.ctypes.data, a.ctypes.data,
+            co.ctypes.data, n, c, bitdepth))
+        return a
+
     def dev_pred_attr(self, encode, lod_params, pred_params_list, offsets, d_xyz, d_attrs, d_values, c, icp=None,
                       d_indexes=None):
         """gpcc_dev_pred_encode_attr / _decode_attr on device buffers; pred_params_list: one

@@ -11,10 +11,10 @@
 // arithmetic decoder and context models, the residual syntax of shim_common.hpp --
 // and ONE device call (gpcc_lift_decode_attr / gpcc_pred_decode_attr: LoD build +
 // inverse transform) turns the values into the attributes.  Since round 4 an intra RAHT
-// slice without QP regions is decoded the same way (decodeColorsRaht / decodeReflectancesRaht
-// :613-674, 527-609): symbols parsed, then gpcc_raht_decode_attr -- Morton codes, sort,
-// inverse transform, clip, scatter -- in one device call.  Every other slice (raw, RAHT with
-// inter prediction or QP regions -- seam 1 --, a partial geometry octree) goes to the
+// slice is decoded the same way (decodeColorsRaht / decodeReflectancesRaht
+// :613-674, 527-609): symbols parsed, then gpcc_raht_decode_attr_regions -- Morton codes, sort,
+// the QP regions' offsets per point (round 5), inverse transform, clip, scatter -- in one device call.
+// Every other slice (raw, RAHT with inter prediction -- seam 1 --, a partial geometry octree) goes to the
 // reference's decoder unchanged.
 //
 // Built against the reference's headers; contains no reference code.
@@ -197,7 +197,8 @@ private:
       return false;
     const QpSet qpSet = deriveQpSet(desc, aps, abh);
     gpcc_raht_params rp;
-    if (!qpSet.regions.empty() || !flatten_raht(aps.rahtPredParams, qpSet, aps.raht_extension, inter, &rp))
+    gpcc_qp_regions regions;  // (round 5: QP regions, offsets per point derived on the device)
+    if (!flatten_regions(qpSet, &regions) || !flatten_raht(aps.rahtPredParams, qpSet, aps.raht_extension, inter, &rp))
       return false;
     gpcc_ctx* ctx = process_context("the attribute decoder");
     if (!ctx)
@@ -222,7 +223,7 @@ private:
     }
     std::vector<int32_t> xyz, attrs(size_t(c) * n);
     positions_of(cloud, &xyz);
-    const int rc = gpcc_raht_decode_attr(ctx, &rp, xyz.data(), attrs.data(), co, n, c, desc.bitdepth);
+    const int rc = gpcc_raht_decode_attr_regions(ctx, &rp, &regions, xyz.data(), attrs.data(), co, n, c, desc.bitdepth);
     if (rc) {
       if (rc != GPCC_ERR_UNSUPPORTED)
         std::fprintf(stderr, "gpcc: %s; the attribute decoder falls back to the CPU\n", gpcc_last_error());

@@ -74,7 +74,7 @@ public:
       g_enc_cpu++;
       strict_check("the lifting / predicting attribute encoder");
     }
-    // RAHT: declined slices (inter prediction, QP regions) are not counted as fall-backs of
+    // RAHT: declined slices (inter prediction) are not counted as fall-backs of
     // this seam -- the reference's driver then calls seam 1, which keeps its own counters
     if (aps.attr_encoding == AttributeEncoding::kRAHTransform
         && raht_on_device(sps, desc, aps, abh, ctxtMem, cloud, payload, inter)) {
@@ -253,8 +253,10 @@ private:
       return false;
     const QpSet qpSet = deriveQpSet(desc, aps, abh);
     gpcc_raht_params rp;
-    // (QP regions: the one-call entry takes the region offsets as zero)
-    if (!qpSet.regions.empty() || !flatten_raht(aps.rahtPredParams, qpSet, aps.raht_extension, inter, &rp))
+    // (QP regions, round 5: the device derives every point's offset from its position, as
+    // qpSet.regionQpOffset does in the reference's drivers, AttributeEncoder.cpp:1262, 1336)
+    gpcc_qp_regions regions;
+    if (!flatten_regions(qpSet, &regions) || !flatten_raht(aps.rahtPredParams, qpSet, aps.raht_extension, inter, &rp))
       return false;
     gpcc_ctx* ctx = process_context("the attribute encoder");
     if (!ctx)
@@ -264,8 +266,8 @@ private:
     attributes_of(cloud, c, &attrs);
     std::vector<int32_t> runs(n), syms(size_t(c) * n);
     int32_t num_symbols = 0, trailing = 0;
-    if (gpcc_raht_encode_attr_packed(
-          ctx, &rp, xyz.data(), attrs.data(), runs.data(), syms.data(), &num_symbols, &trailing, n, c,
+    if (gpcc_raht_encode_attr_packed_regions(
+          ctx, &rp, &regions, xyz.data(), attrs.data(), runs.data(), syms.data(), &num_symbols, &trailing, n, c,
           desc.bitdepth))
       return declined();
     int64_t num_bins = 0;

@@ -248,6 +248,25 @@ flatten_qp(const pcc::QpSet& qpSet, Params* p)
   return true;
 }
 
+// the slice's QP regions for the RAHT slice drivers (gpcc_qp_regions).  false: more regions than the block holds
+inline bool
+flatten_regions(const pcc::QpSet& qpSet, gpcc_qp_regions* p)
+{
+  if (qpSet.regions.size() > GPCC_MAX_QP_REGIONS)
+    return false;
+  *p = gpcc_qp_regions{};
+  p->num_qp_regions = int(qpSet.regions.size());
+  for (int r = 0; r < p->num_qp_regions; r++) {
+    for (int k = 0; k < 3; k++) {
+      p->qp_region_min[r][k] = qpSet.regions[r].region.min[k];
+      p->qp_region_max[r][k] = qpSet.regions[r].region.max[k];
+    }
+    p->qp_region_offset[r][0] = qpSet.regions[r].qpOffset[0];
+    p->qp_region_offset[r][1] = qpSet.regions[r].qpOffset[1];
+  }
+  return true;
+}
+
 inline void
 positions_of(const pcc::PCCPointSet3& cloud, std::vector<int32_t>* xyz)
 {

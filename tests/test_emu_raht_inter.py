@@ -132,3 +132,25 @@ def test_emulated_intra_level_kernels(lib, kw, links, monkeypatch):
         rc, _, dec_e, _, _ = run(lib, "inter_emu_raht", p, False, morton, a_sorted, co_o, morton[:1], a_sorted[:1], -1, 1, 0, 0)
         assert rc == 0
         np.testing.assert_array_equal(dec_e, rec_o, err_msg=f"{name} {kw} decoder")
+
+
+@pytest.mark.parametrize("claim", [3, 8])
+def test_emulated_claims_of_several_rounds(lib, claim, monkeypatch):
+    """the opt-in claim form of the lossy sub-node encoder (raht_subnode.hpp, GPCC_SUB_CLAIM = R consecutive rounds per
+    wavefront, the zero-run state carried between them in registers): measured slower on the MI355X
+    (profiles/r05_claim_rounds_ab.txt) and therefore off, but it stays bit-exact -- noisy attributes at several qp put
+    many coefficients into the RDOQ's undecided band, where the carried state decides"""
+    from mpeg_pcc_tmc13_amd import raht_params, synth
+    monkeypatch.setenv("GPCC_SUB_CLAIM", str(claim))
+    o = ol.oracle()
+    for seed, qp in ((1, 22), (2, 34), (3, 10)):
+        rng = np.random.default_rng(seed)
+        xyz, a = synth.dense_cloud(1500, seed=seed, bits=6)
+        a = np.clip(a[:, :1] + rng.integers(-20, 21, size=(len(a), 1)), 0, 255).astype(np.int32)
+        morton, a_sorted, _ = synth.sort_by_morton(xyz, a)
+        p = raht_params(qp=qp)
+        co_o, rec_o = o.raht_forward(p, morton, a_sorted)
+        rc, co_e, rec_e, _, _ = run(lib, "inter_emu_raht", p, True, morton, a_sorted, None, morton[:1], a_sorted[:1], -1, 1, 0, 0)
+        assert rc == 0
+        np.testing.assert_array_equal(co_e, co_o)
+        np.testing.assert_array_equal(rec_e, rec_o)

@@ -94,3 +94,36 @@ def test_device_tier_with_regions(ctx):
         o_co, o_rec, _ = lh.lift(ol.oracle(), True, lf, o, attrs, qp_off=region_offsets(xyz, regs[i]))
         b = int(offs[i])
         np.testing.assert_array_equal(co[3 * b:3 * (b + sizes[i])].reshape(-1, 3), o_co)
+
+
+@pytest.mark.parametrize("kind,n,c,subnode", [("dense", 50000, 3, True), ("lidar", 40000, 1, True), ("dense", 30000, 3, False)])
+def test_raht_slice_drivers_with_regions(ctx, kind, n, c, subnode):
+    """gpcc_raht_encode_attr_packed_regions / gpcc_raht_decode_attr_regions (round 5): the per-point offsets of
+    qpSet.regionQpOffset derived on the device from the positions -- against the oracle's transform handed the same
+    offsets as an array (Morton order), symbol stream and clipped reconstruction"""
+    from mpeg_pcc_tmc13_amd import raht_params
+    from mpeg_pcc_tmc13_amd.params import qp_regions
+    xyz, attrs = synth.dense_cloud(n, seed=71, bits=9) if kind == "dense" else synth.lidar_cloud(n, seed=71)
+    regs = regions_for(xyz)
+    q = region_offsets(xyz, regs)
+    assert len(np.unique(q, axis=0)) >= 3
+    p = raht_params(qp=34, subnode=subnode, search_range=50000 if kind == "dense" else 2500,
+                    chroma_offset=-1 if c == 3 else 0)
+    morton, a_sorted, order = synth.sort_by_morton(xyz, attrs)
+    o_co, o_rec = ol.oracle().raht_forward(p, morton, a_sorted, qp_off=np.ascontiguousarray(q[order]))
+    runs, vals, trailing, rec = ctx.raht_encode_attr_packed_regions(p, qp_regions(regs), xyz, attrs)
+    # the symbol stream back into the coefficient array (planar [c][n], Morton order)
+    co = np.zeros((len(xyz), c), dtype=np.int32)
+    pos = np.cumsum(runs + 1) - 1
+    co[pos] = vals
+    assert pos[-1] + trailing + 1 == len(xyz) if len(pos) else trailing == len(xyz)
+    np.testing.assert_array_equal(co.T.reshape(-1), o_co)
+    want_rec = np.zeros_like(attrs)
+    want_rec[order] = np.clip(o_rec, 0, 255)
+    np.testing.assert_array_equal(rec, want_rec)
+    np.testing.assert_array_equal(ctx.raht_decode_attr_regions(p, qp_regions(regs), xyz, o_co, c), want_rec)
+    # no regions: the plain entries' result, which is another one
+    runs0, vals0, tr0, rec0 = ctx.raht_encode_attr_packed(p, xyz, attrs)
+    runs1, vals1, tr1, rec1 = ctx.raht_encode_attr_packed_regions(p, None, xyz, attrs)
+    assert np.array_equal(runs0, runs1) and np.array_equal(vals0, vals1) and tr0 == tr1 and np.array_equal(rec0, rec1)
+    assert not (np.array_equal(runs0, runs) and np.array_equal(vals0, vals))

@@ -283,6 +283,12 @@ REGION_CASES = {
     "lifting_refl_region": dict(cloud="lidar", n=50_000, seed=42, transform=2, qp=28, chroma=0, subnode=1, search_range=2500,
                                 region=((0, 0, 0), (120_000, 140_000, 90_000), (5, 0))),
     "pred_dense_ctc_region": dict(transform=1, pred_case="dense_ctc", region=REGION),
+    # round 5: RAHT slices with a QP region stay on the device too (gpcc_raht_encode_attr_packed_regions /
+    # gpcc_raht_decode_attr_regions: the offsets per point derived from the positions)
+    "raht_colour_region": dict(cloud="dense", n=60_000, seed=43, transform=0, qp=34, chroma=-1, subnode=1, search_range=50000,
+                               region=REGION),
+    "raht_refl_sub0_region": dict(cloud="lidar", n=50_000, seed=44, transform=0, qp=28, chroma=0, subnode=0, search_range=2500,
+                                  region=((0, 0, 0), (120_000, 140_000, 90_000), (5, 0))),
 }
 
 
