@@ -854,11 +854,12 @@ typedef struct gpcc_recolour_params {
  * (introsort, not stable beyond 16 entries).  oracle/recolour_oracle.c restates the same and is
  * pinned to the compiled reference (tests/test_oracle_recolour.py); the device equals both
  * (tests/test_gpu_recolour.py).  Needs ns >= num_neighbours_fwd and
- * nt >= num_neighbours_bwd (else GPCC_ERR_UNSUPPORTED); a finite
- * max_geometry_dist2_fwd (< 512) is GPCC_ERR_UNSUPPORTED as well: the reference then
- * shrinks its result vectors for every LATER target point too (they live outside
- * its loop, :292-309), state that is not reproduced; a k-d tree deeper than 64 levels is
- * declined too (the search's stack).  Host tier. */
+ * nt >= num_neighbours_bwd (else GPCC_ERR_UNSUPPORTED).  A finite
+ * max_geometry_dist2_fwd (< 512) is reproduced as the reference behaves (round 5): its result
+ * vectors live outside its loop and its test looks at the farthest neighbour FOUND (:292-313), so
+ * the first target whose k-th neighbour lies beyond the limit shrinks them to one entry for itself
+ * and for every LATER target -- those take the colour of their nearest source point.  A k-d tree
+ * deeper than 64 levels is declined (the search's stack).  Host tier. */
 int gpcc_recolour(
   gpcc_ctx* ctx, const gpcc_recolour_params* params, const int32_t* src_xyz,
   const int32_t* src_attrs, int32_t ns, const int32_t* tgt_xyz, int32_t nt,

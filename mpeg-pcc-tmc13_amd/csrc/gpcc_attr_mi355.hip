@@ -5496,20 +5496,17 @@ recolour_impl(
     return fail(GPCC_ERR_INVALID_ARG, "neighbour counts must be 1..8, bitdepth 1..16, scale > 0");
   if (ns < kf || nt < kb)
     return fail(GPCC_ERR_UNSUPPORTED, "fewer points than neighbours asked for");
-  if (p->max_geometry_dist2_fwd < 512)
-    return fail(
-      GPCC_ERR_UNSUPPORTED,
-      "a finite forward geometry limit makes the reference's result vectors shrink from point "
-      "to point (state carried across the loop): it stays on the reference CPU path");
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
 
   int32_t *d_sx = nullptr, *d_sa = nullptr, *d_tx = nullptr, *d_out = nullptr, *d_box = nullptr;
   int32_t *d_ref1 = nullptr, *d_bt = nullptr, *d_lstart = nullptr, *d_lcur = nullptr, *d_lsrc = nullptr;
+  int32_t* d_near = nullptr;  // finite forward geometry limit: nearest source point per target, then the first limited target
   double *d_bd = nullptr, *d_ldist = nullptr;
   long long* d_sums = nullptr;
   KdAlloc ks, kt;
   auto cleanup = [&]() {
+    pool_free(ctx, d_near);
     for (void* q : {(void*)d_sx, (void*)d_sa, (void*)d_tx, (void*)d_out, (void*)d_box, (void*)d_ref1,
                     (void*)d_bt, (void*)d_lstart, (void*)d_lcur, (void*)d_lsrc, (void*)d_bd, (void*)d_ldist,
                     (void*)d_sums})
@@ -5611,6 +5608,13 @@ recolour_impl(
     HIP_TRY(pool_malloc(ctx, (void**)&d_lsrc, sizeof(int32_t) * total_cap));
     HIP_TRY(pool_malloc(ctx, (void**)&d_sums, sizeof(long long) * (((size_t)nt + 1) / kKdScanBlock + 2)));
     cx.ref1 = d_ref1;
+    if (p->max_geometry_dist2_fwd < 512) {
+      // (round 5: the reference's result vectors shrink for good at the first target beyond the limit)
+      HIP_TRY(pool_malloc(ctx, (void**)&d_near, sizeof(int32_t) * ((size_t)nt + 1)));
+      cx.nearest = d_near;
+      cx.fwd_first = d_near + nt;
+      HIP_TRY(hipMemsetAsync(cx.fwd_first, 0x7f, sizeof(int32_t), st));
+    }
     cx.bt = d_bt;
     cx.bd = d_bd;
     cx.lstart = d_lstart;
@@ -5648,6 +5652,8 @@ recolour_impl(
         GPCC_RC_FWD_K(1);
 #undef GPCC_RC_FWD_K
 #undef GPCC_RC_FWD
+      if (cx.nearest)
+        rc_forward_limit_kernel<<<fgrid, 256, 0, st>>>(cx);
     }
     HIP_TRY(hipMemsetAsync(d_lstart, 0, sizeof(int32_t) * ((size_t)nt + 1), st));
     HIP_TRY(hipMemsetAsync(d_lcur, 0, sizeof(int32_t) * (size_t)nt, st));

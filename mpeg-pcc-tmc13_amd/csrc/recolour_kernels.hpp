@@ -47,6 +47,11 @@ struct RcCtx {
   double* ldist;       // [total]
   int32_t* lsrc;       // [total]
   int32_t* out;        // [nt][c]
+  // a finite max_geometry_dist2_fwd (round 5): every target's nearest source point and the first target whose
+  // k-th neighbour lies beyond the limit -- from there on the reference's shrunk result vectors hold ONE entry
+  // (pointset_processing.cpp:292-313); null without the limit
+  int32_t* nearest;    // [nt]
+  int32_t* fwd_first;  // [1], starts at INT32_MAX
 };
 
 // ---- bounding box ---------------------------------------------------------------
@@ -110,6 +115,11 @@ rc_forward_kernel(RcCtx cx)
     q[a] = (double)(cx.tgt.xyz[3 * t + a] + cx.off[a]) * cx.t2s;
   RcKnn<K> r;
   rc_kd_search<K>(cx.src, q, kf, r);
+  if (cx.nearest) {
+    cx.nearest[t] = r.i[0];
+    if (rc_worst(r, kf) > rc_limit(p.max_geometry_dist2_fwd))
+      atomicMin(cx.fwd_first, t);
+  }
   // the neighbours' attributes, nearest first
   int32_t col[K][C];
 #pragma unroll
@@ -203,6 +213,18 @@ rc_forward_kernel(RcCtx cx)
       out[k] = (int32_t)rc_clip(round(acc[k]), 0.0, clip_max);
     return;
   }
+}
+
+// the targets from the first one beyond a finite forward geometry limit on: the colour of the nearest source
+// point (the reference's result vectors hold one entry from there, pointset_processing.cpp:304-313, 329-334)
+__global__ __launch_bounds__(256) void
+rc_forward_limit_kernel(RcCtx cx)
+{
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= cx.tgt.n || t < *cx.fwd_first)
+    return;
+  for (int k = 0; k < cx.c; k++)
+    cx.ref1[(size_t)t * cx.c + k] = cx.src_attrs[(size_t)cx.nearest[t] * cx.c + k];
 }
 
 // ---- backward (:386-424 / 730-766): nearest targets of every source point ------------

@@ -466,11 +466,15 @@ oracle_recolour(
   const int kf = p->num_neighbours_fwd, kb = p->num_neighbours_bwd;
   if (kf < 1 || kf > RC_MAXK || kb < 1 || kb > RC_MAXK || ns < kf || nt < kb)
     return -2;
-  /* A finite forward geometry limit makes the reference shrink its result vectors
-   * for every LATER target point as well (indicesFwd / sqrDistFwd live outside the
-   * loop, :292-309): state that leaks from point to point, not restated. */
-  if (p->max_geometry_dist2_fwd < 512)
-    return -2;
+  /* A finite forward geometry limit (round 5): indicesFwd / sqrDistFwd live OUTSIDE the reference's loop
+   * (:292-294) and its test (:304-313) looks at the farthest of the k neighbours FOUND
+   * (sqrDistFwd[resultSetFwd.size() - 1]), not at the back of the shrinking vectors -- so the first target
+   * point whose k-th neighbour lies beyond the limit pops the vectors down to ONE entry, and they stay
+   * there: that point and every LATER one take the colour of their nearest source point (nNN =
+   * indicesFwd.size() = 1, :329-334); the points before it are not limited at all.  (The result set still
+   * writes k entries through the vectors' storage; only their size() has changed.) */
+  const double max_g_f = p->max_geometry_dist2_fwd < 512 ? p->max_geometry_dist2_fwd : 1.7976931348623157e308;
+  int fwd_size = kf;
   const double s2t = (double)scale_f;
   const double t2s = 1.0 / s2t;
   const double clip_max = (double)((1 << p->bitdepth) - 1);
@@ -497,13 +501,15 @@ oracle_recolour(
     const int n = kd_search(&gs, q, kf, d2, idx);
     if (n < 0)
       return -5;
+    if (fwd_size > 1 && d2[n - 1] > max_g_f)
+      fwd_size = 1;
     int32_t* out = ref1 + (size_t)t * c;
     if (p->skip_avg_if_identical_fwd && d2[0] < 0.0001) {
       for (int k = 0; k < c; k++)
         out[k] = src_attrs[(size_t)idx[0] * c + k];
       continue;
     }
-    for (int nn = n; nn > 0; nn--) {
+    for (int nn = n < fwd_size ? n : fwd_size; nn > 0; nn--) {
       if (nn == 1) {
         for (int k = 0; k < c; k++)
           out[k] = src_attrs[(size_t)idx[0] * c + k];

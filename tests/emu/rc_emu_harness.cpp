@@ -95,7 +95,7 @@ rc_emu_recolour(
   const int32_t* tgt_xyz, int32_t nt, int32_t c, float scale, const int32_t offset[3], int32_t* tgt_attrs)
 {
   const int kf = p->num_neighbours_fwd, kb = p->num_neighbours_bwd;
-  if (ns < kf || nt < kb || p->max_geometry_dist2_fwd < 512 || (c != 1 && c != 3))
+  if (ns < kf || nt < kb || (c != 1 && c != 3))
     return -2;
   std::vector<void*> blocks;
   int32_t* box = carve<int32_t>(&blocks, 12);
@@ -128,6 +128,11 @@ rc_emu_recolour(
     cx.ldist = carve<double>(&blocks, total_cap);
     cx.lsrc = carve<int32_t>(&blocks, total_cap);
     cx.out = tgt_attrs;
+    if (p->max_geometry_dist2_fwd < 512) {
+      cx.nearest = carve<int32_t>(&blocks, (size_t)nt + 1);
+      cx.fwd_first = cx.nearest + nt;
+      *cx.fwd_first = 0x7f7f7f7f;
+    }
     long long* sums = carve<long long>(&blocks, ((size_t)nt + 1) / kKdScanBlock + 2);
     const bool alimit = p->max_attribute_dist2_fwd < 512;
     const int fgrid = (nt + 255) / 256, bgrid = (ns + 255) / 256;
@@ -143,6 +148,8 @@ rc_emu_recolour(
       else
         hipLaunchKernelGGL(HIP_KERNEL_NAME(rc_forward_kernel<1, 8, false>), dim3(fgrid), dim3(256), 0, nullptr, cx);
     }
+    if (cx.nearest)
+      hipLaunchKernelGGL(rc_forward_limit_kernel, dim3(fgrid), dim3(256), 0, nullptr, cx);
     memset(cx.lstart, 0, sizeof(int32_t) * ((size_t)nt + 1));
     memset(cx.lcur, 0, sizeof(int32_t) * (size_t)nt);
     if (kb <= 1)

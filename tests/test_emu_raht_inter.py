@@ -116,6 +116,8 @@ def test_emulated_intra_level_kernels(lib, kw, links, monkeypatch):
     from mpeg_pcc_tmc13_amd import raht_params, synth
     # (links: the opt-in neighbour links of raht_links.hpp in the dependency kernels -- the library reads the switch
     # at every call)
+    if links and (kw.get("extension") is False or kw.get("subnode") is False):
+        pytest.skip("the links serve the dependency kernels with the RAHT extension only")
     monkeypatch.setenv("GPCC_LINKS", "1" if links else "0")
     o = ol.oracle()
     for name, xyz, attrs in clouds():

@@ -49,7 +49,10 @@ def requantise(xyz, scale):
 CASES = [("dense", 0.5, {}), ("dense", 0.25, dict(k_bwd=2)), ("dense", 1.0, {}), ("dense", 0.37, dict(max_attr_fwd=200.0)),
          ("lidar", 0.25, {}), ("lidar", 0.013, dict(k_fwd=3, skip_fwd=False)),
          ("dense", 0.125, dict(k_bwd=4, max_attr_bwd=400.0)),    # backward lists beyond 16 entries
-         ("dense", 0.5, dict(weighted_fwd=False, weighted_bwd=False, skip_bwd=True, search_range=2))]
+         ("dense", 0.5, dict(weighted_fwd=False, weighted_bwd=False, skip_bwd=True, search_range=2)),
+         # a finite forward geometry limit (round 5): the reference's shrunk result vectors from the first target beyond it
+         ("dense", 0.37, dict(max_geom_fwd=3.0)), ("dense", 0.5, dict(max_geom_fwd=1.5, k_fwd=4)),
+         ("lidar", 0.013, dict(max_geom_fwd=4.0, skip_fwd=False))]
 
 
 @pytest.mark.parametrize("kind,scale,kw", CASES)

@@ -53,10 +53,6 @@ def test_declined_configurations(ctx):
     with pytest.raises(_lib.GpccError) as e:  # fewer source points than neighbours
         ctx.recolour(recolour_params(), xyz, a, xyz)
     assert e.value.code == -2
-    xyz, a = synth.random_cloud(500, seed=2, bits=5, c=3)
-    with pytest.raises(_lib.GpccError) as e:  # the reference's leaking forward geometry limit
-        ctx.recolour(recolour_params(max_geom_fwd=10.0), xyz, a, xyz)
-    assert e.value.code == -2
 
 
 @pytest.mark.skipif(not ol.ref_available(), reason="compiled reference (oracle/_ref) not present")
@@ -64,7 +60,10 @@ def test_declined_configurations(ctx):
     ("dense", 100000, 0.5, {}), ("dense", 100000, 0.25, {}), ("dense", 100000, 1.0, {}), ("dense", 100000, 0.37, {}),
     ("lidar", 100000, 0.013, {}), ("lidar", 100000, 0.25, dict(k_bwd=2)),
     ("dense", 60000, 0.125, dict(k_bwd=4, max_attr_bwd=400.0)),   # backward lists of 60+ entries
-    ("dense", 50000, 0.75, {}), ("dense", 50000, 2.0, {})])
+    ("dense", 50000, 0.75, {}), ("dense", 50000, 2.0, {}),
+    # a finite forward geometry limit (round 5; declined until round 4)
+    ("dense", 60000, 0.37, dict(max_geom_fwd=3.0)), ("dense", 60000, 0.5, dict(max_geom_fwd=1.5, k_fwd=4)),
+    ("lidar", 60000, 0.013, dict(max_geom_fwd=4.0, skip_fwd=False)), ("dense", 40000, 0.37, dict(max_geom_fwd=0.5))])
 def test_against_the_compiled_reference(ctx, kind, n, scale, kw):
     """BASELINE configs[4]'s upstream step at test size: a lossy-geometry target cloud;
     identical to pcc::recolour, ties included"""

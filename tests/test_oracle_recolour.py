@@ -57,6 +57,26 @@ def test_identical_on_dyadic_scales(kind, scale, kw):
     assert np.array_equal(ref, ora)
 
 
+@pytest.mark.parametrize("kind,scale,limit,kw", [
+    ("dense", 0.37, 3.0, {}), ("dense", 0.5, 1.5, dict(k_fwd=4)), ("dense", 0.37, 0.5, {}),   # the first point already
+    ("lidar", 0.013, 4.0, dict(skip_fwd=False)), ("dense", 0.25, 6.0, dict(max_attr_fwd=200.0)),
+    ("dense", 0.37, 500.0, {}),  # finite, never reached
+    ("dense", 0.5, 2.0, dict(k_fwd=1))])
+def test_finite_forward_geometry_limit(kind, scale, limit, kw):
+    """maxGeometryDist2Fwd < 512 (round 5): the reference's result vectors live outside its loop, so the first target
+    whose k-th neighbour lies beyond the limit shrinks them to one entry FOR EVERY LATER TARGET as well
+    (pointset_processing.cpp:292-313) -- restated, and the restatement identical to the compiled reference"""
+    xyz, a = cloud(kind, 20000, 31)
+    tgt = requantise(xyz, scale)
+    p = recolour_params(bitdepth=8, max_geom_fwd=limit, **kw)
+    ref = ol.ref().recolour(p, xyz, a, tgt, scale=scale)
+    ora = ol.oracle().recolour(p, xyz, a, tgt, scale=scale)
+    assert np.array_equal(ref, ora)
+    if limit < 100 and kw.get("k_fwd", 8) > 1 and "max_attr_fwd" not in kw:
+        # the case is not vacuous: the limit changes the result
+        assert not np.array_equal(ref, ol.ref().recolour(recolour_params(bitdepth=8, **kw), xyz, a, tgt, scale=scale))
+
+
 def test_offset_and_bitdepth():
     xyz, a = synth.dense_cloud(8000, seed=9, bits=8, bitdepth=10)
     scale, off = 0.41, (3, -2, 5)
