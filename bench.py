@@ -150,6 +150,7 @@ def timed_stats(torch, dev, fn, steps, warmup=2):
         fn()
         torch.cuda.synchronize(dev)
         ts.append(time.perf_counter() - t0)
+    timed_stats.last_argmax = max(range(len(ts)), key=lambda i: ts[i])  # which step was the slowest
     ts.sort()
     return ts[len(ts) // 2], ts[-1]
 
@@ -642,8 +643,11 @@ def forward_10m(torch, dev, ctx, params_for, first_frames):
         for nf in (1, 2, 5, 10):
             b = Batch(torch, dev, ctx, frames[:nf], p)
             tf, tf_max = timed_stats(torch, dev, b.forward, 10, warmup=2)
+            tf_at = timed_stats.last_argmax
             ti, ti_max = timed_stats(torch, dev, b.inverse, 10, warmup=2)
+            ti_at = timed_stats.last_argmax
             pts.append({"slices": nf, "steps": 10, "forward_ms": round(tf * 1e3, 3), "forward_ms_max": round(tf_max * 1e3, 3),
+                        "forward_slowest_step": tf_at, "inverse_slowest_step": ti_at,
                         "inverse_ms": round(ti * 1e3, 3), "inverse_ms_max": round(ti_max * 1e3, 3),
                         "forward_Mpts": round(b.n / tf / 1e6, 1), "inverse_Mpts": round(b.n / ti / 1e6, 1)})
             del b
