@@ -269,6 +269,10 @@ struct gpcc_ctx {
   bool own_stream = false;
   Arena arena;
   std::vector<size_t> arena_bands;  // guard mode (GPCC_GUARD=1): see Arena
+  // allocation events since the context was made (gpcc_debug_alloc_events): arena (re)allocations, pool misses,
+  // pinned staging (re)allocations -- a step that takes tens of milliseconds longer than its neighbours either shows up here or
+  // was not the library's doing (tools/r05_stall_probe.py)
+  long long alloc_events[4] = {0, 0, 0, 0};
   int morton_bits = 0;  // hint for the device tier, 0 = unknown
   SharedLut* d_lut = nullptr;  // small-weight tables, built once
   int32_t* h_error = nullptr;  // pinned: copy of the sticky device-side error word
@@ -545,6 +549,7 @@ pool_malloc(gpcc_ctx* ctx, void** out, size_t bytes)
     return hipSuccess;
   }
   // a miss: the sizes have changed, drop what is idle before growing
+  ctx->alloc_events[1]++;
   hipStreamSynchronize(ctx->stream);
   for (size_t i = 0; i < ctx->pool.size();) {
     if (!ctx->pool[i].used) {
@@ -765,6 +770,7 @@ ensure_arena(gpcc_ctx* ctx, size_t bytes)
   size_t want = bytes + bytes / 8;
   HIP_TRY(guarded_malloc((void**)&ctx->arena.base, want, "arena"));
   ctx->arena.cap = want;
+  ctx->alloc_events[0]++;
   return GPCC_OK;
 }
 
@@ -823,6 +829,7 @@ launch_transform(
     if (ctx->h_pinned)
       HIP_TRY(hipHostFree(ctx->h_pinned));
     HIP_TRY(hipHostMalloc(&ctx->h_pinned, stage_bytes * 2));
+    ctx->alloc_events[3]++;
     ctx->h_pinned_cap = stage_bytes * 2;
   } else {
     // the previous call's async copies read this buffer
@@ -1181,6 +1188,7 @@ launch_cx(
     ctx->h_cx_stage = nullptr;
     ctx->h_cx_stage_cap = 0;
     HIP_TRY(hipHostMalloc(&ctx->h_cx_stage, stage_bytes * 4));
+    ctx->alloc_events[2]++;
     ctx->h_cx_stage_cap = stage_bytes * 2;
   }
   ctx->cx_stage_flip ^= 1;
@@ -2561,6 +2569,17 @@ gpcc_ctx_synchronize(gpcc_ctx* ctx)
   if (guard_mode())
     guard_check_context(ctx, "gpcc_ctx_synchronize");
   return check_device_error(ctx);
+}
+
+// {arena (re)allocations, pool misses, compact-pass staging reallocations, level-pass staging reallocations}
+extern "C" int
+gpcc_debug_alloc_events(const gpcc_ctx* ctx, long long out[4])
+{
+  if (!ctx || !out)
+    return fail(GPCC_ERR_INVALID_ARG, "ctx / out is null");
+  for (int i = 0; i < 4; i++)
+    out[i] = ctx->alloc_events[i];
+  return GPCC_OK;
 }
 
 // bands compared so far in this process (0 unless GPCC_GUARD=1): lets a test tier prove the guards were armed
@@ -5659,12 +5678,12 @@ recolour_impl(
     HIP_TRY(hipMemsetAsync(d_lcur, 0, sizeof(int32_t) * (size_t)nt, st));
     {
       Timer t(ctx, "rc_backward");
-      const int bgrid = (ns + 255) / 256;
+      const int bgrid = (ns + kKdSearchThreads - 1) / kKdSearchThreads;
       switch (kb <= 1 ? 1 : kb <= 2 ? 2 : kb <= 4 ? 4 : 8) {
-      case 1: rc_backward_kernel<1><<<bgrid, 256, 0, st>>>(cx); break;
-      case 2: rc_backward_kernel<2><<<bgrid, 256, 0, st>>>(cx); break;
-      case 4: rc_backward_kernel<4><<<bgrid, 256, 0, st>>>(cx); break;
-      default: rc_backward_kernel<8><<<bgrid, 256, 0, st>>>(cx); break;
+      case 1: rc_backward_kernel<1><<<bgrid, kKdSearchThreads, 0, st>>>(cx); break;
+      case 2: rc_backward_kernel<2><<<bgrid, kKdSearchThreads, 0, st>>>(cx); break;
+      case 4: rc_backward_kernel<4><<<bgrid, kKdSearchThreads, 0, st>>>(cx); break;
+      default: rc_backward_kernel<8><<<bgrid, kKdSearchThreads, 0, st>>>(cx); break;
       }
     }
     {

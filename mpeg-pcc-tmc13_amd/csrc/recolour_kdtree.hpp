@@ -34,7 +34,23 @@
 namespace gpcc {
 
 constexpr int kKdLeaf = 10;       // KDTreeVectorOfVectorsAdaptor(3, cloud, 10)
-constexpr int kKdMaxDepth = 64;   // deeper trees are declined (the search stack lives in scratch)
+constexpr int kKdMaxDepth = 64;   // deeper trees are declined (the search's frames: LDS, then scratch)
+// Frames of the search's recursion that live in LDS, per lane; deeper ones (a tree of 1 M points is ~20 levels
+// deep) fall back to scratch.  Round 5: until then ALL frames lived in scratch -- 1 472 bytes per lane, indexed by
+// the lane's own stack pointer -- and the counters showed what that costs: rc_forward moved 13.8 GB in + 8.2 GB
+// out per call of a 1 M-point cloud (44 MB algorithmic), 88 % of its wave cycles waiting
+// (profiles/r05_pmc_legs.txt).  One wavefront per workgroup: 24 frames x 20 bytes x 64 lanes = 30 KB.
+#ifndef GPCC_KD_LDS_DEPTH  // (the emulator tier builds a second library with 4: every search then uses the scratch frames too)
+#define GPCC_KD_LDS_DEPTH 24
+#endif
+constexpr int kKdLdsDepth = GPCC_KD_LDS_DEPTH;
+constexpr int kKdSearchThreads = 64;
+
+struct KdLdsStack {
+  int32_t node[kKdLdsDepth][kKdSearchThreads];   // node << 2 | phase
+  double mind[kKdLdsDepth][kKdSearchThreads];    // mindistsq the node was entered with
+  double dst[kKdLdsDepth][kKdSearchThreads];     // the entry of dists[] the second descent replaced
+};
 constexpr int kKdScanBlock = 2048;
 // A node of at most this many points leaves the level-by-level build: ONE WAVEFRONT finishes its
 // whole subtree in LDS (kd_subtree_kernel) -- the lower two thirds of a tree's levels in one launch.
@@ -957,9 +973,10 @@ rc_worst(const RcKnn<K>& r, int k)
 // dists[] that the second descent replaced.  phase 0 = entered, 1 = nearer child done, 2 = both.
 template<int K>
 __device__ __forceinline__ void
-rc_kd_search(const KdTree& t, const double q[3], int k, RcKnn<K>& r)
+rc_kd_search(const KdTree& t, const double q[3], int k, RcKnn<K>& r, KdLdsStack& ls)
 {
 #pragma clang fp contract(off)
+  const int ln = threadIdx.x & (kKdSearchThreads - 1);
   r.count = 0;
 #pragma unroll
   for (int p = 0; p < K; p++) {
@@ -979,14 +996,37 @@ rc_kd_search(const KdTree& t, const double q[3], int k, RcKnn<K>& r)
       distsq += dists[a];
     }
   }
-  int32_t st_node[kKdMaxDepth + 1];  // node << 2 | phase
-  double st_mind[kKdMaxDepth + 1], st_dst[kKdMaxDepth + 1];
+  // frames 0 .. kKdLdsDepth - 1 in LDS (lane-interleaved: no bank conflicts), the rest in scratch
+  constexpr int kDeep = kKdMaxDepth + 1 - kKdLdsDepth;
+  int32_t dp_node[kDeep];
+  double dp_mind[kDeep], dp_dst[kDeep];
+  auto get_node = [&](int i) -> int32_t { return i < kKdLdsDepth ? ls.node[i][ln] : dp_node[i - kKdLdsDepth]; };
+  auto get_mind = [&](int i) -> double { return i < kKdLdsDepth ? ls.mind[i][ln] : dp_mind[i - kKdLdsDepth]; };
+  auto get_dst = [&](int i) -> double { return i < kKdLdsDepth ? ls.dst[i][ln] : dp_dst[i - kKdLdsDepth]; };
+  auto set_node = [&](int i, int32_t v) {
+    if (i < kKdLdsDepth)
+      ls.node[i][ln] = v;
+    else
+      dp_node[i - kKdLdsDepth] = v;
+  };
+  auto set_mind = [&](int i, double v) {
+    if (i < kKdLdsDepth)
+      ls.mind[i][ln] = v;
+    else
+      dp_mind[i - kKdLdsDepth] = v;
+  };
+  auto set_dst = [&](int i, double v) {
+    if (i < kKdLdsDepth)
+      ls.dst[i][ln] = v;
+    else
+      dp_dst[i - kKdLdsDepth] = v;
+  };
   int sp = 0;
-  st_node[0] = 0;
-  st_mind[0] = distsq;
-  st_dst[0] = 0.0;
+  set_node(0, 0);
+  set_mind(0, distsq);
+  set_dst(0, 0.0);
   while (sp >= 0) {
-    const int32_t word = st_node[sp];
+    const int32_t word = get_node(sp);
     const int phase = word & 3;
     const KdNode nd = t.nodes[word >> 2];
     if (nd.feat < 0) {
@@ -1011,27 +1051,27 @@ rc_kd_search(const KdTree& t, const double q[3], int k, RcKnn<K>& r)
     const double diff1 = val - nd.divlow, diff2 = val - nd.divhigh;
     const bool first_is_1 = (diff1 + diff2) < 0;
     if (phase == 0) {
-      st_node[sp] = word | 1;
-      st_node[sp + 1] = (first_is_1 ? nd.a : nd.a + 1) << 2;
-      st_mind[sp + 1] = st_mind[sp];
+      set_node(sp, word | 1);
+      set_node(sp + 1, (first_is_1 ? nd.a : nd.a + 1) << 2);
+      set_mind(sp + 1, get_mind(sp));
       sp++;
     } else if (phase == 1) {
       const double cut_dist = first_is_1 ? (val - nd.divhigh) * (val - nd.divhigh)
                                          : (val - nd.divlow) * (val - nd.divlow);
       const double dst = f == 0 ? dists[0] : (f == 1 ? dists[1] : dists[2]);
-      const double mind = st_mind[sp] + cut_dist - dst;
+      const double mind = get_mind(sp) + cut_dist - dst;
 #pragma unroll
       for (int a = 0; a < 3; a++)
         dists[a] = f == a ? cut_dist : dists[a];
-      st_dst[sp] = dst;
-      st_node[sp] = (word & ~3) | 2;
+      set_dst(sp, dst);
+      set_node(sp, (word & ~3) | 2);
       if (mind <= rc_worst(r, k)) {
-        st_node[sp + 1] = (first_is_1 ? nd.a + 1 : nd.a) << 2;
-        st_mind[sp + 1] = mind;
+        set_node(sp + 1, (first_is_1 ? nd.a + 1 : nd.a) << 2);
+        set_mind(sp + 1, mind);
         sp++;
       }
     } else {
-      const double dst = st_dst[sp];
+      const double dst = get_dst(sp);
 #pragma unroll
       for (int a = 0; a < 3; a++)
         dists[a] = f == a ? dst : dists[a];

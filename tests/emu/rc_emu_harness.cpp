@@ -136,28 +136,29 @@ rc_emu_recolour(
     long long* sums = carve<long long>(&blocks, ((size_t)nt + 1) / kKdScanBlock + 2);
     const bool alimit = p->max_attribute_dist2_fwd < 512;
     const int fgrid = (nt + 255) / 256, bgrid = (ns + 255) / 256;
+    const int sfgrid = (nt + kKdSearchThreads - 1) / kKdSearchThreads, sbgrid = (ns + kKdSearchThreads - 1) / kKdSearchThreads;
     // (the emulator runs one instantiation per list capacity: 8 covers every k)
     if (c == 3) {
       if (alimit)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(rc_forward_kernel<3, 8, true>), dim3(fgrid), dim3(256), 0, nullptr, cx);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(rc_forward_kernel<3, 8, true>), dim3(sfgrid), dim3(kKdSearchThreads), 0, nullptr, cx);
       else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(rc_forward_kernel<3, 8, false>), dim3(fgrid), dim3(256), 0, nullptr, cx);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(rc_forward_kernel<3, 8, false>), dim3(sfgrid), dim3(kKdSearchThreads), 0, nullptr, cx);
     } else {
       if (alimit)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(rc_forward_kernel<1, 8, true>), dim3(fgrid), dim3(256), 0, nullptr, cx);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(rc_forward_kernel<1, 8, true>), dim3(sfgrid), dim3(kKdSearchThreads), 0, nullptr, cx);
       else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(rc_forward_kernel<1, 8, false>), dim3(fgrid), dim3(256), 0, nullptr, cx);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(rc_forward_kernel<1, 8, false>), dim3(sfgrid), dim3(kKdSearchThreads), 0, nullptr, cx);
     }
     if (cx.nearest)
       hipLaunchKernelGGL(rc_forward_limit_kernel, dim3(fgrid), dim3(256), 0, nullptr, cx);
     memset(cx.lstart, 0, sizeof(int32_t) * ((size_t)nt + 1));
     memset(cx.lcur, 0, sizeof(int32_t) * (size_t)nt);
     if (kb <= 1)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(rc_backward_kernel<1>), dim3(bgrid), dim3(256), 0, nullptr, cx);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(rc_backward_kernel<1>), dim3(sbgrid), dim3(kKdSearchThreads), 0, nullptr, cx);
     else if (kb <= 4)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(rc_backward_kernel<4>), dim3(bgrid), dim3(256), 0, nullptr, cx);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(rc_backward_kernel<4>), dim3(sbgrid), dim3(kKdSearchThreads), 0, nullptr, cx);
     else
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(rc_backward_kernel<8>), dim3(bgrid), dim3(256), 0, nullptr, cx);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(rc_backward_kernel<8>), dim3(sbgrid), dim3(kKdSearchThreads), 0, nullptr, cx);
     kd_scan(nullptr, cx.lstart, (size_t)nt + 1, sums);
     hipLaunchKernelGGL(rc_list_fill_kernel, dim3(bgrid), dim3(256), 0, nullptr, cx);
     if (c == 3)

@@ -19,7 +19,12 @@ for w in $WL; do
     legs)       B="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-profile --legs lifting,predicting,recolour,raht_inter" ;;
   esac
   R=$GRAFT_REPO_ROOT
-  ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $R/$OUT/kt_$w -o kt -- bash -c "cd $R && $B" > $R/$OUT/kt_$w.log 2>&1 )
+  ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/kt_$w -o kt -- bash -c "cd $R && $B" > $R/$OUT/kt_$w.log 2>&1 )
+  if [ "${KT_ONLY:-0}" = 1 ]; then
+    find $OUT/kt_$w -name '*kernel_stats*.csv' -exec cp {} $OUT/kernel_stats_$w.csv \; 2>/dev/null
+    rm -rf $OUT/kt_$w
+    continue
+  fi
   ( cd /tmp && timeout 400 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_LDS -d $R/$OUT/sq_$w -o sq -- bash -c "cd $R && $B" > $R/$OUT/sq_$w.log 2>&1 )
   ( cd /tmp && timeout 400 rocprofv3 --pmc FETCH_SIZE -d $R/$OUT/fe_$w -o f -- bash -c "cd $R && $B" > $R/$OUT/fe_$w.log 2>&1 )
   ( cd /tmp && timeout 400 rocprofv3 --pmc WRITE_SIZE -d $R/$OUT/wr_$w -o w -- bash -c "cd $R && $B" > $R/$OUT/wr_$w.log 2>&1 )
