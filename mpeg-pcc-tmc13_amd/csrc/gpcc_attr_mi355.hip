@@ -5561,6 +5561,7 @@ recolour_impl(
         return fail(GPCC_ERR_INVALID_ARG, "coordinates outside (-2^30, 2^30)");
 
     RcCtx cx{};
+    int src_depth = 0, tgt_depth = 0;  // levels of the two k-d trees (the search's frames: LDS up to kKdLdsDepth)
     cx.p = *p;
     cx.c = c;
     cx.s2t = (double)scale;
@@ -5605,6 +5606,7 @@ recolour_impl(
       for (int which = 0; which < 2; which++) {
         if (loop[which].tree_depth() > kKdMaxDepth)
           return fail(GPCC_ERR_UNSUPPORTED, "k-d tree deeper than 64 levels: it stays on the reference CPU path");
+        (which ? tgt_depth : src_depth) = loop[which].tree_depth();
         KdAlloc& ka = which ? kt : ks;
         KdTree& tr = which ? cx.tgt : cx.src;
         tr = ka.b.t;
@@ -5665,7 +5667,13 @@ recolour_impl(
     default: GPCC_RC_FWD(CC, 8); break;                                    \
     }                                                                      \
   } while (0)
-      if (c == 3)
+      if (src_depth > kKdLdsDepth) {
+        // a source tree deeper than the LDS frames hold: the scratch form (one generic instantiation)
+        if (c == 3)
+          rc_forward_kernel<3, 8, true, false><<<fgrid, 256, 0, st>>>(cx);
+        else
+          rc_forward_kernel<1, 8, true, false><<<fgrid, 256, 0, st>>>(cx);
+      } else if (c == 3)
         GPCC_RC_FWD_K(3);
       else
         GPCC_RC_FWD_K(1);
@@ -5679,6 +5687,9 @@ recolour_impl(
     {
       Timer t(ctx, "rc_backward");
       const int bgrid = (ns + kKdSearchThreads - 1) / kKdSearchThreads;
+      if (tgt_depth > kKdLdsDepth)
+        rc_backward_kernel<8, false><<<(ns + 255) / 256, 256, 0, st>>>(cx);
+      else
       switch (kb <= 1 ? 1 : kb <= 2 ? 2 : kb <= 4 ? 4 : 8) {
       case 1: rc_backward_kernel<1><<<bgrid, kKdSearchThreads, 0, st>>>(cx); break;
       case 2: rc_backward_kernel<2><<<bgrid, kKdSearchThreads, 0, st>>>(cx); break;

@@ -35,12 +35,12 @@ namespace gpcc {
 
 constexpr int kKdLeaf = 10;       // KDTreeVectorOfVectorsAdaptor(3, cloud, 10)
 constexpr int kKdMaxDepth = 64;   // deeper trees are declined (the search's frames: LDS, then scratch)
-// Frames of the search's recursion that live in LDS, per lane; deeper ones (a tree of 1 M points is ~20 levels
-// deep) fall back to scratch.  Round 5: until then ALL frames lived in scratch -- 1 472 bytes per lane, indexed by
+// Frames of the search's recursion that live in LDS, per lane; a tree with more levels (one of 1 M points has
+// ~20) is searched by the instantiation that keeps them in scratch.  Round 5: until then ALL frames lived in scratch -- 1 472 bytes per lane, indexed by
 // the lane's own stack pointer -- and the counters showed what that costs: rc_forward moved 13.8 GB in + 8.2 GB
 // out per call of a 1 M-point cloud (44 MB algorithmic), 88 % of its wave cycles waiting
 // (profiles/r05_pmc_legs.txt).  One wavefront per workgroup: 24 frames x 20 bytes x 64 lanes = 30 KB.
-#ifndef GPCC_KD_LDS_DEPTH  // (the emulator tier builds a second library with 4: every search then uses the scratch frames too)
+#ifndef GPCC_KD_LDS_DEPTH  // (the emulator tier builds a second library with 4: its trees then take the scratch form)
 #define GPCC_KD_LDS_DEPTH 24
 #endif
 constexpr int kKdLdsDepth = GPCC_KD_LDS_DEPTH;
@@ -971,7 +971,11 @@ rc_worst(const RcKnn<K>& r, int k)
 // findNeighbors (:1200-1215) + searchLevel (:1308-1365).  The recursion's frames: the node, the
 // mindistsq it was entered with, and -- once its nearer child has returned -- the entry of
 // dists[] that the second descent replaced.  phase 0 = entered, 1 = nearer child done, 2 = both.
-template<int K>
+// LDSF: the frames live in LDS (trees of at most kKdLdsDepth levels -- the host knows the depth when it
+// launches); otherwise in scratch as until round 4 (deeper trees).  Two instantiations rather than two homes
+// behind one accessor: with both in one function the compiler folds them into flat accesses through a
+// selected generic pointer, which faulted on the MI355X.
+template<int K, bool LDSF>
 __device__ __forceinline__ void
 rc_kd_search(const KdTree& t, const double q[3], int k, RcKnn<K>& r, KdLdsStack& ls)
 {
@@ -996,31 +1000,51 @@ rc_kd_search(const KdTree& t, const double q[3], int k, RcKnn<K>& r, KdLdsStack&
       distsq += dists[a];
     }
   }
-  // frames 0 .. kKdLdsDepth - 1 in LDS (lane-interleaved: no bank conflicts), the rest in scratch
-  constexpr int kDeep = kKdMaxDepth + 1 - kKdLdsDepth;
+  constexpr int kDeep = LDSF ? 1 : kKdMaxDepth + 1;
   int32_t dp_node[kDeep];
   double dp_mind[kDeep], dp_dst[kDeep];
-  auto get_node = [&](int i) -> int32_t { return i < kKdLdsDepth ? ls.node[i][ln] : dp_node[i - kKdLdsDepth]; };
-  auto get_mind = [&](int i) -> double { return i < kKdLdsDepth ? ls.mind[i][ln] : dp_mind[i - kKdLdsDepth]; };
-  auto get_dst = [&](int i) -> double { return i < kKdLdsDepth ? ls.dst[i][ln] : dp_dst[i - kKdLdsDepth]; };
+  auto get_node = [&](int i) -> int32_t {
+    if constexpr (LDSF)
+      return ls.node[i][ln];
+    else
+      return dp_node[i];
+  };
+  auto get_mind = [&](int i) -> double {
+    if constexpr (LDSF)
+      return ls.mind[i][ln];
+    else
+      return dp_mind[i];
+  };
+  auto get_dst = [&](int i) -> double {
+    if constexpr (LDSF)
+      return ls.dst[i][ln];
+    else
+      return dp_dst[i];
+  };
   auto set_node = [&](int i, int32_t v) {
-    if (i < kKdLdsDepth)
+    if constexpr (LDSF)
       ls.node[i][ln] = v;
     else
-      dp_node[i - kKdLdsDepth] = v;
+      dp_node[i] = v;
   };
   auto set_mind = [&](int i, double v) {
-    if (i < kKdLdsDepth)
+    if constexpr (LDSF)
       ls.mind[i][ln] = v;
     else
-      dp_mind[i - kKdLdsDepth] = v;
+      dp_mind[i] = v;
   };
   auto set_dst = [&](int i, double v) {
-    if (i < kKdLdsDepth)
+    if constexpr (LDSF)
       ls.dst[i][ln] = v;
     else
-      dp_dst[i - kKdLdsDepth] = v;
+      dp_dst[i] = v;
   };
+  // the query's coordinates as three registers: selected by the split dimension at every node -- left as an
+  // array the compiler keeps a copy in scratch and indexes it, a memory round trip per node visited
+  double q0 = q[0], q1 = q[1], q2 = q[2];
+#ifndef GPCC_EMU
+  asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2));
+#endif
   int sp = 0;
   set_node(0, 0);
   set_mind(0, distsq);
@@ -1047,7 +1071,7 @@ rc_kd_search(const KdTree& t, const double q[3], int k, RcKnn<K>& r, KdLdsStack&
       continue;
     }
     const int f = nd.feat;
-    const double val = f == 0 ? q[0] : (f == 1 ? q[1] : q[2]);
+    const double val = f == 0 ? q0 : (f == 1 ? q1 : q2);
     const double diff1 = val - nd.divlow, diff2 = val - nd.divhigh;
     const bool first_is_1 = (diff1 + diff2) < 0;
     if (phase == 0) {

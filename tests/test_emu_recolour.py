@@ -97,8 +97,9 @@ def test_several_levels_above_the_subtrees():
 
 
 def test_search_frames_beyond_lds():
-    """round 5: the search's frames live in LDS (24 per lane), deeper ones in scratch; a second build of the emulated
-    kernels keeps FOUR in LDS, so every search runs through the scratch frames as well -- same result"""
+    """round 5: the search's frames live in LDS (trees of at most 24 levels), deeper trees take the instantiation with
+    the frames in scratch; a second build of the emulated kernels draws that line at FOUR levels, so these trees take
+    the scratch form -- same result"""
     subprocess.run(["make", "-s", "-C", EMU_DIR, "librc_emu_d4.so"], check=True, stdout=subprocess.DEVNULL)
     l4 = C.CDLL(os.path.join(EMU_DIR, "librc_emu_d4.so"))
     l4.rc_emu_recolour.restype = C.c_int
