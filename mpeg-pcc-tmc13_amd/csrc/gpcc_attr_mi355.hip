@@ -5561,7 +5561,7 @@ recolour_impl(
         return fail(GPCC_ERR_INVALID_ARG, "coordinates outside (-2^30, 2^30)");
 
     RcCtx cx{};
-    int src_depth = 0, tgt_depth = 0;  // levels of the two k-d trees (the search's frames: LDS up to kKdLdsDepth)
+    int src_depth = 0, tgt_depth = 0;  // levels of the two k-d trees (GPCC_RC_DEBUG prints them)
     cx.p = *p;
     cx.c = c;
     cx.s2t = (double)scale;
@@ -5619,6 +5619,27 @@ recolour_impl(
         ka.blocks.push_back((void*)tr.nodes);
       }
     }
+    static const bool rc_debug = [] {
+      const char* e = getenv("GPCC_RC_DEBUG");
+      return e && e[0] == '1';
+    }();
+    // (GPCC_RC_DEBUG=1: the trees' depths and a synchronisation + error check behind every stage)
+    auto stage_check = [&](const char* what) -> int {
+      if (!rc_debug)
+        return GPCC_OK;
+      hipError_t e = hipStreamSynchronize(st);
+      if (e == hipSuccess)
+        e = hipDeviceSynchronize();
+      if (e == hipSuccess)
+        e = hipGetLastError();
+      fprintf(stderr, "gpcc recolour: %s: %s (ns %d nt %d depths %d %d)\n", what, hipGetErrorString(e), ns, nt, src_depth, tgt_depth);
+      return e == hipSuccess ? GPCC_OK : fail(GPCC_ERR_HIP, std::string("recolour stage ") + what + ": " + hipGetErrorString(e));
+    };
+    {
+      int rd = stage_check("trees");
+      if (rd)
+        return rd;
+    }
     const size_t total_cap = (size_t)ns * kb;
     HIP_TRY(pool_malloc(ctx, (void**)&d_ref1, sizeof(int32_t) * (size_t)c * nt));
     HIP_TRY(pool_malloc(ctx, (void**)&d_bt, sizeof(int32_t) * total_cap));
@@ -5667,13 +5688,7 @@ recolour_impl(
     default: GPCC_RC_FWD(CC, 8); break;                                    \
     }                                                                      \
   } while (0)
-      if (src_depth > kKdLdsDepth) {
-        // a source tree deeper than the LDS frames hold: the scratch form (one generic instantiation)
-        if (c == 3)
-          rc_forward_kernel<3, 8, true, false><<<fgrid, 256, 0, st>>>(cx);
-        else
-          rc_forward_kernel<1, 8, true, false><<<fgrid, 256, 0, st>>>(cx);
-      } else if (c == 3)
+      if (c == 3)
         GPCC_RC_FWD_K(3);
       else
         GPCC_RC_FWD_K(1);
@@ -5682,20 +5697,27 @@ recolour_impl(
       if (cx.nearest)
         rc_forward_limit_kernel<<<fgrid, 256, 0, st>>>(cx);
     }
+    {
+      int rd = stage_check("forward");
+      if (rd)
+        return rd;
+    }
     HIP_TRY(hipMemsetAsync(d_lstart, 0, sizeof(int32_t) * ((size_t)nt + 1), st));
     HIP_TRY(hipMemsetAsync(d_lcur, 0, sizeof(int32_t) * (size_t)nt, st));
     {
       Timer t(ctx, "rc_backward");
-      const int bgrid = (ns + kKdSearchThreads - 1) / kKdSearchThreads;
-      if (tgt_depth > kKdLdsDepth)
-        rc_backward_kernel<8, false><<<(ns + 255) / 256, 256, 0, st>>>(cx);
-      else
+      const int bgrid = (ns + 255) / 256;
       switch (kb <= 1 ? 1 : kb <= 2 ? 2 : kb <= 4 ? 4 : 8) {
-      case 1: rc_backward_kernel<1><<<bgrid, kKdSearchThreads, 0, st>>>(cx); break;
-      case 2: rc_backward_kernel<2><<<bgrid, kKdSearchThreads, 0, st>>>(cx); break;
-      case 4: rc_backward_kernel<4><<<bgrid, kKdSearchThreads, 0, st>>>(cx); break;
-      default: rc_backward_kernel<8><<<bgrid, kKdSearchThreads, 0, st>>>(cx); break;
+      case 1: rc_backward_kernel<1><<<bgrid, 256, 0, st>>>(cx); break;
+      case 2: rc_backward_kernel<2><<<bgrid, 256, 0, st>>>(cx); break;
+      case 4: rc_backward_kernel<4><<<bgrid, 256, 0, st>>>(cx); break;
+      default: rc_backward_kernel<8><<<bgrid, 256, 0, st>>>(cx); break;
       }
+    }
+    {
+      int rd = stage_check("backward");
+      if (rd)
+        return rd;
     }
     {
       Timer t(ctx, "rc_lists");

@@ -34,23 +34,7 @@
 namespace gpcc {
 
 constexpr int kKdLeaf = 10;       // KDTreeVectorOfVectorsAdaptor(3, cloud, 10)
-constexpr int kKdMaxDepth = 64;   // deeper trees are declined (the search's frames: LDS, then scratch)
-// Frames of the search's recursion that live in LDS, per lane; a tree with more levels (one of 1 M points has
-// ~20) is searched by the instantiation that keeps them in scratch.  Round 5: until then ALL frames lived in scratch -- 1 472 bytes per lane, indexed by
-// the lane's own stack pointer -- and the counters showed what that costs: rc_forward moved 13.8 GB in + 8.2 GB
-// out per call of a 1 M-point cloud (44 MB algorithmic), 88 % of its wave cycles waiting
-// (profiles/r05_pmc_legs.txt).  One wavefront per workgroup: 24 frames x 20 bytes x 64 lanes = 30 KB.
-#ifndef GPCC_KD_LDS_DEPTH  // (the emulator tier builds a second library with 4: its trees then take the scratch form)
-#define GPCC_KD_LDS_DEPTH 24
-#endif
-constexpr int kKdLdsDepth = GPCC_KD_LDS_DEPTH;
-constexpr int kKdSearchThreads = 64;
-
-struct KdLdsStack {
-  int32_t node[kKdLdsDepth][kKdSearchThreads];   // node << 2 | phase
-  double mind[kKdLdsDepth][kKdSearchThreads];    // mindistsq the node was entered with
-  double dst[kKdLdsDepth][kKdSearchThreads];     // the entry of dists[] the second descent replaced
-};
+constexpr int kKdMaxDepth = 64;   // deeper trees are declined (the search stack lives in scratch)
 constexpr int kKdScanBlock = 2048;
 // A node of at most this many points leaves the level-by-level build: ONE WAVEFRONT finishes its
 // whole subtree in LDS (kd_subtree_kernel) -- the lower two thirds of a tree's levels in one launch.
@@ -971,16 +955,11 @@ rc_worst(const RcKnn<K>& r, int k)
 // findNeighbors (:1200-1215) + searchLevel (:1308-1365).  The recursion's frames: the node, the
 // mindistsq it was entered with, and -- once its nearer child has returned -- the entry of
 // dists[] that the second descent replaced.  phase 0 = entered, 1 = nearer child done, 2 = both.
-// LDSF: the frames live in LDS (trees of at most kKdLdsDepth levels -- the host knows the depth when it
-// launches); otherwise in scratch as until round 4 (deeper trees).  Two instantiations rather than two homes
-// behind one accessor: with both in one function the compiler folds them into flat accesses through a
-// selected generic pointer, which faulted on the MI355X.
-template<int K, bool LDSF>
+template<int K>
 __device__ __forceinline__ void
-rc_kd_search(const KdTree& t, const double q[3], int k, RcKnn<K>& r, KdLdsStack& ls)
+rc_kd_search(const KdTree& t, const double q[3], int k, RcKnn<K>& r)
 {
 #pragma clang fp contract(off)
-  const int ln = threadIdx.x & (kKdSearchThreads - 1);
   r.count = 0;
 #pragma unroll
   for (int p = 0; p < K; p++) {
@@ -1000,57 +979,14 @@ rc_kd_search(const KdTree& t, const double q[3], int k, RcKnn<K>& r, KdLdsStack&
       distsq += dists[a];
     }
   }
-  constexpr int kDeep = LDSF ? 1 : kKdMaxDepth + 1;
-  int32_t dp_node[kDeep];
-  double dp_mind[kDeep], dp_dst[kDeep];
-  auto get_node = [&](int i) -> int32_t {
-    if constexpr (LDSF)
-      return ls.node[i][ln];
-    else
-      return dp_node[i];
-  };
-  auto get_mind = [&](int i) -> double {
-    if constexpr (LDSF)
-      return ls.mind[i][ln];
-    else
-      return dp_mind[i];
-  };
-  auto get_dst = [&](int i) -> double {
-    if constexpr (LDSF)
-      return ls.dst[i][ln];
-    else
-      return dp_dst[i];
-  };
-  auto set_node = [&](int i, int32_t v) {
-    if constexpr (LDSF)
-      ls.node[i][ln] = v;
-    else
-      dp_node[i] = v;
-  };
-  auto set_mind = [&](int i, double v) {
-    if constexpr (LDSF)
-      ls.mind[i][ln] = v;
-    else
-      dp_mind[i] = v;
-  };
-  auto set_dst = [&](int i, double v) {
-    if constexpr (LDSF)
-      ls.dst[i][ln] = v;
-    else
-      dp_dst[i] = v;
-  };
-  // the query's coordinates as three registers: selected by the split dimension at every node -- left as an
-  // array the compiler keeps a copy in scratch and indexes it, a memory round trip per node visited
-  double q0 = q[0], q1 = q[1], q2 = q[2];
-#ifndef GPCC_EMU
-  asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2));
-#endif
+  int32_t st_node[kKdMaxDepth + 1];  // node << 2 | phase
+  double st_mind[kKdMaxDepth + 1], st_dst[kKdMaxDepth + 1];
   int sp = 0;
-  set_node(0, 0);
-  set_mind(0, distsq);
-  set_dst(0, 0.0);
+  st_node[0] = 0;
+  st_mind[0] = distsq;
+  st_dst[0] = 0.0;
   while (sp >= 0) {
-    const int32_t word = get_node(sp);
+    const int32_t word = st_node[sp];
     const int phase = word & 3;
     const KdNode nd = t.nodes[word >> 2];
     if (nd.feat < 0) {
@@ -1071,31 +1007,31 @@ rc_kd_search(const KdTree& t, const double q[3], int k, RcKnn<K>& r, KdLdsStack&
       continue;
     }
     const int f = nd.feat;
-    const double val = f == 0 ? q0 : (f == 1 ? q1 : q2);
+    const double val = f == 0 ? q[0] : (f == 1 ? q[1] : q[2]);
     const double diff1 = val - nd.divlow, diff2 = val - nd.divhigh;
     const bool first_is_1 = (diff1 + diff2) < 0;
     if (phase == 0) {
-      set_node(sp, word | 1);
-      set_node(sp + 1, (first_is_1 ? nd.a : nd.a + 1) << 2);
-      set_mind(sp + 1, get_mind(sp));
+      st_node[sp] = word | 1;
+      st_node[sp + 1] = (first_is_1 ? nd.a : nd.a + 1) << 2;
+      st_mind[sp + 1] = st_mind[sp];
       sp++;
     } else if (phase == 1) {
       const double cut_dist = first_is_1 ? (val - nd.divhigh) * (val - nd.divhigh)
                                          : (val - nd.divlow) * (val - nd.divlow);
       const double dst = f == 0 ? dists[0] : (f == 1 ? dists[1] : dists[2]);
-      const double mind = get_mind(sp) + cut_dist - dst;
+      const double mind = st_mind[sp] + cut_dist - dst;
 #pragma unroll
       for (int a = 0; a < 3; a++)
         dists[a] = f == a ? cut_dist : dists[a];
-      set_dst(sp, dst);
-      set_node(sp, (word & ~3) | 2);
+      st_dst[sp] = dst;
+      st_node[sp] = (word & ~3) | 2;
       if (mind <= rc_worst(r, k)) {
-        set_node(sp + 1, (first_is_1 ? nd.a + 1 : nd.a) << 2);
-        set_mind(sp + 1, mind);
+        st_node[sp + 1] = (first_is_1 ? nd.a + 1 : nd.a) << 2;
+        st_mind[sp + 1] = mind;
         sp++;
       }
     } else {
-      const double dst = get_dst(sp);
+      const double dst = st_dst[sp];
 #pragma unroll
       for (int a = 0; a < 3; a++)
         dists[a] = f == a ? dst : dists[a];

@@ -97,15 +97,11 @@ rc_limit(double v)
 // ---- forward (pointset_processing.cpp:296-384 / 659-728) ---------------------------
 // (ALIMIT: a finite max_attribute_dist2_fwd; without one the k x k comparison of the neighbours'
 // attributes decides nothing and is left out)
-// LDSF: the search's frames in LDS (one wavefront per workgroup, trees of at most kKdLdsDepth levels:
-// recolour_kdtree.hpp); false: in scratch, 256 threads per workgroup
-template<int C, int K, bool ALIMIT, bool LDSF = true>
-__global__ __launch_bounds__(LDSF ? kKdSearchThreads : 256) void
+template<int C, int K, bool ALIMIT>
+__global__ __launch_bounds__(256) void
 rc_forward_kernel(RcCtx cx)
 {
 #pragma clang fp contract(off)
-  GPCC_VGPR_FLOOR_64();  // (long per-lane loops: never the 49..56-register class, gpcc_primitives.hpp)
-  __shared__ KdLdsStack ls;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= cx.tgt.n)
     return;
@@ -118,7 +114,7 @@ rc_forward_kernel(RcCtx cx)
   for (int a = 0; a < 3; a++)
     q[a] = (double)(cx.tgt.xyz[3 * t + a] + cx.off[a]) * cx.t2s;
   RcKnn<K> r;
-  rc_kd_search<K, LDSF>(cx.src, q, kf, r, ls);
+  rc_kd_search<K>(cx.src, q, kf, r);
   if (cx.nearest) {
     cx.nearest[t] = r.i[0];
     if (rc_worst(r, kf) > rc_limit(p.max_geometry_dist2_fwd))
@@ -232,13 +228,11 @@ rc_forward_limit_kernel(RcCtx cx)
 }
 
 // ---- backward (:386-424 / 730-766): nearest targets of every source point ------------
-template<int K, bool LDSF = true>
-__global__ __launch_bounds__(LDSF ? kKdSearchThreads : 256) void
+template<int K>
+__global__ __launch_bounds__(256) void
 rc_backward_kernel(RcCtx cx)
 {
 #pragma clang fp contract(off)
-  GPCC_VGPR_FLOOR_64();
-  __shared__ KdLdsStack ls;
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= cx.src.n)
     return;
@@ -249,7 +243,7 @@ rc_backward_kernel(RcCtx cx)
   for (int a = 0; a < 3; a++)
     q[a] = (double)cx.src.xyz[3 * s + a] * cx.s2t - (double)cx.off[a];
   RcKnn<K> r;
-  rc_kd_search<K, LDSF>(cx.tgt, q, kb, r, ls);
+  rc_kd_search<K>(cx.tgt, q, kb, r);
 #pragma unroll
   for (int i = 0; i < K; i++) {
     if (i < kb) {

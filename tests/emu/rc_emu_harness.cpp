@@ -113,10 +113,10 @@ rc_emu_recolour(
   for (int k = 0; k < 3; k++)
     cx.off[k] = offset[k];
   cx.src_attrs = src_attrs;
-  int depth = 0, tdepth = 0;
+  int depth = 0;
   int rc = 0;
   if (build_tree(&blocks, src_xyz, ns, box, &cx.src, &depth) < 0 || depth > kKdMaxDepth
-      || build_tree(&blocks, tgt_xyz, nt, box + 6, &cx.tgt, &tdepth) < 0 || tdepth > kKdMaxDepth)
+      || build_tree(&blocks, tgt_xyz, nt, box + 6, &cx.tgt, &depth) < 0 || depth > kKdMaxDepth)
     rc = -3;
   if (rc == 0) {
     const size_t total_cap = (size_t)ns * kb;
@@ -136,37 +136,28 @@ rc_emu_recolour(
     long long* sums = carve<long long>(&blocks, ((size_t)nt + 1) / kKdScanBlock + 2);
     const bool alimit = p->max_attribute_dist2_fwd < 512;
     const int fgrid = (nt + 255) / 256, bgrid = (ns + 255) / 256;
-    const int sfgrid = (nt + kKdSearchThreads - 1) / kKdSearchThreads, sbgrid = (ns + kKdSearchThreads - 1) / kKdSearchThreads;
-    // (the emulator runs one instantiation per list capacity: 8 covers every k; a tree deeper than the LDS
-    // frames takes the scratch form, as in the library)
-    if (depth > kKdLdsDepth) {
-      if (c == 3)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(rc_forward_kernel<3, 8, true, false>), dim3(fgrid), dim3(256), 0, nullptr, cx);
-      else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(rc_forward_kernel<1, 8, true, false>), dim3(fgrid), dim3(256), 0, nullptr, cx);
-    } else if (c == 3) {
+    // (the emulator runs one instantiation per list capacity: 8 covers every k)
+    if (c == 3) {
       if (alimit)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(rc_forward_kernel<3, 8, true>), dim3(sfgrid), dim3(kKdSearchThreads), 0, nullptr, cx);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(rc_forward_kernel<3, 8, true>), dim3(fgrid), dim3(256), 0, nullptr, cx);
       else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(rc_forward_kernel<3, 8, false>), dim3(sfgrid), dim3(kKdSearchThreads), 0, nullptr, cx);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(rc_forward_kernel<3, 8, false>), dim3(fgrid), dim3(256), 0, nullptr, cx);
     } else {
       if (alimit)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(rc_forward_kernel<1, 8, true>), dim3(sfgrid), dim3(kKdSearchThreads), 0, nullptr, cx);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(rc_forward_kernel<1, 8, true>), dim3(fgrid), dim3(256), 0, nullptr, cx);
       else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(rc_forward_kernel<1, 8, false>), dim3(sfgrid), dim3(kKdSearchThreads), 0, nullptr, cx);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(rc_forward_kernel<1, 8, false>), dim3(fgrid), dim3(256), 0, nullptr, cx);
     }
     if (cx.nearest)
       hipLaunchKernelGGL(rc_forward_limit_kernel, dim3(fgrid), dim3(256), 0, nullptr, cx);
     memset(cx.lstart, 0, sizeof(int32_t) * ((size_t)nt + 1));
     memset(cx.lcur, 0, sizeof(int32_t) * (size_t)nt);
-    if (tdepth > kKdLdsDepth)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(rc_backward_kernel<8, false>), dim3(bgrid), dim3(256), 0, nullptr, cx);
-    else if (kb <= 1)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(rc_backward_kernel<1>), dim3(sbgrid), dim3(kKdSearchThreads), 0, nullptr, cx);
+    if (kb <= 1)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(rc_backward_kernel<1>), dim3(bgrid), dim3(256), 0, nullptr, cx);
     else if (kb <= 4)
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(rc_backward_kernel<4>), dim3(sbgrid), dim3(kKdSearchThreads), 0, nullptr, cx);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(rc_backward_kernel<4>), dim3(bgrid), dim3(256), 0, nullptr, cx);
     else
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(rc_backward_kernel<8>), dim3(sbgrid), dim3(kKdSearchThreads), 0, nullptr, cx);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(rc_backward_kernel<8>), dim3(bgrid), dim3(256), 0, nullptr, cx);
     kd_scan(nullptr, cx.lstart, (size_t)nt + 1, sums);
     hipLaunchKernelGGL(rc_list_fill_kernel, dim3(bgrid), dim3(256), 0, nullptr, cx);
     if (c == 3)

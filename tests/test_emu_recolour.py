@@ -94,24 +94,3 @@ def test_several_levels_above_the_subtrees():
         got = emu_recolour(p, xyz, a, tgt, scale=scale)
         want = ol.ref().recolour(p, xyz, a, tgt, scale=scale) if ol.ref_available() else ol.oracle().recolour(p, xyz, a, tgt, scale=scale)
         np.testing.assert_array_equal(got, want)
-
-
-def test_search_frames_beyond_lds():
-    """round 5: the search's frames live in LDS (trees of at most 24 levels), deeper trees take the instantiation with
-    the frames in scratch; a second build of the emulated kernels draws that line at FOUR levels, so these trees take
-    the scratch form -- same result"""
-    subprocess.run(["make", "-s", "-C", EMU_DIR, "librc_emu_d4.so"], check=True, stdout=subprocess.DEVNULL)
-    l4 = C.CDLL(os.path.join(EMU_DIR, "librc_emu_d4.so"))
-    l4.rc_emu_recolour.restype = C.c_int
-    l4.rc_emu_recolour.argtypes = lib().rc_emu_recolour.argtypes
-    for kind, scale, kw in (("dense", 0.5, {}), ("lidar", 0.013, dict(k_fwd=3, skip_fwd=False)), ("dense", 0.37, dict(max_geom_fwd=3.0))):
-        xyz, a = synth.dense_cloud(5000, seed=9, bits=7) if kind == "dense" else synth.lidar_cloud(5000, seed=9)
-        tgt = requantise(xyz, scale)
-        p = recolour_params(bitdepth=8, **kw)
-        xyz = np.ascontiguousarray(xyz, dtype=np.int32)
-        a = np.ascontiguousarray(a, dtype=np.int32)
-        out = np.zeros((len(tgt), a.shape[1]), dtype=np.int32)
-        rc = l4.rc_emu_recolour(C.addressof(p), xyz.reshape(-1), a.reshape(-1), len(xyz), tgt.reshape(-1), len(tgt), a.shape[1],
-                                scale, np.zeros(3, dtype=np.int32), out.reshape(-1))
-        assert rc == 0
-        np.testing.assert_array_equal(out, ol.oracle().recolour(p, xyz, a, tgt, scale=scale))
