@@ -217,3 +217,27 @@ def test_subnode_lossy_multi_slice_levels(ctx):
         wco, wrec = chk.raht_forward(p, f[0], f[1])
         np.testing.assert_array_equal(co[c * a:c * b], wco, err_msg=f"slice {i}")
         np.testing.assert_array_equal(rec[a:b], wrec, err_msg=f"slice {i}")
+
+
+@pytest.mark.parametrize("subnode", [False, True])
+def test_neighbour_links_opt_in(subnode, ctx, monkeypatch):
+    """GPCC_LINKS=1 (csrc/raht_links.hpp, round 5): the level kernels take their neighbours from the top-down link
+    records instead of bisecting -- measured slower on the MI355X (profiles/r05_links_ab.txt) and therefore off by
+    default, but bit-exact: the golden cases that use the RAHT extension, multi-slice batches, several search ranges
+    (the window is an index distance at the consumer)"""
+    from mpeg_pcc_tmc13_amd import raht_params, synth
+    monkeypatch.setenv("GPCC_LINKS", "1")   # (read by the library at every call)
+    o = ol.oracle()
+    for kind, n, c, sr in (("dense", 60000, 3, 50000), ("lidar", 90000, 1, 2500), ("dense", 30000, 1, 8), ("lidar", 50000, 1, 8)):
+        xyz, attrs = (synth.dense_cloud(n, seed=17, bits=9) if kind == "dense" else synth.lidar_cloud(n, seed=17))
+        attrs = np.ascontiguousarray(attrs[:, :c])
+        morton, a, _ = synth.sort_by_morton(xyz, attrs)
+        p = raht_params(qp=34, subnode=subnode, search_range=sr, chroma_offset=-1 if c == 3 else 0)
+        co, rec = ctx.raht_forward(p, morton, a)
+        o_co, o_rec = o.raht_forward(p, morton, a)
+        np.testing.assert_array_equal(co, o_co)
+        np.testing.assert_array_equal(rec, o_rec)
+        np.testing.assert_array_equal(ctx.raht_inverse(p, morton, co, c), o_rec)
+    monkeypatch.setenv("GPCC_LINKS", "0")
+    co0, _ = ctx.raht_forward(p, morton, a)
+    np.testing.assert_array_equal(co0, o_co)
