@@ -496,7 +496,7 @@ cx_level_tile(const CxCtx& cx, CxSmem& sm, int li, int tile)
   //      (findNeighbours, tmc3/RAHT.cpp:299-368; findNeighbour :272-293 is a
   //      lower_bound limited to raht_prediction_search_range entries either side) -----
   int nq[6];
-  if (cx.link_rec) {
+  if (GPCC_EXPERIMENTS && cx.link_rec) {
     // round 5: the parent's record holds its 18 neighbours (raht_links.hpp) -- one load per neighbour
     // instead of a 12-step bisection; the search window is an index distance
     const int64_t range = prm->raht_prediction_search_range;

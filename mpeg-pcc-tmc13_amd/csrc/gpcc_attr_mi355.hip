@@ -1119,7 +1119,7 @@ launch_transform(
         const char* e = getenv("GPCC_SUB_CLAIM_PARENTS");
         return e ? (int64_t)atoll(e) : (int64_t)100000;
       }();
-      lc.claim_rounds = (encoder && !pl.haar && claim_r > 1 && parents <= claim_parents) ? claim_r : 1;
+      lc.claim_rounds = (GPCC_EXPERIMENTS && encoder && !pl.haar && claim_r > 1 && parents <= claim_parents) ? claim_r : 1;
     }
     if (!encoder) {
       Timer t(ctx, level_name("level_sub_synth", li));
@@ -2580,6 +2580,13 @@ gpcc_debug_alloc_events(const gpcc_ctx* ctx, long long out[4])
   for (int i = 0; i < 4; i++)
     out[i] = ctx->alloc_events[i];
   return GPCC_OK;
+}
+
+// 1: the library was built with the round-5 experiments compiled in (GPCC_LINKS / GPCC_SUB_CLAIM work)
+extern "C" int
+gpcc_debug_has_experiments(void)
+{
+  return GPCC_EXPERIMENTS;
 }
 
 // bands compared so far in this process (0 unless GPCC_GUARD=1): lets a test tier prove the guards were armed

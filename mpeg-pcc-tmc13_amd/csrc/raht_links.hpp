@@ -304,16 +304,28 @@ link_lookup(const int32_t* __restrict__ rec, int rj, int id, int j, int64_t rang
 
 // ---- host side: storage and launch order --------------------------------------------------------
 
-// GPCC_LINKS=1 turns the links on (read at every call).  They are OFF by default: measured on the MI355X
+// GPCC_LINKS=1 turns the links on (read at every call) in a build with the experiments compiled in (below).  OFF
+// by default: measured on the MI355X
 // (profiles/r05_links_ab.txt) the consumers gain less than the passes cost -- compact level pass of 10 x 1 M
 // points 2.40 -> 2.02 ms, sub-node encoder 25.7 -> 24.7 ms, against 2.4 ms for the link passes (0.9 for a
 // single frame): the bisections they replace run in L2-resident keys that neighbouring lanes share, and
 // the level kernels are bound by instruction issue and by their dependency chains, not by those round trips.
+// The consumers' side of both round-5 experiments (the link look-ups in the level kernels, the multi-round claims of
+// raht_subnode.hpp) is compiled in only with -DGPCC_EXPERIMENTS=1 (the CPU emulator builds of tests/emu always; the
+// gfx950 library on request: GPCC_EXTRA_FLAGS=-DGPCC_EXPERIMENTS=1 python -m ... build): left in unconditionally the
+// dead branches cost the headline kernel 28 bytes of scratch, 350 instructions and 1.6 % of its time.
+#ifndef GPCC_EXPERIMENTS
+#define GPCC_EXPERIMENTS 0
+#endif
 inline bool
 links_enabled()
 {
+#if GPCC_EXPERIMENTS
   const char* e = getenv("GPCC_LINKS");
   return e && e[0] == '1';
+#else
+  return false;
+#endif
 }
 
 // storage of the neighbour links of a batch of n points in s slices: `take` as in cx_carve

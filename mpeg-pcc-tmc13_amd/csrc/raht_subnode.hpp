@@ -178,6 +178,7 @@ raht_level_sub_kernel(LevelCtx ctx)
   // slower on the MI355X (profiles/r05_claim_rounds_ab.txt): the rounds of a claim start one after the other,
   // each with its ~100 us prologue of dependent loads, and the next claim's blocks wait for all of them -- the
   // one-round claims of many wavefronts overlap exactly that.  Kept for the record and pinned under the emulator.
+#if GPCC_EXPERIMENTS
   const int claim_rounds = ctx.claim_rounds > 1 ? ctx.claim_rounds : 1;
   bool stop_all = false;
   for (;;) {
@@ -203,6 +204,22 @@ raht_level_sub_kernel(LevelCtx ctx)
       stop_all = true;
       break;
     }
+#else  // the product library: one round per claim, the loop exactly as in round 4
+  for (;;) {
+    int tk = 0;
+    if (lane == 0)
+      tk = atomicAdd(&ctx.ticket[li * 8 + cls], 1);
+    tk = __shfl(tk, 0);
+    const int64_t wround = (int64_t)tk * 8 + cls;
+    if (wround * 8 >= num_work)
+      break;
+    SubProf prof;
+    prof.round_begin();
+    // a bounded wait has expired somewhere: the result is discarded anyway,
+    // leave at once instead of spinning through every remaining round
+    if (__hip_atomic_load(ctx.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+      break;
+#endif
     const int wi = (int)(wround * 8) + (lane >> 3);
     const bool live = wi < num_work;
     const int j = live ? ctx.worklist[wi] : 0;
@@ -357,7 +374,7 @@ raht_level_sub_kernel(LevelCtx ctx)
     }
     // (group-uniform; other groups of the wave idle through the shuffles)
     int pn[3] = {-1, -1, -1};  // neighbour i = 1 + t + 8*slot
-    if (ctx.link_rec) {
+    if (GPCC_EXPERIMENTS && ctx.link_rec) {
       // round 5: the parent's record holds its 18 neighbours (raht_links.hpp) -- one load each instead of
       // a 12-step bisection; findNeighbour's window (tmc3/RAHT.cpp:272-293) is an index distance
       if (do_search) {
@@ -1129,12 +1146,20 @@ raht_level_sub_kernel(LevelCtx ctx)
             const int pv = __shfl(outv, pl);
             // (nothing but reset-free blocks before this one in the round: the state the claim's previous
             // round left, in registers)
+#if GPCC_EXPERIMENTS
             const bool from_carry = w2 && nt == 0 && carry_known;
             const bool found = (w2 && nt != 0 && pk == 2) || from_carry;
             if (found) {
               lin = from_carry ? carry_l : pv;
               lin_known = lin_exact = true;
             }
+#else
+            const bool found = w2 && nt != 0 && pk == 2;
+            if (found) {
+              lin = pv;
+              lin_known = lin_exact = true;
+            }
+#endif
             if (!__any(found))
               break;
           }
@@ -1251,6 +1276,7 @@ raht_level_sub_kernel(LevelCtx ctx)
       }
     }
     prof.round_end(lane, li);
+#if GPCC_EXPERIMENTS
     if (kLossy && claim_rounds > 1) {
       // what this round leaves for the claim's next one: the state behind its last block that knows it
       // (every later block of the round is reset-free); a round of reset-free blocks that never learnt the
@@ -1264,6 +1290,7 @@ raht_level_sub_kernel(LevelCtx ctx)
       }
     }
    }
+#endif
   }
   // ArithF64: a value left the range in which doubles are exact -- the sticky word stops every
   // later kernel of the call (the source attributes stay intact) and the call is redone with

@@ -225,7 +225,10 @@ def test_neighbour_links_opt_in(subnode, ctx, monkeypatch):
     records instead of bisecting -- measured slower on the MI355X (profiles/r05_links_ab.txt) and therefore off by
     default, but bit-exact: the golden cases that use the RAHT extension, multi-slice batches, several search ranges
     (the window is an index distance at the consumer)"""
-    from mpeg_pcc_tmc13_amd import raht_params, synth
+    from mpeg_pcc_tmc13_amd import _lib, raht_params, synth
+    if not _lib.load().gpcc_debug_has_experiments():
+        pytest.skip("the library was built without -DGPCC_EXPERIMENTS=1 (the default: the experiments' branches cost "
+                    "the headline kernel 1.6 %); the emulator tier pins the links")
     monkeypatch.setenv("GPCC_LINKS", "1")   # (read by the library at every call)
     o = ol.oracle()
     for kind, n, c, sr in (("dense", 60000, 3, 50000), ("lidar", 90000, 1, 2500), ("dense", 30000, 1, 8), ("lidar", 50000, 1, 8)):
