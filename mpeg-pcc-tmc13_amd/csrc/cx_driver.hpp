@@ -123,15 +123,13 @@ cx_run(
   {
     auto t = prof("cx_scan", -1);
     hipLaunchKernelGGL(cx_scan_kernel, dim3(ncol), dim3(256), 0, st, tv, cl, ncol);
+    // (the level table also goes to the host's pinned copy `tab`, written by the kernel itself: no copy engine
+    // between the scan and the event the host waits for)
     hipLaunchKernelGGL(
       HIP_KERNEL_NAME(cx_scan_fin_kernel<C>), dim3(1), dim3(64), 0, st, tv, cl, w.attr_prefix,
-      sum_attrs != nullptr);
+      sum_attrs != nullptr, tab);
   }
-  // (the level table: final behind cx_scan_fin)
-  hipError_t e = hipMemcpyAsync(tab, cl.tab, sizeof(CxLevelTab), hipMemcpyDeviceToHost, st);
-  if (e != hipSuccess)
-    return e;
-  e = mark();
+  hipError_t e = mark();
   if (e != hipSuccess)
     return e;
   {

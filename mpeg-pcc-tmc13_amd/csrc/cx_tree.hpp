@@ -295,9 +295,14 @@ cx_scan_kernel(TreeView tv, CxLists cl, int ncol)
 }
 
 // ---- sentinels and the per-level list offsets --------------------------------------
+// tab_host: a second copy of the level table in pinned HOST memory (or null) -- the host sizes the level launches
+// from it after an event behind this kernel.  (Until round 5 the table came back with a hipMemcpyAsync: one step in
+// ten of a long-running process then took 20-80 ms with every kernel at its usual time -- the copy engine's path, not
+// the kernels'; tools/r05_stall_probe3.py.  The sub-node path never had it: its schedule kernel writes its statistics
+// to pinned memory itself.)
 template<int C>
 __global__ __launch_bounds__(64) void
-cx_scan_fin_kernel(TreeView tv, CxLists cl, int32_t* attr_prefix, int has_attrs)
+cx_scan_fin_kernel(TreeView tv, CxLists cl, int32_t* attr_prefix, int has_attrs, CxLevelTab* tab_host = nullptr)
 {
   const int lane = threadIdx.x;
   const int nlev = tv.nlev;
@@ -327,6 +332,13 @@ cx_scan_fin_kernel(TreeView tv, CxLists cl, int32_t* attr_prefix, int has_attrs)
     cl.tab->nb[lane] = nb;
     cl.tab->nr[lane] = nb + nf;
     cl.tab->nodes[lane] = m;
+    if (tab_host) {
+      tab_host->boff[lane] = (int32_t)(nbi - nb);
+      tab_host->roff[lane] = (int32_t)(nri - (nb + nf));
+      tab_host->nb[lane] = nb;
+      tab_host->nr[lane] = nb + nf;
+      tab_host->nodes[lane] = m;
+    }
     cl.bq[(int)(nbi - nb) + lane + nb] = nb + nf;  // the level's sentinel
   }
   if (lane == 0)
