@@ -138,12 +138,19 @@ def timed(torch, dev, fn, steps, warmup=1):
     return (time.perf_counter() - t0) / steps
 
 
-def timed_stats(torch, dev, fn, steps, warmup=2):
+def timed_stats(torch, dev, fn, steps, warmup=2, settle=0.3):
     """every step timed on its own (a synchronisation per step): median and max tell a steady state from a
-    hiccup (arena regrowth, an expired bounded wait and its retry) -- VERDICT r04 weak #10"""
+    hiccup (arena regrowth, an expired bounded wait and its retry) -- VERDICT r04 weak #10.
+    `settle`: an untimed pause between the warm-up calls and the timed steps.  A batch's buffers (hundreds of MB from
+    torch's allocator, the context's arena regrown by the first warm-up call) have just been allocated, and on the
+    MI355X box the first one or two timed steps right behind that took 10-80 ms with every kernel at its usual time
+    (the device's queue idles between two dispatches) -- in 1-8 of ~640 steps, never with the pause (0 in 3 runs),
+    never in a steady loop (0 of 6479 consecutive steps of the worst leg): profiles/r05_stall_root_cause.txt"""
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize(dev)
+    if settle:
+        time.sleep(settle)
     ts = []
     for _ in range(steps):
         t0 = time.perf_counter()

@@ -236,56 +236,61 @@ schedule_kernel(
   if (threadIdx.x == 0)
     s_fine = s_top = 0;
   __syncthreads();
+  // (no per-thread arrays: the plan is written straight into sched[s] and the level sizes are re-read from the
+  // slice offsets, so the kernel needs no scratch memory -- it used 284 B per lane and was the only dispatch with
+  // scratch in a fixed-point sub-node-off call)
   for (int s = threadIdx.x; s < tv.num_slices; s += blockDim.x) {
-    SliceSched sc;
-    int m[kMaxLevels];
-    for (int li = 0; li < tv.nlev; li++)
-      m[li] = tv.soff[li][s + 1] - tv.soff[li][s];
+    auto nodes = [&](int li) { return tv.soff[li][s + 1] - tv.soff[li][s]; };
+    SliceSched* sc = &sched[s];
     int top = tv.nlev - 1;
     // the level arrays were sized for ONE node per slice at the top level: a
     // Morton-bits hint smaller than the codes' real width breaks that (and
     // tree_emit has then written past the top levels' arrays, inside the
     // workspace) -- report it instead of returning a wrong result
-    if (m[top] != 1)
+    if (nodes(top) != 1)
       atomicExch(tv.error, 2);
-    while (top > 0 && m[top - 1] == 1)
+    while (top > 0 && nodes(top - 1) == 1)
       top--;
-    sc.num_unique = m[0];
-    sc.top_level = top;
+    sc->num_unique = nodes(0);
+    sc->top_level = top;
     int coarse_from = top;  // levels li >= coarse_from belong to the coarse kernel
-    for (int li = top - 1; li >= 0 && m[li + 1] <= coarse_max_parents; li--)
+    for (int li = top - 1; li >= 0 && nodes(li + 1) <= coarse_max_parents; li--)
       coarse_from = li;
     int qp_layer = 0, ac_layer = -1, parity = 1, coeff = 0;
-    for (int li = 0; li < kMaxLevels; li++) {
-      sc.lvl[li].processed = 0;
-      sc.lvl[li].is_root = 0;
-      sc.lvl[li].qp_layer = 0;
-      sc.lvl[li].ac_layer = -1;
-      sc.lvl[li].parity = 0;
-      sc.lvl[li].coarse = 0;
-      sc.lvl[li].pad[0] = sc.lvl[li].pad[1] = 0;
-      sc.lvl[li].coeff_base = 0;
-    }
+    LevelSched none;
+    none.processed = 0;
+    none.is_root = 0;
+    none.qp_layer = 0;
+    none.ac_layer = -1;
+    none.parity = 0;
+    none.coarse = 0;
+    none.pad[0] = none.pad[1] = 0;
+    none.coeff_base = 0;
+    for (int li = kMaxLevels - 1; li >= (top > 0 ? top : 0); li--)
+      sc->lvl[li] = none;
+    int m_up = nodes(top);
     for (int li = top - 1; li >= 0; li--) {
       const bool root = li == top - 1;
-      sc.lvl[li].coarse = li >= coarse_from;
-      if (!root && m[li] == m[li + 1])
-        continue;
-      qp_layer = qp_layer + 1 < num_qp_layers ? qp_layer + 1 : num_qp_layers - 1;
-      ac_layer++;
-      parity ^= 1;
-      LevelSched& e = sc.lvl[li];
-      e.processed = 1;
-      e.is_root = root;
-      e.qp_layer = (uint8_t)qp_layer;
-      e.ac_layer = (int8_t)(ac_layer > 127 ? 127 : ac_layer);
-      e.parity = (uint8_t)parity;
-      e.coeff_base = coeff;
-      coeff += root ? m[li] : m[li] - m[li + 1];
+      const int m_li = nodes(li);
+      LevelSched e = none;
+      e.coarse = li >= coarse_from;
+      if (root || m_li != m_up) {
+        qp_layer = qp_layer + 1 < num_qp_layers ? qp_layer + 1 : num_qp_layers - 1;
+        ac_layer++;
+        parity ^= 1;
+        e.processed = 1;
+        e.is_root = root;
+        e.qp_layer = (uint8_t)qp_layer;
+        e.ac_layer = (int8_t)(ac_layer > 127 ? 127 : ac_layer);
+        e.parity = (uint8_t)parity;
+        e.coeff_base = coeff;
+        coeff += root ? m_li : m_li - m_up;
+      }
+      sc->lvl[li] = e;
+      m_up = m_li;
     }
-    sc.final_qp_layer = qp_layer;
-    sc.final_parity = parity;
-    sched[s] = sc;
+    sc->final_qp_layer = qp_layer;
+    sc->final_parity = parity;
     atomicMax(&s_fine, coarse_from);
     atomicMax(&s_top, top);
   }

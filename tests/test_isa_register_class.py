@@ -30,3 +30,15 @@ def test_no_kernel_in_the_56_register_class(meta):
     names = isa_meta.demangle(list(bad))
     assert not bad, "kernels with a 49..56-register allocation (add GPCC_VGPR_FLOOR_64() at their top): " + ", ".join(
         f"{names[n]} ({v})" for n, v in bad.items())
+
+
+def test_compact_pass_needs_no_scratch(meta):
+    """The fixed-point kernels of a sub-node-off call use no scratch memory (schedule_kernel had 284 B per lane of
+    per-thread arrays until round 5; the queue then never has to ask the runtime for scratch on this path).  The float
+    variants (ArithF64: integer_haar off + fixed_point off) still spill 16-36 B."""
+    names = isa_meta.demangle(list(meta))
+    path = ("schedule_kernel", "cx_count_kernel", "cx_scan_kernel", "cx_scan_fin_kernel", "cx_emit_kernel",
+            "cx_top_kernel", "cx_level_kernel", "finish_kernel")
+    bad = {names[n]: v["scratch"] for n, v in meta.items()
+           if any(k in names[n] for k in path) and "ArithF64" not in names[n] and v["scratch"] > 0}
+    assert not bad, f"compact-pass kernels with scratch: {bad}"
