@@ -169,3 +169,12 @@ rc_emu_recolour(
     free(q);
   return rc;
 }
+
+// kd_scan alone (the inclusive prefix sum the tree build runs ~60 times per tree): in place on a[n]
+extern "C" int
+rc_emu_scan(int32_t* a, int64_t n)
+{
+  std::vector<long long> sums((size_t)n / kKdScanBlock + 2);
+  const hipError_t e = kd_scan(nullptr, a, (size_t)n, sums.data());
+  return e == hipSuccess ? 0 : -1;
+}

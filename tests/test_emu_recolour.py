@@ -94,3 +94,17 @@ def test_several_levels_above_the_subtrees():
         got = emu_recolour(p, xyz, a, tgt, scale=scale)
         want = ol.ref().recolour(p, xyz, a, tgt, scale=scale) if ol.ref_available() else ol.oracle().recolour(p, xyz, a, tgt, scale=scale)
         np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize("n", [1, 2047, 2048, 2049, 70_001, 300_000, 2_200_000])
+def test_tree_build_prefix_sum(n):
+    """kd_scan (inclusive prefix sum, in place) with one block, a few, more than a wavefront's worth of blocks (147) and more
+    than one block per thread of the middle kernel (1075 blocks): against numpy."""
+    rng = np.random.default_rng(n)
+    a = rng.integers(0, 3, n, dtype=np.int32)
+    want = np.cumsum(a, dtype=np.int64).astype(np.int32)
+    l = lib()
+    l.rc_emu_scan.restype = C.c_int
+    l.rc_emu_scan.argtypes = [_i32p, C.c_int64]
+    assert l.rc_emu_scan(a, n) == 0
+    np.testing.assert_array_equal(a, want)
