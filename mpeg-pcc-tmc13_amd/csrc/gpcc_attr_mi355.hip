@@ -2596,6 +2596,44 @@ gpcc_debug_guard_checks(void)
   return g_guard_checks;
 }
 
+// rate_sum_kernel (raht_inter.hpp) alone, for tests/test_gpu_rate_sum.py: the two estimates' sums over
+// terms[2][count] doubles, as the inter encoder's per-layer decision accumulates them
+extern "C" int
+gpcc_debug_rate_sum(gpcc_ctx* ctx, const double* terms, int32_t count, double out[2])
+{
+  if (!ctx || !out || count < 0 || (count > 0 && !terms))
+    return fail(GPCC_ERR_INVALID_ARG, "bad arguments");
+  HIP_TRY(hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  void *d_terms = nullptr, *d_rs = nullptr, *d_err = nullptr;
+  HIP_TRY(pool_malloc(ctx, &d_terms, std::max<size_t>(2 * (size_t)count * sizeof(double), 16)));
+  HIP_TRY(pool_malloc(ctx, &d_rs, sizeof(RateState)));
+  HIP_TRY(pool_malloc(ctx, &d_err, 16));
+  HIP_TRY(hipMemsetAsync(d_rs, 0, sizeof(RateState), st));
+  HIP_TRY(hipMemsetAsync(d_err, 0, 16, st));
+  if (count > 0)
+    HIP_TRY(hipMemcpyAsync(d_terms, terms, 2 * (size_t)count * sizeof(double), hipMemcpyHostToDevice, st));
+  RateCtx cx{};
+  cx.tv.error = (int32_t*)d_err;
+  cx.n = count;
+  cx.a = 0;
+  cx.b = count;
+  cx.c = 1;
+  cx.term = (double*)d_terms;
+  cx.rs = (RateState*)d_rs;
+  hipLaunchKernelGGL(rate_sum_kernel, dim3(2), dim3(kAcSumThreads), 0, st, cx);
+  HIP_TRY(hipGetLastError());
+  RateState h{};
+  HIP_TRY(hipMemcpyAsync(&h, d_rs, sizeof(RateState), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  out[0] = h.bits[0];
+  out[1] = h.bits[1];
+  pool_free(ctx, d_terms);
+  pool_free(ctx, d_rs);
+  pool_free(ctx, d_err);
+  return GPCC_OK;
+}
+
 // guard mode's own test: writes 16 bytes past a pool block (mode 0) or past a sub-allocation of the arena
 // (mode 1) and releases / re-carves it -- with GPCC_GUARD=1 the process must stop with the GUARD BAND message
 // (tests/test_gpu_guard.py runs this in a child process); without guard mode nothing is checked.

@@ -412,139 +412,258 @@ rate_p0_bits_kernel(RateCtx cx)
   }
 }
 
-// e->bits += bits, coefficient after coefficient (RAHT.cpp:77): the additions are a chain no other order
-// reproduces, so one wavefront per estimate does them, every lane alike.  The terms come in by coalesced loads,
-// 512 at a time into LDS (the next 512 in flight meanwhile), and are read back with the same address in every
-// lane (a broadcast read, its latency off the chain): what is left per term is one dependent v_add_f64.
+// e->bits += bits, coefficient after coefficient (RAHT.cpp:77): a chain of double additions that no other ORDER
+// reproduces -- but most of it can be done without the chain.  While the running sum s stays inside one binade
+// [2^e, 2^(e+1)) it is a multiple M of g = 2^(e-52), and adding a term t >= 0 rounds the exact s + t to that grid:
+//     RN(M g + t) = (M + rn(t / g)) g      with rn = round to nearest,
+// which does not depend on M unless t / g lies exactly half-way between two integers (the tie goes to the EVEN
+// neighbour of M + t / g).  So for a chunk of 512 terms with no tie, no negative or oversized term, and
+// M + sum rn(t_i / g) < 2^53 (the sum never leaves the binade: the terms are >= 0, so the last prefix is the
+// largest) the chain's result is (M + sum_i rn(t_i / g)) g -- an INTEGER sum, any order, one wavefront
+// reduction; t / g, rn and the final product are exact (powers of two, integers below 2^53).  A chunk that fails
+// one of the tests (the first one, where s starts at 0; the ~25 chunks in which the sum crosses into the next
+// binade; a tie: about one term in 2^20) takes the chain as before: the terms go to LDS and are read back with the
+// same address in every lane (a broadcast read, its latency off the chain), one dependent v_add_f64 per term.
+// One wavefront per estimate, every lane alike.  (Until round 5 every chunk took the chain: 9 cycles per term,
+// 4.3 of the 22.6 ms of a 1 M-point inter forward.)
 constexpr int kAcSumChunk = 512;
 
-__global__ __launch_bounds__(64) void
+// s += the 512 doubles at `cur` (LDS), in order
+__device__ __forceinline__ double
+rate_sum_chain(double s, const double* cur)
+{
+#pragma clang fp contract(off)
+#if defined(__HIP_DEVICE_COMPILE__)
+  // 32 terms at a time: their sixteen LDS reads are issued together, the additions follow as the reads
+  // arrive.  Written out as machine code: left to the compiler every read ends up in front of its own two
+  // additions -- whatever the source order or the scheduler hints -- and the chain waits an LDS round trip
+  // per pair (measured: 27 cycles per term against 9 here; the addition itself has 8 cycles of latency).
+  typedef __attribute__((address_space(3))) const double LdsDouble;
+  uint32_t addr = (uint32_t)(uintptr_t)(LdsDouble*)cur;
+  for (int u0 = 0; u0 < kAcSumChunk; u0 += 32, addr += 32 * 8) {
+    asm volatile(
+      "ds_read_b128 v[64:67], %1\n\t"
+      "ds_read_b128 v[68:71], %1 offset:16\n\t"
+      "ds_read_b128 v[72:75], %1 offset:32\n\t"
+      "ds_read_b128 v[76:79], %1 offset:48\n\t"
+      "ds_read_b128 v[80:83], %1 offset:64\n\t"
+      "ds_read_b128 v[84:87], %1 offset:80\n\t"
+      "ds_read_b128 v[88:91], %1 offset:96\n\t"
+      "ds_read_b128 v[92:95], %1 offset:112\n\t"
+      "ds_read_b128 v[96:99], %1 offset:128\n\t"
+      "ds_read_b128 v[100:103], %1 offset:144\n\t"
+      "ds_read_b128 v[104:107], %1 offset:160\n\t"
+      "ds_read_b128 v[108:111], %1 offset:176\n\t"
+      "ds_read_b128 v[112:115], %1 offset:192\n\t"
+      "ds_read_b128 v[116:119], %1 offset:208\n\t"
+      "ds_read_b128 v[120:123], %1 offset:224\n\t"
+      "ds_read_b128 v[124:127], %1 offset:240\n\t"
+      "s_waitcnt lgkmcnt(15)\n\t"
+      "v_add_f64 %0, %0, v[64:65]\n\t"
+      "v_add_f64 %0, %0, v[66:67]\n\t"
+      "s_waitcnt lgkmcnt(14)\n\t"
+      "v_add_f64 %0, %0, v[68:69]\n\t"
+      "v_add_f64 %0, %0, v[70:71]\n\t"
+      "s_waitcnt lgkmcnt(13)\n\t"
+      "v_add_f64 %0, %0, v[72:73]\n\t"
+      "v_add_f64 %0, %0, v[74:75]\n\t"
+      "s_waitcnt lgkmcnt(12)\n\t"
+      "v_add_f64 %0, %0, v[76:77]\n\t"
+      "v_add_f64 %0, %0, v[78:79]\n\t"
+      "s_waitcnt lgkmcnt(11)\n\t"
+      "v_add_f64 %0, %0, v[80:81]\n\t"
+      "v_add_f64 %0, %0, v[82:83]\n\t"
+      "s_waitcnt lgkmcnt(10)\n\t"
+      "v_add_f64 %0, %0, v[84:85]\n\t"
+      "v_add_f64 %0, %0, v[86:87]\n\t"
+      "s_waitcnt lgkmcnt(9)\n\t"
+      "v_add_f64 %0, %0, v[88:89]\n\t"
+      "v_add_f64 %0, %0, v[90:91]\n\t"
+      "s_waitcnt lgkmcnt(8)\n\t"
+      "v_add_f64 %0, %0, v[92:93]\n\t"
+      "v_add_f64 %0, %0, v[94:95]\n\t"
+      "s_waitcnt lgkmcnt(7)\n\t"
+      "v_add_f64 %0, %0, v[96:97]\n\t"
+      "v_add_f64 %0, %0, v[98:99]\n\t"
+      "s_waitcnt lgkmcnt(6)\n\t"
+      "v_add_f64 %0, %0, v[100:101]\n\t"
+      "v_add_f64 %0, %0, v[102:103]\n\t"
+      "s_waitcnt lgkmcnt(5)\n\t"
+      "v_add_f64 %0, %0, v[104:105]\n\t"
+      "v_add_f64 %0, %0, v[106:107]\n\t"
+      "s_waitcnt lgkmcnt(4)\n\t"
+      "v_add_f64 %0, %0, v[108:109]\n\t"
+      "v_add_f64 %0, %0, v[110:111]\n\t"
+      "s_waitcnt lgkmcnt(3)\n\t"
+      "v_add_f64 %0, %0, v[112:113]\n\t"
+      "v_add_f64 %0, %0, v[114:115]\n\t"
+      "s_waitcnt lgkmcnt(2)\n\t"
+      "v_add_f64 %0, %0, v[116:117]\n\t"
+      "v_add_f64 %0, %0, v[118:119]\n\t"
+      "s_waitcnt lgkmcnt(1)\n\t"
+      "v_add_f64 %0, %0, v[120:121]\n\t"
+      "v_add_f64 %0, %0, v[122:123]\n\t"
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "v_add_f64 %0, %0, v[124:125]\n\t"
+      "v_add_f64 %0, %0, v[126:127]\n\t"
+      : "+v"(s)
+      : "v"(addr)
+      : "memory", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127");
+  }
+#else
+  for (int u = 0; u < kAcSumChunk; u++)
+    s += cur[u];
+#endif
+  return s;
+}
+
+__device__ __forceinline__ double
+rate_pow2(int k)  // 2^k, -1022 <= k <= 1023
+{
+  const unsigned long long bits = (unsigned long long)(1023 + k) << 52;
+  double v;
+  __builtin_memcpy(&v, &bits, 8);
+  return v;
+}
+
+// Sixteen wavefronts, a group of sixteen chunks at a time, wavefront w owning chunk w of the group (its next chunk's
+// loads in flight meanwhile).  A round: every wavefront whose chunk is still open evaluates it under the binade of
+// the current sum and publishes (integer sum, usable); all threads then walk the summaries in order -- a few
+// integer additions per chunk -- and take chunks as long as they are usable and the sum stays in the binade.  A
+// chunk that is not (the level's first, a crossing, a tie) is summed by its owner with the chain, the new sum is
+// handed round, and the chunks behind it are evaluated again under the new binade: the next round.  One barrier per
+// group when nothing fails.  (One wavefront doing all of this alone is bound by its own instruction stream: ~200
+// double / conversion instructions and a six-step shuffle reduction per chunk -- 2.4 ms per 1 M terms against 4.3
+// for the chain alone.)
+constexpr int kAcSumWaves = 16;
+constexpr int kAcSumThreads = kAcSumWaves * 64;
+
+__global__ __launch_bounds__(kAcSumThreads) void
 rate_sum_kernel(RateCtx cx)
 {
 #pragma clang fp contract(off)
-  __shared__ double buf[2][kAcSumChunk];
+  __shared__ double buf[kAcSumChunk];
+  __shared__ long long part_sum[2][kAcSumWaves];
+  __shared__ int part_bad[2][kAcSumWaves];
+  __shared__ double s_pub;
   if (tree_failed(cx.tv))
     return;
   const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
   const int est = blockIdx.x;
   const int64_t total = (int64_t)(cx.b - cx.a) * cx.c;
   const double* __restrict__ term = cx.term + (size_t)est * cx.n * cx.c;
   const int64_t nchunks = (total + kAcSumChunk - 1) / kAcSumChunk;
-  double r[kAcSumChunk / 64];
-  auto load = [&](int64_t c) {
+  const int64_t ngroups = (nchunks + kAcSumWaves - 1) / kAcSumWaves;
+  constexpr int J = kAcSumChunk / 64, W = kAcSumWaves;
+  double cur[J], nxt[J] = {};
+  auto load = [&](int64_t grp, double* r) {
 #pragma unroll
-    for (int j = 0; j < kAcSumChunk / 64; j++) {
-      const int64_t i = c * kAcSumChunk + j * 64 + lane;
+    for (int j = 0; j < J; j++) {
+      const int64_t i = (grp * W + wave) * kAcSumChunk + j * 64 + lane;
       r[j] = i < total ? term[i] : 0.0;
     }
   };
-  auto store = [&](int which) {
-#pragma unroll
-    for (int j = 0; j < kAcSumChunk / 64; j++)
-      buf[which][j * 64 + lane] = r[j];
-  };
   double s = 0.0;
-  if (nchunks > 0) {
-    load(0);
-    store(0);
-  }
-  __syncthreads();
-  for (int64_t c = 0; c < nchunks; c++) {
-    if (c + 1 < nchunks)
-      load(c + 1);
-    const double* __restrict__ cur = buf[c & 1];
-    const int64_t left = total - c * kAcSumChunk;
-    if (left >= kAcSumChunk) {
-#if defined(__HIP_DEVICE_COMPILE__)
-      // 32 terms at a time: their sixteen LDS reads are issued together, the additions follow as the reads
-      // arrive.  Written out as machine code: left to the compiler every read ends up in front of its own two
-      // additions -- whatever the source order or the scheduler hints -- and the chain waits an LDS round trip
-      // per pair (measured: 27 cycles per term against 9 here; the addition itself has 8 cycles of latency).
-      typedef __attribute__((address_space(3))) const double LdsDouble;
-      uint32_t addr = (uint32_t)(uintptr_t)(LdsDouble*)cur;
-      for (int u0 = 0; u0 < kAcSumChunk; u0 += 32, addr += 32 * 8) {
-        asm volatile(
-          "ds_read_b128 v[64:67], %1\n\t"
-          "ds_read_b128 v[68:71], %1 offset:16\n\t"
-          "ds_read_b128 v[72:75], %1 offset:32\n\t"
-          "ds_read_b128 v[76:79], %1 offset:48\n\t"
-          "ds_read_b128 v[80:83], %1 offset:64\n\t"
-          "ds_read_b128 v[84:87], %1 offset:80\n\t"
-          "ds_read_b128 v[88:91], %1 offset:96\n\t"
-          "ds_read_b128 v[92:95], %1 offset:112\n\t"
-          "ds_read_b128 v[96:99], %1 offset:128\n\t"
-          "ds_read_b128 v[100:103], %1 offset:144\n\t"
-          "ds_read_b128 v[104:107], %1 offset:160\n\t"
-          "ds_read_b128 v[108:111], %1 offset:176\n\t"
-          "ds_read_b128 v[112:115], %1 offset:192\n\t"
-          "ds_read_b128 v[116:119], %1 offset:208\n\t"
-          "ds_read_b128 v[120:123], %1 offset:224\n\t"
-          "ds_read_b128 v[124:127], %1 offset:240\n\t"
-          "s_waitcnt lgkmcnt(15)\n\t"
-          "v_add_f64 %0, %0, v[64:65]\n\t"
-          "v_add_f64 %0, %0, v[66:67]\n\t"
-          "s_waitcnt lgkmcnt(14)\n\t"
-          "v_add_f64 %0, %0, v[68:69]\n\t"
-          "v_add_f64 %0, %0, v[70:71]\n\t"
-          "s_waitcnt lgkmcnt(13)\n\t"
-          "v_add_f64 %0, %0, v[72:73]\n\t"
-          "v_add_f64 %0, %0, v[74:75]\n\t"
-          "s_waitcnt lgkmcnt(12)\n\t"
-          "v_add_f64 %0, %0, v[76:77]\n\t"
-          "v_add_f64 %0, %0, v[78:79]\n\t"
-          "s_waitcnt lgkmcnt(11)\n\t"
-          "v_add_f64 %0, %0, v[80:81]\n\t"
-          "v_add_f64 %0, %0, v[82:83]\n\t"
-          "s_waitcnt lgkmcnt(10)\n\t"
-          "v_add_f64 %0, %0, v[84:85]\n\t"
-          "v_add_f64 %0, %0, v[86:87]\n\t"
-          "s_waitcnt lgkmcnt(9)\n\t"
-          "v_add_f64 %0, %0, v[88:89]\n\t"
-          "v_add_f64 %0, %0, v[90:91]\n\t"
-          "s_waitcnt lgkmcnt(8)\n\t"
-          "v_add_f64 %0, %0, v[92:93]\n\t"
-          "v_add_f64 %0, %0, v[94:95]\n\t"
-          "s_waitcnt lgkmcnt(7)\n\t"
-          "v_add_f64 %0, %0, v[96:97]\n\t"
-          "v_add_f64 %0, %0, v[98:99]\n\t"
-          "s_waitcnt lgkmcnt(6)\n\t"
-          "v_add_f64 %0, %0, v[100:101]\n\t"
-          "v_add_f64 %0, %0, v[102:103]\n\t"
-          "s_waitcnt lgkmcnt(5)\n\t"
-          "v_add_f64 %0, %0, v[104:105]\n\t"
-          "v_add_f64 %0, %0, v[106:107]\n\t"
-          "s_waitcnt lgkmcnt(4)\n\t"
-          "v_add_f64 %0, %0, v[108:109]\n\t"
-          "v_add_f64 %0, %0, v[110:111]\n\t"
-          "s_waitcnt lgkmcnt(3)\n\t"
-          "v_add_f64 %0, %0, v[112:113]\n\t"
-          "v_add_f64 %0, %0, v[114:115]\n\t"
-          "s_waitcnt lgkmcnt(2)\n\t"
-          "v_add_f64 %0, %0, v[116:117]\n\t"
-          "v_add_f64 %0, %0, v[118:119]\n\t"
-          "s_waitcnt lgkmcnt(1)\n\t"
-          "v_add_f64 %0, %0, v[120:121]\n\t"
-          "v_add_f64 %0, %0, v[122:123]\n\t"
-          "s_waitcnt lgkmcnt(0)\n\t"
-          "v_add_f64 %0, %0, v[124:125]\n\t"
-          "v_add_f64 %0, %0, v[126:127]\n\t"
-          : "+v"(s)
-          : "v"(addr)
-          : "memory", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127");
+  if (ngroups > 0)
+    load(0, cur);
+  int par = 0;  // which half of part_* the next round writes
+  for (int64_t grp = 0; grp < ngroups; grp++) {
+    if (grp + 1 < ngroups)
+      load(grp + 1, nxt);
+    int k = 0;  // first open chunk of the group
+    while (k < W) {
+      // ---- a round: the open chunks under the binade of s ----
+      const bool usable_s = s >= 1.0 && s < 1.0e60;
+      int e = 0;
+      if (usable_s) {
+        unsigned long long sb;
+        __builtin_memcpy(&sb, &s, 8);
+        e = (int)((sb >> 52) & 0x7ff) - 1023;
       }
-#else
-      for (int u = 0; u < kAcSumChunk; u++)
-        s += cur[u];
+      const double ginv = rate_pow2(52 - e), g = rate_pow2(e - 52);
+      if (wave >= k) {
+        // (a lane's eight rn(t / g) are added as doubles: each is an integer below 2^49, so the sum is exact, and
+        // there is ONE conversion to int64 per lane -- the conversion is a dozen instructions)
+        double lane_sum = 0.0;
+        bool bad = !usable_s;
+#pragma unroll
+        for (int j = 0; j < J; j++) {
+          const double x = cur[j] * ginv;
+          bad |= !(x >= 0.0 && x < 562949953421312.0);  // negative / NaN, or 2^49 grid steps and more
+          const double r = __builtin_rint(x);
+          bad |= __builtin_fabs(x - r) == 0.5;
+          lane_sum += r;
+        }
+        long long sum = bad ? 0 : (long long)lane_sum;
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1)
+          sum += __shfl_xor(sum, m);
+        const bool any_bad = __any(bad);
+        if (lane == 0) {
+          part_sum[par][wave] = sum;
+          part_bad[par][wave] = any_bad;
+        }
+      }
+      __syncthreads();
+      if (usable_s) {
+        const long long M = (long long)(s * ginv);  // 2^52 <= M < 2^53, exact
+        long long acc = M;
+        long long ps[W];
+        int pb[W];
+#pragma unroll
+        for (int w = 0; w < W; w++) {  // (all summaries with one LDS round trip; the walk below runs on registers)
+          ps[w] = part_sum[par][w];
+          pb[w] = part_bad[par][w];
+        }
+        bool open = true;
+#pragma unroll
+        for (int w = 0; w < W; w++) {
+          if (w >= k && open) {
+            if (!pb[w] && acc + ps[w] < (1ll << 53))
+              acc += ps[w];
+            else
+              open = false;
+          }
+          if (w >= k && open)
+            k = w + 1;
+        }
+        s = (double)acc * g;
+      }
+      par ^= 1;
+      if (k == W)
+        break;
+      // ---- chunk k by the chain, by its owner ----
+      if (wave == k) {
+#pragma unroll
+        for (int j = 0; j < J; j++)
+          buf[j * 64 + lane] = cur[j];
+        // (the owner's own stores, read back by the same wavefront: no workgroup barrier needed)
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
-    } else {
-      for (int u = 0; u < (int)left; u++)
-        s += cur[u];
+        __builtin_amdgcn_wave_barrier();
+        const int64_t left = total - (grp * W + k) * kAcSumChunk;
+        double t = s;
+        if (left >= kAcSumChunk) {
+          t = rate_sum_chain(t, buf);
+        } else {
+          for (int u = 0; u < (int)left; u++)
+            t += buf[u];
+        }
+        if (lane == 0)
+          s_pub = t;
+      }
+      __syncthreads();
+      s = s_pub;
+      k++;
+      // (s_pub and buf are written again only behind the next round's barrier)
     }
-    if (c + 1 < nchunks)
-      store((int)((c + 1) & 1));
-    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < J; j++)
+      cur[j] = nxt[j];
   }
-  if (lane == 0)
+  if (threadIdx.x == 0)
     cx.rs->bits[est] = s;
 }
 

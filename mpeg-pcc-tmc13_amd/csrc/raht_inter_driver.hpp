@@ -708,7 +708,7 @@ inter_run(
           }
           {
             auto t = prof("rate_sum", li);
-            hipLaunchKernelGGL(rate_sum_kernel, dim3(2), dim3(64), 0, st, rt);
+            hipLaunchKernelGGL(rate_sum_kernel, dim3(2), dim3(kAcSumThreads), 0, st, rt);
           }
           {
             auto t = prof("rate_decide", li);
@@ -782,7 +782,7 @@ inter_run(
         }
         {
           auto t = prof("rate_sum", li);
-          hipLaunchKernelGGL(rate_sum_kernel, dim3(2), dim3(64), 0, st, rt);
+          hipLaunchKernelGGL(rate_sum_kernel, dim3(2), dim3(kAcSumThreads), 0, st, rt);
         }
         {
           auto t = prof("rate_decide", li);
@@ -832,7 +832,7 @@ inter_run(
         }
         {
           auto t = prof("rate_sum", li);
-          hipLaunchKernelGGL(rate_sum_kernel, dim3(2), dim3(64), 0, st, rt);
+          hipLaunchKernelGGL(rate_sum_kernel, dim3(2), dim3(kAcSumThreads), 0, st, rt);
         }
         {
           auto t = prof("rate_decide", li);

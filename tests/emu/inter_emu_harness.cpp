@@ -148,3 +148,23 @@ inter_emu_raht_qp(
     params, fwd, morton, attrs, coeffs, n, c, morton_ref, attrs_ref, n_ref, depth_minus1, layer_rdo, filter_est, skip_layers,
     layer_modes, num_modes, filter_taps, num_taps, qp_off);
 }
+
+// rate_sum_kernel alone: the two estimates' chains over terms[2][count] (one component); out[2] = the sums
+extern "C" int
+inter_emu_rate_sum(const double* terms, int32_t count, double* out)
+{
+  int32_t err = 0;
+  RateState rs{};
+  RateCtx cx{};
+  cx.tv.error = &err;
+  cx.n = count;
+  cx.a = 0;
+  cx.b = count;
+  cx.c = 1;
+  cx.term = const_cast<double*>(terms);
+  cx.rs = &rs;
+  hipLaunchKernelGGL(rate_sum_kernel, dim3(2), dim3(kAcSumThreads), 0, nullptr, cx);
+  out[0] = rs.bits[0];
+  out[1] = rs.bits[1];
+  return err;
+}

@@ -156,3 +156,65 @@ def test_emulated_claims_of_several_rounds(lib, claim, monkeypatch):
         assert rc == 0
         np.testing.assert_array_equal(co_e, co_o)
         np.testing.assert_array_equal(rec_e, rec_o)
+
+
+def _seq_sum(t):
+    s = 0.0
+    for v in t.tolist():
+        s += v
+    return s
+
+
+@pytest.mark.parametrize("case", ["costs", "ties", "ties_every_binade", "crossings", "zeros_tiny_huge", "negative",
+                                  "short", "empty", "ragged"])
+def test_rate_sum_is_the_sequential_sum(lib, case):
+    """rate_sum_kernel replaces most of the chain of double additions by an integer sum per 512 terms (exact while
+    the running sum stays in one binade and no term sits half-way between two grid points); everything else takes the
+    chain.  Bit for bit against the additions done one after the other, on inputs built to hit every exit: ties (terms
+    that are odd multiples of half the grid), binade crossings inside a chunk, a sum that starts at 0, terms too large
+    for the grid, a negative term, chunk tails."""
+    rng = np.random.default_rng(sum(map(ord, case)))
+    n = 40_000
+    if case == "costs":
+        t = rng.uniform(0.0, 24.0, (2, n))
+    elif case == "ties":
+        # multiples of 2^-37: half-way cases whenever the grid is 2^-36 (sum in [2^16, 2^17)), exact otherwise
+        t = rng.integers(0, 1 << 41, (2, n)).astype(np.float64) * 2.0 ** -37
+    elif case == "ties_every_binade":
+        # a term that is an odd multiple of half the CURRENT grid in every chunk, whatever the sum is by then
+        t = rng.uniform(0.0, 8.0, (2, n))
+        for e in range(2):
+            s = 0.0
+            for i in range(n):
+                if i % 97 == 13 and s >= 1.0:
+                    g = 2.0 ** (int(np.floor(np.log2(s))) - 52)
+                    t[e, i] = (2 * int(rng.integers(1, 1 << 20)) + 1) * (g / 2)
+                s += t[e, i]
+    elif case == "crossings":
+        t = rng.uniform(0.0, 4.0, (2, n))
+        t[:, ::50] = 2.0 ** rng.integers(0, 30, t[:, ::50].shape)
+    elif case == "zeros_tiny_huge":
+        t = np.zeros((2, n))
+        t[:, 5::7] = 1e-300
+        t[:, 11::13] = rng.uniform(0, 3, t[:, 11::13].shape)
+        t[0, 20_000] = 1e70
+        t[1, 700] = 2.0 ** 60
+    elif case == "negative":
+        t = rng.uniform(0.0, 24.0, (2, n))
+        t[0, 12_345] = -3.25
+        t[1, 100] = -1e-9
+    elif case == "short":
+        t = rng.uniform(0.0, 24.0, (2, 300))
+    elif case == "empty":
+        t = np.zeros((2, 0))
+    else:
+        t = rng.uniform(0.0, 24.0, (2, 512 * 9 + 1))
+    t = np.ascontiguousarray(t, dtype=np.float64)
+    out = np.zeros(2)
+    fn = lib.inter_emu_rate_sum
+    fn.restype = C.c_int
+    fn.argtypes = [np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS"), C.c_int32,
+                   np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")]
+    assert fn(t.reshape(-1), t.shape[1], out) == 0
+    want = np.array([_seq_sum(t[0]), _seq_sum(t[1])])
+    assert out.tobytes() == want.tobytes(), (case, out, want, out - want)
