@@ -477,56 +477,105 @@ pred_rate_events_kernel(
 // One recurrence over `m` events (up[e] from the values for probResGt0: stride c,
 // non-zero test; from the event bytes for probResGt1); state[e] = the state in front of
 // event e, state[m] behind the last (m is read from *m_ptr when given).
+// One wavefront per 64 chunks.  The wavefront first packs the flags of ITS events -- the 1024 of the first
+// chunk's warm-up and the 64 x 256 of the chunks -- into bit words in LDS with coalesced loads and ballots; the
+// threads then run their recurrences on the words, stage the states in LDS and the wavefront writes them out
+// 64 consecutive events per store.  (Until round 5 a thread read its 1 280 flags itself, sixteen loads at a
+// time, every lane in a different cache line, and stored its 256 states the same way: 1.07 ms per call for
+// 1 M events, 8.6 ms of a predicting encode.)  A warm-up that has not met after 1024 events is continued from
+// global memory with quadrupled windows, as before.
+constexpr int kRateWarm = 1024;
+constexpr int kRateHalf = kRateChunk / 2;
+
 __global__ __launch_bounds__(64) void
 pred_rate_scan_kernel(
   const int32_t* __restrict__ values, int stride, const uint8_t* __restrict__ ev, int m_max,
   const int32_t* __restrict__ m_ptr, int32_t* __restrict__ state, int state_stride, int write_final)
 {
+  __shared__ unsigned long long wbits[(kRateWarm + 64 * kRateChunk) / 64];
+  __shared__ int32_t stage[64 * (kRateHalf + 1)];
   const int m = m_ptr ? *m_ptr : m_max;
-  const int chunk = blockIdx.x * blockDim.x + threadIdx.x;
-  const long long start = (long long)chunk * kRateChunk;
-  if (start > m || (start == m && m > 0))
-    return;
-  const int end = start + kRateChunk < m ? (int)(start + kRateChunk) : m;
-  auto up = [&](int e) -> bool { return values ? values[(size_t)e * stride] != 0 : ev[e] != 0; };
+  const int lane = threadIdx.x;
+  const long long wave_start = (long long)blockIdx.x * 64 * kRateChunk;
+  if (wave_start > m || (wave_start == m && m > 0))
+    return;  // (no chunk of this wavefront holds an event, and state[m] is another wavefront's)
+  auto up = [&](long long e) -> bool { return values ? values[(size_t)e * stride] != 0 : ev[e] != 0; };
+  // ---- the flags of events [base, last) as bit words: bit (e - base) ----
+  const long long base = wave_start - kRateWarm;
+  const long long last = wave_start + 64 * kRateChunk < m ? wave_start + 64 * kRateChunk : m;
+  const int nwords = (int)((last - base + 63) >> 6);
+#pragma unroll 8
+  for (int w = 0; w < nwords; w++) {
+    const long long e = base + (long long)w * 64 + lane;
+    const unsigned long long b = __ballot(e >= 0 && e < last && up(e));
+    if (lane == 0)
+      wbits[w] = b;
+  }
+  __syncthreads();
+  const long long start = wave_start + (long long)lane * kRateChunk;
+  const bool active = !(start > m || (start == m && m > 0));
+  const int end = !active ? 0 : (start + kRateChunk < m ? (int)(start + kRateChunk) : m);
   int x = kRateScale >> 1;
-  if (start > 0) {
-    for (long long w = 1024;; w *= 4) {
-      const int b = start - w > 0 ? (int)(start - w) : 0;
-      int lo = b == 0 ? kRateScale >> 1 : kRateMin, hi = b == 0 ? kRateScale >> 1 : kRateMax;
-      // (the loads of a batch do not depend on the state: issued together)
-      for (int e0 = b; e0 < (int)start; e0 += 16) {
-        bool u[16];
-#pragma unroll
-        for (int j = 0; j < 16; j++)
-          u[j] = e0 + j < (int)start ? up(e0 + j) : false;
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-          if (e0 + j < (int)start) {
-            lo = pred_rate_step(lo, u[j]);
-            hi = pred_rate_step(hi, u[j]);
-          }
+  if (active && start > 0) {
+    // warm-up over [b, start): b = start - 1024 or 0
+    const int b = start - kRateWarm > 0 ? (int)(start - kRateWarm) : 0;
+    int lo = b == 0 ? kRateScale >> 1 : kRateMin, hi = b == 0 ? kRateScale >> 1 : kRateMax;
+    for (long long e = b; e < start;) {
+      const int bit = (int)(e - base);
+      const int b1 = start - (e - (bit & 63)) < 64 ? (int)(start - (e - (bit & 63))) : 64;
+      unsigned long long w = wbits[bit >> 6] >> (bit & 63);
+      for (int q = bit & 63; q < b1; q++, w >>= 1) {
+        lo = pred_rate_step(lo, w & 1);
+        hi = pred_rate_step(hi, w & 1);
+      }
+      e += b1 - (bit & 63);
+    }
+    x = lo;
+    if (lo != hi) {
+      for (long long w = 4 * kRateWarm;; w *= 4) {
+        const int bb = start - w > 0 ? (int)(start - w) : 0;
+        lo = bb == 0 ? kRateScale >> 1 : kRateMin;
+        hi = bb == 0 ? kRateScale >> 1 : kRateMax;
+        for (int e = bb; e < (int)start; e++) {
+          const bool u = up(e);
+          lo = pred_rate_step(lo, u);
+          hi = pred_rate_step(hi, u);
+        }
+        x = lo;
+        if (lo == hi)
+          break;
+      }
+    }
+  }
+  // ---- the chunk, in two halves: states staged in LDS (row of a lane: kRateHalf + 1 words, so that the lanes'
+  // stores fall into different banks), written out 64 consecutive events at a time ----
+  for (int h = 0; h < 2; h++) {
+    const long long h0 = start + (long long)h * kRateHalf;
+    if (active) {
+      for (int q = 0; q < kRateHalf; q += 64) {
+        const long long e0 = h0 + q;
+        if (e0 >= end)
+          break;
+        const int bit = (int)(e0 - base);  // (a multiple of 64)
+        unsigned long long w = wbits[bit >> 6];
+        const int cnt = end - e0 < 64 ? (int)(end - e0) : 64;
+        for (int t = 0; t < cnt; t++, w >>= 1) {
+          stage[lane * (kRateHalf + 1) + q + t] = x;
+          x = pred_rate_step(x, w & 1);
         }
       }
-      x = lo;
-      if (lo == hi)
-        break;
     }
-  }
-  for (int e0 = (int)start; e0 < end; e0 += 16) {
-    bool u[16];
-#pragma unroll
-    for (int j = 0; j < 16; j++)
-      u[j] = e0 + j < end ? up(e0 + j) : false;
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-      if (e0 + j < end) {
-        state[(size_t)(e0 + j) * state_stride] = x;
-        x = pred_rate_step(x, u[j]);
-      }
+    __syncthreads();
+    for (int i = 0; i < kRateHalf; i++) {
+      const int idx = i * 64 + lane;
+      const int c = idx / kRateHalf, t = idx % kRateHalf;
+      const long long e = wave_start + (long long)c * kRateChunk + (long long)h * kRateHalf + t;
+      if (e < m)
+        state[(size_t)e * state_stride] = stage[c * (kRateHalf + 1) + t];
     }
+    __syncthreads();
   }
-  if (write_final && end == m)
+  if (active && write_final && end == m)
     state[(size_t)m * state_stride] = x;
 }
 

@@ -622,3 +622,18 @@ pred_emu_inter(
     free(b);
   return err ? -6 - err : 0;
 }
+
+// pred_rate_scan_kernel alone, launched as the library launches it (one thread per chunk of 256 events, `m_max`
+// sizing the grid, the event count read from memory when m >= 0): values (stride) or event bytes in, states out
+extern "C" int
+lod_emu_rate_scan(
+  const int32_t* values, int32_t stride, const uint8_t* ev, int32_t m_max, int32_t m, int32_t* state,
+  int32_t state_stride, int32_t write_final)
+{
+  const int chunks = m_max / kRateChunk + 1;
+  int32_t m_mem = m;
+  hipLaunchKernelGGL(
+    pred_rate_scan_kernel, dim3((chunks + 63) / 64), dim3(64), 0, nullptr, values, stride, ev, m_max,
+    m >= 0 ? (const int32_t*)&m_mem : (const int32_t*)nullptr, state, state_stride, write_final);
+  return 0;
+}

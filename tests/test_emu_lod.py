@@ -189,3 +189,55 @@ def test_ordinary_lod_build_under_the_emulator(vi):
         for k in ("npl", "indexes", "nc", "ni"):
             np.testing.assert_array_equal(e[k], o[k], err_msg=f"{name} {kw} {k}")
         np.testing.assert_array_equal(e["w"].astype(np.uint32), (o["w"] & 0xffffffff).astype(np.uint32), err_msg=f"{name} {kw} w")
+
+
+def _rate_states(up, x0=1 << 19):
+    """state in front of every event, and behind the last: resStatUpdate's recurrence (AttributeEncoder.cpp:137-165)"""
+    out = np.empty(len(up) + 1, np.int64)
+    x = x0
+    for i, u in enumerate(up.tolist()):
+        out[i] = x
+        x = x + (((1 << 20) - x) >> 6) if u else x - (x >> 6)
+    out[len(up)] = x
+    return out
+
+
+@pytest.mark.parametrize("m,kind", [(0, "values"), (1, "values"), (255, "events"), (256, "values"), (257, "events"),
+                                    (16_384, "values"), (16_385, "events"), (50_000, "values"), (70_001, "events"),
+                                    (40_000, "runs"), (40_000, "rare")])
+def test_rate_model_scan_under_the_emulator(m, kind):
+    """pred_rate_scan_kernel (a wavefront packs its events' flags into LDS words, the threads run their chunks'
+    recurrences from the two extreme states over a 1024-event warm-up, the states leave through LDS): against the
+    recurrence run from the first event, for event counts around the chunk (256) and wavefront (16 384) sizes, dense,
+    in long runs and rare events, from strided values (probResGt0) and from event bytes with the count in memory
+    (probResGt1)."""
+    import ctypes as C
+    l = el.lib()
+    rng = np.random.default_rng(m * 7 + len(kind))
+    if kind == "runs":
+        up = (np.arange(m) // 3000) % 2 == 0
+    elif kind == "rare":
+        up = rng.random(m) < 0.002
+    else:
+        up = rng.random(m) < 0.4
+    want = _rate_states(up)
+    fn = l.lod_emu_rate_scan
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32]
+    if kind == "events":
+        # event bytes, capacity larger than the count (the library sizes the grid by n, the count comes from memory)
+        cap = m + 5000
+        ev = np.zeros(cap, np.uint8)
+        ev[:m] = up
+        state = np.full(cap + 1, -1, np.int32)
+        assert fn(None, 0, ev.ctypes.data, cap, m, state.ctypes.data, 1, 1) == 0
+        np.testing.assert_array_equal(state[:m + 1], want)
+        assert (state[m + 1:] == -1).all()
+    else:
+        stride = 3
+        vals = np.zeros((max(m, 1), stride), np.int32)
+        vals[:m, 1] = np.where(up, rng.integers(1, 9, m) * rng.choice([-1, 1], m), 0)
+        state = np.full((max(m, 1) + 1, 6), -1, np.int32)
+        assert fn(vals[:, 1:].ctypes.data, stride, None, m, -1, state[:, 2:].ctypes.data, 6, 0) == 0
+        np.testing.assert_array_equal(state[:m, 2], want[:m])
+        assert (state[:, [0, 1, 3, 4, 5]] == -1).all() and (state[m:, 2] == -1).all()
