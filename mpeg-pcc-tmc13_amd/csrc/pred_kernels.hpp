@@ -504,12 +504,35 @@ pred_rate_scan_kernel(
   const long long base = wave_start - kRateWarm;
   const long long last = wave_start + 64 * kRateChunk < m ? wave_start + 64 * kRateChunk : m;
   const int nwords = (int)((last - base + 63) >> 6);
-#pragma unroll 8
-  for (int w = 0; w < nwords; w++) {
-    const long long e = base + (long long)w * 64 + lane;
-    const unsigned long long b = __ballot(e >= 0 && e < last && up(e));
-    if (lane == 0)
-      wbits[w] = b;
+  // (sixteen words per batch: the sixteen loads are unconditional -- the index clamped into the range, the range
+  // test applied to the loaded flag -- so that they are in flight together; behind a test per event every load
+  // waited for its predecessor's ballot: 272 round trips to memory per wavefront)
+  if (last > 0) {
+    auto pack = [&](auto flag_at) {
+      for (int w0 = 0; w0 < nwords; w0 += 16) {
+        int f[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+          const long long e = base + (long long)(w0 + j) * 64 + lane;
+          const long long ec = e < 0 ? 0 : (e >= last ? last - 1 : e);
+          f[j] = flag_at(ec);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+          const long long e = base + (long long)(w0 + j) * 64 + lane;
+          const unsigned long long b = __ballot((f[j] != 0) & (e >= 0) & (e < last));
+          if (lane == 0 && w0 + j < nwords)
+            wbits[w0 + j] = b;
+        }
+      }
+    };
+    if (values)
+      pack([&](long long e) -> int { return values[(size_t)e * stride]; });
+    else
+      pack([&](long long e) -> int { return ev[e]; });
+  } else {
+    for (int w = lane; w < nwords; w += 64)
+      wbits[w] = 0;
   }
   __syncthreads();
   const long long start = wave_start + (long long)lane * kRateChunk;
