@@ -2611,8 +2611,10 @@ gpcc_debug_rate_sum(gpcc_ctx* ctx, const double* terms, int32_t count, double ou
   HIP_TRY(pool_malloc(ctx, &d_err, 16));
   HIP_TRY(hipMemsetAsync(d_rs, 0, sizeof(RateState), st));
   HIP_TRY(hipMemsetAsync(d_err, 0, 16, st));
+  // (through the context's pinned buffers, as every entry: the runtime never pins the caller's pages)
   if (count > 0)
-    HIP_TRY(hipMemcpyAsync(d_terms, terms, 2 * (size_t)count * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(h2d_user(ctx, d_terms, terms, 2 * (size_t)count * sizeof(double), st));
+  HIP_TRY(small_reset(ctx));
   RateCtx cx{};
   cx.tv.error = (int32_t*)d_err;
   cx.n = count;
@@ -2623,9 +2625,10 @@ gpcc_debug_rate_sum(gpcc_ctx* ctx, const double* terms, int32_t count, double ou
   cx.rs = (RateState*)d_rs;
   hipLaunchKernelGGL(rate_sum_kernel, dim3(2), dim3(kAcSumThreads), 0, st, cx);
   HIP_TRY(hipGetLastError());
-  RateState h{};
-  HIP_TRY(hipMemcpyAsync(&h, d_rs, sizeof(RateState), hipMemcpyDeviceToHost, st));
+  void* p_rs = nullptr;
+  HIP_TRY(small_d2h(ctx, &p_rs, d_rs, sizeof(RateState), st));
   HIP_TRY(hipStreamSynchronize(st));
+  const RateState& h = *(const RateState*)p_rs;
   out[0] = h.bits[0];
   out[1] = h.bits[1];
   pool_free(ctx, d_terms);
