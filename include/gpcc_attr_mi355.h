@@ -34,7 +34,7 @@ extern "C" {
  * inter-frame RAHT entries were added.  A caller compares gpcc_abi_version() with this constant before its first call
  * (the shim TUs do, shim/shim_common.hpp process_context): a library built from another header would read parameter
  * blocks of another size. */
-#define GPCC_ABI_VERSION 5
+#define GPCC_ABI_VERSION 6
 #define GPCC_MAX_POINTS (1 << 29) /* 32-bit device indices, stride <= 3 */
 
 #define GPCC_MAX_QP_LAYERS 32
@@ -111,6 +111,18 @@ void gpcc_ctx_destroy(gpcc_ctx* ctx);
 int gpcc_ctx_synchronize(gpcc_ctx* ctx);
 /* Bytes of HBM currently held by the context's workspace. */
 size_t gpcc_ctx_workspace_bytes(const gpcc_ctx* ctx);
+/* Reserve, ahead of the first transform, everything the RAHT entries allocate on demand for
+ * calls of up to `max_points` points in up to `max_slices` slices with `max_c` attribute
+ * components at the context's current Morton-bits hint (set that first): the device workspace
+ * of the largest flag combination, the pooled blocks and the pinned staging buffers; the
+ * device memory is written once and the call returns with the device idle.  A codec that
+ * creates a context per sequence and then calls once per (slice, attribute) -- the
+ * reference's call pattern, tmc3/AttributeEncoder.cpp:1273, 1341 -- calls this once with its
+ * largest slice: no transform allocates afterwards (gpcc_ctx_workspace_bytes stays put), so the
+ * first call is not followed by the tens of milliseconds a fresh allocation can cost the calls
+ * right behind it.  Not needed for correctness: workspace still grows on
+ * demand when a call is larger than what was reserved. */
+int gpcc_ctx_reserve(gpcc_ctx* ctx, int64_t max_points, int32_t max_slices, int32_t max_c);
 /* Device-tier hint: number of significant Morton-code bits (3 x coordinate
  * bits) of the batches that follow; 0 = unknown (63).  Bounds the number of
  * octree levels that are launched; the host tier derives it itself. */
@@ -865,6 +877,27 @@ int gpcc_recolour(
   const int32_t* src_attrs, int32_t ns, const int32_t* tgt_xyz, int32_t nt,
   int32_t c, float source_to_target_scale, const int32_t target_to_source_offset[3],
   int32_t* tgt_attrs);
+
+/* ------------------------------------------------------------------ */
+/* debug / test support (exported by every build; nothing an integrator */
+/* needs): used by tests/ and tools/ only                               */
+/* ------------------------------------------------------------------ */
+
+/* Allocation events of the context since it was created: out[0] arena (re)allocations, out[1]
+ * misses of the pooled device buffers, out[2] / out[3] (re)allocations of the pinned staging of
+ * the compact level pass / of the level kernels.  A steady loop shows none. */
+int gpcc_debug_alloc_events(const gpcc_ctx* ctx, long long out[4]);
+/* 1 when the library was built with -DGPCC_EXPERIMENTS=1 (opt-in kernel variants compiled in). */
+int gpcc_debug_has_experiments(void);
+/* Guard bands compared so far in this process (0 unless GPCC_GUARD=1 in the environment). */
+unsigned long long gpcc_debug_guard_checks(void);
+/* The inter-frame encoder's rate sum (csrc/raht_inter.hpp, rate_sum_kernel) on its own:
+ * out[e] = terms[e][0] + terms[e][1] + ... for the two estimates e, doubles added in order. */
+int gpcc_debug_rate_sum(gpcc_ctx* ctx, const double* terms, int32_t count, double out[2]);
+/* With GPCC_GUARD=1: writes 16 bytes past a pooled block (mode 0) or an arena sub-allocation
+ * (mode 1) ON PURPOSE -- the process must stop with the guard-band message; without guard mode
+ * it does nothing.  tests/test_gpu_guard.py runs it in a child process. */
+int gpcc_debug_guard_selftest(gpcc_ctx* ctx, int mode);
 
 #ifdef __cplusplus
 }

@@ -9,7 +9,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 # GPCC_LIB_PATH: an experiment build of the same library (tools/, parameter sweeps)
 LIB_PATH = os.environ.get("GPCC_LIB_PATH") or os.path.join(PKG_DIR, "libgpcc_attr_mi355.so")
 
-ABI_VERSION = 5  # GPCC_ABI_VERSION of include/gpcc_attr_mi355.h
+ABI_VERSION = 6  # GPCC_ABI_VERSION of include/gpcc_attr_mi355.h
 
 # every symbol the header declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
@@ -29,6 +29,9 @@ ABI_SYMBOLS = [
     "gpcc_multi_lift_encode_attr", "gpcc_multi_lift_decode_attr", "gpcc_multi_pred_encode_attr", "gpcc_multi_pred_decode_attr",
     "gpcc_pred_forward", "gpcc_pred_inverse", "gpcc_pred_encode_attr", "gpcc_pred_decode_attr",
     "gpcc_dev_pred_encode_attr", "gpcc_dev_pred_decode_attr",
+    "gpcc_ctx_reserve",
+    "gpcc_debug_alloc_events", "gpcc_debug_has_experiments", "gpcc_debug_guard_checks", "gpcc_debug_rate_sum",
+    "gpcc_debug_guard_selftest",
 ]
 
 
@@ -82,6 +85,7 @@ def load():
     lib.gpcc_ctx_workspace_bytes.argtypes = [vp]
     lib.gpcc_ctx_workspace_bytes.restype = C.c_size_t
     lib.gpcc_ctx_set_morton_bits.argtypes = [vp, i32]
+    lib.gpcc_ctx_reserve.argtypes = [vp, C.c_int64, i32, i32]
     lib.gpcc_ctx_set_fast_arith.argtypes = [vp, i32]
     lib.gpcc_ctx_pred_pass_stats.argtypes = [vp, C.POINTER(C.c_int64)]
     lib.gpcc_ctx_set_profiling.argtypes = [vp, C.c_int]

@@ -38,6 +38,7 @@
 #include "raht_rdoq.hpp"
 #include "raht_subnode.hpp"
 #include "raht_pipe.hpp"
+#include "raht_sweep.hpp"
 #include "raht_tile.hpp"
 #include "raht_tree.hpp"
 #include "cx_driver.hpp"
@@ -117,7 +118,7 @@ struct GuardedBlock {
 };
 std::mutex g_guard_mu;
 std::map<void*, GuardedBlock> g_guard_blocks;  // by user pointer
-unsigned long long g_guard_checks = 0;         // bands compared so far (gpcc_debug_guard_checks)
+std::atomic<unsigned long long> g_guard_checks{0};  // bands compared so far (gpcc_debug_guard_checks)
 
 [[noreturn]] void
 guard_violation(const char* what, const char* tag, size_t index, size_t offset, const unsigned char* got, size_t len)
@@ -226,9 +227,11 @@ struct Arena {
   {
     if (!guard_mode())
       return;
-    if (base && bands) {
-      hipMemsetAsync(base + used, kGuardByte, kGuardInner, gstream);
-      bands->push_back(used);
+    // (a carving that has run past the arena is reported by its caller's used > cap test: no band is
+    // written outside the allocation, and a failed memset leaves a band that the next check reports)
+    if (base && bands && used + kGuardInner <= cap) {
+      if (hipMemsetAsync(base + used, kGuardByte, kGuardInner, gstream) == hipSuccess)
+        bands->push_back(used);
     }
     used += kGuardInner;
   }
@@ -877,10 +880,23 @@ launch_transform(
   // levels the coarse kernel may take: a slice's top levels with at most
   // kCoarseTiles tiles of parents each (sub-node prediction has its own path)
   const bool tiles = !pl.sub;
+  // sub-node prediction: a slice's levels with at most kSweepMaxParents parents are walked by ONE
+  // workgroup per slice inside one launch (raht_sweep.hpp); GPCC_SWEEP=0 keeps the per-level kernels
+  static const bool sweep_on = [] {
+    const char* e = getenv("GPCC_SWEEP");
+    return !(e && e[0] == '0');
+  }();
+  // which levels: those where every slice has at most so many parents (GPCC_SWEEP_PARENTS; <= kSweepMaxParents)
+  static const int sweep_parents = [] {
+    const char* e = getenv("GPCC_SWEEP_PARENTS");
+    const int v = e ? atoi(e) : kSweepDefaultParents;
+    return v < 1 ? 1 : (v > kSweepMaxParents ? kSweepMaxParents : v);
+  }();
+  const bool sweep = pl.sub && !pl.haar && !pl.has_qp && !pl.pipe && !pl.links && sweep_on;
   {
     Timer t(ctx, "schedule");
     schedule_kernel<<<1, 256, 0, st>>>(
-      tv, pl.sched, hp->num_qp_layers, tiles ? kCoarseParents : 0, ctx->h_stats);
+      tv, pl.sched, hp->num_qp_layers, tiles ? kCoarseParents : (sweep ? sweep_parents : 0), ctx->h_stats);
   }
   HIP_TRY(hipEventRecord(ctx->ev_stats, st));
 
@@ -1045,7 +1061,25 @@ launch_transform(
     links.lv = pl.lv;
     links.begin(st, ts.nodes, first_level, link_prof);
   }
-  for (int li = piped ? -1 : first_level - 1; li >= 0; li--) {
+  // ---- sub-node prediction, the coarse levels of every slice: one launch (raht_sweep.hpp) ----
+  int level_from = first_level;  // the per-level launches start below this level
+  void* sweep_mem = nullptr;
+  if (sweep && !piped && ts.fine_levels < first_level) {
+    const int lo = std::max(0, ts.fine_levels);
+    const SweepCtx sw{first_level - 1, lo};
+    SweepRec rec{};
+    const int64_t sweep_parents = sweep_rec_layout(&rec, ts.nodes, sw.li_hi, sw.li_lo);
+    // the records of the levels the sweep takes, sized by the real node counts the host has just read:
+    // from the context's caching pool (reuse is ordered on the context's stream)
+    if (pool_malloc(ctx, &sweep_mem, sweep_rec_bytes(sweep_parents, C)) == hipSuccess) {
+      level_from = lo;
+      sweep_rec_carve(&rec, sweep_mem, sweep_parents, C);
+      Timer t(ctx, encoder ? "sub_sweep_lossy" : "sub_sweep_synth");
+      sweep_launch<C>(st, lc, sw, rec, ts.nodes, s, encoder, pl.f64);
+      pool_free(ctx, sweep_mem);
+    }
+  }
+  for (int li = piped ? -1 : level_from - 1; li >= 0; li--) {
     lc.li = li;
     lc.mtag = (uint32_t)(li + 1);
     const int64_t parents = ts.nodes[li + 1];
@@ -2593,7 +2627,7 @@ gpcc_debug_has_experiments(void)
 extern "C" unsigned long long
 gpcc_debug_guard_checks(void)
 {
-  return g_guard_checks;
+  return g_guard_checks.load();
 }
 
 // rate_sum_kernel (raht_inter.hpp) alone, for tests/test_gpu_rate_sum.py: the two estimates' sums over
@@ -2606,35 +2640,40 @@ gpcc_debug_rate_sum(gpcc_ctx* ctx, const double* terms, int32_t count, double ou
   HIP_TRY(hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   void *d_terms = nullptr, *d_rs = nullptr, *d_err = nullptr;
-  HIP_TRY(pool_malloc(ctx, &d_terms, std::max<size_t>(2 * (size_t)count * sizeof(double), 16)));
-  HIP_TRY(pool_malloc(ctx, &d_rs, sizeof(RateState)));
-  HIP_TRY(pool_malloc(ctx, &d_err, 16));
-  HIP_TRY(hipMemsetAsync(d_rs, 0, sizeof(RateState), st));
-  HIP_TRY(hipMemsetAsync(d_err, 0, 16, st));
-  // (through the context's pinned buffers, as every entry: the runtime never pins the caller's pages)
-  if (count > 0)
-    HIP_TRY(h2d_user(ctx, d_terms, terms, 2 * (size_t)count * sizeof(double), st));
-  HIP_TRY(small_reset(ctx));
-  RateCtx cx{};
-  cx.tv.error = (int32_t*)d_err;
-  cx.n = count;
-  cx.a = 0;
-  cx.b = count;
-  cx.c = 1;
-  cx.term = (double*)d_terms;
-  cx.rs = (RateState*)d_rs;
-  hipLaunchKernelGGL(rate_sum_kernel, dim3(2), dim3(kAcSumThreads), 0, st, cx);
-  HIP_TRY(hipGetLastError());
-  void* p_rs = nullptr;
-  HIP_TRY(small_d2h(ctx, &p_rs, d_rs, sizeof(RateState), st));
-  HIP_TRY(hipStreamSynchronize(st));
-  const RateState& h = *(const RateState*)p_rs;
-  out[0] = h.bits[0];
-  out[1] = h.bits[1];
-  pool_free(ctx, d_terms);
-  pool_free(ctx, d_rs);
-  pool_free(ctx, d_err);
-  return GPCC_OK;
+  // (the blocks go back to the pool on every path)
+  auto run = [&]() -> int {
+    HIP_TRY(pool_malloc(ctx, &d_terms, std::max<size_t>(2 * (size_t)count * sizeof(double), 16)));
+    HIP_TRY(pool_malloc(ctx, &d_rs, sizeof(RateState)));
+    HIP_TRY(pool_malloc(ctx, &d_err, 16));
+    HIP_TRY(hipMemsetAsync(d_rs, 0, sizeof(RateState), st));
+    HIP_TRY(hipMemsetAsync(d_err, 0, 16, st));
+    // (through the context's pinned buffers, as every entry: the runtime never pins the caller's pages)
+    if (count > 0)
+      HIP_TRY(h2d_user(ctx, d_terms, terms, 2 * (size_t)count * sizeof(double), st));
+    HIP_TRY(small_reset(ctx));
+    RateCtx cx{};
+    cx.tv.error = (int32_t*)d_err;
+    cx.n = count;
+    cx.a = 0;
+    cx.b = count;
+    cx.c = 1;
+    cx.term = (double*)d_terms;
+    cx.rs = (RateState*)d_rs;
+    hipLaunchKernelGGL(rate_sum_kernel, dim3(2), dim3(kAcSumThreads), 0, st, cx);
+    HIP_TRY(hipGetLastError());
+    void* p_rs = nullptr;
+    HIP_TRY(small_d2h(ctx, &p_rs, d_rs, sizeof(RateState), st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const RateState& h = *(const RateState*)p_rs;
+    out[0] = h.bits[0];
+    out[1] = h.bits[1];
+    return GPCC_OK;
+  };
+  const int rc = run();
+  for (void* p : {d_terms, d_rs, d_err})
+    if (p)
+      pool_free(ctx, p);
+  return rc;
 }
 
 // guard mode's own test: writes 16 bytes past a pool block (mode 0) or past a sub-allocation of the arena
@@ -2704,6 +2743,99 @@ size_t
 gpcc_ctx_workspace_bytes(const gpcc_ctx* ctx)
 {
   return ctx ? ctx->arena.cap : 0;
+}
+
+// Grow everything a RAHT call of up to max_points points in up to max_slices slices with max_c
+// components allocates on demand -- the arena for the largest workspace any flag combination carves,
+// the pooled record block of the coarse-level sweep, the pinned staging blocks -- touch the device
+// memory once, and return with the device idle.  A transform that follows allocates nothing.
+int
+gpcc_ctx_reserve(gpcc_ctx* ctx, int64_t max_points, int32_t max_slices, int32_t max_c)
+{
+  if (!ctx)
+    return fail(GPCC_ERR_INVALID_ARG, "ctx is null");
+  if (max_points < 1 || max_points > kMaxPoints || max_slices < 1 || max_slices > max_points || max_c < 1 || max_c > 3)
+    return fail(GPCC_ERR_INVALID_ARG, "gpcc_ctx_reserve: sizes out of range");
+  HIP_TRY(hipSetDevice(ctx->device));
+  const int bits = ctx->morton_bits > 0 ? std::min(ctx->morton_bits, 63) : 63;
+  const int nlev = std::min((bits + 2) / 3 + 1, (int)kMaxLevels);
+  size_t need = 0;
+  // the level kernels' plans: lossy encoder and integer-Haar encoder with sub-node prediction and region QPs
+  // (the decoder's and the other flag combinations' workspaces are subsets)
+  for (int haar = 0; haar < 2; haar++) {
+    Plan pl;
+    pl.n = (int)max_points;
+    pl.s = max_slices;
+    pl.c = max_c;
+    pl.nlev = nlev;
+    pl.encoder = true;
+    pl.haar = haar != 0;
+    pl.has_qp = true;
+    pl.lossy = !pl.haar;
+    pl.sub = true;
+    pl.num_rtiles = (int)((max_points + kRdoqTile - 1) / kRdoqTile) + max_slices;
+    Arena measure;
+    carve(measure, pl);
+    need = std::max(need, measure.used);
+  }
+  {
+    // the compact level pass (sub-node prediction off)
+    CxWork w;
+    w.n = (int)max_points;
+    w.s = max_slices;
+    w.c = max_c;
+    w.nlev = nlev;
+    w.encoder = true;
+    w.f64 = false;
+    w.links = links_enabled();
+    size_t used = 0;
+    cx_carve(
+      [&](size_t bytes) {
+        used += ((bytes + 255) & ~size_t(255)) + (guard_mode() ? kGuardInner : 0);
+        return (char*)nullptr;
+      },
+      w);
+    need = std::max(need, used);
+  }
+  int rcode = ensure_arena(ctx, need);
+  if (rcode)
+    return rcode;
+  HIP_TRY(hipMemsetAsync(ctx->arena.base, 0, ctx->arena.cap, ctx->stream));
+  {
+    // the sweep's records (raht_sweep.hpp): at most kSweepDefaultParents parents per slice and level
+    void* rec = nullptr;
+    const size_t rb = sweep_rec_bytes((int64_t)max_slices * nlev * kSweepDefaultParents, max_c);
+    if (pool_malloc(ctx, &rec, rb) == hipSuccess) {
+      HIP_TRY(hipMemsetAsync(rec, 0, rb, ctx->stream));
+      pool_free(ctx, rec);
+    }
+  }
+  // pinned staging of the level kernels and of the compact level pass (launch_transform / launch_cx)
+  const size_t stage_bytes = sizeof(gpcc_raht_params) + 2 * ((size_t)max_slices + 1) * sizeof(int32_t)
+    + 2 * (size_t)nlev * sizeof(void*) + 64;
+  if (ctx->h_pinned_cap < stage_bytes) {
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->h_pinned)
+      HIP_TRY(hipHostFree(ctx->h_pinned));
+    ctx->h_pinned = nullptr;
+    ctx->h_pinned_cap = 0;
+    HIP_TRY(hipHostMalloc(&ctx->h_pinned, stage_bytes * 2));
+    ctx->alloc_events[3]++;
+    ctx->h_pinned_cap = stage_bytes * 2;
+  }
+  const size_t cx_stage = (sizeof(gpcc_raht_params) + ((size_t)max_slices + 1) * sizeof(int32_t) + 64 + 255) & ~size_t(255);
+  if (ctx->h_cx_stage_cap < cx_stage) {
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->h_cx_stage)
+      HIP_TRY(hipHostFree(ctx->h_cx_stage));
+    ctx->h_cx_stage = nullptr;
+    ctx->h_cx_stage_cap = 0;
+    HIP_TRY(hipHostMalloc(&ctx->h_cx_stage, cx_stage * 4));
+    ctx->alloc_events[2]++;
+    ctx->h_cx_stage_cap = cx_stage * 2;
+  }
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return GPCC_OK;
 }
 
 int
@@ -4150,7 +4282,7 @@ gpcc_debug_sub_prof(unsigned long long* out, int reset)
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gpcc::g_sub_prof), sizeof(gpcc::g_sub_prof)) != hipSuccess)
     return -1;
   if (reset) {
-    unsigned long long z[16 + 32 * 4] = {};
+    static unsigned long long z[16 + 32 * 10] = {};
     if (hipMemcpyToSymbol(HIP_SYMBOL(gpcc::g_sub_prof), z, sizeof(z)) != hipSuccess)
       return -1;
   }

@@ -52,7 +52,7 @@ namespace gpcc {
 // s_memtime around the stages of the loop, summed per launch and per level
 // into g_sub_prof, read back with gpcc_debug_sub_prof).  Empty otherwise.
 #ifdef GPCC_SUB_PROF
-__device__ unsigned long long g_sub_prof[16 + 32 * 4];
+__device__ unsigned long long g_sub_prof[16 + 32 * 10];  // [16 + li * 4 + ..] rounds, prologue, loop, iterations; [144 + li * 6 + ..] stage ticks 0-3, idle iterations
 struct SubProf {
   unsigned long long t0 = 0, t1 = 0, last = 0, acc[4] = {0, 0, 0, 0}, iters = 0, idle_iters = 0;
   __device__ static unsigned long long now() { return __builtin_amdgcn_s_memtime(); }
@@ -73,6 +73,9 @@ struct SubProf {
     atomicAdd(&g_sub_prof[16 + li * 4 + 1], t1 - t0);
     atomicAdd(&g_sub_prof[16 + li * 4 + 2], t2 - t1);
     atomicAdd(&g_sub_prof[16 + li * 4 + 3], iters);
+    for (int i = 0; i < 4; i++)
+      atomicAdd(&g_sub_prof[144 + li * 6 + i], acc[i]);
+    atomicAdd(&g_sub_prof[144 + li * 6 + 4], idle_iters);
   }
 };
 #else

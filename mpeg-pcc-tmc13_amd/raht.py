@@ -49,6 +49,10 @@ class Context:
     def set_morton_bits(self, bits):
         _lib.check(self._lib.gpcc_ctx_set_morton_bits(self._h, int(bits)))
 
+    def reserve(self, max_points, max_slices=1, max_c=3):
+        """gpcc_ctx_reserve: everything the RAHT entries allocate on demand, ahead of the first call"""
+        _lib.check(self._lib.gpcc_ctx_reserve(self._h, int(max_points), int(max_slices), int(max_c)))
+
     def set_fast_arith(self, on):
         """doubles where they are exact (default) / int64 always in the sub-node kernels"""
         _lib.check(self._lib.gpcc_ctx_set_fast_arith(self._h, int(bool(on))))

@@ -38,8 +38,8 @@ def test_abi_version_and_struct_size(lib):
     from mpeg_pcc_tmc13_amd import _lib
     import re
     hdr = open(os.path.join(ROOT, "include", "gpcc_attr_mi355.h")).read()
-    assert int(re.search(r"#define GPCC_ABI_VERSION (\d+)", hdr).group(1)) == 5
-    assert lib.gpcc_abi_version() == 5 == _lib.ABI_VERSION
+    assert int(re.search(r"#define GPCC_ABI_VERSION (\d+)", hdr).group(1)) == 6
+    assert lib.gpcc_abi_version() == 6 == _lib.ABI_VERSION
     # 6 + 19 + 12 + 1 + 1 + 64 + 1 + 1 + 1 + 448 ints
     assert C.sizeof(RahtParams) == 4 * (6 + 19 + 12 + 1 + 1 + 64 + 3 + 32 * 7 * 2)
 

@@ -1,0 +1,113 @@
+"""CPU tier: the coarse-level sweep of the block loop with sub-node prediction
+(mpeg-pcc-tmc13_amd/csrc/raht_sweep.hpp: one workgroup per slice, the levels of a slice with few
+parents inside ONE launch, hand-offs through LDS) under the lock-step wavefront emulator, against
+the oracle.  The same kernel source the gfx950 library launches; the launch order of the library's
+launch_transform is restated in tests/emu/sweep_emu_harness.cpp.  Pins the round / ring / zero-run
+bookkeeping and the hand-over to the per-level kernels (raht_subnode.hpp) below the sweep; the
+`-m gpu` tests remain the parity tests proper."""
+import numpy as np
+import pytest
+
+import emu_sweep_loader as es
+import oracle_loader as ol
+import raht_cases as rc
+from mpeg_pcc_tmc13_amd import raht_params, synth
+
+
+def _sub(case):
+    pk = case["params"]
+    return (pk.get("subnode", True) and not pk.get("haar", False) and pk.get("prediction", True)
+            and case["qp_region"] is None and case["gen"][1].get("n", 0) <= 2000)
+
+
+ELIGIBLE = [c for c in rc.CASES if _sub(c)]
+F64 = pytest.mark.parametrize("f64", [False, True], ids=["i64", "f64"])
+
+
+def test_case_table_has_eligible_cases():
+    assert len(ELIGIBLE) >= 12
+
+
+def _check(p, morton, attrs, offsets=None, f64=False, sweep_parents=8192, min_swept=1):
+    c = attrs.shape[1]
+    if offsets is None:
+        o_co, o_rec = ol.oracle().raht_forward(p, morton, attrs)
+    else:
+        o_co = np.zeros(attrs.size, np.int32)
+        o_rec = np.zeros_like(attrs)
+        for a, b in zip(offsets[:-1], offsets[1:]):
+            co, rec = ol.oracle().raht_forward(p, morton[a:b], attrs[a:b])
+            o_co[a * c:b * c] = co
+            o_rec[a:b] = rec
+    co, rec, swept = es.forward(p, morton, attrs, offsets=offsets, f64=f64, sweep_parents=sweep_parents)
+    assert swept >= min_swept
+    assert np.array_equal(co, o_co)
+    assert np.array_equal(rec, o_rec)
+    inv, _ = es.inverse(p, morton, o_co, c, offsets=offsets, f64=f64, sweep_parents=sweep_parents)
+    assert np.array_equal(inv, o_rec)
+
+
+@pytest.mark.parametrize("case", ELIGIBLE, ids=[c["name"] for c in ELIGIBLE])
+def test_sweep_matches_the_oracle(case):
+    p, morton, attrs, _ = rc.make_inputs(case)
+    if len(morton) < 2:
+        pytest.skip("a single point has no level")
+    _check(p, morton, attrs, f64=bool(p.raht_extension) and case["gen"][1].get("bitdepth", 8) <= 8,
+           min_swept=1 if len(np.unique(morton)) > 1 else 0)
+
+
+# the sweep takes the top levels and hands over to the per-level kernels where a level has more
+# parents than `sweep_parents`: every split point of a small tree
+@pytest.mark.parametrize("sweep_parents", [1, 8, 64, 512])
+@pytest.mark.parametrize("c", [1, 3])
+def test_hand_over_to_the_level_kernels(c, sweep_parents):
+    xyz, attrs = synth.random_cloud(n=2500, seed=31 + c, bits=5, c=c, dup_fraction=0.1)
+    morton, attrs, _ = synth.sort_by_morton(xyz, attrs)
+    _check(raht_params(qp=28), morton, attrs, sweep_parents=sweep_parents, min_swept=1)
+
+
+# the zero-run state (tmc3/RAHT.cpp:1618-1669) binds where many coefficients sit in the undecided
+# band: every rate point, smooth and textured fields, with the rounds of EIGHT wavefronts in flight
+@F64
+@pytest.mark.parametrize("qp", [4, 10, 16, 22, 28, 34, 40, 46, 51])
+def test_lossy_qp_sweep(qp, f64):
+    xyz, a = synth.lidar_cloud(4000, seed=qp, refl_noise=6 + (qp % 3) * 9)
+    morton, attrs, _ = synth.sort_by_morton(xyz, a)
+    _check(raht_params(qp=qp), morton, attrs, f64=f64)
+
+
+@pytest.mark.parametrize("c", [1, 2, 3])
+def test_dense_surface(c):
+    xyz, col = synth.dense_cloud(5000, seed=9, bits=7)
+    morton, attrs, _ = synth.sort_by_morton(xyz, col[:, :c])
+    _check(raht_params(qp=34 - 6 * c), morton, attrs)
+
+
+def test_batch_of_ragged_slices():
+    parts = []
+    for i, n in enumerate([1, 700, 2, 1500, 40, 9, 1200]):
+        if i % 3 == 0:
+            xyz, a = synth.lidar_cloud(max(n, 4), seed=40 + i)
+        else:
+            xyz, a = synth.random_cloud(n=n, seed=40 + i, bits=2 + i % 4, c=1, dup_fraction=0.2 if i % 2 else 0.0)
+        m, a, _ = synth.sort_by_morton(xyz[:n], a[:n])
+        parts.append((m, a))
+    morton = np.concatenate([m for m, _ in parts])
+    attrs = np.concatenate([a for _, a in parts])
+    offs = np.concatenate([[0], np.cumsum([len(m) for m, _ in parts])])
+    _check(raht_params(qp=22), morton, attrs, offsets=offs, min_swept=1)
+
+
+VARIANTS = [dict(search_range=8), dict(threshold0=4, threshold1=10), dict(weights=(4, 2, 1, 3, 1)),
+            dict(layers=[(30, -1), (34, -2), (38, 0), (28, 1)]),
+            dict(ac_offsets=[[(i - 3, 3 - i) for i in range(7)], [(2, 1)] * 7, [(-4, 0)] * 7]),
+            dict(qp=40, bitdepth=10), dict(extension=False)]
+
+
+@pytest.mark.parametrize("vi", range(len(VARIANTS)))
+def test_parameter_variants(vi):
+    kw = dict(VARIANTS[vi])
+    xyz, attrs = synth.random_cloud(n=1800 + 100 * vi, seed=60 + vi, bits=5, c=3 if vi % 2 else 1,
+                                    dup_fraction=0.1 if vi % 2 else 0.0, bitdepth=kw.get("bitdepth", 8))
+    morton, attrs, _ = synth.sort_by_morton(xyz, attrs)
+    _check(raht_params(**kw), morton, attrs)
