@@ -73,6 +73,8 @@ def parse():
     ap.add_argument("--legs", default="",
                     help="N=1: run ONLY these extra legs (comma separated: lifting,predicting,recolour,raht_inter) after "
                          "the headline step -- for profiler passes of one leg (tools/r05_pmc.sh)")
+    ap.add_argument("--frames-per-gpu-batched", type=int, default=10,
+                    help="frames per GPU of the weak_batched leg (the regime where one GPU is busy)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the alternative-flag, 10M-forward, calibration and lifting legs")
     return ap.parse_args()
@@ -138,14 +140,15 @@ def timed(torch, dev, fn, steps, warmup=1):
     return (time.perf_counter() - t0) / steps
 
 
-def timed_stats(torch, dev, fn, steps, warmup=2, settle=0.3):
-    """every step timed on its own (a synchronisation per step): median and max tell a steady state from a
-    hiccup (arena regrowth, an expired bounded wait and its retry) -- VERDICT r04 weak #10.
-    `settle`: an untimed pause between the warm-up calls and the timed steps.  A batch's buffers (hundreds of MB from
-    torch's allocator, the context's arena regrown by the first warm-up call) have just been allocated, and on the
-    MI355X box the first one or two timed steps right behind that took 10-80 ms with every kernel at its usual time
-    (the device's queue idles between two dispatches) -- in 1-8 of ~640 steps, never with the pause (0 in 3 runs),
-    never in a steady loop (0 of 6479 consecutive steps of the worst leg): profiles/r05_stall_root_cause.txt"""
+def timed_stats(torch, dev, fn, steps, warmup=2, settle=0.0):
+    """every step timed on its own (a synchronisation per step): (median, max, index of the slowest step) tell a
+    steady state from a hiccup (arena regrowth, an expired bounded wait and its retry).
+    `settle`: an untimed pause between the warm-up calls and the timed steps.  On the MI355X box the first one or two
+    calls right behind a large ALLOCATION (a batch's buffers from torch's allocator, the context's arena regrown by
+    the first warm-up call) took 10-80 ms with every kernel at its usual time (profiles/r05_stall_root_cause.txt);
+    round 5 benchmarked around it with a 0.3 s pause.  Since round 6 the library has gpcc_ctx_reserve -- the bench
+    reserves once, before any batch exists -- and the legs are timed with settle = 0; the batch curve reports both
+    variants so that the pause's effect stays visible."""
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize(dev)
@@ -157,9 +160,9 @@ def timed_stats(torch, dev, fn, steps, warmup=2, settle=0.3):
         fn()
         torch.cuda.synchronize(dev)
         ts.append(time.perf_counter() - t0)
-    timed_stats.last_argmax = max(range(len(ts)), key=lambda i: ts[i])  # which step was the slowest
+    slowest = max(range(len(ts)), key=lambda i: ts[i])
     ts.sort()
-    return ts[len(ts) // 2], ts[-1]
+    return ts[len(ts) // 2], ts[-1], slowest
 
 
 def kernel_profile(torch, dev, ctx, fn, steps):
@@ -238,6 +241,12 @@ def main():
     ctx = context(local_rank, stream=stream.cuda_stream)
 
     frames = [make_frame(args.cloud, args.points, seed=1 + rank * args.frames + f) for f in range(args.frames)]
+    # everything the transforms allocate on demand, once, before any batch exists (gpcc_ctx_reserve): the legs below
+    # are timed without a pause behind their warm-up (timed_stats)
+    ctx.set_morton_bits(frames[0][2])
+    biggest = max(args.points * args.frames, 0 if args.no_extras else max(
+        10 * 1_000_000, 10 * args.configs4_points, args.frames_per_gpu_batched * args.points, args.configs3_points))
+    ctx.reserve(biggest, max(args.frames, 10), 3)
     b = Batch(torch, dev, ctx, frames, p)
     c, n = b.c, b.n
 
@@ -335,6 +344,62 @@ def main():
         out["config"]["scaling_scope"] = ("transform + one RCCL gather of the coefficient buffers; the CPU "
                                           "arithmetic coder that consumes them is not in the loop")
 
+    if world > 1:
+        # where a step's time goes on every rank: the transforms alone (device time, no collective) and the
+        # gather alone, 3 steps each, every rank's figure on rank 0
+        def rank_times(batch):
+            gathered_ = make_gather_buffers(batch)
+            torch.cuda.synchronize(dev)
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                if args.direction in ("both", "forward"):
+                    batch.forward()
+                if args.direction in ("both", "inverse"):
+                    batch.inverse()
+            torch.cuda.synchronize(dev)
+            dev_ms = (time.perf_counter() - t0) / 3 * 1e3
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                gather_step(batch, gathered_)
+            torch.cuda.synchronize(dev)
+            dist.barrier()
+            gat_ms = (time.perf_counter() - t0) / 3 * 1e3
+            mine_ = torch.tensor([dev_ms, gat_ms], dtype=torch.float64, device=xdev)
+            allr = [torch.zeros(2, dtype=torch.float64, device=xdev) for _ in range(world)] if rank == 0 else None
+            dist.gather(mine_, allr, dst=0)
+            if rank != 0:
+                return None
+            return {"device_ms_per_rank": [round(float(t[0]), 3) for t in allr],
+                    "gather_ms_per_rank": [round(float(t[1]), 3) for t in allr]}
+        rt = rank_times(b)
+        if rank == 0:
+            out["distributed"].update(rt)
+
+    if not args.no_extras and args.direction == "both":
+        # ---- the weak-scaling line in the regime where ONE GPU is busy: frames_per_gpu_batched frames per GPU and
+        #      step (a single 1 M-point frame is a latency-bound unit: its time says nothing about throughput).
+        #      The same leg runs at N = 1, so the N-GPU figure divides by a like-for-like single-GPU figure. ----
+        fb = [make_frame(args.cloud, args.points, seed=1000 + rank * args.frames_per_gpu_batched + f)
+              for f in range(args.frames_per_gpu_batched)]
+        bb = Batch(torch, dev, ctx, fb, p)
+        kb = 3
+        elb, _ = run_timed(bb, "both", kb, 1)
+        wb = {"workload": f"{args.frames_per_gpu_batched} x {args.points}-point S-{args.cloud} frames per GPU and step, "
+                          "forward+inverse, default flags" + (" + gather of the coefficient buffers" if world > 1 else ""),
+              "frames_per_gpu": args.frames_per_gpu_batched, "scaling": "weak",
+              "value": round(bb.n * world * kb / elb / 1e6, 3), "unit": "Mpoints/s",
+              "ms_per_step": round(elb / kb * 1e3, 3), "steps": kb,
+              "roundtrip_decoder_equals_encoder_recon": bb.roundtrip_ok()}
+        if world > 1:
+            rtb = rank_times(bb)
+            if rank == 0:
+                wb.update(rtb)
+        if rank == 0:
+            out["weak_batched"] = wb
+        del bb
+
     if world > 1 and args.verify_gather and rank == 0 and args.direction != "inverse":
         # what rank 0 gathered is what a single GPU computes for the same frames
         same = True
@@ -427,7 +492,7 @@ def main():
             def stept():
                 bt.forward()
                 bt.inverse()
-            med, mx = timed_stats(torch, dev, stept, 10, warmup=2)
+            med, mx, _ = timed_stats(torch, dev, stept, 10, warmup=2)
             bt.forward()
             torch.cuda.synchronize(dev)
             nzt = float((bt.d_coeffs != 0).sum().item()) / bt.d_coeffs.numel()
@@ -439,6 +504,11 @@ def main():
                 "nonzero_coefficient_fraction": round(nzt, 4),
                 "roundtrip_decoder_equals_encoder_recon": bt.roundtrip_ok()}
             del bt
+            # (next to `value`: the headline cannot be read without it -- VERDICT r05)
+            out["config"]["same_call_on_textured_field"] = {
+                "value": out["headline_textured"]["value"], "unit": "Mpoints/s",
+                "ms_per_step": out["headline_textured"]["ms_per_step"],
+                "nonzero_coefficient_fraction": out["headline_textured"]["nonzero_coefficient_fraction"]}
         if args.legs:
             for leg in args.legs.split(","):
                 out[leg] = {"lifting": lambda: lifting_leg(ctx, args), "predicting": lambda: predicting_leg(ctx, args),
@@ -453,6 +523,7 @@ def main():
                 if r:
                     r["frac_calibrated"] = round(r["achieved"] / cal, 5)
                     r["pipeline_frac_calibrated"] = round(r["pipeline_achieved"] / cal, 5)
+            out["first_call"] = first_call_leg(torch, dev, local_rank, stream, frames[0], p)
             out["host_tier"] = host_tier_leg(ctx, frames[0], p)
             out["lifting"] = lifting_leg(ctx, args)
             out["predicting"] = predicting_leg(ctx, args)
@@ -618,8 +689,11 @@ def forward_10m(torch, dev, ctx, params_for, first_frames):
     for sub in (1, 0):
         p = params_for("lidar", sub)
         b = Batch(torch, dev, ctx, frames, p)
-        k = 5
-        dt = timed(torch, dev, b.forward, k, warmup=2)
+        # (median of 10 steps timed one by one: one step in a few hundred lands in the tens of milliseconds the
+        # device's queue can idle behind a large free / allocation -- timed_stats -- and a mean of five would
+        # report that instead of the transform; the slowest step is in the line)
+        k = 10
+        dt, dt_max, dt_at = timed_stats(torch, dev, b.forward, k, warmup=2)
         ctx.synchronize()
         kt = kernel_profile(torch, dev, ctx, b.forward, 3)
         name, (ms, launches) = max(kt.items(), key=lambda kv: kv[1][0])
@@ -627,6 +701,7 @@ def forward_10m(torch, dev, ctx, params_for, first_frames):
         achieved = nbytes / (ms / 1e3) / 1e9
         res[f"subnode_{sub}"] = {
             "value": round(b.n / dt / 1e6, 2), "unit": "Mpoints/s", "ms_per_forward": round(dt * 1e3, 3),
+            "ms_per_forward_max": round(dt_max * 1e3, 3), "slowest_step": dt_at,
             "steps": k, "launches_per_forward": round(sum(v[1] for v in kt.values()), 1),
             "roofline": {
                 "bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
@@ -649,17 +724,63 @@ def forward_10m(torch, dev, ctx, params_for, first_frames):
         pts = []
         for nf in (1, 2, 5, 10):
             b = Batch(torch, dev, ctx, frames[:nf], p)
-            tf, tf_max = timed_stats(torch, dev, b.forward, 10, warmup=2)
-            tf_at = timed_stats.last_argmax
-            ti, ti_max = timed_stats(torch, dev, b.inverse, 10, warmup=2)
-            ti_at = timed_stats.last_argmax
+            tf, tf_max, tf_at = timed_stats(torch, dev, b.forward, 10, warmup=2)
+            ti, ti_max, ti_at = timed_stats(torch, dev, b.inverse, 10, warmup=2)
+            # the same with round 5's 0.3 s pause behind the warm-up (see timed_stats)
+            sf, sf_max, _ = timed_stats(torch, dev, b.forward, 10, warmup=1, settle=0.3)
+            si, si_max, _ = timed_stats(torch, dev, b.inverse, 10, warmup=1, settle=0.3)
             pts.append({"slices": nf, "steps": 10, "forward_ms": round(tf * 1e3, 3), "forward_ms_max": round(tf_max * 1e3, 3),
                         "forward_slowest_step": tf_at, "inverse_slowest_step": ti_at,
                         "inverse_ms": round(ti * 1e3, 3), "inverse_ms_max": round(ti_max * 1e3, 3),
+                        "settled_0p3s": {"forward_ms": round(sf * 1e3, 3), "forward_ms_max": round(sf_max * 1e3, 3),
+                                         "inverse_ms": round(si * 1e3, 3), "inverse_ms_max": round(si_max * 1e3, 3)},
                         "forward_Mpts": round(b.n / tf / 1e6, 1), "inverse_Mpts": round(b.n / ti / 1e6, 1)})
             del b
         curve[f"subnode_{sub}"] = pts
     res["batch_curve"] = curve
+    return res
+
+
+def first_call_leg(torch, dev, local_rank, stream, frame, p, trials=20):
+    """The reference's call pattern through the seams (tmc3/AttributeEncoder.cpp:1273, 1341): a context, then ONE
+    transform per (slice, attribute).  Per trial: a FRESH context, the first forward transform of the headline frame
+    timed on its own, no pause anywhere -- with gpcc_ctx_reserve in front (what INTEGRATION.md tells a seam user to
+    do) and without it (the first call then pays for the arena).  max / median of the reserved variant is the
+    figure: a call right behind the allocation used to take 10-80 ms now and then (profiles/r05_stall_root_cause.txt)."""
+    from mpeg_pcc_tmc13_amd import context
+    morton, attrs, bits = frame
+    d_m = to_device(torch, morton, dev)
+    src = to_device(torch, attrs.reshape(-1), dev)
+    c = attrs.shape[1]
+    n = len(morton)
+    offs = np.array([0, n], dtype=np.int64)
+    res = {}
+    for name, reserve in (("reserved", True), ("unreserved", False)):
+        first, second = [], []
+        for _ in range(trials):
+            cx = context(local_rank, stream=stream.cuda_stream)
+            cx.set_morton_bits(bits)
+            if reserve:
+                cx.reserve(n, 1, c)
+            d_a = src.clone()
+            d_c = torch.zeros(c * n, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize(dev)
+            for lst in (first, second):
+                d_a.copy_(src)
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                cx.dev_raht_forward(p, offs, d_m.data_ptr(), d_a.data_ptr(), d_c.data_ptr(), c)
+                torch.cuda.synchronize(dev)
+                lst.append(time.perf_counter() - t0)
+            cx.close()
+            del d_a, d_c
+        f = sorted(first)
+        g = sorted(second)
+        res[name] = {"trials": trials, "first_call_ms_median": round(f[len(f) // 2] * 1e3, 3),
+                     "first_call_ms_max": round(f[-1] * 1e3, 3),
+                     "max_over_median": round(f[-1] / f[len(f) // 2], 2),
+                     "second_call_ms_median": round(g[len(g) // 2] * 1e3, 3), "second_call_ms_max": round(g[-1] * 1e3, 3)}
+    res["note"] = "forward transform of the headline frame, device tier, one call per fresh context; no pause"
     return res
 
 

@@ -284,6 +284,8 @@ struct gpcc_ctx {
   TreeStats* h_stats = nullptr;   // pinned: what schedule_kernel tells the host about the tree
   CxLevelTab* h_cxtab = nullptr;  // pinned: blocks / real children per level (compact level pass)
   double* d_log2 = nullptr;       // log2 of 0 .. 2^20 from the host's libm (predicting encoder's rate model)
+  void* sweep_mem = nullptr;      // records of the coarse-level sweep (raht_sweep.hpp), grown on demand
+  size_t sweep_cap = 0;
   int pred_passes = 0;            // passes the last predicting encode with direct predictors took
   int64_t pred_pass_stats[4] = {0, 0, 0, 0};  // slices, passes, most passes, declined at the limit
   hipEvent_t ev_stats = nullptr;  // recorded behind schedule_kernel
@@ -356,6 +358,7 @@ guard_check_context(gpcc_ctx* ctx, const char* what)
   guarded_check(ctx->d_lut, what);
   guarded_check(ctx->d_error, what);
   guarded_check(ctx->d_log2, what);
+  guarded_check(ctx->sweep_mem, what);
   for (gpcc_ctx* lane : ctx->lanes) {
     hipStreamSynchronize(lane->stream);
     guard_check_context(lane, what);
@@ -777,6 +780,25 @@ ensure_arena(gpcc_ctx* ctx, size_t bytes)
   return GPCC_OK;
 }
 
+// the record block of the coarse-level sweep (raht_sweep.hpp): one allocation per context, grown on demand
+// (its size follows the tree, not the point count: the pool's best-fit reuse would miss it)
+int
+ensure_sweep_mem(gpcc_ctx* ctx, size_t bytes)
+{
+  if (ctx->sweep_cap >= bytes)
+    return GPCC_OK;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (ctx->sweep_mem)
+    HIP_TRY(guarded_free(ctx->sweep_mem));
+  ctx->sweep_mem = nullptr;
+  ctx->sweep_cap = 0;
+  const size_t want = bytes + bytes / 4;
+  HIP_TRY(guarded_malloc(&ctx->sweep_mem, want, "sweep records"));
+  ctx->sweep_cap = want;
+  ctx->alloc_events[1]++;
+  return GPCC_OK;
+}
+
 // log2 of every integer the rate estimates can ask for (0 .. 2^20), from THIS host's libm -- the
 // reference's own log2: once per context (predicting encoder's rate model, inter-frame RAHT's per-layer decision)
 int
@@ -1063,20 +1085,18 @@ launch_transform(
   }
   // ---- sub-node prediction, the coarse levels of every slice: one launch (raht_sweep.hpp) ----
   int level_from = first_level;  // the per-level launches start below this level
-  void* sweep_mem = nullptr;
   if (sweep && !piped && ts.fine_levels < first_level) {
     const int lo = std::max(0, ts.fine_levels);
     const SweepCtx sw{first_level - 1, lo};
     SweepRec rec{};
     const int64_t sweep_parents = sweep_rec_layout(&rec, ts.nodes, sw.li_hi, sw.li_lo);
-    // the records of the levels the sweep takes, sized by the real node counts the host has just read:
-    // from the context's caching pool (reuse is ordered on the context's stream)
-    if (pool_malloc(ctx, &sweep_mem, sweep_rec_bytes(sweep_parents, C)) == hipSuccess) {
+    // the records of the levels the sweep takes, sized by the real node counts the host has just read
+    // (reuse of the context's block is ordered on the context's stream)
+    if (ensure_sweep_mem(ctx, sweep_rec_bytes(sweep_parents, C)) == GPCC_OK) {
       level_from = lo;
-      sweep_rec_carve(&rec, sweep_mem, sweep_parents, C);
+      sweep_rec_carve(&rec, ctx->sweep_mem, sweep_parents, C);
       Timer t(ctx, encoder ? "sub_sweep_lossy" : "sub_sweep_synth");
       sweep_launch<C>(st, lc, sw, rec, ts.nodes, s, encoder, pl.f64);
-      pool_free(ctx, sweep_mem);
     }
   }
   for (int li = piped ? -1 : level_from - 1; li >= 0; li--) {
@@ -2576,6 +2596,8 @@ gpcc_ctx_destroy(gpcc_ctx* ctx)
     hipStreamDestroy(ctx->kd_stream);
   if (ctx->d_log2)
     guarded_free(ctx->d_log2);
+  if (ctx->sweep_mem)
+    guarded_free(ctx->sweep_mem);
   if (ctx->ev_stats)
     hipEventDestroy(ctx->ev_stats);
   if (ctx->h_pinned)
@@ -2801,14 +2823,25 @@ gpcc_ctx_reserve(gpcc_ctx* ctx, int64_t max_points, int32_t max_slices, int32_t 
   if (rcode)
     return rcode;
   HIP_TRY(hipMemsetAsync(ctx->arena.base, 0, ctx->arena.cap, ctx->stream));
+  // the sweep's records (raht_sweep.hpp): at most kSweepDefaultParents parents per slice and level
+  rcode = ensure_sweep_mem(ctx, sweep_rec_bytes((int64_t)max_slices * nlev * kSweepDefaultParents, max_c));
+  if (rcode)
+    return rcode;
+  HIP_TRY(hipMemsetAsync(ctx->sweep_mem, 0, ctx->sweep_cap, ctx->stream));
   {
-    // the sweep's records (raht_sweep.hpp): at most kSweepDefaultParents parents per slice and level
-    void* rec = nullptr;
-    const size_t rb = sweep_rec_bytes((int64_t)max_slices * nlev * kSweepDefaultParents, max_c);
-    if (pool_malloc(ctx, &rec, rb) == hipSuccess) {
-      HIP_TRY(hipMemsetAsync(rec, 0, rb, ctx->stream));
-      pool_free(ctx, rec);
-    }
+    // the host tier's device buffers for a slice of max_points points (host_transform): Morton codes,
+    // attributes, coefficients, region QP offsets -- into the pool, where the calls find them
+    const size_t n = (size_t)max_points;
+    void* blk[4] = {nullptr, nullptr, nullptr, nullptr};
+    const size_t sz[4] = {8 * n, 4 * n * (size_t)max_c, 4 * n * (size_t)max_c, 8 * n};
+    for (int i = 0; i < 4; i++)
+      if (pool_malloc(ctx, &blk[i], sz[i]) != hipSuccess)
+        blk[i] = nullptr;
+    for (int i = 0; i < 4; i++)
+      if (blk[i]) {
+        hipMemsetAsync(blk[i], 0, sz[i], ctx->stream);
+        pool_free(ctx, blk[i]);
+      }
   }
   // pinned staging of the level kernels and of the compact level pass (launch_transform / launch_cx)
   const size_t stage_bytes = sizeof(gpcc_raht_params) + 2 * ((size_t)max_slices + 1) * sizeof(int32_t)

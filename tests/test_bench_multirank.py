@@ -27,7 +27,8 @@ def run_bench(world, points, c3, c4):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
            os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
-           "--points", str(points), "--configs3-points", str(c3), "--configs4-points", str(c4)]
+           "--points", str(points), "--configs3-points", str(c3), "--configs4-points", str(c4),
+           "--frames-per-gpu-batched", "3"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -50,6 +51,12 @@ def test_bench_eight_ranks_share_the_gpu():
     assert c4["ceiling"].startswith("at most 5.00x")
     assert c4["roundtrip_decoder_equals_encoder_recon"] is True and c4["gathered_equals_single_rank"] is True
     assert c4["value"] > 0
+    # the throughput regime of the weak-scaling line: several frames per GPU and step, per-rank device and gather times
+    wb = d["weak_batched"]
+    assert wb["frames_per_gpu"] == 3 and wb["scaling"] == "weak" and wb["value"] > 0
+    assert wb["roundtrip_decoder_equals_encoder_recon"] is True
+    assert len(wb["device_ms_per_rank"]) == 8 and len(wb["gather_ms_per_rank"]) == 8
+    assert len(d["distributed"]["device_ms_per_rank"]) == 8 and min(d["distributed"]["device_ms_per_rank"]) > 0
 
 
 @pytest.mark.gpu
@@ -64,3 +71,5 @@ def test_bench_two_ranks_one_json_line():
     assert d["config"]["gathered_equals_single_rank"] is True
     # BASELINE configs[3] shape (dense colour frames, one per rank) in the same line
     assert d["configs3"]["roundtrip_decoder_equals_encoder_recon"] is True and d["configs3"]["value"] > 0
+    assert d["weak_batched"]["frames_per_gpu"] == 3 and len(d["weak_batched"]["device_ms_per_rank"]) == 2
+    assert len(d["distributed"]["gather_ms_per_rank"]) == 2
