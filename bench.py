@@ -72,7 +72,7 @@ def parse():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--legs", default="",
                     help="N=1: run ONLY these extra legs (comma separated: lifting,predicting,recolour,raht_inter) after "
-                         "the headline step -- for profiler passes of one leg (tools/r05_pmc.sh)")
+                         "the headline step -- for profiler passes of one leg (tools/pmc.sh)")
     ap.add_argument("--frames-per-gpu-batched", type=int, default=10,
                     help="frames per GPU of the weak_batched leg (the regime where one GPU is busy)")
     ap.add_argument("--no-extras", action="store_true",
@@ -905,11 +905,11 @@ def hbm_calibration(torch, dev):
 
 def pmc_traffic(args, kernel, workload=None):
     """HBM-side bytes per launch of a kernel (FETCH_SIZE + WRITE_SIZE of rocprofv3, separate --pmc passes) from the
-    committed counter passes of THIS workload at this round's HEAD (profiles/r05_pmc_traffic.json, made by
-    tools/r05_pmc.sh + tools/r05_pmc_json.py); None for any other workload or kernel.  PMC passes cannot run inside
+    committed counter passes of THIS workload at this round's HEAD (profiles/r06_pmc_traffic.json, made by
+    tools/pmc.sh + tools/pmc_json.py); None for any other workload or kernel.  PMC passes cannot run inside
     this process.  Raw counter bytes: the guide's x2 correction of FETCH_SIZE applies to wide coalesced streams only,
     and these kernels' traffic is 4..16-byte gathers, polls and write-through granules."""
-    path = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r06_pmc_traffic.json")
     if workload is None:
         default = (args.cloud == "lidar" and args.points == 1_000_000 and args.frames == 1 and args.subnode == 1
                    and args.qp == 34 and not args.haar and args.direction == "both")

@@ -120,7 +120,7 @@ size_t gpcc_ctx_workspace_bytes(const gpcc_ctx* ctx);
  * reference's call pattern, tmc3/AttributeEncoder.cpp:1273, 1341 -- calls this once with its
  * largest slice: no transform allocates afterwards (gpcc_ctx_workspace_bytes stays put), so the
  * first call is not followed by the tens of milliseconds a fresh allocation can cost the calls
- * right behind it (DESIGN.md section 8).  Not needed for correctness: workspace still grows on
+ * right behind it (DESIGN.md section 7).  Not needed for correctness: workspace still grows on
  * demand when a call is larger than what was reserved. */
 int gpcc_ctx_reserve(gpcc_ctx* ctx, int64_t max_points, int32_t max_slices, int32_t max_c);
 /* Device-tier hint: number of significant Morton-code bits (3 x coordinate

@@ -298,7 +298,7 @@ cx_scan_kernel(TreeView tv, CxLists cl, int ncol)
 // tab_host: a second copy of the level table in pinned HOST memory (or null) -- the host sizes the level launches
 // from it after an event behind this kernel.  (Until round 5 the table came back with a hipMemcpyAsync: one step in
 // ten of a long-running process then took 20-80 ms with every kernel at its usual time -- the copy engine's path, not
-// the kernels'; tools/r05_stall_probe3.py.  The sub-node path never had it: its schedule kernel writes its statistics
+// the kernels'; tools/archive/r05_stall_probe3.py.  The sub-node path never had it: its schedule kernel writes its statistics
 // to pinned memory itself.)
 template<int C>
 __global__ __launch_bounds__(64) void

@@ -274,7 +274,7 @@ struct gpcc_ctx {
   std::vector<size_t> arena_bands;  // guard mode (GPCC_GUARD=1): see Arena
   // allocation events since the context was made (gpcc_debug_alloc_events): arena (re)allocations, pool misses,
   // pinned staging (re)allocations -- a step that takes tens of milliseconds longer than its neighbours either shows up here or
-  // was not the library's doing (tools/r05_stall_probe.py)
+  // was not the library's doing (tools/archive/r05_stall_probe.py)
   long long alloc_events[4] = {0, 0, 0, 0};
   int morton_bits = 0;  // hint for the device tier, 0 = unknown
   SharedLut* d_lut = nullptr;  // small-weight tables, built once

@@ -237,7 +237,7 @@ qpset_quantizers(
 // |d| entries before / after `from`, clamped to the slice's node range.
 // (A per-level hash table was measured instead of this search: the level
 // kernels are VALU-bound, not latency-bound, so the look-ups bought nothing
-// while the 3.3 M atomic inserts cost 1 ms -- see DESIGN.md.)
+// while the 3.3 M atomic inserts cost 1 ms -- see profiles/HISTORY.md.)
 __device__ __forceinline__ int
 find_in_window(
   const int64_t* __restrict__ key, int first, int last, int from,

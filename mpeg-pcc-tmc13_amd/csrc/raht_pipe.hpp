@@ -9,7 +9,7 @@
 // it predicts from -- a handful of nodes of level li -- not the whole level:
 // walked across levels the longest path of the same frame is 1 214 hops.  The
 // encoder cannot follow (its RDOQ state is carried in coding order, all of a
-// level before the next: DESIGN.md section 5.2); the decoder can, and this is
+// level before the next: DESIGN.md section 4.2); the decoder can, and this is
 // it.
 //
 // What changes against the per-level kernel:

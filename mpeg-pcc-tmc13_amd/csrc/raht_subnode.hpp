@@ -26,7 +26,7 @@
 // the SAME wavefront (Morton-adjacent blocks: most hops of the longest
 // chains) are taken from its registers instead.  The poll is the only
 // vector-memory wait inside the loop -- on gfx9 any s_waitcnt vmcnt(0) also
-// waits for the write-through stores in flight (DESIGN.md section 8).  Spins
+// waits for the write-through stores in flight (DESIGN.md section 7).  Spins
 // are bounded: a stuck launch raises ctx.error instead of hanging the GPU.
 //
 // Modes: kSynth (decoder), kFused (integer-Haar encoder) and kLossySub, the

@@ -209,6 +209,32 @@ def ref_two_attr_roundtrip(lp_a, transform_a, lp_b, transform_b, qp, xyz, colour
     return pay[:ln].tobytes(), (out[0].reshape(n, 3), out[1]), (out[2].reshape(n, 3), out[3]), tuple(int(v) for v in reused)
 
 
+def ref_multi_slice_roundtrip(lp_a, transform_a, lp_b, transform_b, qp, offsets, xyz, colours, refl, lib=None):
+    """several slices of a frame through the operator as the reference's compressPartition drives it: new coder
+    objects per slice, colour then reflectance inside a slice, the entropy context memory of each attribute carried
+    from slice to slice.  -> (payloads back to back, lengths [2 per slice], (rec colour, rec reflectance) of the
+    encoder, of the decoder, objects kept for B per slice)"""
+    lib = lib or ol.ref().lib
+    lib.ref_multi_slice_roundtrip.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, i32p, i32p,
+                                              i32p, i32p, i32p, i32p, i32p, i32p, u8p, C.c_int32, i32p, i32p]
+    offs = np.ascontiguousarray(offsets, dtype=np.int32)
+    k = len(offs) - 1
+    xyz = np.ascontiguousarray(xyz, dtype=np.int32)
+    colours = np.ascontiguousarray(colours, dtype=np.int32)
+    refl = np.ascontiguousarray(refl, dtype=np.int32).reshape(-1)
+    n = len(xyz)
+    out = [np.zeros(3 * n, np.int32), np.zeros(n, np.int32), np.zeros(3 * n, np.int32), np.zeros(n, np.int32)]
+    pay = np.zeros(n * 4 * 8 + 8192 * k, np.uint8)
+    lens = np.zeros(2 * k, np.int32)
+    reused = np.zeros(k, np.int32)
+    ln = lib.ref_multi_slice_roundtrip(C.addressof(lp_a), transform_a, C.addressof(lp_b), transform_b, qp, k, offs,
+                                       xyz.reshape(-1), colours.reshape(-1), refl, out[0], out[1], out[2], out[3], pay,
+                                       pay.size, lens, reused)
+    assert 0 < ln <= pay.size
+    return (pay[:ln].tobytes(), [int(v) for v in lens], (out[0].reshape(n, 3), out[1]), (out[2].reshape(n, 3), out[3]),
+            [int(v) for v in reused])
+
+
 def oracle_estimate_dist2(xyz, period=100, search_range=128, percentile=0.85):
     lib = ol.oracle().lib
     xyz = np.ascontiguousarray(xyz, dtype=np.int32)

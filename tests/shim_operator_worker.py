@@ -86,6 +86,20 @@ def two_attr_case(case):
     return xyz, col, refl, lps[0], ta, lps[1], tb
 
 
+def multi_slice_case(case):
+    """slices of different size of one frame, two attributes each (as two_attr_case)"""
+    from mpeg_pcc_tmc13_amd import lod_params, synth
+    parts = []
+    for i, n in enumerate(case["sizes"]):
+        xyz, col = synth.dense_cloud(n, seed=case["seed"] + i, bits=case.get("bits", 9))
+        parts.append((xyz, col, ((col[:, 0].astype(np.int64) * 3 + xyz[:, 2]) % 256).astype(np.int32)))
+    offs = np.concatenate([[0], np.cumsum([len(p[0]) for p in parts])]).astype(np.int32)
+    ta, tb = case["transforms"]
+    lps = [lod_params(lifting=t == 2, blend=bool(case.get("blending", 1))) for t in (ta, tb)]
+    return (offs, np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts]),
+            np.concatenate([p[2] for p in parts]), lps[0], ta, lps[1], tb)
+
+
 def digest(a):
     return hashlib.md5(np.ascontiguousarray(a).tobytes()).hexdigest()
 
@@ -101,7 +115,13 @@ def main():
     if case.get("region"):
         lh.ref_set_qp_region(case["region"], lib=lib)
     extra = {}
-    if case.get("two_attr"):
+    if case.get("multi_slice"):
+        offs, xyz, col, refl, lpa, ta, lpb, tb = multi_slice_case(case)
+        payload, lens, enc2, dec2, reused = lh.ref_multi_slice_roundtrip(lpa, ta, lpb, tb, case["qp"], offs, xyz, col, refl, lib=lib)
+        rec_enc = np.concatenate([enc2[0].reshape(-1), enc2[1]])
+        rec_dec = np.concatenate([dec2[0].reshape(-1), dec2[1]])
+        extra = {"reused": list(reused), "payload_lens": lens}
+    elif case.get("two_attr"):
         xyz, col, refl, lpa, ta, lpb, tb = two_attr_case(case)
         payload, enc2, dec2, reused = lh.ref_two_attr_roundtrip(lpa, ta, lpb, tb, case["qp"], xyz, col, refl, lib=lib)
         rec_enc = np.concatenate([enc2[0].reshape(-1), enc2[1]])

@@ -62,6 +62,14 @@ def _unmodified(case):
     import lod_helpers as lh
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import shim_operator_worker as w
+    if case.get("multi_slice"):
+        offs, xyz, col, refl, lpa, ta, lpb, tb = w.multi_slice_case(case)
+        payload, lens, enc2, dec2, reused = lh.ref_multi_slice_roundtrip(lpa, ta, lpb, tb, case["qp"], offs, xyz, col, refl)
+        rec_enc = np.concatenate([enc2[0].reshape(-1), enc2[1]])
+        rec_dec = np.concatenate([dec2[0].reshape(-1), dec2[1]])
+        np.testing.assert_array_equal(rec_enc, rec_dec)
+        assert reused == [1] * (len(offs) - 1)
+        return hashlib.md5(payload).hexdigest(), len(payload), w.digest(rec_enc)
     if case.get("two_attr"):
         xyz, col, refl, lpa, ta, lpb, tb = w.two_attr_case(case)
         payload, enc2, dec2, reused = lh.ref_two_attr_roundtrip(lpa, ta, lpb, tb, case["qp"], xyz, col, refl)
@@ -259,6 +267,45 @@ def test_second_attribute_runs_over_the_first_attributes_structure(name):
     assert got["rec_enc_md5"] == rec and got["rec_dec_md5"] == rec
     assert got["reused"] == list(case.get("expect_reused", (1, 1)))
     assert (got["enc_device"], got["enc_cpu"], got["dec_device"], got["dec_cpu"]) == (2, 0, 2, 0)
+
+
+# ---- several slices of a frame (tmc3/encoder.cpp:1044, 1209-1240, 1366-1368): new coder objects per slice, two
+#      attributes inside a slice over one cached LoD structure, and the arithmetic coder's context memory of each
+#      attribute CARRIED from slice to slice (entropy continuation) -- slices of different size ------------------------
+MULTI_SLICE = {
+    "three_slices_pred_then_lifting": dict(multi_slice=1, sizes=(30_000, 9_000, 17_000), seed=51, qp=28, transforms=(1, 2)),
+    "four_slices_lifting_then_pred": dict(multi_slice=1, sizes=(12_000, 25_000, 3_000, 8_000), seed=55, qp=34, transforms=(2, 1)),
+}
+
+
+@needs3
+def test_context_memory_is_carried_between_slices():
+    """the case is not vacuous: the payload of a later slice coded on its own (fresh contexts) is another one"""
+    import lod_helpers as lh
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import shim_operator_worker as w
+    case = dict(MULTI_SLICE["three_slices_pred_then_lifting"], sizes=(5000, 3000, 4000))
+    offs, xyz, col, refl, lpa, ta, lpb, tb = w.multi_slice_case(case)
+    payload, lens, _, _, reused = lh.ref_multi_slice_roundtrip(lpa, ta, lpb, tb, case["qp"], offs, xyz, col, refl)
+    assert reused == [1, 1, 1] and len(lens) == 6 and sum(lens) == len(payload)
+    a, b = int(offs[1]), int(offs[2])
+    alone, _, _, _ = lh.ref_two_attr_roundtrip(lpa, ta, lpb, tb, case["qp"], xyz[a:b], col[a:b], refl[a:b])
+    second = payload[lens[0] + lens[1]:lens[0] + lens[1] + lens[2] + lens[3]]
+    assert second != alone
+
+
+@needs3
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(MULTI_SLICE))
+def test_slices_of_a_frame_with_entropy_continuation(name):
+    case = dict(MULTI_SLICE[name], lib="libtmc3_shim3.so")
+    got, err = run_worker(case, strict=True)
+    md5, ln, rec = unmodified(case)
+    assert got["payload_len"] == ln and got["payload_md5"] == md5, "payloads differ from the unmodified build"
+    assert got["rec_enc_md5"] == rec and got["rec_dec_md5"] == rec
+    k = len(case["sizes"])
+    assert got["reused"] == [1] * k
+    assert (got["enc_device"], got["enc_cpu"], got["dec_device"], got["dec_cpu"]) == (2 * k, 0, 2 * k, 0)
 
 
 @needs3

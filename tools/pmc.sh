@@ -1,12 +1,12 @@
 #!/bin/bash
-# Round 5: rocprofv3 passes of the bench legs at HEAD -- kernel trace (--stats) and the PMC counters in passes of
+# rocprofv3 passes of the bench legs at HEAD -- kernel trace (--stats) and the PMC counters in passes of
 # their own (SQ_*, FETCH_SIZE, WRITE_SIZE: gpurun refuses --pmc together with the trace domains), then
-# tools/r05_pmc_json.py turns the .db files into profiles-ready summaries.
-#   bash tools/r05_pmc.sh [out-dir-name] [workloads...]      workloads: headline fwd10_sub0 fwd10_sub1 legs
+# tools/pmc_json.py turns the .db files into profiles-ready summaries.
+#   bash tools/pmc.sh [out-dir-name] [workloads...]      workloads: headline fwd10_sub0 fwd10_sub1 legs
 set -u
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
-OUT=gpurun_out/${1:-r05_pmc}
+OUT=gpurun_out/${1:-pmc}
 shift || true
 WL=${@:-headline fwd10_sub0 fwd10_sub1 legs}
 mkdir -p $OUT
@@ -29,7 +29,7 @@ for w in $WL; do
   ( cd /tmp && timeout 400 rocprofv3 --pmc FETCH_SIZE -d $R/$OUT/fe_$w -o f -- bash -c "cd $R && $B" > $R/$OUT/fe_$w.log 2>&1 )
   ( cd /tmp && timeout 400 rocprofv3 --pmc WRITE_SIZE -d $R/$OUT/wr_$w -o w -- bash -c "cd $R && $B" > $R/$OUT/wr_$w.log 2>&1 )
   python tools/pmc_summary.py $(find $OUT/sq_$w $OUT/fe_$w $OUT/wr_$w -name '*.db') > $OUT/pmc_$w.txt 2>&1
-  python tools/r05_pmc_json.py $w $(find $OUT/fe_$w $OUT/wr_$w -name '*.db') > $OUT/traffic_$w.json 2> $OUT/traffic_$w.err
+  python tools/pmc_json.py $w $(find $OUT/fe_$w $OUT/wr_$w -name '*.db') > $OUT/traffic_$w.json 2> $OUT/traffic_$w.err
   # the kernel-trace summary (csv) of the same command
   find $OUT/kt_$w -name '*kernel_stats*.csv' -exec cp {} $OUT/kernel_stats_$w.csv \; 2>/dev/null
   find $OUT -name '*.db' -delete

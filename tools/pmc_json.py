@@ -2,7 +2,7 @@
 """FETCH_SIZE / WRITE_SIZE passes of rocprofv3 (rocpd .db files) -> {kernel: {fetch_bytes_per_launch,
 write_bytes_per_launch, launches}} for one workload (raw counter bytes: rocprofv3 reports KiB).
 
-    python tools/r05_pmc_json.py <workload> <results.db> [...]  > traffic_<workload>.json"""
+    python tools/pmc_json.py <workload> <results.db> [...]  > traffic_<workload>.json"""
 import collections
 import json
 import sqlite3
@@ -15,6 +15,9 @@ def timer_name(k):
     m = re.match(r"raht_level_sub_kernel<\d+, (\d)", k)
     if m:
         return {"1": "level_sub_synth", "2": "level_sub_fused", "3": "level_sub_lossy"}[m.group(1)]
+    m = re.match(r"raht_sub_sweep_kernel<\d+, (\d)", k)
+    if m:
+        return {"1": "sub_sweep_synth", "3": "sub_sweep_lossy"}[m.group(1)]
     m = re.match(r"cx_level_kernel<\d+, (true|false)", k)
     if m:
         return "cx_level_enc" if m.group(1) == "true" else "cx_level_dec"
