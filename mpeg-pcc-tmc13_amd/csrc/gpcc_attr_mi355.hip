@@ -1085,6 +1085,21 @@ launch_transform(
   }
   // ---- sub-node prediction, the coarse levels of every slice: one launch (raht_sweep.hpp) ----
   int level_from = first_level;  // the per-level launches start below this level
+  // Block records for the per-level kernels (raht_level_sub_kernel<.., REC>): the static half of every round's
+  // prologue written by a full-occupancy pass per level.  OPT-IN (GPCC_REC=1), measured and not kept
+  // (profiles/r06_rec_ab.txt): the level kernels lose 4-7 % of their time and the record pass costs 12-13 % -- a batch
+  // of ten 1 M-point frames forward 28.2 -> 30.1 ms, one frame 7.38 -> 7.62 ms.  The ~25 dependent loads in front of a
+  // round are not what a level waits for (round 3 found the same with partial records).
+  static const int rec_mode = [] {
+    const char* e = getenv("GPCC_REC");
+    return e ? atoi(e) : 0;
+  }();
+  const bool ext_flag = hp->raht_extension != 0;
+  const bool use_rec = pl.sub && !pl.haar && !pl.has_qp && !pl.links && !piped && rec_mode == 1;
+  size_t rec_need = 0;
+  if (use_rec)
+    for (int li = std::min(first_level, sweep ? std::max(0, ts.fine_levels) : first_level) - 1; li >= 0; li--)
+      rec_need = std::max(rec_need, sweep_rec_bytes(level_max_blocks(ts.nodes, li, ext_flag), C));
   if (sweep && !piped && ts.fine_levels < first_level) {
     const int lo = std::max(0, ts.fine_levels);
     const SweepCtx sw{first_level - 1, lo};
@@ -1092,7 +1107,7 @@ launch_transform(
     const int64_t sweep_parents = sweep_rec_layout(&rec, ts.nodes, sw.li_hi, sw.li_lo);
     // the records of the levels the sweep takes, sized by the real node counts the host has just read
     // (reuse of the context's block is ordered on the context's stream)
-    if (ensure_sweep_mem(ctx, sweep_rec_bytes(sweep_parents, C)) == GPCC_OK) {
+    if (ensure_sweep_mem(ctx, std::max(rec_need, sweep_rec_bytes(sweep_parents, C))) == GPCC_OK) {
       level_from = lo;
       sweep_rec_carve(&rec, ctx->sweep_mem, sweep_parents, C);
       Timer t(ctx, encoder ? "sub_sweep_lossy" : "sub_sweep_synth");
@@ -1175,7 +1190,25 @@ launch_transform(
       }();
       lc.claim_rounds = (GPCC_EXPERIMENTS && encoder && !pl.haar && claim_r > 1 && parents <= claim_parents) ? claim_r : 1;
     }
-    if (!encoder) {
+    bool rec_level = false;
+    if (use_rec && ensure_sweep_mem(ctx, rec_need) == GPCC_OK) {
+      Timer t(ctx, level_name("level_record", li));
+      lc.brec = level_record_launch<C>(st, lc, li, ctx->sweep_mem, level_max_blocks(ts.nodes, li, ext_flag), encoder, pl.f64);
+      rec_level = true;
+    }
+    if (rec_level && !encoder) {
+      Timer t(ctx, level_name("level_sub_synth", li));
+      if (pl.f64)
+        raht_level_sub_kernel<C, kSynth, ArithF64, false, true><<<sgrid, 256, 0, st>>>(lc);
+      else
+        raht_level_sub_kernel<C, kSynth, ArithI64, false, true><<<sgrid, 256, 0, st>>>(lc);
+    } else if (rec_level) {
+      Timer t(ctx, level_name("level_sub_lossy", li));
+      if (pl.f64)
+        raht_level_sub_kernel<C, kLossySub, ArithF64, false, true><<<sgrid, 256, 0, st>>>(lc);
+      else
+        raht_level_sub_kernel<C, kLossySub, ArithI64, false, true><<<sgrid, 256, 0, st>>>(lc);
+    } else if (!encoder) {
       Timer t(ctx, level_name("level_sub_synth", li));
       if (pl.f64)
         raht_level_sub_kernel<C, kSynth, ArithF64><<<sgrid, 256, 0, st>>>(lc);

@@ -326,6 +326,10 @@ lod_cell_keys_kernel(LodCtx cx)
 #ifndef GPCC_LOD_SUB_WAVES
 #define GPCC_LOD_SUB_WAVES 3
 #endif
+// granules polled side by side per memory round trip of the loop (19 = all of a lane's neighbours at once)
+#ifndef GPCC_LOD_BATCH
+#define GPCC_LOD_BATCH 10
+#endif
 __global__ __launch_bounds__(256, GPCC_LOD_SUB_WAVES) void
 lod_subsample_distance_kernel(LodCtx cx)
 {
@@ -484,17 +488,17 @@ lod_subsample_distance_kernel(LodCtx cx)
       // BEFORE any result is looked at (two batches bound the live registers)
       const uint32_t todo = pending ? pend : 0;
 #pragma unroll
-      for (int k0 = 0; k0 < 19; k0 += 10) {
-        u32x4 vv[10];
+      for (int k0 = 0; k0 < 19; k0 += GPCC_LOD_BATCH) {
+        u32x4 vv[GPCC_LOD_BATCH];
 #pragma unroll
-        for (int q = 0; q < 10; q++) {
+        for (int q = 0; q < GPCC_LOD_BATCH; q++) {
           const int k = k0 + q;
           vv[q] = u32x4{0, 0, 0, 0};
           if (k < 19 && ((todo >> k) & 1))
             vv[q] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lo[k] * 16, 0, /*sc1*/ 16);
         }
 #pragma unroll
-        for (int q = 0; q < 10; q++) {
+        for (int q = 0; q < GPCC_LOD_BATCH; q++) {
           const int k = k0 + q;
           if (k < 19 && ((todo >> k) & 1) && (vv[q].w >> 1) == (uint32_t)cx.epoch) {
             pend &= ~(1u << k);

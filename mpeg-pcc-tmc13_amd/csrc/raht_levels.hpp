@@ -68,6 +68,29 @@ struct InterRef {
   int32_t* icoeffs;       // ... and coefficients (layouts of desc / ptrans / coeffs)
 };
 
+// ---- block records (raht_sweep.hpp: raht_sweep_record_kernel writes them) --------------------------------
+enum SweepField {
+  kSfW = 0, kSfCa = 1, kSfCb = 4, kSfNsq = 7, kSfNrs = 8, kSfPn = 9, kSfNbc0 = 12, kSfPk = 15, kSfPk2 = 16,
+  kSfC0 = 17, kSfSlice = 18, kSweepFields = 19
+};
+// pk : occupancies of the three neighbours this lane owns (8 bits each) | their single-child bits << 24
+//      | the normaliser's shift << 27
+// pk2: occupancy of the block (8) | coded-position mask `present` << 8 | neighbours found << 16
+//      | butterfly stages with both sides << 21 | stages that only move << 24 | block takes a round << 27
+
+struct SweepRec {
+  int32_t* f32;    // [kSweepFields][lanes]
+  int64_t* src;    // [C][lanes] forward-transformed source, bit pattern of the launch's arithmetic (encoder)
+  uint8_t* occ;    // [lanes / 8] child occupancy of every parent (sweep_occ_kernel)
+  int32_t lanes;   // 8 x (parents of all levels of the sweep + 8: a slice's last round reads whole)
+  int32_t rbase[kMaxLevels];  // first record of children level li (in parents)
+  // records of ONE level by worklist index (raht_level_sub_kernel<.., REC>): record wi belongs to block worklist[wi];
+  // null: records of several levels by parent index (raht_sub_sweep_kernel)
+  const int32_t* worklist;
+  const int32_t* work_count;  // [nlev]
+};
+
+
 struct LevelCtx {
   TreeView tv;
   const gpcc_raht_params* params;  // device copy
@@ -104,6 +127,8 @@ struct LevelCtx {
   // rounds of 8 blocks a wavefront of the sub-node kernels takes per claim: 0 / 1 = one round from one of
   // eight tickets, R > 1 = R consecutive rounds from a single ticket (raht_subnode.hpp)
   int32_t claim_rounds;
+  // block records of this level by worklist index (raht_level_sub_kernel<.., REC = true>)
+  SweepRec brec;
 };
 
 // ctx.X[parity] with a per-lane parity, as a select between the two kernel

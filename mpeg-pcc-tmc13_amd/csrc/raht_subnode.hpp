@@ -131,10 +131,18 @@ store_agent_i64(int64_t* p, int64_t v)
 // one of the reference frame takes the frame's coefficients as its prediction; such a block waits for nobody.
 // (The encoder's second, intra-only candidate of a level is a launch of the kernel WITHOUT the flag on a
 // workspace of its own: raht_inter_driver.hpp.)
-template<int C, int MODE, class A = ArithI64, bool INTER = false>
+// REC: the static half of a round's prologue comes from block records by worklist index (ctx.brec, written by
+// raht_sweep_record_kernel right behind the level's prepass: raht_sweep.hpp) -- children, weights, butterfly constants,
+// normalisers, the source's forward transform, the 18-neighbour search, the neighbours' child tables; a round then
+// starts with 19 + 2 C coalesced loads instead of ~25 dependent ones.  OPT-IN (GPCC_REC=1): measured on the MI355X it
+// takes 4-7 % off the level kernels and the record pass costs 12-13 % (profiles/r06_rec_ab.txt) -- the prologue is not
+// what a level waits for, in a batch either.  Bit-exact (GPU tier with GPCC_REC=1, tests/test_emu_sweep.py).
+// Not with region QPs, integer Haar or INTER (the host decides).
+template<int C, int MODE, class A = ArithI64, bool INTER = false, bool REC = false>
 __global__ __launch_bounds__(256, MODE == kLossySub ? GPCC_SUB_LOSSY_WAVES : (C == 3 ? GPCC_SUB_SYNTH3_WAVES : 4)) void
 raht_level_sub_kernel(LevelCtx ctx)
 {
+  static_assert(!(REC && (INTER || MODE == kFused)), "records: fixed-point intra kernels only");
   static_assert(MODE == kSynth || MODE == kFused || MODE == kLossySub, "mode");
   static_assert(!(A::kF64 && MODE == kFused), "integer Haar is integer arithmetic");
   typedef typename A::T VT;
@@ -230,8 +238,15 @@ raht_level_sub_kernel(LevelCtx ctx)
     int s = 0;
     LevelSched e;
     e.processed = 0;
+    // (REC) this lane's record: field f at rf[f * rln]
+    const size_t rln = REC ? (size_t)ctx.brec.lanes : 0;
+    const size_t rat = (size_t)wround * 64 + lane;
+    const int32_t* __restrict__ rf = REC ? ctx.brec.f32 + rat : nullptr;
     if (live) {
-      s = find_slice(tv.soff[li + 1], tv.num_slices, j);
+      if constexpr (REC)
+        s = rf[kSfSlice * rln];
+      else
+        s = find_slice(tv.soff[li + 1], tv.num_slices, j);
       e = ctx.sched[s].lvl[li];
     }
     // all shuffles below run in wave-uniform control flow; lanes of dead
@@ -242,15 +257,26 @@ raht_level_sub_kernel(LevelCtx ctx)
     const int sc0 = on ? tv.soff[li][s] : 0;          // slice's children
     const int pt0 = on ? tv.pt_off[s] : 0;
     const int n_s = on ? tv.pt_off[s + 1] - pt0 : 0;
-    const int c0 = on ? tv.fc[li + 1][j] : 0;
-    const int nchild = on ? tv.fc[li + 1][j + 1] - c0 : 0;
+    uint32_t rpk = 0, rpk2 = 0;
+    if constexpr (REC) {
+      rpk = (uint32_t)rf[kSfPk * rln];
+      rpk2 = on ? (uint32_t)rf[kSfPk2 * rln] : 0u;
+    }
+    const int c0 = on ? (REC ? rf[kSfC0 * rln] : tv.fc[li + 1][j]) : 0;
+    const int nchild = on ? (REC ? popc32(rpk2 & 0xffu) : tv.fc[li + 1][j + 1] - c0) : 0;
     const int pj = j - sp0;
     const int par_par = e.parity ^ 1, cur_par = e.parity;
     const int64_t prow = (int64_t)pt0 + pj;  // parent row in rec buffers
 
     // ---- children -> positions ---------------------------------------
-    const int64_t ckey = t < nchild ? tv.key[li][c0 + t] : 0;
-    const uint32_t occ = group8_or(t < nchild ? 1u << (int)(ckey & 7) : 0u);
+    uint32_t occ_;
+    if constexpr (REC) {
+      occ_ = rpk2 & 0xffu;
+    } else {
+      const int64_t ckey = t < nchild ? tv.key[li][c0 + t] : 0;
+      occ_ = group8_or(t < nchild ? 1u << (int)(ckey & 7) : 0u);
+    }
+    const uint32_t occ = occ_;
     const bool has = (occ >> t) & 1;
     const int child = c0 + popc32(occ & ((1u << t) - 1));
     const int64_t crow = (int64_t)pt0 + (child - sc0);
@@ -259,7 +285,14 @@ raht_level_sub_kernel(LevelCtx ctx)
 #pragma unroll
     for (int k = 0; k < C; k++)
       src[k] = A::zero();
-    if (has) {
+    if constexpr (REC) {
+      w = has ? rf[kSfW * rln] : 0;
+      if (kEnc) {
+#pragma unroll
+        for (int k = 0; k < C; k++)
+          src[k] = __builtin_bit_cast(VT, ctx.brec.src[(size_t)k * rln + rat]);  // (already transformed)
+      }
+    } else if (has) {
       const int f0 = tv.fp[li][child], f1 = tv.fp[li][child + 1];
       w = f1 - f0;
       if (kEnc) {
@@ -334,6 +367,18 @@ raht_level_sub_kernel(LevelCtx ctx)
     int32_t wl[3], wr[3];
     VC ca[3], cb[3];
     int32_t cw = w;
+    if constexpr (REC) {
+      // (of the weights only "both sides" / "right side only" is used below: flags)
+#pragma unroll
+      for (int st = 0; st < 3; st++) {
+        const bool both = (rpk2 >> (21 + st)) & 1u, swap = (rpk2 >> (24 + st)) & 1u;
+        wl[st] = swap ? 0 : 1;
+        wr[st] = (both || swap) ? 1 : 0;
+        ca[st] = A::coef(rf[(kSfCa + st) * rln]);
+        cb[st] = A::coef(rf[(kSfCb + st) * rln]);
+      }
+      cw = (int32_t)((rpk2 >> (8 + t)) & 1u);  // this position holds a coefficient (`present`)
+    } else {
 #pragma unroll
     for (int st = 0; st < 3; st++) {
       const int bit = 1 << st;
@@ -351,6 +396,7 @@ raht_level_sub_kernel(LevelCtx ctx)
       }
       ca[st] = A::coef(ia);
       cb[st] = A::coef(ib);
+    }
     }
 
     // ---- inter-level prediction (tmc3/RAHT.cpp:1391-1432) --------------
@@ -377,7 +423,14 @@ raht_level_sub_kernel(LevelCtx ctx)
     }
     // (group-uniform; other groups of the wave idle through the shuffles)
     int pn[3] = {-1, -1, -1};  // neighbour i = 1 + t + 8*slot
-    if (GPCC_EXPERIMENTS && ctx.link_rec) {
+    if constexpr (REC) {
+      // (the record pass searched wherever the level predicts: tmc3/RAHT.cpp:299-368)
+      if (do_search) {
+#pragma unroll
+        for (int slot = 0; slot < 3; slot++)
+          pn[slot] = rf[(kSfPn + slot) * rln];
+      }
+    } else if (GPCC_EXPERIMENTS && ctx.link_rec) {
       // round 5: the parent's record holds its 18 neighbours (raht_links.hpp) -- one load each instead of
       // a 12-step bisection; findNeighbour's window (tmc3/RAHT.cpp:272-293) is an index distance
       if (do_search) {
@@ -470,8 +523,13 @@ raht_level_sub_kernel(LevelCtx ctx)
       }
     }
     {
-      int found = (pn[0] >= 0) + (pn[1] >= 0) + (pn[2] >= 0);
-      found = group8_sum(found);
+      int found;
+      if constexpr (REC) {
+        found = (int)((rpk2 >> 16) & 31u);
+      } else {
+        found = (pn[0] >= 0) + (pn[1] >= 0) + (pn[2] >= 0);
+        found = group8_sum(found);
+      }
       if (do_search) {
         neigh_count = found + 1;
         if (neigh_count < prm->raht_prediction_threshold1)
@@ -513,7 +571,11 @@ raht_level_sub_kernel(LevelCtx ctx)
     // an irsqrt evaluation per hop): sqrt(w) for the prediction, the
     // (shift, 1/sqrt(w)) pair of scale_rsqrt for the reconstruction
     int32_t nrm_sq_i = 0, nrm_rs_i = 0, nrm_shift = 0;
-    if (!haar && w > 1) {
+    if constexpr (REC) {
+      nrm_sq_i = rf[kSfNsq * rln];
+      nrm_rs_i = rf[kSfNrs * rln];
+      nrm_shift = (int)(rpk >> 27);
+    } else if (!haar && w > 1) {
       nrm_sq_i = (int32_t)sqrt_weight(w, lut);
       if (w < kSmallN) {
         nrm_rs_i = lut.norm_rs[w];
@@ -525,7 +587,7 @@ raht_level_sub_kernel(LevelCtx ctx)
     }
     const VC nrm_sq = A::coef(nrm_sq_i), nrm_rs = A::coef(nrm_rs_i);
     const typename A::Quant qaa[2] = {A::quant(qa[0]), A::quant(qa[1])};
-    if (kEnc) {
+    if (kEnc && !REC) {
       // forward butterflies of the source (normalised first unless Haar:
       // scale_rsqrt, tmc3/RAHT.cpp:1474-1481)
       if (!haar && w > 1) {
@@ -660,7 +722,11 @@ raht_level_sub_kernel(LevelCtx ctx)
           nb_v[slot][k] = A::from_i64(prec[(rbase + q) * C + k]);
           in_range = in_range && A::below(nb_v[slot][k], A::kRecLimit);
         }
-        if (q < j) {  // processed before this block: its children count
+        if constexpr (REC) {
+          nb_c0[slot] = rf[(kSfNbc0 + slot) * rln];
+          nb_occ[slot] = (rpk >> (8 * slot)) & 0xffu;  // (zero for a neighbour behind this block)
+          nb_single[slot] = (int)((rpk >> (24 + slot)) & 1u);
+        } else if (q < j) {  // processed before this block: its children count
           const int qc0 = tv.fc[li + 1][q];
           nb_c0[slot] = qc0;
           nb_occ[slot] = ctx.pocc[q];

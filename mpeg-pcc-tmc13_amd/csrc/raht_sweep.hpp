@@ -83,23 +83,6 @@ struct SweepRing {
 // (raht_sweep_record_kernel, one 8-lane group per parent of every level the sweep takes), and a
 // round of the sweep starts with 18 + 2 C coalesced loads.  Fields are lane-major: field f of lane
 // t of parent j of children level li is f32[f * lanes + (rbase[li] + j) * 8 + t].
-enum SweepField {
-  kSfW = 0, kSfCa = 1, kSfCb = 4, kSfNsq = 7, kSfNrs = 8, kSfPn = 9, kSfNbc0 = 12, kSfPk = 15, kSfPk2 = 16,
-  kSfC0 = 17, kSweepFields = 18
-};
-// pk : occupancies of the three neighbours this lane owns (8 bits each) | their single-child bits << 24
-//      | the normaliser's shift << 27
-// pk2: occupancy of the block (8) | coded-position mask `present` << 8 | neighbours found << 16
-//      | butterfly stages with both sides << 21 | stages that only move << 24 | block takes a round << 27
-
-struct SweepRec {
-  int32_t* f32;    // [kSweepFields][lanes]
-  int64_t* src;    // [C][lanes] forward-transformed source, bit pattern of the launch's arithmetic (encoder)
-  uint8_t* occ;    // [lanes / 8] child occupancy of every parent (sweep_occ_kernel)
-  int32_t lanes;   // 8 x (parents of all levels of the sweep + 8: a slice's last round reads whole)
-  int32_t rbase[kMaxLevels];  // first record of children level li (in parents)
-};
-
 inline size_t
 sweep_rec_bytes(int64_t parents, int c)
 {
@@ -156,12 +139,13 @@ raht_sweep_record_kernel(LevelCtx ctx, SweepCtx sw, SweepRec rec)
   const int lane = lane_id();
   const bool ext = A::kF64 || prm->raht_extension != 0;
   bool in_range = true;
-  const int num_parents = tv.soff[li + 1][tv.num_slices];
+  const bool by_list = rec.worklist != nullptr;
+  const int num_parents = by_list ? rec.work_count[li] : tv.soff[li + 1][tv.num_slices];
   const int wave_global = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
   for (int j8 = wave_global * 8; j8 < num_parents; j8 += (int)gridDim.x * 32) {
     const int jj = j8 + (lane >> 3);
     const bool live0 = jj < num_parents;
-    const int j = live0 ? jj : 0;
+    const int j = live0 ? (by_list ? rec.worklist[jj] : jj) : 0;
     const int s = find_slice(tv.soff[li + 1], tv.num_slices, j);
     const LevelSched e = ctx.sched[s].lvl[li];
     const bool live = live0 && e.processed;
@@ -346,7 +330,7 @@ raht_sweep_record_kernel(LevelCtx ctx, SweepCtx sw, SweepRec rec)
         swapm |= (!wl[st] && wr[st]) ? 1u << st : 0u;
       }
       if (live0) {
-        const size_t at = (size_t)(rec.rbase[li] + j) * 8 + t;
+        const size_t at = (size_t)(by_list ? jj : rec.rbase[li] + j) * 8 + t;
         int32_t* __restrict__ f = rec.f32 + at;
         const size_t ln = (size_t)rec.lanes;
         f[kSfW * ln] = w;
@@ -365,6 +349,7 @@ raht_sweep_record_kernel(LevelCtx ctx, SweepCtx sw, SweepRec rec)
         f[kSfPk2 * ln] = (int32_t)(occ | present << 8 | (uint32_t)found_sum << 16 | bothm << 21 | swapm << 24
                                    | (on ? 1u << 27 : 0u));
         f[kSfC0 * ln] = c0;
+        f[kSfSlice * ln] = s;
         if (kEnc) {
 #pragma unroll
           for (int k = 0; k < C; k++)
@@ -1308,6 +1293,45 @@ sweep_launch(
       hipLaunchKernelGGL(HIP_KERNEL_NAME(raht_sub_sweep_kernel<C, kLossySub, ArithI64, 512>), dim3(num_slices), dim3(512), 0, st, lc, sw, rec);
     }
   }
+}
+
+// block records of ONE level by worklist index, for raht_level_sub_kernel<.., REC = true>: behind the level's prepass
+// (worklist, work_count[li], pocc are the prepass's), `mem` holds sweep_rec_bytes(max_blocks, C)
+template<int C>
+inline SweepRec
+level_record_launch(
+  hipStream_t st, const LevelCtx& lc, int li, void* mem, int64_t max_blocks, bool encoder, bool f64)
+{
+  SweepRec rec{};
+  sweep_rec_carve(&rec, mem, max_blocks, C);
+  for (int l = 0; l < kMaxLevels; l++)
+    rec.rbase[l] = 0;
+  rec.occ = lc.pocc;  // (child occupancy of every parent of the level, by parent index)
+  rec.worklist = lc.worklist;
+  rec.work_count = lc.work_count;
+  const SweepCtx sw{li, li};
+  const int rgrid = (int)((max_blocks + 31) / 32 < 4096 ? (max_blocks + 31) / 32 : 4096);
+  if (!encoder) {
+    if (f64)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(raht_sweep_record_kernel<C, false, ArithF64>), dim3(rgrid < 1 ? 1 : rgrid), dim3(256), 0, st, lc, sw, rec);
+    else
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(raht_sweep_record_kernel<C, false, ArithI64>), dim3(rgrid < 1 ? 1 : rgrid), dim3(256), 0, st, lc, sw, rec);
+  } else {
+    if (f64)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(raht_sweep_record_kernel<C, true, ArithF64>), dim3(rgrid < 1 ? 1 : rgrid), dim3(256), 0, st, lc, sw, rec);
+    else
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(raht_sweep_record_kernel<C, true, ArithI64>), dim3(rgrid < 1 ? 1 : rgrid), dim3(256), 0, st, lc, sw, rec);
+  }
+  return rec;
+}
+
+// blocks a level can hold at most (what the host knows from the node counts): every block has a parent, and with the
+// RAHT extension at least two children
+inline int64_t
+level_max_blocks(const int32_t* nodes, int li, bool ext)
+{
+  const int64_t parents = nodes[li + 1], by_children = (int64_t)nodes[li] / 2 + 1;
+  return ext && by_children < parents ? by_children : parents;
 }
 
 }  // namespace gpcc

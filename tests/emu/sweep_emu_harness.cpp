@@ -37,7 +37,7 @@ struct Carver {
 template<int C>
 int
 run(
-  const gpcc_raht_params* params, bool encoder, bool f64, int sweep_parents, int S, const int64_t* offsets,
+  const gpcc_raht_params* params, bool encoder, bool f64, bool use_rec, int sweep_parents, int S, const int64_t* offsets,
   const int64_t* morton, int32_t* attrs, int32_t* coeffs, int bits, int32_t* levels_swept)
 {
   Carver ar;
@@ -158,8 +158,22 @@ run(
       HIP_KERNEL_NAME(raht_level_prepass_kernel<C>), dim3((int)std::min<int64_t>((parents + 1023) / 1024, 1024)), dim3(256), 0,
       nullptr, lc);
     const int sgrid = (int)std::min<int64_t>(1024, std::max<int64_t>(8, (parents / 64 + 7) / 8 * 8));
+    if (use_rec) {
+      const int64_t mb = level_max_blocks(ts.nodes, li, params->raht_extension != 0);
+      lc.brec = level_record_launch<C>(nullptr, lc, li, ar.take<char>(sweep_rec_bytes(mb, C)), mb, encoder, f64);
+    }
     emu::set_concurrent_blocks(8);  // (the workgroups of a dependency kernel wait for one another)
-    if (!encoder) {
+    if (use_rec && !encoder) {
+      if (f64)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(raht_level_sub_kernel<C, kSynth, ArithF64, false, true>), dim3(sgrid), dim3(256), 0, nullptr, lc);
+      else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(raht_level_sub_kernel<C, kSynth, ArithI64, false, true>), dim3(sgrid), dim3(256), 0, nullptr, lc);
+    } else if (use_rec) {
+      if (f64)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(raht_level_sub_kernel<C, kLossySub, ArithF64, false, true>), dim3(sgrid), dim3(256), 0, nullptr, lc);
+      else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(raht_level_sub_kernel<C, kLossySub, ArithI64, false, true>), dim3(sgrid), dim3(256), 0, nullptr, lc);
+    } else if (!encoder) {
       if (f64)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(raht_level_sub_kernel<C, kSynth, ArithF64>), dim3(sgrid), dim3(256), 0, nullptr, lc);
       else
@@ -193,7 +207,7 @@ run(
 }  // namespace
 
 // attrs: in source (encoder) / out reconstruction; coeffs: planar per slice.
-// flags: bit 0 = encoder, bit 1 = ArithF64.  sweep_parents: a slice's levels with at most so many
+// flags: bit 0 = encoder, bit 1 = ArithF64, bit 2 = block records in the per-level kernels (raht_level_sub_kernel<.., REC>).  sweep_parents: a slice's levels with at most so many
 // parents go to raht_sub_sweep_kernel (0: none -- the per-level kernels only).
 extern "C" int
 sweep_emu_transform(
@@ -201,13 +215,13 @@ sweep_emu_transform(
   const int64_t* morton, int32_t* attrs, int32_t* coeffs, int32_t c, int32_t morton_bits, int32_t* levels_swept)
 {
   const int bits = morton_bits > 0 ? std::min(morton_bits, 63) : 63;
-  const bool enc = (flags & 1) != 0, f64 = (flags & 2) != 0;
+  const bool enc = (flags & 1) != 0, f64 = (flags & 2) != 0, rec = (flags & 4) != 0;
   if (sweep_parents > kSweepMaxParents)
     return -3;
   switch (c) {
-  case 1: return run<1>(params, enc, f64, sweep_parents, num_slices, offsets, morton, attrs, coeffs, bits, levels_swept);
-  case 2: return run<2>(params, enc, f64, sweep_parents, num_slices, offsets, morton, attrs, coeffs, bits, levels_swept);
-  case 3: return run<3>(params, enc, f64, sweep_parents, num_slices, offsets, morton, attrs, coeffs, bits, levels_swept);
+  case 1: return run<1>(params, enc, f64, rec, sweep_parents, num_slices, offsets, morton, attrs, coeffs, bits, levels_swept);
+  case 2: return run<2>(params, enc, f64, rec, sweep_parents, num_slices, offsets, morton, attrs, coeffs, bits, levels_swept);
+  case 3: return run<3>(params, enc, f64, rec, sweep_parents, num_slices, offsets, morton, attrs, coeffs, bits, levels_swept);
   }
   return -2;
 }

@@ -45,18 +45,18 @@ def _run(p, flags, sweep_parents, morton, rec, co, c, offsets):
     return swept.value
 
 
-def forward(p, morton, attrs, offsets=None, f64=False, sweep_parents=8192):
+def forward(p, morton, attrs, offsets=None, f64=False, sweep_parents=8192, rec=False):
     """-> (coeffs planar per slice, recon [n, c], levels taken by the sweep kernel)"""
     n, c = attrs.shape
-    rec = np.ascontiguousarray(attrs, dtype=np.int32).copy().reshape(-1)
+    out = np.ascontiguousarray(attrs, dtype=np.int32).copy().reshape(-1)
     co = np.zeros(n * c, dtype=np.int32)
-    swept = _run(p, 1 | (2 if f64 else 0), sweep_parents, morton, rec, co, c, offsets)
-    return co, rec.reshape(n, c), swept
+    swept = _run(p, 1 | (2 if f64 else 0) | (4 if rec else 0), sweep_parents, morton, out, co, c, offsets)
+    return co, out.reshape(n, c), swept
 
 
-def inverse(p, morton, coeffs, c, offsets=None, f64=False, sweep_parents=8192):
+def inverse(p, morton, coeffs, c, offsets=None, f64=False, sweep_parents=8192, rec=False):
     n = len(morton)
-    rec = np.zeros(n * c, dtype=np.int32)
+    out = np.zeros(n * c, dtype=np.int32)
     co = np.ascontiguousarray(coeffs, dtype=np.int32).copy()
-    swept = _run(p, 2 if f64 else 0, sweep_parents, morton, rec, co, c, offsets)
-    return rec.reshape(n, c), swept
+    swept = _run(p, (2 if f64 else 0) | (4 if rec else 0), sweep_parents, morton, out, co, c, offsets)
+    return out.reshape(n, c), swept

@@ -17,4 +17,9 @@ GPCC_ISA_INSTANCE(3, kSynth, ArithI64);
 GPCC_ISA_INSTANCE(3, kSynth, ArithF64);
 GPCC_ISA_INSTANCE(3, kLossySub, ArithI64);
 GPCC_ISA_INSTANCE(3, kLossySub, ArithF64);
+#define GPCC_ISA_REC_INSTANCE(C, MODE, A) template __global__ void raht_level_sub_kernel<C, MODE, A, false, true>(LevelCtx)
+GPCC_ISA_REC_INSTANCE(1, kSynth, ArithF64);
+GPCC_ISA_REC_INSTANCE(1, kLossySub, ArithF64);
+GPCC_ISA_REC_INSTANCE(1, kLossySub, ArithI64);
+GPCC_ISA_REC_INSTANCE(3, kSynth, ArithI64);
 }  // namespace gpcc

@@ -28,7 +28,7 @@ def test_case_table_has_eligible_cases():
     assert len(ELIGIBLE) >= 12
 
 
-def _check(p, morton, attrs, offsets=None, f64=False, sweep_parents=8192, min_swept=1):
+def _check(p, morton, attrs, offsets=None, f64=False, sweep_parents=8192, min_swept=1, use_rec=False):
     c = attrs.shape[1]
     if offsets is None:
         o_co, o_rec = ol.oracle().raht_forward(p, morton, attrs)
@@ -39,11 +39,11 @@ def _check(p, morton, attrs, offsets=None, f64=False, sweep_parents=8192, min_sw
             co, rec = ol.oracle().raht_forward(p, morton[a:b], attrs[a:b])
             o_co[a * c:b * c] = co
             o_rec[a:b] = rec
-    co, rec, swept = es.forward(p, morton, attrs, offsets=offsets, f64=f64, sweep_parents=sweep_parents)
+    co, out, swept = es.forward(p, morton, attrs, offsets=offsets, f64=f64, sweep_parents=sweep_parents, rec=use_rec)
     assert swept >= min_swept
     assert np.array_equal(co, o_co)
-    assert np.array_equal(rec, o_rec)
-    inv, _ = es.inverse(p, morton, o_co, c, offsets=offsets, f64=f64, sweep_parents=sweep_parents)
+    assert np.array_equal(out, o_rec)
+    inv, _ = es.inverse(p, morton, o_co, c, offsets=offsets, f64=f64, sweep_parents=sweep_parents, rec=use_rec)
     assert np.array_equal(inv, o_rec)
 
 
@@ -111,3 +111,26 @@ def test_parameter_variants(vi):
                                     dup_fraction=0.1 if vi % 2 else 0.0, bitdepth=kw.get("bitdepth", 8))
     morton, attrs, _ = synth.sort_by_morton(xyz, attrs)
     _check(raht_params(**kw), morton, attrs)
+
+
+# the per-level kernels with the static half of a round taken from block records (raht_level_sub_kernel<.., REC>,
+# GPCC_REC=1 in the library): every level below the sweep, and all levels (sweep_parents = 0)
+@pytest.mark.parametrize("sweep_parents", [0, 32])
+@pytest.mark.parametrize("c,f64,ext", [(1, True, True), (3, False, True), (1, False, False)])
+def test_level_kernels_from_block_records(c, f64, ext, sweep_parents):
+    xyz, attrs = synth.random_cloud(n=2600, seed=71 + c, bits=5, c=c, dup_fraction=0.1)
+    morton, attrs, _ = synth.sort_by_morton(xyz, attrs)
+    _check(raht_params(qp=22 if c == 1 else 34, extension=ext), morton, attrs, f64=f64 and ext, sweep_parents=sweep_parents,
+           min_swept=0, use_rec=True)
+
+
+def test_level_kernels_from_block_records_ragged_batch():
+    parts = []
+    for i, n in enumerate([900, 3, 1400, 60]):
+        xyz, a = synth.lidar_cloud(max(n, 4), seed=80 + i) if i % 2 == 0 else synth.random_cloud(n=n, seed=80 + i, bits=3, c=1)
+        m, a, _ = synth.sort_by_morton(xyz[:n], a[:n])
+        parts.append((m, a))
+    morton = np.concatenate([m for m, _ in parts])
+    attrs = np.concatenate([a for _, a in parts])
+    offs = np.concatenate([[0], np.cumsum([len(m) for m, _ in parts])])
+    _check(raht_params(qp=28), morton, attrs, offsets=offs, sweep_parents=16, min_swept=0, use_rec=True)

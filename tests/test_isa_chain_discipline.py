@@ -56,8 +56,8 @@ def loop_region(body):
     return body[polls[0]:sleeps[0]]
 
 
-def kernel_name(c, mode, arith):
-    return f"_ZN4gpcc21raht_level_sub_kernelILi{c}ELi{mode}ENS_8Arith{arith}ELb0EEEvNS_8LevelCtxE"
+def kernel_name(c, mode, arith, rec=0):
+    return f"_ZN4gpcc21raht_level_sub_kernelILi{c}ELi{mode}ENS_8Arith{arith}ELb0ELb{rec}EEEvNS_8LevelCtxE"
 
 
 # mode 1 = decoder, 2 = integer-Haar encoder, 3 = lossy encoder (LevelMode); the arithmetic back
@@ -95,6 +95,18 @@ _SPILLS = pytest.mark.xfail(
 def test_no_spill_reloads_inside_the_loop(kernels, c, mode, arith):
     region = loop_region(kernels[kernel_name(c, mode, arith)])
     assert not [s for s in region if s.startswith("scratch_load")]
+
+
+# the variants that take the static half of a round from block records (round 6, REC): the same loop discipline
+@pytest.mark.parametrize("c,mode,arith", [(1, 1, "F64"), (1, 3, "F64"), (1, 3, "I64"), (3, 1, "I64")])
+def test_record_variants_keep_the_discipline(kernels, c, mode, arith):
+    region = loop_region(kernels[kernel_name(c, mode, arith, rec=1)])
+    loads = [s for s in region if re.match(r"(global_load|flat_load|buffer_load)", s)]
+    polls = [s for s in loads if s.startswith("buffer_load_dwordx4") and "sc1" in s]
+    assert len(polls) == c, polls
+    assert not [s for s in region if s.startswith("flat_")]
+    assert not [s for s in region if s.startswith("scratch_load")]
+    assert len([s for s in loads if s not in polls]) <= (4 if mode == 3 else 0)
 
 
 def test_group_exchanges_are_dpp(kernels):
