@@ -88,6 +88,11 @@ device_context()
         gpcc_last_error());
       ctx = nullptr;
     }
+    // GPCC_RESERVE_POINTS=n: the sequence's largest slice, known to whoever starts the codec -- everything the
+    // transforms would allocate on demand is reserved once, before the first slice (gpcc_ctx_reserve)
+    const char* rsv = std::getenv("GPCC_RESERVE_POINTS");
+    if (ctx && rsv && std::atoll(rsv) > 0 && gpcc_ctx_reserve(ctx, std::atoll(rsv), 1, 3) != GPCC_OK)
+      std::fprintf(stderr, "gpcc: GPCC_RESERVE_POINTS=%s not reserved (%s); workspace grows on demand\n", rsv, gpcc_last_error());
   }
   return ctx;
 }

@@ -45,6 +45,10 @@ process_context(const char* what)
       std::fprintf(stderr, "gpcc: no MI355X context (%s); %s stays on the CPU\n", gpcc_last_error(), what);
       ctx = nullptr;
     }
+    // GPCC_RESERVE_POINTS=n (the sequence's largest slice): reserve once, before the first slice (gpcc_ctx_reserve)
+    const char* rsv = std::getenv("GPCC_RESERVE_POINTS");
+    if (ctx && rsv && std::atoll(rsv) > 0 && gpcc_ctx_reserve(ctx, std::atoll(rsv), 1, 3) != GPCC_OK)
+      std::fprintf(stderr, "gpcc: GPCC_RESERVE_POINTS=%s not reserved (%s); workspace grows on demand\n", rsv, gpcc_last_error());
   }
   return ctx;
 }
