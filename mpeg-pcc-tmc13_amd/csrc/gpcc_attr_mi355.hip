@@ -1178,18 +1178,7 @@ launch_transform(
     // which the one-round claims of many wavefronts overlap; the blocks of the NEXT claim wait for all of them.
     // Opt-in for experiments only: GPCC_SUB_CLAIM=R (default 1), GPCC_SUB_CLAIM_PARENTS (levels with at most
     // so many parents, default 100 000).
-    {
-      static const int claim_r = [] {
-        const char* e = getenv("GPCC_SUB_CLAIM");
-        const int v = e ? atoi(e) : 1;
-        return v < 1 ? 1 : (v > 64 ? 64 : v);
-      }();
-      static const int64_t claim_parents = [] {
-        const char* e = getenv("GPCC_SUB_CLAIM_PARENTS");
-        return e ? (int64_t)atoll(e) : (int64_t)100000;
-      }();
-      lc.claim_rounds = (GPCC_EXPERIMENTS && encoder && !pl.haar && claim_r > 1 && parents <= claim_parents) ? claim_r : 1;
-    }
+    lc.claim_rounds = sub_claim_rounds(encoder, pl.haar, parents);
     bool rec_level = false;
     if (use_rec && ensure_sweep_mem(ctx, rec_need) == GPCC_OK) {
       Timer t(ctx, level_name("level_record", li));

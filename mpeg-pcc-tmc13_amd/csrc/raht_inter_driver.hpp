@@ -605,11 +605,7 @@ inter_run(
       const int sgrid = (int)std::min<int64_t>(kInterSubGrid, std::max<int64_t>(8, (parents / 64 + 7) / 8 * 8));
       // (claims of several consecutive rounds, raht_subnode.hpp: an opt-in experiment -- measured slower --
       // that the emulator tier keeps pinned by setting GPCC_SUB_CLAIM itself)
-      {
-        const char* ce = getenv("GPCC_SUB_CLAIM");
-        const int cr = ce ? atoi(ce) : 1;
-        lc.claim_rounds = (encoder && !haar && cr > 1 && parents <= 100000) ? (cr > 64 ? 64 : cr) : 1;
-      }
+      lc.claim_rounds = sub_claim_rounds(encoder, haar, parents);
 #ifdef GPCC_EMU  // (the workgroups of a dependency kernel wait for one another: eight run together)
 #define GPCC_EMU_CONCURRENT(n) emu::set_concurrent_blocks(n)
 #else

@@ -41,6 +41,8 @@
 // block with a reset, the slice start, or `reach` reset-free coefficients.
 #pragma once
 
+#include <stdlib.h>
+
 #include "raht_arith.hpp"
 #include "raht_inter.hpp"
 #include "raht_levels.hpp"
@@ -88,6 +90,40 @@ struct SubProf {
   __device__ void round_end(int, int) {}
 };
 #endif
+
+// Rounds of 8 blocks a wavefront of the lossy sub-node encoder takes per claim at a level with `parents` parents
+// (LevelCtx::claim_rounds; an experiment, 10-20 x slower: profiles/r05_claim_rounds_ab.txt).  One place for both
+// drivers (gpcc_attr_mi355.hip launch_transform, raht_inter_driver.hpp inter_run): only in experiment builds,
+// GPCC_SUB_CLAIM = R (default 1) for levels with at most GPCC_SUB_CLAIM_PARENTS parents (default 100 000); read once
+// per process, except under the emulator, whose tests change the environment between calls.
+inline int
+sub_claim_rounds(bool encoder, bool haar, int64_t parents)
+{
+#if GPCC_EXPERIMENTS
+  auto rounds = [] {
+    const char* e = getenv("GPCC_SUB_CLAIM");
+    const int v = e ? atoi(e) : 1;
+    return v < 1 ? 1 : (v > 64 ? 64 : v);
+  };
+  auto limit = [] {
+    const char* e = getenv("GPCC_SUB_CLAIM_PARENTS");
+    return e ? (int64_t)atoll(e) : (int64_t)100000;
+  };
+#ifdef GPCC_EMU
+  const int r = rounds();
+  const int64_t lim = limit();
+#else
+  static const int r = rounds();
+  static const int64_t lim = limit();
+#endif
+  return (encoder && !haar && r > 1 && parents <= lim) ? r : 1;
+#else
+  (void)encoder;
+  (void)haar;
+  (void)parents;
+  return 1;
+#endif
+}
 
 __device__ __forceinline__ int
 occu_shift(int i12)

@@ -42,3 +42,26 @@ def test_compact_pass_needs_no_scratch(meta):
     bad = {names[n]: v["scratch"] for n, v in meta.items()
            if any(k in names[n] for k in path) and "ArithF64" not in names[n] and v["scratch"] > 0}
     assert not bad, f"compact-pass kernels with scratch: {bad}"
+
+
+def test_rate_sum_kernel_keeps_its_register_budget(meta):
+    """rate_sum_kernel (csrc/raht_inter.hpp) runs with __launch_bounds__(1024): 128 registers per lane, of which its
+    hand-scheduled chain (rate_sum_chain's inline asm) names v64-v127 -- everything else has to fit v0-v63 or spill.
+    A change of register budget or compiler would break that silently (the asm path runs on hardware only): the
+    built kernel stays at 128 registers and at most a few bytes of scratch."""
+    names = isa_meta.demangle(list(meta))
+    ks = {names[n]: v for n, v in meta.items() if "rate_sum_kernel" in names[n]}
+    assert ks, "rate_sum_kernel is not in the library"
+    for name, v in ks.items():
+        assert v["vgpr"] <= 128, (name, v)
+        assert v["scratch"] <= 16, (name, v)
+
+
+def test_sweep_kernels_have_no_scratch(meta):
+    """raht_sub_sweep_kernel walks a slice's coarse levels on ONE compute unit at two wavefronts per SIMD (512 threads):
+    its 256-register budget holds the loop's state without spills; the record pass is a streaming kernel."""
+    names = isa_meta.demangle(list(meta))
+    ks = {names[n]: v for n, v in meta.items() if "raht_sub_sweep_kernel" in names[n] or "raht_sweep_record_kernel" in names[n]}
+    assert len(ks) >= 8
+    bad = {k: v["scratch"] for k, v in ks.items() if v["scratch"] > 0}
+    assert not bad, bad
