@@ -511,7 +511,8 @@ def main():
                 "nonzero_coefficient_fraction": out["headline_textured"]["nonzero_coefficient_fraction"]}
         if args.legs:
             for leg in args.legs.split(","):
-                out[leg] = {"lifting": lambda: lifting_leg(ctx, args), "predicting": lambda: predicting_leg(ctx, args),
+                out[leg] = {"first_call": lambda: first_call_leg(torch, dev, local_rank, stream, frames[0], p),
+                            "lifting": lambda: lifting_leg(ctx, args), "predicting": lambda: predicting_leg(ctx, args),
                             "recolour": lambda: recolour_leg(ctx, args), "raht_inter": lambda: raht_inter_leg(ctx, args)}[leg]()
         if not args.no_extras:
             out["raht_forward_10M"] = forward_10m(torch, dev, ctx, params_for, frames)

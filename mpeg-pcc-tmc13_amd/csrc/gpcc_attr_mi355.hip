@@ -2841,15 +2841,22 @@ gpcc_ctx_reserve(gpcc_ctx* ctx, int64_t max_points, int32_t max_slices, int32_t 
       w);
     need = std::max(need, used);
   }
+  // (GPCC_RESERVE_TOUCH=0: allocate only, do not write the memory -- for measurements)
+  static const bool touch = [] {
+    const char* e = getenv("GPCC_RESERVE_TOUCH");
+    return !(e && e[0] == '0');
+  }();
   int rcode = ensure_arena(ctx, need);
   if (rcode)
     return rcode;
-  HIP_TRY(hipMemsetAsync(ctx->arena.base, 0, ctx->arena.cap, ctx->stream));
+  if (touch)
+    HIP_TRY(hipMemsetAsync(ctx->arena.base, 0, ctx->arena.cap, ctx->stream));
   // the sweep's records (raht_sweep.hpp): at most kSweepDefaultParents parents per slice and level
   rcode = ensure_sweep_mem(ctx, sweep_rec_bytes((int64_t)max_slices * nlev * kSweepDefaultParents, max_c));
   if (rcode)
     return rcode;
-  HIP_TRY(hipMemsetAsync(ctx->sweep_mem, 0, ctx->sweep_cap, ctx->stream));
+  if (touch)
+    HIP_TRY(hipMemsetAsync(ctx->sweep_mem, 0, ctx->sweep_cap, ctx->stream));
   {
     // the host tier's device buffers for a slice of max_points points (host_transform): Morton codes,
     // attributes, coefficients, region QP offsets -- into the pool, where the calls find them
@@ -2861,7 +2868,8 @@ gpcc_ctx_reserve(gpcc_ctx* ctx, int64_t max_points, int32_t max_slices, int32_t 
         blk[i] = nullptr;
     for (int i = 0; i < 4; i++)
       if (blk[i]) {
-        hipMemsetAsync(blk[i], 0, sz[i], ctx->stream);
+        if (touch)
+          hipMemsetAsync(blk[i], 0, sz[i], ctx->stream);
         pool_free(ctx, blk[i]);
       }
   }
