@@ -155,6 +155,9 @@ store_agent_i64(int64_t* p, int64_t v)
 #ifndef GPCC_SUB_SLEEP
 #define GPCC_SUB_SLEEP 4
 #endif
+#ifndef GPCC_SUB_POLL_RR
+#define GPCC_SUB_POLL_RR 0
+#endif
 #ifndef GPCC_SUB_LOSSY_WAVES
 #define GPCC_SUB_LOSSY_WAVES 3
 #endif
@@ -899,6 +902,7 @@ raht_level_sub_kernel(LevelCtx ctx)
     int look = wi - 1;      // look-back cursor
     int outk = 0, outv = -1;   // outgoing RDOQ state: 0 unknown, 1 transparent, 2 final (= outv)
     unsigned long long done = 0;  // children of this round whose value lies in the mailbox (wave-uniform)
+    int poll_last = 31;           // the granule polled last (31: none yet -- start with the lowest awaited one)
 #pragma unroll
     for (int k = 0; k < C; k++) {
       pt[k] = A::zero();
@@ -946,7 +950,16 @@ raht_level_sub_kernel(LevelCtx ctx)
       // against 6.98 / 3.95, arrivals from other wavefronts are what the frame waits for.)
       const uint32_t pm = stage == 0 ? (pend & ~inw) : 0u;
       if (pm) {
+#if GPCC_SUB_POLL_RR
+        // round robin over the awaited granules: the one behind the last polled.  Polling the LOWEST awaited one until it
+        // arrives makes every other neighbour -- long there -- wait its turn behind a late one, an iteration each after it
+        // has arrived; in turn they are consumed while the late one is still out (the sums are exact: order is free)
+        const uint32_t above = pm & ~((2u << poll_last) - 1u);
+        const int slot = __ffs(above ? above : pm) - 1;
+        poll_last = slot;
+#else
         const int slot = __ffs(pm) - 1;
+#endif
         int32_t row = 0;
         int pwc = 0;
 #pragma unroll
