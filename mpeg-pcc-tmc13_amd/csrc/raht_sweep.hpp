@@ -1262,6 +1262,9 @@ sweep_rec_layout(SweepRec* rec, const int32_t* nodes, int li_hi, int li_lo)
   return total;
 }
 
+#ifndef GPCC_SWEEP_NT
+#define GPCC_SWEEP_NT 512  // threads of the walking workgroup (8 wavefronts; experiments: 64 .. 512)
+#endif
 // occupancies, records, the walk: `rec` carved (sweep_rec_carve) for sweep_rec_layout's parents
 template<int C>
 inline void
@@ -1279,18 +1282,18 @@ sweep_launch(
   if (!encoder) {
     if (f64) {
       hipLaunchKernelGGL(HIP_KERNEL_NAME(raht_sweep_record_kernel<C, false, ArithF64>), dim3(rgrid, nlv), dim3(256), 0, st, lc, sw, rec);
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(raht_sub_sweep_kernel<C, kSynth, ArithF64, 512>), dim3(num_slices), dim3(512), 0, st, lc, sw, rec);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(raht_sub_sweep_kernel<C, kSynth, ArithF64, GPCC_SWEEP_NT>), dim3(num_slices), dim3(GPCC_SWEEP_NT), 0, st, lc, sw, rec);
     } else {
       hipLaunchKernelGGL(HIP_KERNEL_NAME(raht_sweep_record_kernel<C, false, ArithI64>), dim3(rgrid, nlv), dim3(256), 0, st, lc, sw, rec);
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(raht_sub_sweep_kernel<C, kSynth, ArithI64, 512>), dim3(num_slices), dim3(512), 0, st, lc, sw, rec);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(raht_sub_sweep_kernel<C, kSynth, ArithI64, GPCC_SWEEP_NT>), dim3(num_slices), dim3(GPCC_SWEEP_NT), 0, st, lc, sw, rec);
     }
   } else {
     if (f64) {
       hipLaunchKernelGGL(HIP_KERNEL_NAME(raht_sweep_record_kernel<C, true, ArithF64>), dim3(rgrid, nlv), dim3(256), 0, st, lc, sw, rec);
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(raht_sub_sweep_kernel<C, kLossySub, ArithF64, 512>), dim3(num_slices), dim3(512), 0, st, lc, sw, rec);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(raht_sub_sweep_kernel<C, kLossySub, ArithF64, GPCC_SWEEP_NT>), dim3(num_slices), dim3(GPCC_SWEEP_NT), 0, st, lc, sw, rec);
     } else {
       hipLaunchKernelGGL(HIP_KERNEL_NAME(raht_sweep_record_kernel<C, true, ArithI64>), dim3(rgrid, nlv), dim3(256), 0, st, lc, sw, rec);
-      hipLaunchKernelGGL(HIP_KERNEL_NAME(raht_sub_sweep_kernel<C, kLossySub, ArithI64, 512>), dim3(num_slices), dim3(512), 0, st, lc, sw, rec);
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(raht_sub_sweep_kernel<C, kLossySub, ArithI64, GPCC_SWEEP_NT>), dim3(num_slices), dim3(GPCC_SWEEP_NT), 0, st, lc, sw, rec);
     }
   }
 }
