@@ -4345,7 +4345,7 @@ gpcc_debug_sub_prof(unsigned long long* out, int reset)
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(gpcc::g_sub_prof), sizeof(gpcc::g_sub_prof)) != hipSuccess)
     return -1;
   if (reset) {
-    static unsigned long long z[16 + 32 * 10] = {};
+    static unsigned long long z[16 + 32 * 20] = {};
     if (hipMemcpyToSymbol(HIP_SYMBOL(gpcc::g_sub_prof), z, sizeof(z)) != hipSuccess)
       return -1;
   }

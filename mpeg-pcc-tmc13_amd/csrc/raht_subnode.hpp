@@ -54,9 +54,13 @@ namespace gpcc {
 // s_memtime around the stages of the loop, summed per launch and per level
 // into g_sub_prof, read back with gpcc_debug_sub_prof).  Empty otherwise.
 #ifdef GPCC_SUB_PROF
-__device__ unsigned long long g_sub_prof[16 + 32 * 10];  // [16 + li * 4 + ..] rounds, prologue, loop, iterations; [144 + li * 6 + ..] stage ticks 0-3, idle iterations
+__device__ unsigned long long g_sub_prof[16 + 32 * 20];  // [16 + li * 4 + ..] rounds, prologue, loop, iterations; [144 + li * 6 + ..] stage ticks 0-3, idle iterations
 struct SubProf {
   unsigned long long t0 = 0, t1 = 0, last = 0, acc[4] = {0, 0, 0, 0}, iters = 0, idle_iters = 0;
+  // finer marks inside (P) and (W): [336 + li * 10 + ..] P executions, W executions, then the sub-steps' cycles
+  unsigned long long last2 = 0, sub_acc[6] = {0, 0, 0, 0, 0, 0}, execs[2] = {0, 0};
+  template<int WHICH> __device__ void enter() { execs[WHICH]++; last2 = now(); }
+  template<int K> __device__ void sub() { const unsigned long long t = now(); sub_acc[K] += t - last2; last2 = t; }
   __device__ static unsigned long long now() { return __builtin_amdgcn_s_memtime(); }
   __device__ void round_begin() { t0 = now(); }
   __device__ void loop_begin() { t1 = now(); }
@@ -78,6 +82,10 @@ struct SubProf {
     for (int i = 0; i < 4; i++)
       atomicAdd(&g_sub_prof[144 + li * 6 + i], acc[i]);
     atomicAdd(&g_sub_prof[144 + li * 6 + 4], idle_iters);
+    atomicAdd(&g_sub_prof[336 + li * 10 + 0], execs[0]);
+    atomicAdd(&g_sub_prof[336 + li * 10 + 1], execs[1]);
+    for (int i = 0; i < 6; i++)
+      atomicAdd(&g_sub_prof[336 + li * 10 + 2 + i], sub_acc[i]);
   }
 };
 #else
@@ -86,6 +94,8 @@ struct SubProf {
   __device__ void loop_begin() {}
   __device__ void iter_begin() {}
   template<int STAGE> __device__ void mark() {}
+  template<int WHICH> __device__ void enter() {}
+  template<int K> __device__ void sub() {}
   __device__ void idle() {}
   __device__ void round_end(int, int) {}
 };
@@ -993,6 +1003,7 @@ raht_level_sub_kernel(LevelCtx ctx)
       if (__any(nready)) {
         progressed = true;
         // ---- (P) normalise the prediction, transform -----------------------
+        prof.template enter<0>();
         VT pw_[C];
 #pragma unroll
         for (int k = 0; k < C; k++)
@@ -1048,6 +1059,7 @@ raht_level_sub_kernel(LevelCtx ctx)
               pw_[k] = ipin[k];
           }
         }
+        prof.template sub<0>();
         // encoder: residual, tentative coefficient, RDOQ descriptor
         uint32_t d = kDescZero;
         int32_t qn_[C];
@@ -1074,22 +1086,26 @@ raht_level_sub_kernel(LevelCtx ctx)
           if (kLossy) {
             d = kDescNever;
             if (sum_coeff < 3) {
-              const int64_t l0 = qr[0].step;
-              d = rdoq_threshold(dist2, l0 * l0 * (C == 1 ? 25 : 35), rate_coeff, (uint32_t)n_s);
-              if (sum_coeff == 0) {
-                // an all-zero coefficient never resets; whether RDOQ "zeroes"
-                // it only matters if the AC-offset quantiser made the
-                // tentative value non-zero -- otherwise it must not make the
-                // block wait for L
-                bool any = false;
+              // an all-zero coefficient never resets; whether RDOQ "zeroes" it only matters if the AC-offset
+              // quantiser made the tentative value non-zero -- otherwise it must not make the block wait for L,
+              // and its threshold (a double division and two exact corrections: ~700 cycles on the hop) is never
+              // looked at: on a smooth field that is nearly every coefficient, and the branch is skipped wave-wide
+              bool any = false;
 #pragma unroll
-                for (int k = 0; k < C; k++)
-                  any |= qn_[k] != 0;
-                d = (any ? d : 0u) | kDescZero;
+              for (int k = 0; k < C; k++)
+                any |= qn_[k] != 0;
+              if (sum_coeff == 0 && !any) {
+                d = kDescZero;
+              } else {
+                const int64_t l0 = qr[0].step;
+                d = rdoq_threshold(dist2, l0 * l0 * (C == 1 ? 25 : 35), rate_coeff, (uint32_t)n_s);
+                if (sum_coeff == 0)
+                  d |= kDescZero;
               }
             }
           }
         }
+        prof.template sub<1>();
         uint32_t drn = kDescZero;
         if (kLossy) {
           // descriptors in coding order: lane r of the group gets rank r
@@ -1299,6 +1315,7 @@ raht_level_sub_kernel(LevelCtx ctx)
       if (__any(can)) {
         progressed = true;
         // ---- (W) coefficients, DC, inverse transform, commit ---------------
+        prof.template enter<1>();
         VT pw_[C];
 #pragma unroll
         for (int k = 0; k < C; k++)
@@ -1352,6 +1369,7 @@ raht_level_sub_kernel(LevelCtx ctx)
             }
           }
         }
+        prof.template sub<2>();
         // children of the committing groups: the value later launches read
         // (plain store) and the mailbox granule later blocks of THIS launch
         // poll (one 16-byte write-through store: value + tag, untorn)
@@ -1370,12 +1388,14 @@ raht_level_sub_kernel(LevelCtx ctx)
             const u32x4 gr = {(uint32_t)vb, (uint32_t)(vb >> 32), ctx.mtag, 0u};
             __builtin_amdgcn_raw_buffer_store_b128(gr, mrsrc, (int)((crow * C + k) * 16), 0, /*sc1*/ 16);
           }
+          prof.template sub<3>();
 #pragma unroll
           for (int k = 0; k < C; k++) {
             par2(ctx.rec_us, cur_par)[crow * C + k] = A::to_i64(ext ? pw_[k] : A::round_int(A::muli(pw_[k], 4)));
             par2(ctx.rec, cur_par)[crow * C + k] = A::to_i64(vn[k]);
           }
           par2(ctx.nneigh, cur_par)[crow] = inherit_dc ? neigh_count : 19;
+          prof.template sub<4>();
         }
         if (can)
           stage = 3;

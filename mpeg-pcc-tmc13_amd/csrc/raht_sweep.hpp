@@ -942,14 +942,19 @@ raht_sub_sweep_kernel(LevelCtx ctx, SweepCtx sw, SweepRec rec)
             if (kLossy) {
               d = kDescNever;
               if (sum_coeff < 3) {
-                const int64_t l0 = qr[0].step;
-                d = rdoq_threshold(dist2, l0 * l0 * (C == 1 ? 25 : 35), rate_coeff, (uint32_t)n_s);
-                if (sum_coeff == 0) {
-                  bool any = false;
+                // (an all-zero coefficient that no AC-offset quantiser made non-zero never looks at its threshold:
+                // raht_subnode.hpp)
+                bool any = false;
 #pragma unroll
-                  for (int k = 0; k < C; k++)
-                    any |= qn_[k] != 0;
-                  d = (any ? d : 0u) | kDescZero;
+                for (int k = 0; k < C; k++)
+                  any |= qn_[k] != 0;
+                if (sum_coeff == 0 && !any) {
+                  d = kDescZero;
+                } else {
+                  const int64_t l0 = qr[0].step;
+                  d = rdoq_threshold(dist2, l0 * l0 * (C == 1 ? 25 : 35), rate_coeff, (uint32_t)n_s);
+                  if (sum_coeff == 0)
+                    d |= kDescZero;
                 }
               }
             }

@@ -32,7 +32,7 @@ src = torch.from_numpy(np.concatenate([a for m, a in fr]).reshape(-1)).to(dev)
 d_a = torch.empty_like(src)
 d_c = torch.zeros(int(offs[-1]), dtype=torch.int32, device=dev)
 lib = _lib.load()
-out = (C.c_ulonglong * (16 + 32 * 10))()
+out = (C.c_ulonglong * (16 + 32 * 20))()
 ctx.set_morton_bits(54)
 import time
 for it in range(3):
@@ -58,3 +58,8 @@ for li in range(0, 21):
     if r:
         print(f"  level {li:2d}: rounds {r:8d} prologue {v[17 + li * 4] / r:9.0f} loop {v[18 + li * 4] / r:9.0f} iterations {v[19 + li * 4] / r:6.2f}"
               f" idle {v[148 + li * 6] / r:6.2f} stage ticks X {v[144 + li * 6] / r:8.0f} P {v[145 + li * 6] / r:7.0f} Z {v[146 + li * 6] / r:7.0f} W {v[147 + li * 6] / r:7.0f}")
+        b = 336 + li * 10
+        if v[b] or v[b + 1]:
+            pe, we = max(1, v[b]), max(1, v[b + 1])
+            print(f"            (P) x {v[b] / r:5.2f} per round: to butterflies' end {v[b + 2] / pe:6.0f}, quantise + descriptor {v[b + 3] / pe:6.0f} cycles each | "
+                  f"(W) x {v[b + 1] / r:5.2f}: to inverse butterflies' end {v[b + 4] / we:6.0f}, mailbox + granule store {v[b + 5] / we:6.0f}, rec stores {v[b + 6] / we:6.0f}")
