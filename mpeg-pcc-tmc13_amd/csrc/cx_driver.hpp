@@ -20,6 +20,11 @@
 #include "raht_edges.hpp"
 #include "raht_links.hpp"
 
+// workgroups (four wavefront-tiles each) of the count / emit launches at most
+#ifndef GPCC_CX_TGRID_CAP
+#define GPCC_CX_TGRID_CAP 2048
+#endif
+
 namespace gpcc {
 
 struct CxWork {
@@ -115,7 +120,7 @@ cx_run(
   const CxLists cl = w.cl;
   const int ncol = 3 * w.nlev + C;
   const int32_t* sum_attrs = w.encoder ? d_attrs : nullptr;
-  const int tgrid = std::min(std::max((tv.num_tiles + 3) / 4, 1), 2048);
+  const int tgrid = std::min(std::max((tv.num_tiles + 3) / 4, 1), GPCC_CX_TGRID_CAP);
   {
     auto t = prof("cx_count", -1);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(cx_count_kernel<C>), dim3(tgrid), dim3(256), 0, st, tv, sum_attrs, cl);

@@ -77,7 +77,10 @@ fail(int code, const std::string& msg)
 constexpr int32_t kMaxPoints = GPCC_MAX_POINTS;
 constexpr int kGridMax = 2048;  // 256 CUs x 8 workgroups of 256 threads
 constexpr int kLevelGridMax = 1 << 16;
-constexpr int kSubGrid = 1024;      // sub-node kernel: 4 workgroups per CU, resident
+#ifndef GPCC_SUB_GRID
+#define GPCC_SUB_GRID 1024
+#endif
+constexpr int kSubGrid = GPCC_SUB_GRID;  // sub-node kernel: 4 workgroups per CU, resident
 #ifndef GPCC_SUB_BLOCKS_PER_WG
 #define GPCC_SUB_BLOCKS_PER_WG 64   // parents of the level per workgroup when sizing its grid
 #endif

@@ -330,6 +330,9 @@ lod_cell_keys_kernel(LodCtx cx)
 #ifndef GPCC_LOD_BATCH
 #define GPCC_LOD_BATCH 10
 #endif
+#ifndef GPCC_LOD_IDLE_FAST
+#define GPCC_LOD_IDLE_FAST 1
+#endif
 __global__ __launch_bounds__(256, GPCC_LOD_SUB_WAVES) void
 lod_subsample_distance_kernel(LodCtx cx)
 {
@@ -483,6 +486,7 @@ lod_subsample_distance_kernel(LodCtx cx)
     uint32_t hasmask = 0;  // neighbours that arrived with a retained point
     bool pending = live;
     unsigned spins = 0;
+    bool decided_once = false;  // the decision below has been taken with the current `pend` / `elim`
     while (__any(pending)) {
       // poll every pending neighbour; the loads of a batch are issued together
       // BEFORE any result is looked at (two batches bound the live registers)
@@ -523,6 +527,18 @@ lod_subsample_distance_kernel(LodCtx cx)
           }
         }
       }
+      // (no neighbour of any lane has arrived since the last decision: it stands -- the waiting iteration, of
+      // which a cell spends tens, is the polls and this test; GPCC_LOD_IDLE_FAST, profiles/r06_idle_ab.txt)
+      if (GPCC_LOD_IDLE_FAST && decided_once && !__any(pending && pend != todo)) {
+        if (++spins > (1u << 20)) {
+          if (lane == 0)
+            atomicExch(cx.error, 1);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+        continue;
+      }
+      decided_once = true;
       // ---- decide as far as the arrived neighbours allow -----------------
       int kept = -1;
       int32_t kp[3] = {0, 0, 0};

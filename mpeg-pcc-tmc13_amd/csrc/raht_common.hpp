@@ -29,7 +29,11 @@
 namespace gpcc {
 
 constexpr int kMaxLevels = 22;   // ceil(63 / 3) + root
-constexpr int kTilePoints = 1024;  // points per wave in the tree build
+// points per wavefront-tile of the tree build (a multiple of 64)
+#ifndef GPCC_TILE_POINTS
+#define GPCC_TILE_POINTS 1024
+#endif
+constexpr int kTilePoints = GPCC_TILE_POINTS;
 constexpr int kWave = 64;
 
 // value slots of the compact level pass (cx_tree.hpp): hold = slot | top level << 27

@@ -50,6 +50,31 @@
 
 namespace gpcc {
 
+// Which round the `tk`-th claim of class `cls` (workgroup index mod 8 -- the XCD, with the round-robin placement
+// of workgroups) takes: GPCC_SUB_CHUNK = K consecutive rounds per class and turn (K = 1: rounds interleave,
+// round r belongs to class r mod 8).  Monotone in tk for every class.
+#ifndef GPCC_SUB_CHUNK
+#define GPCC_SUB_CHUNK 1
+#endif
+#ifndef GPCC_SUB_DSTORE
+#define GPCC_SUB_DSTORE 0
+#endif
+#ifndef GPCC_SUB_POLL_N
+#define GPCC_SUB_POLL_N 1
+#endif
+#ifndef GPCC_SUB_IDLE_FAST
+#define GPCC_SUB_IDLE_FAST 1
+#endif
+#ifndef GPCC_SUB_IDLE_SPIN
+#define GPCC_SUB_IDLE_SPIN 0
+#endif
+__device__ __forceinline__ int64_t
+sub_round_of_ticket(int tk, int cls)
+{
+  constexpr int K = GPCC_SUB_CHUNK;
+  return ((int64_t)(tk / K) * 8 + cls) * K + tk % K;
+}
+
 // Where a wavefront's time goes (experiment builds only, -DGPCC_SUB_PROF:
 // s_memtime around the stages of the loop, summed per launch and per level
 // into g_sub_prof, read back with gpcc_debug_sub_prof).  Empty otherwise.
@@ -246,7 +271,7 @@ raht_level_sub_kernel(LevelCtx ctx)
     if (lane == 0)
       tk = atomicAdd(&ctx.ticket[li * 8 + (claim_rounds > 1 ? 0 : cls)], 1);
     tk = __shfl(tk, 0);
-    const int64_t wround0 = claim_rounds > 1 ? (int64_t)tk * claim_rounds : (int64_t)tk * 8 + cls;
+    const int64_t wround0 = claim_rounds > 1 ? (int64_t)tk * claim_rounds : sub_round_of_ticket(tk, cls);
     if (wround0 * 8 >= num_work || stop_all)
       break;
     // the zero-run state behind the previous round of this claim, when it is known exactly
@@ -270,7 +295,7 @@ raht_level_sub_kernel(LevelCtx ctx)
     if (lane == 0)
       tk = atomicAdd(&ctx.ticket[li * 8 + cls], 1);
     tk = __shfl(tk, 0);
-    const int64_t wround = (int64_t)tk * 8 + cls;
+    const int64_t wround = sub_round_of_ticket(tk, cls);
     if (wround * 8 >= num_work)
       break;
     SubProf prof;
@@ -913,6 +938,10 @@ raht_level_sub_kernel(LevelCtx ctx)
     int outk = 0, outv = -1;   // outgoing RDOQ state: 0 unknown, 1 transparent, 2 final (= outv)
     unsigned long long done = 0;  // children of this round whose value lies in the mailbox (wave-uniform)
     int poll_last = 31;           // the granule polled last (31: none yet -- start with the lowest awaited one)
+    unsigned long long done_seen = ~0ull;  // `done` when the mailbox loop last ran
+    int cur_slot = -1, cur_pwc = 0;        // the granule this lane polls: slot, weight, row -- looked up when the slot changes
+    int32_t cur_row = 0;
+    int cur_mul = 0;
 #pragma unroll
     for (int k = 0; k < C; k++) {
       pt[k] = A::zero();
@@ -924,7 +953,10 @@ raht_level_sub_kernel(LevelCtx ctx)
       bool progressed = false;
       prof.iter_begin();
       // ---- (X) awaited children of blocks of this wavefront: the mailbox ----
-      {
+      // (only when the mailbox has gained a child since the loop last ran: nothing else lets it consume one, and a waiting
+      // iteration -- a round waits for ~100 of them -- is then the poll below and a handful of tests)
+      if (!GPCC_SUB_IDLE_FAST || done != done_seen) {
+        done_seen = done;
         uint32_t mi = stage == 0 ? (pend & inw) : 0u;
         while (__any(mi != 0)) {
           const bool act = mi != 0;
@@ -959,6 +991,48 @@ raht_level_sub_kernel(LevelCtx ctx)
       // inside the wavefront never stalls on a memory round trip -- was measured: 7.22 / 4.17 ms
       // against 6.98 / 3.95, arrivals from other wavefronts are what the frame waits for.)
       const uint32_t pm = stage == 0 ? (pend & ~inw) : 0u;
+#if GPCC_SUB_POLL_N > 1
+      // (experiment) the GPCC_SUB_POLL_N lowest awaited granules of a lane side by side: neighbours produced by ONE earlier
+      // round arrive together, and one granule per iteration consumes them a memory round trip apart
+      if (pm) {
+        uint32_t pmm = pm;
+        int slot_[GPCC_SUB_POLL_N], pwc_[GPCC_SUB_POLL_N];
+        bool act_[GPCC_SUB_POLL_N];
+        u32x4 g[GPCC_SUB_POLL_N][C];
+#pragma unroll
+        for (int u = 0; u < GPCC_SUB_POLL_N; u++) {
+          act_[u] = pmm != 0;
+          slot_[u] = act_[u] ? __ffs(pmm) - 1 : __ffs(pm) - 1;
+          pmm &= pmm - 1;
+          int32_t row = 0;
+          pwc_[u] = 0;
+#pragma unroll
+          for (int i12 = 0; i12 < 12; i12++) {
+            if (slot_[u] == i12) {
+              row = nrow12[i12];
+              pwc_[u] = pwc12[i12];
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < C; k++)
+            g[u][k] = __builtin_amdgcn_raw_buffer_load_b128(mrsrc, (row * C + k) * 16, 0, /*sc1*/ 16);
+        }
+#pragma unroll
+        for (int u = 0; u < GPCC_SUB_POLL_N; u++) {
+          bool ok = act_[u];
+#pragma unroll
+          for (int k = 0; k < C; k++)
+            ok = ok && g[u][k].z == ctx.mtag;
+          if (ok) {
+            const int mul = ext ? pwc_[u] : (pwc_[u] << kFpFrac);
+#pragma unroll
+            for (int k = 0; k < C; k++)
+              pred[k] += A::muli(__builtin_bit_cast(VT, ((uint64_t)g[u][k].y << 32) | g[u][k].x), mul);
+            pend &= ~(1u << slot_[u]);
+          }
+        }
+      }
+#else
       if (pm) {
 #if GPCC_SUB_POLL_RR
         // round robin over the awaited granules: the one behind the last polled.  Polling the LOWEST awaited one until it
@@ -972,13 +1046,73 @@ raht_level_sub_kernel(LevelCtx ctx)
 #endif
         int32_t row = 0;
         int pwc = 0;
+        if (GPCC_SUB_IDLE_FAST && !GPCC_SUB_POLL_RR) {
+          if (slot != cur_slot) {
+            cur_slot = slot;
 #pragma unroll
-        for (int i12 = 0; i12 < 12; i12++) {
-          if (slot == i12) {
-            row = nrow12[i12];
-            pwc = prm->pred_weight_child[i12];
+            for (int i12 = 0; i12 < 12; i12++) {
+              if (slot == i12) {
+                cur_row = nrow12[i12];
+                cur_pwc = pwc12[i12];
+              }
+            }
+          }
+          row = cur_row;
+          pwc = cur_pwc;
+        } else {
+#pragma unroll
+          for (int i12 = 0; i12 < 12; i12++) {
+            if (slot == i12) {
+              row = nrow12[i12];
+              pwc = prm->pred_weight_child[i12];
+            }
           }
         }
+#if GPCC_SUB_IDLE_SPIN
+        cur_mul = ext ? pwc : (pwc << kFpFrac);
+      }
+      {
+        // Nothing but an arrival from another wavefront lets this one go on -- no group waits for the zero-run state,
+        // none is ready to predict, the mailbox has been looked at: poll in place.  (The waiting iteration is what a
+        // round spends ~100 of, three wavefronts per SIMD at a time: every instruction of it is also taken from the
+        // issue slots of the wavefront that has work -- profiles/r06_idle_ab.txt.)
+        const bool spin_ok = !__any(stage == 1) && !__any(stage == 0 && !group8_any(stage == 0 && pend));
+        u32x4 g[C];
+        bool ok = false;
+        bool expired = false;
+        for (;;) {
+          if (pm) {
+#pragma unroll
+            for (int k = 0; k < C; k++)
+              g[k] = __builtin_amdgcn_raw_buffer_load_b128(mrsrc, (cur_row * C + k) * 16, 0, /*sc1*/ 16);
+            ok = true;
+#pragma unroll
+            for (int k = 0; k < C; k++)
+              ok = ok && g[k].z == ctx.mtag;
+          }
+          if (!spin_ok || __any(ok) || !__any(pm != 0))
+            break;
+          prof.idle();
+          if (++spins > (1u << 21)) {
+            expired = true;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(GPCC_SUB_SLEEP);
+        }
+        if (expired) {
+          if (lane == 0)
+            atomicExch(ctx.error, 1);  // fail loudly instead of hanging the GPU
+          break;
+        }
+        if (ok) {
+          // (a granule carries the value in the launch's arithmetic: every reader is this launch)
+#pragma unroll
+          for (int k = 0; k < C; k++)
+            pred[k] += A::muli(__builtin_bit_cast(VT, ((uint64_t)g[k].y << 32) | g[k].x), cur_mul);
+          pend &= ~(1u << cur_slot);
+        }
+      }
+#else
         u32x4 g[C];
 #pragma unroll
         for (int k = 0; k < C; k++)
@@ -996,6 +1130,8 @@ raht_level_sub_kernel(LevelCtx ctx)
           pend &= ~(1u << slot);
         }
       }
+#endif
+#endif
       prof.mark<0>();
       const bool blocked = group8_any(stage == 0 && pend);
       const bool nready = stage == 0 && !blocked;
@@ -1386,6 +1522,10 @@ raht_level_sub_kernel(LevelCtx ctx)
             const uint64_t vb = __builtin_bit_cast(uint64_t, v);
             wm[lane * C + k] = vb;  // read by later groups of this wavefront once `done` says so
             const u32x4 gr = {(uint32_t)vb, (uint32_t)(vb >> 32), ctx.mtag, 0u};
+#if GPCC_SUB_DSTORE
+            // (first into this XCD's L2, where the pollers of the same XCD find it at once; then through to memory)
+            __builtin_amdgcn_raw_buffer_store_b128(gr, mrsrc, (int)((crow * C + k) * 16), 0, 0);
+#endif
             __builtin_amdgcn_raw_buffer_store_b128(gr, mrsrc, (int)((crow * C + k) * 16), 0, /*sc1*/ 16);
           }
           prof.template sub<3>();

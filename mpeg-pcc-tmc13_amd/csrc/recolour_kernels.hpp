@@ -94,11 +94,21 @@ rc_limit(double v)
   return v < 512 ? v : 1.7976931348623157e308;
 }
 
+// wavefronts per SIMD the two search kernels are compiled for (0: the compiler's choice); an experiment knob
+#ifndef GPCC_RC_WAVES
+#define GPCC_RC_WAVES 0
+#endif
+#if GPCC_RC_WAVES > 0
+#define GPCC_RC_OCCUPANCY __attribute__((amdgpu_waves_per_eu(GPCC_RC_WAVES)))
+#else
+#define GPCC_RC_OCCUPANCY
+#endif
+
 // ---- forward (pointset_processing.cpp:296-384 / 659-728) ---------------------------
 // (ALIMIT: a finite max_attribute_dist2_fwd; without one the k x k comparison of the neighbours'
 // attributes decides nothing and is left out)
 template<int C, int K, bool ALIMIT>
-__global__ __launch_bounds__(256) void
+__global__ __launch_bounds__(256) GPCC_RC_OCCUPANCY void
 rc_forward_kernel(RcCtx cx)
 {
 #pragma clang fp contract(off)
@@ -229,7 +239,7 @@ rc_forward_limit_kernel(RcCtx cx)
 
 // ---- backward (:386-424 / 730-766): nearest targets of every source point ------------
 template<int K>
-__global__ __launch_bounds__(256) void
+__global__ __launch_bounds__(256) GPCC_RC_OCCUPANCY void
 rc_backward_kernel(RcCtx cx)
 {
 #pragma clang fp contract(off)

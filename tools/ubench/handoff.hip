@@ -6,7 +6,7 @@
 #include <stdint.h>
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-template<int ST, int LD>  // aux bits: 0 plain, 1 sc0, 16 sc1, 17 sc0 sc1
+template<int ST, int LD>  // aux bits: 0 plain, 1 sc0, 16 sc1, 17 sc0 sc1; ST = 100: a plain store, then an sc1 store of the same granule
 __global__ void pingpong(uint32_t* box, int peer, int iters, unsigned long long* out, int* xcc)
 {
   const int b = blockIdx.x;
@@ -27,7 +27,12 @@ __global__ void pingpong(uint32_t* box, int peer, int iters, unsigned long long*
   for (int i = 1; i <= iters && !dead; i++) {
     if (me == 0) {
       const u32x4 g = {(uint32_t)i, 0u, (uint32_t)i, 0u};
-      __builtin_amdgcn_raw_buffer_store_b128(g, rs, 0, 0, ST);
+      if (ST == 100) {
+        __builtin_amdgcn_raw_buffer_store_b128(g, rs, 0, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(g, rs, 0, 0, 16);
+      } else {
+        __builtin_amdgcn_raw_buffer_store_b128(g, rs, 0, 0, ST);
+      }
       for (int spin = 0;; spin++) {
         asm volatile("" ::: "memory");  // (the poll is a fresh load every time)
         const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rs, 64, 0, LD);
@@ -50,7 +55,12 @@ __global__ void pingpong(uint32_t* box, int peer, int iters, unsigned long long*
         }
       }
       const u32x4 g = {(uint32_t)i, 0u, (uint32_t)i, 0u};
-      __builtin_amdgcn_raw_buffer_store_b128(g, rs, 64, 0, ST);
+      if (ST == 100) {
+        __builtin_amdgcn_raw_buffer_store_b128(g, rs, 64, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(g, rs, 64, 0, 16);
+      } else {
+        __builtin_amdgcn_raw_buffer_store_b128(g, rs, 64, 0, ST);
+      }
     }
   }
   unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -101,6 +111,7 @@ int main()
     run<17, 17>("store sc0sc1 / load sc0sc1", peer);
     run<0, 17>("store plain / load sc0sc1", peer);
     run<1, 16>("store sc0 / load sc1", peer);
+    run<100, 16>("store plain+sc1 / load sc1", peer);
   }
   return 0;
 }
