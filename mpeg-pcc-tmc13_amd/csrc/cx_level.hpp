@@ -33,6 +33,14 @@
 #include "raht_links.hpp"
 #include "raht_rdoq.hpp"
 
+// pivots + 1 of a step of the neighbour search (2: bisection)
+#ifndef GPCC_CX_SEARCH_ARY
+#define GPCC_CX_SEARCH_ARY 2
+#endif
+#ifndef GPCC_CX_SEARCH_MASKED
+#define GPCC_CX_SEARCH_MASKED 0
+#endif
+
 namespace gpcc {
 
 constexpr int kCxG = 57;        // ranks per wavefront; whole blocks: <= 57 + 7 lanes
@@ -548,6 +556,66 @@ cx_level_tile(const CxCtx& cx, CxSmem& sm, int li, int tile)
     // (a window of the parent keys staged in LDS in front of this search was
     // measured: 19 of 20 look-ups of a lidar frame end there, but its instructions
     // and registers -- 4 waves per SIMD instead of 5 -- cost more than the loads)
+#if GPCC_CX_SEARCH_ARY == 1
+    // Six lower_bounds side by side as UNIFORM halving: every search adds the same power of two per step when the key in
+    // front of the new position is still smaller (and the position stays inside its window) -- an add, a bound test, a
+    // clamp, the load, the compare and a select per search and step, half the instructions of the (lo, hi) form below,
+    // whose lock-step loop ran to the longest window of the wavefront anyway.  (Experiment: same time -- the pass is bound by
+    // the NUMBER of its vector loads, profiles/r06_cx_ta_counters.txt.)  Positions in bytes; a window's end is
+    // readable (sentinel entry), so a step that would leave the window reads the end instead.
+    {
+      const char* __restrict__ pkb = (const char*)pk;
+      const uint32_t wmax = (uint32_t)(range < (1 << 28) ? range + 1 : (1 << 28));
+      uint32_t pos8[6], gb8[6];
+#pragma unroll
+      for (int t = 0; t < 6; t++) {
+        pos8[t] = (uint32_t)lo[t] << 3;
+        gb8[t] = (uint32_t)hi[t] << 3;
+      }
+      for (uint32_t half8 = (1u << (31 - __builtin_clz(wmax))) << 3; half8 >= 8; half8 >>= 1) {
+        uint32_t t8[6];
+        int64_t kv[6];
+#pragma unroll
+        for (int t = 0; t < 6; t++) {
+          t8[t] = pos8[t] + half8;
+          const uint32_t at = t8[t] < gb8[t] + 8 ? t8[t] : gb8[t] + 8;
+          kv[t] = *(const int64_t*)(pkb + (at - 8));
+        }
+#pragma unroll
+        for (int t = 0; t < 6; t++)
+          pos8[t] = (t8[t] <= gb8[t] && kv[t] < want[t]) ? t8[t] : pos8[t];
+      }
+#pragma unroll
+      for (int t = 0; t < 6; t++)
+        lo[t] = (int)(pos8[t] >> 3);
+    }
+#elif GPCC_CX_SEARCH_ARY == 3
+    // (experiment) two pivots per step: a third of the window left instead of half -- 8 memory round trips for a
+    // 2 500-entry window instead of 12, twelve loads in flight per lane: 96 loads instead of 72, a third slower
+    while (__any((lo[0] < hi[0]) | (lo[1] < hi[1]) | (lo[2] < hi[2]) | (lo[3] < hi[3])
+                 | (lo[4] < hi[4]) | (lo[5] < hi[5]))) {
+      int m1[6], m2[6];
+      int64_t k1[6], k2[6];
+#pragma unroll
+      for (int t = 0; t < 6; t++) {
+        const uint32_t len = (uint32_t)(hi[t] - lo[t]);
+        m1[t] = lo[t] + (int)__umulhi(len, 0x55555556u);      // lo + len / 3
+        m2[t] = lo[t] + (int)__umulhi(2 * len, 0x55555556u);  // lo + 2 len / 3 (>= m1; == m1 only for len 1)
+        k1[t] = pk[m1[t]];
+        k2[t] = pk[m2[t]];
+      }
+#pragma unroll
+      for (int t = 0; t < 6; t++) {
+        const bool act = lo[t] < hi[t];
+        const bool ge1 = !(k1[t] < want[t]);
+        const bool ge2 = !(k2[t] < want[t]);
+        const int nlo = ge1 ? lo[t] : (ge2 ? m1[t] + 1 : m2[t] + 1);
+        const int nhi = ge1 ? m1[t] : (ge2 ? m2[t] : hi[t]);
+        lo[t] = act ? nlo : lo[t];
+        hi[t] = act ? nhi : hi[t];
+      }
+    }
+#else
     while (__any((lo[0] < hi[0]) | (lo[1] < hi[1]) | (lo[2] < hi[2]) | (lo[3] < hi[3])
                  | (lo[4] < hi[4]) | (lo[5] < hi[5]))) {
       int mid[6];
@@ -555,7 +623,15 @@ cx_level_tile(const CxCtx& cx, CxSmem& sm, int li, int tile)
 #pragma unroll
       for (int t = 0; t < 6; t++) {
         mid[t] = lo[t] + ((hi[t] - lo[t]) >> 1);
+#if GPCC_CX_SEARCH_MASKED
+        // (experiment) a finished search asks for nothing -- 7 % fewer load instructions (most windows are the full
+        // search range), same time
+        kv[t] = 0;
+        if (lo[t] < hi[t])
+          kv[t] = pk[mid[t]];
+#else
         kv[t] = pk[mid[t]];  // (a finished search reloads key[lo]: the arrays have a sentinel entry)
+#endif
       }
 #pragma unroll
       for (int t = 0; t < 6; t++) {
@@ -565,6 +641,7 @@ cx_level_tile(const CxCtx& cx, CxSmem& sm, int li, int tile)
         hi[t] = (act && !less) ? mid[t] : hi[t];
       }
     }
+#endif
     int64_t kf[6];
 #pragma unroll
     for (int t = 0; t < 6; t++)
