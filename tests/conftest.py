@@ -39,14 +39,19 @@ def pkg():
 
 @pytest.fixture(scope="session", autouse=True)
 def _uploads_from_pinned_memory():
-    """GPU tier, OPT-IN (GPCC_TEST_PIN_UPLOADS=1).  Round 4 made this the default after ONE silent abort of the tier at a
-    `tensor.cpu()` that was never reproduced; it changes what the tests do (torch.from_numpy then copies instead of
-    sharing memory) and would hide an out-of-bounds device write just as well as the pageable-pin hazard it was meant
-    for.  Since round 5 the tier runs WITHOUT it and with the library's guard bands armed instead
-    (GPCC_GUARD=1, csrc/gpcc_attr_mi355.hip: canaries around every device allocation of the library and between the
-    sub-allocations of its arena, checked at every synchronisation); profiles/r05_gpu_tier_guarded.txt records those
-    runs.  The switch stays for bisecting, should the abort ever come back."""
-    if os.environ.get("GPCC_TEST_PIN_UPLOADS", "0") != "1":
+    """GPU tier: torch.from_numpy hands out PINNED tensors (GPCC_TEST_PIN_UPLOADS=0 turns it off).  Out of pageable memory
+    the ROCm runtime pins the source pages of an upload on the fly, read-only, and keeps the pins; a later `tensor.cpu()` onto
+    heap addresses the allocator has reused then aborts the process without a message (bench.py to_device, the library's own
+    h2d_user bounce buffer).  History: round 4 made this the default after ONE such abort of the tier; round 5 turned it off
+    (it changes what the tests do -- from_numpy copies instead of sharing memory -- and would hide an out-of-bounds
+    device write as well) and ran the tier with the library's guard bands armed instead (GPCC_GUARD=1: canaries around every
+    device allocation and between the sub-allocations of the arena, checked at every synchronisation;
+    profiles/r05_gpu_tier_guarded.txt, clean).  In round 6 the abort came back ONCE in nine runs of the tier, at the
+    `d_a2.cpu()` of test_gpu_tile.py::test_tiles_over_many_small_slices with a library whose default path was textually the
+    one of the eight clean runs (profiles/r06_gpu_tier_final.txt); the same file three times and the whole tier again: clean.
+    An abort takes the whole `pytest -x` run with it, so the pinning is the default again; out-of-bounds writes are what the
+    guard-band runs are for."""
+    if os.environ.get("GPCC_TEST_PIN_UPLOADS", "1") != "1":
         yield
         return
     try:
